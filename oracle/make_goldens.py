@@ -1,0 +1,284 @@
+"""Generate golden vectors by EXECUTING THE REFERENCE'S OWN MODULES (container-only tool).
+
+TEST INFRASTRUCTURE.  Run here (never on the GPU box -- /root/reference does not exist
+there):
+
+    python oracle/make_goldens.py            # writes tests/golden/*.npz
+
+How: ``oracle/tf1_stub.py`` is registered as ``tensorflow``; ``/root/reference/utils`` is
+put on ``sys.path`` at run time and ``dynamics``, ``layers``, ``distributions`` are imported
+unchanged; ``sampler.py`` (tab/space mixed, Python-2 only) is read, ``expandtabs(8)``-ed
+(exactly Py2's rule) and exec'd in memory.  The notebook's ``network`` factory
+(SCGExperiment.ipynb raw lines 51-78) is restated below in terms of the reference's own
+``layers`` classes.  Nothing of the reference is copied into the repo: only inputs,
+weights, recorded random draws and the outputs the reference code produced are stored.
+
+Each .npz holds, per case: energy parameters, net weights (xnet.*, vnet.*), eps, mask, the
+inputs, the recorded random draws, and the reference outputs for `_forward_step`,
+`_backward_step`, `forward`, `backward`, `p_accept` and `propose`.
+"""
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import tf1_stub  # noqa: E402
+
+REF = '/root/reference/utils'
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+tf = tf1_stub.install()
+sys.path.insert(0, REF)
+import contextlib  # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import dynamics as ref_dynamics            # noqa: E402  /root/reference/utils/dynamics.py
+    import layers as ref_layers                # noqa: E402
+    import distributions as ref_distributions  # noqa: E402
+
+_src = open(os.path.join(REF, 'sampler.py')).read().expandtabs(8)
+ref_sampler = type(sys)('ref_sampler')
+exec(compile(_src, os.path.join(REF, 'sampler.py'), 'exec'), ref_sampler.__dict__)
+
+Linear, Sequential, Zip, Parallel, ScaleTanh = (ref_layers.Linear, ref_layers.Sequential,
+                                                ref_layers.Zip, ref_layers.Parallel,
+                                                ref_layers.ScaleTanh)
+
+
+def make_network(H):
+    """The notebook's S/T/Q net (nb:51-78) with hidden width H, built from the reference's
+    own layer classes."""
+    def network(x_dim, scope, factor):
+        with tf.variable_scope(scope):
+            net = Sequential([
+                Zip([
+                    Linear(x_dim, H, scope='embed_1', factor=1.0 / 3),
+                    Linear(x_dim, H, scope='embed_2', factor=factor * 1.0 / 3),
+                    Linear(2, H, scope='embed_3', factor=1.0 / 3),
+                    lambda _: 0.,
+                ]),
+                sum,
+                tf.nn.relu,
+                Linear(H, H, scope='linear_1'),
+                tf.nn.relu,
+                Parallel([
+                    Sequential([
+                        Linear(H, x_dim, scope='linear_s', factor=0.001),
+                        ScaleTanh(x_dim, scope='scale_s'),
+                    ]),
+                    Linear(H, x_dim, scope='linear_t', factor=0.001),
+                    Sequential([
+                        Linear(H, x_dim, scope='linear_f', factor=0.001),
+                        ScaleTanh(x_dim, scope='scale_f'),
+                    ]),
+                ]),
+            ])
+        return net
+    return network
+
+
+TF2KEY = {'embed_1/W': 'W1', 'embed_1/b': 'b1', 'embed_2/W': 'W2', 'embed_2/b': 'b2',
+          'embed_3/W': 'W3', 'embed_3/b': 'b3', 'linear_1/W': 'W4', 'linear_1/b': 'b4',
+          'linear_s/W': 'Ws', 'linear_s/b': 'bs', 'linear_t/W': 'Wt', 'linear_t/b': 'bt',
+          'linear_f/W': 'Wq', 'linear_f/b': 'bq', 'scale_s/scale': 'lam_s',
+          'scale_f/scale': 'lam_q'}
+
+
+def variable_hook_factory(seed, head_std):
+    """Replace the reference initialisation (heads ~1e-3 => S,T,Q ~ 0, i.e. plain HMC) by
+    seeded values that exercise every term: head weights std `head_std`, small random biases
+    and log-scales."""
+    rng = np.random.RandomState(seed)
+
+    def hook(full, shape, default):
+        if full == 'alpha':
+            return None
+        leaf = '/'.join(full.split('/')[-2:])
+        if leaf.endswith('/W'):
+            if leaf.startswith('linear_s') or leaf.startswith('linear_t') or leaf.startswith('linear_f'):
+                return (rng.randn(*shape) * head_std / np.sqrt(shape[0])).astype(np.float32)
+            return default          # reference's own variance-scaling init for embeds / linear_1
+        if leaf.endswith('/b'):
+            return (0.1 * rng.randn(*shape)).astype(np.float32)
+        if leaf.endswith('/scale'):
+            return (0.2 * rng.randn(*shape)).astype(np.float32)
+        return None
+    return hook
+
+
+def npy(t):
+    return t.detach().numpy().copy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def leaf(a):
+    return torch.tensor(np.asarray(a, dtype=np.float32), requires_grad=True)
+
+
+def run_case(name, x_dim, H, T, eps, N, energy_fn, energy_params, seed, hmc=False,
+             head_std=1.0, x_scale=1.0, steps_to_check=(0, 3, None), x0=None):
+    tf1_stub.reset(seed)
+    np.random.seed(seed)                      # masks come from numpy's global RNG (dynamics.py:88)
+    tf1_stub.VARIABLE_HOOK = variable_hook_factory(seed + 1, head_std)
+    with contextlib.redirect_stdout(io.StringIO()):
+        dyn = ref_dynamics.Dynamics(x_dim, energy_fn, T=T, eps=eps, hmc=hmc,
+                                    net_factory=None if hmc else make_network(H))
+    out = dict(energy_params)
+    out.update(case=name, x_dim=x_dim, H=H, T=T, N=N, hmc=int(hmc),
+               eps=npy(dyn.eps), mask=npy(dyn.mask))
+    if not hmc:
+        for full, val in tf1_stub.VARIABLES.items():
+            if full == 'alpha':
+                continue
+            scope, rest = full.split('/', 1)
+            out['%s.%s' % (scope.lower(), TF2KEY[rest])] = npy(val)
+
+    rng = np.random.RandomState(seed + 2)
+    if x0 is None:
+        x0 = (x_scale * rng.randn(N, x_dim)).astype(np.float32)
+    v0 = rng.randn(N, x_dim).astype(np.float32)
+    out['x'], out['v'] = x0, v0
+
+    # energy / grad / hamiltonian  (dynamics.py:203-218)
+    xl = leaf(x0)
+    out['energy'] = npy(dyn.energy(xl))
+    out['grad_energy'] = npy(dyn.grad_energy(xl))
+
+    # single steps (dynamics.py:115-201)
+    steps = [T - 1 if s is None else s for s in steps_to_check if (s is None or s < T)]
+    out['steps'] = np.array(steps, dtype=np.int32)
+    for s in steps:
+        st = torch.tensor(float(s))
+        xo, vo, lj = dyn._forward_step(leaf(x0), leaf(v0), st)
+        out['fstep%d.x' % s], out['fstep%d.v' % s], out['fstep%d.logdet' % s] = npy(xo), npy(vo), npy(lj)
+        xo, vo, lj = dyn._backward_step(leaf(x0), leaf(v0), st)
+        out['bstep%d.x' % s], out['bstep%d.v' % s], out['bstep%d.logdet' % s] = npy(xo), npy(vo), npy(lj)
+
+    # full trajectories (dynamics.py:246-300)
+    for nm, fn in (('fwd', dyn.forward), ('bwd', dyn.backward)):
+        X, V, lj = fn(leaf(x0), init_v=leaf(v0), log_jac=True)
+        out[nm + '.x'], out[nm + '.v'], out[nm + '.logjac'] = npy(X), npy(V), npy(lj)
+        X, V, p = fn(leaf(x0), init_v=leaf(v0))
+        out[nm + '.p'] = npy(p)
+        assert np.array_equal(npy(X), out[nm + ".x"], equal_nan=True)
+
+    # propose with do_mh_step (sampler.py:28-55); randomness recorded by the stub
+    del tf1_stub.RANDOM_LOG[:]
+    Lx, Lv, px, outs = ref_sampler.propose(leaf(x0), dyn, do_mh_step=True)
+    log = list(tf1_stub.RANDOM_LOG)
+    kinds = [k for k, _ in log]
+    if hmc:
+        assert kinds == ['normal', 'uniform'], kinds
+        out['prop.v_fwd'], out['prop.u'] = log[0][1], log[1][1]
+    else:
+        assert kinds == ['randint', 'normal', 'normal', 'uniform'], kinds
+        out['prop.dir'] = log[0][1][:, 0].astype(np.uint8)
+        out['prop.v_fwd'], out['prop.v_bwd'], out['prop.u'] = log[1][1], log[2][1], log[3][1]
+    out['prop.Lx'], out['prop.px'], out['prop.x_next'] = npy(Lx), npy(px), npy(outs[0])
+    assert Lv is None or hmc
+
+    for k, v in out.items():
+        if isinstance(v, np.ndarray) and v.dtype == np.float64:
+            raise AssertionError('float64 leaked into golden %s/%s' % (name, k))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print('%-18s N=%-4d d=%-3d T=%-3d  mean p fwd %.3f bwd %.3f  |x|max %.2f' % (
+        name, N, x_dim, T, out['fwd.p'].mean(), out['bwd.p'].mean(), np.abs(out['fwd.x']).max()))
+
+
+def gaussian_case(name, mu, cov, **kw):
+    with contextlib.redirect_stdout(io.StringIO()):
+        dist = ref_distributions.Gaussian(np.asarray(mu, dtype=np.float64), np.asarray(cov, dtype=np.float64))
+    params = {'energy.kind': 'gaussian', 'energy.mu': dist.mu.astype(np.float32),
+              'energy.i_sigma': dist.i_sigma.astype(np.float32)}
+    run_case(name, len(mu), energy_fn=dist.get_energy_function(), energy_params=params, **kw)
+
+
+def main():
+    # C1: Strongly-correlated Gaussian 2D, exactly the notebook's target (nb:103-108)
+    cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
+    gaussian_case('scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=11, x_scale=1.0)
+    gaussian_case('scg2d_hmc', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=12, hmc=True)
+
+    # C2 (subset of chains): ill-conditioned Gaussian d=50, variances log-spaced 1e-2..1e2
+    var = np.exp(np.linspace(np.log(1e-2), np.log(1e2), 50))
+    rng = np.random.RandomState(5)
+    x0 = (rng.randn(64, 50) * np.sqrt(var)).astype(np.float32)     # start in the typical set
+    gaussian_case('icg50', np.zeros(50), np.diag(var), H=10, T=10, eps=0.1, N=64, seed=13,
+                  head_std=0.05, x0=x0)
+    gaussian_case('icg50_hmc', np.zeros(50), np.diag(var), H=10, T=10, eps=0.05, N=64, seed=14,
+                  hmc=True, x0=x0)
+
+    # dense (rotated) Gaussian d=8 with non-zero mean: exercises the dense-precision path
+    rng = np.random.RandomState(7)
+    R = np.linalg.qr(rng.randn(8, 8))[0]
+    cov8 = R.T.dot(np.diag(np.exp(np.log(10.) * rng.uniform(-1, 1, size=8)))).dot(R)
+    gaussian_case('tilted8', rng.randn(8) * 0.5, cov8, H=10, T=7, eps=0.1, N=48, seed=15)
+
+    # C3 shape: 2-component MoG in 2D (paper-style: centres (+-2,0), var 0.1), T=25
+    mus = [np.array([2.0, 0.0], dtype=np.float32), np.array([-2.0, 0.0], dtype=np.float32)]
+    sig = [0.1 * np.eye(2), 0.1 * np.eye(2)]
+    # (mus handed over as float32 torch tensors: TF would convert the numpy constants to
+    #  float32 tensors at `x - mu`; torch cannot subtract a numpy array from a grad tensor)
+    gmm = ref_distributions.GMM([torch.tensor(m) for m in mus], sig, [0.5, 0.5])
+    params = {'energy.kind': 'gmm', 'energy.mus': np.stack(mus),
+              'energy.i_sigmas': np.stack(gmm.i_sigmas),
+              'energy.constants': np.array(gmm.constants, dtype=np.float32)}
+    rng = np.random.RandomState(9)
+    x0 = (np.stack(mus)[rng.randint(0, 2, size=96)] + np.sqrt(0.1) * rng.randn(96, 2)).astype(np.float32)
+    run_case('mog2d', 2, H=10, T=25, eps=0.1, N=96, energy_fn=gmm.get_energy_function(),
+             energy_params=params, seed=16, x0=x0, head_std=0.5)
+
+    # ring of 4 (gen_ring, distributions.py:201-213), unequal-looking pis path
+    ring = ref_distributions.gen_ring(r=2.0, var=0.3, nb_mixtures=4)
+    ring_mus = [m.astype(np.float32) for m in ring.mus]
+    ring.mus = [torch.tensor(m) for m in ring_mus]
+    params = {'energy.kind': 'gmm', 'energy.mus': np.stack(ring_mus),
+              'energy.i_sigmas': np.stack(ring.i_sigmas),
+              'energy.constants': np.array(ring.constants, dtype=np.float32)}
+    run_case('ring4', 2, H=10, T=10, eps=0.15, N=64, energy_fn=ring.get_energy_function(),
+             energy_params=params, seed=17, x_scale=2.0, head_std=0.5)
+
+    # C4 shape: Rough Well (easy: cos(x/eta)) d=8 and d=50, and the non-easy form
+    for nm, d, eta, easy, N in (('rough8_easy', 8, 0.1, True, 64), ('rough50_easy', 50, 0.1, True, 32),
+                                ('rough8', 8, 0.5, False, 64)):
+        rw = ref_distributions.RoughWell(d, eta, easy=easy)
+        params = {'energy.kind': 'roughwell', 'energy.eta': np.float32(eta),
+                  'energy.easy': np.int32(easy)}
+        run_case(nm, d, H=10, T=10, eps=0.1, N=N, energy_fn=rw.get_energy_function(),
+                 energy_params=params, seed=18 + d, head_std=0.5)
+
+    # Gaussian funnel d=3 incl. chains beyond both clip thresholds (|v| > 8)
+    with contextlib.redirect_stdout(io.StringIO()):
+        fn = ref_distributions.GaussianFunnel(dim=3).get_energy_function()
+    rng = np.random.RandomState(21)
+    x0 = rng.randn(64, 3).astype(np.float32)
+    x0[:, 0] *= 2.0
+    x0[:4, 0] = [9.0, -9.0, 8.5, -8.25]
+    params = {'energy.kind': 'funnel', 'energy.sigma': np.float32(2.0)}
+    run_case('funnel3', 3, H=10, T=5, eps=0.05, N=64, energy_fn=fn, energy_params=params,
+             seed=22, x0=x0, head_std=0.3)
+
+    # p_accept edge cases (dynamics.py:302-309): +-inf / NaN Hamiltonian differences -> 0
+    tf1_stub.reset(0)
+    np.random.seed(0)
+    tf1_stub.VARIABLE_HOOK = None
+    with contextlib.redirect_stdout(io.StringIO()):
+        dist = ref_distributions.Gaussian(np.zeros(2), np.eye(2))
+        dyn = ref_dynamics.Dynamics(2, dist.get_energy_function(), T=2, eps=0.1, hmc=True)
+    x0 = np.array([[0, 0], [1, 1], [0, 0], [1e20, 0], [0, 0], [0.5, -0.5]], dtype=np.float32)
+    v0 = np.array([[0, 0], [1, 0], [1e20, 0], [0, 0], [0, 0], [0.1, 0.2]], dtype=np.float32)
+    x1 = np.array([[1, 1], [0, 0], [1e20, 0], [1e20, 0], [np.nan, 0], [0.25, 0.1]], dtype=np.float32)
+    v1 = np.array([[0, 1], [0, 0], [0, 0], [1e20, 1], [0, 0], [0.3, -0.2]], dtype=np.float32)
+    lj = np.array([0.1, 0.2, 0.0, 0.0, 0.0, np.inf], dtype=np.float32)
+    p = dyn.p_accept(leaf(x0), leaf(v0), leaf(x1), leaf(v1), torch.tensor(lj))
+    np.savez_compressed(os.path.join(OUT, 'p_accept_edge.npz'), x0=x0, v0=v0, x1=x1, v1=v1,
+                        logjac=lj, p=npy(p))
+    print('p_accept_edge      p =', npy(p))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,138 @@
+"""CPU: pin the numpy oracle against the golden vectors produced by the reference's own
+modules (executed under oracle/tf1_stub.py by oracle/make_goldens.py).
+
+Tolerances: both sides are fp32 implementations of the same op sequence (numpy vs torch-CPU
+kernels), so single steps agree to ~1e-6 and T-step trajectories to ~2e-5 relative
+(measured max 2.0e-5 on ring4); gates are 5e-6-ish x margin: 2e-5 / 1e-4.
+"""
+import numpy as np
+import pytest
+
+from oracle import l2hmc_oracle as O
+from tests.helpers import CASES, abs_err, check_x_next, load, oracle_dynamics, rel_err
+
+STEP_TOL = 3e-5     # one generalised leapfrog step (funnel's |grad| ~ 5e3 amplifies: 1.3e-5 seen)
+TRAJ_TOL = 1e-4     # T steps
+P_TOL = 5e-5        # accept probability (north_star asks 1e-4)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_energy_and_grad(case):
+    g = load(case)
+    d = oracle_dynamics(g)
+    assert rel_err(d.energy(g["x"]), g["energy"]) < 2e-6
+    assert rel_err(d.grad_energy(g["x"]), g["grad_energy"]) < 2e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_single_steps(case):
+    g = load(case)
+    d = oracle_dynamics(g)
+    x, v = g["x"], g["v"]
+    for s in g["steps"]:
+        with np.errstate(all="ignore"):
+            xo, vo, lj = d.forward_step(x, v, np.float32(s))
+            xb, vb, ljb = d.backward_step(x, v, np.float32(s))
+        for got, key in ((xo, "fstep%d.x"), (vo, "fstep%d.v"), (lj, "fstep%d.logdet"),
+                         (xb, "bstep%d.x"), (vb, "bstep%d.v"), (ljb, "bstep%d.logdet")):
+            assert rel_err(got, g[key % s]) < STEP_TOL, (case, key % s)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_trajectories_and_accept_prob(case):
+    g = load(case)
+    d = oracle_dynamics(g)
+    x, v = g["x"], g["v"]
+    with np.errstate(all="ignore"):
+        for nm, fn in (("fwd", d.forward), ("bwd", d.backward)):
+            X, V, lj = fn(x, v, log_jac=True)
+            _, _, p = fn(x, v)
+            assert rel_err(X, g[nm + ".x"]) < TRAJ_TOL
+            assert rel_err(V, g[nm + ".v"]) < TRAJ_TOL
+            assert rel_err(lj, g[nm + ".logjac"]) < TRAJ_TOL
+            assert abs_err(p, g[nm + ".p"]) < P_TOL
+            # NaN trajectories of the reference must be rejected (dynamics.py:309)
+            bad = ~np.all(np.isfinite(g[nm + ".x"]), axis=1)
+            assert np.all(p[bad] == 0)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("both", [True, False])
+def test_propose(case, both):
+    g = load(case)
+    d = oracle_dynamics(g)
+    x = g["x"]
+    with np.errstate(all="ignore"):
+        if int(g["hmc"]):
+            Lx, Lv, px, xn = O.propose(x, d, g["prop.v_fwd"], u=g["prop.u"])
+        else:
+            Lx, Lv, px, xn = O.propose(x, d, g["prop.v_fwd"], g["prop.v_bwd"], g["prop.dir"],
+                                       g["prop.u"], both_directions=both)
+    assert rel_err(Lx, g["prop.Lx"]) < TRAJ_TOL
+    assert abs_err(px, g["prop.px"]) < P_TOL
+    check_x_next(xn, x, g["prop.Lx"], g["prop.px"], g["prop.u"], 1e-4)
+    check_x_next(g["prop.x_next"], x, g["prop.Lx"], g["prop.px"], g["prop.u"], 1e-4)
+
+
+def test_p_accept_edge_cases():
+    """dynamics.py:302-309: non-finite accept probabilities become 0."""
+    g = load("p_accept_edge")
+    d = O.Dynamics(2, O.Gaussian(np.zeros(2), np.eye(2)), 2, 0.1, np.zeros((2, 2)))
+    p = d.p_accept(g["x0"], g["v0"], g["x1"], g["v1"], g["logjac"])
+    assert np.all(np.isfinite(p))
+    assert abs_err(p, g["p"]) < 1e-6
+
+
+def test_reversibility_fp64():
+    """backward(forward(x,v)) == (x,v) and the log-Jacobians cancel."""
+    g = load("scg2d")
+    d = oracle_dynamics(g, np.float64)
+    x, v = g["x"].astype(np.float64), g["v"].astype(np.float64)
+    X, V, lj = d.forward(x, v, log_jac=True)
+    x2, v2, lj2 = d.backward(X, V, log_jac=True)
+    assert np.max(np.abs(x2 - x)) < 1e-9 and np.max(np.abs(v2 - v)) < 1e-9
+    assert np.max(np.abs(lj + lj2)) < 1e-10
+
+
+def test_logdet_is_log_abs_det_jacobian_fp64():
+    """logdet of one forward step == log|det d(x',v')/d(x,v)| by central differences."""
+    g = load("tilted8")
+    d = oracle_dynamics(g, np.float64)
+    x, v = g["x"][:1].astype(np.float64), g["v"][:1].astype(np.float64)
+    n = x.shape[1]
+    z0 = np.concatenate([x, v], axis=1)
+
+    def f(z):
+        xo, vo, lj = d.forward_step(z[:, :n], z[:, n:], np.float64(2))
+        return np.concatenate([xo, vo], axis=1)[0], lj[0]
+
+    h = 1e-6
+    J = np.zeros((2 * n, 2 * n))
+    for i in range(2 * n):
+        dz = np.zeros_like(z0)
+        dz[0, i] = h
+        J[:, i] = (f(z0 + dz)[0] - f(z0 - dz)[0]) / (2 * h)
+    _, logabsdet = np.linalg.slogdet(J)
+    assert abs(logabsdet - f(z0)[1]) < 1e-6
+
+
+def test_hmc_limit_logjac_zero():
+    g = load("scg2d_hmc")
+    d = oracle_dynamics(g)
+    X, V, lj = d.forward(g["x"], g["v"], log_jac=True)
+    assert np.all(lj == 0)
+    assert d.p_accept(g["x"], g["v"], X, V, lj).mean() > 0.99
+
+
+def test_masks_have_floor_half_ones():
+    m = O.init_mask(7, 9, np.random.RandomState(0))
+    assert m.shape == (7, 9) and np.all(m.sum(axis=1) == 4)
+
+
+def test_ess_helpers():
+    rng = np.random.RandomState(0)
+    X = rng.randn(50, 8, 2)
+    A = O.acl_spectrum(X, 1.0)
+    assert A.shape == (49,)
+    assert abs(A[0] - np.mean(np.sum(X * X, axis=(1, 2)) / 8)) < 1e-12
+    assert 0 < O.ESS(A / A[0]) <= 1.0 + 1e-9
