@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py -- chain·leapfrog-steps/s of the fused L2HMC trajectory kernel on MI355X.
+
+Workload (BASELINE.json configs[1]): ill-conditioned Gaussian d=50, 4 096 chains PER GPU,
+Lf (T) = 10, S/T/Q nets with H=10.  One "step" = one `propose` (sampler.py:28-55): T
+generalised leapfrog steps on every chain in its drawn direction + accept probability + MH
+select -- one launch of the fused kernel; the chain state carries over from step to step.
+Synthetic inputs (seeded weights, masks, start points and the per-step random draws
+v / direction / u) are resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torchrun)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant
+kernel = traj_kernel, MFMA-bound: algorithmic fp32 flops / launch duration vs the 157.3
+TFLOP/s fp32-MFMA peak) and `cpu_baseline` (the numpy oracle -- reference algorithm, both
+directions computed like sampler.py:35-36 -- timed on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, H, T, CHAINS = 50, 10, 10, 4096
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector) peak
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops_per_chain_step(d, h, t, grad_flops):
+    """F = 4 F_net + (1 + 1/T) F_gradU + F_ew, F_net = 2H(5d + H + 2), F_ew ~ 30 d."""
+    return 4 * 2 * h * (5 * d + h + 2) + (1.0 + 1.0 / t) * grad_flops + 30 * d
+
+
+def algorithmic_bytes_per_chain_step(d, t):
+    """T-fused kernel: read x, v (+dir, u), write Lx, Lv?, x_next, p: (5 d + 3) floats / T steps."""
+    return 4.0 * (5 * d + 3) / t
+
+
+def make_problem(seed, n_chains, device):
+    """Seeded ICG-50 problem shared by the GPU run and the CPU baseline."""
+    rng = np.random.RandomState(seed)
+    var = np.exp(np.linspace(np.log(1e-2), np.log(1e2), D))
+    prob = {"var": var, "mask": None, "nets": {}}
+    masks = []
+    for _ in range(T):
+        m = np.zeros(D, dtype=np.float32)
+        m[rng.permutation(D)[:D // 2]] = 1
+        masks.append(m)
+    prob["mask"] = np.stack(masks)
+    for net, fac in (("xnet", 2.0), ("vnet", 1.0)):
+        def vs(shape, factor):
+            std = math.sqrt(1.3 * 2.0 * factor / shape[0])
+            return np.clip(rng.randn(*shape), -2, 2).astype(np.float32) * np.float32(std)
+        w = {"W1": vs((D, H), 1 / 3.), "W2": vs((D, H), fac / 3.), "W3": vs((2, H), 1 / 3.),
+             "W4": vs((H, H), 1.0)}
+        for k in ("Ws", "Wt", "Wq"):      # heads raised from the reference's 1e-3 init so S,T,Q matter
+            w[k] = (0.05 * rng.randn(H, D) / math.sqrt(H)).astype(np.float32)
+        for k, n in (("b1", H), ("b2", H), ("b3", H), ("b4", H), ("bs", D), ("bt", D), ("bq", D)):
+            w[k] = (0.05 * rng.randn(n)).astype(np.float32)
+        w["lam_s"] = (0.1 * rng.randn(1, D)).astype(np.float32)
+        w["lam_q"] = (0.1 * rng.randn(1, D)).astype(np.float32)
+        prob["nets"][net] = w
+    prob["x0"] = (rng.randn(n_chains, D) * np.sqrt(var)).astype(np.float32)
+    return prob
+
+
+def cpu_baseline(prob, budget_s=12.0):
+    """Reference algorithm (numpy oracle, fp32, both directions for all chains) on the host."""
+    from oracle import l2hmc_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    cores = os.cpu_count() or 1
+    n = min(CHAINS, prob["x0"].shape[0])
+    en = O.Gaussian(np.zeros(D), np.diag(1.0 / prob["var"]))
+    dyn = O.Dynamics(D, en, T, 0.1, prob["mask"], prob["nets"]["xnet"], prob["nets"]["vnet"])
+    rng = np.random.RandomState(1)
+    x = prob["x0"][:n]
+    reps, t0 = 0, time.perf_counter()
+    ctx = threadpool_limits(limits=cores) if threadpool_limits else None
+    with np.errstate(all="ignore"):
+        while True:
+            vf, vb = rng.randn(n, D).astype(np.float32), rng.randn(n, D).astype(np.float32)
+            dr, u = rng.randint(0, 2, n), rng.rand(n).astype(np.float32)
+            _, _, _, x = O.propose(x, dyn, vf, vb, dr, u, both_directions=True)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or reps >= 200:
+                break
+    if ctx is not None:
+        ctx.unregister() if hasattr(ctx, "unregister") else None
+    return {"value": n * T * reps / el, "unit": "chain·leapfrog-steps/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d proposals of %d chains (ICG d=50, T=10), numpy fp32 oracle, both directions "
+                      "computed as the reference does, row-wise Gaussian energy; %.1f s" % (reps, n, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bank", type=int, default=16, help="distinct pre-generated random draws (cycled)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+
+    from l2hmc_amd import Dynamics, _ffi, distributions, layers
+    from oracle import l2hmc_oracle as O   # only for NET_KEYS naming + the cpu_baseline leg
+
+    n = args.chains
+    prob = make_problem(0, n, dev)                     # identical model on every rank
+    layers.set_default_device(dev)
+    dyn = Dynamics(D, distributions.Gaussian(np.zeros(D), np.diag(prob["var"])).get_energy_function(),
+                   T=T, eps=0.1, net_factory=layers.stq_network(H), device=dev)
+    dyn.mask = prob["mask"]
+    dyn.variant = args.variant
+    with torch.no_grad():
+        for w, key in ((dyn._xw, "xnet"), (dyn._vw, "vnet")):
+            for k in O.NET_KEYS:
+                w[k].copy_(torch.as_tensor(prob["nets"][key][k]).reshape(w[k].shape))
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)   # chains differ per rank
+    xa = (torch.randn(n, D, device=dev, generator=gen) *
+          torch.as_tensor(np.sqrt(prob["var"]), dtype=torch.float32, device=dev)).contiguous()
+    xb = torch.empty_like(xa)
+    B = args.bank
+    v_bank = torch.randn(B, n, D, device=dev, generator=gen)
+    d_bank = torch.randint(0, 2, (B, n), device=dev, dtype=torch.uint8, generator=gen)
+    u_bank = torch.rand(B, n, device=dev, generator=gen)
+    p_out = torch.empty(n, device=dev)
+    lx_out = torch.empty_like(xa)
+
+    L = _ffi.lib()
+    a = _ffi.L2hmcTrajectoryArgs()
+    a.packed_nets = dyn._packed_nets().data_ptr()
+    a.energy = dyn._fn.c_struct(dev, 1.0)
+    a.masks, a.trig = dyn._mask.data_ptr(), dyn._trig.data_ptr()
+    a.alpha, a.eps_host = dyn.alpha.data_ptr(), 0.0
+    a.n_chains, a.d, a.H, a.T, a.step_begin, a.n_steps = n, D, H, T, 0, T
+    a.x_out, a.p_out, a.variant = lx_out.data_ptr(), p_out.data_ptr(), args.variant
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    bufs = [xa, xb]
+    acc_sum = torch.zeros((), device=dev)
+
+    def step(k):
+        src, dst = bufs[k & 1], bufs[(k + 1) & 1]
+        b = k % B
+        a.x, a.x_next = src.data_ptr(), dst.data_ptr()
+        a.v = v_bank[b].data_ptr()
+        a.direction = d_bank[b].data_ptr()
+        a.u = u_bank[b].data_ptr()
+        rc = L.l2hmc_trajectory(a, stream)
+        if rc:
+            _ffi.check(rc)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    mean_p = float(p_out.mean())
+    finite = bool(torch.isfinite(bufs[(args.warmup + args.steps) & 1]).all())
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    if rank == 0:
+        steps_total = float(n) * world * T * args.steps
+        flops_cs = algorithmic_flops_per_chain_step(D, H, T, 3 * D)      # diagonal precision: 3d
+        per_launch_flops = flops_cs * n * T
+        launch_s = gpu_ms * 1e-3 / args.steps                            # HIP events on the launch stream
+        ach = per_launch_flops / launch_s / 1e12
+        out = {
+            "metric": "chain_leapfrog_steps_per_sec", "value": steps_total / elapsed,
+            "unit": "chain·leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "ICG-50D (ill-conditioned Gaussian d=50), %d chains per GPU, Lf=10, "
+                                   "S/T/Q nets H=10, direction-mixed propose + MH per step" % n,
+                       "chains_per_gpu": n, "x_dim": D, "hidden": H, "leapfrog_steps": T,
+                       "parallelism": "chains sharded, no data-path collective",
+                       "mean_accept_prob": mean_p, "state_finite": finite},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "traj_kernel", "flops_per_chain_step": flops_cs,
+                         "launch_us": launch_s * 1e6,
+                         "hbm_frac": algorithmic_bytes_per_chain_step(D, T) * n * T / launch_s / 1e9 / PEAK_HBM_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

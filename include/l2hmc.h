@@ -1,0 +1,150 @@
+/*
+ * l2hmc.h -- C ABI of libl2hmc_hip.so: the MI355X (gfx950) L2HMC leapfrog hot path.
+ *
+ * The reference (brain-research/l2hmc) has no native/FFI layer: its hot path is the
+ * Python API of utils/dynamics.py + utils/sampler.py.  This header is the boundary a
+ * drop-in replacement binds instead (ctypes from Python -- see INTEGRATION.md): every
+ * entry point names the reference function(s) it replaces.  All paths below are relative
+ * to the reference tree (/root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in `_host`;
+ *     the caller (torch) owns all buffers; the library allocates nothing and keeps no
+ *     pointer after a call returns;
+ *   - all arrays are float32, row-major, C-contiguous; chains are rows: x is (N, d);
+ *   - calls are asynchronous on `stream` (a hipStream_t; NULL = default stream), never
+ *     synchronise, and may run concurrently on distinct streams/devices;
+ *   - return value: 0 on success, a negative L2HMC_ERR_* code otherwise; the message is
+ *     available from l2hmc_last_error() (thread-local).  Nothing throws or aborts.
+ */
+#ifndef L2HMC_H_
+#define L2HMC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2HMC_ABI_VERSION 1
+
+enum {
+  L2HMC_OK = 0,
+  L2HMC_ERR_ARG = -1,          /* null / inconsistent argument                       */
+  L2HMC_ERR_UNSUPPORTED = -2,  /* shape outside what the fused kernels cover          */
+  L2HMC_ERR_HIP = -3           /* HIP runtime error (launch, attribute, no device)    */
+};
+
+/* Target energies of utils/distributions.py that are fused into the kernels. */
+enum {
+  L2HMC_ENERGY_GAUSS_DIAG = 1,  /* Gaussian, diagonal precision   distributions.py:41-57,31-32 */
+  L2HMC_ENERGY_GAUSS_DENSE = 2, /* Gaussian, dense precision      distributions.py:41-57,31-32 */
+  L2HMC_ENERGY_GMM = 3,         /* mixture of Gaussians           distributions.py:104-134     */
+  L2HMC_ENERGY_ROUGHWELL = 4,   /* rough well                     distributions.py:84-97       */
+  L2HMC_ENERGY_FUNNEL = 5       /* Gaussian funnel                distributions.py:155-180     */
+};
+
+/* One S/T/Q network in the reference's own parameter layout: `Linear` keeps W as
+ * (in, out) row-major and b as (out,) (utils/layers.py:29-37); `ScaleTanh` keeps a (1, d)
+ * log-scale (utils/layers.py:81-86).  Architecture = SCGExperiment.ipynb `network`:
+ *   h1 = relu(a W1 + b1 + b W2 + b2 + tau W3 + b3);  h2 = relu(h1 W4 + b4);
+ *   S = exp(lam_s) * tanh(h2 Ws + bs);  T = h2 Wt + bt;  Q = exp(lam_q) * tanh(h2 Wq + bq)
+ * Shapes: W1, W2 (d,H); W3 (2,H); W4 (H,H); Ws, Wt, Wq (H,d); b1,b2,b3,b4 (H); bs,bt,bq (d);
+ * lam_s, lam_q (d). */
+typedef struct L2hmcNet {
+  const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4;
+  const float *Ws, *bs, *Wt, *bt, *Wq, *bq, *lam_s, *lam_q;
+} L2hmcNet;
+
+/* Target energy U(x) (dynamics.py:203-212 `energy`, :217-218 `grad_energy`).
+ *   GAUSS_DIAG : mu (d), prec (d) = diagonal of the fp32 precision matrix
+ *   GAUSS_DENSE: mu (d), prec = buffer written by l2hmc_pack_gaussian (n_comp = 1)
+ *   GMM        : mu (n_comp, d), prec = n_comp packed precisions back to back
+ *                (stride l2hmc_packed_gaussian_floats(d)), logc (n_comp) = log(pi_i / sqrt((2 pi)^d det Sigma_i))
+ *   ROUGHWELL  : eta, easy (distributions.py:84-97: U = |x|^2/2 + eta sum cos(x / eta^2), or x / eta if easy)
+ *   FUNNEL     : eta = sigma (distributions.py:155-180; clip = 4 sigma)
+ * temperature divides U and grad U (dynamics.py:204-212); 1.0 when unused. */
+typedef struct L2hmcEnergy {
+  int32_t kind;
+  int32_t n_comp;
+  const float* mu;
+  const float* prec;
+  const float* logc;
+  float eta;
+  int32_t easy;
+  float temperature;
+} L2hmcEnergy;
+
+/* Arguments of l2hmc_trajectory (passed by pointer; a HOST struct of device pointers). */
+typedef struct L2hmcTrajectoryArgs {
+  /* ---- model ------------------------------------------------------------------------- */
+  const float* packed_nets; /* from l2hmc_pack_nets; NULL = HMC mode (nets == 0, dynamics.py:73-76) */
+  L2hmcEnergy energy;
+  const float* masks;       /* (T, d) 0/1 rows, `Dynamics.mask` (dynamics.py:84-97)          */
+  const float* trig;        /* (T, 2) [cos(2 pi t/T), sin(2 pi t/T)] (dynamics.py:99-105)    */
+  const float* alpha;       /* device scalar log(eps) (dynamics.py:50-58) or NULL ...        */
+  float eps_host;           /* ... then this step size is used                               */
+  /* ---- state -------------------------------------------------------------------------- */
+  int64_t n_chains;
+  int32_t d, H, T;
+  int32_t step_begin;       /* leapfrog iterations [step_begin, step_begin + n_steps) of the  */
+  int32_t n_steps;          /* T-step schedule; a full trajectory is (0, T)                   */
+  const float* x;           /* (N, d) start positions                                         */
+  const float* v;           /* (N, d) start momenta (the injected N(0,I) draw)                */
+  const uint8_t* direction; /* (N) 1 = forward, 0 = backward (sampler.py:34) or NULL ...      */
+  int32_t direction_all;    /* ... then every chain runs forward (1) or backward (0)          */
+  const float* u;           /* (N) accept uniforms (sampler.py:54) or NULL (no MH step)       */
+  /* ---- outputs (any may be NULL) ------------------------------------------------------- */
+  float* x_out;             /* (N, d) proposal Lx                                             */
+  float* v_out;             /* (N, d) proposal Lv                                             */
+  float* logjac_out;        /* (N) summed log|det J| of the executed steps                    */
+  float* p_out;             /* (N) accept prob, dynamics.py:302-309                           */
+  float* x_next;            /* (N, d) MH-selected state, sampler.py:53-55 (needs u and p)     */
+  /* ---- tuning ---------------------------------------------------------------------------- */
+  int32_t variant;          /* 0 = auto; else waves per 16-chain tile (1 or 4)                */
+} L2hmcTrajectoryArgs;
+
+int l2hmc_abi_version(void);
+const char* l2hmc_last_error(void);
+
+/* Number of floats of the fragment-ordered weight buffer for both nets, or a negative
+ * L2HMC_ERR_* if (d, H) is outside the fused kernels' range. */
+int64_t l2hmc_packed_nets_floats(int32_t d, int32_t H);
+
+/* Re-orders XNet and VNet (utils/layers.py parameter layout, built by the `net_factory`
+ * of dynamics.py:78-79) into MFMA A-operand fragment order.  Run once per weight update. */
+int l2hmc_pack_nets(const L2hmcNet* xnet, const L2hmcNet* vnet, int32_t d, int32_t H,
+                    float* packed, void* stream);
+
+int64_t l2hmc_packed_gaussian_floats(int32_t d);
+/* i_sigma: (d, d) fp32 precision matrix `Gaussian.i_sigma.astype('float32')`
+ * (distributions.py:48,52); packs (S + S^T)/2 in fragment order. */
+int l2hmc_pack_gaussian(const float* i_sigma, int32_t d, float* packed, void* stream);
+
+/* The fused generalised-leapfrog trajectory:
+ *   Dynamics.forward / .backward           dynamics.py:246-300  (n_steps = T)
+ *   Dynamics._forward_step/_backward_step  dynamics.py:115-201  (n_steps = 1; a backward
+ *       step at schedule index s is step_begin = T-1-s with direction 0)
+ *   Dynamics.p_accept                      dynamics.py:302-309  (p_out)
+ *   propose + tf_accept                    sampler.py:28-55     (direction, u, x_next)
+ * Each chain runs only in its drawn direction (the reference runs both and discards one). */
+int l2hmc_trajectory(const L2hmcTrajectoryArgs* args, void* stream);
+
+/* Dynamics.energy / Dynamics.grad_energy (dynamics.py:203-218).  U_out (N) and/or
+ * grad_out (N, d) may be NULL. */
+int l2hmc_energy(const L2hmcEnergy* energy, const float* x, int64_t n_chains, int32_t d,
+                 float* U_out, float* grad_out, void* stream);
+
+/* Dynamics.p_accept (dynamics.py:302-309) on arbitrary end points. */
+int l2hmc_p_accept(const L2hmcEnergy* energy, const float* x0, const float* v0,
+                   const float* x1, const float* v1, const float* logjac,
+                   int64_t n_chains, int32_t d, float* p_out, void* stream);
+
+/* tf_accept (sampler.py:53-55): x_next[n,:] = (px[n] - u[n] >= 0) ? Lx[n,:] : x[n,:]. */
+int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const float* u,
+                    int64_t n_chains, int32_t d, float* x_next, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L2HMC_H_ */

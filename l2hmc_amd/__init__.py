@@ -1,0 +1,12 @@
+"""l2hmc_amd -- the L2HMC generalised-leapfrog hot path, MI355X-native.
+
+Python surface = the reference's `utils/dynamics.py`, `utils/sampler.py`, `utils/layers.py`,
+`utils/distributions.py` (+ the chain diagnostics of `utils/func_utils.py`); compute = the
+hand-written HIP kernels of `csrc/` behind the C ABI of `include/l2hmc.h`.
+"""
+from . import _ffi, distributions, func_utils, layers  # noqa: F401
+from .dynamics import Dynamics  # noqa: F401
+from .sampler import chain_operator, propose, tf_accept  # noqa: F401
+
+__all__ = ["Dynamics", "propose", "tf_accept", "chain_operator", "layers", "distributions",
+           "func_utils"]

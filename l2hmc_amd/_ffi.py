@@ -1,0 +1,92 @@
+"""ctypes binding of libl2hmc_hip.so (the C ABI declared in include/l2hmc.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails this
+module raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C l2hmc_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libl2hmc_hip.so")
+
+ENERGY_GAUSS_DIAG, ENERGY_GAUSS_DENSE, ENERGY_GMM, ENERGY_ROUGHWELL, ENERGY_FUNNEL = 1, 2, 3, 4, 5
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+NET_FIELDS = ("W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4",
+              "Ws", "bs", "Wt", "bt", "Wq", "bq", "lam_s", "lam_q")
+
+
+class L2hmcNet(C.Structure):
+    _fields_ = [(k, _fp) for k in NET_FIELDS]
+
+
+class L2hmcEnergy(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_comp", C.c_int32), ("mu", _fp), ("prec", _fp),
+                ("logc", _fp), ("eta", C.c_float), ("easy", C.c_int32),
+                ("temperature", C.c_float)]
+
+
+class L2hmcTrajectoryArgs(C.Structure):
+    _fields_ = [("packed_nets", _fp), ("energy", L2hmcEnergy), ("masks", _fp), ("trig", _fp),
+                ("alpha", _fp), ("eps_host", C.c_float),
+                ("n_chains", C.c_int64), ("d", C.c_int32), ("H", C.c_int32), ("T", C.c_int32),
+                ("step_begin", C.c_int32), ("n_steps", C.c_int32),
+                ("x", _fp), ("v", _fp), ("direction", _fp), ("direction_all", C.c_int32),
+                ("u", _fp),
+                ("x_out", _fp), ("v_out", _fp), ("logjac_out", _fp), ("p_out", _fp),
+                ("x_next", _fp), ("variant", C.c_int32)]
+
+
+# every symbol include/l2hmc.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "l2hmc_abi_version": (C.c_int, []),
+    "l2hmc_last_error": (C.c_char_p, []),
+    "l2hmc_packed_nets_floats": (C.c_int64, [C.c_int32, C.c_int32]),
+    "l2hmc_pack_nets": (C.c_int, [C.POINTER(L2hmcNet), C.POINTER(L2hmcNet), C.c_int32, C.c_int32,
+                                  _fp, _fp]),
+    "l2hmc_packed_gaussian_floats": (C.c_int64, [C.c_int32]),
+    "l2hmc_pack_gaussian": (C.c_int, [_fp, C.c_int32, _fp, _fp]),
+    "l2hmc_trajectory": (C.c_int, [C.POINTER(L2hmcTrajectoryArgs), _fp]),
+    "l2hmc_energy": (C.c_int, [C.POINTER(L2hmcEnergy), _fp, C.c_int64, C.c_int32, _fp, _fp, _fp]),
+    "l2hmc_p_accept": (C.c_int, [C.POINTER(L2hmcEnergy), _fp, _fp, _fp, _fp, _fp, C.c_int64,
+                                 C.c_int32, _fp, _fp]),
+    "l2hmc_mh_select": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (raises loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "l2hmc_amd: %s is missing -- the HIP extension has not been built "
+                "(run `make -C l2hmc_amd/csrc`); there is no CPU/eager fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.l2hmc_abi_version() != 1:
+            raise RuntimeError("l2hmc_amd: ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise RuntimeError("libl2hmc_hip: %s (code %d)" % (lib().l2hmc_last_error().decode(), rc))
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,297 @@
+"""`Dynamics` -- API of the reference's utils/dynamics.py, executed by fused HIP kernels.
+
+Constructor and method signatures follow utils/dynamics.py:34-309; tensors are float32
+torch tensors on a ROCm device instead of `tf.Tensor`s, and every method runs eagerly (one
+kernel launch through the C ABI of include/l2hmc.h) instead of building a TF graph.
+
+Differences that are additions, not removals:
+  * randomness can be injected (`init_v`, and `direction` / `u` in sampler.propose) so runs
+    are reproducible and comparable with the reference on identical draws;
+  * `mask` is an assignable (T, d) tensor that is part of `state_dict()` (the reference keeps
+    it as an un-checkpointed graph constant, eval_sampler.py:52-59);
+  * the energy must be one of the fused targets of `l2hmc_amd.distributions` and the nets the
+    S/T/Q architecture of `l2hmc_amd.layers.stq_network` (anything else raises: there is
+    no eager fallback).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .distributions import EnergyFunction, as_device_f32
+from .layers import default_device, extract_stq
+
+TF_FLOAT = torch.float32
+NP_FLOAT = np.float32
+
+
+class _ZeroNet(object):
+    """HMC mode: S = T = Q = 0 (dynamics.py:73-76)."""
+
+    def __call__(self, inp):
+        return [torch.zeros_like(inp[0]) for _ in range(3)]
+
+
+class Dynamics(object):
+    def __init__(self,
+                 x_dim,
+                 energy_function,
+                 T=25,
+                 eps=0.1,
+                 hmc=False,
+                 net_factory=None,
+                 eps_trainable=True,
+                 use_temperature=False,
+                 device=None):
+        self.x_dim = int(x_dim)
+        self.T = int(T)
+        self.hmc = bool(hmc)
+        self.use_temperature = use_temperature
+        self.temperature = 1.0          # the reference's fed placeholder (dynamics.py:47)
+        self.device = torch.device(device) if device is not None else default_device()
+        self.generator = None           # optional torch.Generator for the momentum draws
+        self.variant = 0                # kernel geometry override (0 = auto), see l2hmc.h
+        self.eps_override = None        # float: bypass exp(alpha) (exact step size for parity tests)
+
+        if not isinstance(energy_function, EnergyFunction):
+            raise TypeError(
+                "Dynamics needs an energy from l2hmc_amd.distributions (got %r): only those are "
+                "fused into the HIP leapfrog kernel and there is no eager fallback" % (energy_function,))
+        if energy_function.x_dim is not None and energy_function.x_dim != self.x_dim:
+            raise ValueError("energy is %d-dimensional, Dynamics x_dim=%d" % (energy_function.x_dim, x_dim))
+        self._fn = energy_function
+
+        # eps = exp(alpha), one scalar shared by all steps and both nets (dynamics.py:50-58)
+        alpha = torch.tensor(math.log(eps), dtype=torch.float32, device=self.device)
+        if not self.hmc:
+            self.alpha = torch.nn.Parameter(alpha, requires_grad=bool(eps_trainable))
+        else:
+            self.alpha = alpha
+
+        self._init_mask()
+        self._trig = self._time_table()
+
+        if self.hmc:
+            self.XNet = _ZeroNet()
+            self.VNet = _ZeroNet()
+            self._xw = self._vw = None
+            self.H = 0
+        else:
+            self.XNet = net_factory(x_dim, scope='XNet', factor=2.0)
+            self.VNet = net_factory(x_dim, scope='VNet', factor=1.0)
+            self._xw = extract_stq(self.XNet, self.x_dim)
+            self._vw = extract_stq(self.VNet, self.x_dim)
+            if self._xw is None or self._vw is None or self._xw['H'] != self._vw['H']:
+                raise NotImplementedError(
+                    "net_factory must build the S/T/Q architecture of l2hmc_amd.layers.stq_network "
+                    "(SCGExperiment.ipynb `network`); other structures are not fused")
+            self.H = self._xw['H']
+            for w in (self._xw, self._vw):
+                for k in _ffi.NET_FIELDS:
+                    if w[k].device != self.device:
+                        raise ValueError("net parameters live on %s, Dynamics on %s" % (w[k].device, self.device))
+        self._packed = None
+        self._packed_key = None
+
+    # ---- masks / time encoding -----------------------------------------------------------------
+    def _init_mask(self):
+        """dynamics.py:84-93: T masks with floor(d/2) ones, numpy global RNG."""
+        rows = []
+        for _ in range(self.T):
+            ind = np.random.permutation(np.arange(self.x_dim))[:int(self.x_dim / 2)]
+            m = np.zeros((self.x_dim,))
+            m[ind] = 1
+            rows.append(m)
+        self.mask = np.stack(rows)
+
+    @property
+    def mask(self):
+        return self._mask
+
+    @mask.setter
+    def mask(self, value):
+        m = torch.as_tensor(np.asarray(value.detach().cpu() if isinstance(value, torch.Tensor) else value,
+                                       dtype=np.float32))
+        if tuple(m.shape) != (self.T, self.x_dim):
+            raise ValueError("mask must be (T, x_dim) = (%d, %d)" % (self.T, self.x_dim))
+        self._mask = m.to(self.device).contiguous()
+
+    def _get_mask(self, step):
+        m = self._mask[int(step)]
+        return m, 1. - m
+
+    def _time_table(self):
+        """dynamics.py:99-105 for t = 0..T-1, in float32 like the reference's graph."""
+        t = np.arange(self.T, dtype=np.float32)
+        ang = np.float32(2 * np.pi) * t / np.float32(self.T)
+        tab = np.stack([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)
+        return torch.as_tensor(tab, device=self.device).contiguous()
+
+    def _format_time(self, t, tile=1):
+        return self._trig[int(t)].unsqueeze(0).repeat(tile, 1)
+
+    @property
+    def eps(self):
+        return torch.exp(self.alpha.detach())
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def parameters(self):
+        """[(name, tensor)] with the reference's variable names."""
+        if self.hmc:
+            return []
+        return [('alpha', self.alpha)] + self.XNet.parameters() + self.VNet.parameters()
+
+    def state_dict(self):
+        sd = {k: v.detach().cpu().clone() for k, v in self.parameters()}
+        sd['mask'] = self._mask.cpu().clone()
+        if self.hmc:
+            sd['alpha'] = self.alpha.cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for k, v in self.parameters():
+                v.copy_(sd[k].to(v.device))
+            if self.hmc and 'alpha' in sd:
+                self.alpha = sd['alpha'].to(self.device)
+        self.mask = sd['mask']
+        self._packed_key = None
+
+    def _packed_nets(self):
+        """Fragment-ordered weights for the kernels; re-packed when any parameter changed."""
+        if self.hmc:
+            return None
+        key = tuple((w[k].data_ptr(), w[k]._version) for w in (self._xw, self._vw) for k in _ffi.NET_FIELDS)
+        if key != self._packed_key:
+            L = _ffi.lib()
+            n = _ffi.check(L.l2hmc_packed_nets_floats(self.x_dim, self.H))
+            if self._packed is None or self._packed.numel() != n:
+                self._packed = torch.empty(n, dtype=torch.float32, device=self.device)
+            structs = []
+            for w in (self._xw, self._vw):
+                for k in _ffi.NET_FIELDS:
+                    if not w[k].is_contiguous():
+                        raise ValueError("net parameter %s must be contiguous" % k)
+                structs.append(_ffi.L2hmcNet(*[w[k].data_ptr() for k in _ffi.NET_FIELDS]))
+            _ffi.check(L.l2hmc_pack_nets(structs[0], structs[1], self.x_dim, self.H,
+                                         self._packed.data_ptr(), _ffi.current_stream(self.device)))
+            self._packed_key = key
+        return self._packed
+
+    # ---- the fused trajectory ----------------------------------------------------------------------
+    def _check_aux(self, aux):
+        if aux is not None:
+            raise NotImplementedError("aux-conditioned nets/energies (mnist_vae.py) are not fused yet")
+
+    def _randn_like(self, x):
+        return torch.randn(x.shape, dtype=torch.float32, device=x.device, generator=self.generator)
+
+    def run(self, x, v, step_begin, n_steps, direction=None, direction_all=1, u=None,
+            want=('x', 'v', 'logjac')):
+        """Launch `l2hmc_trajectory` (include/l2hmc.h).  Returns a dict of the requested
+        outputs among x, v, logjac, p, x_next."""
+        x = as_device_f32(x, self.device)
+        v = as_device_f32(v, self.device)
+        N, d = x.shape
+        if d != self.x_dim or v.shape != x.shape:
+            raise ValueError("x, v must be (N, %d)" % self.x_dim)
+        out = {}
+        if 'x' in want:
+            out['x'] = torch.empty_like(x)
+        if 'v' in want:
+            out['v'] = torch.empty_like(x)
+        for k in ('logjac', 'p'):
+            if k in want:
+                out[k] = torch.empty(N, dtype=torch.float32, device=x.device)
+        if 'x_next' in want:
+            out['x_next'] = torch.empty_like(x)
+            out.setdefault('p', torch.empty(N, dtype=torch.float32, device=x.device))
+        if direction is not None:
+            direction = direction.to(device=x.device, dtype=torch.uint8).contiguous()
+            if direction.shape != (N,):
+                raise ValueError("direction must be (N,)")
+        if u is not None:
+            u = as_device_f32(u, self.device)
+            if u.shape != (N,):
+                raise ValueError("u must be (N,)")
+        a = _ffi.L2hmcTrajectoryArgs()
+        a.packed_nets = _ffi.ptr(self._packed_nets())
+        a.energy = self._fn.c_struct(x.device, self.temperature if self.use_temperature else 1.0)
+        a.masks, a.trig = self._mask.data_ptr(), self._trig.data_ptr()
+        if self.eps_override is None:
+            a.alpha, a.eps_host = self.alpha.data_ptr(), 0.0
+        else:
+            a.alpha, a.eps_host = None, float(self.eps_override)
+        a.n_chains, a.d, a.H, a.T = N, d, self.H, self.T
+        a.step_begin, a.n_steps = int(step_begin), int(n_steps)
+        a.x, a.v = x.data_ptr(), v.data_ptr()
+        a.direction, a.direction_all = _ffi.ptr(direction), int(direction_all)
+        a.u = _ffi.ptr(u)
+        a.x_out, a.v_out = _ffi.ptr(out.get('x')), _ffi.ptr(out.get('v'))
+        a.logjac_out, a.p_out = _ffi.ptr(out.get('logjac')), _ffi.ptr(out.get('p'))
+        a.x_next = _ffi.ptr(out.get('x_next'))
+        a.variant = int(self.variant)
+        _ffi.check(_ffi.lib().l2hmc_trajectory(a, _ffi.current_stream(x.device)))
+        return out
+
+    # ---- reference API -------------------------------------------------------------------------------
+    def kinetic(self, v):
+        """dynamics.py:107-108."""
+        return 0.5 * torch.sum(torch.square(v), dim=1)
+
+    def energy(self, x, aux=None):
+        """dynamics.py:203-212."""
+        self._check_aux(aux)
+        return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0)[0]
+
+    def grad_energy(self, x, aux=None):
+        """dynamics.py:217-218 (analytic, computed by the HIP energy kernel)."""
+        self._check_aux(aux)
+        return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
+                                 want_U=False, want_grad=True)[1]
+
+    def hamiltonian(self, x, v, aux=None):
+        """dynamics.py:214-215."""
+        return self.energy(x, aux=aux) + self.kinetic(v)
+
+    def _forward_step(self, x, v, step, aux=None):
+        """dynamics.py:115-157 -> (x_o, v_o, log_jac_contrib)."""
+        self._check_aux(aux)
+        o = self.run(x, v, int(step), 1, direction_all=1)
+        return o['x'], o['v'], o['logjac']
+
+    def _backward_step(self, x_o, v_o, step, aux=None):
+        """dynamics.py:159-201 -> (x, v, log_jac_contrib)."""
+        self._check_aux(aux)
+        o = self.run(x_o, v_o, self.T - 1 - int(step), 1, direction_all=0)
+        return o['x'], o['v'], o['logjac']
+
+    def _trajectory(self, x, init_v, aux, log_jac, direction_all):
+        self._check_aux(aux)
+        x = as_device_f32(x, self.device)
+        v = self._randn_like(x) if init_v is None else init_v      # dynamics.py:247-250
+        want = ('x', 'v', 'logjac') if log_jac else ('x', 'v', 'p')
+        o = self.run(x, v, 0, self.T, direction_all=direction_all, want=want)
+        return o['x'], o['v'], (o['logjac'] if log_jac else o['p'])
+
+    def forward(self, x, init_v=None, aux=None, log_path=False, log_jac=False):
+        """dynamics.py:246-272 -> (X, V, p_accept) or (X, V, log_jac)."""
+        return self._trajectory(x, init_v, aux, log_jac, 1)
+
+    def backward(self, x, init_v=None, aux=None, log_jac=False):
+        """dynamics.py:274-300."""
+        return self._trajectory(x, init_v, aux, log_jac, 0)
+
+    def p_accept(self, x0, v0, x1, v1, log_jac, aux=None):
+        """dynamics.py:302-309."""
+        self._check_aux(aux)
+        x0, v0, x1, v1 = (as_device_f32(t, self.device) for t in (x0, v0, x1, v1))
+        lj = as_device_f32(log_jac, self.device)
+        N, d = x0.shape
+        p = torch.empty(N, dtype=torch.float32, device=x0.device)
+        e = self._fn.c_struct(x0.device, self.temperature if self.use_temperature else 1.0)
+        _ffi.check(_ffi.lib().l2hmc_p_accept(e, x0.data_ptr(), v0.data_ptr(), x1.data_ptr(),
+                                             v1.data_ptr(), lj.data_ptr(), N, d, p.data_ptr(),
+                                             _ffi.current_stream(x0.device)))
+        return p

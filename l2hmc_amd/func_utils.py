@@ -1,0 +1,35 @@
+"""Chain diagnostics -- the sampler-related part of the reference's utils/func_utils.py
+(`accept` :33-42, `autocovariance` :45-54, `acl_spectrum` :114-116, `ESS` :118-120).
+Host-side numpy on recorded chains of shape (steps, chains, dim); the MNIST/VAE helpers of
+that file are out of scope."""
+import numpy as np
+
+
+def accept(x_i, x_p, p, rng=None):
+    """Numpy Metropolis select: rows with p - u >= 0 move to the proposal."""
+    if x_i.shape != x_p.shape:
+        raise ValueError("state and proposal shapes differ")
+    u = (np.random if rng is None else rng).uniform(size=(x_i.shape[0],))
+    take = (p - u >= 0)[:, None]
+    return np.where(take, x_p, x_i)
+
+
+def autocovariance(X, tau=0):
+    """mean_t [ sum_{n,k} X[t,n,k] X[t+tau,n,k] / N ]  -- no mean subtraction, like the reference."""
+    X = np.asarray(X)
+    steps, chains, _ = X.shape
+    a, b = X[:steps - tau], X[tau:]
+    return float(np.einsum('tnk,tnk->', a, b) / chains / (steps - tau))
+
+
+def acl_spectrum(X, scale):
+    """A(tau) for tau = 0 .. steps-2 on X / scale."""
+    Xs = np.asarray(X) / scale
+    return np.array([autocovariance(Xs, tau=t) for t in range(Xs.shape[0] - 1)])
+
+
+def ESS(A):
+    """1 / (1 + 2 sum_{tau>=1} A(tau) [A(tau) > 0.05])."""
+    A = np.asarray(A)
+    kept = np.where(A > 0.05, A, 0.0)
+    return 1. / (1. + 2 * np.sum(kept[1:]))

@@ -1,0 +1,110 @@
+"""Sampling operators -- API of the reference's utils/sampler.py:28-85.
+
+`propose` launches ONE fused kernel per call: every chain runs only in its drawn direction
+(the reference runs forward AND backward on all chains and discards half, sampler.py:35-44),
+and the accept probability and the Metropolis select are part of the same kernel.
+
+Randomness (all optional, keyword-only, for reproducibility / parity on identical draws):
+  direction : (N,) 0/1, 1 = forward       -- the draw of sampler.py:34
+  v         : (N, d) momenta, or a pair (v_fwd, v_bwd) -- the reference draws one N(0, I)
+              per direction (dynamics.py:247-250, 275-278); a chain uses the one of its own
+              direction
+  u         : (N,) accept uniforms         -- the draw of sampler.py:54
+"""
+import torch
+
+from . import _ffi
+from .distributions import as_device_f32
+
+TF_FLOAT = torch.float32
+
+
+def _rand(shape, dynamics):
+    return torch.rand(shape, dtype=torch.float32, device=dynamics.device, generator=dynamics.generator)
+
+
+def propose(x, dynamics, init_v=None, aux=None, do_mh_step=False, log_jac=False, *,
+            direction=None, v=None, u=None):
+    """sampler.py:28-51 -> (Lx, Lv, px, outputs).
+
+    HMC mode (:29-31): one forward trajectory from `init_v` (or a fresh draw); `outputs` always
+    holds the MH-selected state.  L2HMC mode (:33-51): direction-mixed proposal; as in the
+    reference `init_v` is NOT the start momentum (each proposal draws its own) and only
+    controls whether `Lv` is returned; with `log_jac=True` the third return is the
+    log-Jacobian, not a probability (used by `chain_operator`)."""
+    dynamics._check_aux(aux)
+    x = as_device_f32(x, dynamics.device)
+    N = x.shape[0]
+    if dynamics.hmc:
+        v0 = init_v if init_v is not None else (v if v is not None else dynamics._randn_like(x))
+        uu = u if u is not None else _rand((N,), dynamics)
+        o = dynamics.run(x, v0, 0, dynamics.T, direction_all=1, u=uu, want=('x', 'v', 'p', 'x_next'))
+        return o['x'], o['v'], o['p'], [o['x_next']]
+
+    if direction is None:
+        direction = torch.randint(0, 2, (N,), device=dynamics.device, dtype=torch.uint8,
+                                  generator=dynamics.generator)
+    else:
+        direction = torch.as_tensor(direction, device=dynamics.device).to(torch.uint8)
+    if v is None:
+        v0 = dynamics._randn_like(x)
+    elif isinstance(v, (tuple, list)):
+        v_f, v_b = (as_device_f32(t, dynamics.device) for t in v)
+        v0 = torch.where(direction.bool().unsqueeze(1), v_f, v_b)
+    else:
+        v0 = v
+    want = ['x', 'v', 'logjac' if log_jac else 'p']
+    uu = None
+    if do_mh_step and not log_jac:
+        uu = u if u is not None else _rand((N,), dynamics)
+        want.append('x_next')
+    o = dynamics.run(x, v0, 0, dynamics.T, direction=direction, u=uu, want=tuple(want))
+    Lv = o['v'] if init_v is not None else None
+    px = o['logjac'] if log_jac else o['p']
+    outputs = []
+    if do_mh_step:
+        if log_jac:     # reference quirk: tf_accept on a log-Jacobian "probability" (:44-49)
+            outputs.append(tf_accept(x, o['x'], px, u=u, dynamics=dynamics))
+        else:
+            outputs.append(o['x_next'])
+    return o['x'], Lv, px, outputs
+
+
+def tf_accept(x, Lx, px, u=None, dynamics=None):
+    """sampler.py:53-55: rows with px - u >= 0 take the proposal (HIP kernel l2hmc_mh_select)."""
+    x = as_device_f32(x)
+    Lx = as_device_f32(Lx, x.device)
+    px = as_device_f32(px, x.device)
+    N, d = x.shape
+    if u is None:
+        u = torch.rand((N,), dtype=torch.float32, device=x.device,
+                       generator=None if dynamics is None else dynamics.generator)
+    u = as_device_f32(u, x.device)
+    out = torch.empty_like(x)
+    _ffi.check(_ffi.lib().l2hmc_mh_select(x.data_ptr(), Lx.data_ptr(), px.data_ptr(), u.data_ptr(),
+                                          N, d, out.data_ptr(), _ffi.current_stream(x.device)))
+    return out
+
+
+def chain_operator(init_x, dynamics, nb_steps, aux=None, init_v=None, do_mh_step=False, *,
+                   directions=None, vs=None, u=None):
+    """sampler.py:57-85: `nb_steps` composed proposals with summed log-Jacobians, then one
+    accept probability against (init_x, init_v).  As in the reference, the momentum threaded
+    through the composition is only the returned `Lv`; every proposal draws fresh momenta.
+    `directions` / `vs`: optional per-step injected draws (lists of length nb_steps)."""
+    dynamics._check_aux(aux)
+    init_x = as_device_f32(init_x, dynamics.device)
+    if init_v is None:
+        init_v = dynamics._randn_like(init_x)
+    x, v = init_x, init_v
+    log_jac = torch.zeros(init_x.shape[0], dtype=torch.float32, device=init_x.device)
+    for k in range(int(nb_steps)):
+        x, v, lj, _ = propose(x, dynamics, init_v=v, aux=aux, log_jac=True, do_mh_step=False,
+                              direction=None if directions is None else directions[k],
+                              v=None if vs is None else vs[k])
+        log_jac = log_jac + lj
+    p_accept = dynamics.p_accept(init_x, init_v, x, v, log_jac, aux=aux)
+    outputs = []
+    if do_mh_step:
+        outputs.append(tf_accept(init_x, x, p_accept, u=u, dynamics=dynamics))
+    return x, v, p_accept, outputs

@@ -66,3 +66,53 @@ def check_x_next(x_next, x, Lx, px, u, tol):
     fin = np.all(np.isfinite(Lx), axis=1)
     assert rel_err(x_next[acc & fin], Lx[acc & fin]) <= tol
     assert np.array_equal(x_next[rej], x[rej])
+
+
+# ---- HIP side ------------------------------------------------------------------------------
+def hip_energy(g):
+    """l2hmc_amd energy function carrying exactly the golden's fp32 parameters."""
+    from l2hmc_amd import distributions as D
+    kind = str(g["energy.kind"])
+    if kind == "gaussian":
+        obj = D.Gaussian.__new__(D.Gaussian)
+        obj.mu, obj.sigma, obj.i_sigma = g["energy.mu"], None, g["energy.i_sigma"]
+        return obj.get_energy_function()
+    if kind == "gmm":
+        obj = D.GMM.__new__(D.GMM)
+        obj.mus = list(g["energy.mus"])
+        obj.i_sigmas = list(g["energy.i_sigmas"])
+        obj.constants = list(g["energy.constants"])
+        obj.nb_mixtures, obj.k = len(obj.mus), obj.mus[0].shape[0]
+        return obj.get_energy_function()
+    if kind == "roughwell":
+        return D.RoughWell(int(g["x_dim"]), float(g["energy.eta"]), bool(g["energy.easy"])).get_energy_function()
+    if kind == "funnel":
+        return D.GaussianFunnel(int(g["x_dim"])).get_energy_function()
+    raise ValueError(kind)
+
+
+def hip_dynamics(g, variant=0):
+    """l2hmc_amd.Dynamics loaded with the golden's weights, mask and step size."""
+    import torch
+    from l2hmc_amd import Dynamics, layers
+    hmc = bool(int(g["hmc"]))
+    dyn = Dynamics(int(g["x_dim"]), hip_energy(g), T=int(g["T"]), eps=float(g["eps"]), hmc=hmc,
+                   net_factory=None if hmc else layers.stq_network(int(g["H"])))
+    dyn.mask = g["mask"]
+    dyn.eps_override = float(g["eps"])
+    dyn.variant = variant
+    if not hmc:
+        with torch.no_grad():
+            for w, pre in ((dyn._xw, "xnet."), (dyn._vw, "vnet.")):
+                for k in O.NET_KEYS:
+                    w[k].copy_(torch.as_tensor(g[pre + k]).reshape(w[k].shape))
+    return dyn
+
+
+def to_dev(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()

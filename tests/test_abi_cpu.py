@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads and exports every symbol include/l2hmc.h declares; host-side
+argument validation works without a GPU (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from l2hmc_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "l2hmc.h")).read()
+    declared = set(re.findall(r"\b(l2hmc_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no prototypes found in the header"
+    lib = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export %s" % name
+    assert declared == set(_ffi.SYMBOLS), (declared ^ set(_ffi.SYMBOLS))
+
+
+def test_abi_version_and_size_queries():
+    L = _ffi.lib()
+    assert L.l2hmc_abi_version() == 1
+    assert L.l2hmc_packed_nets_floats(50, 10) == 2 * ((5 * 4 + 2) * 256 + 32 * 4)
+    assert L.l2hmc_packed_nets_floats(2, 10) == 2 * (7 * 256 + 32)
+    assert L.l2hmc_packed_gaussian_floats(50) == 16 * 256
+    assert L.l2hmc_packed_nets_floats(50, 16) == -2          # unsupported hidden width
+    assert b"H <= 15" in L.l2hmc_last_error()
+
+
+def test_argument_validation_without_gpu():
+    L = _ffi.lib()
+    a = _ffi.L2hmcTrajectoryArgs()
+    assert L.l2hmc_trajectory(None, None) == -1
+    a.n_chains, a.d, a.T = 16, 2, 10
+    assert L.l2hmc_trajectory(a, None) == -1                 # x, v, masks, trig missing
+    assert b"required" in L.l2hmc_last_error()
+    with pytest.raises(RuntimeError, match="libl2hmc_hip"):
+        _ffi.check(L.l2hmc_trajectory(a, None))
+    assert L.l2hmc_mh_select(None, None, None, None, 4, 2, None, None) == -1
+
+
+def test_struct_layout_matches_header():
+    # field order / sizes of the ctypes mirrors (x86-64: pointers 8, ints 4, natural alignment)
+    assert ctypes.sizeof(_ffi.L2hmcNet) == 16 * 8
+    assert ctypes.sizeof(_ffi.L2hmcEnergy) == 48
+    assert _ffi.L2hmcTrajectoryArgs.energy.offset == 8
+    assert _ffi.L2hmcTrajectoryArgs.n_chains.offset == 8 + 48 + 3 * 8 + 8

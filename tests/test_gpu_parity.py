@@ -1,0 +1,185 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors the reference's
+own modules produced, and against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32, stated per north_star): positions / momenta / log-det within 1e-4 of
+max(1,|ref|) after a full T-step trajectory (single steps: 3e-5); accept probability within
+1e-4 absolute.  Both sides are fp32 evaluations of the same real-valued map whose mutual
+distance is a few ulp per step amplified by the dynamics (measured: see DESIGN.md)."""
+import numpy as np
+import pytest
+
+from oracle import l2hmc_oracle as O
+from tests.helpers import (CASES, abs_err, check_x_next, hip_dynamics, load, oracle_dynamics, rel_err,
+                           to_dev, to_np)
+
+pytestmark = pytest.mark.gpu
+
+STEP_TOL, TRAJ_TOL, P_TOL = 3e-5, 1e-4, 1e-4
+
+
+def variants(g):
+    d = int(g["x_dim"])
+    return [0] if d <= 16 else [1, 4]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_energy_and_grad(case):
+    g = load(case)
+    dyn = hip_dynamics(g)
+    x = to_dev(g["x"])
+    assert rel_err(to_np(dyn.energy(x)), g["energy"]) < 2e-6
+    assert rel_err(to_np(dyn.grad_energy(x)), g["grad_energy"]) < 2e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_single_steps(case):
+    g = load(case)
+    for var in variants(g):
+        dyn = hip_dynamics(g, var)
+        x, v = to_dev(g["x"]), to_dev(g["v"])
+        for s in g["steps"]:
+            xo, vo, lj = dyn._forward_step(x, v, int(s))
+            xb, vb, ljb = dyn._backward_step(x, v, int(s))
+            for got, key in ((xo, "fstep%d.x"), (vo, "fstep%d.v"), (lj, "fstep%d.logdet"),
+                             (xb, "bstep%d.x"), (vb, "bstep%d.v"), (ljb, "bstep%d.logdet")):
+                assert rel_err(to_np(got), g[key % s]) < STEP_TOL, (case, var, key % s)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_trajectories_and_accept_prob(case):
+    g = load(case)
+    for var in variants(g):
+        dyn = hip_dynamics(g, var)
+        x, v = to_dev(g["x"]), to_dev(g["v"])
+        for nm, fn in (("fwd", dyn.forward), ("bwd", dyn.backward)):
+            X, V, lj = fn(x, init_v=v, log_jac=True)
+            X2, V2, p = fn(x, init_v=v)
+            assert np.array_equal(to_np(X), to_np(X2), equal_nan=True)
+            assert rel_err(to_np(X), g[nm + ".x"]) < TRAJ_TOL, (case, var, nm)
+            assert rel_err(to_np(V), g[nm + ".v"]) < TRAJ_TOL, (case, var, nm)
+            assert rel_err(to_np(lj), g[nm + ".logjac"]) < TRAJ_TOL, (case, var, nm)
+            p = to_np(p)
+            assert np.all(np.isfinite(p))
+            assert abs_err(p, g[nm + ".p"]) < P_TOL, (case, var, nm)
+            bad = ~np.all(np.isfinite(g[nm + ".x"]), axis=1)       # diverged chains are rejected
+            assert np.all(p[bad] == 0)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_propose_matches_reference(case):
+    """sampler.propose on the reference's recorded draws (direction, v_fwd, v_bwd, u)."""
+    from l2hmc_amd import propose
+    g = load(case)
+    for var in variants(g):
+        dyn = hip_dynamics(g, var)
+        x = to_dev(g["x"])
+        if int(g["hmc"]):
+            Lx, Lv, px, outs = propose(x, dyn, do_mh_step=True, v=to_dev(g["prop.v_fwd"]),
+                                       u=to_dev(g["prop.u"]))
+        else:
+            Lx, Lv, px, outs = propose(x, dyn, do_mh_step=True, direction=to_dev(g["prop.dir"]),
+                                       v=(to_dev(g["prop.v_fwd"]), to_dev(g["prop.v_bwd"])),
+                                       u=to_dev(g["prop.u"]))
+            assert Lv is None                       # sampler.py:40-42: no init_v -> no Lv
+        assert rel_err(to_np(Lx), g["prop.Lx"]) < TRAJ_TOL
+        assert abs_err(to_np(px), g["prop.px"]) < P_TOL
+        check_x_next(to_np(outs[0]), g["x"], g["prop.Lx"], g["prop.px"], g["prop.u"], P_TOL)
+
+
+def test_p_accept_edge_cases():
+    from l2hmc_amd import Dynamics, distributions as D
+    g = load("p_accept_edge")
+    dyn = Dynamics(2, D.Gaussian(np.zeros(2), np.eye(2)).get_energy_function(), T=2, eps=0.1, hmc=True)
+    p = to_np(dyn.p_accept(to_dev(g["x0"]), to_dev(g["v0"]), to_dev(g["x1"]), to_dev(g["v1"]),
+                           to_dev(g["logjac"])))
+    assert np.all(np.isfinite(p))
+    assert abs_err(p, g["p"]) < 1e-6
+
+
+def test_tf_accept_and_empty_batch():
+    import torch
+    from l2hmc_amd import tf_accept
+    x = torch.zeros(5, 3).cuda()
+    Lx = torch.ones(5, 3).cuda()
+    px = torch.tensor([0.1, 0.5, 0.5, 0.9, 0.0]).cuda()
+    u = torch.tensor([0.2, 0.5, 0.4, 0.1, 0.0]).cuda()
+    out = to_np(tf_accept(x, Lx, px, u=u))
+    assert np.array_equal(out[:, 0], np.array([0, 1, 1, 1, 1], dtype=np.float32))
+    g = load("scg2d")
+    dyn = hip_dynamics(g)
+    X, V, p = dyn.forward(torch.zeros(0, 2).cuda(), init_v=torch.zeros(0, 2).cuda())
+    assert X.shape == (0, 2) and p.shape == (0,)
+
+
+@pytest.mark.parametrize("case", ["scg2d", "icg50", "mog2d", "rough50_easy"])
+def test_reversibility(case):
+    """backward(forward(x, v)) returns to (x, v) and the log-Jacobians cancel (fp32:
+    the reference itself reaches ~1e-5 here)."""
+    g = load(case)
+    dyn = hip_dynamics(g)
+    x, v = to_dev(g["x"]), to_dev(g["v"])
+    X, V, lj = dyn.forward(x, init_v=v, log_jac=True)
+    x2, v2, lj2 = dyn.backward(X, init_v=V, log_jac=True)
+    ok = np.all(np.isfinite(to_np(X)), axis=1) & (np.abs(to_np(X)).max(axis=1) < 1e3)
+    assert ok.mean() > 0.9
+    assert rel_err(to_np(x2)[ok], g["x"][ok]) < 5e-4
+    assert rel_err(to_np(v2)[ok], g["v"][ok]) < 5e-4
+    assert abs_err(to_np(lj + lj2)[ok], 0 * g["x"][ok, 0]) < 5e-4
+
+
+def _big_case(case, N, seed):
+    g = dict(load(case))
+    rng = np.random.RandomState(seed)
+    d = int(g["x_dim"])
+    scale = g["x"].std(axis=0, keepdims=True)
+    g["x"] = (rng.randn(N, d) * scale).astype(np.float32)
+    g["v"] = rng.randn(N, d).astype(np.float32)
+    return g
+
+
+@pytest.mark.parametrize("case,N", [("scg2d", 200), ("icg50", 4096), ("mog2d", 65536)])
+def test_full_size_configs_against_oracle(case, N):
+    """BASELINE.json configs C1/C2/C3 at full chain counts: direction-mixed propose vs the
+    oracle on the same seeded draws, plus sharding invariance (two half-batches == one batch,
+    bit for bit: chains never interact)."""
+    import torch
+    from l2hmc_amd import propose
+    g = _big_case(case, N, 123)
+    rng = np.random.RandomState(7)
+    direction = rng.randint(0, 2, size=N).astype(np.uint8)
+    u = rng.rand(N).astype(np.float32)
+    # pin the kernel geometry so that N and N/2 chains run the very same code path
+    dyn = hip_dynamics(g, variant=4 if int(g["x_dim"]) > 16 else 0)
+    x, v = to_dev(g["x"]), to_dev(g["v"])
+    Lx, _, px, outs = propose(x, dyn, do_mh_step=True, direction=to_dev(direction), v=v, u=to_dev(u))
+    od = oracle_dynamics(g)
+    with np.errstate(all="ignore"):
+        rLx, _, rpx, _ = O.propose(g["x"], od, g["v"], g["v"], direction, u, both_directions=False)
+    fin = np.all(np.isfinite(rLx), axis=1) & (np.abs(rLx).max(axis=1) < 1e4)
+    assert fin.mean() > 0.95
+    assert rel_err(to_np(Lx)[fin], rLx[fin]) < 2 * TRAJ_TOL
+    assert abs_err(to_np(px)[fin], rpx[fin]) < P_TOL
+    h = N // 2
+    for lo, hi in ((0, h), (h, N)):
+        Lx_h, _, px_h, _ = propose(x[lo:hi].contiguous(), dyn, do_mh_step=True,
+                                   direction=to_dev(direction[lo:hi]), v=v[lo:hi].contiguous(),
+                                   u=to_dev(u[lo:hi]))
+        assert torch.equal(Lx_h, Lx[lo:hi]) and torch.equal(px_h, px[lo:hi])
+
+
+def test_hmc_limit():
+    """nets == 0: plain leapfrog, log-det exactly 0, accept ~ 1 for small eps."""
+    g = load("scg2d_hmc")
+    dyn = hip_dynamics(g)
+    X, V, lj = dyn.forward(to_dev(g["x"]), init_v=to_dev(g["v"]), log_jac=True)
+    assert np.all(to_np(lj) == 0)
+    _, _, p = dyn.forward(to_dev(g["x"]), init_v=to_dev(g["v"]))
+    assert to_np(p).mean() > 0.99
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    from l2hmc_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", "/nonexistent/libl2hmc_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        _ffi.lib()
