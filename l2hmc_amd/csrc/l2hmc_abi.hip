@@ -1,0 +1,310 @@
+// libl2hmc_hip.so -- C ABI (include/l2hmc.h) of the L2HMC leapfrog hot path for MI355X:
+// argument validation, LDS planning, geometry selection, weight packing kernels.
+// The fused kernels live in l2hmc_kernels.hpp, instantiated per energy kind in traj_ek*.hip.
+#include "l2hmc_kernels.hpp"
+
+namespace l2hmc {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a, long long b, long long c) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+  return code;
+}
+
+__global__ void pack_net_kernel(L2hmcNet net, int d, int H, int KH, int NT, float* out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ngf = net_groups(NT) * 256;
+  if (idx >= net_floats(NT)) return;
+  float val = 0.f;
+  if (idx < ngf) {
+    const int g = idx >> 8, lane = (idx >> 2) & 63, r = idx & 3;
+    const int i = lane & 15, q = lane >> 4;
+    const int ui = ((i & 3) < KH) ? (i >> 2) * KH + (i & 3) : -1;  // unit on output row i
+    const int uk = (r < KH) ? q * KH + r : -1;                     // unit on k index (q, r)
+    if (g < 2 * NT) {                                              // layer 1: embeds of a / b
+      const int tg = g < NT ? g : g - NT;
+      const float* W = g < NT ? net.W1 : net.W2;
+      const int dim = 16 * tg + 4 * q + r;
+      if (dim < d && ui >= 0 && ui < H) val = W[dim * H + ui];
+    } else if (g == 2 * NT) {                                      // time embed + biases
+      if (r == 0 && ui >= 0) {
+        if (q == 0 && ui < H) val = net.W3[ui];
+        if (q == 1 && ui < H) val = net.W3[H + ui];
+        if (q == 2) val = ui < H ? (net.b1[ui] + net.b2[ui]) + net.b3[ui] : (ui == H ? 1.f : 0.f);
+      }
+    } else if (g == 2 * NT + 1) {                                  // layer 2 (+ b4, + 1 -> 1)
+      if (uk >= 0 && ui >= 0) {
+        if (uk < H && ui < H) val = net.W4[uk * H + ui];
+        else if (uk == H && ui < H) val = net.b4[ui];
+        else if (uk == H && ui == H) val = 1.f;
+      }
+    } else {                                                       // heads S, T, Q
+      const int hg = g - (2 * NT + 2), tg = hg / 3, h = hg % 3;
+      const float* W = h == 0 ? net.Ws : (h == 1 ? net.Wt : net.Wq);
+      const float* b = h == 0 ? net.bs : (h == 1 ? net.bt : net.bq);
+      const int dim = 16 * tg + i;
+      if (dim < d && uk >= 0) {
+        if (uk < H) val = W[uk * d + dim];
+        else if (uk == H) val = b[dim];
+      }
+    }
+  } else {                                                          // exp(log-scale) of ScaleTanh
+    const int j = idx - ngf, which = j / (16 * NT), dim = j % (16 * NT);
+    const float* lam = which == 0 ? net.lam_s : net.lam_q;
+    if (dim < d) val = expf(lam[dim]);
+  }
+  out[idx] = val;
+}
+
+__global__ void pack_gauss_kernel(const float* S, int d, int NT, float* out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= gauss_floats(NT)) return;
+  const int g = idx >> 8, lane = (idx >> 2) & 63, r = idx & 3;
+  const int to = g / NT, ti = g % NT;
+  const int a = 16 * to + (lane & 15), b = 16 * ti + 4 * (lane >> 4) + r;
+  out[idx] = (a < d && b < d) ? 0.5f * (S[a * d + b] + S[b * d + a]) : 0.f;
+}
+
+__global__ void mh_select_kernel(const float* x, const float* Lx, const float* px, const float* u,
+                                 long long N, int d, float* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * d) return;
+  const long long n = i / d;
+  out[i] = (px[n] - u[n] >= 0.f) ? Lx[i] : x[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side: LDS planning and dispatch
+// ------------------------------------------------------------------------------------------
+int round4(int v) { return (v + 3) & ~3; }
+
+// Fills the LDS offsets of `k`; returns the dynamic LDS size in bytes.
+long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW) {
+  const int NT = k.NT, DP = 16 * NT;
+  long long o = 0;
+  if (with_nets) o += 2LL * net_floats(NT);
+  k.o_mask = (int)o;
+  if (with_schedule) o += (long long)k.T * DP;
+  k.o_trig = (int)o;
+  if (with_schedule) o += round4(2 * k.T);
+  k.o_P = (int)o;
+  if (NW > 1) o += 2LL * NW * 256;
+  k.xb_stride = DP + 4;
+  k.o_XB = (int)o;
+  if (NW > 1 && (k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM))
+    o += 16LL * k.xb_stride;
+  k.o_red = (int)o;
+  o += (long long)NW * 16 * 8;
+  const int nc = k.ekind == L2HMC_ENERGY_GMM ? k.ncomp : 1;
+  k.o_mu = (int)o;
+  o += (long long)nc * DP;
+  k.o_prec = (int)o;
+  if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) o += DP;
+  if (k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM)
+    o += (long long)nc * gauss_floats(NT);
+  k.o_logc = (int)o;
+  o += round4(nc);
+  return o * 4;
+}
+
+int check_energy(const L2hmcEnergy* e, int d) {
+  if (e == nullptr) return fail(L2HMC_ERR_ARG, "energy is NULL%s");
+  switch (e->kind) {
+    case L2HMC_ENERGY_GAUSS_DIAG:
+    case L2HMC_ENERGY_GAUSS_DENSE:
+      if (!e->mu || !e->prec) return fail(L2HMC_ERR_ARG, "gaussian energy needs mu and prec%s");
+      break;
+    case L2HMC_ENERGY_GMM:
+      if (!e->mu || !e->prec || !e->logc || e->n_comp < 1)
+        return fail(L2HMC_ERR_ARG, "gmm energy needs mu, prec, logc, n_comp >= 1%s");
+      break;
+    case L2HMC_ENERGY_ROUGHWELL:
+      if (!(e->eta > 0.f)) return fail(L2HMC_ERR_ARG, "roughwell needs eta > 0%s");
+      break;
+    case L2HMC_ENERGY_FUNNEL:
+      if (!(e->eta > 0.f) || d < 2) return fail(L2HMC_ERR_ARG, "funnel needs sigma > 0 and d >= 2%s");
+      break;
+    default:
+      return fail(L2HMC_ERR_ARG, "unknown energy kind %s%lld", "", e->kind);
+  }
+  if (!(e->temperature > 0.f)) return fail(L2HMC_ERR_ARG, "temperature must be > 0%s");
+  return L2HMC_OK;
+}
+
+void fill_energy(KArgs& k, const L2hmcEnergy* e) {
+  k.ekind = e->kind;
+  k.ncomp = e->kind == L2HMC_ENERGY_GMM ? e->n_comp : 1;
+  k.easy = e->easy;
+  k.mu = e->mu;
+  k.prec = e->prec;
+  k.logc = e->logc;
+  k.eta = e->eta;
+  k.temperature = e->temperature;
+}
+
+// (DT, NW) geometry for d dimensions.  NW = 4 spreads a 16-chain tile over the 4 SIMDs of
+// a CU (more parallelism per chain: right when there are few chains); NW = 1 keeps a tile
+// in one wave (no LDS exchange, fewer MFMAs: right when chains are plentiful).
+bool pick_geometry(int d, long long N, int variant, int& DT, int& NW) {
+  const int NT = tiles_of(d);
+  if (NT <= 1) { DT = 1; NW = 1; return variant == 0 || variant == 1; }
+  if (NT <= 4) {
+    const bool want4 = variant == 4 || (variant == 0 && N <= 16LL * 256 * 16);
+    if (want4) { DT = 1; NW = 4; } else { DT = NT <= 2 ? 2 : 4; NW = 1; }
+    return variant == 0 || variant == 1 || variant == 4;
+  }
+  if (variant == 1) return false;
+  NW = 4;
+  DT = NT <= 8 ? 2 : (NT <= 16 ? 4 : 8);
+  return NT <= 32;
+}
+
+int dispatch(int op, const KArgs& k, int DT, int NW, int KH, long long lds, hipStream_t s) {
+  switch (k.ekind) {
+    case L2HMC_ENERGY_GAUSS_DIAG: return launch_ek<1>(op, k, DT, NW, KH, lds, s);
+    case L2HMC_ENERGY_GAUSS_DENSE: return launch_ek<2>(op, k, DT, NW, KH, lds, s);
+    case L2HMC_ENERGY_GMM: return launch_ek<3>(op, k, DT, NW, KH, lds, s);
+    case L2HMC_ENERGY_ROUGHWELL: return launch_ek<4>(op, k, DT, NW, KH, lds, s);
+    case L2HMC_ENERGY_FUNNEL: return launch_ek<5>(op, k, DT, NW, KH, lds, s);
+  }
+  return fail(L2HMC_ERR_ARG, "unknown energy kind%s");
+}
+
+}  // namespace l2hmc
+
+using namespace l2hmc;
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int l2hmc_abi_version(void) { return L2HMC_ABI_VERSION; }
+
+const char* l2hmc_last_error(void) { return g_err; }
+
+int64_t l2hmc_packed_nets_floats(int32_t d, int32_t H) {
+  if (d < 1 || H < 1) return fail(L2HMC_ERR_ARG, "d and H must be >= 1%s");
+  if (H > 15) return fail(L2HMC_ERR_UNSUPPORTED, "fused nets support H <= 15 (got %s%lld)", "", H);
+  if (d > 512) return fail(L2HMC_ERR_UNSUPPORTED, "fused nets support d <= 512 (got %s%lld)", "", d);
+  return 2LL * net_floats(tiles_of(d));
+}
+
+int l2hmc_pack_nets(const L2hmcNet* xnet, const L2hmcNet* vnet, int32_t d, int32_t H,
+                    float* packed, void* stream) {
+  const int64_t n = l2hmc_packed_nets_floats(d, H);
+  if (n < 0) return (int)n;
+  if (!xnet || !vnet || !packed) return fail(L2HMC_ERR_ARG, "l2hmc_pack_nets: NULL argument%s");
+  const L2hmcNet* nets[2] = {xnet, vnet};
+  const int NT = tiles_of(d), NF = net_floats(NT), KH = khid_of(H);
+  for (int i = 0; i < 2; ++i) {
+    const float* const* p = reinterpret_cast<const float* const*>(nets[i]);
+    for (int j = 0; j < 16; ++j)
+      if (p[j] == nullptr) return fail(L2HMC_ERR_ARG, "l2hmc_pack_nets: NULL weight pointer%s");
+    hipLaunchKernelGGL(pack_net_kernel, dim3((NF + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       *nets[i], d, H, KH, NT, packed + (size_t)i * NF);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "pack launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int64_t l2hmc_packed_gaussian_floats(int32_t d) {
+  if (d < 1) return fail(L2HMC_ERR_ARG, "d must be >= 1%s");
+  return gauss_floats(tiles_of(d));
+}
+
+int l2hmc_pack_gaussian(const float* i_sigma, int32_t d, float* packed, void* stream) {
+  if (!i_sigma || !packed || d < 1) return fail(L2HMC_ERR_ARG, "l2hmc_pack_gaussian: bad argument%s");
+  const int NT = tiles_of(d), n = gauss_floats(NT);
+  hipLaunchKernelGGL(pack_gauss_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     i_sigma, d, NT, packed);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "pack launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
+  if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
+  if (a->n_chains < 0 || a->d < 1 || a->T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / T%s");
+  if (a->n_chains == 0) return L2HMC_OK;
+  if (!a->x || !a->v || !a->masks || !a->trig) return fail(L2HMC_ERR_ARG, "x, v, masks, trig are required%s");
+  if (a->step_begin < 0 || a->n_steps < 0 || a->step_begin + a->n_steps > a->T)
+    return fail(L2HMC_ERR_ARG, "steps [%s%lld, +%lld) outside the T-step schedule", "", a->step_begin, a->n_steps);
+  if (a->x_next && (!a->u)) return fail(L2HMC_ERR_ARG, "x_next needs u%s");
+  if (a->x_out == a->x || a->x_next == a->x) return fail(L2HMC_ERR_ARG, "x_out / x_next must not alias x%s");
+  if (!a->alpha && !(a->eps_host > 0.f)) return fail(L2HMC_ERR_ARG, "eps must be > 0%s");
+  int rc = check_energy(&a->energy, a->d);
+  if (rc) return rc;
+  int KH = 3;
+  if (a->packed_nets) {
+    if (l2hmc_packed_nets_floats(a->d, a->H) < 0) return L2HMC_ERR_UNSUPPORTED;
+    KH = khid_of(a->H);
+  }
+  int DT, NW;
+  if (!pick_geometry(a->d, a->n_chains, a->variant, DT, NW))
+    return fail(L2HMC_ERR_UNSUPPORTED, "d = %s%lld not supported with variant %lld", "", a->d, a->variant);
+  KArgs k;
+  memset(&k, 0, sizeof(k));
+  k.packed = a->packed_nets; k.masks = a->masks; k.trig = a->trig; k.alpha = a->alpha;
+  k.eps_host = a->eps_host; k.N = a->n_chains; k.d = a->d; k.H = a->H; k.T = a->T;
+  k.step_begin = a->step_begin; k.n_steps = a->n_steps; k.NT = tiles_of(a->d);
+  k.x = a->x; k.v = a->v; k.dir = a->direction; k.dir_all = a->direction_all; k.u = a->u;
+  k.x_out = a->x_out; k.v_out = a->v_out; k.logjac_out = a->logjac_out; k.p_out = a->p_out;
+  k.x_next = a->x_next;
+  fill_energy(k, &a->energy);
+  const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW);
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch(OP_TRAJ, k, DT, NW, KH, lds, s);
+}
+
+int l2hmc_energy(const L2hmcEnergy* energy, const float* x, int64_t n_chains, int32_t d,
+                 float* U_out, float* grad_out, void* stream) {
+  if (n_chains < 0 || d < 1 || !x) return fail(L2HMC_ERR_ARG, "l2hmc_energy: bad argument%s");
+  if (n_chains == 0) return L2HMC_OK;
+  int rc = check_energy(energy, d);
+  if (rc) return rc;
+  int DT, NW;
+  if (!pick_geometry(d, n_chains, 0, DT, NW)) return fail(L2HMC_ERR_UNSUPPORTED, "d = %s%lld too large", "", d);
+  KArgs k;
+  memset(&k, 0, sizeof(k));
+  k.N = n_chains; k.d = d; k.NT = tiles_of(d); k.x = x; k.U_out = U_out; k.grad_out = grad_out;
+  fill_energy(k, energy);
+  const long long lds = plan_lds(k, false, false, NW);
+  return dispatch(OP_ENERGY, k, DT, NW, 3, lds, (hipStream_t)stream);
+}
+
+int l2hmc_p_accept(const L2hmcEnergy* energy, const float* x0, const float* v0, const float* x1,
+                   const float* v1, const float* logjac, int64_t n_chains, int32_t d, float* p_out,
+                   void* stream) {
+  if (n_chains < 0 || d < 1 || !x0 || !v0 || !x1 || !v1 || !logjac || !p_out)
+    return fail(L2HMC_ERR_ARG, "l2hmc_p_accept: bad argument%s");
+  if (n_chains == 0) return L2HMC_OK;
+  int rc = check_energy(energy, d);
+  if (rc) return rc;
+  int DT, NW;
+  if (!pick_geometry(d, n_chains, 0, DT, NW)) return fail(L2HMC_ERR_UNSUPPORTED, "d = %s%lld too large", "", d);
+  KArgs k;
+  memset(&k, 0, sizeof(k));
+  k.N = n_chains; k.d = d; k.NT = tiles_of(d);
+  k.x = x0; k.v = v0; k.x1 = x1; k.v1 = v1; k.logjac_in = logjac; k.p_out = p_out;
+  fill_energy(k, energy);
+  const long long lds = plan_lds(k, false, false, NW);
+  return dispatch(OP_PACCEPT, k, DT, NW, 3, lds, (hipStream_t)stream);
+}
+
+int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const float* u,
+                    int64_t n_chains, int32_t d, float* x_next, void* stream) {
+  if (n_chains < 0 || d < 1 || !x || !Lx || !px || !u || !x_next)
+    return fail(L2HMC_ERR_ARG, "l2hmc_mh_select: bad argument%s");
+  if (n_chains == 0) return L2HMC_OK;
+  const long long n = n_chains * (long long)d;
+  hipLaunchKernelGGL(mh_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, Lx, px, u, (long long)n_chains, d, x_next);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+}  // extern "C"
