@@ -89,7 +89,7 @@ long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW) {
   k.o_trig = (int)o;
   if (with_schedule) o += round4(2 * k.T);
   k.o_P = (int)o;
-  if (NW > 1) o += 2LL * NW * 256;
+  if (NW > 1) o += 2LL * NW * 2 * 256;   // 2 buffers x NW waves x 2 partial vectors
   k.xb_stride = DP + 4;
   k.o_XB = (int)o;
   if (NW > 1 && (k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM))
@@ -175,6 +175,14 @@ int dispatch(int op, const KArgs& k, int DT, int NW, int KH, long long lds, hipS
 
 using namespace l2hmc;
 
+#ifdef L2HMC_PHASE_TIMING
+static unsigned long long* g_dbg = nullptr;
+extern "C" void l2hmc_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
+#define L2HMC_DBG_PTR g_dbg
+#else
+#define L2HMC_DBG_PTR nullptr
+#endif
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -253,6 +261,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   k.x = a->x; k.v = a->v; k.dir = a->direction; k.dir_all = a->direction_all; k.u = a->u;
   k.x_out = a->x_out; k.v_out = a->v_out; k.logjac_out = a->logjac_out; k.p_out = a->p_out;
   k.x_next = a->x_next;
+  k.dbg = L2HMC_DBG_PTR;
   fill_energy(k, &a->energy);
   const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW);
   hipStream_t s = (hipStream_t)stream;

@@ -79,7 +79,31 @@ struct KArgs {
   float *U_out, *grad_out;
   // LDS offsets (floats)
   int o_mask, o_trig, o_P, o_XB, o_red, o_mu, o_prec, o_logc, xb_stride;
+  unsigned long long* dbg;   // phase-timing buffer (profiling builds only, else NULL)
 };
+
+// Phase timers: compiled in only with -DL2HMC_PHASE_TIMING (tools/phase_timing.py).  Wave w of
+// block 0 accumulates s_memtime deltas per phase into dbg[w * 16 + phase].
+#ifdef L2HMC_PHASE_TIMING
+#define PT_DECL unsigned long long pt_t0 = __builtin_amdgcn_s_memtime(), pt_acc[12] = {0}
+#define PT_MARK(i)                                                     \
+  do {                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    const unsigned long long pt_t1 = __builtin_amdgcn_s_memtime();     \
+    pt_acc[i] += pt_t1 - pt_t0;                                        \
+    pt_t0 = pt_t1;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  } while (0)
+#define PT_FLUSH(w, lane)                                                                \
+  do {                                                                                   \
+    if (A.dbg != nullptr && blockIdx.x == 0 && (lane) == 0)                              \
+      for (int pt_i = 0; pt_i < 12; ++pt_i) A.dbg[(w) * 16 + pt_i] = pt_acc[pt_i];       \
+  } while (0)
+#else
+#define PT_DECL
+#define PT_MARK(i)
+#define PT_FLUSH(w, lane)
+#endif
 
 __device__ __forceinline__ f4 splat(float a) { return f4{a, a, a, a}; }
 // Branch-free transcendental forms for the hot loop (ocml's expf / tanhf carry range and
@@ -305,67 +329,124 @@ __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, 
   Upart = U;
 }
 
-// [S, T, Q] = net([a, b, tau]) for every tile of this wave; `apply(t, S, T, Q)` consumes one
-// 16-dimension tile at a time so the head outputs never live longer than a tile.
-template <int DT, int NW, int KH, class F>
-__device__ __forceinline__ void net_eval(const float* wn, const KArgs& A, float* smem, int w,
-                                         int lane, const f4 (&a)[DT], const f4 (&b)[DT],
-                                         float tauB, int& pb, F&& apply) {
-  const int NT = A.NT, d = A.d, q = lane >> 4;
-  f4 acc0 = splat(0.f), acc1 = splat(0.f);
+// ---- S/T/Q network, split so that layer-1 partial products can be shared -------------------
+// h1_pre = W1^T a + W2^T b + (W3^T tau + biases).  The (a, b) contractions are K-split over the
+// NW waves (`l1_part` + `xchg`); the tau/bias k-step, layer 2 and the heads are `net_tail`.
+// Sharing (DESIGN.md "layer-1 reuse"): VNet is evaluated at the same (x, grad U) at the end of
+// step t and the start of step t+1, and both XNet calls of a step see the same v_h -- those
+// partial products are computed and exchanged once.
+
+// Layer-1 partial pre-activation from one input, summed over this wave's dimension tiles.
+// grp0 = 0 selects the weights of input `a` (W1), grp0 = NT those of input `b` (W2).
+template <int DT, int NW>
+__device__ __forceinline__ f4 l1_part(const float* wn, int grp0, const KArgs& A, int w, int lane,
+                                      const f4 (&z)[DT], f4 acc) {
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
     const int tg = w * DT + t;
-    if (16 * tg < d) {
-      const f4 Wa = lds4(wn + (tg * 64 + lane) * 4);
-      const f4 Wb = lds4(wn + ((NT + tg) * 64 + lane) * 4);
+    if (16 * tg < A.d) {
+      const f4 W = lds4(wn + ((grp0 + tg) * 64 + lane) * 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {   // dead k-steps (dims >= d) multiply zeros: no guard branch
-        acc0 = MFMA16(Wa[r], a[t][r], acc0);
-        acc1 = MFMA16(Wb[r], b[t][r], acc1);
-      }
+      for (int r = 0; r < 4; ++r)     // dead k-steps (dims >= d) multiply zeros: no guard branch
+        acc = MFMA16(W[r], z[t][r], acc);
     }
   }
-  if (w == NW - 1) acc0 = MFMA16(wn[(2 * NT * 64 + lane) * 4], tauB, acc0);
-  f4 h = acc0 + acc1;
-  if (NW > 1) {  // K-split over waves: exchange partial pre-activations through LDS
-    float* P = smem + A.o_P + pb * (NW * 256);
-    *reinterpret_cast<f4*>(P + (w * 64 + lane) * 4) = h;
-    __syncthreads();
-    h = lds4(P + lane * 4);
+  return acc;
+}
+
+// Sum NP partial vectors over the NW waves of the workgroup: one LDS hop, one barrier
+// (double-buffered so the next exchange never overwrites a buffer still being read).
+template <int NW, int NP>
+__device__ __forceinline__ void xchg(f4 (&p)[NP], const KArgs& A, float* smem, int w, int lane,
+                                     int& pb) {
+  if (NW > 1) {
+    float* P = smem + A.o_P + pb * (NW * 2 * 256);
 #pragma unroll
-    for (int ww = 1; ww < NW; ++ww) h += lds4(P + (ww * 64 + lane) * 4);
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<f4*>(P + ((w * 2 + i) * 64 + lane) * 4) = p[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      f4 sum = lds4(P + (i * 64 + lane) * 4);
+#pragma unroll
+      for (int ww = 1; ww < NW; ++ww) sum += lds4(P + ((ww * 2 + i) * 64 + lane) * 4);
+      p[i] = sum;
+    }
     pb ^= 1;
   }
-  h = relu4(h);
+}
+
+// Weight fragments of the tail (tau/bias k-step, layer 2, heads, ScaleTanh scales).  Loaded
+// BEFORE the exchange barrier so their LDS latency hides under it.
+// (Head fragments are register-prefetched only for DT <= 2; wider waves read them from LDS
+// tile by tile inside net_tail to stay within the register budget.)
+template <int DT>
+struct TailW {
+  static constexpr int NH = DT <= 2 ? DT : 1;
+  float tau;
+  f4 w2;
+  f4 hs[NH], ht[NH], hq[NH], es[NH], eq[NH];
+  const float* wn;
+  int NT, w, lane;
+};
+
+template <int DT, int NW>
+__device__ __forceinline__ void load_tail(TailW<DT>& tw, const float* wn, const KArgs& A, int w,
+                                          int lane) {
+  const int NT = A.NT, q = lane >> 4;
+  tw.wn = wn; tw.NT = NT; tw.w = w; tw.lane = lane;
+  tw.tau = wn[(2 * NT * 64 + lane) * 4];
+  tw.w2 = lds4(wn + ((2 * NT + 1) * 64 + lane) * 4);
+  const float* sc = wn + net_groups(NT) * 256;
+  if constexpr (DT > 2) return;
+#pragma unroll
+  for (int t = 0; t < TailW<DT>::NH; ++t) {
+    const int tg = w * DT + t;
+    if (tg < NT) {
+      tw.hs[t] = lds4(wn + ((2 * NT + 2 + 3 * tg + 0) * 64 + lane) * 4);
+      tw.ht[t] = lds4(wn + ((2 * NT + 2 + 3 * tg + 1) * 64 + lane) * 4);
+      tw.hq[t] = lds4(wn + ((2 * NT + 2 + 3 * tg + 2) * 64 + lane) * 4);
+      tw.es[t] = lds4(sc + 16 * tg + 4 * q);
+      tw.eq[t] = lds4(sc + 16 * NT + 16 * tg + 4 * q);
+    } else {
+      tw.hs[t] = tw.ht[t] = tw.hq[t] = tw.es[t] = tw.eq[t] = splat(0.f);
+    }
+  }
+}
+
+// h1 = relu(hpre + tau/bias k-step); h2 = relu(W4^T h1); heads; `apply(t, S, T, Q)` consumes one
+// 16-dimension tile at a time so the head outputs never live longer than a tile.
+template <int DT, int KH, class F>
+__device__ __forceinline__ void net_tail(const TailW<DT>& tw, f4 hpre, float tauB, F&& apply) {
+  f4 h = relu4(MFMA16(tw.tau, tauB, hpre));
   {
-    const f4 W2 = lds4(wn + ((2 * NT + 1) * 64 + lane) * 4);
     f4 acc = splat(0.f);
 #pragma unroll
-    for (int r = 0; r < KH; ++r) acc = MFMA16(W2[r], h[r], acc);
+    for (int r = 0; r < KH; ++r) acc = MFMA16(tw.w2[r], h[r], acc);
     h = relu4(acc);
   }
-  const float* sc = wn + net_groups(NT) * 256;
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
-    const int tg = w * DT + t;
-    if (16 * tg < d) {
-      const f4 Ws = lds4(wn + ((2 * NT + 2 + 3 * tg + 0) * 64 + lane) * 4);
-      const f4 Wt = lds4(wn + ((2 * NT + 2 + 3 * tg + 1) * 64 + lane) * 4);
-      const f4 Wq = lds4(wn + ((2 * NT + 2 + 3 * tg + 2) * 64 + lane) * 4);
-      f4 zs = splat(0.f), zt = splat(0.f), zq = splat(0.f);
-#pragma unroll
-      for (int r = 0; r < KH; ++r) {
-        zs = MFMA16(Ws[r], h[r], zs);
-        zt = MFMA16(Wt[r], h[r], zt);
-        zq = MFMA16(Wq[r], h[r], zq);
-      }
-      const f4 es = lds4(sc + 16 * tg + 4 * q);
-      const f4 eq = lds4(sc + 16 * NT + 16 * tg + 4 * q);
-      apply(t, es * tanh4(zs), zt, eq * tanh4(zq));
+    f4 Ws, Wt, Wq, es, eq;
+    if constexpr (DT <= 2) {
+      Ws = tw.hs[t]; Wt = tw.ht[t]; Wq = tw.hq[t]; es = tw.es[t]; eq = tw.eq[t];
     } else {
-      apply(t, splat(0.f), splat(0.f), splat(0.f));
+      const int tg = tw.w * DT + t, NT = tw.NT, lane = tw.lane;
+      const float* sc = tw.wn + net_groups(NT) * 256;
+      const bool ok = tg < NT;
+      Ws = ok ? lds4(tw.wn + ((2 * NT + 2 + 3 * tg + 0) * 64 + lane) * 4) : splat(0.f);
+      Wt = ok ? lds4(tw.wn + ((2 * NT + 2 + 3 * tg + 1) * 64 + lane) * 4) : splat(0.f);
+      Wq = ok ? lds4(tw.wn + ((2 * NT + 2 + 3 * tg + 2) * 64 + lane) * 4) : splat(0.f);
+      es = ok ? lds4(sc + 16 * tg + 4 * (lane >> 4)) : splat(0.f);
+      eq = ok ? lds4(sc + 16 * NT + 16 * tg + 4 * (lane >> 4)) : splat(0.f);
     }
+    f4 zs = splat(0.f), zt = splat(0.f), zq = splat(0.f);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) {
+      zs = MFMA16(Ws[r], h[r], zs);
+      zq = MFMA16(Wq[r], h[r], zq);
+      zt = MFMA16(Wt[r], h[r], zt);
+    }
+    apply(t, es * tanh4(zs), zt, eq * tanh4(zq));
   }
 }
 
@@ -502,61 +583,92 @@ __global__ __launch_bounds__(64 * NW) void traj_kernel(const KArgs A) {
   float ld = 0.f;
   const f4 Z = splat(0.f);
 
+  // VNet layer-1 partial at the current (x, grad U): shared by the closing half-update of one
+  // step and the opening half-update of the next.
+  TailW<DT> tw;
+  f4 pv[1] = {Z};
+  PT_DECL;
+  PT_MARK(0);      // prologue (staging + first grad)
+  if (has_nets && A.n_steps > 0) {
+    load_tail<DT, NW>(tw, wv, A, w, lane);
+    pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z));
+    xchg<NW, 1>(pv, A, smem, w, lane, pb);
+  }
+
   for (int it = 0; it < A.n_steps; ++it) {
     const int sf = A.step_begin + it;
     const int s = fwd ? sf : (A.T - 1 - sf);
     const float ct = smem[A.o_trig + 2 * s], st = smem[A.o_trig + 2 * s + 1];
     const float tauB = q == 0 ? ct : (q == 1 ? st : (q == 2 ? 1.f : 0.f));
-
-    // ---- momentum half-update #1: VNet([x, grad U(x), t])  (dynamics.py:118-125 / :162-170)
-    f4 vh[DT];
-    if (has_nets) {
-      net_eval<DT, NW, KH>(wv, A, smem, w, lane, x, g, tauB, pb, [&](int t, f4 S, f4 T, f4 Q) {
-        vh[t] = v_half(v[t], g[t], S, T, Q, eps, heps, sgn, fwd, ld);
-      });
-    } else {
-#pragma unroll
-      for (int t = 0; t < DT; ++t) vh[t] = v_half(v[t], g[t], Z, Z, Z, eps, heps, sgn, fwd, ld);
-    }
-
-    // ---- two masked position updates: XNet([v_h, kept * x, t])  (:127-145 / :172-190)
-    f4 k1[DT], xin[DT], y[DT];
+    f4 k1[DT], xin[DT], y[DT], vh[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
       const bool ok = (w * DT + t) < NT;
       const f4 m = ok ? lds4(smem + A.o_mask + s * DP + 16 * (w * DT + t) + 4 * q) : Z;
       k1[t] = sel4(fwd, m, splat(1.f) - m);   // forward keeps m first, backward keeps 1-m first
-      xin[t] = k1[t] * x[t];
     }
+
     if (has_nets) {
-      net_eval<DT, NW, KH>(wx, A, smem, w, lane, vh, xin, tauB, pb, [&](int t, f4 S, f4 T, f4 Q) {
+      // ---- momentum half-update #1: VNet([x, grad U(x), t])  (dynamics.py:118-125 / :162-170)
+      PT_MARK(1);  // step head: tau, masks
+      net_tail<DT, KH>(tw, pv[0], tauB, [&](int t, f4 S, f4 T, f4 Q) {
+        vh[t] = v_half(v[t], g[t], S, T, Q, eps, heps, sgn, fwd, ld);
+      });
+      PT_MARK(2);  // VNet tail #1
+
+      // ---- two masked position updates: XNet([v_h, kept * x, t])  (:127-145 / :172-190);
+      //      the v_h contraction is shared by both
+      load_tail<DT, NW>(tw, wx, A, w, lane);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) xin[t] = k1[t] * x[t];
+      f4 px[2];
+      px[0] = l1_part<DT, NW>(wx, 0, A, w, lane, vh, Z);
+      px[1] = l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z);
+      PT_MARK(3);  // XNet layer-1 partials (a, b)
+      xchg<NW, 2>(px, A, smem, w, lane, pb);
+      PT_MARK(4);  // exchange
+      net_tail<DT, KH>(tw, px[0] + px[1], tauB, [&](int t, f4 S, f4 T, f4 Q) {
         y[t] = x_half(x[t], k1[t], vh[t], S, T, Q, eps, sgn, fwd, ld);
       });
+      PT_MARK(5);  // XNet tail #1
 #pragma unroll
       for (int t = 0; t < DT; ++t) xin[t] = (splat(1.f) - k1[t]) * y[t];
-      net_eval<DT, NW, KH>(wx, A, smem, w, lane, vh, xin, tauB, pb, [&](int t, f4 S, f4 T, f4 Q) {
+      f4 py[1];
+      py[0] = l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z);
+      PT_MARK(6);  // XNet layer-1 partial (b only)
+      xchg<NW, 1>(py, A, smem, w, lane, pb);
+      PT_MARK(7);  // exchange
+      net_tail<DT, KH>(tw, px[0] + py[0], tauB, [&](int t, f4 S, f4 T, f4 Q) {
         x[t] = x_half(y[t], splat(1.f) - k1[t], vh[t], S, T, Q, eps, sgn, fwd, ld);
       });
+      PT_MARK(8);  // XNet tail #2
+
+      // ---- momentum half-update #2 at the new position  (:147-153 / :192-199)
+      load_tail<DT, NW>(tw, wv, A, w, lane);
+      grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1);
+      pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z));
+      PT_MARK(9);  // grad U + VNet layer-1 partials
+      xchg<NW, 1>(pv, A, smem, w, lane, pb);
+      PT_MARK(10); // exchange
+      net_tail<DT, KH>(tw, pv[0], tauB, [&](int t, f4 S, f4 T, f4 Q) {
+        v[t] = v_half(vh[t], g[t], S, T, Q, eps, heps, sgn, fwd, ld);
+      });
+      PT_MARK(11); // VNet tail #2
     } else {
+      // HMC mode: S = T = Q = 0 (dynamics.py:73-76)
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
+        vh[t] = v_half(v[t], g[t], Z, Z, Z, eps, heps, sgn, fwd, ld);
         y[t] = x_half(x[t], k1[t], vh[t], Z, Z, Z, eps, sgn, fwd, ld);
         x[t] = x_half(y[t], splat(1.f) - k1[t], vh[t], Z, Z, Z, eps, sgn, fwd, ld);
       }
-    }
-
-    // ---- momentum half-update #2 at the new position  (:147-153 / :192-199)
-    grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1);
-    if (has_nets) {
-      net_eval<DT, NW, KH>(wv, A, smem, w, lane, x, g, tauB, pb, [&](int t, f4 S, f4 T, f4 Q) {
-        v[t] = v_half(vh[t], g[t], S, T, Q, eps, heps, sgn, fwd, ld);
-      });
-    } else {
+      grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1);
 #pragma unroll
       for (int t = 0; t < DT; ++t) v[t] = v_half(vh[t], g[t], Z, Z, Z, eps, heps, sgn, fwd, ld);
     }
   }
 
+  PT_FLUSH(w, lane);
   // ---- epilogue: proposal, log-det, accept probability, MH select ---------------------------
   store_state<DT, NW>(A.x_out, A, chain, live, w, q, x);
   store_state<DT, NW>(A.v_out, A, chain, live, w, q, v);
