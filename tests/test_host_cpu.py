@@ -1,0 +1,112 @@
+"""CPU: host-side logic that needs no GPU -- the layer kit / net recognition, distributions'
+host parameters, diagnostics vs the oracle's restatement of utils/func_utils.py."""
+import numpy as np
+import pytest
+import torch
+
+from l2hmc_amd import _ffi, distributions as D, func_utils, layers
+from oracle import l2hmc_oracle as O
+
+
+@pytest.fixture(autouse=True)
+def cpu_params():
+    layers.set_default_device("cpu")      # parameter holders only; nothing is computed here
+    yield
+
+
+def test_stq_network_is_recognised_with_reference_names():
+    net = layers.stq_network(10)(50, scope="XNet", factor=2.0)
+    w = layers.extract_stq(net, 50)
+    assert w is not None and w["H"] == 10
+    assert w["W1"].shape == (50, 10) and w["W3"].shape == (2, 10) and w["Ws"].shape == (10, 50)
+    assert w["lam_s"].shape == (1, 50)
+    names = [n for n, _ in net.parameters()]
+    assert "XNet/embed_1/W" in names and "XNet/linear_f/b" in names and "XNet/scale_s/scale" in names
+    assert len(names) == 16
+    # parameter count of SURVEY.md 2.2: 5dH + H^2 + 6H + 5d
+    assert sum(p.numel() for _, p in net.parameters()) == 5 * 50 * 10 + 100 + 60 + 250
+
+
+def test_init_follows_variance_scaling_and_heads_start_near_zero():
+    torch.manual_seed(0)
+    net = layers.stq_network(10)(50, scope="VNet", factor=1.0)
+    w = layers.extract_stq(net, 50)
+    std = float(w["W1"].std())
+    assert abs(std - np.sqrt(1.3 * (2.0 / 3) / 50) * 0.88) < 0.03      # truncated normal ~0.88 sigma
+    assert float(w["Ws"].abs().max()) < 0.1 and float(w["b1"].abs().max()) == 0.0
+
+
+def test_foreign_structures_are_rejected():
+    bad = layers.Sequential([layers.Linear(4, 4, scope="a"), layers.relu])
+    assert layers.extract_stq(bad, 4) is None
+    net = layers.stq_network(10)(4, scope="X", factor=1.0)
+    assert layers.extract_stq(net, 5) is None                          # wrong x_dim
+
+
+def test_layer_call_protocol_matches_oracle_net():
+    """Zip/Sequential/Parallel call protocol (layers.py:60-95): evaluating the holder objects
+    with torch reproduces the oracle's net_apply on the same weights."""
+    torch.manual_seed(1)
+    net = layers.stq_network(10)(6, scope="XNet", factor=2.0)
+    w = layers.extract_stq(net, 6)
+    with torch.no_grad():
+        for k in ("Ws", "Wt", "Wq"):
+            w[k].normal_(0, 0.3)
+        w["lam_s"].normal_(0, 0.2)
+    rng = np.random.RandomState(0)
+    a, b, tau = rng.randn(5, 6).astype(np.float32), rng.randn(5, 6).astype(np.float32), rng.randn(5, 2).astype(np.float32)
+    S, T, Q = net([torch.as_tensor(a), torch.as_tensor(b), torch.as_tensor(tau), None])
+    onet = {k: w[k].detach().numpy() for k in O.NET_KEYS}
+    rS, rT, rQ = O.net_apply(onet, a, b, tau)
+    assert np.allclose(S.detach().numpy(), rS, atol=1e-6) and np.allclose(T.detach().numpy(), rT, atol=1e-6)
+    assert np.allclose(Q.detach().numpy(), rQ, atol=1e-6)
+
+
+def test_gaussian_kind_selection_and_parameters():
+    var = np.exp(np.linspace(np.log(1e-2), np.log(1e2), 50))
+    e = D.Gaussian(np.zeros(50), np.diag(var)).get_energy_function()
+    assert e.kind == _ffi.ENERGY_GAUSS_DIAG and np.allclose(e._host["prec"], 1.0 / var, rtol=1e-6)
+    scg = D.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]])).get_energy_function()
+    assert scg.kind == _ffi.ENERGY_GAUSS_DENSE
+    assert np.allclose(scg._host["prec"], [[5.005, 4.995], [4.995, 5.005]], atol=1e-4)   # nb:105 / SURVEY E1
+
+
+def test_gmm_constants_match_reference_formula():
+    g = D.gen_ring(r=2.0, var=0.3, nb_mixtures=4)
+    assert g.nb_mixtures == 4 and sum(g.pis) == 1.0
+    c = 0.25 / np.sqrt((2 * np.pi) ** 2 * 0.3 ** 2)
+    assert np.allclose(g.constants, c, rtol=1e-6)
+    e = g.get_energy_function()
+    assert e.kind == _ffi.ENERGY_GMM and e.n_comp == 4 and e._host["mu"].shape == (4, 2)
+    s = g.get_samples(500, rng=np.random.RandomState(0))
+    assert s.shape == (500, 2) and abs(np.linalg.norm(s, axis=1).mean() - 2.0) < 0.3
+
+
+def test_samplers_have_the_right_moments():
+    rng = np.random.RandomState(0)
+    gs = D.Gaussian(np.array([1.0, -1.0]), np.array([[2.0, 0.5], [0.5, 1.0]]))
+    s = gs.get_samples(20000, rng=rng)
+    assert np.allclose(s.mean(0), [1, -1], atol=0.05) and np.allclose(np.cov(s.T), gs.sigma, atol=0.08)
+    f = D.GaussianFunnel(dim=3).get_samples(20000, rng=rng)
+    assert abs(f[:, 0].std() - 2.0) < 0.06
+    assert D.RoughWell(4, 0.1).get_samples(7, rng=rng).shape == (7, 4)
+
+
+def test_diagnostics_match_oracle_restatement():
+    X = np.random.RandomState(3).randn(30, 6, 2)
+    for tau in (0, 1, 7):
+        assert abs(func_utils.autocovariance(X, tau) - O.autocovariance(X, tau)) < 1e-12
+    A = func_utils.acl_spectrum(X, 1.3)
+    assert np.allclose(A, O.acl_spectrum(X, 1.3))
+    assert abs(func_utils.ESS(A) - O.ESS(A)) < 1e-12
+    x, xp = np.zeros((4, 2)), np.ones((4, 2))
+    out = func_utils.accept(x, xp, np.array([1.0, 0.0, 1.0, 0.0]), rng=np.random.RandomState(0))
+    assert np.array_equal(out[:, 0], [1, 0, 1, 0])
+
+
+def test_product_refuses_cpu_tensors_and_foreign_energies():
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        D.as_device_f32(torch.zeros(2, 2))
+    from l2hmc_amd import Dynamics
+    with pytest.raises(TypeError, match="no eager fallback"):
+        Dynamics(2, lambda x: (x * x).sum(1), T=3, eps=0.1, hmc=True, device="cpu")
