@@ -119,6 +119,18 @@ __device__ __forceinline__ float ftanh(float z) {
 }
 __device__ __forceinline__ f4 exp4(f4 a) { return f4{fexp(a.x), fexp(a.y), fexp(a.z), fexp(a.w)}; }
 __device__ __forceinline__ f4 tanh4(f4 a) { return f4{ftanh(a.x), ftanh(a.y), ftanh(a.z), ftanh(a.w)}; }
+__device__ __forceinline__ f4 exp2_4(f4 a) {
+  return f4{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y), __builtin_amdgcn_exp2f(a.z),
+            __builtin_amdgcn_exp2f(a.w)};
+}
+// c * tanh(z) with the constant folded in: c (1 - 2 / (1 + 2^(z * 2 log2 e)))
+__device__ __forceinline__ f4 ctanh4(f4 c, f4 z) {
+  const f4 t = exp2_4(z * 2.8853900817779268f);
+  const f4 u = t + 1.f;
+  const f4 r = f4{__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y), __builtin_amdgcn_rcpf(u.z),
+                  __builtin_amdgcn_rcpf(u.w)};
+  return c * (r * -2.f + 1.f);
+}
 __device__ __forceinline__ f4 relu4(f4 a) {
   return f4{fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)};
 }
@@ -413,10 +425,14 @@ __device__ __forceinline__ void load_tail(TailW<DT>& tw, const float* wn, const 
   }
 }
 
-// h1 = relu(hpre + tau/bias k-step); h2 = relu(W4^T h1); heads; `apply(t, S, T, Q)` consumes one
-// 16-dimension tile at a time so the head outputs never live longer than a tile.
+// h1 = relu(hpre + tau/bias k-step); h2 = relu(W4^T h1); heads.  The heads' nonlinearities are
+// emitted in "folded" form: with kS = (+-)eps log2(e) (eps/2 for VNet) and kQ = eps log2(e),
+//   aS = kS e^{lam_s} tanh(z_s)   (= log2 of the scale factor; sums to the log-det / ln 2)
+//   ES = 2^{aS} = exp(+-eps S),   EQ = 2^{kQ e^{lam_q} tanh(z_q)} = exp(eps Q),   T = z_t
+// `apply(t, ES, aS, T, EQ)` consumes one 16-dimension tile at a time.
 template <int DT, int KH, class F>
-__device__ __forceinline__ void net_tail(const TailW<DT>& tw, f4 hpre, float tauB, F&& apply) {
+__device__ __forceinline__ void net_tail(const TailW<DT>& tw, f4 hpre, float tauB, float kS,
+                                         float kQ, F&& apply) {
   f4 h = relu4(MFMA16(tw.tau, tauB, hpre));
   {
     f4 acc = splat(0.f);
@@ -446,33 +462,31 @@ __device__ __forceinline__ void net_tail(const TailW<DT>& tw, f4 hpre, float tau
       zq = MFMA16(Wq[r], h[r], zq);
       zt = MFMA16(Wt[r], h[r], zt);
     }
-    apply(t, es * tanh4(zs), zt, eq * tanh4(zq));
+    const f4 aS = ctanh4(es * kS, zs);
+    apply(t, exp2_4(aS), aS, zt, exp2_4(ctanh4(eq * kQ, zq)));
   }
 }
 
 // One momentum half-update.  forward (dynamics.py:121-125,149-153):
 //   v' = v e^{eps S / 2} + (eps/2)(T - e^{eps Q} grad);   backward (:164-170,194-199):
-//   v' = (v - (eps/2)(T - e^{eps Q} grad)) e^{-eps S / 2}.   `ld` accumulates log|det|.
-__device__ __forceinline__ f4 v_half(f4 vin, f4 g, f4 S, f4 T, f4 Q, float eps, float heps,
-                                     float sgn, bool fwd, float& ld) {
-  const f4 sv = (sgn * heps) * S;
-  const f4 e = exp4(sv);
-  const f4 cc = heps * (T - exp4(eps * Q) * g);
-  ld += hsum(sv);
-  return sel4(fwd, vin * e + cc, (vin - cc) * e);
+//   v' = (v - (eps/2)(T - e^{eps Q} grad)) e^{-eps S / 2}.
+// ES = e^{+-eps S / 2}, EQ = e^{eps Q}, aS = log2(ES); `ld2` accumulates log2|det|.
+__device__ __forceinline__ f4 v_half(f4 vin, f4 g, f4 ES, f4 aS, f4 T, f4 EQ, float heps, bool fwd,
+                                     float& ld2) {
+  const f4 cc = heps * (T - EQ * g);
+  ld2 += hsum(aS);
+  return sel4(fwd, vin * ES + cc, (vin - cc) * ES);
 }
 
 // One masked position update; `kp` = kept coordinates (0/1).  forward (dynamics.py:131-145):
 //   z' = kp z + (1-kp)(z e^{eps S} + eps (e^{eps Q} v_h + T));   backward (:176-190):
 //   z' = kp z + (1-kp) e^{-eps S} (z - eps (e^{eps Q} v_h + T)).
-__device__ __forceinline__ f4 x_half(f4 zin, f4 kp, f4 vh, f4 S, f4 T, f4 Q, float eps,
-                                     float sgn, bool fwd, float& ld) {
+__device__ __forceinline__ f4 x_half(f4 zin, f4 kp, f4 vh, f4 ES, f4 aS, f4 T, f4 EQ, float eps,
+                                     bool fwd, float& ld2) {
   const f4 up = splat(1.f) - kp;
-  const f4 sx = (sgn * eps) * S;
-  const f4 e = exp4(sx);
-  const f4 tr = eps * (exp4(eps * Q) * vh + T);
-  const f4 nw = sel4(fwd, zin * e + tr, e * (zin - tr));
-  ld += hsum(up * sx);
+  const f4 tr = eps * (EQ * vh + T);
+  const f4 nw = sel4(fwd, zin * ES + tr, ES * (zin - tr));
+  ld2 += hsum(up * aS);
   return kp * zin + up * nw;
 }
 
@@ -595,24 +609,46 @@ __global__ __launch_bounds__(64 * NW) void traj_kernel(const KArgs A) {
     xchg<NW, 1>(pv, A, smem, w, lane, pb);
   }
 
-  for (int it = 0; it < A.n_steps; ++it) {
-    const int sf = A.step_begin + it;
-    const int s = fwd ? sf : (A.T - 1 - sf);
+  // folded constants: sgn eps log2(e) scales S of XNet, sgn (eps/2) log2(e) S of VNet, eps log2(e) Q
+  const float LOG2E = 1.4426950408889634f;
+  const float kSx = sgn * eps * LOG2E, kSv = sgn * heps * LOG2E, kQ = eps * LOG2E;
+  const f4 O = splat(1.f);
+
+  // schedule row of this chain at iteration `it`: forward chains walk 0..T-1, backward T-1..0
+  auto row_of = [&](int it) { const int sf = A.step_begin + it; return fwd ? sf : (A.T - 1 - sf); };
+  // tau operand (k = q: [cos, sin, 1, 0]) and the first-kept mask of that row; both are
+  // PREFETCHED one step ahead so their LDS latency never sits on the critical path
+  auto tau_of = [&](int s) {
     const float ct = smem[A.o_trig + 2 * s], st = smem[A.o_trig + 2 * s + 1];
-    const float tauB = q == 0 ? ct : (q == 1 ? st : (q == 2 ? 1.f : 0.f));
-    f4 k1[DT], xin[DT], y[DT], vh[DT];
+    return q == 0 ? ct : (q == 1 ? st : (q == 2 ? 1.f : 0.f));
+  };
+  auto mask_of = [&](int s, f4 (&k)[DT]) {
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
       const bool ok = (w * DT + t) < NT;
       const f4 m = ok ? lds4(smem + A.o_mask + s * DP + 16 * (w * DT + t) + 4 * q) : Z;
-      k1[t] = sel4(fwd, m, splat(1.f) - m);   // forward keeps m first, backward keeps 1-m first
+      k[t] = sel4(fwd, m, O - m);             // forward keeps m first, backward keeps 1-m first
+    }
+  };
+  f4 k1[DT], k1n[DT];
+  float tauB = 0.f, tauN = 0.f;
+  if (A.n_steps > 0) {
+    tauB = tau_of(row_of(0));
+    mask_of(row_of(0), k1);
+  }
+
+  for (int it = 0; it < A.n_steps; ++it) {
+    f4 xin[DT], y[DT], vh[DT];
+    if (it + 1 < A.n_steps) {                 // prefetch the next step's schedule row
+      tauN = tau_of(row_of(it + 1));
+      mask_of(row_of(it + 1), k1n);
     }
 
     if (has_nets) {
+      PT_MARK(1);  // step head
       // ---- momentum half-update #1: VNet([x, grad U(x), t])  (dynamics.py:118-125 / :162-170)
-      PT_MARK(1);  // step head: tau, masks
-      net_tail<DT, KH>(tw, pv[0], tauB, [&](int t, f4 S, f4 T, f4 Q) {
-        vh[t] = v_half(v[t], g[t], S, T, Q, eps, heps, sgn, fwd, ld);
+      net_tail<DT, KH>(tw, pv[0], tauB, kSv, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+        vh[t] = v_half(v[t], g[t], ES, aS, T, EQ, heps, fwd, ld);
       });
       PT_MARK(2);  // VNet tail #1
 
@@ -627,46 +663,51 @@ __global__ __launch_bounds__(64 * NW) void traj_kernel(const KArgs A) {
       PT_MARK(3);  // XNet layer-1 partials (a, b)
       xchg<NW, 2>(px, A, smem, w, lane, pb);
       PT_MARK(4);  // exchange
-      net_tail<DT, KH>(tw, px[0] + px[1], tauB, [&](int t, f4 S, f4 T, f4 Q) {
-        y[t] = x_half(x[t], k1[t], vh[t], S, T, Q, eps, sgn, fwd, ld);
+      net_tail<DT, KH>(tw, px[0] + px[1], tauB, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+        y[t] = x_half(x[t], k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ld);
       });
       PT_MARK(5);  // XNet tail #1
 #pragma unroll
-      for (int t = 0; t < DT; ++t) xin[t] = (splat(1.f) - k1[t]) * y[t];
+      for (int t = 0; t < DT; ++t) xin[t] = (O - k1[t]) * y[t];
       f4 py[1];
       py[0] = l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z);
       PT_MARK(6);  // XNet layer-1 partial (b only)
       xchg<NW, 1>(py, A, smem, w, lane, pb);
       PT_MARK(7);  // exchange
-      net_tail<DT, KH>(tw, px[0] + py[0], tauB, [&](int t, f4 S, f4 T, f4 Q) {
-        x[t] = x_half(y[t], splat(1.f) - k1[t], vh[t], S, T, Q, eps, sgn, fwd, ld);
+      net_tail<DT, KH>(tw, px[0] + py[0], tauB, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+        x[t] = x_half(y[t], O - k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ld);
       });
       PT_MARK(8);  // XNet tail #2
 
-      // ---- momentum half-update #2 at the new position  (:147-153 / :192-199)
+      // ---- momentum half-update #2 at the new position  (:147-153 / :192-199); its layer-1
+      //      partial is reused by half-update #1 of the next step
       load_tail<DT, NW>(tw, wv, A, w, lane);
       grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1);
       pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z));
       PT_MARK(9);  // grad U + VNet layer-1 partials
       xchg<NW, 1>(pv, A, smem, w, lane, pb);
       PT_MARK(10); // exchange
-      net_tail<DT, KH>(tw, pv[0], tauB, [&](int t, f4 S, f4 T, f4 Q) {
-        v[t] = v_half(vh[t], g[t], S, T, Q, eps, heps, sgn, fwd, ld);
+      net_tail<DT, KH>(tw, pv[0], tauB, kSv, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+        v[t] = v_half(vh[t], g[t], ES, aS, T, EQ, heps, fwd, ld);
       });
       PT_MARK(11); // VNet tail #2
     } else {
       // HMC mode: S = T = Q = 0 (dynamics.py:73-76)
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        vh[t] = v_half(v[t], g[t], Z, Z, Z, eps, heps, sgn, fwd, ld);
-        y[t] = x_half(x[t], k1[t], vh[t], Z, Z, Z, eps, sgn, fwd, ld);
-        x[t] = x_half(y[t], splat(1.f) - k1[t], vh[t], Z, Z, Z, eps, sgn, fwd, ld);
+        vh[t] = v_half(v[t], g[t], O, Z, Z, O, heps, fwd, ld);
+        y[t] = x_half(x[t], k1[t], vh[t], O, Z, Z, O, eps, fwd, ld);
+        x[t] = x_half(y[t], O - k1[t], vh[t], O, Z, Z, O, eps, fwd, ld);
       }
       grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1);
 #pragma unroll
-      for (int t = 0; t < DT; ++t) v[t] = v_half(vh[t], g[t], Z, Z, Z, eps, heps, sgn, fwd, ld);
+      for (int t = 0; t < DT; ++t) v[t] = v_half(vh[t], g[t], O, Z, Z, O, heps, fwd, ld);
     }
+    tauB = tauN;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) k1[t] = k1n[t];
   }
+  ld *= 0.6931471805599453f;   // the log-det was accumulated in log2 units
 
   PT_FLUSH(w, lane);
   // ---- epilogue: proposal, log-det, accept probability, MH select ---------------------------
