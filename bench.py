@@ -223,6 +223,12 @@ def main():
                          "launch_us": launch_s * 1e6,
                          "hbm_frac": algorithmic_bytes_per_chain_step(D, T) * n * T / launch_s / 1e9 / PEAK_HBM_GBS},
         }
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):          # HBM bytes per launch from the committed PMC passes
+            t = json.load(open(tj))
+            if t.get("workload_chains") == n:
+                out["roofline"]["traffic"] = 1024.0 * (t["fetch_kb"] + t["write_kb"])
+                out["roofline"]["traffic_source"] = t["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob)
         print(json.dumps(out))
