@@ -4,7 +4,10 @@
 Workload (BASELINE.json configs[1]): ill-conditioned Gaussian d=50, 4 096 chains PER GPU,
 Lf (T) = 10, S/T/Q nets with H=10.  One "step" = one `propose` (sampler.py:28-55): T
 generalised leapfrog steps on every chain in its drawn direction + accept probability + MH
-select -- one launch of the fused kernel; the chain state carries over from step to step.
+select; the chain state carries over from step to step.  Steps are issued through the
+persistent sampler kernel, `--proposals-per-launch` (default 25) chained proposals per launch
+(the notebook's per-step sess.run loop, raw 288-298, without the host round trip);
+`--proposals-per-launch 1` gives one launch per step.
 Synthetic inputs (seeded weights, masks, start points and the per-step random draws
 v / direction / u) are resident in HBM before the timed region.
 
@@ -110,7 +113,11 @@ def main():
     ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bank", type=int, default=16, help="distinct pre-generated random draws (cycled)")
+    ap.add_argument("--bank", type=int, default=0,
+                    help="distinct pre-generated random draws, cycled (0 = 2 x proposals-per-launch, min 16)")
+    ap.add_argument("--proposals-per-launch", type=int, default=25,
+                    help="MH proposals chained inside one launch of the persistent sampler kernel "
+                         "(1 = one launch per step); a shorter last launch covers any remainder")
     args = ap.parse_args()
 
     import torch
@@ -145,12 +152,12 @@ def main():
     xa = (torch.randn(n, D, device=dev, generator=gen) *
           torch.as_tensor(np.sqrt(prob["var"]), dtype=torch.float32, device=dev)).contiguous()
     xb = torch.empty_like(xa)
-    B = args.bank
+    M = max(1, args.proposals_per_launch)
+    B = args.bank if args.bank > 0 else max(16, 2 * M)
+    B = (B + M - 1) // M * M
     v_bank = torch.randn(B, n, D, device=dev, generator=gen)
     d_bank = torch.randint(0, 2, (B, n), device=dev, dtype=torch.uint8, generator=gen)
     u_bank = torch.rand(B, n, device=dev, generator=gen)
-    p_out = torch.empty(n, device=dev)
-    lx_out = torch.empty_like(xa)
 
     L = _ffi.lib()
     a = _ffi.L2hmcTrajectoryArgs()
@@ -159,14 +166,23 @@ def main():
     a.masks, a.trig = dyn._mask.data_ptr(), dyn._trig.data_ptr()
     a.alpha, a.eps_host = dyn.alpha.data_ptr(), 0.0
     a.n_chains, a.d, a.H, a.T, a.step_begin, a.n_steps = n, D, H, T, 0, T
-    a.x_out, a.p_out, a.variant = lx_out.data_ptr(), p_out.data_ptr(), args.variant
+    a.variant, a.n_proposals = args.variant, M
+    p_out = torch.empty((M, n), device=dev)
+    a.p_out = p_out.data_ptr()
     stream = torch.cuda.current_stream(dev).cuda_stream
     bufs = [xa, xb]
     acc_sum = torch.zeros((), device=dev)
 
-    def step(k):
-        src, dst = bufs[k & 1], bufs[(k + 1) & 1]
-        b = k % B
+    state = {"flip": 0}
+
+    def launch(first, count):
+        """proposals [first, first + count): one launch of the persistent sampler kernel"""
+        src, dst = bufs[state["flip"]], bufs[state["flip"] ^ 1]
+        state["flip"] ^= 1
+        b = first % B
+        if b + count > B:
+            b = 0
+        a.n_proposals = count
         a.x, a.x_next = src.data_ptr(), dst.data_ptr()
         a.v = v_bank[b].data_ptr()
         a.direction = d_bank[b].data_ptr()
@@ -181,20 +197,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        step(k)
+    def plan(first, total):
+        return [(first + i, min(M, total - i)) for i in range(0, total, M)]
+
+    for f, c in plan(0, args.warmup):
+        launch(f, c)
+    timed = plan(args.warmup, args.steps)
+    nl = len(timed)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for k in range(args.warmup, args.warmup + args.steps):
-        step(k)
+    for f, c in timed:
+        launch(f, c)
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
     mean_p = float(p_out.mean())
-    finite = bool(torch.isfinite(bufs[(args.warmup + args.steps) & 1]).all())
+    finite = bool(torch.isfinite(bufs[state["flip"]]).all())
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -203,8 +224,9 @@ def main():
     if rank == 0:
         steps_total = float(n) * world * T * args.steps
         flops_cs = algorithmic_flops_per_chain_step(D, H, T, 3 * D)      # diagonal precision: 3d
-        per_launch_flops = flops_cs * n * T
-        launch_s = gpu_ms * 1e-3 / args.steps                            # HIP events on the launch stream
+        m_avg = args.steps / float(nl)                                   # proposals per launch (mean)
+        per_launch_flops = flops_cs * n * T * m_avg
+        launch_s = gpu_ms * 1e-3 / nl                                    # HIP events on the launch stream
         ach = per_launch_flops / launch_s / 1e12
         out = {
             "metric": "chain_leapfrog_steps_per_sec", "value": steps_total / elapsed,
@@ -215,18 +237,19 @@ def main():
             "config": {"workload": "ICG-50D (ill-conditioned Gaussian d=50), %d chains per GPU, Lf=10, "
                                    "S/T/Q nets H=10, direction-mixed propose + MH per step" % n,
                        "chains_per_gpu": n, "x_dim": D, "hidden": H, "leapfrog_steps": T,
+                       "proposals_per_launch": M,
                        "parallelism": "chains sharded, no data-path collective",
                        "mean_accept_prob": mean_p, "state_finite": finite},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "kernel": "traj_kernel", "flops_per_chain_step": flops_cs,
                          "launch_us": launch_s * 1e6,
-                         "hbm_frac": algorithmic_bytes_per_chain_step(D, T) * n * T / launch_s / 1e9 / PEAK_HBM_GBS},
+                         "hbm_frac": algorithmic_bytes_per_chain_step(D, T) * n * T * m_avg / launch_s / 1e9 / PEAK_HBM_GBS},
         }
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):          # HBM bytes per launch from the committed PMC passes
             t = json.load(open(tj))
-            if t.get("workload_chains") == n:
+            if t.get("workload_chains") == n and t.get("proposals_per_launch", 1) == M:
                 out["roofline"]["traffic"] = 1024.0 * (t["fetch_kb"] + t["write_kb"])
                 out["roofline"]["traffic_source"] = t["source"]
         if world == 1 and not args.no_cpu_baseline:

@@ -102,6 +102,12 @@ typedef struct L2hmcTrajectoryArgs {
   float* x_next;            /* (N, d) MH-selected state, sampler.py:53-55 (needs u and p)     */
   /* ---- tuning ---------------------------------------------------------------------------- */
   int32_t variant;          /* 0 = auto; else waves per 16-chain tile (1 or 4)                */
+  /* ---- persistent sampler loop (the notebook's per-MH-step sess.run loop, nb raw 288-298) -- */
+  int32_t n_proposals;      /* M >= 1 proposals per launch (0 = 1).  With M > 1: v is (M,N,d),  */
+                            /* direction (M,N), u (M,N) [required], p_out / logjac_out (M,N);   */
+                            /* each proposal starts from the previous MH-selected state;        */
+                            /* x_out / v_out hold the LAST proposal, x_next the final state     */
+  float* x_hist;            /* (M, N, d) MH-selected state after every proposal, or NULL        */
 } L2hmcTrajectoryArgs;
 
 int l2hmc_abi_version(void);

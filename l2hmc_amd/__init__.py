@@ -6,7 +6,7 @@ hand-written HIP kernels of `csrc/` behind the C ABI of `include/l2hmc.h`.
 """
 from . import _ffi, distributions, func_utils, layers  # noqa: F401
 from .dynamics import Dynamics  # noqa: F401
-from .sampler import chain_operator, propose, tf_accept  # noqa: F401
+from .sampler import chain_operator, propose, sample_chain, tf_accept  # noqa: F401
 
-__all__ = ["Dynamics", "propose", "tf_accept", "chain_operator", "layers", "distributions",
+__all__ = ["Dynamics", "propose", "tf_accept", "chain_operator", "sample_chain", "layers", "distributions",
            "func_utils"]

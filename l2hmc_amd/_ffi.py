@@ -36,7 +36,7 @@ class L2hmcTrajectoryArgs(C.Structure):
                 ("x", _fp), ("v", _fp), ("direction", _fp), ("direction_all", C.c_int32),
                 ("u", _fp),
                 ("x_out", _fp), ("v_out", _fp), ("logjac_out", _fp), ("p_out", _fp),
-                ("x_next", _fp), ("variant", C.c_int32)]
+                ("x_next", _fp), ("variant", C.c_int32), ("n_proposals", C.c_int32), ("x_hist", _fp)]
 
 
 # every symbol include/l2hmc.h declares: name -> (restype, argtypes)

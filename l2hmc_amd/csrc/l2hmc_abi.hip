@@ -241,6 +241,9 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   if (a->step_begin < 0 || a->n_steps < 0 || a->step_begin + a->n_steps > a->T)
     return fail(L2HMC_ERR_ARG, "steps [%s%lld, +%lld) outside the T-step schedule", "", a->step_begin, a->n_steps);
   if (a->x_next && (!a->u)) return fail(L2HMC_ERR_ARG, "x_next needs u%s");
+  if (a->n_proposals > 1 && !a->u) return fail(L2HMC_ERR_ARG, "n_proposals > 1 needs u (the MH step links the proposals)%s");
+  if (a->n_proposals < 0) return fail(L2HMC_ERR_ARG, "n_proposals must be >= 0%s");
+  if (a->x_hist == a->x && a->x) return fail(L2HMC_ERR_ARG, "x_hist must not alias x%s");
   if (a->x_out == a->x || a->x_next == a->x) return fail(L2HMC_ERR_ARG, "x_out / x_next must not alias x%s");
   if (!a->alpha && !(a->eps_host > 0.f)) return fail(L2HMC_ERR_ARG, "eps must be > 0%s");
   int rc = check_energy(&a->energy, a->d);
@@ -261,6 +264,8 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   k.x = a->x; k.v = a->v; k.dir = a->direction; k.dir_all = a->direction_all; k.u = a->u;
   k.x_out = a->x_out; k.v_out = a->v_out; k.logjac_out = a->logjac_out; k.p_out = a->p_out;
   k.x_next = a->x_next;
+  k.x_hist = a->x_hist;
+  k.M = a->n_proposals > 1 ? a->n_proposals : 1;
   k.dbg = L2HMC_DBG_PTR;
   fill_energy(k, &a->energy);
   const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW);

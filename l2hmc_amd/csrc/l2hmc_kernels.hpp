@@ -69,7 +69,8 @@ struct KArgs {
   const unsigned char* dir;
   int dir_all;
   const float* u;
-  float *x_out, *v_out, *logjac_out, *p_out, *x_next;
+  float *x_out, *v_out, *logjac_out, *p_out, *x_next, *x_hist;
+  int M;                     // proposals per launch (persistent sampler loop)
   // energy
   int ekind, ncomp, easy;
   const float *mu, *prec, *logc;
@@ -120,6 +121,9 @@ __device__ __forceinline__ float ftanh(float z) {
 __device__ __forceinline__ f4 exp4(f4 a) { return f4{fexp(a.x), fexp(a.y), fexp(a.z), fexp(a.w)}; }
 __device__ __forceinline__ f4 tanh4(f4 a) { return f4{ftanh(a.x), ftanh(a.y), ftanh(a.z), ftanh(a.w)}; }
 __device__ __forceinline__ f4 exp2_4(f4 a) {
+#ifdef L2HMC_ABL_NOTRANS
+  return a + 1.f;
+#endif
   return f4{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y), __builtin_amdgcn_exp2f(a.z),
             __builtin_amdgcn_exp2f(a.w)};
 }
@@ -127,6 +131,9 @@ __device__ __forceinline__ f4 exp2_4(f4 a) {
 __device__ __forceinline__ f4 ctanh4(f4 c, f4 z) {
   const f4 t = exp2_4(z * 2.8853900817779268f);
   const f4 u = t + 1.f;
+#ifdef L2HMC_ABL_NOTRANS
+  return c * (u * -2.f + 1.f);
+#endif
   const f4 r = f4{__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y), __builtin_amdgcn_rcpf(u.z),
                   __builtin_amdgcn_rcpf(u.w)};
   return c * (r * -2.f + 1.f);
@@ -371,6 +378,9 @@ __device__ __forceinline__ f4 l1_part(const float* wn, int grp0, const KArgs& A,
 template <int NW, int NP>
 __device__ __forceinline__ void xchg(f4 (&p)[NP], const KArgs& A, float* smem, int w, int lane,
                                      int& pb) {
+#ifdef L2HMC_ABL_NOXCHG
+  return;
+#endif
   if (NW > 1) {
     float* P = smem + A.o_P + pb * (NW * 2 * 256);
 #pragma unroll
@@ -456,12 +466,16 @@ __device__ __forceinline__ void net_tail(const TailW<DT>& tw, f4 hpre, float tau
       eq = ok ? lds4(sc + 16 * NT + 16 * tg + 4 * (lane >> 4)) : splat(0.f);
     }
     f4 zs = splat(0.f), zt = splat(0.f), zq = splat(0.f);
+#ifdef L2HMC_ABL_NOHEADS
+    zs = h * Ws; zq = h * Wq; zt = h * Wt;
+#else
 #pragma unroll
     for (int r = 0; r < KH; ++r) {
       zs = MFMA16(Ws[r], h[r], zs);
       zq = MFMA16(Wq[r], h[r], zq);
       zt = MFMA16(Wt[r], h[r], zt);
     }
+#endif
     const f4 aS = ctanh4(es * kS, zs);
     apply(t, exp2_4(aS), aS, zt, exp2_4(ctanh4(eq * kQ, zq)));
   }
@@ -551,7 +565,9 @@ __device__ __forceinline__ void stage_energy(const KArgs& A, float* smem, int ti
 // The fused trajectory kernel
 // ------------------------------------------------------------------------------------------
 template <int EK, int DT, int NW, int KH>
-__global__ __launch_bounds__(64 * NW) void traj_kernel(const KArgs A) {
+// (waves-per-SIMD hint 2 for DT <= 2 caps the kernel at 256 VGPRs, which makes the compiler keep
+// MFMA accumulators in VGPRs -- no v_accvgpr_read traffic; wide-DT kernels keep all 512.)
+__global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const KArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * NW;
   const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
@@ -577,28 +593,20 @@ __global__ __launch_bounds__(64 * NW) void traj_kernel(const KArgs A) {
 
   f4 x[DT], v[DT], g[DT];
   load_state<DT, NW>(A.x, A, chain, live, w, q, x);
-  load_state<DT, NW>(A.v, A, chain, live, w, q, v);
-  const bool fwd = A.dir != nullptr ? (live ? A.dir[chain] != 0 : true) : (A.dir_all != 0);
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
-  const float sgn = fwd ? 1.f : -1.f;
-  const bool need_p = A.p_out != nullptr || A.x_next != nullptr;
+  const bool need_p = A.p_out != nullptr || A.x_next != nullptr || A.u != nullptr;
   __syncthreads();
 
   const float* wx = smem;        // XNet fragments
   const float* wv = smem + NF;   // VNet fragments
   int pb = 0;
-  float red[5];                  // U0, K0, U1, K1, logdet (per-lane partial sums)
-  red[1] = 0.f;
-#pragma unroll
-  for (int t = 0; t < DT; ++t) red[1] += 0.5f * hsum(v[t] * v[t]);
-  grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[0], need_p);
-  red[2] = 0.f;
-  float ld = 0.f;
   const f4 Z = splat(0.f);
+  float U_start;                 // this lane's share of U at the current state
+  grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, U_start, need_p);
 
   // VNet layer-1 partial at the current (x, grad U): shared by the closing half-update of one
-  // step and the opening half-update of the next.
+  // step and the opening half-update of the next, and kept across proposals.
   TailW<DT> tw;
   f4 pv[1] = {Z};
   PT_DECL;
@@ -608,6 +616,38 @@ __global__ __launch_bounds__(64 * NW) void traj_kernel(const KArgs A) {
     pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z));
     xchg<NW, 1>(pv, A, smem, w, lane, pb);
   }
+
+  // ---- persistent sampler loop: M proposals per launch (M = 1: a single trajectory) ---------
+  // the next proposal's draws (momenta, direction bit, accept uniform) are fetched one proposal
+  // ahead so their HBM latency hides under the current trajectory
+  f4 vn[DT];
+  load_state<DT, NW>(A.v, A, chain, live, w, q, vn);
+  bool fwd_n = A.dir != nullptr ? (live ? A.dir[chain] != 0 : true) : (A.dir_all != 0);
+  float u_n = (A.u != nullptr && live) ? A.u[chain] : 0.f;
+  for (int m = 0; m < A.M; ++m) {
+  const long long moff = (long long)m * A.N;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) v[t] = vn[t];
+  const bool fwd = fwd_n;
+  const float u_m = u_n;
+  if (m + 1 < A.M) {
+    load_state<DT, NW>(A.v + (moff + A.N) * A.d, A, chain, live, w, q, vn);
+    if (A.dir != nullptr && live) fwd_n = A.dir[moff + A.N + chain] != 0;
+    if (A.u != nullptr && live) u_n = A.u[moff + A.N + chain];
+  }
+  const float sgn = fwd ? 1.f : -1.f;
+  // the start point: a rejected chain resumes from it (sampler.py:53-55)
+  f4 x0[DT], g0[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) { x0[t] = x[t]; g0[t] = g[t]; }
+  const f4 pv0 = pv[0];
+  float red[5];                  // U0, K0, U1, K1, logdet (per-lane partial sums)
+  red[0] = U_start;
+  red[1] = 0.f;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) red[1] += 0.5f * hsum(v[t] * v[t]);
+  red[2] = 0.f;
+  float ld = 0.f;
 
   // folded constants: sgn eps log2(e) scales S of XNet, sgn (eps/2) log2(e) S of VNet, eps log2(e) Q
   const float LOG2E = 1.4426950408889634f;
@@ -709,30 +749,47 @@ __global__ __launch_bounds__(64 * NW) void traj_kernel(const KArgs A) {
   }
   ld *= 0.6931471805599453f;   // the log-det was accumulated in log2 units
 
-  PT_FLUSH(w, lane);
-  // ---- epilogue: proposal, log-det, accept probability, MH select ---------------------------
-  store_state<DT, NW>(A.x_out, A, chain, live, w, q, x);
-  store_state<DT, NW>(A.v_out, A, chain, live, w, q, v);
+  // ---- per-proposal epilogue: proposal, log-det, accept probability, MH select ---------------
+  const bool last = m == A.M - 1;
+  if (last) {
+    store_state<DT, NW>(A.x_out, A, chain, live, w, q, x);
+    store_state<DT, NW>(A.v_out, A, chain, live, w, q, v);
+  }
   if (A.n_steps == 0) red[2] = red[0];
   red[3] = 0.f;
 #pragma unroll
   for (int t = 0; t < DT; ++t) red[3] += 0.5f * hsum(v[t] * v[t]);
   red[4] = ld;
+  const float U_end = red[2];
   chain_allreduce<NW, 5>(red, smem + A.o_red, w, lane);
   const bool writer = live && w == 0 && lane < 16;
-  if (A.logjac_out != nullptr && writer) A.logjac_out[chain] = red[4];
+  if (A.logjac_out != nullptr && writer) A.logjac_out[moff + chain] = red[4];
   if (need_p) {
     // dynamics.py:302-309
     const float e_new = red[2] + red[3], e_old = red[0] + red[1];
     const float val = e_old - e_new + red[4];
     const float p = accept_prob(val);
-    if (A.p_out != nullptr && writer) A.p_out[chain] = p;
-    if (A.x_next != nullptr && live) {
-      const bool acc = (p - A.u[chain]) >= 0.f;      // sampler.py:53-55
-      if (!acc) load_state<DT, NW>(A.x, A, chain, live, w, q, x);
-      store_state<DT, NW>(A.x_next, A, chain, live, w, q, x);
+    if (A.p_out != nullptr && writer) A.p_out[moff + chain] = p;
+    if (A.u != nullptr) {
+      const bool acc = live && (p - u_m) >= 0.f;                      // sampler.py:53-55
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        x[t] = sel4(acc, x[t], x0[t]);
+        g[t] = sel4(acc, g[t], g0[t]);
+      }
+      pv[0] = sel4(acc, pv[0], pv0);
+      U_start = acc ? U_end : U_start;
+    } else {
+      U_start = U_end;
     }
+  } else {
+    U_start = U_end;
   }
+  if (A.x_hist != nullptr) store_state<DT, NW>(A.x_hist + moff * A.d, A, chain, live, w, q, x);
+  }  // proposals
+
+  PT_FLUSH(w, lane);
+  store_state<DT, NW>(A.x_next, A, chain, live, w, q, x);
 }
 
 // energy / grad only  (Dynamics.energy, Dynamics.grad_energy)

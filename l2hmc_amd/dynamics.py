@@ -188,14 +188,18 @@ class Dynamics(object):
         return torch.randn(x.shape, dtype=torch.float32, device=x.device, generator=self.generator)
 
     def run(self, x, v, step_begin, n_steps, direction=None, direction_all=1, u=None,
-            want=('x', 'v', 'logjac')):
+            want=('x', 'v', 'logjac'), n_proposals=1):
         """Launch `l2hmc_trajectory` (include/l2hmc.h).  Returns a dict of the requested
-        outputs among x, v, logjac, p, x_next."""
+        outputs among x, v, logjac, p, x_next, x_hist.  With n_proposals = M > 1 the kernel
+        runs M chained proposals (persistent sampler loop): v is (M, N, d), direction and u
+        are (M, N), p / logjac come back as (M, N), x_hist as (M, N, d)."""
+        M = int(n_proposals)
         x = as_device_f32(x, self.device)
         v = as_device_f32(v, self.device)
         N, d = x.shape
-        if d != self.x_dim or v.shape != x.shape:
-            raise ValueError("x, v must be (N, %d)" % self.x_dim)
+        lead = (M,) if M > 1 else ()
+        if d != self.x_dim or tuple(v.shape) != lead + (N, d):
+            raise ValueError("x must be (N, %d) and v %s" % (self.x_dim, lead + (N, d)))
         out = {}
         if 'x' in want:
             out['x'] = torch.empty_like(x)
@@ -203,18 +207,20 @@ class Dynamics(object):
             out['v'] = torch.empty_like(x)
         for k in ('logjac', 'p'):
             if k in want:
-                out[k] = torch.empty(N, dtype=torch.float32, device=x.device)
+                out[k] = torch.empty(lead + (N,), dtype=torch.float32, device=x.device)
         if 'x_next' in want:
             out['x_next'] = torch.empty_like(x)
-            out.setdefault('p', torch.empty(N, dtype=torch.float32, device=x.device))
+            out.setdefault('p', torch.empty(lead + (N,), dtype=torch.float32, device=x.device))
+        if 'x_hist' in want:
+            out['x_hist'] = torch.empty((M, N, d), dtype=torch.float32, device=x.device)
         if direction is not None:
             direction = direction.to(device=x.device, dtype=torch.uint8).contiguous()
-            if direction.shape != (N,):
-                raise ValueError("direction must be (N,)")
+            if tuple(direction.shape) != lead + (N,):
+                raise ValueError("direction must be %s" % (lead + (N,),))
         if u is not None:
             u = as_device_f32(u, self.device)
-            if u.shape != (N,):
-                raise ValueError("u must be (N,)")
+            if tuple(u.shape) != lead + (N,):
+                raise ValueError("u must be %s" % (lead + (N,),))
         a = _ffi.L2hmcTrajectoryArgs()
         a.packed_nets = _ffi.ptr(self._packed_nets())
         a.energy = self._fn.c_struct(x.device, self.temperature if self.use_temperature else 1.0)
@@ -231,7 +237,9 @@ class Dynamics(object):
         a.x_out, a.v_out = _ffi.ptr(out.get('x')), _ffi.ptr(out.get('v'))
         a.logjac_out, a.p_out = _ffi.ptr(out.get('logjac')), _ffi.ptr(out.get('p'))
         a.x_next = _ffi.ptr(out.get('x_next'))
+        a.x_hist = _ffi.ptr(out.get('x_hist'))
         a.variant = int(self.variant)
+        a.n_proposals = M
         _ffi.check(_ffi.lib().l2hmc_trajectory(a, _ffi.current_stream(x.device)))
         return out
 

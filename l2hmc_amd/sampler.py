@@ -108,3 +108,39 @@ def chain_operator(init_x, dynamics, nb_steps, aux=None, init_v=None, do_mh_step
     if do_mh_step:
         outputs.append(tf_accept(init_x, x, p_accept, u=u, dynamics=dynamics))
     return x, v, p_accept, outputs
+
+
+def sample_chain(x, dynamics, nb_proposals, *, direction=None, v=None, u=None, record=False):
+    """`nb_proposals` chained `propose(..., do_mh_step=True)` calls -- the per-MH-step
+    `sess.run` loop of the notebook (SCGExperiment.ipynb raw lines 288-298) and of
+    `notebook_utils.get_hmc_samples` (:25-39) -- as ONE persistent kernel launch: weights stay
+    in LDS, the chain state / gradient / layer-1 partial stay in registers between proposals,
+    nothing returns to the host.
+
+    Optional injected draws: direction (M, N) 0/1, v (M, N, d), u (M, N).
+    Returns (x_final (N, d), p (M, N), x_hist (M, N, d) or None); x_hist[m] is the state AFTER
+    proposal m (the notebook records the state BEFORE each step: that is [x] + x_hist[:-1])."""
+    x = as_device_f32(x, dynamics.device)
+    N, d = x.shape
+    M = int(nb_proposals)
+    if M < 1:
+        raise ValueError("nb_proposals must be >= 1")
+    gen, dev = dynamics.generator, dynamics.device
+    if v is None:
+        v = torch.randn((M, N, d), dtype=torch.float32, device=dev, generator=gen)
+    if u is None:
+        u = torch.rand((M, N), dtype=torch.float32, device=dev, generator=gen)
+    if dynamics.hmc:
+        direction = None
+    elif direction is None:
+        direction = torch.randint(0, 2, (M, N), device=dev, dtype=torch.uint8, generator=gen)
+    else:
+        direction = torch.as_tensor(direction, device=dev).to(torch.uint8)
+    v = as_device_f32(v, dev).reshape((M, N, d) if M > 1 else (N, d))
+    u = as_device_f32(u, dev).reshape((M, N) if M > 1 else (N,))
+    if direction is not None:
+        direction = direction.reshape((M, N) if M > 1 else (N,))
+    want = ('p', 'x_next') + (('x_hist',) if record else ())
+    o = dynamics.run(x, v, 0, dynamics.T, direction=direction, direction_all=1, u=u, want=want,
+                     n_proposals=M)
+    return o['x_next'], o['p'].reshape(M, N), (o['x_hist'] if record else None)

@@ -201,3 +201,42 @@ def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(_ffi, "LIB_PATH", "/nonexistent/libl2hmc_hip.so")
     with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
         _ffi.lib()
+
+
+@pytest.mark.parametrize("case", ["scg2d", "icg50", "mog2d", "scg2d_hmc"])
+def test_sample_chain_matches_oracle_loop(case):
+    """The persistent sampler loop (M proposals in one launch) == M oracle proposals chained on
+    the host with the same draws; also == M single-proposal launches of the HIP path."""
+    import torch
+    from l2hmc_amd import propose, sample_chain
+    g = load(case)
+    M, N, d = 6, g["x"].shape[0], int(g["x_dim"])
+    rng = np.random.RandomState(42)
+    vb = rng.randn(M, N, d).astype(np.float32)
+    db = rng.randint(0, 2, size=(M, N)).astype(np.uint8)
+    ub = rng.rand(M, N).astype(np.float32)
+    hmc = bool(int(g["hmc"]))
+    for var in variants(g):
+        dyn = hip_dynamics(g, var)
+        xf, p, xh = sample_chain(to_dev(g["x"]), dyn, M, direction=None if hmc else to_dev(db),
+                                 v=to_dev(vb), u=to_dev(ub), record=True)
+        # (a) against M separate launches (bit-exact: same kernel, same per-chain arithmetic)
+        xs = to_dev(g["x"])
+        for m in range(M):
+            kw = {} if hmc else {"direction": to_dev(db[m])}
+            _, _, pm, outs = propose(xs, dyn, do_mh_step=True, v=to_dev(vb[m]), u=to_dev(ub[m]), **kw)
+            assert torch.equal(pm, p[m]) and torch.equal(outs[0], xh[m]), (case, var, m)
+            xs = outs[0]
+        assert torch.equal(xs, xf)
+        # (b) against the oracle, as long as the accept decisions are not fp32 ties
+        od = oracle_dynamics(g)
+        xo = g["x"]
+        ok = np.ones(N, dtype=bool)
+        with np.errstate(all="ignore"):
+            for m in range(M):
+                _, _, po, xo = O.propose(xo, od, vb[m], vb[m], db[m], ub[m], both_directions=False)
+                ok &= np.abs(po - ub[m]) > 1e-4
+                ok &= np.all(np.isfinite(xo), axis=1)
+                assert abs_err(to_np(p[m])[ok], po[ok]) < 5 * P_TOL, (case, var, m)
+        assert ok.mean() > 0.8
+        assert rel_err(to_np(xf)[ok], xo[ok]) < 5 * TRAJ_TOL
