@@ -150,6 +150,16 @@ int l2hmc_p_accept(const L2hmcEnergy* energy, const float* x0, const float* v0,
 int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const float* u,
                     int64_t n_chains, int32_t d, float* x_next, void* stream);
 
+/* autocovariance / acl_spectrum (utils/func_utils.py:45-54,114-116) of a recorded chain history
+ * X (steps, N, d) kept on the device:
+ *   A_out[tau] = mean_t [ sum_{n,k} X[t,n,k] X[t+tau,n,k] / N ] / scale^2,  tau = 0 .. steps-2
+ * (no mean subtraction, like the reference).  sums_out (steps-1 doubles) receives the raw
+ * sums S(tau) = sum_t sum_{n,k} X[t] X[t+tau] -- the quantity ranks all-reduce when the chains
+ * are sharded; pass n_total = chains over ALL ranks for the normalisation of A_out (A_out may be
+ * NULL when only the partial sums are wanted). */
+int l2hmc_autocov(const float* X, int64_t steps, int64_t n_chains, int32_t d, double scale,
+                  int64_t n_total, double* sums_out, double* A_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

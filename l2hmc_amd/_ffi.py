@@ -53,6 +53,7 @@ SYMBOLS = {
     "l2hmc_p_accept": (C.c_int, [C.POINTER(L2hmcEnergy), _fp, _fp, _fp, _fp, _fp, C.c_int64,
                                  C.c_int32, _fp, _fp]),
     "l2hmc_mh_select": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp]),
+    "l2hmc_autocov": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int64, _fp, _fp, _fp]),
 }
 
 _lib = None

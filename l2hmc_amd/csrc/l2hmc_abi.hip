@@ -74,6 +74,63 @@ __global__ void mh_select_kernel(const float* x, const float* Lx, const float* p
   out[i] = (px[n] - u[n] >= 0.f) ? Lx[i] : x[i];
 }
 
+// K7: raw autocovariance sums.  Thread = one series j = (chain, dim) of the (steps, J) history;
+// block = 256 consecutive series (coalesced rows) x 32 lags; per-lag block reduction in LDS, one
+// double atomicAdd per (block, lag).
+const int kLagTile = 32;
+__global__ __launch_bounds__(256) void autocov_kernel(const float* X, long long steps, long long J,
+                                                      double* S) {
+  __shared__ double part[4][kLagTile];
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long tau0 = (long long)blockIdx.y * kLagTile;
+  float acc[kLagTile];
+#pragma unroll
+  for (int l = 0; l < kLagTile; ++l) acc[l] = 0.f;
+  double dacc[kLagTile];
+#pragma unroll
+  for (int l = 0; l < kLagTile; ++l) dacc[l] = 0.0;
+  if (j < J) {
+    const float* col = X + j;
+    long long t = 0;
+    // fp32 inner chunks of 64 steps, folded into fp64 (the reference accumulates in float64)
+    for (long long tb = 0; tb < steps - tau0; tb += 64) {
+      const long long te = (tb + 64 < steps - tau0) ? tb + 64 : steps - tau0;
+      for (t = tb; t < te; ++t) {
+        const float x0 = col[t * J];
+#pragma unroll
+        for (int l = 0; l < kLagTile; ++l) {
+          const long long t2 = t + tau0 + l;
+          const float x1 = t2 < steps ? col[t2 * J] : 0.f;
+          acc[l] = fmaf(x0, x1, acc[l]);
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < kLagTile; ++l) { dacc[l] += (double)acc[l]; acc[l] = 0.f; }
+    }
+  }
+  // wave reduction, then across the 4 waves through LDS
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int l = 0; l < kLagTile; ++l) {
+    double v = dacc[l];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) part[wv][l] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLagTile) {
+    const long long tau = tau0 + threadIdx.x;
+    if (tau < steps - 1) {
+      const double v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+      atomicAdd(&S[tau], v);
+    }
+  }
+}
+
+__global__ void autocov_finish_kernel(const double* S, long long steps, double inv, double* A) {
+  const long long tau = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tau < steps - 1) A[tau] = S[tau] * inv / (double)(steps - tau);
+}
+
 // ------------------------------------------------------------------------------------------
 // Host side: LDS planning and dispatch
 // ------------------------------------------------------------------------------------------
@@ -317,6 +374,30 @@ int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const floa
   hipLaunchKernelGGL(mh_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, x, Lx, px, u, (long long)n_chains, d, x_next);
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int l2hmc_autocov(const float* X, int64_t steps, int64_t n_chains, int32_t d, double scale,
+                  int64_t n_total, double* sums_out, double* A_out, void* stream) {
+  if (!X || !sums_out || steps < 2 || n_chains < 0 || d < 1 || !(scale > 0.0) || n_total < 1)
+    return fail(L2HMC_ERR_ARG, "l2hmc_autocov: bad argument%s");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sums_out, 0, sizeof(double) * (size_t)(steps - 1), s);
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+  const long long J = (long long)n_chains * d;
+  if (J > 0) {
+    const long long gx = (J + 255) / 256, gy = (steps - 1 + kLagTile - 1) / kLagTile;
+    if (gx > 0x7fffffffLL || gy > 65535) return fail(L2HMC_ERR_UNSUPPORTED, "history too large%s");
+    hipLaunchKernelGGL(autocov_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, X,
+                       (long long)steps, J, sums_out);
+  }
+  if (A_out) {
+    const double inv = 1.0 / ((double)n_total * scale * scale);
+    hipLaunchKernelGGL(autocov_finish_kernel, dim3((unsigned)((steps - 1 + 255) / 256)), dim3(256), 0, s,
+                       sums_out, (long long)steps, inv, A_out);
+  }
+  e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;
 }

@@ -1,8 +1,34 @@
 """Chain diagnostics -- the sampler-related part of the reference's utils/func_utils.py
-(`accept` :33-42, `autocovariance` :45-54, `acl_spectrum` :114-116, `ESS` :118-120).
-Host-side numpy on recorded chains of shape (steps, chains, dim); the MNIST/VAE helpers of
-that file are out of scope."""
+(`accept` :33-42, `autocovariance` :45-54, `acl_spectrum` :114-116, `ESS` :118-120) on recorded
+chains of shape (steps, chains, dim).  numpy input -> numpy arithmetic exactly like the
+reference; a ROCm tensor (e.g. the `x_hist` of `sample_chain`) -> the HIP kernel `l2hmc_autocov`,
+the history never leaves the GPU.  The MNIST/VAE helpers of that file are out of scope."""
 import numpy as np
+
+
+def _is_device_tensor(X):
+    try:
+        import torch
+        return isinstance(X, torch.Tensor) and X.is_cuda
+    except ImportError:
+        return False
+
+
+def device_autocov(X, scale=1.0, n_total=None):
+    """(raw sums S(tau), A(tau)) of a (steps, N, d) float32 device history via `l2hmc_autocov`;
+    both are float64 device tensors of length steps-1."""
+    import torch
+    from . import _ffi
+    X = X.detach()
+    if X.dtype != torch.float32 or not X.is_contiguous():
+        X = X.to(torch.float32).contiguous()
+    steps, N, d = X.shape
+    S = torch.empty(steps - 1, dtype=torch.float64, device=X.device)
+    A = torch.empty(steps - 1, dtype=torch.float64, device=X.device)
+    _ffi.check(_ffi.lib().l2hmc_autocov(X.data_ptr(), steps, N, d, float(scale),
+                                        int(N if n_total is None else n_total), S.data_ptr(),
+                                        A.data_ptr(), _ffi.current_stream(X.device)))
+    return S, A
 
 
 def accept(x_i, x_p, p, rng=None):
@@ -24,6 +50,8 @@ def autocovariance(X, tau=0):
 
 def acl_spectrum(X, scale):
     """A(tau) for tau = 0 .. steps-2 on X / scale."""
+    if _is_device_tensor(X):
+        return device_autocov(X, scale)[1].cpu().numpy()
     Xs = np.asarray(X) / scale
     return np.array([autocovariance(Xs, tau=t) for t in range(Xs.shape[0] - 1)])
 

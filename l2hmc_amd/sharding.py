@@ -58,9 +58,14 @@ def acl_spectrum(X_local, scale, n_total):
     """`acl_spectrum` of utils/func_utils.py:114-116 for chains sharded over ranks: one
     all-reduce of the (steps-1,) partial sums; equals the single-process value on the
     concatenated chains."""
-    X = torch.as_tensor(X_local, dtype=torch.float64) / scale
-    steps = X.shape[0]
-    s = _allreduce_sum(autocov_partial_sums(X))
+    if isinstance(X_local, torch.Tensor) and X_local.is_cuda:      # HIP kernel, history stays in HBM
+        from .func_utils import device_autocov
+        steps = X_local.shape[0]
+        s = _allreduce_sum(device_autocov(X_local, 1.0)[0] / (scale * scale))
+    else:
+        X = torch.as_tensor(X_local, dtype=torch.float64) / scale
+        steps = X.shape[0]
+        s = _allreduce_sum(autocov_partial_sums(X))
     lags = torch.arange(steps - 1, dtype=torch.float64, device=s.device)
     return (s / float(n_total) / (steps - lags)).cpu().numpy()
 
