@@ -105,6 +105,36 @@ def cpu_baseline(prob, budget_s=12.0):
                       "computed as the reference does, row-wise Gaussian energy; %.1f s" % (reps, n, el)}
 
 
+def ess_leg(dev):
+    """ESS/sec on the notebook's SCG-2D target (BASELINE.json configs[0] shape: 200 chains, Lf=10)
+    with the HMC(eps=0.15) sampler whose ESS the reference publishes (nb raw 388: 5.63e-3 per MH
+    step): 2000 MH steps in one persistent launch, history + autocovariance on the device."""
+    import torch
+    from l2hmc_amd import Dynamics, distributions, func_utils, sample_chain
+    cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
+    dist = distributions.Gaussian(np.zeros(2), cov)
+    dyn = Dynamics(2, dist.get_energy_function(), T=10, eps=0.15, hmc=True, device=dev)
+    dyn.generator = torch.Generator(device=dev).manual_seed(0)
+    n, steps = 200, 2000
+    x0 = torch.as_tensor(dist.get_samples(n, rng=np.random.RandomState(0)), dtype=torch.float32, device=dev)
+    v = torch.randn((steps, n, 2), device=dev, generator=dyn.generator)
+    u = torch.rand((steps, n), device=dev, generator=dyn.generator)
+    sample_chain(x0, dyn, steps, v=v, u=u, record=True)                     # warm-up
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    xf, p, hist = sample_chain(x0, dyn, steps, v=v, u=u, record=True)
+    X = torch.cat([x0[None], hist[:-1]], dim=0)
+    A = func_utils.acl_spectrum(X, float(np.sqrt(np.trace(cov))))
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    ess = float(func_utils.ESS(A))
+    return {"workload": "SCG-2D, HMC eps=0.15, 200 chains x 2000 MH steps, Lf=10 (nb raw 288-298, 388)",
+            "ess_per_mh_step": ess, "reference_ess_per_mh_step": 5.63e-3,
+            "mh_steps_per_sec_per_chain": steps / el, "ess_per_sec": ess * steps / el * n,
+            "chain_leapfrog_steps_per_sec": n * 10 * steps / el, "mean_accept_prob": float(p.mean()),
+            "seconds_incl_autocov": el}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +143,7 @@ def main():
     ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ess", action="store_true", help="skip the SCG-2D ESS/sec leg (N=1 only)")
     ap.add_argument("--bank", type=int, default=0,
                     help="distinct pre-generated random draws, cycled (0 = 2 x proposals-per-launch, min 16)")
     ap.add_argument("--proposals-per-launch", type=int, default=25,
@@ -252,6 +283,8 @@ def main():
             if t.get("workload_chains") == n and t.get("proposals_per_launch", 1) == M:
                 out["roofline"]["traffic"] = 1024.0 * (t["fetch_kb"] + t["write_kb"])
                 out["roofline"]["traffic_source"] = t["source"]
+        if world == 1 and not args.no_ess:
+            out["ess"] = ess_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob)
         print(json.dumps(out))
