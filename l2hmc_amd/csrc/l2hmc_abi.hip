@@ -137,7 +137,9 @@ __global__ void autocov_finish_kernel(const double* S, long long steps, double i
 int round4(int v) { return (v + 3) & ~3; }
 
 // Fills the LDS offsets of `k`; returns the dynamic LDS size in bytes.
-long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW) {
+long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW, int DT) {
+  const bool wg = weights_in_global(DT);
+  with_nets = with_nets && !wg;
   const int NT = k.NT, DP = 16 * NT;
   long long o = 0;
   if (with_nets) o += 2LL * net_floats(NT);
@@ -158,7 +160,7 @@ long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW) {
   o += (long long)nc * DP;
   k.o_prec = (int)o;
   if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) o += DP;
-  if (k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM)
+  if ((k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM) && !wg)
     o += (long long)nc * gauss_floats(NT);
   k.o_logc = (int)o;
   o += round4(nc);
@@ -325,7 +327,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   k.M = a->n_proposals > 1 ? a->n_proposals : 1;
   k.dbg = L2HMC_DBG_PTR;
   fill_energy(k, &a->energy);
-  const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW);
+  const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW, DT);
   hipStream_t s = (hipStream_t)stream;
   return dispatch(OP_TRAJ, k, DT, NW, KH, lds, s);
 }
@@ -342,7 +344,7 @@ int l2hmc_energy(const L2hmcEnergy* energy, const float* x, int64_t n_chains, in
   memset(&k, 0, sizeof(k));
   k.N = n_chains; k.d = d; k.NT = tiles_of(d); k.x = x; k.U_out = U_out; k.grad_out = grad_out;
   fill_energy(k, energy);
-  const long long lds = plan_lds(k, false, false, NW);
+  const long long lds = plan_lds(k, false, false, NW, DT);
   return dispatch(OP_ENERGY, k, DT, NW, 3, lds, (hipStream_t)stream);
 }
 
@@ -361,7 +363,7 @@ int l2hmc_p_accept(const L2hmcEnergy* energy, const float* x0, const float* v0, 
   k.N = n_chains; k.d = d; k.NT = tiles_of(d);
   k.x = x0; k.v = v0; k.x1 = x1; k.v1 = v1; k.logjac_in = logjac; k.p_out = p_out;
   fill_energy(k, energy);
-  const long long lds = plan_lds(k, false, false, NW);
+  const long long lds = plan_lds(k, false, false, NW, DT);
   return dispatch(OP_PACCEPT, k, DT, NW, 3, lds, (hipStream_t)stream);
 }
 

@@ -36,6 +36,13 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Geometries with DT >= 4 tiles per wave (d > 128 with NW = 4, or the one-wave-per-tile kernels
+// for d > 32) read the packed weight / precision fragments straight from global memory (L2-hot,
+// prefetched a phase ahead) instead of staging them in LDS: beyond d ~ 190 the two nets no longer
+// fit the 160 KiB, and for the NW = 1 kernels a 45 KiB staging buffer per 64-thread workgroup
+// would cap the occupancy.
+__host__ __device__ constexpr bool weights_in_global(int DT) { return DT >= 4; }
+
 int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0);
 
 // ------------------------------------------------------------------------------------------
@@ -256,7 +263,7 @@ __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, 
         const f4 mu = ok ? lds4(smem + A.o_mu + 16 * (w * DT + t) + 4 * q) : splat(0.f);
         dx[t] = x[t] - mu;
       }
-      dense_matvec<DT, NW>(smem + A.o_prec, A, smem, w, lane, dx, g);
+      dense_matvec<DT, NW>(weights_in_global(DT) ? A.prec : smem + A.o_prec, A, smem, w, lane, dx, g);
 #pragma unroll
       for (int t = 0; t < DT; ++t) U += 0.5f * hsum(dx[t] * g[t]);
     }
@@ -276,7 +283,7 @@ __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, 
           const f4 mu = ok ? lds4(smem + A.o_mu + i * DP + 16 * (w * DT + t) + 4 * q) : splat(0.f);
           dx[t] = x[t] - mu;
         }
-        dense_matvec<DT, NW>(smem + A.o_prec + i * gauss_floats(A.NT), A, smem, w, lane, dx, y);
+        dense_matvec<DT, NW>((weights_in_global(DT) ? A.prec : smem + A.o_prec) + i * gauss_floats(A.NT), A, smem, w, lane, dx, y);
         float qq[1] = {0.f};
 #pragma unroll
         for (int t = 0; t < DT; ++t) qq[0] += hsum(dx[t] * y[t]);
@@ -538,7 +545,7 @@ __device__ __forceinline__ void store_state(float* p, const KArgs& A, long long 
 }
 
 // Stage energy parameters into LDS (padded with zeros to 16*NT dims).
-template <int EK>
+template <int EK, bool WG = false>
 __device__ __forceinline__ void stage_energy(const KArgs& A, float* smem, int tid, int nthr) {
   const int DP = 16 * A.NT;
   const int nc = EK == L2HMC_ENERGY_GMM ? A.ncomp : 1;
@@ -552,10 +559,12 @@ __device__ __forceinline__ void stage_energy(const KArgs& A, float* smem, int ti
   if (EK == L2HMC_ENERGY_GAUSS_DIAG) {
     for (int i = tid; i < DP; i += nthr) smem[A.o_prec + i] = i < A.d ? A.prec[i] : 0.f;
   } else if (EK == L2HMC_ENERGY_GAUSS_DENSE || EK == L2HMC_ENERGY_GMM) {
-    const int n4 = nc * gauss_floats(A.NT) / 4;
-    const f4* src = reinterpret_cast<const f4*>(A.prec);
-    f4* dst = reinterpret_cast<f4*>(smem + A.o_prec);
-    for (int i = tid; i < n4; i += nthr) dst[i] = src[i];
+    if (!WG) {
+      const int n4 = nc * gauss_floats(A.NT) / 4;
+      const f4* src = reinterpret_cast<const f4*>(A.prec);
+      f4* dst = reinterpret_cast<f4*>(smem + A.o_prec);
+      for (int i = tid; i < n4; i += nthr) dst[i] = src[i];
+    }
     if (EK == L2HMC_ENERGY_GMM)
       for (int i = tid; i < nc; i += nthr) smem[A.o_logc + i] = A.logc[i];
   }
@@ -579,7 +588,8 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
   const int NF = net_floats(NT);
 
   // ---- prologue: stage weights / masks / time table / energy parameters into LDS ----------
-  if (has_nets) {
+  constexpr bool WG = weights_in_global(DT);
+  if (has_nets && !WG) {
     const f4* src = reinterpret_cast<const f4*>(A.packed);
     f4* dst = reinterpret_cast<f4*>(smem);
     for (int i = tid; i < 2 * NF / 4; i += nthr) dst[i] = src[i];
@@ -589,7 +599,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
     smem[A.o_mask + i] = dim < A.d ? A.masks[row * A.d + dim] : 0.f;
   }
   for (int i = tid; i < 2 * A.T; i += nthr) smem[A.o_trig + i] = A.trig[i];
-  stage_energy<EK>(A, smem, tid, nthr);
+  stage_energy<EK, weights_in_global(DT)>(A, smem, tid, nthr);
 
   f4 x[DT], v[DT], g[DT];
   load_state<DT, NW>(A.x, A, chain, live, w, q, x);
@@ -598,8 +608,8 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
   const bool need_p = A.p_out != nullptr || A.x_next != nullptr || A.u != nullptr;
   __syncthreads();
 
-  const float* wx = smem;        // XNet fragments
-  const float* wv = smem + NF;   // VNet fragments
+  const float* wx = WG ? A.packed : smem;   // XNet fragments
+  const float* wv = wx + NF;                // VNet fragments
   int pb = 0;
   const f4 Z = splat(0.f);
   float U_start;                 // this lane's share of U at the current state
@@ -801,7 +811,7 @@ __global__ __launch_bounds__(64 * NW) void energy_kernel(const KArgs A) {
   const int c = lane & 15, q = lane >> 4;
   const long long chain = (long long)blockIdx.x * 16 + c;
   const bool live = chain < A.N;
-  stage_energy<EK>(A, smem, tid, 64 * NW);
+  stage_energy<EK, weights_in_global(DT)>(A, smem, tid, 64 * NW);
   f4 x[DT], g[DT];
   load_state<DT, NW>(A.x, A, chain, live, w, q, x);
   __syncthreads();
@@ -821,7 +831,7 @@ __global__ __launch_bounds__(64 * NW) void paccept_kernel(const KArgs A) {
   const int c = lane & 15, q = lane >> 4;
   const long long chain = (long long)blockIdx.x * 16 + c;
   const bool live = chain < A.N;
-  stage_energy<EK>(A, smem, tid, 64 * NW);
+  stage_energy<EK, weights_in_global(DT)>(A, smem, tid, 64 * NW);
   f4 x[DT], v[DT], g[DT];
   float red[4];
   __syncthreads();

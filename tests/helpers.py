@@ -116,3 +116,41 @@ def to_dev(a):
 
 def to_np(t):
     return t.detach().cpu().numpy()
+
+
+def synthetic_case(kind, d, H=10, T=10, N=64, seed=0, eps=0.1, head_std=0.3):
+    """A golden-shaped dict (weights, mask, energy parameters, inputs) for sizes the committed
+    fixtures do not cover; consumed by oracle_dynamics() and hip_dynamics() alike."""
+    rng = np.random.RandomState(seed)
+    g = {"x_dim": d, "H": H, "T": T, "N": N, "hmc": 0, "eps": np.float32(eps),
+         "mask": O.init_mask(T, d, rng)}
+    for net, fac in (("xnet", 2.0), ("vnet", 1.0)):
+        def vs(shape, f):
+            return (np.clip(rng.randn(*shape), -2, 2) * np.sqrt(1.3 * 2 * f / shape[0])).astype(np.float32)
+        w = {"W1": vs((d, H), 1 / 3.), "W2": vs((d, H), fac / 3.), "W3": vs((2, H), 1 / 3.), "W4": vs((H, H), 1.)}
+        for k in ("Ws", "Wt", "Wq"):
+            w[k] = (head_std * rng.randn(H, d) / np.sqrt(H)).astype(np.float32)
+        for k, n in (("b1", H), ("b2", H), ("b3", H), ("b4", H), ("bs", d), ("bt", d), ("bq", d)):
+            w[k] = (0.1 * rng.randn(n)).astype(np.float32)
+        w["lam_s"] = (0.2 * rng.randn(1, d)).astype(np.float32)
+        w["lam_q"] = (0.2 * rng.randn(1, d)).astype(np.float32)
+        for k, v in w.items():
+            g[net + "." + k] = v
+    scale = np.ones(d, dtype=np.float32)
+    if kind == "gauss_diag":
+        var = np.exp(np.linspace(np.log(1e-1), np.log(1e1), d))
+        g.update({"energy.kind": "gaussian", "energy.mu": (0.3 * rng.randn(d)).astype(np.float32),
+                  "energy.i_sigma": np.diag(1.0 / var).astype(np.float32)})
+        scale = np.sqrt(var).astype(np.float32)
+    elif kind == "gauss_dense":
+        R = np.linalg.qr(rng.randn(d, d))[0]
+        prec = (R.T * np.exp(rng.uniform(-1, 1, size=d))) @ R
+        g.update({"energy.kind": "gaussian", "energy.mu": (0.3 * rng.randn(d)).astype(np.float32),
+                  "energy.i_sigma": prec.astype(np.float32)})
+    elif kind == "roughwell_easy":
+        g.update({"energy.kind": "roughwell", "energy.eta": np.float32(0.1), "energy.easy": np.int32(1)})
+    else:
+        raise ValueError(kind)
+    g["x"] = (rng.randn(N, d) * scale).astype(np.float32)
+    g["v"] = rng.randn(N, d).astype(np.float32)
+    return g

@@ -278,3 +278,32 @@ def test_hmc_ess_on_scg_reproduces_notebook_number():
     # the sampler leaves the target invariant: second moments of the final state ~ cov
     emp = np.cov(to_np(xf).T)
     assert abs(emp[0, 0] - 50.05) < 18 and abs(emp[0, 1] + 49.95) < 18
+
+
+@pytest.mark.parametrize("kind,d,variant", [("roughwell_easy", 512, 0), ("roughwell_easy", 200, 0),
+                                            ("gauss_diag", 300, 0), ("gauss_dense", 150, 0),
+                                            ("gauss_dense", 40, 1), ("gauss_dense", 40, 4),
+                                            ("gauss_diag", 64, 1), ("gauss_diag", 17, 1)])
+def test_wide_dims_against_oracle(kind, d, variant):
+    """BASELINE.json config 4 range (d up to 512) and the geometries the fixtures do not reach:
+    LDS-staged weights (DT <= 2) and global-memory weights (DT >= 4), every NW/DT kernel."""
+    from l2hmc_amd import propose
+    from tests.helpers import synthetic_case
+    g = synthetic_case(kind, d, N=48, seed=d, head_std=0.3 if d < 100 else 0.1)
+    dyn = hip_dynamics(g, variant)
+    od = oracle_dynamics(g)
+    x, v = to_dev(g["x"]), to_dev(g["v"])
+    rng = np.random.RandomState(1)
+    direction = rng.randint(0, 2, size=48).astype(np.uint8)
+    u = rng.rand(48).astype(np.float32)
+    Lx, _, px, outs = propose(x, dyn, do_mh_step=True, direction=to_dev(direction), v=v, u=to_dev(u))
+    xo, vo, lj = dyn._forward_step(x, v, 3)
+    with np.errstate(all="ignore"):
+        rLx, _, rpx, _ = O.propose(g["x"], od, g["v"], g["v"], direction, u, both_directions=False)
+        rxo, rvo, rlj = od.forward_step(g["x"], g["v"], np.float32(3))
+    assert rel_err(to_np(xo), rxo) < STEP_TOL and rel_err(to_np(vo), rvo) < STEP_TOL
+    assert rel_err(to_np(lj), rlj) < STEP_TOL
+    fin = np.all(np.isfinite(rLx), axis=1) & (np.abs(rLx).max(axis=1) < 1e3)
+    assert fin.mean() > 0.9
+    assert rel_err(to_np(Lx)[fin], rLx[fin]) < 2 * TRAJ_TOL
+    assert abs_err(to_np(px)[fin], rpx[fin]) < 2 * P_TOL
