@@ -307,3 +307,50 @@ def test_wide_dims_against_oracle(kind, d, variant):
     assert fin.mean() > 0.9
     assert rel_err(to_np(Lx)[fin], rLx[fin]) < 2 * TRAJ_TOL
     assert abs_err(to_np(px)[fin], rpx[fin]) < 2 * P_TOL
+
+
+@pytest.mark.parametrize("case", ["scg2d", "tilted8"])
+def test_chain_operator_matches_oracle(case):
+    """sampler.py:57-85: nb_steps composed proposals with summed log-Jacobians, one accept."""
+    from l2hmc_amd import chain_operator
+    g = load(case)
+    dyn, od = hip_dynamics(g), oracle_dynamics(g)
+    N, d, K = g["x"].shape[0], int(g["x_dim"]), 3
+    rng = np.random.RandomState(3)
+    dirs = [rng.randint(0, 2, size=N).astype(np.uint8) for _ in range(K)]
+    vs = [rng.randn(N, d).astype(np.float32) for _ in range(K)]
+    u = rng.rand(N).astype(np.float32)
+    fx, fv, p, outs = chain_operator(to_dev(g["x"]), dyn, K, init_v=to_dev(g["v"]), do_mh_step=True,
+                                     directions=[to_dev(a) for a in dirs], vs=[to_dev(a) for a in vs],
+                                     u=to_dev(u))
+    with np.errstate(all="ignore"):
+        rx, rv, rp, rn = O.chain_operator(g["x"], od, K, g["v"], vs, vs, dirs, u)
+    fin = np.all(np.isfinite(rx), axis=1) & (np.abs(rx).max(axis=1) < 1e3)
+    assert fin.mean() > 0.8
+    assert rel_err(to_np(fx)[fin], rx[fin]) < 3 * TRAJ_TOL
+    assert rel_err(to_np(fv)[fin], rv[fin]) < 3 * TRAJ_TOL
+    assert abs_err(to_np(p)[fin], rp[fin]) < 3 * P_TOL
+    check_x_next(to_np(outs[0])[fin], g["x"][fin], rx[fin], rp[fin], u[fin], 3 * P_TOL)
+
+
+def test_l2hmc_sampler_leaves_target_invariant():
+    """End-to-end statistical check of log-det + direction mixing + MH: an L2HMC sampler with
+    NON-trivial (random, untrained) S/T/Q nets started from exact target samples must keep the
+    target's second moments (any error in the Jacobian or the accept rule biases them)."""
+    import torch
+    from l2hmc_amd import Dynamics, distributions as D, layers, sample_chain
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cov = np.array([[2.0, 1.2], [1.2, 1.5]])
+    dist = D.Gaussian(np.zeros(2), cov)
+    dyn = Dynamics(2, dist.get_energy_function(), T=5, eps=0.2, net_factory=layers.stq_network(10, head_factor=0.6))
+    dyn.generator = torch.Generator(device="cuda").manual_seed(1)
+    N = 16384
+    x0 = to_dev(dist.get_samples(N, rng=np.random.RandomState(1)).astype(np.float32))
+    xf, p, _ = sample_chain(x0, dyn, 60)
+    acc = float(p.mean())
+    emp = np.cov(to_np(xf).T)
+    print("L2HMC(random nets): accept %.3f, cov %s" % (acc, np.round(emp, 3).tolist()))
+    assert 0.05 < acc < 0.98                      # the nets really perturb the dynamics
+    assert np.abs(emp - cov).max() < 0.08         # ~4 sigma of the sampling error at N=16384
+    assert np.abs(to_np(xf).mean(0)).max() < 0.05
