@@ -108,7 +108,17 @@ typedef struct L2hmcTrajectoryArgs {
                             /* each proposal starts from the previous MH-selected state;        */
                             /* x_out / v_out hold the LAST proposal, x_next the final state     */
   float* x_hist;            /* (M, N, d) MH-selected state after every proposal, or NULL        */
+  /* ---- in-kernel randomness (replaces tf.random_normal / random_uniform of dynamics.py:247-250, */
+  /*      sampler.py:34,54): counter-based Philox4x32-10, keyed by (seed), counter = (global chain, */
+  /*      dim/4, proposal index, stream) => independent of kernel geometry and of chain sharding.   */
+  uint32_t rng_flags;       /* L2HMC_RNG_V | L2HMC_RNG_DIR | L2HMC_RNG_U: draw that input in-kernel  */
+                            /* (the corresponding pointer v / direction / u is then ignored)          */
+  uint64_t rng_seed;
+  uint64_t rng_proposal0;   /* stream index of this launch's first proposal                          */
+  int64_t chain_offset;     /* global index of row 0 (rank r owning rows [lo, hi) passes lo)          */
 } L2hmcTrajectoryArgs;
+
+enum { L2HMC_RNG_V = 1, L2HMC_RNG_DIR = 2, L2HMC_RNG_U = 4 };
 
 int l2hmc_abi_version(void);
 const char* l2hmc_last_error(void);
@@ -149,6 +159,12 @@ int l2hmc_p_accept(const L2hmcEnergy* energy, const float* x0, const float* v0,
 /* tf_accept (sampler.py:53-55): x_next[n,:] = (px[n] - u[n] >= 0) ? Lx[n,:] : x[n,:]. */
 int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const float* u,
                     int64_t n_chains, int32_t d, float* x_next, void* stream);
+
+/* The draws the sampler loop would use, written out ((M,N,d) normals, (M,N) direction bits,
+ * (M,N) uniforms; any output may be NULL): for tests, and for reproducing a run's randomness. */
+int l2hmc_rng_fill(uint64_t seed, uint64_t proposal0, int64_t chain_offset, int64_t n_chains,
+                   int32_t d, int32_t n_proposals, float* v_out, uint8_t* dir_out, float* u_out,
+                   void* stream);
 
 /* autocovariance / acl_spectrum (utils/func_utils.py:45-54,114-116) of a recorded chain history
  * X (steps, N, d) kept on the device:

@@ -36,7 +36,12 @@ class L2hmcTrajectoryArgs(C.Structure):
                 ("x", _fp), ("v", _fp), ("direction", _fp), ("direction_all", C.c_int32),
                 ("u", _fp),
                 ("x_out", _fp), ("v_out", _fp), ("logjac_out", _fp), ("p_out", _fp),
-                ("x_next", _fp), ("variant", C.c_int32), ("n_proposals", C.c_int32), ("x_hist", _fp)]
+                ("x_next", _fp), ("variant", C.c_int32), ("n_proposals", C.c_int32), ("x_hist", _fp),
+                ("rng_flags", C.c_uint32), ("rng_seed", C.c_uint64), ("rng_proposal0", C.c_uint64),
+                ("chain_offset", C.c_int64)]
+
+
+RNG_V, RNG_DIR, RNG_U = 1, 2, 4
 
 
 # every symbol include/l2hmc.h declares: name -> (restype, argtypes)
@@ -53,6 +58,8 @@ SYMBOLS = {
     "l2hmc_p_accept": (C.c_int, [C.POINTER(L2hmcEnergy), _fp, _fp, _fp, _fp, _fp, C.c_int64,
                                  C.c_int32, _fp, _fp]),
     "l2hmc_mh_select": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp]),
+    "l2hmc_rng_fill": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                 _fp, _fp, _fp, _fp]),
     "l2hmc_autocov": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int64, _fp, _fp, _fp]),
 }
 

@@ -74,6 +74,31 @@ __global__ void mh_select_kernel(const float* x, const float* Lx, const float* p
   out[i] = (px[n] - u[n] >= 0.f) ? Lx[i] : x[i];
 }
 
+// The sampler's Philox draws written out (l2hmc_rng_fill): thread = (proposal, chain, 4-dim block).
+__global__ void rng_fill_kernel(unsigned long long seed, unsigned long long prop0, long long chain_off,
+                                long long N, int d, int M, float* v, unsigned char* dir, float* u) {
+  const int nblk = (d + 3) / 4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * N * nblk) return;
+  const int blk = (int)(i % nblk);
+  const long long n = (i / nblk) % N, m = i / ((long long)nblk * N);
+  if (v != nullptr) {
+    const f4 z = philox_normal4(seed, chain_off + n, (unsigned)blk, prop0 + m);
+    float* row = v + (m * N + n) * d + 4 * blk;
+    if (4 * blk + 0 < d) row[0] = z.x;
+    if (4 * blk + 1 < d) row[1] = z.y;
+    if (4 * blk + 2 < d) row[2] = z.z;
+    if (4 * blk + 3 < d) row[3] = z.w;
+  }
+  if (blk == 0 && (dir != nullptr || u != nullptr)) {
+    bool f;
+    float uu;
+    philox_dir_u(seed, chain_off + n, prop0 + m, f, uu);
+    if (dir != nullptr) dir[m * N + n] = f ? 1 : 0;
+    if (u != nullptr) u[m * N + n] = uu;
+  }
+}
+
 // K7: raw autocovariance sums.  Thread = one series j = (chain, dim) of the (steps, J) history;
 // block = 256 consecutive series (coalesced rows) x 32 lags; per-lag block reduction in LDS, one
 // double atomicAdd per (block, lag).
@@ -296,11 +321,13 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
   if (a->n_chains < 0 || a->d < 1 || a->T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / T%s");
   if (a->n_chains == 0) return L2HMC_OK;
-  if (!a->x || !a->v || !a->masks || !a->trig) return fail(L2HMC_ERR_ARG, "x, v, masks, trig are required%s");
+  if (!a->x || !a->masks || !a->trig) return fail(L2HMC_ERR_ARG, "x, masks, trig are required%s");
+  if (!a->v && !(a->rng_flags & L2HMC_RNG_V)) return fail(L2HMC_ERR_ARG, "v is required unless L2HMC_RNG_V is set%s");
   if (a->step_begin < 0 || a->n_steps < 0 || a->step_begin + a->n_steps > a->T)
     return fail(L2HMC_ERR_ARG, "steps [%s%lld, +%lld) outside the T-step schedule", "", a->step_begin, a->n_steps);
-  if (a->x_next && (!a->u)) return fail(L2HMC_ERR_ARG, "x_next needs u%s");
-  if (a->n_proposals > 1 && !a->u) return fail(L2HMC_ERR_ARG, "n_proposals > 1 needs u (the MH step links the proposals)%s");
+  const bool has_u = a->u != nullptr || (a->rng_flags & L2HMC_RNG_U);
+  if (a->x_next && !has_u) return fail(L2HMC_ERR_ARG, "x_next needs u (or L2HMC_RNG_U)%s");
+  if (a->n_proposals > 1 && !has_u) return fail(L2HMC_ERR_ARG, "n_proposals > 1 needs u (the MH step links the proposals)%s");
   if (a->n_proposals < 0) return fail(L2HMC_ERR_ARG, "n_proposals must be >= 0%s");
   if (a->x_hist == a->x && a->x) return fail(L2HMC_ERR_ARG, "x_hist must not alias x%s");
   if (a->x_out == a->x || a->x_next == a->x) return fail(L2HMC_ERR_ARG, "x_out / x_next must not alias x%s");
@@ -325,6 +352,8 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   k.x_next = a->x_next;
   k.x_hist = a->x_hist;
   k.M = a->n_proposals > 1 ? a->n_proposals : 1;
+  k.rng_flags = a->rng_flags; k.rng_seed = a->rng_seed; k.rng_prop0 = a->rng_proposal0;
+  k.chain_off = a->chain_offset;
   k.dbg = L2HMC_DBG_PTR;
   fill_energy(k, &a->energy);
   const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW, DT);
@@ -375,6 +404,20 @@ int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const floa
   const long long n = n_chains * (long long)d;
   hipLaunchKernelGGL(mh_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, x, Lx, px, u, (long long)n_chains, d, x_next);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int l2hmc_rng_fill(uint64_t seed, uint64_t proposal0, int64_t chain_offset, int64_t n_chains,
+                   int32_t d, int32_t n_proposals, float* v_out, uint8_t* dir_out, float* u_out,
+                   void* stream) {
+  if (n_chains < 0 || d < 1 || n_proposals < 1) return fail(L2HMC_ERR_ARG, "l2hmc_rng_fill: bad argument%s");
+  const long long total = (long long)n_proposals * n_chains * ((d + 3) / 4);
+  if (total == 0) return L2HMC_OK;
+  hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned long long)seed, (unsigned long long)proposal0, (long long)chain_offset,
+                     (long long)n_chains, d, n_proposals, v_out, dir_out, u_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;

@@ -78,6 +78,9 @@ struct KArgs {
   const float* u;
   float *x_out, *v_out, *logjac_out, *p_out, *x_next, *x_hist;
   int M;                     // proposals per launch (persistent sampler loop)
+  unsigned rng_flags;        // L2HMC_RNG_*: which draws come from the in-kernel Philox
+  unsigned long long rng_seed, rng_prop0;
+  long long chain_off;
   // energy
   int ekind, ncomp, easy;
   const float *mu, *prec, *logc;
@@ -158,6 +161,53 @@ __device__ __forceinline__ float accept_prob(float val) {
   const float mn = (val != val) ? val : fminf(val, 0.f);
   const float p = expf(mn);
   return (fabsf(p) <= 3.402823466e38f) ? p : 0.f;
+}
+
+// ---- counter-based RNG (K6): Philox4x32-10 (Salmon et al. 2011), same constants as
+// Random123 / cuRAND.  counter = (global chain, dim / 4, proposal index, stream), key = seed.
+struct U4 { unsigned x, y, z, w; };
+__host__ __device__ inline U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned long long p0 = 0xD2511F53ull * c.x, p1 = 0xCD9E8D57ull * c.z;
+    const U4 n = {(unsigned)(p1 >> 32) ^ c.y ^ k0, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k1, (unsigned)p0};
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+// 4 standard normals from one Philox block (two Box-Muller pairs, 24-bit uniforms)
+__device__ __forceinline__ f4 philox_normal4(unsigned long long seed, long long gchain, unsigned blk,
+                                             unsigned long long prop) {
+  const U4 r = philox4x32_10(U4{(unsigned)gchain, blk, (unsigned)prop, (unsigned)(prop >> 32) << 1},
+                             (unsigned)seed, (unsigned)(seed >> 32));
+  const float k = 5.9604644775390625e-08f;   // 2^-24
+  const float u1 = ((r.x >> 8) + 1) * k, u2 = (r.y >> 8) * k, u3 = ((r.z >> 8) + 1) * k, u4 = (r.w >> 8) * k;
+  const float ra = sqrtf(-2.f * logf(u1)), rb = sqrtf(-2.f * logf(u3));
+  float sa, ca, sb, cb;
+  sincosf(6.283185307179586f * u2, &sa, &ca);
+  sincosf(6.283185307179586f * u4, &sb, &cb);
+  return f4{ra * ca, ra * sa, rb * cb, rb * sb};
+}
+// direction bit and accept uniform of (chain, proposal): stream 1
+__device__ __forceinline__ void philox_dir_u(unsigned long long seed, long long gchain,
+                                             unsigned long long prop, bool& fwd, float& u) {
+  const U4 r = philox4x32_10(U4{(unsigned)gchain, 0u, (unsigned)prop, ((unsigned)(prop >> 32) << 1) | 1u},
+                             (unsigned)seed, (unsigned)(seed >> 32));
+  fwd = (r.x & 1u) != 0;
+  u = (r.y >> 8) * 5.9604644775390625e-08f;
+}
+template <int DT, int NW>
+__device__ __forceinline__ void rng_state(const KArgs& A, long long gchain, unsigned long long prop,
+                                          int w, int q, f4 (&z)[DT]) {
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    const int dim0 = 16 * (w * DT + t) + 4 * q;
+    f4 n = philox_normal4(A.rng_seed, gchain, (unsigned)(dim0 >> 2), prop);
+    z[t] = f4{dim0 + 0 < A.d ? n.x : 0.f, dim0 + 1 < A.d ? n.y : 0.f, dim0 + 2 < A.d ? n.z : 0.f,
+              dim0 + 3 < A.d ? n.w : 0.f};
+  }
 }
 
 // Sum over the lanes / waves that hold one chain; every lane of the chain gets the total.
@@ -605,7 +655,8 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
   load_state<DT, NW>(A.x, A, chain, live, w, q, x);
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
-  const bool need_p = A.p_out != nullptr || A.x_next != nullptr || A.u != nullptr;
+  const bool need_p = A.p_out != nullptr || A.x_next != nullptr || A.u != nullptr ||
+                      (A.rng_flags & L2HMC_RNG_U) != 0;
   __syncthreads();
 
   const float* wx = WG ? A.packed : smem;   // XNet fragments
@@ -628,22 +679,39 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
   }
 
   // ---- persistent sampler loop: M proposals per launch (M = 1: a single trajectory) ---------
-  // the next proposal's draws (momenta, direction bit, accept uniform) are fetched one proposal
-  // ahead so their HBM latency hides under the current trajectory
+  // This proposal's draws (momenta, direction bit, accept uniform): either injected from HBM --
+  // then fetched one proposal ahead so the latency hides under the current trajectory -- or
+  // drawn in-kernel from the counter-based Philox stream.
+  const long long gchain = A.chain_off + chain;
+  const bool rng_v = (A.rng_flags & L2HMC_RNG_V) != 0, rng_d = (A.rng_flags & L2HMC_RNG_DIR) != 0;
+  const bool rng_u = (A.rng_flags & L2HMC_RNG_U) != 0;
   f4 vn[DT];
-  load_state<DT, NW>(A.v, A, chain, live, w, q, vn);
-  bool fwd_n = A.dir != nullptr ? (live ? A.dir[chain] != 0 : true) : (A.dir_all != 0);
-  float u_n = (A.u != nullptr && live) ? A.u[chain] : 0.f;
+  if (!rng_v) load_state<DT, NW>(A.v, A, chain, live, w, q, vn);
+  bool fwd_n = (A.dir != nullptr && !rng_d) ? (live ? A.dir[chain] != 0 : true) : (A.dir_all != 0);
+  float u_n = (A.u != nullptr && !rng_u && live) ? A.u[chain] : 0.f;
+  const bool have_u = A.u != nullptr || rng_u;
   for (int m = 0; m < A.M; ++m) {
   const long long moff = (long long)m * A.N;
+  const unsigned long long prop = A.rng_prop0 + (unsigned long long)m;
+  if (rng_v) {
+    rng_state<DT, NW>(A, gchain, prop, w, q, v);
+  } else {
 #pragma unroll
-  for (int t = 0; t < DT; ++t) v[t] = vn[t];
-  const bool fwd = fwd_n;
-  const float u_m = u_n;
+    for (int t = 0; t < DT; ++t) v[t] = vn[t];
+  }
+  bool fwd = fwd_n;
+  float u_m = u_n;
+  if (rng_d || rng_u) {
+    bool fr;
+    float ur;
+    philox_dir_u(A.rng_seed, gchain, prop, fr, ur);
+    if (rng_d) fwd = fr;
+    if (rng_u) u_m = ur;
+  }
   if (m + 1 < A.M) {
-    load_state<DT, NW>(A.v + (moff + A.N) * A.d, A, chain, live, w, q, vn);
-    if (A.dir != nullptr && live) fwd_n = A.dir[moff + A.N + chain] != 0;
-    if (A.u != nullptr && live) u_n = A.u[moff + A.N + chain];
+    if (!rng_v) load_state<DT, NW>(A.v + (moff + A.N) * A.d, A, chain, live, w, q, vn);
+    if (A.dir != nullptr && !rng_d && live) fwd_n = A.dir[moff + A.N + chain] != 0;
+    if (A.u != nullptr && !rng_u && live) u_n = A.u[moff + A.N + chain];
   }
   const float sgn = fwd ? 1.f : -1.f;
   // the start point: a rejected chain resumes from it (sampler.py:53-55)
@@ -780,7 +848,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
     const float val = e_old - e_new + red[4];
     const float p = accept_prob(val);
     if (A.p_out != nullptr && writer) A.p_out[moff + chain] = p;
-    if (A.u != nullptr) {
+    if (have_u) {
       const bool acc = live && (p - u_m) >= 0.f;                      // sampler.py:53-55
 #pragma unroll
       for (int t = 0; t < DT; ++t) {

@@ -188,18 +188,30 @@ class Dynamics(object):
         return torch.randn(x.shape, dtype=torch.float32, device=x.device, generator=self.generator)
 
     def run(self, x, v, step_begin, n_steps, direction=None, direction_all=1, u=None,
-            want=('x', 'v', 'logjac'), n_proposals=1):
+            want=('x', 'v', 'logjac'), n_proposals=1, rng=None):
         """Launch `l2hmc_trajectory` (include/l2hmc.h).  Returns a dict of the requested
         outputs among x, v, logjac, p, x_next, x_hist.  With n_proposals = M > 1 the kernel
         runs M chained proposals (persistent sampler loop): v is (M, N, d), direction and u
-        are (M, N), p / logjac come back as (M, N), x_hist as (M, N, d)."""
+        are (M, N), p / logjac come back as (M, N), x_hist as (M, N, d).
+        rng = dict(seed=, proposal0=0, chain_offset=0): inputs passed as None among v /
+        direction / u are drawn in-kernel from the Philox stream (include/l2hmc.h)."""
         M = int(n_proposals)
         x = as_device_f32(x, self.device)
-        v = as_device_f32(v, self.device)
         N, d = x.shape
         lead = (M,) if M > 1 else ()
-        if d != self.x_dim or tuple(v.shape) != lead + (N, d):
-            raise ValueError("x must be (N, %d) and v %s" % (self.x_dim, lead + (N, d)))
+        flags = 0
+        if rng is not None:
+            flags = (_ffi.RNG_V if v is None else 0) | (_ffi.RNG_U if (u is None and rng.get('u', True)) else 0)
+            if direction is None and not self.hmc and rng.get('direction', True):
+                flags |= _ffi.RNG_DIR
+        if v is not None:
+            v = as_device_f32(v, self.device)
+            if tuple(v.shape) != lead + (N, d):
+                raise ValueError("v must be %s" % (lead + (N, d),))
+        elif not flags & _ffi.RNG_V:
+            raise ValueError("v is required unless rng= is given")
+        if d != self.x_dim:
+            raise ValueError("x must be (N, %d)" % self.x_dim)
         out = {}
         if 'x' in want:
             out['x'] = torch.empty_like(x)
@@ -231,7 +243,10 @@ class Dynamics(object):
             a.alpha, a.eps_host = None, float(self.eps_override)
         a.n_chains, a.d, a.H, a.T = N, d, self.H, self.T
         a.step_begin, a.n_steps = int(step_begin), int(n_steps)
-        a.x, a.v = x.data_ptr(), v.data_ptr()
+        a.x, a.v = x.data_ptr(), _ffi.ptr(v)
+        if rng is not None:
+            a.rng_flags, a.rng_seed = flags, int(rng['seed']) & 0xFFFFFFFFFFFFFFFF
+            a.rng_proposal0, a.chain_offset = int(rng.get('proposal0', 0)), int(rng.get('chain_offset', 0))
         a.direction, a.direction_all = _ffi.ptr(direction), int(direction_all)
         a.u = _ffi.ptr(u)
         a.x_out, a.v_out = _ffi.ptr(out.get('x')), _ffi.ptr(out.get('v'))

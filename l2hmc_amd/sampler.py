@@ -110,14 +110,18 @@ def chain_operator(init_x, dynamics, nb_steps, aux=None, init_v=None, do_mh_step
     return x, v, p_accept, outputs
 
 
-def sample_chain(x, dynamics, nb_proposals, *, direction=None, v=None, u=None, record=False):
+def sample_chain(x, dynamics, nb_proposals, *, direction=None, v=None, u=None, record=False,
+                 seed=None, proposal0=0, chain_offset=0):
     """`nb_proposals` chained `propose(..., do_mh_step=True)` calls -- the per-MH-step
     `sess.run` loop of the notebook (SCGExperiment.ipynb raw lines 288-298) and of
     `notebook_utils.get_hmc_samples` (:25-39) -- as ONE persistent kernel launch: weights stay
     in LDS, the chain state / gradient / layer-1 partial stay in registers between proposals,
     nothing returns to the host.
 
-    Optional injected draws: direction (M, N) 0/1, v (M, N, d), u (M, N).
+    Randomness: injected draws direction (M, N) 0/1, v (M, N, d), u (M, N); or `seed=` -- then
+    every draw not injected comes from the in-kernel counter-based Philox stream (proposal
+    index `proposal0 + m`, global chain index `chain_offset + n`: identical numbers whatever
+    the kernel geometry or the sharding of chains over GPUs); else torch's generator.
     Returns (x_final (N, d), p (M, N), x_hist (M, N, d) or None); x_hist[m] is the state AFTER
     proposal m (the notebook records the state BEFORE each step: that is [x] + x_hist[:-1])."""
     x = as_device_f32(x, dynamics.device)
@@ -126,21 +130,39 @@ def sample_chain(x, dynamics, nb_proposals, *, direction=None, v=None, u=None, r
     if M < 1:
         raise ValueError("nb_proposals must be >= 1")
     gen, dev = dynamics.generator, dynamics.device
-    if v is None:
-        v = torch.randn((M, N, d), dtype=torch.float32, device=dev, generator=gen)
-    if u is None:
-        u = torch.rand((M, N), dtype=torch.float32, device=dev, generator=gen)
+    rng = None
+    if seed is not None:
+        rng = {'seed': seed, 'proposal0': proposal0, 'chain_offset': chain_offset}
+    else:
+        if v is None:
+            v = torch.randn((M, N, d), dtype=torch.float32, device=dev, generator=gen)
+        if u is None:
+            u = torch.rand((M, N), dtype=torch.float32, device=dev, generator=gen)
+        if direction is None and not dynamics.hmc:
+            direction = torch.randint(0, 2, (M, N), device=dev, dtype=torch.uint8, generator=gen)
     if dynamics.hmc:
         direction = None
-    elif direction is None:
-        direction = torch.randint(0, 2, (M, N), device=dev, dtype=torch.uint8, generator=gen)
-    else:
-        direction = torch.as_tensor(direction, device=dev).to(torch.uint8)
-    v = as_device_f32(v, dev).reshape((M, N, d) if M > 1 else (N, d))
-    u = as_device_f32(u, dev).reshape((M, N) if M > 1 else (N,))
+    if v is not None:
+        v = as_device_f32(v, dev).reshape((M, N, d) if M > 1 else (N, d))
+    if u is not None:
+        u = as_device_f32(u, dev).reshape((M, N) if M > 1 else (N,))
     if direction is not None:
-        direction = direction.reshape((M, N) if M > 1 else (N,))
+        direction = torch.as_tensor(direction, device=dev).to(torch.uint8).reshape((M, N) if M > 1 else (N,))
     want = ('p', 'x_next') + (('x_hist',) if record else ())
     o = dynamics.run(x, v, 0, dynamics.T, direction=direction, direction_all=1, u=u, want=want,
-                     n_proposals=M)
+                     n_proposals=M, rng=rng)
     return o['x_next'], o['p'].reshape(M, N), (o['x_hist'] if record else None)
+
+
+def philox_draws(seed, n_chains, d, nb_proposals, *, proposal0=0, chain_offset=0, device=None):
+    """The (v (M,N,d), direction (M,N) u8, u (M,N)) the in-kernel stream yields (`l2hmc_rng_fill`)."""
+    from .layers import default_device
+    dev = torch.device(device) if device is not None else default_device()
+    M, N = int(nb_proposals), int(n_chains)
+    v = torch.empty((M, N, d), dtype=torch.float32, device=dev)
+    dr = torch.empty((M, N), dtype=torch.uint8, device=dev)
+    u = torch.empty((M, N), dtype=torch.float32, device=dev)
+    _ffi.check(_ffi.lib().l2hmc_rng_fill(int(seed) & 0xFFFFFFFFFFFFFFFF, int(proposal0), int(chain_offset),
+                                         N, int(d), M, v.data_ptr(), dr.data_ptr(), u.data_ptr(),
+                                         _ffi.current_stream(dev)))
+    return v, dr, u

@@ -406,3 +406,59 @@ def acl_spectrum(X, scale):
 def ESS(A):
     A = A * (A > 0.05)
     return 1. / (1. + 2 * np.sum(A[1:]))
+
+
+# --------------------------------------------------------------------------------------------
+# Counter-based randomness of the sampler loop (not in the reference, which uses TF's streams:
+# dynamics.py:247-250, sampler.py:34,54).  Philox4x32-10 as published (Salmon, Moraes, Dror,
+# Shaw, SC'11; constants as in Random123).  Known-answer vectors: tests/test_oracle_golden.py.
+# --------------------------------------------------------------------------------------------
+def philox4x32_10(c, k0, k1):
+    """c: (..., 4) uint32 counters; k0, k1: uint32 key words -> (..., 4) uint32."""
+    c = np.asarray(c, dtype=np.uint64).copy()
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M0, M1, m32 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[..., 0], M1 * c[..., 2]
+        n = np.stack([(p1 >> np.uint64(32)) ^ c[..., 1] ^ k0, p1 & m32,
+                      (p0 >> np.uint64(32)) ^ c[..., 3] ^ k1, p0 & m32], axis=-1)
+        c = n & m32
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c.astype(np.uint32)
+
+
+def philox_draws(seed, n_chains, d, nb_proposals, proposal0=0, chain_offset=0):
+    """(v (M,N,d) f32, direction (M,N) u8, u (M,N) f32) of the in-kernel stream: counter =
+    (global chain, dim // 4, proposal lo, (proposal hi << 1) | stream); 24-bit uniforms,
+    Box-Muller pairs (float32 arithmetic)."""
+    M, N = int(nb_proposals), int(n_chains)
+    nblk = (d + 3) // 4
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    prop = proposal0 + np.arange(M, dtype=np.uint64)
+    gch = (chain_offset + np.arange(N, dtype=np.int64)).astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    plo, phi = prop & np.uint64(0xFFFFFFFF), (prop >> np.uint64(32)) << np.uint64(1)
+    c = np.zeros((M, N, nblk, 4), dtype=np.uint64)
+    c[..., 0] = gch[None, :, None]
+    c[..., 1] = np.arange(nblk, dtype=np.uint64)[None, None, :]
+    c[..., 2] = plo[:, None, None]
+    c[..., 3] = phi[:, None, None]
+    r = philox4x32_10(c, k0, k1)
+    k = np.float32(2.0 ** -24)
+    u1 = ((r[..., 0] >> 8) + 1).astype(np.float32) * k
+    u2 = (r[..., 1] >> 8).astype(np.float32) * k
+    u3 = ((r[..., 2] >> 8) + 1).astype(np.float32) * k
+    u4 = (r[..., 3] >> 8).astype(np.float32) * k
+    two_pi = np.float32(6.283185307179586)
+    ra, rb = np.sqrt(np.float32(-2.0) * np.log(u1)), np.sqrt(np.float32(-2.0) * np.log(u3))
+    z = np.stack([ra * np.cos(two_pi * u2), ra * np.sin(two_pi * u2),
+                  rb * np.cos(two_pi * u4), rb * np.sin(two_pi * u4)], axis=-1).astype(np.float32)
+    v = z.reshape(M, N, nblk * 4)[:, :, :d].copy()
+    c1 = np.zeros((M, N, 4), dtype=np.uint64)
+    c1[..., 0] = gch[None, :]
+    c1[..., 2] = plo[:, None]
+    c1[..., 3] = phi[:, None] | np.uint64(1)
+    r1 = philox4x32_10(c1, k0, k1)
+    direction = (r1[..., 0] & 1).astype(np.uint8)
+    u = (r1[..., 1] >> 8).astype(np.float32) * k
+    return v, direction, u

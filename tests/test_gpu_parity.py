@@ -354,3 +354,37 @@ def test_l2hmc_sampler_leaves_target_invariant():
     assert 0.05 < acc < 0.98                      # the nets really perturb the dynamics
     assert np.abs(emp - cov).max() < 0.08         # ~4 sigma of the sampling error at N=16384
     assert np.abs(to_np(xf).mean(0)).max() < 0.05
+
+
+def test_in_kernel_philox_matches_oracle_stream():
+    """K6: the draws of the in-kernel stream == the oracle's Philox restatement (integers exact,
+    Box-Muller normals to float32 rounding), for any sharding of the chains."""
+    from l2hmc_amd.sampler import philox_draws
+    v, dr, u = philox_draws(99, 200, 50, 4)
+    rv, rd, ru = O.philox_draws(99, 200, 50, 4)
+    assert np.array_equal(to_np(dr), rd) and np.array_equal(to_np(u), ru)
+    assert np.allclose(to_np(v), rv, rtol=0, atol=2e-6)
+    v2, d2, u2 = philox_draws(99, 100, 50, 2, proposal0=2, chain_offset=100)
+    assert np.array_equal(to_np(v2), to_np(v)[2:, 100:]) and np.array_equal(to_np(u2), to_np(u)[2:, 100:])
+
+
+@pytest.mark.parametrize("case", ["icg50", "scg2d", "scg2d_hmc"])
+def test_sample_chain_with_in_kernel_rng(case):
+    """seed= : the sampler loop draws v / direction / u itself; identical to injecting the
+    stream's draws, for both kernel geometries and for sharded chains."""
+    import torch
+    from l2hmc_amd import sample_chain
+    from l2hmc_amd.sampler import philox_draws
+    g = load(case)
+    N, d, M = g["x"].shape[0], int(g["x_dim"]), 5
+    hmc = bool(int(g["hmc"]))
+    v, dr, u = philox_draws(2024, N, d, M)
+    ref = None
+    for var in variants(g):
+        dyn = hip_dynamics(g, var)
+        xf, p, xh = sample_chain(to_dev(g["x"]), dyn, M, seed=2024, record=True)
+        xi, pi, xhi = sample_chain(to_dev(g["x"]), dyn, M, v=v, u=u, direction=None if hmc else dr, record=True)
+        assert torch.equal(p, pi) and torch.equal(xf, xi) and torch.equal(xh, xhi), (case, var)
+        lo = 16 * (N // 32)
+        xs, ps, _ = sample_chain(to_dev(g["x"][lo:]), dyn, M, seed=2024, chain_offset=lo)
+        assert torch.equal(ps, p[:, lo:]) and torch.equal(xs, xf[lo:])

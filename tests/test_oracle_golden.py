@@ -136,3 +136,24 @@ def test_ess_helpers():
     assert A.shape == (49,)
     assert abs(A[0] - np.mean(np.sum(X * X, axis=(1, 2)) / 8)) < 1e-12
     assert 0 < O.ESS(A / A[0]) <= 1.0 + 1e-9
+
+
+def test_philox_known_answers():
+    """Philox4x32-10 known-answer vectors published with Random123 (kat_vectors: counters/keys
+    all-zero, all-ones, and the pi digits)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        got = O.philox4x32_10(np.array(c, dtype=np.uint32), k[0], k[1])
+        assert tuple(int(g) for g in got) == want
+
+
+def test_philox_draws_are_sharding_invariant_and_standard():
+    v, dr, u = O.philox_draws(1234, 64, 7, 5)
+    v2, dr2, u2 = O.philox_draws(1234, 32, 7, 3, proposal0=2, chain_offset=32)
+    assert np.array_equal(v[2:, 32:], v2) and np.array_equal(dr[2:, 32:], dr2) and np.array_equal(u[2:, 32:], u2)
+    vb, db, ub = O.philox_draws(7, 4096, 8, 8)
+    assert abs(vb.mean()) < 0.01 and abs(vb.std() - 1) < 0.01 and abs(db.mean() - 0.5) < 0.02
+    assert 0 <= ub.min() and ub.max() < 1 and abs(ub.mean() - 0.5) < 0.01
