@@ -8,8 +8,9 @@ select; the chain state carries over from step to step.  Steps are issued throug
 persistent sampler kernel, `--proposals-per-launch` (default 25) chained proposals per launch
 (the notebook's per-step sess.run loop, raw 288-298, without the host round trip);
 `--proposals-per-launch 1` gives one launch per step.
-Synthetic inputs (seeded weights, masks, start points and the per-step random draws
-v / direction / u) are resident in HBM before the timed region.
+Synthetic inputs (seeded weights, masks, start points) are resident in HBM before the timed
+region; the per-step random draws v / direction / u come from the in-kernel Philox stream
+(`--rng bank`: pre-generated in HBM instead).
 
     python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torchrun)
 
@@ -142,6 +143,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--rng", choices=["philox", "bank"], default="philox",
+                    help="philox: momenta / direction / accept uniforms drawn in-kernel (counter-based, "
+                         "keyed by global chain index); bank: pre-generated draws read from HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true", help="skip the SCG-2D ESS/sec leg (N=1 only)")
     ap.add_argument("--bank", type=int, default=0,
@@ -186,9 +190,10 @@ def main():
     M = max(1, args.proposals_per_launch)
     B = args.bank if args.bank > 0 else max(16, 2 * M)
     B = (B + M - 1) // M * M
-    v_bank = torch.randn(B, n, D, device=dev, generator=gen)
-    d_bank = torch.randint(0, 2, (B, n), device=dev, dtype=torch.uint8, generator=gen)
-    u_bank = torch.rand(B, n, device=dev, generator=gen)
+    if args.rng == "bank":
+        v_bank = torch.randn(B, n, D, device=dev, generator=gen)
+        d_bank = torch.randint(0, 2, (B, n), device=dev, dtype=torch.uint8, generator=gen)
+        u_bank = torch.rand(B, n, device=dev, generator=gen)
 
     L = _ffi.lib()
     a = _ffi.L2hmcTrajectoryArgs()
@@ -215,9 +220,13 @@ def main():
             b = 0
         a.n_proposals = count
         a.x, a.x_next = src.data_ptr(), dst.data_ptr()
-        a.v = v_bank[b].data_ptr()
-        a.direction = d_bank[b].data_ptr()
-        a.u = u_bank[b].data_ptr()
+        if args.rng == "philox":
+            a.rng_flags, a.rng_seed = _ffi.RNG_V | _ffi.RNG_DIR | _ffi.RNG_U, 20260926
+            a.rng_proposal0, a.chain_offset = first, rank * n
+        else:
+            a.v = v_bank[b].data_ptr()
+            a.direction = d_bank[b].data_ptr()
+            a.u = u_bank[b].data_ptr()
         rc = L.l2hmc_trajectory(a, stream)
         if rc:
             _ffi.check(rc)
@@ -268,7 +277,7 @@ def main():
             "config": {"workload": "ICG-50D (ill-conditioned Gaussian d=50), %d chains per GPU, Lf=10, "
                                    "S/T/Q nets H=10, direction-mixed propose + MH per step" % n,
                        "chains_per_gpu": n, "x_dim": D, "hidden": H, "leapfrog_steps": T,
-                       "proposals_per_launch": M,
+                       "proposals_per_launch": M, "rng": args.rng,
                        "parallelism": "chains sharded, no data-path collective",
                        "mean_accept_prob": mean_p, "state_finite": finite},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
