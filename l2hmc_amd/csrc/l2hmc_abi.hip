@@ -172,6 +172,8 @@ long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW, int DT)
   if (with_schedule) o += (long long)k.T * DP;
   k.o_trig = (int)o;
   if (with_schedule) o += round4(2 * k.T);
+  k.o_tb = (int)o;
+  if (with_schedule) o += 2LL * k.T * 16;
   k.o_P = (int)o;
   if (NW > 1) o += 2LL * NW * 2 * 256;   // 2 buffers x NW waves x 2 partial vectors
   k.xb_stride = DP + 4;

@@ -89,7 +89,7 @@ struct KArgs {
   const float *x1, *v1, *logjac_in;
   float *U_out, *grad_out;
   // LDS offsets (floats)
-  int o_mask, o_trig, o_P, o_XB, o_red, o_mu, o_prec, o_logc, xb_stride;
+  int o_mask, o_trig, o_tb, o_P, o_XB, o_red, o_mu, o_prec, o_logc, xb_stride;
   unsigned long long* dbg;   // phase-timing buffer (profiling builds only, else NULL)
 };
 
@@ -461,7 +461,6 @@ __device__ __forceinline__ void xchg(f4 (&p)[NP], const KArgs& A, float* smem, i
 template <int DT>
 struct TailW {
   static constexpr int NH = DT <= 2 ? DT : 1;
-  float tau;
   f4 w2;
   f4 hs[NH], ht[NH], hq[NH], es[NH], eq[NH];
   const float* wn;
@@ -473,7 +472,6 @@ __device__ __forceinline__ void load_tail(TailW<DT>& tw, const float* wn, const 
                                           int lane) {
   const int NT = A.NT, q = lane >> 4;
   tw.wn = wn; tw.NT = NT; tw.w = w; tw.lane = lane;
-  tw.tau = wn[(2 * NT * 64 + lane) * 4];
   tw.w2 = lds4(wn + ((2 * NT + 1) * 64 + lane) * 4);
   const float* sc = wn + net_groups(NT) * 256;
   if constexpr (DT > 2) return;
@@ -492,15 +490,17 @@ __device__ __forceinline__ void load_tail(TailW<DT>& tw, const float* wn, const 
   }
 }
 
-// h1 = relu(hpre + tau/bias k-step); h2 = relu(W4^T h1); heads.  The heads' nonlinearities are
+// h1 = relu(hpre + tau/bias term); h2 = relu(W4^T h1); heads.  The heads' nonlinearities are
 // emitted in "folded" form: with kS = (+-)eps log2(e) (eps/2 for VNet) and kQ = eps log2(e),
 //   aS = kS e^{lam_s} tanh(z_s)   (= log2 of the scale factor; sums to the log-det / ln 2)
 //   ES = 2^{aS} = exp(+-eps S),   EQ = 2^{kQ e^{lam_q} tanh(z_q)} = exp(eps Q),   T = z_t
 // `apply(t, ES, aS, T, EQ)` consumes one 16-dimension tile at a time.
 template <int DT, int KH, class F>
-__device__ __forceinline__ void net_tail(const TailW<DT>& tw, f4 hpre, float tauB, float kS,
+__device__ __forceinline__ void net_tail(const TailW<DT>& tw, f4 hpre, f4 tb, float kS,
                                          float kQ, F&& apply) {
-  f4 h = relu4(MFMA16(tw.tau, tauB, hpre));
+  // tb = W3^T tau + (b1 + b2 + b3) for this chain's schedule row: a per-(net, row) table built
+  // once per launch (it is the same for every chain), so no tau k-step MFMA on the critical path
+  f4 h = relu4(hpre + tb);
   {
     f4 acc = splat(0.f);
 #pragma unroll
@@ -661,6 +661,17 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
 
   const float* wx = WG ? A.packed : smem;   // XNet fragments
   const float* wv = wx + NF;                // VNet fragments
+  if (has_nets) {
+    // time-embedding table TB[net][row s][unit row i] = W3[0,u] cos_s + W3[1,u] sin_s + b1+b2+b3
+    // from the packed tau fragment (lane (i, q): q = 0 -> W3[0], 1 -> W3[1], 2 -> biases)
+    for (int idx = tid; idx < 2 * A.T * 16; idx += nthr) {
+      const int net = idx / (A.T * 16), srow = (idx / 16) % A.T, i = idx & 15;
+      const float* tf = (net == 0 ? wx : wv) + (2 * NT * 64) * 4;
+      const float ct = smem[A.o_trig + 2 * srow], st = smem[A.o_trig + 2 * srow + 1];
+      smem[A.o_tb + idx] = fmaf(tf[i * 4], ct, fmaf(tf[(16 + i) * 4], st, tf[(32 + i) * 4]));
+    }
+    __syncthreads();
+  }
   int pb = 0;
   const f4 Z = splat(0.f);
   float U_start;                 // this lane's share of U at the current state
@@ -734,12 +745,10 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
 
   // schedule row of this chain at iteration `it`: forward chains walk 0..T-1, backward T-1..0
   auto row_of = [&](int it) { const int sf = A.step_begin + it; return fwd ? sf : (A.T - 1 - sf); };
-  // tau operand (k = q: [cos, sin, 1, 0]) and the first-kept mask of that row; both are
-  // PREFETCHED one step ahead so their LDS latency never sits on the critical path
-  auto tau_of = [&](int s) {
-    const float ct = smem[A.o_trig + 2 * s], st = smem[A.o_trig + 2 * s + 1];
-    return q == 0 ? ct : (q == 1 ? st : (q == 2 ? 1.f : 0.f));
-  };
+  // time-embedding terms (XNet, VNet) and the first-kept mask of that row; all are PREFETCHED
+  // one step ahead so their LDS latency never sits on the critical path
+  auto tbx_of = [&](int s) { return lds4(smem + A.o_tb + s * 16 + 4 * q); };
+  auto tbv_of = [&](int s) { return lds4(smem + A.o_tb + (A.T + s) * 16 + 4 * q); };
   auto mask_of = [&](int s, f4 (&k)[DT]) {
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
@@ -749,23 +758,23 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
     }
   };
   f4 k1[DT], k1n[DT];
-  float tauB = 0.f, tauN = 0.f;
+  f4 tbx = Z, tbv = Z, tbxn = Z, tbvn = Z;
   if (A.n_steps > 0) {
-    tauB = tau_of(row_of(0));
+    if (has_nets) { tbx = tbx_of(row_of(0)); tbv = tbv_of(row_of(0)); }
     mask_of(row_of(0), k1);
   }
 
   for (int it = 0; it < A.n_steps; ++it) {
     f4 xin[DT], y[DT], vh[DT];
     if (it + 1 < A.n_steps) {                 // prefetch the next step's schedule row
-      tauN = tau_of(row_of(it + 1));
+      if (has_nets) { tbxn = tbx_of(row_of(it + 1)); tbvn = tbv_of(row_of(it + 1)); }
       mask_of(row_of(it + 1), k1n);
     }
 
     if (has_nets) {
       PT_MARK(1);  // step head
       // ---- momentum half-update #1: VNet([x, grad U(x), t])  (dynamics.py:118-125 / :162-170)
-      net_tail<DT, KH>(tw, pv[0], tauB, kSv, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+      net_tail<DT, KH>(tw, pv[0], tbv, kSv, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
         vh[t] = v_half(v[t], g[t], ES, aS, T, EQ, heps, fwd, ld);
       });
       PT_MARK(2);  // VNet tail #1
@@ -781,7 +790,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
       PT_MARK(3);  // XNet layer-1 partials (a, b)
       xchg<NW, 2>(px, A, smem, w, lane, pb);
       PT_MARK(4);  // exchange
-      net_tail<DT, KH>(tw, px[0] + px[1], tauB, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+      net_tail<DT, KH>(tw, px[0] + px[1], tbx, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
         y[t] = x_half(x[t], k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ld);
       });
       PT_MARK(5);  // XNet tail #1
@@ -792,7 +801,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
       PT_MARK(6);  // XNet layer-1 partial (b only)
       xchg<NW, 1>(py, A, smem, w, lane, pb);
       PT_MARK(7);  // exchange
-      net_tail<DT, KH>(tw, px[0] + py[0], tauB, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+      net_tail<DT, KH>(tw, px[0] + py[0], tbx, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
         x[t] = x_half(y[t], O - k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ld);
       });
       PT_MARK(8);  // XNet tail #2
@@ -805,7 +814,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
       PT_MARK(9);  // grad U + VNet layer-1 partials
       xchg<NW, 1>(pv, A, smem, w, lane, pb);
       PT_MARK(10); // exchange
-      net_tail<DT, KH>(tw, pv[0], tauB, kSv, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+      net_tail<DT, KH>(tw, pv[0], tbv, kSv, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
         v[t] = v_half(vh[t], g[t], ES, aS, T, EQ, heps, fwd, ld);
       });
       PT_MARK(11); // VNet tail #2
@@ -821,7 +830,8 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
 #pragma unroll
       for (int t = 0; t < DT; ++t) v[t] = v_half(vh[t], g[t], O, Z, Z, O, heps, fwd, ld);
     }
-    tauB = tauN;
+    tbx = tbxn;
+    tbv = tbvn;
 #pragma unroll
     for (int t = 0; t < DT; ++t) k1[t] = k1n[t];
   }
