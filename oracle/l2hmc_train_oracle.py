@@ -1,0 +1,216 @@
+"""CPU oracle for the L2HMC training gradient -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Hand-derived reverse mode of the notebook's training loss (SCGExperiment.ipynb raw lines
+156-169: two direction-mixed proposals, sampler.py:28-51, ESJD-style loss) through the
+generalised leapfrog trajectory (dynamics.py:115-201, 246-309), including the
+Hessian-vector path through `grad_energy` (TF1 differentiates through `tf.gradients`).
+Gaussian targets only (Hessian = (S + S^T)/2).  The HIP training kernel follows exactly this
+derivation; this file is pinned against gradients produced by the reference's own graph under
+oracle/tf1_stub.py (tests/golden/train_*.npz, tests/test_oracle_golden.py).
+
+Per chain the trajectory runs only in its drawn direction (the reference's other direction
+carries a zero mixing weight, hence a zero gradient).
+"""
+import numpy as np
+
+from oracle.l2hmc_oracle import NET_KEYS, format_time
+
+
+def _net_fwd(net, a, b, tau):
+    h1p = a @ net['W1'] + net['b1'] + b @ net['W2'] + net['b2'] + tau @ net['W3'] + net['b3']
+    h1 = np.maximum(h1p, 0)
+    h2p = h1 @ net['W4'] + net['b4']
+    h2 = np.maximum(h2p, 0)
+    ts, tq = np.tanh(h2 @ net['Ws'] + net['bs']), np.tanh(h2 @ net['Wq'] + net['bq'])
+    es, eq = np.exp(net['lam_s']), np.exp(net['lam_q'])
+    S, T, Q = es * ts, h2 @ net['Wt'] + net['bt'], eq * tq
+    return (S, T, Q), dict(a=a, b=b, tau=tau, h1=h1, h2=h2, ts=ts, tq=tq, es=es, eq=eq, S=S, Q=Q)
+
+
+def _net_bwd(net, c, dS, dT, dQ, grad):
+    """Accumulates parameter gradients into `grad` (dict like NET_KEYS); returns (d a, d b)."""
+    dzs = dS * c['es'] * (1 - c['ts'] ** 2)
+    dzq = dQ * c['eq'] * (1 - c['tq'] ** 2)
+    dzt = dT
+    grad['lam_s'] += np.sum(dS * c['S'], axis=0, keepdims=True)
+    grad['lam_q'] += np.sum(dQ * c['Q'], axis=0, keepdims=True)
+    for W, b, dz in (('Ws', 'bs', dzs), ('Wt', 'bt', dzt), ('Wq', 'bq', dzq)):
+        grad[W] += c['h2'].T @ dz
+        grad[b] += dz.sum(0)
+    dh2 = dzs @ net['Ws'].T + dzt @ net['Wt'].T + dzq @ net['Wq'].T
+    da2 = dh2 * (c['h2'] > 0)
+    grad['W4'] += c['h1'].T @ da2
+    grad['b4'] += da2.sum(0)
+    da1 = (da2 @ net['W4'].T) * (c['h1'] > 0)
+    grad['W1'] += c['a'].T @ da1
+    grad['W2'] += c['b'].T @ da1
+    grad['W3'] += c['tau'].T @ da1
+    for b in ('b1', 'b2', 'b3'):
+        grad[b] += da1.sum(0)
+    return da1 @ net['W1'].T, da1 @ net['W2'].T
+
+
+def _v_half(vin, g, S, T, Q, eps, sgn, fwd):
+    ES, EQ = np.exp(sgn * 0.5 * eps * S), np.exp(eps * Q)
+    cc = 0.5 * eps * (T - EQ * g)
+    return np.where(fwd, vin * ES + cc, (vin - cc) * ES), (ES, EQ, cc)
+
+
+def _v_half_bwd(dout, lam_ld, vin, g, S, T, Q, eps, sgn, fwd, aux):
+    ES, EQ, cc = aux
+    dvin = dout * ES
+    dES = np.where(fwd, dout * vin, dout * (vin - cc))
+    dcc = np.where(fwd, dout, -dout * ES)
+    ds = dES * ES + lam_ld
+    dS = ds * sgn * 0.5 * eps
+    deps = np.sum(ds * sgn * 0.5 * S, axis=1)
+    dT = dcc * 0.5 * eps
+    dEQ = -dcc * 0.5 * eps * g
+    dg = -dcc * 0.5 * eps * EQ
+    deps += np.sum(dcc * 0.5 * (T - EQ * g), axis=1)
+    dq = dEQ * EQ
+    deps += np.sum(dq * Q, axis=1)
+    return dvin, dg, dS, dT, dq * eps, deps
+
+
+def _x_half(zin, kp, vh, S, T, Q, eps, sgn, fwd):
+    ES, EQ = np.exp(sgn * eps * S), np.exp(eps * Q)
+    tr = eps * (EQ * vh + T)
+    nw = np.where(fwd, zin * ES + tr, ES * (zin - tr))
+    return kp * zin + (1 - kp) * nw, (ES, EQ, tr)
+
+
+def _x_half_bwd(dout, lam_ld, zin, kp, vh, S, T, Q, eps, sgn, fwd, aux):
+    ES, EQ, tr = aux
+    up = 1 - kp
+    dnw = up * dout
+    dzin = kp * dout + dnw * ES
+    dES = np.where(fwd, dnw * zin, dnw * (zin - tr))
+    dtr = np.where(fwd, dnw, -dnw * ES)
+    dsx = dES * ES + up * lam_ld
+    dS = dsx * sgn * eps
+    deps = np.sum(dsx * sgn * S, axis=1)
+    dEQ = dtr * eps * vh
+    dvh = dtr * eps * EQ
+    dT = dtr * eps
+    deps += np.sum(dtr * (EQ * vh + T), axis=1)
+    dq = dEQ * EQ
+    deps += np.sum(dq * Q, axis=1)
+    return dzin, dvh, dS, dT, dq * eps, deps
+
+
+def propose_loss_and_grad(x0, v0, direction, mu, i_sigma, xnet, vnet, eps, mask, T, scale=0.1,
+                          dtype=np.float64):
+    """One direction-mixed proposal from x0 with momenta v0 (each chain in its own direction) and
+    its loss term  scale * mean(1/v1) - mean(v1)/scale,  v1 = |x0 - Lx|^2 p + 1e-4  (nb 164-169).
+    Returns (loss, Lx, p, grads) with grads = {'xnet': {...}, 'vnet': {...}, 'eps': d loss/d eps}."""
+    x0, v0 = np.asarray(x0, dtype), np.asarray(v0, dtype)
+    N, d = x0.shape
+    mu = np.asarray(mu, np.float32).astype(dtype)
+    Sm = np.asarray(i_sigma, np.float32).astype(dtype)
+    G = 0.5 * (Sm + Sm.T)
+    xn = {k: np.asarray(xnet[k], np.float32).astype(dtype) for k in NET_KEYS}
+    vn = {k: np.asarray(vnet[k], np.float32).astype(dtype) for k in NET_KEYS}
+    eps = dtype(eps)
+    mask = np.asarray(mask, dtype)
+    fwd = (np.asarray(direction) != 0)[:, None]
+    sgn = np.where(fwd, 1.0, -1.0).astype(dtype)
+    taus = np.stack([format_time(t, T, np.float32) for t in range(T)]).astype(dtype)
+
+    def gradU(x):
+        return (x - mu) @ G
+
+    def energy(x):
+        dx = x - mu
+        return 0.5 * np.sum((dx @ Sm) * dx, axis=1)
+
+    # ---- forward, keeping what the reverse sweep needs ------------------------------------------
+    x, v = x0, v0
+    ld = np.zeros(N, dtype)
+    tape = []
+    for it in range(T):
+        srow = np.where(fwd[:, 0], it, T - 1 - it)
+        tau, m = taus[srow], mask[srow]
+        k1 = np.where(fwd, m, 1 - m)
+        k2 = 1 - k1
+        g1 = gradU(x)
+        (S1, T1, Q1), c1 = _net_fwd(vn, x, g1, tau)
+        vh, a1 = _v_half(v, g1, S1, T1, Q1, eps, sgn, fwd)
+        (Sa, Ta, Qa), ca = _net_fwd(xn, vh, k1 * x, tau)
+        y, aa = _x_half(x, k1, vh, Sa, Ta, Qa, eps, sgn, fwd)
+        (Sb, Tb, Qb), cb = _net_fwd(xn, vh, k2 * y, tau)
+        xo, ab = _x_half(y, k2, vh, Sb, Tb, Qb, eps, sgn, fwd)
+        g2 = gradU(xo)
+        (S2, T2, Q2), c2 = _net_fwd(vn, xo, g2, tau)
+        vo, a2 = _v_half(vh, g2, S2, T2, Q2, eps, sgn, fwd)
+        ld = ld + np.sum(sgn * 0.5 * eps * (S1 + S2) + k2 * sgn * eps * Sa + k1 * sgn * eps * Sb, axis=1)
+        tape.append(dict(x=x, v=v, k1=k1, k2=k2, g1=g1, c1=c1, a1=a1, vh=vh, ca=ca, aa=aa, y=y,
+                         cb=cb, ab=ab, xo=xo, g2=g2, c2=c2, a2=a2,
+                         out=((S1, T1, Q1), (Sa, Ta, Qa), (Sb, Tb, Qb), (S2, T2, Q2))))
+        x, v = xo, vo
+    val = (energy(x0) + 0.5 * np.sum(v0 * v0, 1)) - (energy(x) + 0.5 * np.sum(v * v, 1)) + ld
+    with np.errstate(all='ignore'):
+        p = np.exp(np.minimum(val, 0.0))
+    finite = np.isfinite(p)
+    p = np.where(finite, p, 0.0)
+    sq = np.sum((x0 - x) ** 2, axis=1)
+    v1 = sq * p + 1e-4
+    loss = scale * np.mean(1.0 / v1) - np.mean(v1) / scale
+
+    # ---- reverse sweep ---------------------------------------------------------------------------
+    dv1 = (scale * (-1.0 / v1 ** 2) - 1.0 / scale) / N
+    dp = dv1 * sq
+    dval = np.where(finite & (val < 0), dp * p, 0.0)
+    lx = (dv1 * p)[:, None] * 2 * (x - x0) - dval[:, None] * gradU(x)
+    lv = -dval[:, None] * v
+    lam_ld = dval[:, None]
+    gx = {k: np.zeros_like(xn[k]) for k in NET_KEYS}
+    gv = {k: np.zeros_like(vn[k]) for k in NET_KEYS}
+    deps = np.zeros(N, dtype)
+    for it in reversed(range(T)):
+        t = tape[it]
+        (S1, T1, Q1), (Sa, Ta, Qa), (Sb, Tb, Qb), (S2, T2, Q2) = t['out']
+        # v' = v_half(vh, g2, V(x', g2))
+        dvh, dg2, dS, dT, dQ, de = _v_half_bwd(lv, lam_ld, t['vh'], t['g2'], S2, T2, Q2, eps, sgn, fwd, t['a2'])
+        deps += de
+        da, db = _net_bwd(vn, t['c2'], dS, dT, dQ, gv)
+        dxo = lx + da + (dg2 + db) @ G
+        # x' = x_half(y, k2, vh, X(vh, k2 y))
+        dy, dvh2, dS, dT, dQ, de = _x_half_bwd(dxo, lam_ld, t['y'], t['k2'], t['vh'], Sb, Tb, Qb, eps, sgn, fwd, t['ab'])
+        deps += de
+        da, db = _net_bwd(xn, t['cb'], dS, dT, dQ, gx)
+        dvh = dvh + dvh2 + da
+        dy = dy + t['k2'] * db
+        # y = x_half(x, k1, vh, X(vh, k1 x))
+        dx, dvh2, dS, dT, dQ, de = _x_half_bwd(dy, lam_ld, t['x'], t['k1'], t['vh'], Sa, Ta, Qa, eps, sgn, fwd, t['aa'])
+        deps += de
+        da, db = _net_bwd(xn, t['ca'], dS, dT, dQ, gx)
+        dvh = dvh + dvh2 + da
+        dx = dx + t['k1'] * db
+        # vh = v_half(v, g1, V(x, g1))
+        dv, dg1, dS, dT, dQ, de = _v_half_bwd(dvh, lam_ld, t['v'], t['g1'], S1, T1, Q1, eps, sgn, fwd, t['a1'])
+        deps += de
+        da, db = _net_bwd(vn, t['c1'], dS, dT, dQ, gv)
+        lx = dx + da + (dg1 + db) @ G
+        lv = dv
+    return loss, x, p, {'xnet': gx, 'vnet': gv, 'eps': float(np.sum(deps))}
+
+
+def training_loss_and_grad(g, dtype=np.float64):
+    """Full notebook loss on a golden-shaped dict `g` (x with its draws + z with its draws):
+    returns (loss, grads keyed like the golden: 'xnet.W1', ..., 'alpha')."""
+    xn = {k: g['xnet.' + k] for k in NET_KEYS}
+    vn = {k: g['vnet.' + k] for k in NET_KEYS}
+    total, out = 0.0, {}
+    for tag, start in (('x', g['x']), ('z', g['z'])):
+        dr = g[tag + '.dir']
+        v0 = np.where(dr[:, None] != 0, g[tag + '.v_fwd'], g[tag + '.v_bwd'])
+        loss, Lx, p, gr = propose_loss_and_grad(start, v0, dr, g['energy.mu'], g['energy.i_sigma'], xn, vn,
+                                                g['eps'], g['mask'], int(g['T']), dtype=dtype)
+        total += loss
+        for net in ('xnet', 'vnet'):
+            for k in NET_KEYS:
+                out[net + '.' + k] = out.get(net + '.' + k, 0) + gr[net][k]
+        out['alpha'] = out.get('alpha', 0.0) + gr['eps'] * float(g['eps'])     # eps = exp(alpha)
+        out['L' + tag], out['p' + tag] = Lx, p
+    return total, out

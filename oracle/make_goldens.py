@@ -189,6 +189,62 @@ def run_case(name, x_dim, H, T, eps, N, energy_fn, energy_params, seed, hmc=Fals
         name, N, x_dim, T, out['fwd.p'].mean(), out['bwd.p'].mean(), np.abs(out['fwd.x']).max()))
 
 
+def train_case(name, mu, cov, H, T, eps, N, seed, head_std=0.3):
+    """Gradient of the notebook's training loss (SCGExperiment.ipynb raw lines 156-169) w.r.t. every
+    variable, produced by the reference's own graph (propose on x with MH + propose on z,
+    sampler.py:28-51) differentiated by the stub's tf.gradients (= torch autograd)."""
+    tf1_stub.reset(seed)
+    np.random.seed(seed)
+    tf1_stub.VARIABLE_HOOK = variable_hook_factory(seed + 1, head_std)
+    x_dim = len(mu)
+    with contextlib.redirect_stdout(io.StringIO()):
+        dist = ref_distributions.Gaussian(np.asarray(mu, dtype=np.float64), np.asarray(cov, dtype=np.float64))
+        dyn = ref_dynamics.Dynamics(x_dim, dist.get_energy_function(), T=T, eps=eps, net_factory=make_network(H))
+    out = {'energy.kind': 'gaussian', 'energy.mu': dist.mu.astype(np.float32),
+           'energy.i_sigma': dist.i_sigma.astype(np.float32), 'case': name, 'x_dim': x_dim, 'H': H,
+           'T': T, 'N': N, 'hmc': 0, 'eps': npy(dyn.eps), 'mask': npy(dyn.mask)}
+    names = []
+    for full, val in tf1_stub.VARIABLES.items():
+        if full == 'alpha':
+            continue
+        scope, rest = full.split('/', 1)
+        out['%s.%s' % (scope.lower(), TF2KEY[rest])] = npy(val)
+        names.append((full, '%s.%s' % (scope.lower(), TF2KEY[rest])))
+    rng = np.random.RandomState(seed + 2)
+    C = np.linalg.cholesky(np.asarray(cov))
+    x = (rng.randn(N, x_dim) @ C.T + np.asarray(mu)).astype(np.float32)
+    z = rng.randn(N, x_dim).astype(np.float32)
+    out['x'], out['z'] = x, z
+    del tf1_stub.RANDOM_LOG[:]
+    xt, zt = leaf(x), leaf(z)
+    Lx, _, px, output = ref_sampler.propose(xt, dyn, do_mh_step=True)
+    Lz, _, pz, _ = ref_sampler.propose(zt, dyn, do_mh_step=False)
+    log = list(tf1_stub.RANDOM_LOG)
+    kinds = [k for k, _ in log]
+    assert kinds == ['randint', 'normal', 'normal', 'uniform', 'randint', 'normal', 'normal'], kinds
+    out['x.dir'], out['x.v_fwd'], out['x.v_bwd'], out['x.u'] = log[0][1][:, 0].astype(np.uint8), log[1][1], log[2][1], log[3][1]
+    out['z.dir'], out['z.v_fwd'], out['z.v_bwd'] = log[4][1][:, 0].astype(np.uint8), log[5][1], log[6][1]
+    # nb raw 164-169
+    v1 = (tf.reduce_sum(tf.square(xt - Lx), axis=1) * px) + 1e-4
+    v2 = (tf.reduce_sum(tf.square(zt - Lz), axis=1) * pz) + 1e-4
+    scale = 0.1
+    loss = scale * (tf.reduce_mean(1.0 / v1) + tf.reduce_mean(1.0 / v2))
+    loss = loss + (- tf.reduce_mean(v1) - tf.reduce_mean(v2)) / scale
+    variables = [tf1_stub.VARIABLES[full] for full, _ in names] + [tf1_stub.VARIABLES['alpha']]
+    grads = tf.gradients(loss, variables)
+    out['loss'] = npy(loss)
+    out['Lx'], out['px'], out['Lz'], out['pz'] = npy(Lx), npy(px), npy(Lz), npy(pz)
+    for (full, key), gr in zip(names, grads[:-1]):
+        out['grad.' + key] = npy(gr)
+    out['grad.alpha'] = npy(grads[-1])
+    assert all(np.all(np.isfinite(out[k])) for k in out if k.startswith('grad.')), 'non-finite gradient'
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    gn = np.sqrt(sum(float(np.sum(out[k].astype(np.float64) ** 2)) for k in out if k.startswith('grad.')))
+    print('%-18s N=%-4d d=%-3d T=%-3d  loss %.4e  |grad| %.3e  grad.alpha %.3e  mean px %.3f pz %.3f' % (
+        name, N, x_dim, T, float(out['loss']), gn, float(out['grad.alpha']), out['px'].mean(), out['pz'].mean()))
+
+
 def gaussian_case(name, mu, cov, **kw):
     with contextlib.redirect_stdout(io.StringIO()):
         dist = ref_distributions.Gaussian(np.asarray(mu, dtype=np.float64), np.asarray(cov, dtype=np.float64))
@@ -216,7 +272,8 @@ def main():
     rng = np.random.RandomState(7)
     R = np.linalg.qr(rng.randn(8, 8))[0]
     cov8 = R.T.dot(np.diag(np.exp(np.log(10.) * rng.uniform(-1, 1, size=8)))).dot(R)
-    gaussian_case('tilted8', rng.randn(8) * 0.5, cov8, H=10, T=7, eps=0.1, N=48, seed=15)
+    rng8_mu = rng.randn(8) * 0.5
+    gaussian_case('tilted8', rng8_mu, cov8, H=10, T=7, eps=0.1, N=48, seed=15)
 
     # C3 shape: 2-component MoG in 2D (paper-style: centres (+-2,0), var 0.1), T=25
     mus = [np.array([2.0, 0.0], dtype=np.float32), np.array([-2.0, 0.0], dtype=np.float32)]
@@ -261,6 +318,11 @@ def main():
     params = {'energy.kind': 'funnel', 'energy.sigma': np.float32(2.0)}
     run_case('funnel3', 3, H=10, T=5, eps=0.05, N=64, energy_fn=fn, energy_params=params,
              seed=22, x0=x0, head_std=0.3)
+
+    # training-loss gradients (next-row f1): SCG (notebook), dense d=8, diagonal ICG d=50
+    train_case('train_scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=64, seed=31)
+    train_case('train_tilted8', rng8_mu, cov8, H=10, T=5, eps=0.1, N=32, seed=32)
+    train_case('train_icg50', np.zeros(50), np.diag(var), H=10, T=4, eps=0.05, N=16, seed=33, head_std=0.05)
 
     # p_accept edge cases (dynamics.py:302-309): +-inf / NaN Hamiltonian differences -> 0
     tf1_stub.reset(0)

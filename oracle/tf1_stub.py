@@ -92,6 +92,8 @@ def get_variable(name, shape=None, initializer=None, trainable=True, dtype=float
         new = VARIABLE_HOOK(full, tuple(val.shape), val)
         if new is not None:
             val = _t(new).reshape(val.shape).clone()
+    if trainable and val.dtype.is_floating_point:
+        val = val.detach().clone().requires_grad_(True)     # so tf.gradients(loss, variables) works
     VARIABLES[full] = val
     return val
 
@@ -192,7 +194,9 @@ def random_uniform(shape, minval=0, maxval=None, dtype=float32, name=None):
 def gradients(ys, xs, name=None):
     single = not isinstance(xs, (list, tuple))
     xs_ = [xs] if single else list(xs)
-    g = torch.autograd.grad(ys.sum(), xs_, retain_graph=True, allow_unused=True)
+    # create_graph: like TF1, an outer tf.gradients differentiates THROUGH this one (the training
+    # loss back-propagates through grad_energy, i.e. needs Hessian-vector products of U)
+    g = torch.autograd.grad(ys.sum(), xs_, retain_graph=True, create_graph=True, allow_unused=True)
     return list(g)
 
 

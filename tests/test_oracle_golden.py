@@ -157,3 +157,21 @@ def test_philox_draws_are_sharding_invariant_and_standard():
     vb, db, ub = O.philox_draws(7, 4096, 8, 8)
     assert abs(vb.mean()) < 0.01 and abs(vb.std() - 1) < 0.01 and abs(db.mean() - 0.5) < 0.02
     assert 0 <= ub.min() and ub.max() < 1 and abs(ub.mean() - 0.5) < 0.01
+
+
+@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50"])
+def test_training_gradient_oracle_matches_reference_graph(case):
+    """oracle/l2hmc_train_oracle.py (hand-derived reverse mode incl. the Hessian-vector path)
+    vs tf.gradients of the notebook loss evaluated by the reference's own graph (stub)."""
+    from oracle import l2hmc_train_oracle as TO
+    g = load(case)
+    loss, out = TO.training_loss_and_grad(g, np.float64)
+    assert abs(loss - float(g["loss"])) < 2e-5 * max(1.0, abs(float(g["loss"])))
+    assert rel_err(out["Lx"], g["Lx"]) < TRAJ_TOL and abs_err(out["px"], g["px"]) < P_TOL
+    scale = max(float(np.abs(g["grad." + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+    for n in ("xnet", "vnet"):
+        for k in O.NET_KEYS:
+            ref = g["grad.%s.%s" % (n, k)]
+            got = np.asarray(out[n + "." + k]).reshape(ref.shape)
+            assert np.abs(got - ref).max() < 2e-5 * scale, (case, n, k)
+    assert abs(out["alpha"] - float(g["grad.alpha"])) < 2e-5 * max(scale, abs(float(g["grad.alpha"])))
