@@ -160,6 +160,43 @@ int l2hmc_p_accept(const L2hmcEnergy* energy, const float* x0, const float* v0,
 int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const float* u,
                     int64_t n_chains, int32_t d, float* x_next, void* stream);
 
+/* ---- training (next-row f1): one proposal + the gradient of its loss term ------------------- */
+/* Loss of SCGExperiment.ipynb raw lines 156-169 for ONE of its two proposals:
+ *   v1_n = |x_n - Lx_n|^2 p_n + 1e-4;   term = scale * mean_n(1 / v1_n) - mean_n(v1_n) / scale
+ * (the notebook adds the term of `propose(x)` and of `propose(z), z ~ N(0, I)`; call twice).
+ * `grad` (l2hmc_train_grad_floats(d, H) floats) is ACCUMULATED (+=): the flat layout is
+ * [XNet | VNet | d/d eps], each net in the field order of L2hmcNet (W1, b1, ..., lam_q);
+ * d/d alpha = eps * d/d eps (dynamics.py:50-58).  inv_n = 1 / (chains over ALL ranks) so that
+ * per-rank gradients simply all-reduce(sum).  The nets are the RAW reference-layout weights
+ * (not the packed buffer); for the dense Gaussian `energy.prec` is the raw (d, d) precision.
+ * Gaussian targets, d <= 64, H <= 16 in this round.  Every chain runs in its own direction. */
+typedef struct L2hmcTrainArgs {
+  const L2hmcNet* xnet;
+  const L2hmcNet* vnet;
+  L2hmcEnergy energy;
+  const float* masks;       /* (T, d)   */
+  const float* trig;        /* (T, 2)   */
+  const float* alpha;       /* device log(eps) or NULL -> eps_host */
+  float eps_host;
+  int64_t n_chains;
+  int32_t d, H, T;
+  const float* x;           /* (N, d) start points                                   */
+  const float* v;           /* (N, d) momenta of each chain's own direction          */
+  const uint8_t* direction; /* (N) or NULL -> direction_all                          */
+  int32_t direction_all;
+  float scale;              /* 0.1 in the notebook                                   */
+  float inv_n;
+  float* Lx;                /* (N, d) proposal                                       */
+  float* p;                 /* (N) accept probability                                */
+  float* v1;                /* (N) per-chain loss argument                           */
+  float* grad;              /* flat gradient, accumulated                            */
+  float* workspace;         /* l2hmc_train_workspace_floats(N, d, T) floats          */
+} L2hmcTrainArgs;
+
+int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t T);
+int64_t l2hmc_train_grad_floats(int32_t d, int32_t H);
+int l2hmc_train_propose_grad(const L2hmcTrainArgs* args, void* stream);
+
 /* The draws the sampler loop would use, written out ((M,N,d) normals, (M,N) direction bits,
  * (M,N) uniforms; any output may be NULL): for tests, and for reproducing a run's randomness. */
 int l2hmc_rng_fill(uint64_t seed, uint64_t proposal0, int64_t chain_offset, int64_t n_chains,

@@ -44,6 +44,15 @@ class L2hmcTrajectoryArgs(C.Structure):
 RNG_V, RNG_DIR, RNG_U = 1, 2, 4
 
 
+class L2hmcTrainArgs(C.Structure):
+    _fields_ = [("xnet", C.POINTER(L2hmcNet)), ("vnet", C.POINTER(L2hmcNet)), ("energy", L2hmcEnergy),
+                ("masks", _fp), ("trig", _fp), ("alpha", _fp), ("eps_host", C.c_float),
+                ("n_chains", C.c_int64), ("d", C.c_int32), ("H", C.c_int32), ("T", C.c_int32),
+                ("x", _fp), ("v", _fp), ("direction", _fp), ("direction_all", C.c_int32),
+                ("scale", C.c_float), ("inv_n", C.c_float),
+                ("Lx", _fp), ("p", _fp), ("v1", _fp), ("grad", _fp), ("workspace", _fp)]
+
+
 # every symbol include/l2hmc.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "l2hmc_abi_version": (C.c_int, []),
@@ -58,6 +67,9 @@ SYMBOLS = {
     "l2hmc_p_accept": (C.c_int, [C.POINTER(L2hmcEnergy), _fp, _fp, _fp, _fp, _fp, C.c_int64,
                                  C.c_int32, _fp, _fp]),
     "l2hmc_mh_select": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp]),
+    "l2hmc_train_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "l2hmc_train_grad_floats": (C.c_int64, [C.c_int32, C.c_int32]),
+    "l2hmc_train_propose_grad": (C.c_int, [C.POINTER(L2hmcTrainArgs), _fp]),
     "l2hmc_rng_fill": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                  _fp, _fp, _fp, _fp]),
     "l2hmc_autocov": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int64, _fp, _fp, _fp]),

@@ -388,3 +388,34 @@ def test_sample_chain_with_in_kernel_rng(case):
         lo = 16 * (N // 32)
         xs, ps, _ = sample_chain(to_dev(g["x"][lo:]), dyn, M, seed=2024, chain_offset=lo)
         assert torch.equal(ps, p[:, lo:]) and torch.equal(xs, xf[lo:])
+
+
+@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50"])
+def test_training_gradient_matches_reference_graph(case):
+    """l2hmc_train_propose_grad (HIP, hand-derived reverse mode) vs tf.gradients of the notebook
+    loss from the reference's own graph: loss, proposals, every parameter gradient and alpha."""
+    from l2hmc_amd.training import Trainer
+    g = load(case)
+    dyn = hip_dynamics(g)
+    dyn.eps_override = None
+    import torch
+    with torch.no_grad():
+        dyn.alpha.fill_(float(np.log(g["eps"])))
+    tr = Trainer(dyn)
+    draws = {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
+             "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
+             "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
+    loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    assert rel_err(to_np(Lx), g["Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["px"]) < P_TOL
+    scale = max(float(np.abs(g["grad." + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+    worst = 0.0
+    for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
+        for k in O.NET_KEYS:
+            ref = g["grad.%s.%s" % (n, k)]
+            got = to_np(w[k].grad).reshape(ref.shape)
+            worst = max(worst, float(np.abs(got - ref).max()))
+            assert np.abs(got - ref).max() < 2e-4 * scale, (case, n, k)
+    ga = float(dyn.alpha.grad)
+    print("%s: loss %.6e  max |dgrad| %.2e (scale %.2e)  alpha %.5e vs %.5e" % (case, float(loss), worst, scale, ga, float(g["grad.alpha"])))
+    assert abs(ga - float(g["grad.alpha"])) < 2e-4 * max(scale, abs(float(g["grad.alpha"])))
