@@ -33,8 +33,10 @@ def net_cast(net, dtype):
     return {k: np.asarray(net[k], dtype=dtype) for k in NET_KEYS}
 
 
-def net_apply(net, a, b, tau):
-    """[S, T, Q] = net([a, b, tau, aux])  with the notebook architecture.
+def net_apply(net, a, b, tau, aux_h=None):
+    """[S, T, Q] = net([a, b, tau, aux])  with the notebook architecture (aux_h = None) or the
+    VAE sampler's (mnist_vae.py:142-167: the 4th Zip branch `encoder_sampler(aux)` is added into
+    the pre-ReLU sum; pass its output as aux_h).
 
     Zip of three Linear embeds + `lambda _: 0.` (nb:53-60), python `sum` (0 + e1 + e2 + e3
     + 0.), relu, Linear(H,H), relu (nb:61-64), Parallel heads (nb:65-76):
@@ -44,7 +46,7 @@ def net_apply(net, a, b, tau):
     e1 = a @ net['W1'] + net['b1']
     e2 = b @ net['W2'] + net['b2']
     e3 = tau @ net['W3'] + net['b3']
-    h = ((0 + e1) + e2) + e3 + 0.0
+    h = ((0 + e1) + e2) + e3 + (0.0 if aux_h is None else aux_h)
     h = np.maximum(h, 0)
     h = h @ net['W4'] + net['b4']
     h = np.maximum(h, 0)
@@ -52,6 +54,45 @@ def net_apply(net, a, b, tau):
     T = h @ net['Wt'] + net['bt']
     Q = np.exp(net['lam_q']) * np.tanh(h @ net['Wq'] + net['bq'])
     return S, T, Q
+
+
+def softplus(x):
+    return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def mlp3(w, x):
+    """Linear-softplus-Linear-softplus-Linear (mnist_vae.py decoder :104-111, encoder_sampler
+    :134-140); w = dict(W1, b1, W2, b2, W3, b3), Linear = x W + b."""
+    h = softplus(x @ w['W1'] + w['b1'])
+    h = softplus(h @ w['W2'] + w['b2'])
+    return h @ w['W3'] + w['b3']
+
+
+class VAEPosterior:
+    """mnist_vae.py:122-126: U(z; x) = sum_pix BCE_with_logits(x, decoder(z)) + |z|^2 / 2 with the
+    decoder of :104-111.  Gradient w.r.t. z analytic (the reference uses tf.gradients)."""
+
+    def __init__(self, dec, aux, dtype=np.float32):
+        self.w = {k: np.asarray(v, np.float32).astype(dtype) for k, v in dec.items()}
+        self.aux = np.asarray(aux, np.float32).astype(dtype)
+
+    def __call__(self, z):
+        w = self.w
+        p1 = z @ w['W1'] + w['b1']
+        a1 = softplus(p1)
+        p2 = a1 @ w['W2'] + w['b2']
+        a2 = softplus(p2)
+        lg = a2 @ w['W3'] + w['b3']
+        bce = np.maximum(lg, 0) - lg * self.aux + np.log1p(np.exp(-np.abs(lg)))
+        U = np.sum(bce, axis=1) + 0.5 * np.sum(np.square(z), axis=1)
+        dl = sigmoid(lg) - self.aux
+        d2 = (dl @ w['W3'].T) * sigmoid(p2)
+        d1 = (d2 @ w['W2'].T) * sigmoid(p1)
+        return U, d1 @ w['W1'].T + z
 
 
 def zero_net(a, b, tau):
@@ -199,7 +240,7 @@ class Dynamics:
     """
 
     def __init__(self, x_dim, energy, T, eps, mask, xnet=None, vnet=None,
-                 temperature=1.0, dtype=np.float32):
+                 temperature=1.0, dtype=np.float32, aux_h=None):
         self.x_dim, self.T, self.dtype = x_dim, int(T), dtype
         self.eps = dtype(eps)
         self.mask = np.asarray(mask, dtype=dtype)
@@ -210,8 +251,9 @@ class Dynamics:
             self.XNet = self.VNet = zero_net
         else:
             xn, vn = net_cast(xnet, dtype), net_cast(vnet, dtype)
-            self.XNet = lambda a, b, t: net_apply(xn, a, b, t)
-            self.VNet = lambda a, b, t: net_apply(vn, a, b, t)
+            ah = None if aux_h is None else np.asarray(aux_h, dtype=dtype)
+            self.XNet = lambda a, b, t: net_apply(xn, a, b, t, ah)
+            self.VNet = lambda a, b, t: net_apply(vn, a, b, t, ah)
 
     # dynamics.py:203-218
     def energy(self, x):
@@ -364,13 +406,14 @@ def propose(x, dyn, v_fwd, v_bwd=None, direction=None, u=None, log_jac=False,
         Lv = mask * Lv1 + (1 - mask) * Lv2
         px = mask[:, 0] * px1 + (1 - mask[:, 0]) * px2
     else:
-        f = mask[:, 0] > 0
-        Lx, Lv = np.empty_like(x), np.empty_like(x)
-        px = np.empty((x.shape[0],), dtype=dyn.dtype)
-        if f.any():
-            Lx[f], Lv[f], px[f] = dyn.forward(x[f], v_fwd[f], log_jac=log_jac)
-        if (~f).any():
-            Lx[~f], Lv[~f], px[~f] = dyn.backward(x[~f], v_bwd[~f], log_jac=log_jac)
+        # each chain keeps only its drawn direction: a SELECT instead of the reference's 0/1
+        # weighted sum, so a non-finite discarded trajectory cannot leak (0 * inf = NaN, :38)
+        f = mask > 0
+        with np.errstate(all='ignore'):
+            Lx1, Lv1, px1 = dyn.forward(x, v_fwd, log_jac=log_jac)
+            Lx2, Lv2, px2 = dyn.backward(x, v_bwd, log_jac=log_jac)
+        Lx, Lv = np.where(f, Lx1, Lx2), np.where(f, Lv1, Lv2)
+        px = np.where(f[:, 0], px1, px2)
     return Lx, Lv, px, (tf_accept(x, Lx, px, u) if u is not None else None)
 
 

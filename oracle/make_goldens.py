@@ -245,6 +245,95 @@ def train_case(name, mu, cov, H, T, eps, N, seed, head_std=0.3):
         name, N, x_dim, T, float(out['loss']), gn, float(out['grad.alpha']), out['px'].mean(), out['pz'].mean()))
 
 
+def vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
+    """Config-5-shaped case at fixture-friendly sizes: the VAE latent posterior of
+    mnist_vae.py:104-178 -- decoder energy (:122-126), S/T/Q nets whose 4th Zip branch is the shared
+    `encoder_sampler(aux)` (:134-150) -- assembled from the reference's own layer classes and run
+    through the reference's Dynamics / propose with aux."""
+    tf1_stub.reset(seed)
+    np.random.seed(seed)
+    hook = variable_hook_factory(seed + 1, 0.3)
+
+    def vae_hook(full, shape, default):
+        if full.startswith('sampler/XNet') or full.startswith('sampler/VNet'):
+            return hook('/'.join(full.split('/')[1:]), shape, default)
+        return None
+    tf1_stub.VARIABLE_HOOK = vae_hook
+    with tf.variable_scope('decoder'):
+        decoder = Sequential([Linear(latent, dec_h, scope='decoder_1'), tf.nn.softplus,
+                              Linear(dec_h, dec_h, scope='decoder_2'), tf.nn.softplus,
+                              Linear(dec_h, n_pix, scope='decoder_3', factor=0.01)])
+
+    def energy(z, aux=None):                                    # mnist_vae.py:122-126
+        logits = decoder(z)
+        log_posterior = -tf.reduce_sum(tf.nn.sigmoid_cross_entropy_with_logits(labels=aux, logits=logits), axis=1)
+        log_prior = -0.5 * tf.reduce_sum(tf.square(z), axis=1)
+        return (-log_posterior - log_prior)
+
+    with tf.variable_scope('sampler'):
+        encoder_sampler = Sequential([Linear(n_pix, enc_h, scope='encoder_1'), tf.nn.softplus,
+                                      Linear(enc_h, enc_h, scope='encoder_2'), tf.nn.softplus,
+                                      Linear(enc_h, H, scope='encoder_3')])
+
+        def net_factory(x_dim, scope, factor):                  # mnist_vae.py:142-167
+            with tf.variable_scope(scope):
+                return Sequential([
+                    Zip([Linear(latent, H, scope='embed_1', factor=0.33),
+                         Linear(latent, H, scope='embed_2', factor=factor * 0.33),
+                         Linear(2, H, scope='embed_3', factor=0.33),
+                         encoder_sampler]),
+                    sum, tf.nn.relu, Linear(H, H, scope='linear_1'), tf.nn.relu,
+                    Parallel([Sequential([Linear(H, latent, scope='linear_s', factor=0.01),
+                                          ScaleTanh(latent, scope='scale_s')]),
+                              Linear(H, latent, scope='linear_t', factor=0.01),
+                              Sequential([Linear(H, latent, scope='linear_f', factor=0.01),
+                                          ScaleTanh(latent, scope='scale_f')])])])
+        with contextlib.redirect_stdout(io.StringIO()):
+            dyn = ref_dynamics.Dynamics(latent, energy, T=T, eps=eps, net_factory=net_factory)
+    out = {'energy.kind': 'vae', 'case': name, 'x_dim': latent, 'H': H, 'T': T, 'N': N, 'hmc': 0,
+           'eps': npy(dyn.eps), 'mask': npy(dyn.mask)}
+    for full, val in tf1_stub.VARIABLES.items():
+        parts = full.split('/')
+        if parts[0] == 'decoder':
+            out['dec.%s%s' % (parts[2], parts[1][-1])] = npy(val)            # dec.W1 ... dec.b3
+        elif parts[0] == 'sampler' and parts[1].startswith('encoder_'):
+            out['enc.%s%s' % (parts[2], parts[1][-1])] = npy(val)
+        elif parts[0] == 'sampler' and parts[1] in ('XNet', 'VNet'):
+            out['%s.%s' % (parts[1].lower(), TF2KEY['/'.join(parts[2:])])] = npy(val)
+    rng = np.random.RandomState(seed + 2)
+    x0 = rng.randn(N, latent).astype(np.float32)
+    v0 = rng.randn(N, latent).astype(np.float32)
+    aux = (rng.rand(N, n_pix) < 0.3).astype(np.float32)          # binarised "image" rows
+    out['x'], out['v'], out['aux'] = x0, v0, aux
+    auxt = torch.tensor(aux)
+    out['aux_h'] = npy(encoder_sampler(auxt))
+    xl = leaf(x0)
+    out['energy'] = npy(dyn.energy(xl, aux=auxt))
+    out['grad_energy'] = npy(dyn.grad_energy(xl, aux=auxt))
+    st = torch.tensor(2.0)
+    xo, vo, lj = dyn._forward_step(leaf(x0), leaf(v0), st, aux=auxt)
+    out['fstep2.x'], out['fstep2.v'], out['fstep2.logdet'] = npy(xo), npy(vo), npy(lj)
+    xo, vo, lj = dyn._backward_step(leaf(x0), leaf(v0), st, aux=auxt)
+    out['bstep2.x'], out['bstep2.v'], out['bstep2.logdet'] = npy(xo), npy(vo), npy(lj)
+    out['steps'] = np.array([2], dtype=np.int32)
+    for nm, fn in (('fwd', dyn.forward), ('bwd', dyn.backward)):
+        X, V, lj = fn(leaf(x0), init_v=leaf(v0), aux=auxt, log_jac=True)
+        out[nm + '.x'], out[nm + '.v'], out[nm + '.logjac'] = npy(X), npy(V), npy(lj)
+        X, V, p = fn(leaf(x0), init_v=leaf(v0), aux=auxt)
+        out[nm + '.p'] = npy(p)
+    del tf1_stub.RANDOM_LOG[:]
+    Lx, Lv, px, outs = ref_sampler.propose(leaf(x0), dyn, aux=auxt, do_mh_step=True)
+    log = list(tf1_stub.RANDOM_LOG)
+    assert [k for k, _ in log] == ['randint', 'normal', 'normal', 'uniform']
+    out['prop.dir'] = log[0][1][:, 0].astype(np.uint8)
+    out['prop.v_fwd'], out['prop.v_bwd'], out['prop.u'] = log[1][1], log[2][1], log[3][1]
+    out['prop.Lx'], out['prop.px'], out['prop.x_next'] = npy(Lx), npy(px), npy(outs[0])
+    tf1_stub.VARIABLE_HOOK = None
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print('%-18s N=%-4d d=%-3d T=%-3d  mean p fwd %.3f bwd %.3f  |U| %.1f' % (
+        name, N, latent, T, out['fwd.p'].mean(), out['bwd.p'].mean(), np.abs(out['energy']).mean()))
+
+
 def gaussian_case(name, mu, cov, **kw):
     with contextlib.redirect_stdout(io.StringIO()):
         dist = ref_distributions.Gaussian(np.asarray(mu, dtype=np.float64), np.asarray(cov, dtype=np.float64))
@@ -318,6 +407,9 @@ def main():
     params = {'energy.kind': 'funnel', 'energy.sigma': np.float32(2.0)}
     run_case('funnel3', 3, H=10, T=5, eps=0.05, N=64, energy_fn=fn, energy_params=params,
              seed=22, x0=x0, head_std=0.3)
+
+    # config-5 shape (VAE latent posterior + aux-conditioned wide nets) at fixture-friendly sizes
+    vae_case('vae_small', latent=10, H=24, dec_h=48, n_pix=40, enc_h=32, T=5, eps=0.1, N=32, seed=41)
 
     # training-loss gradients (next-row f1): SCG (notebook), dense d=8, diagonal ICG d=50
     train_case('train_scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=64, seed=31)

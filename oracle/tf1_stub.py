@@ -216,6 +216,10 @@ def _make_module():
     nn = types.ModuleType('tensorflow.nn')
     nn.relu = lambda x, name=None: torch.relu(_t(x))
     nn.tanh = lambda x, name=None: torch.tanh(_t(x))
+    nn.softplus = lambda x, name=None: torch.nn.functional.softplus(_t(x))
+    # TF's stable form max(l, 0) - l z + log1p(exp(-|l|))  (mnist_vae.py:124)
+    nn.sigmoid_cross_entropy_with_logits = lambda labels=None, logits=None, name=None: (
+        torch.clamp(_t(logits), min=0) - _t(logits) * _t(labels) + torch.log1p(torch.exp(-torch.abs(_t(logits)))))
     m.nn = nn
     contrib = types.ModuleType('tensorflow.contrib')
     layers = types.ModuleType('tensorflow.contrib.layers')

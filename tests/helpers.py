@@ -28,7 +28,13 @@ def oracle_energy(g, dtype=np.float32):
         return O.RoughWell(float(g["energy.eta"]), bool(g["energy.easy"]), dtype)
     if kind == "funnel":
         return O.GaussianFunnel(float(g["energy.sigma"]), dtype)
+    if kind == "vae":
+        return O.VAEPosterior(mlp_weights(g, "dec."), g["aux"], dtype)
     raise ValueError(kind)
+
+
+def mlp_weights(g, prefix):
+    return {k: g[prefix + k] for k in ("W1", "b1", "W2", "b2", "W3", "b3")}
 
 
 def golden_nets(g):
@@ -39,8 +45,12 @@ def golden_nets(g):
 
 def oracle_dynamics(g, dtype=np.float32):
     xn, vn = golden_nets(g)
+    aux_h = None
+    if str(g["energy.kind"]) == "vae":        # shared encoder_sampler(aux) branch, mnist_vae.py:134-150
+        w = {k: v.astype(dtype) for k, v in mlp_weights(g, "enc.").items()}
+        aux_h = O.mlp3(w, g["aux"].astype(dtype))
     return O.Dynamics(int(g["x_dim"]), oracle_energy(g, dtype), int(g["T"]), g["eps"], g["mask"],
-                      xn, vn, dtype=dtype)
+                      xn, vn, dtype=dtype, aux_h=aux_h)
 
 
 def rel_err(a, b):

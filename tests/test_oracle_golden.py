@@ -175,3 +175,9 @@ def test_training_gradient_oracle_matches_reference_graph(case):
             got = np.asarray(out[n + "." + k]).reshape(ref.shape)
             assert np.abs(got - ref).max() < 2e-5 * scale, (case, n, k)
     assert abs(out["alpha"] - float(g["grad.alpha"])) < 2e-5 * max(scale, abs(float(g["grad.alpha"])))
+
+
+def test_vae_aux_branch_matches_reference_layers():
+    g = load("vae_small")
+    from tests.helpers import mlp_weights
+    assert rel_err(O.mlp3(mlp_weights(g, "enc."), g["aux"]), g["aux_h"]) < 2e-6
