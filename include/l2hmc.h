@@ -160,6 +160,52 @@ int l2hmc_p_accept(const L2hmcEnergy* energy, const float* x0, const float* v0,
 int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const float* u,
                     int64_t n_chains, int32_t d, float* x_next, void* stream);
 
+/* ---- split engine: wide / image-conditioned nets + VAE latent-posterior energy (config 5) ------ */
+/* Linear-softplus-Linear-softplus-Linear with reference-layout weights W (in, out), b (out):
+ * the VAE decoder (mnist_vae.py:104-111) and the sampler's image branch `encoder_sampler`
+ * (mnist_vae.py:134-140). */
+typedef struct L2hmcMlp3 {
+  const float *W1, *b1, *W2, *b2, *W3, *b3;
+  int32_t n_in, n_h1, n_h2, n_out;
+} L2hmcMlp3;
+
+/* l2hmc_trajectory_split: same contract as l2hmc_trajectory (steps [step_begin, +n_steps) of the
+ * T-step schedule, per-chain direction, accept probability, MH select) for
+ *   energy  U(z; aux) = sum_pix BCE_with_logits(aux, decoder(z)) + |z|^2 / 2   (mnist_vae.py:122-126)
+ *   nets    the S/T/Q architecture with ANY hidden width H and, if aux_encoder != NULL, the 4th Zip
+ *           branch aux_encoder(aux) added into the first hidden layer (mnist_vae.py:142-167);
+ *           RAW reference-layout weights (not the packed buffer).
+ * The dense products run in rocBLAS (fp32), everything else in this library's kernels. */
+typedef struct L2hmcSplitArgs {
+  const L2hmcNet* xnet;
+  const L2hmcNet* vnet;
+  int32_t H;
+  const L2hmcMlp3* aux_encoder;  /* (n_pix -> H) or NULL                                    */
+  const L2hmcMlp3* decoder;      /* (d -> n_pix)                                            */
+  const float* aux;              /* (N, n_pix) conditioning images                          */
+  const float* masks;            /* (T, d) */
+  const float* trig;             /* (T, 2) */
+  const float* alpha;
+  float eps_host;
+  int64_t n_chains;
+  int32_t d, T, step_begin, n_steps;
+  const float* x;
+  const float* v;
+  const uint8_t* direction;
+  int32_t direction_all;
+  const float* u;
+  float *x_out, *v_out, *logjac_out, *p_out, *x_next;
+  float* workspace;              /* l2hmc_split_workspace_floats(...) floats                */
+  int64_t workspace_floats;
+} L2hmcSplitArgs;
+
+int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,
+                                     const L2hmcMlp3* aux_encoder, const L2hmcMlp3* decoder);
+int l2hmc_trajectory_split(const L2hmcSplitArgs* args, void* stream);
+/* Dynamics.energy / grad_energy for the VAE posterior; workspace as for the split trajectory. */
+int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x, int64_t n_chains,
+                     int32_t d, float* U_out, float* grad_out, float* workspace, void* stream);
+
 /* ---- training (next-row f1): one proposal + the gradient of its loss term ------------------- */
 /* Loss of SCGExperiment.ipynb raw lines 156-169 for ONE of its two proposals:
  *   v1_n = |x_n - Lx_n|^2 p_n + 1e-4;   term = scale * mean_n(1 / v1_n) - mean_n(v1_n) / scale

@@ -44,6 +44,22 @@ class L2hmcTrajectoryArgs(C.Structure):
 RNG_V, RNG_DIR, RNG_U = 1, 2, 4
 
 
+class L2hmcMlp3(C.Structure):
+    _fields_ = [(k, _fp) for k in ("W1", "b1", "W2", "b2", "W3", "b3")] + \
+               [(k, C.c_int32) for k in ("n_in", "n_h1", "n_h2", "n_out")]
+
+
+class L2hmcSplitArgs(C.Structure):
+    _fields_ = [("xnet", C.POINTER(L2hmcNet)), ("vnet", C.POINTER(L2hmcNet)), ("H", C.c_int32),
+                ("aux_encoder", C.POINTER(L2hmcMlp3)), ("decoder", C.POINTER(L2hmcMlp3)), ("aux", _fp),
+                ("masks", _fp), ("trig", _fp), ("alpha", _fp), ("eps_host", C.c_float),
+                ("n_chains", C.c_int64), ("d", C.c_int32), ("T", C.c_int32), ("step_begin", C.c_int32),
+                ("n_steps", C.c_int32), ("x", _fp), ("v", _fp), ("direction", _fp),
+                ("direction_all", C.c_int32), ("u", _fp),
+                ("x_out", _fp), ("v_out", _fp), ("logjac_out", _fp), ("p_out", _fp), ("x_next", _fp),
+                ("workspace", _fp), ("workspace_floats", C.c_int64)]
+
+
 class L2hmcTrainArgs(C.Structure):
     _fields_ = [("xnet", C.POINTER(L2hmcNet)), ("vnet", C.POINTER(L2hmcNet)), ("energy", L2hmcEnergy),
                 ("masks", _fp), ("trig", _fp), ("alpha", _fp), ("eps_host", C.c_float),
@@ -67,6 +83,10 @@ SYMBOLS = {
     "l2hmc_p_accept": (C.c_int, [C.POINTER(L2hmcEnergy), _fp, _fp, _fp, _fp, _fp, C.c_int64,
                                  C.c_int32, _fp, _fp]),
     "l2hmc_mh_select": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp]),
+    "l2hmc_split_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                                 C.POINTER(L2hmcMlp3), C.POINTER(L2hmcMlp3)]),
+    "l2hmc_trajectory_split": (C.c_int, [C.POINTER(L2hmcSplitArgs), _fp]),
+    "l2hmc_vae_energy": (C.c_int, [C.POINTER(L2hmcMlp3), _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp]),
     "l2hmc_train_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "l2hmc_train_grad_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_train_propose_grad": (C.c_int, [C.POINTER(L2hmcTrainArgs), _fp]),

@@ -93,6 +93,17 @@ class Dynamics(object):
                         raise ValueError("net parameters live on %s, Dynamics on %s" % (w[k].device, self.device))
         self._packed = None
         self._packed_key = None
+        # Engine choice: the single fused kernel covers the built-in targets with H <= 15 and no
+        # image branch; everything else (VAE posterior, wide nets, encoder_sampler(aux) branch) runs
+        # on the split engine (rocBLAS products + HIP update kernels) of the same library.
+        from .vae import ENERGY_VAE
+        self._split = energy_function.kind == ENERGY_VAE
+        if not self._split and not self.hmc and (self.H > 15 or self._xw['aux_encoder'] is not None):
+            raise NotImplementedError("H > 15 or an aux branch needs the split engine, which currently "
+                                      "implements the VAE posterior energy only")
+        if self._split and self.hmc:
+            raise NotImplementedError("HMC mode on the split engine is not implemented")
+        self._split_ws = None
 
     # ---- masks / time encoding -----------------------------------------------------------------
     def _init_mask(self):
@@ -181,14 +192,68 @@ class Dynamics(object):
 
     # ---- the fused trajectory ----------------------------------------------------------------------
     def _check_aux(self, aux):
-        if aux is not None:
-            raise NotImplementedError("aux-conditioned nets/energies (mnist_vae.py) are not fused yet")
+        if self._split:
+            if aux is None:
+                raise ValueError("this Dynamics is image-conditioned (mnist_vae.py): pass aux=")
+        elif aux is not None:
+            raise ValueError("aux= is only meaningful for an aux-conditioned model (mnist_vae.py)")
+
+    def _run_split(self, x, v, step_begin, n_steps, direction, direction_all, u, want, aux):
+        """Launch `l2hmc_trajectory_split` (include/l2hmc.h)."""
+        import ctypes as C
+        from .vae import mlp3_struct
+        x = as_device_f32(x, self.device)
+        v = as_device_f32(v, self.device)
+        aux = as_device_f32(aux, self.device)
+        N, d = x.shape
+        if v.shape != x.shape or d != self.x_dim or aux.shape != (N, self._fn.n_pix):
+            raise ValueError("x, v must be (N, %d) and aux (N, %d)" % (self.x_dim, self._fn.n_pix))
+        out = {}
+        for k in ('x', 'v', 'x_next'):
+            if k in want:
+                out[k] = torch.empty_like(x)
+        if 'x_next' in want:
+            out.setdefault('p', None)
+        for k in ('logjac', 'p'):
+            if k in want or k in out:
+                out[k] = torch.empty(N, dtype=torch.float32, device=x.device)
+        if direction is not None:
+            direction = direction.to(device=x.device, dtype=torch.uint8).contiguous()
+        if u is not None:
+            u = as_device_f32(u, self.device)
+        xs = _ffi.L2hmcNet(*[self._xw[k].data_ptr() for k in _ffi.NET_FIELDS])
+        vs = _ffi.L2hmcNet(*[self._vw[k].data_ptr() for k in _ffi.NET_FIELDS])
+        dec = mlp3_struct(self._fn.decoder)
+        enc = mlp3_struct(self._xw['aux_encoder']) if self._xw['aux_encoder'] is not None else None
+        L = _ffi.lib()
+        need = _ffi.check(L.l2hmc_split_workspace_floats(N, d, self.H, self.T,
+                                                         C.byref(enc) if enc is not None else None, C.byref(dec)))
+        if self._split_ws is None or self._split_ws.numel() < need:
+            self._split_ws = torch.empty(int(need), dtype=torch.float32, device=self.device)
+        a = _ffi.L2hmcSplitArgs()
+        a.xnet, a.vnet, a.H = C.pointer(xs), C.pointer(vs), self.H
+        a.aux_encoder = C.pointer(enc) if enc is not None else None
+        a.decoder, a.aux = C.pointer(dec), aux.data_ptr()
+        a.masks, a.trig = self._mask.data_ptr(), self._trig.data_ptr()
+        if self.eps_override is None:
+            a.alpha, a.eps_host = self.alpha.data_ptr(), 0.0
+        else:
+            a.alpha, a.eps_host = None, float(self.eps_override)
+        a.n_chains, a.d, a.T = N, d, self.T
+        a.step_begin, a.n_steps = int(step_begin), int(n_steps)
+        a.x, a.v = x.data_ptr(), v.data_ptr()
+        a.direction, a.direction_all, a.u = _ffi.ptr(direction), int(direction_all), _ffi.ptr(u)
+        a.x_out, a.v_out = _ffi.ptr(out.get('x')), _ffi.ptr(out.get('v'))
+        a.logjac_out, a.p_out, a.x_next = _ffi.ptr(out.get('logjac')), _ffi.ptr(out.get('p')), _ffi.ptr(out.get('x_next'))
+        a.workspace, a.workspace_floats = self._split_ws.data_ptr(), self._split_ws.numel()
+        _ffi.check(L.l2hmc_trajectory_split(a, _ffi.current_stream(x.device)))
+        return out
 
     def _randn_like(self, x):
         return torch.randn(x.shape, dtype=torch.float32, device=x.device, generator=self.generator)
 
     def run(self, x, v, step_begin, n_steps, direction=None, direction_all=1, u=None,
-            want=('x', 'v', 'logjac'), n_proposals=1, rng=None):
+            want=('x', 'v', 'logjac'), n_proposals=1, rng=None, aux=None):
         """Launch `l2hmc_trajectory` (include/l2hmc.h).  Returns a dict of the requested
         outputs among x, v, logjac, p, x_next, x_hist.  With n_proposals = M > 1 the kernel
         runs M chained proposals (persistent sampler loop): v is (M, N, d), direction and u
@@ -196,6 +261,10 @@ class Dynamics(object):
         rng = dict(seed=, proposal0=0, chain_offset=0): inputs passed as None among v /
         direction / u are drawn in-kernel from the Philox stream (include/l2hmc.h)."""
         M = int(n_proposals)
+        if self._split:
+            if M != 1 or rng is not None:
+                raise NotImplementedError("the split engine runs one injected-draw proposal per call")
+            return self._run_split(x, v, step_begin, n_steps, direction, direction_all, u, want, aux)
         x = as_device_f32(x, self.device)
         N, d = x.shape
         lead = (M,) if M > 1 else ()
@@ -266,11 +335,15 @@ class Dynamics(object):
     def energy(self, x, aux=None):
         """dynamics.py:203-212."""
         self._check_aux(aux)
+        if self._split:
+            return self._fn.evaluate(x, aux=aux)[0]
         return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0)[0]
 
     def grad_energy(self, x, aux=None):
         """dynamics.py:217-218 (analytic, computed by the HIP energy kernel)."""
         self._check_aux(aux)
+        if self._split:
+            return self._fn.evaluate(x, want_U=False, want_grad=True, aux=aux)[1]
         return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
                                  want_U=False, want_grad=True)[1]
 
@@ -281,13 +354,13 @@ class Dynamics(object):
     def _forward_step(self, x, v, step, aux=None):
         """dynamics.py:115-157 -> (x_o, v_o, log_jac_contrib)."""
         self._check_aux(aux)
-        o = self.run(x, v, int(step), 1, direction_all=1)
+        o = self.run(x, v, int(step), 1, direction_all=1, aux=aux)
         return o['x'], o['v'], o['logjac']
 
     def _backward_step(self, x_o, v_o, step, aux=None):
         """dynamics.py:159-201 -> (x, v, log_jac_contrib)."""
         self._check_aux(aux)
-        o = self.run(x_o, v_o, self.T - 1 - int(step), 1, direction_all=0)
+        o = self.run(x_o, v_o, self.T - 1 - int(step), 1, direction_all=0, aux=aux)
         return o['x'], o['v'], o['logjac']
 
     def _trajectory(self, x, init_v, aux, log_jac, direction_all):
@@ -295,7 +368,7 @@ class Dynamics(object):
         x = as_device_f32(x, self.device)
         v = self._randn_like(x) if init_v is None else init_v      # dynamics.py:247-250
         want = ('x', 'v', 'logjac') if log_jac else ('x', 'v', 'p')
-        o = self.run(x, v, 0, self.T, direction_all=direction_all, want=want)
+        o = self.run(x, v, 0, self.T, direction_all=direction_all, want=want, aux=aux)
         return o['x'], o['v'], (o['logjac'] if log_jac else o['p'])
 
     def forward(self, x, init_v=None, aux=None, log_path=False, log_jac=False):
@@ -309,6 +382,9 @@ class Dynamics(object):
     def p_accept(self, x0, v0, x1, v1, log_jac, aux=None):
         """dynamics.py:302-309."""
         self._check_aux(aux)
+        if self._split:
+            raise NotImplementedError("p_accept on arbitrary end points is not implemented on the split "
+                                      "engine (forward / backward / propose return it)")
         x0, v0, x1, v1 = (as_device_f32(t, self.device) for t in (x0, v0, x1, v1))
         lj = as_device_f32(log_jac, self.device)
         N, d = x0.shape

@@ -49,6 +49,10 @@ def relu(x):
     return torch.relu(x)
 
 
+def softplus(x):
+    return torch.nn.functional.softplus(x)
+
+
 def _variance_scaling(shape, factor):
     """`tf.contrib.layers.variance_scaling_initializer(factor, 'FAN_IN', uniform=False)`
     as used at layers.py:32: truncated normal (+-2 sigma), stddev sqrt(1.3 * factor / fan_in)."""
@@ -205,6 +209,26 @@ def stq_network(hidden=10, embed_factor=1.0 / 3, head_factor=0.001):
     return network
 
 
+def extract_mlp3(seq):
+    """Recognise Sequential([Linear, softplus, Linear, softplus, Linear]) -- the VAE decoder and
+    the sampler's `encoder_sampler` (mnist_vae.py:104-111,134-140) -- and return its weights, or
+    None."""
+    try:
+        ls = seq.layers
+        if not (isinstance(seq, Sequential) and len(ls) == 5):
+            return None
+        l1, a1, l2, a2, l3 = ls
+        if not (all(isinstance(l, Linear) for l in (l1, l2, l3))
+                and all(callable(a) and getattr(a, '__name__', '') == 'softplus' for a in (a1, a2))):
+            return None
+        if not (l1.out_ == l2.in_ and l2.out_ == l3.in_):
+            return None
+        return {'W1': l1.W, 'b1': l1.b, 'W2': l2.W, 'b2': l2.b, 'W3': l3.W, 'b3': l3.b,
+                'dims': (l1.in_, l1.out_, l2.out_, l3.out_)}
+    except (AttributeError, TypeError):
+        return None
+
+
 _RELU_NAMES = ('relu',)
 
 
@@ -227,7 +251,8 @@ def extract_stq(net, x_dim):
         e1, e2, e3, e4 = z.layers
         if not all(isinstance(e, Linear) for e in (e1, e2, e3)) or isinstance(e4, Linear):
             return None
-        if e4(None) != 0.:
+        aux_encoder = extract_mlp3(e4)            # mnist_vae.py:149: image branch; else `lambda _: 0.`
+        if aux_encoder is None and e4(None) != 0.:
             return None
         hs, ht, hq = par.layers
         if not (isinstance(hs, Sequential) and len(hs.layers) == 2 and isinstance(ht, Linear)
@@ -239,6 +264,8 @@ def extract_stq(net, x_dim):
                 and isinstance(sq, ScaleTanh)):
             return None
         H = l1.in_
+        if aux_encoder is not None and aux_encoder['dims'][3] != H:
+            return None
         shapes_ok = (e1.in_ == x_dim and e2.in_ == x_dim and e3.in_ == 2
                      and e1.out_ == e2.out_ == e3.out_ == l1.out_ == H
                      and ls.in_ == ht.in_ == lq.in_ == H
@@ -247,6 +274,7 @@ def extract_stq(net, x_dim):
             return None
         return {'W1': e1.W, 'b1': e1.b, 'W2': e2.W, 'b2': e2.b, 'W3': e3.W, 'b3': e3.b,
                 'W4': l1.W, 'b4': l1.b, 'Ws': ls.W, 'bs': ls.b, 'Wt': ht.W, 'bt': ht.b,
-                'Wq': lq.W, 'bq': lq.b, 'lam_s': ss.log_scale, 'lam_q': sq.log_scale, 'H': H}
+                'Wq': lq.W, 'bq': lq.b, 'lam_s': ss.log_scale, 'lam_q': sq.log_scale, 'H': H,
+                'aux_encoder': aux_encoder}
     except (AttributeError, TypeError):
         return None

@@ -38,7 +38,7 @@ def propose(x, dynamics, init_v=None, aux=None, do_mh_step=False, log_jac=False,
     if dynamics.hmc:
         v0 = init_v if init_v is not None else (v if v is not None else dynamics._randn_like(x))
         uu = u if u is not None else _rand((N,), dynamics)
-        o = dynamics.run(x, v0, 0, dynamics.T, direction_all=1, u=uu, want=('x', 'v', 'p', 'x_next'))
+        o = dynamics.run(x, v0, 0, dynamics.T, direction_all=1, u=uu, want=('x', 'v', 'p', 'x_next'), aux=aux)
         return o['x'], o['v'], o['p'], [o['x_next']]
 
     if direction is None:
@@ -58,7 +58,7 @@ def propose(x, dynamics, init_v=None, aux=None, do_mh_step=False, log_jac=False,
     if do_mh_step and not log_jac:
         uu = u if u is not None else _rand((N,), dynamics)
         want.append('x_next')
-    o = dynamics.run(x, v0, 0, dynamics.T, direction=direction, u=uu, want=tuple(want))
+    o = dynamics.run(x, v0, 0, dynamics.T, direction=direction, u=uu, want=tuple(want), aux=aux)
     Lv = o['v'] if init_v is not None else None
     px = o['logjac'] if log_jac else o['p']
     outputs = []

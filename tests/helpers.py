@@ -102,13 +102,36 @@ def hip_energy(g):
     raise ValueError(kind)
 
 
+def _load_mlp(seq, g, prefix):
+    import torch
+    from l2hmc_amd import layers
+    w = layers.extract_mlp3(seq)
+    with torch.no_grad():
+        for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
+            w[k].copy_(torch.as_tensor(g[prefix + k]).reshape(w[k].shape))
+
+
+def aux_of(g):
+    """Device tensor of the conditioning images for the VAE-shaped cases, else None."""
+    return to_dev(g["aux"]) if str(g["energy.kind"]) == "vae" else None
+
+
 def hip_dynamics(g, variant=0):
     """l2hmc_amd.Dynamics loaded with the golden's weights, mask and step size."""
     import torch
     from l2hmc_amd import Dynamics, layers
     hmc = bool(int(g["hmc"]))
-    dyn = Dynamics(int(g["x_dim"]), hip_energy(g), T=int(g["T"]), eps=float(g["eps"]), hmc=hmc,
-                   net_factory=None if hmc else layers.stq_network(int(g["H"])))
+    if str(g["energy.kind"]) == "vae":
+        from l2hmc_amd import vae
+        d, H = int(g["x_dim"]), int(g["H"])
+        dec = vae.make_decoder(d, g["dec.W1"].shape[1], g["dec.W3"].shape[1])
+        enc = vae.make_encoder_sampler(g["enc.W1"].shape[0], g["enc.W1"].shape[1], H)
+        _load_mlp(dec, g, "dec.")
+        _load_mlp(enc, g, "enc.")
+        energy, factory = vae.VAEPosterior(dec).get_energy_function(), vae.sampler_net_factory(d, enc, H, H)
+    else:
+        energy, factory = hip_energy(g), (None if hmc else layers.stq_network(int(g["H"])))
+    dyn = Dynamics(int(g["x_dim"]), energy, T=int(g["T"]), eps=float(g["eps"]), hmc=hmc, net_factory=factory)
     dyn.mask = g["mask"]
     dyn.eps_override = float(g["eps"])
     dyn.variant = variant
@@ -164,4 +187,21 @@ def synthetic_case(kind, d, H=10, T=10, N=64, seed=0, eps=0.1, head_std=0.3):
         raise ValueError(kind)
     g["x"] = (rng.randn(N, d) * scale).astype(np.float32)
     g["v"] = rng.randn(N, d).astype(np.float32)
+    return g
+
+
+def synthetic_vae_case(latent=50, H=200, dec_h=1024, n_pix=784, enc_h=512, T=5, N=256, seed=0, eps=0.1):
+    """Config-5 sized golden-shaped dict (random weights at init-like scales; no checkpoint or
+    MNIST exists offline): consumed by oracle_dynamics() and hip_dynamics()."""
+    rng = np.random.RandomState(seed)
+    g = synthetic_case("roughwell_easy", latent, H=H, T=T, N=N, seed=seed, eps=eps, head_std=0.05)
+    g["energy.kind"] = "vae"
+
+    def lin(i, o, f=1.0):
+        return (np.clip(rng.randn(i, o), -2, 2) * np.sqrt(1.3 * 2 * f / i)).astype(np.float32)
+    for pre, dims, f3 in (("dec.", (latent, dec_h, dec_h, n_pix), 0.01), ("enc.", (n_pix, enc_h, enc_h, H), 1.0)):
+        g[pre + "W1"], g[pre + "W2"], g[pre + "W3"] = lin(dims[0], dims[1]), lin(dims[1], dims[2]), lin(dims[2], dims[3], f3)
+        for i, n in enumerate(dims[1:], 1):
+            g[pre + "b%d" % i] = (0.05 * rng.randn(n)).astype(np.float32)
+    g["aux"] = (rng.rand(N, n_pix) < 0.13).astype(np.float32)
     return g

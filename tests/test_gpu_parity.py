@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import l2hmc_oracle as O
-from tests.helpers import (CASES, abs_err, check_x_next, hip_dynamics, load, oracle_dynamics, rel_err,
+from tests.helpers import (CASES, abs_err, aux_of, check_x_next, hip_dynamics, load, oracle_dynamics, rel_err,
                            to_dev, to_np)
 
 pytestmark = pytest.mark.gpu
@@ -27,8 +27,8 @@ def test_energy_and_grad(case):
     g = load(case)
     dyn = hip_dynamics(g)
     x = to_dev(g["x"])
-    assert rel_err(to_np(dyn.energy(x)), g["energy"]) < 1e-5
-    assert rel_err(to_np(dyn.grad_energy(x)), g["grad_energy"]) < 1e-5
+    assert rel_err(to_np(dyn.energy(x, aux=aux_of(g))), g["energy"]) < 1e-5
+    assert rel_err(to_np(dyn.grad_energy(x, aux=aux_of(g))), g["grad_energy"]) < 1e-5
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -38,8 +38,8 @@ def test_single_steps(case):
         dyn = hip_dynamics(g, var)
         x, v = to_dev(g["x"]), to_dev(g["v"])
         for s in g["steps"]:
-            xo, vo, lj = dyn._forward_step(x, v, int(s))
-            xb, vb, ljb = dyn._backward_step(x, v, int(s))
+            xo, vo, lj = dyn._forward_step(x, v, int(s), aux=aux_of(g))
+            xb, vb, ljb = dyn._backward_step(x, v, int(s), aux=aux_of(g))
             for got, key in ((xo, "fstep%d.x"), (vo, "fstep%d.v"), (lj, "fstep%d.logdet"),
                              (xb, "bstep%d.x"), (vb, "bstep%d.v"), (ljb, "bstep%d.logdet")):
                 assert rel_err(to_np(got), g[key % s]) < STEP_TOL, (case, var, key % s)
@@ -52,8 +52,8 @@ def test_trajectories_and_accept_prob(case):
         dyn = hip_dynamics(g, var)
         x, v = to_dev(g["x"]), to_dev(g["v"])
         for nm, fn in (("fwd", dyn.forward), ("bwd", dyn.backward)):
-            X, V, lj = fn(x, init_v=v, log_jac=True)
-            X2, V2, p = fn(x, init_v=v)
+            X, V, lj = fn(x, init_v=v, log_jac=True, aux=aux_of(g))
+            X2, V2, p = fn(x, init_v=v, aux=aux_of(g))
             assert np.array_equal(to_np(X), to_np(X2), equal_nan=True)
             assert rel_err(to_np(X), g[nm + ".x"]) < TRAJ_TOL, (case, var, nm)
             assert rel_err(to_np(V), g[nm + ".v"]) < TRAJ_TOL, (case, var, nm)
@@ -79,7 +79,7 @@ def test_propose_matches_reference(case):
         else:
             Lx, Lv, px, outs = propose(x, dyn, do_mh_step=True, direction=to_dev(g["prop.dir"]),
                                        v=(to_dev(g["prop.v_fwd"]), to_dev(g["prop.v_bwd"])),
-                                       u=to_dev(g["prop.u"]))
+                                       u=to_dev(g["prop.u"]), aux=aux_of(g))
             assert Lv is None                       # sampler.py:40-42: no init_v -> no Lv
         assert rel_err(to_np(Lx), g["prop.Lx"]) < TRAJ_TOL
         assert abs_err(to_np(px), g["prop.px"]) < P_TOL
@@ -462,3 +462,28 @@ def test_short_training_run_improves_the_objective():
     print("loss %.1f -> %.1f, accept %.2f" % (losses[0], np.mean(losses[-20:]), float(px.mean())))
     assert -200 < losses[0] < 0 and np.mean(losses[-20:]) < -1000
     assert torch.isfinite(x).all()
+
+
+def test_config5_full_size_against_oracle():
+    """BASELINE.json config 5 shapes (latent 50, nets H=200 with the 784->512->512->200 image branch,
+    decoder 50->1024->1024->784, Lf=5) on the split engine vs the oracle, direction-mixed propose."""
+    from l2hmc_amd import propose
+    from tests.helpers import synthetic_vae_case
+    g = synthetic_vae_case(N=192, seed=3)
+    dyn, od = hip_dynamics(g), oracle_dynamics(g)
+    N = 192
+    rng = np.random.RandomState(1)
+    direction = rng.randint(0, 2, size=N).astype(np.uint8)
+    u = rng.rand(N).astype(np.float32)
+    aux = aux_of(g)
+    x, v = to_dev(g["x"]), to_dev(g["v"])
+    U, gr = dyn.energy(x, aux=aux), dyn.grad_energy(x, aux=aux)
+    rU, rg = od._energy(g["x"])
+    assert rel_err(to_np(U), rU) < 1e-5 and rel_err(to_np(gr), rg) < 1e-4
+    Lx, _, px, outs = propose(x, dyn, do_mh_step=True, direction=to_dev(direction), v=v, u=to_dev(u), aux=aux)
+    with np.errstate(all="ignore"):
+        rLx, _, rpx, _ = O.propose(g["x"], od, g["v"], g["v"], direction, u, both_directions=False)
+    print("config5: mean p %.3f  max rel err x %.2e  max abs err p %.2e" % (float(rpx.mean()), rel_err(to_np(Lx), rLx), abs_err(to_np(px), rpx)))
+    assert rel_err(to_np(Lx), rLx) < 2 * TRAJ_TOL
+    assert abs_err(to_np(px), rpx) < 5 * P_TOL       # |U| ~ 550: fp32 rounding of the energy difference
+    check_x_next(to_np(outs[0]), g["x"], rLx, rpx, u, 5 * P_TOL)
