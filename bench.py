@@ -207,7 +207,6 @@ def main():
     a.p_out = p_out.data_ptr()
     stream = torch.cuda.current_stream(dev).cuda_stream
     bufs = [xa, xb]
-    acc_sum = torch.zeros((), device=dev)
 
     state = {"flip": 0}
 
