@@ -285,20 +285,53 @@ __device__ __forceinline__ void dense_matvec(const float* Gp, const KArgs& A, fl
 
 // grad U (S-layout) and this lane's share of U (summing `Upart` over the chain's lanes
 // gives U).  dynamics.py:203-218 with the energies of distributions.py.
+// Per-lane energy constants kept in registers across the whole launch (diagonal Gaussian: this
+// lane's slice of the mean and of the precision diagonal).
+template <int EK, int DT>
+struct EnergyRegs {
+  static constexpr int NR = (EK == L2HMC_ENERGY_GAUSS_DIAG && DT <= 2) ? DT : 1;
+  f4 mu[NR], prec[NR];
+  bool loaded;
+};
+template <int EK, int DT, int NW>
+__device__ __forceinline__ void load_energy_regs(EnergyRegs<EK, DT>& er, const KArgs& A, const float* smem, int w,
+                                                 int lane) {
+  er.loaded = false;
+  if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG && DT <= 2) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const int off = 16 * (w * DT + t) + 4 * (lane >> 4);
+      const bool ok = (w * DT + t) < A.NT;
+      er.mu[t] = ok ? lds4(smem + A.o_mu + off) : splat(0.f);
+      er.prec[t] = ok ? lds4(smem + A.o_prec + off) : splat(0.f);
+    }
+    er.loaded = true;
+  }
+}
+
 template <int EK, int DT, int NW>
 __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, int lane,
                                             const f4 (&x)[DT], f4 (&g)[DT], float& Upart,
-                                            bool wantU) {
+                                            bool wantU, const EnergyRegs<EK, DT>* er = nullptr) {
   const int q = lane >> 4, DP = 16 * A.NT;
   float U = 0.f;
   if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
     {
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        const int off = 16 * (w * DT + t) + 4 * q;
-        const bool ok = (w * DT + t) < A.NT;
-        const f4 mu = ok ? lds4(smem + A.o_mu + off) : splat(0.f);
-        const f4 s = ok ? lds4(smem + A.o_prec + off) : splat(0.f);
+        f4 mu, s;
+        if constexpr (DT <= 2) {
+          if (er != nullptr) { mu = er->mu[t]; s = er->prec[t]; }
+          else {
+            const bool ok = (w * DT + t) < A.NT;
+            mu = ok ? lds4(smem + A.o_mu + 16 * (w * DT + t) + 4 * q) : splat(0.f);
+            s = ok ? lds4(smem + A.o_prec + 16 * (w * DT + t) + 4 * q) : splat(0.f);
+          }
+        } else {
+          const bool ok = (w * DT + t) < A.NT;
+          mu = ok ? lds4(smem + A.o_mu + 16 * (w * DT + t) + 4 * q) : splat(0.f);
+          s = ok ? lds4(smem + A.o_prec + 16 * (w * DT + t) + 4 * q) : splat(0.f);
+        }
         const f4 dx = x[t] - mu;
         g[t] = s * dx;
         U += 0.5f * hsum(dx * g[t]);
@@ -414,17 +447,45 @@ __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, 
 
 // Layer-1 partial pre-activation from one input, summed over this wave's dimension tiles.
 // grp0 = 0 selects the weights of input `a` (W1), grp0 = NT those of input `b` (W2).
+// For DT <= 2 the wave's layer-1 A fragments (one float4 per tile per input per net) are loaded
+// ONCE per launch and stay in registers (`L1W`): no LDS round trip in front of the MFMAs.
+template <int DT>
+struct L1W {
+  static constexpr bool RES = DT <= 2;          // register-resident?
+  f4 xa[RES ? DT : 1], xb[RES ? DT : 1], va[RES ? DT : 1], vb[RES ? DT : 1];
+};
+template <int DT, int NW>
+__device__ __forceinline__ void load_l1w(L1W<DT>& l, const float* wx, const float* wv, const KArgs& A, int w,
+                                         int lane) {
+  if constexpr (L1W<DT>::RES) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const int tg = w * DT + t;
+      const bool ok = 16 * tg < A.d;
+      l.xa[t] = ok ? lds4(wx + (tg * 64 + lane) * 4) : splat(0.f);
+      l.xb[t] = ok ? lds4(wx + ((A.NT + tg) * 64 + lane) * 4) : splat(0.f);
+      l.va[t] = ok ? lds4(wv + (tg * 64 + lane) * 4) : splat(0.f);
+      l.vb[t] = ok ? lds4(wv + ((A.NT + tg) * 64 + lane) * 4) : splat(0.f);
+    }
+  }
+}
 template <int DT, int NW>
 __device__ __forceinline__ f4 l1_part(const float* wn, int grp0, const KArgs& A, int w, int lane,
-                                      const f4 (&z)[DT], f4 acc) {
+                                      const f4 (&z)[DT], f4 acc, const f4* Wres = nullptr) {
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
     const int tg = w * DT + t;
-    if (16 * tg < A.d) {
-      const f4 W = lds4(wn + ((grp0 + tg) * 64 + lane) * 4);
+    if constexpr (L1W<DT>::RES) {
+      const f4 W = Wres[t];           // zero for dead tiles: no guard branch at all
 #pragma unroll
-      for (int r = 0; r < 4; ++r)     // dead k-steps (dims >= d) multiply zeros: no guard branch
-        acc = MFMA16(W[r], z[t][r], acc);
+      for (int r = 0; r < 4; ++r) acc = MFMA16(W[r], z[t][r], acc);
+    } else {
+      if (16 * tg < A.d) {
+        const f4 W = lds4(wn + ((grp0 + tg) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)   // dead k-steps (dims >= d) multiply zeros: no guard branch
+          acc = MFMA16(W[r], z[t][r], acc);
+      }
     }
   }
   return acc;
@@ -443,11 +504,19 @@ __device__ __forceinline__ void xchg(f4 (&p)[NP], const KArgs& A, float* smem, i
 #pragma unroll
     for (int i = 0; i < NP; ++i) *reinterpret_cast<f4*>(P + ((w * 2 + i) * 64 + lane) * 4) = p[i];
     __syncthreads();
+    // all NW * NP reads are issued back to back into distinct registers and summed afterwards
+    // (a running sum makes the compiler wait for each read before issuing the next)
+    f4 part[NP][NW];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) part[i][ww] = lds4(P + ((ww * 2 + i) * 64 + lane) * 4);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      f4 sum = lds4(P + (i * 64 + lane) * 4);
+      f4 sum = part[i][0];
 #pragma unroll
-      for (int ww = 1; ww < NW; ++ww) sum += lds4(P + ((ww * 2 + i) * 64 + lane) * 4);
+      for (int ww = 1; ww < NW; ++ww) sum += part[i][ww];
       p[i] = sum;
     }
     pb ^= 1;
@@ -532,6 +601,9 @@ __device__ __forceinline__ void net_tail(const TailW<DT>& tw, f4 hpre, f4 tb, fl
       zq = MFMA16(Wq[r], h[r], zq);
       zt = MFMA16(Wt[r], h[r], zt);
     }
+#endif
+#ifdef L2HMC_IGLP
+    __builtin_amdgcn_iglp_opt(L2HMC_IGLP);
 #endif
     const f4 aS = ctanh4(es * kS, zs);
     apply(t, exp2_4(aS), aS, zt, exp2_4(ctanh4(eq * kQ, zq)));
@@ -675,17 +747,21 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
   int pb = 0;
   const f4 Z = splat(0.f);
   float U_start;                 // this lane's share of U at the current state
-  grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, U_start, need_p);
+  EnergyRegs<EK, DT> er;
+  load_energy_regs<EK, DT, NW>(er, A, smem, w, lane);
+  grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, U_start, need_p, &er);
 
   // VNet layer-1 partial at the current (x, grad U): shared by the closing half-update of one
   // step and the opening half-update of the next, and kept across proposals.
   TailW<DT> tw;
+  L1W<DT> l1w;
+  if (has_nets) load_l1w<DT, NW>(l1w, wx, wv, A, w, lane);
   f4 pv[1] = {Z};
   PT_DECL;
   PT_MARK(0);      // prologue (staging + first grad)
   if (has_nets && A.n_steps > 0) {
     load_tail<DT, NW>(tw, wv, A, w, lane);
-    pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z));
+    pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z, l1w.va), l1w.vb);
     xchg<NW, 1>(pv, A, smem, w, lane, pb);
   }
 
@@ -785,8 +861,8 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
 #pragma unroll
       for (int t = 0; t < DT; ++t) xin[t] = k1[t] * x[t];
       f4 px[2];
-      px[0] = l1_part<DT, NW>(wx, 0, A, w, lane, vh, Z);
-      px[1] = l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z);
+      px[0] = l1_part<DT, NW>(wx, 0, A, w, lane, vh, Z, l1w.xa);
+      px[1] = l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z, l1w.xb);
       PT_MARK(3);  // XNet layer-1 partials (a, b)
       xchg<NW, 2>(px, A, smem, w, lane, pb);
       PT_MARK(4);  // exchange
@@ -797,7 +873,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
 #pragma unroll
       for (int t = 0; t < DT; ++t) xin[t] = (O - k1[t]) * y[t];
       f4 py[1];
-      py[0] = l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z);
+      py[0] = l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z, l1w.xb);
       PT_MARK(6);  // XNet layer-1 partial (b only)
       xchg<NW, 1>(py, A, smem, w, lane, pb);
       PT_MARK(7);  // exchange
@@ -809,8 +885,8 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
       // ---- momentum half-update #2 at the new position  (:147-153 / :192-199); its layer-1
       //      partial is reused by half-update #1 of the next step
       load_tail<DT, NW>(tw, wv, A, w, lane);
-      grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1);
-      pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z));
+      grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1, &er);
+      pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z, l1w.va), l1w.vb);
       PT_MARK(9);  // grad U + VNet layer-1 partials
       xchg<NW, 1>(pv, A, smem, w, lane, pb);
       PT_MARK(10); // exchange
@@ -826,7 +902,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
         y[t] = x_half(x[t], k1[t], vh[t], O, Z, Z, O, eps, fwd, ld);
         x[t] = x_half(y[t], O - k1[t], vh[t], O, Z, Z, O, eps, fwd, ld);
       }
-      grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1);
+      grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1, &er);
 #pragma unroll
       for (int t = 0; t < DT; ++t) v[t] = v_half(vh[t], g[t], O, Z, Z, O, heps, fwd, ld);
     }
