@@ -761,7 +761,8 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
   PT_MARK(0);      // prologue (staging + first grad)
   if (has_nets && A.n_steps > 0) {
     load_tail<DT, NW>(tw, wv, A, w, lane);
-    pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z, l1w.va), l1w.vb);
+    // (two independent accumulators: the MFMA chain is pipe-bound, not latency-bound)
+    pv[0] = l1_part<DT, NW>(wv, 0, A, w, lane, x, Z, l1w.va) + l1_part<DT, NW>(wv, NT, A, w, lane, g, Z, l1w.vb);
     xchg<NW, 1>(pv, A, smem, w, lane, pb);
   }
 
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
       //      partial is reused by half-update #1 of the next step
       load_tail<DT, NW>(tw, wv, A, w, lane);
       grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1, &er);
-      pv[0] = l1_part<DT, NW>(wv, NT, A, w, lane, g, l1_part<DT, NW>(wv, 0, A, w, lane, x, Z, l1w.va), l1w.vb);
+      pv[0] = l1_part<DT, NW>(wv, 0, A, w, lane, x, Z, l1w.va) + l1_part<DT, NW>(wv, NT, A, w, lane, g, Z, l1w.vb);
       PT_MARK(9);  // grad U + VNet layer-1 partials
       xchg<NW, 1>(pv, A, smem, w, lane, pb);
       PT_MARK(10); // exchange
