@@ -102,8 +102,8 @@ class ConcatLinear(object):
 class Parallel(object):
     """layers.py:60-66."""
 
-    def __init__(self, layers=[]):
-        self.layers = layers
+    def __init__(self, layers=None):
+        self.layers = [] if layers is None else layers       # (no shared mutable default)
 
     def add(self, layer):
         self.layers.append(layer)
@@ -118,8 +118,8 @@ class Parallel(object):
 class Sequential(object):
     """layers.py:68-79."""
 
-    def __init__(self, layers=[]):
-        self.layers = layers
+    def __init__(self, layers=None):
+        self.layers = [] if layers is None else layers       # (no shared mutable default)
 
     def add(self, layer):
         self.layers.append(layer)
@@ -156,8 +156,8 @@ class ScaleTanh(object):
 class Zip(object):
     """layers.py:88-95."""
 
-    def __init__(self, layers=[]):
-        self.layers = layers
+    def __init__(self, layers=None):
+        self.layers = [] if layers is None else layers       # (no shared mutable default)
 
     def parameters(self):
         return _collect(self.layers)

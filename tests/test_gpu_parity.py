@@ -487,3 +487,25 @@ def test_config5_full_size_against_oracle():
     assert rel_err(to_np(Lx), rLx) < 2 * TRAJ_TOL
     assert abs_err(to_np(px), rpx) < 5 * P_TOL       # |U| ~ 550: fp32 rounding of the energy difference
     check_x_next(to_np(outs[0]), g["x"], rLx, rpx, u, 5 * P_TOL)
+
+
+def test_logdet_is_log_abs_det_jacobian_on_the_hip_path():
+    """the log-det returned by `_forward_step` / `_backward_step` equals
+    log|det d(x', v')/d(x, v)| of the map the kernel actually computes (central differences,
+    every perturbation is one chain of a single batched launch)."""
+    g = load("scg2d")
+    dyn = hip_dynamics(g)
+    n = 2
+    h = 2e-2
+    for step_fn in (dyn._forward_step, dyn._backward_step):
+        for c in (0, 7, 33):
+            z0 = np.concatenate([g["x"][c], g["v"][c]]).astype(np.float64)
+            Z = np.repeat(z0[None], 1 + 4 * n, axis=0)
+            for i in range(2 * n):
+                Z[1 + 2 * i, i] += h
+                Z[2 + 2 * i, i] -= h
+            xo, vo, lj = step_fn(to_dev(Z[:, :n].astype(np.float32)), to_dev(Z[:, n:].astype(np.float32)), 4)
+            F = np.concatenate([to_np(xo), to_np(vo)], axis=1).astype(np.float64)
+            J = np.stack([(F[1 + 2 * i] - F[2 + 2 * i]) / (2 * h) for i in range(2 * n)], axis=1)
+            _, logabsdet = np.linalg.slogdet(J)
+            assert abs(logabsdet - float(lj[0])) < 2e-2, (step_fn.__name__, c, logabsdet, float(lj[0]))
