@@ -215,7 +215,9 @@ int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x,
  * d/d alpha = eps * d/d eps (dynamics.py:50-58).  inv_n = 1 / (chains over ALL ranks) so that
  * per-rank gradients simply all-reduce(sum).  The nets are the RAW reference-layout weights
  * (not the packed buffer); for the dense Gaussian `energy.prec` is the raw (d, d) precision.
- * Gaussian targets, d <= 64, H <= 16 in this round.  Every chain runs in its own direction. */
+ * Targets with analytic Hessian-vector products: Gaussian (diag / dense), GMM (prec = RAW (k,d,d)
+ * precisions, logc, n_comp <= 8), Rough Well; d <= 64, H <= 16 in this round.  Every chain runs in
+ * its own direction. */
 typedef struct L2hmcTrainArgs {
   const L2hmcNet* xnet;
   const L2hmcNet* vnet;

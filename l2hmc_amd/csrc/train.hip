@@ -23,8 +23,10 @@ struct TArgs {
   const float *x, *v;
   const unsigned char* dir;
   int dir_all;
-  int ekind;                 // GAUSS_DIAG: prec = (d) | GAUSS_DENSE: prec = raw (d, d) precision
-  const float *mu, *prec;
+  int ekind;                 // GAUSS_DIAG: prec = (d) | GAUSS_DENSE: raw (d, d) | GMM: raw (k, d, d)
+  int ncomp, easy;
+  const float *mu, *prec, *logc;
+  float eta;
   float scale, inv_n;
   float *Lx, *p, *v1, *grad, *ws;
 };
@@ -152,8 +154,11 @@ __global__ __launch_bounds__(256) void train_kernel(const TArgs A) {
   float* Ge = smem + 4 * P;
   float* Msk = smem + 4 * P + 4;     // masks (T, d)
   float* Trg = Msk + T * d;          // trig (T, 2)
-  float* Mu = Trg + 2 * T;           // mean (d), precision diag (d) or dense (d, d)
-  float* Pr = Mu + d;
+  const int nc = A.ekind == L2HMC_ENERGY_GMM ? A.ncomp : 1;
+  float* Mu = Trg + 2 * T;           // means (nc, d); precision diag (d) / dense (d, d) / (nc, d, d); log c (nc)
+  float* Pr = Mu + nc * d;
+  const int npr = A.ekind == L2HMC_ENERGY_GAUSS_DIAG ? d : (A.ekind == L2HMC_ENERGY_ROUGHWELL ? 0 : nc * d * d);
+  float* Lc = Pr + npr;
 
   // ---- stage ------------------------------------------------------------------------------------
   {
@@ -170,9 +175,12 @@ __global__ __launch_bounds__(256) void train_kernel(const TArgs A) {
     for (int i = tid; i < 2 * P + 4; i += 256) Gx[i] = 0.f;
     for (int i = tid; i < T * d; i += 256) Msk[i] = A.masks[i];
     for (int i = tid; i < 2 * T; i += 256) Trg[i] = A.trig[i];
-    for (int i = tid; i < d; i += 256) Mu[i] = A.mu[i];
-    const int np = A.ekind == L2HMC_ENERGY_GAUSS_DIAG ? d : d * d;
-    for (int i = tid; i < np; i += 256) Pr[i] = A.prec[i];
+    if (A.ekind != L2HMC_ENERGY_ROUGHWELL) {
+      for (int i = tid; i < nc * d; i += 256) Mu[i] = A.mu[i];
+      for (int i = tid; i < npr; i += 256) Pr[i] = A.prec[i];
+    }
+    if (A.ekind == L2HMC_ENERGY_GMM)
+      for (int i = tid; i < nc; i += 256) Lc[i] = A.logc[i];
   }
   __syncthreads();
 
@@ -185,22 +193,93 @@ __global__ __launch_bounds__(256) void train_kernel(const TArgs A) {
   const float heps = 0.5f * eps;
   const bool dense = A.ekind == L2HMC_ENERGY_GAUSS_DENSE;
 
-  // grad U = G (x - mu), G = (S + S^T)/2; also the Hessian-vector product (mu = 0 there)
-  auto matG = [&](const float* z, bool center, float* out) {
+  // ---- target: U, grad U, Hessian-vector product (oracle/l2hmc_train_oracle.py *Target classes) ----
+  const int ek = A.ekind;
+  const float rw_den = A.easy ? A.eta : A.eta * A.eta;
+  // y = G_c (z - mu_c) for component c (G = (S + S^T)/2; diagonal kind: elementwise); center=false: G z
+  auto matG = [&](int c, const float* z, bool center, float* out) {
+    const float* mu = Mu + c * d;
     for (int k = 0; k < d; ++k) {
-      if (!dense) {
-        out[k] = Pr[k] * (z[k] - (center ? Mu[k] : 0.f));
+      if (ek == L2HMC_ENERGY_GAUSS_DIAG) {
+        out[k] = Pr[k] * (z[k] - (center ? mu[k] : 0.f));
       } else {
+        const float* S = Pr + c * d * d;
         float acc = 0.f;
-        for (int j = 0; j < d; ++j) acc += 0.5f * (Pr[k * d + j] + Pr[j * d + k]) * (z[j] - (center ? Mu[j] : 0.f));
+        for (int j = 0; j < d; ++j) acc += 0.5f * (S[k * d + j] + S[j * d + k]) * (z[j] - (center ? mu[j] : 0.f));
         out[k] = acc;
       }
     }
   };
-  auto energy = [&](const float* z, const float* gz) {   // U = (x - mu) . G (x - mu) / 2
+  constexpr int KC = 8;      // max mixture components
+  // softmax weights w_c and y_c of the GMM at z; returns logsumexp
+  auto gmm_parts = [&](const float* z, float (*ys)[DM], float* wts) {
+    float V[KC], m = -INFINITY;
+    for (int c = 0; c < nc; ++c) {
+      matG(c, z, true, ys[c]);
+      const float* S = Pr + c * d * d;
+      float q = 0.f;                       // (z - mu)^T S (z - mu) == (z - mu)^T G (z - mu)
+      for (int k = 0; k < d; ++k) q += (z[k] - Mu[c * d + k]) * ys[c][k];
+      (void)S;
+      V[c] = -0.5f * q + Lc[c];
+      m = fmaxf(m, V[c]);
+    }
+    float sum = 0.f;
+    for (int c = 0; c < nc; ++c) { wts[c] = expf(V[c] - m); sum += wts[c]; }
+    for (int c = 0; c < nc; ++c) wts[c] /= sum;
+    return m + logf(sum);
+  };
+  auto gradU = [&](const float* z, float* out) {
+    if (ek == L2HMC_ENERGY_ROUGHWELL) {
+      for (int k = 0; k < d; ++k) out[k] = z[k] - (A.eta / rw_den) * sinf(z[k] / rw_den);
+    } else if (ek == L2HMC_ENERGY_GMM) {
+      float ys[KC][DM], wts[KC];
+      gmm_parts(z, ys, wts);
+      for (int k = 0; k < d; ++k) {
+        float acc = 0.f;
+        for (int c = 0; c < nc; ++c) acc += wts[c] * ys[c][k];
+        out[k] = acc;
+      }
+    } else {
+      matG(0, z, true, out);
+    }
+  };
+  auto energyU = [&](const float* z) {
     float u = 0.f;
-    for (int k = 0; k < d; ++k) u += 0.5f * (z[k] - Mu[k]) * gz[k];
+    if (ek == L2HMC_ENERGY_ROUGHWELL) {
+      for (int k = 0; k < d; ++k) u += 0.5f * z[k] * z[k] + A.eta * cosf(z[k] / rw_den);
+    } else if (ek == L2HMC_ENERGY_GMM) {
+      float ys[KC][DM], wts[KC];
+      u = -gmm_parts(z, ys, wts);
+    } else {
+      float gz[DM];
+      matG(0, z, true, gz);
+      for (int k = 0; k < d; ++k) u += 0.5f * (z[k] - Mu[k]) * gz[k];
+    }
     return u;
+  };
+  // out = H(z) vec
+  auto hessvec = [&](const float* z, const float* vec, float* out) {
+    if (ek == L2HMC_ENERGY_ROUGHWELL) {
+      for (int k = 0; k < d; ++k) out[k] = (1.f - (A.eta / (rw_den * rw_den)) * cosf(z[k] / rw_den)) * vec[k];
+    } else if (ek == L2HMC_ENERGY_GMM) {
+      float ys[KC][DM], wts[KC], gz[DM], gv = 0.f, tmpv[DM];
+      gmm_parts(z, ys, wts);
+      for (int k = 0; k < d; ++k) {
+        float acc = 0.f;
+        for (int c = 0; c < nc; ++c) acc += wts[c] * ys[c][k];
+        gz[k] = acc;
+        gv += acc * vec[k];
+      }
+      for (int k = 0; k < d; ++k) out[k] = gz[k] * gv;
+      for (int c = 0; c < nc; ++c) {
+        float yv = 0.f;
+        for (int k = 0; k < d; ++k) yv += ys[c][k] * vec[k];
+        matG(c, vec, false, tmpv);
+        for (int k = 0; k < d; ++k) out[k] += wts[c] * (tmpv[k] - ys[c][k] * yv);
+      }
+    } else {
+      matG(0, vec, false, out);
+    }
   };
 
   float x[DM], v[DM], g1[DM], vh[DM], y[DM], xo[DM], g2[DM], kin[DM], tmp[DM];
@@ -211,15 +290,14 @@ __global__ __launch_bounds__(256) void train_kernel(const TArgs A) {
   for (int k = 0; k < d; ++k) { x[k] = live ? A.x[nn * d + k] : 0.f; v[k] = live ? A.v[nn * d + k] : 0.f; }
   float x0[DM], U0, K0 = 0.f, ld = 0.f;
   for (int k = 0; k < d; ++k) { x0[k] = x[k]; K0 += 0.5f * v[k] * v[k]; }
-  matG(x, true, g1);
-  U0 = energy(x, g1);
+  U0 = energyU(x);
 
   // one forward step from (x, v); fills vh, y, xo, g1, g2, the four caches and (x, v) <- new state
   auto step_fwd = [&](int it, bool keep_ld) {
     const int s = fwd ? it : (T - 1 - it);
     const float t0 = Trg[2 * s], t1 = Trg[2 * s + 1];
     const float* m = Msk + s * d;
-    matG(x, true, g1);
+    gradU(x, g1);
     net_fwd<DM, HM>(Wv, o, d, H, x, g1, t0, t1, c1);
     for (int k = 0; k < d; ++k) {
       const float ES = expf(sgn * heps * c1.S[k]), EQ = expf(eps * c1.Q[k]);
@@ -245,7 +323,7 @@ __global__ __launch_bounds__(256) void train_kernel(const TArgs A) {
       xo[k] = (1.f - kin[k]) * y[k] + kin[k] * nw;
       if (keep_ld) ld += kin[k] * sgn * eps * cb.S[k];
     }
-    matG(xo, true, g2);
+    gradU(xo, g2);
     net_fwd<DM, HM>(Wv, o, d, H, xo, g2, t0, t1, c2);
   };
 
@@ -264,8 +342,8 @@ __global__ __launch_bounds__(256) void train_kernel(const TArgs A) {
   }
   // ---- accept probability, loss term and the adjoint seeds ------------------------------------------
   float K1 = 0.f, sq = 0.f;
-  matG(x, true, g2);
-  const float U1 = energy(x, g2);
+  gradU(x, g2);
+  const float U1 = energyU(x);
   for (int k = 0; k < d; ++k) { K1 += 0.5f * v[k] * v[k]; sq += (x0[k] - x[k]) * (x0[k] - x[k]); }
   const float val = (U0 + K0) - (U1 + K1) + ld;
   const float p = accept_prob(val);
@@ -315,7 +393,7 @@ __global__ __launch_bounds__(256) void train_kernel(const TArgs A) {
     }
     net_bwd<DM, HM>(Wv, Gv, o, d, H, xo, g2, t0, t1, c2, dS, dT, dQ, da, db, lane);
     for (int k = 0; k < d; ++k) tmp[k] = dg[k] + db[k];
-    matG(tmp, false, dz);                                   // Hessian-vector product
+    hessvec(xo, tmp, dz);                                   // Hessian-vector product at x'
     for (int k = 0; k < d; ++k) lx[k] = lx[k] + da[k] + dz[k];   // = d xo
     // x' = x_half(y, k2, vh, X(vh, k2 y)),  k2 = 1 - k1
     for (int k = 0; k < d; ++k) {
@@ -378,7 +456,7 @@ __global__ __launch_bounds__(256) void train_kernel(const TArgs A) {
     }
     net_bwd<DM, HM>(Wv, Gv, o, d, H, x, g1, t0, t1, c1, dS, dT, dQ, da, db, lane);
     for (int k = 0; k < d; ++k) tmp[k] = dg[k] + db[k];
-    matG(tmp, false, dz);
+    hessvec(x, tmp, dz);
     for (int k = 0; k < d; ++k) lx[k] = lx[k] + da[k] + dz[k];
   }
   {
@@ -414,9 +492,15 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
   if (!a->xnet || !a->vnet || !a->masks || !a->trig || !a->x || !a->v || !a->Lx || !a->p || !a->v1 ||
       !a->grad || !a->workspace)
     return fail(L2HMC_ERR_ARG, "l2hmc_train_propose_grad: NULL pointer%s");
-  if (a->energy.kind != L2HMC_ENERGY_GAUSS_DIAG && a->energy.kind != L2HMC_ENERGY_GAUSS_DENSE)
-    return fail(L2HMC_ERR_UNSUPPORTED, "training supports Gaussian targets only (Hessian-vector products)%s");
-  if (!a->energy.mu || !a->energy.prec) return fail(L2HMC_ERR_ARG, "energy needs mu and prec (raw (d,d) precision for the dense kind)%s");
+  const int ek = a->energy.kind;
+  if (ek != L2HMC_ENERGY_GAUSS_DIAG && ek != L2HMC_ENERGY_GAUSS_DENSE && ek != L2HMC_ENERGY_GMM &&
+      ek != L2HMC_ENERGY_ROUGHWELL)
+    return fail(L2HMC_ERR_UNSUPPORTED, "training supports the Gaussian, GMM and Rough-Well targets (analytic Hessian-vector products)%s");
+  if (ek != L2HMC_ENERGY_ROUGHWELL && (!a->energy.mu || !a->energy.prec))
+    return fail(L2HMC_ERR_ARG, "energy needs mu and prec (RAW (d,d) precisions for the dense / GMM kinds)%s");
+  if (ek == L2HMC_ENERGY_GMM && (!a->energy.logc || a->energy.n_comp < 1 || a->energy.n_comp > 8))
+    return fail(L2HMC_ERR_ARG, "GMM training needs logc and 1 <= n_comp <= 8%s");
+  if (ek == L2HMC_ENERGY_ROUGHWELL && !(a->energy.eta > 0.f)) return fail(L2HMC_ERR_ARG, "roughwell needs eta > 0%s");
   if (!(a->energy.temperature == 1.f)) return fail(L2HMC_ERR_UNSUPPORTED, "training kernel: temperature must be 1%s");
   if (!a->alpha && !(a->eps_host > 0.f)) return fail(L2HMC_ERR_ARG, "eps must be > 0%s");
   if (!(a->scale > 0.f) || !(a->inv_n > 0.f)) return fail(L2HMC_ERR_ARG, "scale and inv_n must be > 0%s");
@@ -425,11 +509,14 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
   k.masks = a->masks; k.trig = a->trig; k.alpha = a->alpha; k.eps_host = a->eps_host;
   k.N = a->n_chains; k.d = a->d; k.H = a->H; k.T = a->T; k.x = a->x; k.v = a->v;
   k.dir = a->direction; k.dir_all = a->direction_all; k.ekind = a->energy.kind;
-  k.mu = a->energy.mu; k.prec = a->energy.prec; k.scale = a->scale; k.inv_n = a->inv_n;
+  k.mu = a->energy.mu; k.prec = a->energy.prec; k.logc = a->energy.logc; k.eta = a->energy.eta;
+  k.ncomp = ek == L2HMC_ENERGY_GMM ? a->energy.n_comp : 1; k.easy = a->energy.easy;
+  k.scale = a->scale; k.inv_n = a->inv_n;
   k.Lx = a->Lx; k.p = a->p; k.v1 = a->v1; k.grad = a->grad; k.ws = a->workspace;
   const int P = net_params(a->d, a->H);
-  const long long lds = 4LL * (4 * P + 4 + (long long)a->T * a->d + 2 * a->T + a->d +
-                               (a->energy.kind == L2HMC_ENERGY_GAUSS_DIAG ? a->d : a->d * a->d));
+  const int ncs = k.ncomp;
+  const long long npr = ek == L2HMC_ENERGY_GAUSS_DIAG ? a->d : (ek == L2HMC_ENERGY_ROUGHWELL ? 0 : (long long)ncs * a->d * a->d);
+  const long long lds = 4LL * (4 * P + 4 + (long long)a->T * a->d + 2 * a->T + (long long)ncs * a->d + npr + ncs + 4);
   if (lds > 160 * 1024) return fail(L2HMC_ERR_UNSUPPORTED, "training kernel needs %s%lld bytes of LDS", "", lds);
   const unsigned blocks = (unsigned)((a->n_chains + 255) / 256);
   hipStream_t s = (hipStream_t)stream;

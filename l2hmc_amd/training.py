@@ -70,13 +70,16 @@ class Trainer(object):
         buf = fn._buffers(dyn.device)
         if fn.kind == _ffi.ENERGY_GAUSS_DIAG:
             prec = buf["prec"]
-        elif fn.kind == _ffi.ENERGY_GAUSS_DENSE:
-            prec = buf["_raw"][0]
+        elif fn.kind in (_ffi.ENERGY_GAUSS_DENSE, _ffi.ENERGY_GMM):
+            prec = buf["_raw"]                         # RAW (k, d, d) precisions, not the MFMA packing
+        elif fn.kind == _ffi.ENERGY_ROUGHWELL:
+            prec = None
         else:
-            raise NotImplementedError("training supports Gaussian targets only in this round")
+            raise NotImplementedError("training supports the Gaussian, GMM and Rough-Well targets")
         a = _ffi.L2hmcTrainArgs()
         a.xnet, a.vnet = C.pointer(xs), C.pointer(vs)
-        a.energy = _ffi.L2hmcEnergy(fn.kind, 1, buf["mu"].data_ptr(), prec.data_ptr(), None, 0.0, 0, 1.0)
+        a.energy = _ffi.L2hmcEnergy(fn.kind, fn.n_comp, _ffi.ptr(buf["mu"]), _ffi.ptr(prec), _ffi.ptr(buf["logc"]),
+                                    fn.eta, int(fn.easy), 1.0)
         a.masks, a.trig = dyn._mask.data_ptr(), dyn._trig.data_ptr()
         if dyn.eps_override is None:
             a.alpha, a.eps_host = dyn.alpha.data_ptr(), 0.0

@@ -4,7 +4,7 @@ Hand-derived reverse mode of the notebook's training loss (SCGExperiment.ipynb r
 156-169: two direction-mixed proposals, sampler.py:28-51, ESJD-style loss) through the
 generalised leapfrog trajectory (dynamics.py:115-201, 246-309), including the
 Hessian-vector path through `grad_energy` (TF1 differentiates through `tf.gradients`).
-Gaussian targets only (Hessian = (S + S^T)/2).  The HIP training kernel follows exactly this
+Targets with analytic Hessian-vector products: Gaussian, GMM, Rough Well.  The HIP training kernel follows exactly this
 derivation; this file is pinned against gradients produced by the reference's own graph under
 oracle/tf1_stub.py (tests/golden/train_*.npz, tests/test_oracle_golden.py).
 
@@ -99,16 +99,94 @@ def _x_half_bwd(dout, lam_ld, zin, kp, vh, S, T, Q, eps, sgn, fwd, aux):
     return dzin, dvh, dS, dT, dq * eps, deps
 
 
-def propose_loss_and_grad(x0, v0, direction, mu, i_sigma, xnet, vnet, eps, mask, T, scale=0.1,
+class GaussianTarget:
+    """U, grad U and Hessian-vector products of the reference's Gaussian (distributions.py:41-57)."""
+
+    def __init__(self, mu, i_sigma, dtype):
+        self.mu = np.asarray(mu, np.float32).astype(dtype)
+        self.S = np.asarray(i_sigma, np.float32).astype(dtype)
+        self.G = 0.5 * (self.S + self.S.T)
+
+    def energy(self, x):
+        dx = x - self.mu
+        return 0.5 * np.sum((dx @ self.S) * dx, axis=1)
+
+    def grad(self, x):
+        return (x - self.mu) @ self.G
+
+    def hessvec(self, x, v):
+        return v @ self.G
+
+
+class GMMTarget:
+    """distributions.py:104-134.  grad = sum_i w_i y_i, y_i = G_i (x - mu_i), w = softmax(V);
+    H v = sum_i w_i G_i v - sum_i w_i y_i (y_i . v) + g (g . v)."""
+
+    def __init__(self, mus, i_sigmas, constants, dtype):
+        self.mus = [np.asarray(m, np.float32).astype(dtype) for m in mus]
+        self.S = [np.asarray(s_, np.float32).astype(dtype) for s_ in i_sigmas]
+        self.G = [0.5 * (s_ + s_.T) for s_ in self.S]
+        self.logc = [np.log(np.asarray(c, np.float32)).astype(dtype) for c in constants]
+
+    def _parts(self, x):
+        ys = [(x - m) @ G for m, G in zip(self.mus, self.G)]
+        V = np.stack([-0.5 * np.sum(((x - m) @ S) * (x - m), axis=1) + lc
+                      for m, S, lc in zip(self.mus, self.S, self.logc)], axis=1)
+        mx = V.max(axis=1, keepdims=True)
+        e = np.exp(V - mx)
+        return ys, e / e.sum(axis=1, keepdims=True), np.log(e.sum(axis=1)) + mx[:, 0]
+
+    def energy(self, x):
+        return -self._parts(x)[2]
+
+    def grad(self, x):
+        ys, w, _ = self._parts(x)
+        return sum(w[:, i:i + 1] * ys[i] for i in range(len(ys)))
+
+    def hessvec(self, x, v):
+        ys, w, _ = self._parts(x)
+        g = sum(w[:, i:i + 1] * ys[i] for i in range(len(ys)))
+        out = g * np.sum(g * v, axis=1, keepdims=True)
+        for i, y in enumerate(ys):
+            out = out + w[:, i:i + 1] * (v @ self.G[i]) - w[:, i:i + 1] * y * np.sum(y * v, axis=1, keepdims=True)
+        return out
+
+
+class RoughWellTarget:
+    """distributions.py:84-97: grad = x - (eta/den) sin(x/den), H = diag(1 - (eta/den^2) cos(x/den))."""
+
+    def __init__(self, eta, easy, dtype):
+        self.eta = dtype(eta)
+        self.den = self.eta if easy else self.eta * self.eta
+
+    def energy(self, x):
+        return 0.5 * np.sum(x * x, axis=1) + self.eta * np.sum(np.cos(x / self.den), axis=1)
+
+    def grad(self, x):
+        return x - (self.eta / self.den) * np.sin(x / self.den)
+
+    def hessvec(self, x, v):
+        return (1.0 - (self.eta / (self.den * self.den)) * np.cos(x / self.den)) * v
+
+
+def target_of(g, dtype=np.float64):
+    kind = str(g['energy.kind'])
+    if kind == 'gaussian':
+        return GaussianTarget(g['energy.mu'], g['energy.i_sigma'], dtype)
+    if kind == 'gmm':
+        return GMMTarget(g['energy.mus'], g['energy.i_sigmas'], g['energy.constants'], dtype)
+    if kind == 'roughwell':
+        return RoughWellTarget(float(g['energy.eta']), bool(g['energy.easy']), dtype)
+    raise ValueError(kind)
+
+
+def propose_loss_and_grad(x0, v0, direction, target, xnet, vnet, eps, mask, T, scale=0.1,
                           dtype=np.float64):
     """One direction-mixed proposal from x0 with momenta v0 (each chain in its own direction) and
     its loss term  scale * mean(1/v1) - mean(v1)/scale,  v1 = |x0 - Lx|^2 p + 1e-4  (nb 164-169).
     Returns (loss, Lx, p, grads) with grads = {'xnet': {...}, 'vnet': {...}, 'eps': d loss/d eps}."""
     x0, v0 = np.asarray(x0, dtype), np.asarray(v0, dtype)
     N, d = x0.shape
-    mu = np.asarray(mu, np.float32).astype(dtype)
-    Sm = np.asarray(i_sigma, np.float32).astype(dtype)
-    G = 0.5 * (Sm + Sm.T)
     xn = {k: np.asarray(xnet[k], np.float32).astype(dtype) for k in NET_KEYS}
     vn = {k: np.asarray(vnet[k], np.float32).astype(dtype) for k in NET_KEYS}
     eps = dtype(eps)
@@ -117,12 +195,7 @@ def propose_loss_and_grad(x0, v0, direction, mu, i_sigma, xnet, vnet, eps, mask,
     sgn = np.where(fwd, 1.0, -1.0).astype(dtype)
     taus = np.stack([format_time(t, T, np.float32) for t in range(T)]).astype(dtype)
 
-    def gradU(x):
-        return (x - mu) @ G
-
-    def energy(x):
-        dx = x - mu
-        return 0.5 * np.sum((dx @ Sm) * dx, axis=1)
+    gradU, energy = target.grad, target.energy
 
     # ---- forward, keeping what the reverse sweep needs ------------------------------------------
     x, v = x0, v0
@@ -174,7 +247,7 @@ def propose_loss_and_grad(x0, v0, direction, mu, i_sigma, xnet, vnet, eps, mask,
         dvh, dg2, dS, dT, dQ, de = _v_half_bwd(lv, lam_ld, t['vh'], t['g2'], S2, T2, Q2, eps, sgn, fwd, t['a2'])
         deps += de
         da, db = _net_bwd(vn, t['c2'], dS, dT, dQ, gv)
-        dxo = lx + da + (dg2 + db) @ G
+        dxo = lx + da + target.hessvec(t['xo'], dg2 + db)
         # x' = x_half(y, k2, vh, X(vh, k2 y))
         dy, dvh2, dS, dT, dQ, de = _x_half_bwd(dxo, lam_ld, t['y'], t['k2'], t['vh'], Sb, Tb, Qb, eps, sgn, fwd, t['ab'])
         deps += de
@@ -191,7 +264,7 @@ def propose_loss_and_grad(x0, v0, direction, mu, i_sigma, xnet, vnet, eps, mask,
         dv, dg1, dS, dT, dQ, de = _v_half_bwd(dvh, lam_ld, t['v'], t['g1'], S1, T1, Q1, eps, sgn, fwd, t['a1'])
         deps += de
         da, db = _net_bwd(vn, t['c1'], dS, dT, dQ, gv)
-        lx = dx + da + (dg1 + db) @ G
+        lx = dx + da + target.hessvec(t['x'], dg1 + db)
         lv = dv
     return loss, x, p, {'xnet': gx, 'vnet': gv, 'eps': float(np.sum(deps))}
 
@@ -205,7 +278,7 @@ def training_loss_and_grad(g, dtype=np.float64):
     for tag, start in (('x', g['x']), ('z', g['z'])):
         dr = g[tag + '.dir']
         v0 = np.where(dr[:, None] != 0, g[tag + '.v_fwd'], g[tag + '.v_bwd'])
-        loss, Lx, p, gr = propose_loss_and_grad(start, v0, dr, g['energy.mu'], g['energy.i_sigma'], xn, vn,
+        loss, Lx, p, gr = propose_loss_and_grad(start, v0, dr, target_of(g, dtype), xn, vn,
                                                 g['eps'], g['mask'], int(g['T']), dtype=dtype)
         total += loss
         for net in ('xnet', 'vnet'):

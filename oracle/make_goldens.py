@@ -189,7 +189,7 @@ def run_case(name, x_dim, H, T, eps, N, energy_fn, energy_params, seed, hmc=Fals
         name, N, x_dim, T, out['fwd.p'].mean(), out['bwd.p'].mean(), np.abs(out['fwd.x']).max()))
 
 
-def train_case(name, mu, cov, H, T, eps, N, seed, head_std=0.3):
+def train_case(name, mu, cov, H, T, eps, N, seed, head_std=0.3, dist=None, params=None, x_start=None):
     """Gradient of the notebook's training loss (SCGExperiment.ipynb raw lines 156-169) w.r.t. every
     variable, produced by the reference's own graph (propose on x with MH + propose on z,
     sampler.py:28-51) differentiated by the stub's tf.gradients (= torch autograd)."""
@@ -198,11 +198,14 @@ def train_case(name, mu, cov, H, T, eps, N, seed, head_std=0.3):
     tf1_stub.VARIABLE_HOOK = variable_hook_factory(seed + 1, head_std)
     x_dim = len(mu)
     with contextlib.redirect_stdout(io.StringIO()):
-        dist = ref_distributions.Gaussian(np.asarray(mu, dtype=np.float64), np.asarray(cov, dtype=np.float64))
+        if dist is None:
+            dist = ref_distributions.Gaussian(np.asarray(mu, dtype=np.float64), np.asarray(cov, dtype=np.float64))
+            params = {'energy.kind': 'gaussian', 'energy.mu': dist.mu.astype(np.float32),
+                      'energy.i_sigma': dist.i_sigma.astype(np.float32)}
         dyn = ref_dynamics.Dynamics(x_dim, dist.get_energy_function(), T=T, eps=eps, net_factory=make_network(H))
-    out = {'energy.kind': 'gaussian', 'energy.mu': dist.mu.astype(np.float32),
-           'energy.i_sigma': dist.i_sigma.astype(np.float32), 'case': name, 'x_dim': x_dim, 'H': H,
-           'T': T, 'N': N, 'hmc': 0, 'eps': npy(dyn.eps), 'mask': npy(dyn.mask)}
+    out = dict(params)
+    out.update({'case': name, 'x_dim': x_dim, 'H': H,
+                'T': T, 'N': N, 'hmc': 0, 'eps': npy(dyn.eps), 'mask': npy(dyn.mask)})
     names = []
     for full, val in tf1_stub.VARIABLES.items():
         if full == 'alpha':
@@ -211,8 +214,11 @@ def train_case(name, mu, cov, H, T, eps, N, seed, head_std=0.3):
         out['%s.%s' % (scope.lower(), TF2KEY[rest])] = npy(val)
         names.append((full, '%s.%s' % (scope.lower(), TF2KEY[rest])))
     rng = np.random.RandomState(seed + 2)
-    C = np.linalg.cholesky(np.asarray(cov))
-    x = (rng.randn(N, x_dim) @ C.T + np.asarray(mu)).astype(np.float32)
+    if x_start is not None:
+        x = np.asarray(x_start(rng), dtype=np.float32)
+    else:
+        C = np.linalg.cholesky(np.asarray(cov))
+        x = (rng.randn(N, x_dim) @ C.T + np.asarray(mu)).astype(np.float32)
     z = rng.randn(N, x_dim).astype(np.float32)
     out['x'], out['z'] = x, z
     del tf1_stub.RANDOM_LOG[:]
@@ -415,6 +421,18 @@ def main():
     train_case('train_scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=64, seed=31)
     train_case('train_tilted8', rng8_mu, cov8, H=10, T=5, eps=0.1, N=32, seed=32)
     train_case('train_icg50', np.zeros(50), np.diag(var), H=10, T=4, eps=0.05, N=16, seed=33, head_std=0.05)
+
+    # ... and for the non-Gaussian smooth targets (Hessian-vector products of GMM / Rough Well)
+    mus_t = [np.array([2.0, 0.0], dtype=np.float32), np.array([-2.0, 0.0], dtype=np.float32)]
+    gmm_t = ref_distributions.GMM([torch.tensor(m) for m in mus_t], [0.5 * np.eye(2), 0.5 * np.eye(2)], [0.5, 0.5])
+    train_case('train_mog2d', np.zeros(2), None, H=10, T=6, eps=0.1, N=48, seed=34, head_std=0.3, dist=gmm_t,
+               params={'energy.kind': 'gmm', 'energy.mus': np.stack(mus_t), 'energy.i_sigmas': np.stack(gmm_t.i_sigmas),
+                       'energy.constants': np.array(gmm_t.constants, dtype=np.float32)},
+               x_start=lambda r: np.stack(mus_t)[r.randint(0, 2, size=48)] + np.sqrt(0.5) * r.randn(48, 2))
+    rw_t = ref_distributions.RoughWell(6, 0.3, easy=True)
+    train_case('train_rough6', np.zeros(6), None, H=10, T=5, eps=0.1, N=32, seed=35, head_std=0.3, dist=rw_t,
+               params={'energy.kind': 'roughwell', 'energy.eta': np.float32(0.3), 'energy.easy': np.int32(1)},
+               x_start=lambda r: r.randn(32, 6))
 
     # p_accept edge cases (dynamics.py:302-309): +-inf / NaN Hamiltonian differences -> 0
     tf1_stub.reset(0)

@@ -390,7 +390,7 @@ def test_sample_chain_with_in_kernel_rng(case):
         assert torch.equal(ps, p[:, lo:]) and torch.equal(xs, xf[lo:])
 
 
-@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50"])
+@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6"])
 def test_training_gradient_matches_reference_graph(case):
     """l2hmc_train_propose_grad (HIP, hand-derived reverse mode) vs tf.gradients of the notebook
     loss from the reference's own graph: loss, proposals, every parameter gradient and alpha."""
