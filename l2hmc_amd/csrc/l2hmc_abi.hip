@@ -167,7 +167,7 @@ long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW, int DT)
   with_nets = with_nets && !wg;
   const int NT = k.NT, DP = 16 * NT;
   long long o = 0;
-  if (with_nets) o += 2LL * net_floats(NT);
+  if (with_nets) o += 2LL * (net_floats(NT) - (DT <= 2 ? 2 * NT * 256 : 0));   // layer-1 groups live in registers
   k.o_mask = (int)o;
   if (with_schedule) o += (long long)k.T * DP;
   k.o_trig = (int)o;
@@ -175,7 +175,7 @@ long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW, int DT)
   k.o_tb = (int)o;
   if (with_schedule) o += 2LL * k.T * 16;
   k.o_P = (int)o;
-  if (NW > 1) o += 2LL * NW * 2 * 256;   // 2 buffers x NW waves x 2 partial vectors
+  if (NW > 1) o += 2LL * NW * 256;       // 2 buffers x NW waves x 1 partial vector
   k.xb_stride = DP + 4;
   k.o_XB = (int)o;
   if (NW > 1 && (k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM))

@@ -500,9 +500,9 @@ __device__ __forceinline__ void xchg(f4 (&p)[NP], const KArgs& A, float* smem, i
   return;
 #endif
   if (NW > 1) {
-    float* P = smem + A.o_P + pb * (NW * 2 * 256);
+    float* P = smem + A.o_P + pb * (NW * NP * 256);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) *reinterpret_cast<f4*>(P + ((w * 2 + i) * 64 + lane) * 4) = p[i];
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<f4*>(P + ((w * NP + i) * 64 + lane) * 4) = p[i];
     __syncthreads();
     // all NW * NP reads are issued back to back into distinct registers and summed afterwards
     // (a running sum makes the compiler wait for each read before issuing the next)
@@ -510,7 +510,7 @@ __device__ __forceinline__ void xchg(f4 (&p)[NP], const KArgs& A, float* smem, i
 #pragma unroll
     for (int i = 0; i < NP; ++i)
 #pragma unroll
-      for (int ww = 0; ww < NW; ++ww) part[i][ww] = lds4(P + ((ww * 2 + i) * 64 + lane) * 4);
+      for (int ww = 0; ww < NW; ++ww) part[i][ww] = lds4(P + ((ww * NP + i) * 64 + lane) * 4);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -698,7 +698,10 @@ __device__ __forceinline__ void stage_energy(const KArgs& A, float* smem, int ti
 template <int EK, int DT, int NW, int KH>
 // (waves-per-SIMD hint 2 for DT <= 2 caps the kernel at 256 VGPRs, which makes the compiler keep
 // MFMA accumulators in VGPRs -- no v_accvgpr_read traffic; wide-DT kernels keep all 512.)
-__global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const KArgs A) {
+#ifndef L2HMC_WAVES_PER_SIMD
+#define L2HMC_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void traj_kernel(const KArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * NW;
   const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
@@ -711,10 +714,16 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
 
   // ---- prologue: stage weights / masks / time table / energy parameters into LDS ----------
   constexpr bool WG = weights_in_global(DT);
+  // Layer-1 groups (the first 2 NT groups of each net) go straight from global memory into
+  // registers when L1W is resident, so only the rest of each net is staged in LDS.
+  const int skip = (L1W<DT>::RES && !WG) ? 2 * NT * 256 : 0;      // floats not staged per net
   if (has_nets && !WG) {
-    const f4* src = reinterpret_cast<const f4*>(A.packed);
+    const int per = (NF - skip) / 4;
     f4* dst = reinterpret_cast<f4*>(smem);
-    for (int i = tid; i < 2 * NF / 4; i += nthr) dst[i] = src[i];
+    for (int i = tid; i < 2 * per; i += nthr) {
+      const int net = i >= per, j = i - net * per;
+      dst[i] = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + skip)[j];
+    }
   }
   for (int i = tid; i < A.T * DP; i += nthr) {
     const int row = i / DP, dim = i % DP;
@@ -731,8 +740,10 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
                       (A.rng_flags & L2HMC_RNG_U) != 0;
   __syncthreads();
 
-  const float* wx = WG ? A.packed : smem;   // XNet fragments
-  const float* wv = wx + NF;                // VNet fragments
+  // bases such that `base + group * 256` addresses group `group` (the skipped layer-1 groups lie
+  // before the staged region and are never dereferenced through these)
+  const float* wx = WG ? A.packed : smem - skip;                    // XNet fragments
+  const float* wv = WG ? A.packed + NF : smem + (NF - skip) - skip;  // VNet fragments
   if (has_nets) {
     // time-embedding table TB[net][row s][unit row i] = W3[0,u] cos_s + W3[1,u] sin_s + b1+b2+b3
     // from the packed tau fragment (lane (i, q): q = 0 -> W3[0], 1 -> W3[1], 2 -> biases)
@@ -755,7 +766,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
   // step and the opening half-update of the next, and kept across proposals.
   TailW<DT> tw;
   L1W<DT> l1w;
-  if (has_nets) load_l1w<DT, NW>(l1w, wx, wv, A, w, lane);
+  if (has_nets) load_l1w<DT, NW>(l1w, A.packed, A.packed + NF, A, w, lane);
   f4 pv[1] = {Z};
   PT_DECL;
   PT_MARK(0);      // prologue (staging + first grad)
@@ -861,24 +872,26 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? 2 : 1)) void traj_kernel(const 
       load_tail<DT, NW>(tw, wx, A, w, lane);
 #pragma unroll
       for (int t = 0; t < DT; ++t) xin[t] = k1[t] * x[t];
-      f4 px[2];
-      px[0] = l1_part<DT, NW>(wx, 0, A, w, lane, vh, Z, l1w.xa);
-      px[1] = l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z, l1w.xb);
+      // the v_h contraction `pa` is computed once and enters both exchanges un-summed, so every
+      // exchange carries ONE partial vector per wave
+      const f4 pa = l1_part<DT, NW>(wx, 0, A, w, lane, vh, Z, l1w.xa);
+      f4 px[1];
+      px[0] = pa + l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z, l1w.xb);
       PT_MARK(3);  // XNet layer-1 partials (a, b)
-      xchg<NW, 2>(px, A, smem, w, lane, pb);
+      xchg<NW, 1>(px, A, smem, w, lane, pb);
       PT_MARK(4);  // exchange
-      net_tail<DT, KH>(tw, px[0] + px[1], tbx, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+      net_tail<DT, KH>(tw, px[0], tbx, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
         y[t] = x_half(x[t], k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ld);
       });
       PT_MARK(5);  // XNet tail #1
 #pragma unroll
       for (int t = 0; t < DT; ++t) xin[t] = (O - k1[t]) * y[t];
       f4 py[1];
-      py[0] = l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z, l1w.xb);
+      py[0] = pa + l1_part<DT, NW>(wx, NT, A, w, lane, xin, Z, l1w.xb);
       PT_MARK(6);  // XNet layer-1 partial (b only)
       xchg<NW, 1>(py, A, smem, w, lane, pb);
       PT_MARK(7);  // exchange
-      net_tail<DT, KH>(tw, px[0] + py[0], tbx, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
+      net_tail<DT, KH>(tw, py[0], tbx, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
         x[t] = x_half(y[t], O - k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ld);
       });
       PT_MARK(8);  // XNet tail #2
