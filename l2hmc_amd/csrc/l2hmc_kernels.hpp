@@ -148,9 +148,10 @@ __device__ __forceinline__ f4 ctanh4(f4 c, f4 z) {
                   __builtin_amdgcn_rcpf(u.w)};
   return c * (r * -2.f + 1.f);
 }
-__device__ __forceinline__ f4 relu4(f4 a) {
-  return f4{fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)};
-}
+// (an inline-asm single v_max_f32 was tried: it hides the MFMA->VALU read hazard from the
+// compiler's hazard recogniser and produced wrong results -- keep the builtin)
+__device__ __forceinline__ float relu1(float a) { return fmaxf(a, 0.f); }
+__device__ __forceinline__ f4 relu4(f4 a) { return f4{relu1(a.x), relu1(a.y), relu1(a.z), relu1(a.w)}; }
 __device__ __forceinline__ float hsum(f4 a) { return (a.x + a.y) + (a.z + a.w); }
 __device__ __forceinline__ f4 sel4(bool c, f4 a, f4 b) { return c ? a : b; }
 __device__ __forceinline__ f4 lds4(const float* p) { return *reinterpret_cast<const f4*>(p); }

@@ -4,12 +4,21 @@
 // trajectory (dynamics.py:115-201, 246-309), including the Hessian-vector path through
 // `grad_energy` (TF1 differentiates through tf.gradients).  Derivation = oracle/l2hmc_train_oracle.py.
 //
-// Round-1 form, correctness first: ONE CHAIN PER LANE, scalar loops over d and H, raw weights
-// staged in LDS (wave-uniform reads broadcast), per-step states checkpointed to a caller
-// workspace, step intermediates re-computed in the reverse sweep, parameter gradients reduced
-// over the wave with shuffles and accumulated in LDS, one global atomicAdd per parameter per
-// workgroup.  (The sampling hot path is the MFMA kernel in l2hmc_kernels.hpp; an MFMA form of
-// this kernel is future work.)  Gaussian targets (diagonal or dense precision), d <= 64, H <= 16.
+// Tile form: a workgroup of 4 waves owns 16 chains (= the N of v_mfma_f32_16x16x4_f32).  Every
+// per-chain vector lives in LDS as a (16, ld) matrix; every matrix product of the forward AND the
+// reverse sweep is a set of 16x16 fp32 MFMA tiles whose operands are gathered from those LDS
+// matrices with strides:
+//     forward layers            out(c, i)  = sum_k in(c, k) W(k, i)         K = d or H
+//     input adjoints            din(c, k)  = sum_i dout(c, i) W(k, i)       K = H or d
+//     weight gradients          dW(k, i)  += sum_c in(c, k) dout(c, i)      K = 16 chains
+// Bias / scale gradients are column sums over the 16 chains.  Gradients accumulate in an LDS
+// image of the flat parameter vector (each element owned by one lane per pass: no atomics) and
+// leave with one global atomicAdd per parameter per workgroup.  The forward trajectory checkpoints
+// (x, v, v_half, y, x') per step to a caller workspace; the reverse sweep re-evaluates each net
+// right before back-propagating through it, so only ONE net's activations are resident.
+// Thread t of the 256 owns chain t & 15 and dims / hidden units (t >> 4) + 16 j in every elementwise
+// phase (no index divisions; its chain's sign, step index and seeds sit in registers); with the
+// row pitch below those accesses and the MFMA operand gathers are bank-conflict free.
 #include "l2hmc_kernels.hpp"
 
 namespace l2hmc {
@@ -31,6 +40,12 @@ struct TArgs {
   float *Lx, *p, *v1, *grad, *ws;
 };
 
+constexpr int TC = 16;       // chains per workgroup
+constexpr int TNW = 4;       // waves per workgroup
+constexpr int TTHREADS = 64 * TNW;
+constexpr int KC = 8;        // max mixture components
+constexpr int CKPT = 5;      // checkpointed vectors per chain-step: x, v, v_half, y, x'
+
 __host__ __device__ inline int net_params(int d, int H) { return 5 * d * H + H * H + 6 * H + 5 * d; }
 // flat parameter layout of one net == NET_FIELDS order of include/l2hmc.h
 struct NetOff { int W1, b1, W2, b2, W3, b3, W4, b4, Ws, bs, Wt, bt, Wq, bq, ls, lq; };
@@ -44,428 +59,699 @@ __host__ __device__ inline NetOff net_off(int d, int H) {
   return o;
 }
 
+// row pitch of a (16, n) LDS matrix: a multiple of 4 floats (float4 epilogue stores) whose
+// quarter is odd, so the 16 chains x 4 k-groups of an MFMA operand gather hit 64 distinct banks
+__host__ __device__ inline int pitch(int n) {
+  int p = (n + 3) / 4 * 4;
+  if (((p / 4) & 1) == 0) p += 4;
+  return p;
+}
+
+// the (16, ldd) matrices
+enum { MX, MV, MVH, MY, MXO, MG, MLX, MLV, MDVH, MDZ, MTMP, MDS, MDT, MDQ, MDA, MDB, MDG, MTS, MT, MTQ, N_MD };
+// the (16, ldh) matrices
+enum { MH1, MH2, MDA2, MDA1, MPART, N_MH = MPART + TNW };
+
+struct TLayout {
+  int Wx, Wv, Gx, Gv, Ge, Msk, Trg, Mu, Pr, Lc, Ex, md, mh, wv, yv, cs, total;
+  int ldd, ldh, P;
+};
+__host__ __device__ inline TLayout train_layout(int d, int H, int T, int ek, int nc) {
+  TLayout L;
+  auto up4 = [](int n) { return (n + 3) / 4 * 4; };
+  L.ldd = pitch(d); L.ldh = pitch(H); L.P = net_params(d, H);
+  int p = 0;
+  L.Wx = p; p += up4(L.P);
+  L.Wv = p; p += up4(L.P);
+  L.Gx = p; p += up4(L.P);                 // Gx, Gv, Ge contiguous: zeroed / flushed together
+  L.Gv = L.Gx + L.P; p += up4(L.P);
+  L.Ge = L.Gx + 2 * L.P; p += 4;
+  L.Msk = p; p += up4(T * d);
+  L.Trg = p; p += up4(2 * T);
+  L.Mu = p; p += up4(nc * d);
+  const int npr = ek == L2HMC_ENERGY_GAUSS_DIAG ? d : (ek == L2HMC_ENERGY_ROUGHWELL ? 0 : nc * d * d);
+  L.Pr = p; p += up4(npr);
+  L.Lc = p; p += up4(nc);
+  L.Ex = p; p += 4 * up4(d);               // exp(lam_s), exp(lam_q) of the X net, then of the V net
+  L.md = p; p += N_MD * TC * L.ldd;
+  L.mh = p; p += N_MH * TC * L.ldh;
+  L.wv = p; p += TC * KC;
+  L.yv = p; p += TC * KC;
+  L.cs = p; p += 16 * TC;                  // per-chain scalars
+  L.total = p;
+  return L;
+}
+// per-chain scalar slots
+enum { CS_SGN, CS_LIVE, CS_U0, CS_K0, CS_LAM, CS_DV1P, CS_OK, CS_U1 };
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
 
-template <int DM, int HM>
-struct NetCache {
-  float h1[HM], h2[HM], ts[DM], tq[DM], S[DM], T[DM], Q[DM];
+// One 16x16 output tile: acc(m, n) += sum_{kk in [k0, k1)} A(m0 + m, kk) B(kk, n0 + n) with
+// A(m, kk) = Ap[m * a_sm + kk * a_sk] (m < M) and B(kk, n) = Bp[kk * b_sk + n * b_sn] (n < N).
+// Result layout (v_mfma_f32_16x16x4_f32): lane l holds rows m0 + 4 (l >> 4) + r, column n0 + (l & 15).
+__device__ __forceinline__ f4 mm_tile(f4 acc, const float* Ap, int a_sm, int a_sk, int M, int m0,
+                                      const float* Bp, int b_sk, int b_sn, int N, int n0, int k0,
+                                      int k1, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  const bool mok = m0 + r < M, nok = n0 + r < N;
+  const float* ap = Ap + (m0 + r) * a_sm;
+  const float* bp = Bp + (n0 + r) * b_sn;
+  for (int ks = k0; ks < k1; ks += 4) {
+    const int kk = ks + g;
+    const bool kok = kk < k1;
+    const float a = (mok && kok) ? ap[kk * a_sk] : 0.f;
+    const float b = (nok && kok) ? bp[kk * b_sk] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+struct TCtx {
+  int tid, lane, wave, g, r;       // g = lane >> 4, r = lane & 15
+  int d, H, T, ldd, ldh, tD, tH;   // tD, tH = 16-tiles over d and H
+  NetOff o;
+  float* md;                       // (N_MD, 16, ldd)
+  float* mh;                       // (N_MH, 16, ldh)
+  float* cs;                       // per-chain scalars [slot][16]
+  const float *Msk, *Trg;
+  int it;                          // trajectory step being processed
+  int c, kb;                       // this thread's chain (tid & 15) and first dim / hidden unit (tid >> 4)
+  float t0, t1;                    // time encoding of this thread's chain at step `it`
+  __device__ __forceinline__ float* D(int m) const { return md + m * TC * ldd; }
+  __device__ __forceinline__ float* Hm(int m) const { return mh + m * TC * ldh; }
+  __device__ __forceinline__ bool fwd(int c_) const { return cs[CS_SGN * TC + c_] > 0.f; }
+  __device__ __forceinline__ int step_of(int c_) const { return fwd(c_) ? it : (T - 1 - it); }
 };
 
-// [S, T, Q] = net([a, b, tau]) for this lane's chain; W = this net's flat weights in LDS.
-template <int DM, int HM>
-__device__ void net_fwd(const float* W, const NetOff& o, int d, int H, const float* a, const float* b,
-                        float t0, float t1, NetCache<DM, HM>& c) {
-  for (int i = 0; i < H; ++i) {
-    float acc = (W[o.b1 + i] + W[o.b2 + i]) + W[o.b3 + i] + t0 * W[o.W3 + i] + t1 * W[o.W3 + H + i];
-    for (int k = 0; k < d; ++k) acc += a[k] * W[o.W1 + k * H + i] + b[k] * W[o.W2 + k * H + i];
-    c.h1[i] = fmaxf(acc, 0.f);
-  }
-  for (int j = 0; j < H; ++j) {
-    float acc = W[o.b4 + j];
-    for (int i = 0; i < H; ++i) acc += c.h1[i] * W[o.W4 + i * H + j];
-    c.h2[j] = fmaxf(acc, 0.f);
-  }
-  for (int k = 0; k < d; ++k) {
-    float zs = W[o.bs + k], zt = W[o.bt + k], zq = W[o.bq + k];
-    for (int j = 0; j < H; ++j) {
-      zs += c.h2[j] * W[o.Ws + j * d + k];
-      zt += c.h2[j] * W[o.Wt + j * d + k];
-      zq += c.h2[j] * W[o.Wq + j * d + k];
+// ---- [ts, T, tq] caches and h1, h2 of net W at inputs (a, b, tau): 4 phases ---------------------------
+// (t_net_fwd / t_net_bwd are force-inlined: with the default heuristic the compiler inlined one and
+//  called the other, and that build produced wrong gradients and intermittent hangs on gfx950,
+//  while the all-inlined and the all-outlined builds of the same source are both correct)
+__device__ __forceinline__ void t_net_fwd(const TCtx& X, const float* W, const float* a, const float* b) {
+  const NetOff& o = X.o;
+  const int d = X.d, H = X.H, ldd = X.ldd, ldh = X.ldh, lane = X.lane;
+  {  // layer 1, K split over the 4 waves: waves 0,1 take W1^T a (two halves of k), waves 2,3 W2^T b
+    const int w = X.wave;
+    const float* in = (w < 2) ? a : b;
+    const float* Wt = W + ((w < 2) ? o.W1 : o.W2);
+    const int kh = (d + 7) / 8 * 4;
+    const int k0 = (w & 1) ? kh : 0, k1 = (w & 1) ? d : (kh < d ? kh : d);
+    float* part = X.Hm(MPART + w);
+    for (int tm = 0; tm < X.tH; ++tm) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mm_tile(acc, Wt, 1, H, H, 16 * tm, in, 1, ldd, TC, 0, k0, k1, lane);
+      const int i0 = 16 * tm + 4 * X.g;
+      if (i0 < ldh) *reinterpret_cast<f4*>(part + X.r * ldh + i0) = acc;
     }
-    c.ts[k] = tanhf(zs);
-    c.tq[k] = tanhf(zq);
-    c.S[k] = expf(W[o.ls + k]) * c.ts[k];
-    c.T[k] = zt;
-    c.Q[k] = expf(W[o.lq + k]) * c.tq[k];
   }
+  __syncthreads();
+  {
+    float* h1 = X.Hm(MH1);
+    const float *p0 = X.Hm(MPART), *p1 = X.Hm(MPART + 1), *p2 = X.Hm(MPART + 2), *p3 = X.Hm(MPART + 3);
+    for (int i = X.kb; i < H; i += 16) {
+      const int q = X.c * ldh + i;
+      const float acc = (W[o.b1 + i] + W[o.b2 + i]) + W[o.b3 + i] + X.t0 * W[o.W3 + i] + X.t1 * W[o.W3 + H + i];
+      h1[q] = fmaxf(acc + ((p0[q] + p1[q]) + (p2[q] + p3[q])), 0.f);
+    }
+  }
+  __syncthreads();
+  {  // layer 2
+    const float* h1 = X.Hm(MH1);
+    float* h2 = X.Hm(MH2);
+    for (int tm = X.wave; tm < X.tH; tm += TNW) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mm_tile(acc, W + o.W4, 1, H, H, 16 * tm, h1, 1, ldh, TC, 0, 0, H, lane);
+      for (int rr = 0; rr < 4; ++rr) {
+        const int j = 16 * tm + 4 * X.g + rr;
+        if (j < H) h2[X.r * ldh + j] = fmaxf(acc[rr] + W[o.b4 + j], 0.f);
+      }
+    }
+  }
+  __syncthreads();
+  {  // heads
+    const float* h2 = X.Hm(MH2);
+    for (int t = X.wave; t < 3 * X.tD; t += TNW) {
+      const int head = t / X.tD, tm = t - head * X.tD;
+      const float* Wh = W + (head == 0 ? o.Ws : (head == 1 ? o.Wt : o.Wq));
+      const int bo = head == 0 ? o.bs : (head == 1 ? o.bt : o.bq);
+      float* out = X.D(head == 0 ? MTS : (head == 1 ? MT : MTQ));
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mm_tile(acc, Wh, 1, d, d, 16 * tm, h2, 1, ldh, TC, 0, 0, H, lane);
+      for (int rr = 0; rr < 4; ++rr) {
+        const int k = 16 * tm + 4 * X.g + rr;
+        if (k < d) {
+          const float z = acc[rr] + W[bo + k];
+          out[X.r * ldd + k] = head == 1 ? z : ftanh(z);
+        }
+      }
+    }
+  }
+  __syncthreads();
 }
 
-// Reverse of net_fwd: parameter gradients (summed over the wave's chains) go to the LDS
-// accumulator G (same flat layout), input gradients to da, db.  dS/dT/dQ are consumed.
-template <int DM, int HM>
-__device__ void net_bwd(const float* W, float* G, const NetOff& o, int d, int H, const float* a,
-                        const float* b, float t0, float t1, const NetCache<DM, HM>& c, float* dS,
-                        float* dT, float* dQ, float* da, float* db, int lane) {
-  auto acc = [&](int idx, float v) {
-    const float s = wave_sum(v);
-    if (lane == 0) atomicAdd(&G[idx], s);
-  };
-  float dh[HM];
-  for (int j = 0; j < H; ++j) dh[j] = 0.f;
-  for (int k = 0; k < d; ++k) {
-    const float es = expf(W[o.ls + k]), eq = expf(W[o.lq + k]);
-    acc(o.ls + k, dS[k] * c.S[k]);
-    acc(o.lq + k, dQ[k] * c.Q[k]);
-    const float dzs = dS[k] * es * (1.f - c.ts[k] * c.ts[k]);
-    const float dzq = dQ[k] * eq * (1.f - c.tq[k] * c.tq[k]);
-    const float dzt = dT[k];
-    acc(o.bs + k, dzs);
-    acc(o.bt + k, dzt);
-    acc(o.bq + k, dzq);
-    for (int j = 0; j < H; ++j) {
-      acc(o.Ws + j * d + k, c.h2[j] * dzs);
-      acc(o.Wt + j * d + k, c.h2[j] * dzt);
-      acc(o.Wq + j * d + k, c.h2[j] * dzq);
-      dh[j] += W[o.Ws + j * d + k] * dzs + W[o.Wt + j * d + k] * dzt + W[o.Wq + j * d + k] * dzq;
+// ---- reverse of t_net_fwd: consumes dS, dT, dQ (MDS, MDT, MDQ), accumulates parameter gradients into
+// G, leaves the input adjoints in MDA (w.r.t. a) and MDB (w.r.t. b): 4 phases -------------------------------
+__device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* G, const float* a, const float* b) {
+  const NetOff& o = X.o;
+  const int d = X.d, H = X.H, ldd = X.ldd, ldh = X.ldh, lane = X.lane;
+  // on entry (written by the *_half_bwd phase): MDS, MDT, MDQ = d zs, d zt, d zq;  MDA = dS * S, MDB = dQ * Q
+  float *dS = X.D(MDS), *dT = X.D(MDT), *dQ = X.D(MDQ), *dA = X.D(MDA), *dB = X.D(MDB);
+  {
+    const float *h2 = X.Hm(MH2);
+    // head weight gradients  dWh(j, k) += sum_c h2(c, j) dz_h(c, k)
+    for (int t = X.wave; t < 3 * X.tH * X.tD; t += TNW) {
+      const int head = t / (X.tH * X.tD), u = t - head * X.tH * X.tD, tm = u / X.tD, tn = u - tm * X.tD;
+      const float* dz = head == 0 ? dS : (head == 1 ? dT : dQ);
+      float* Gh = G + (head == 0 ? o.Ws : (head == 1 ? o.Wt : o.Wq));
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mm_tile(acc, h2, 1, ldh, H, 16 * tm, dz, ldd, 1, d, 16 * tn, 0, TC, lane);
+      const int k = 16 * tn + X.r;
+      for (int rr = 0; rr < 4; ++rr) {
+        const int j = 16 * tm + 4 * X.g + rr;
+        if (j < H && k < d) Gh[j * d + k] += acc[rr];
+      }
+    }
+    // d h2 partial of head w:  part_w(c, j) = sum_k Wh(j, k) dz_h(c, k)      (wave 3: zero)
+    {
+      const int w = X.wave;
+      const float* dz = w == 0 ? dS : (w == 1 ? dT : dQ);
+      const float* Wh = W + (w == 0 ? o.Ws : (w == 1 ? o.Wt : o.Wq));
+      float* part = X.Hm(MPART + w);
+      for (int tm = 0; tm < X.tH; ++tm) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (w < 3) acc = mm_tile(acc, Wh, d, 1, H, 16 * tm, dz, 1, ldd, TC, 0, 0, d, lane);
+        const int j0 = 16 * tm + 4 * X.g;
+        if (j0 < ldh) *reinterpret_cast<f4*>(part + X.r * ldh + j0) = acc;
+      }
+    }
+    // column sums over the chains: bs, bt, bq, lam_s, lam_q
+    for (int e = X.tid; e < 5 * d; e += TTHREADS) {
+      const int which = e / d, k = e - which * d;
+      const float* src = which == 0 ? dS : (which == 1 ? dT : (which == 2 ? dQ : (which == 3 ? dA : dB)));
+      const int dst = which == 0 ? o.bs : (which == 1 ? o.bt : (which == 2 ? o.bq : (which == 3 ? o.ls : o.lq)));
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < TC; ++c) s += src[c * ldd + k];
+      G[dst + k] += s;
     }
   }
-  float d1[HM];
-  for (int i = 0; i < H; ++i) d1[i] = 0.f;
-  for (int j = 0; j < H; ++j) {
-    const float da2 = c.h2[j] > 0.f ? dh[j] : 0.f;
-    acc(o.b4 + j, da2);
-    for (int i = 0; i < H; ++i) {
-      acc(o.W4 + i * H + j, c.h1[i] * da2);
-      d1[i] += W[o.W4 + i * H + j] * da2;
+  __syncthreads();
+  {
+    const float* h2 = X.Hm(MH2);
+    float* da2 = X.Hm(MDA2);
+    const float *p0 = X.Hm(MPART), *p1 = X.Hm(MPART + 1), *p2 = X.Hm(MPART + 2);
+    for (int j = X.kb; j < H; j += 16) {
+      const int q = X.c * ldh + j;
+      da2[q] = h2[q] > 0.f ? (p0[q] + p1[q]) + p2[q] : 0.f;
     }
   }
-  for (int k = 0; k < d; ++k) { da[k] = 0.f; db[k] = 0.f; }
-  for (int i = 0; i < H; ++i) {
-    const float da1 = c.h1[i] > 0.f ? d1[i] : 0.f;
-    acc(o.b1 + i, da1);
-    acc(o.b2 + i, da1);
-    acc(o.b3 + i, da1);
-    acc(o.W3 + i, t0 * da1);
-    acc(o.W3 + H + i, t1 * da1);
-    for (int k = 0; k < d; ++k) {
-      acc(o.W1 + k * H + i, a[k] * da1);
-      acc(o.W2 + k * H + i, b[k] * da1);
-      da[k] += W[o.W1 + k * H + i] * da1;
-      db[k] += W[o.W2 + k * H + i] * da1;
+  __syncthreads();
+  {
+    const float *h1 = X.Hm(MH1), *da2 = X.Hm(MDA2);
+    float* da1 = X.Hm(MDA1);
+    const int nW4 = X.tH * X.tH;
+    for (int t = X.wave; t < nW4 + X.tH; t += TNW) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (t < nW4) {          // dW4(i, j) += sum_c h1(c, i) da2(c, j)
+        const int tm = t / X.tH, tn = t - tm * X.tH;
+        acc = mm_tile(acc, h1, 1, ldh, H, 16 * tm, da2, ldh, 1, H, 16 * tn, 0, TC, lane);
+        const int j = 16 * tn + X.r;
+        for (int rr = 0; rr < 4; ++rr) {
+          const int i = 16 * tm + 4 * X.g + rr;
+          if (i < H && j < H) G[o.W4 + i * H + j] += acc[rr];
+        }
+      } else {                // da1(c, i) = [h1 > 0] sum_j W4(i, j) da2(c, j)
+        const int tm = t - nW4;
+        acc = mm_tile(acc, W + o.W4, H, 1, H, 16 * tm, da2, 1, ldh, TC, 0, 0, H, lane);
+        for (int rr = 0; rr < 4; ++rr) {
+          const int i = 16 * tm + 4 * X.g + rr;
+          if (i < H) da1[X.r * ldh + i] = h1[X.r * ldh + i] > 0.f ? acc[rr] : 0.f;
+        }
+      }
+    }
+    for (int j = X.tid; j < H; j += TTHREADS) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < TC; ++c) s += da2[c * ldh + j];
+      G[o.b4 + j] += s;
     }
   }
+  __syncthreads();
+  {
+    const float* da1 = X.Hm(MDA1);
+    const int nWg = X.tD * X.tH;        // tiles of one layer-1 weight gradient
+    for (int t = X.wave; t < 2 * nWg + 2 * X.tD; t += TNW) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (t < 2 * nWg) {      // dW1(k, i) += sum_c a(c, k) da1(c, i);  dW2 likewise with b
+        const int which = t / nWg, u = t - which * nWg, tm = u / X.tH, tn = u - tm * X.tH;
+        acc = mm_tile(acc, which == 0 ? a : b, 1, ldd, d, 16 * tm, da1, ldh, 1, H, 16 * tn, 0, TC, lane);
+        float* Gw = G + (which == 0 ? o.W1 : o.W2);
+        const int i = 16 * tn + X.r;
+        for (int rr = 0; rr < 4; ++rr) {
+          const int k = 16 * tm + 4 * X.g + rr;
+          if (k < d && i < H) Gw[k * H + i] += acc[rr];
+        }
+      } else {                // da(c, k) = sum_i W1(k, i) da1(c, i);  db with W2
+        const int u = t - 2 * nWg, which = u / X.tD, tm = u - which * X.tD;
+        acc = mm_tile(acc, W + (which == 0 ? o.W1 : o.W2), H, 1, d, 16 * tm, da1, 1, ldh, TC, 0, 0, H, lane);
+        float* out = which == 0 ? dA : dB;
+        for (int rr = 0; rr < 4; ++rr) {
+          const int k = 16 * tm + 4 * X.g + rr;
+          if (k < d) out[X.r * ldd + k] = acc[rr];
+        }
+      }
+    }
+    for (int i = X.tid; i < H; i += TTHREADS) {
+      float s = 0.f, s0 = 0.f, s1 = 0.f;
+      for (int c = 0; c < TC; ++c) {
+        const float v = da1[c * ldh + i];
+        const int st = X.step_of(c);
+        s += v; s0 += X.Trg[2 * st] * v; s1 += X.Trg[2 * st + 1] * v;
+      }
+      G[o.b1 + i] += s; G[o.b2 + i] += s; G[o.b3 + i] += s;
+      G[o.W3 + i] += s0; G[o.W3 + H + i] += s1;
+    }
+  }
+  __syncthreads();
 }
 
-template <int DM, int HM>
-__global__ __launch_bounds__(256) void train_kernel(const TArgs A) {
+__global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int d = A.d, H = A.H, T = A.T;
-  const int P = net_params(d, H);
-  const NetOff o = net_off(d, H);
-  float* Wx = smem;                  // XNet weights (flat), then VNet
-  float* Wv = smem + P;
-  float* Gx = smem + 2 * P;          // gradient accumulators, same layout, + 1 for eps
-  float* Gv = smem + 3 * P;
-  float* Ge = smem + 4 * P;
-  float* Msk = smem + 4 * P + 4;     // masks (T, d)
-  float* Trg = Msk + T * d;          // trig (T, 2)
-  const int nc = A.ekind == L2HMC_ENERGY_GMM ? A.ncomp : 1;
-  float* Mu = Trg + 2 * T;           // means (nc, d); precision diag (d) / dense (d, d) / (nc, d, d); log c (nc)
-  float* Pr = Mu + nc * d;
-  const int npr = A.ekind == L2HMC_ENERGY_GAUSS_DIAG ? d : (A.ekind == L2HMC_ENERGY_ROUGHWELL ? 0 : nc * d * d);
-  float* Lc = Pr + npr;
+  const int ek = A.ekind;
+  const int nc = ek == L2HMC_ENERGY_GMM ? A.ncomp : 1;
+  const TLayout L = train_layout(d, H, T, ek, nc);
+  const int P = L.P, ldd = L.ldd;
+  float *Wx = smem + L.Wx, *Wv = smem + L.Wv, *Gx = smem + L.Gx, *Gv = smem + L.Gv, *Ge = smem + L.Ge;
+  float *Msk = smem + L.Msk, *Trg = smem + L.Trg, *Mu = smem + L.Mu, *Pr = smem + L.Pr, *Lc = smem + L.Lc;
+  float *WV = smem + L.wv, *YV = smem + L.yv;
+  const int dpad = (d + 3) / 4 * 4;
+  float *ESx = smem + L.Ex, *EQx = ESx + dpad, *ESv = EQx + dpad, *EQv = ESv + dpad;
+  TCtx X;
+  X.tid = tid; X.lane = tid & 63; X.wave = tid >> 6; X.g = X.lane >> 4; X.r = X.lane & 15;
+  X.d = d; X.H = H; X.T = T; X.ldd = ldd; X.ldh = L.ldh; X.tD = (d + 15) / 16; X.tH = (H + 15) / 16;
+  X.o = net_off(d, H);
+  X.md = smem + L.md; X.mh = smem + L.mh; X.cs = smem + L.cs; X.Msk = Msk; X.Trg = Trg; X.it = 0;
+  X.c = tid & 15; X.kb = tid >> 4;
+  const int c = X.c, kb = X.kb;
+  const long long n = (long long)blockIdx.x * TC + c;          // this thread's chain
+  const bool alive = n < A.N;
+  const bool isf = A.dir != nullptr ? (alive ? A.dir[n] != 0 : true) : (A.dir_all != 0);
+  const float sg = isf ? 1.f : -1.f;
 
   // ---- stage ------------------------------------------------------------------------------------
   {
+    const NetOff& o = X.o;
     const float* const* srcs[2] = {reinterpret_cast<const float* const*>(&A.xnet),
                                    reinterpret_cast<const float* const*>(&A.vnet)};
     const int offs[17] = {o.W1, o.b1, o.W2, o.b2, o.W3, o.b3, o.W4, o.b4, o.Ws, o.bs, o.Wt, o.bt, o.Wq,
                           o.bq, o.ls, o.lq, P};
-    for (int n = 0; n < 2; ++n)
+    for (int nn = 0; nn < 2; ++nn)
       for (int f = 0; f < 16; ++f) {
-        const float* src = srcs[n][f];
-        float* dst = (n == 0 ? Wx : Wv) + offs[f];
-        for (int i = tid; i < offs[f + 1] - offs[f]; i += 256) dst[i] = src[i];
+        const float* src = srcs[nn][f];
+        float* dst = (nn == 0 ? Wx : Wv) + offs[f];
+        for (int i = tid; i < offs[f + 1] - offs[f]; i += TTHREADS) dst[i] = src[i];
       }
-    for (int i = tid; i < 2 * P + 4; i += 256) Gx[i] = 0.f;
-    for (int i = tid; i < T * d; i += 256) Msk[i] = A.masks[i];
-    for (int i = tid; i < 2 * T; i += 256) Trg[i] = A.trig[i];
-    if (A.ekind != L2HMC_ENERGY_ROUGHWELL) {
-      for (int i = tid; i < nc * d; i += 256) Mu[i] = A.mu[i];
-      for (int i = tid; i < npr; i += 256) Pr[i] = A.prec[i];
+    for (int i = tid; i < d; i += TTHREADS) {
+      ESx[i] = expf(A.xnet.lam_s[i]); EQx[i] = expf(A.xnet.lam_q[i]);
+      ESv[i] = expf(A.vnet.lam_s[i]); EQv[i] = expf(A.vnet.lam_q[i]);
     }
-    if (A.ekind == L2HMC_ENERGY_GMM)
-      for (int i = tid; i < nc; i += 256) Lc[i] = A.logc[i];
+    for (int i = tid; i < 2 * P + 4; i += TTHREADS) Gx[i] = 0.f;
+    for (int i = tid; i < T * d; i += TTHREADS) Msk[i] = A.masks[i];
+    for (int i = tid; i < 2 * T; i += TTHREADS) Trg[i] = A.trig[i];
+    if (ek != L2HMC_ENERGY_ROUGHWELL) {
+      for (int i = tid; i < nc * d; i += TTHREADS) Mu[i] = A.mu[i];
+      if (ek == L2HMC_ENERGY_GAUSS_DIAG) {
+        for (int i = tid; i < d; i += TTHREADS) Pr[i] = A.prec[i];
+      } else {                  // symmetric part G = (S + S^T) / 2 of each raw precision
+        for (int i = tid; i < nc * d * d; i += TTHREADS) {
+          const int cc = i / (d * d), u = i - cc * d * d, k = u / d, j = u - k * d;
+          Pr[i] = 0.5f * (A.prec[cc * d * d + k * d + j] + A.prec[cc * d * d + j * d + k]);
+        }
+      }
+    }
+    if (ek == L2HMC_ENERGY_GMM)
+      for (int i = tid; i < nc; i += TTHREADS) Lc[i] = A.logc[i];
+    for (int i = tid; i < (N_MD * TC * ldd); i += TTHREADS) X.md[i] = 0.f;
+    for (int i = tid; i < (N_MH * TC * L.ldh); i += TTHREADS) X.mh[i] = 0.f;
+    if (kb == 0) X.cs[CS_SGN * TC + c] = sg;
   }
   __syncthreads();
 
-  const long long n = (long long)blockIdx.x * 256 + tid;
-  const bool live = n < A.N;
-  const long long nn = live ? n : 0;
-  const bool fwd = A.dir != nullptr ? A.dir[nn] != 0 : (A.dir_all != 0);
-  const float sgn = fwd ? 1.f : -1.f;
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
-  const bool dense = A.ekind == L2HMC_ENERGY_GAUSS_DENSE;
-
-  // ---- target: U, grad U, Hessian-vector product (oracle/l2hmc_train_oracle.py *Target classes) ----
-  const int ek = A.ekind;
   const float rw_den = A.easy ? A.eta : A.eta * A.eta;
-  // y = G_c (z - mu_c) for component c (G = (S + S^T)/2; diagonal kind: elementwise); center=false: G z
-  auto matG = [&](int c, const float* z, bool center, float* out) {
-    const float* mu = Mu + c * d;
-    for (int k = 0; k < d; ++k) {
-      if (ek == L2HMC_ENERGY_GAUSS_DIAG) {
-        out[k] = Pr[k] * (z[k] - (center ? mu[k] : 0.f));
-      } else {
-        const float* S = Pr + c * d * d;
-        float acc = 0.f;
-        for (int j = 0; j < d; ++j) acc += 0.5f * (S[k * d + j] + S[j * d + k]) * (z[j] - (center ? mu[j] : 0.f));
-        out[k] = acc;
-      }
-    }
+  const bool EL = ek == L2HMC_ENERGY_GAUSS_DIAG || ek == L2HMC_ENERGY_ROUGHWELL;   // elementwise grad / Hessian
+  float deps = 0.f;           // this thread's share of d loss / d eps
+  int s_me = 0;               // step index of this thread's chain at iteration X.it
+
+  auto set_step = [&](int it) {
+    X.it = it;
+    s_me = isf ? it : (T - 1 - it);
+    X.t0 = Trg[2 * s_me];
+    X.t1 = Trg[2 * s_me + 1];
   };
-  constexpr int KC = 8;      // max mixture components
-  // softmax weights w_c and y_c of the GMM at z; returns logsumexp
-  auto gmm_parts = [&](const float* z, float (*ys)[DM], float* wts) {
-    float V[KC], m = -INFINITY;
-    for (int c = 0; c < nc; ++c) {
-      matG(c, z, true, ys[c]);
-      const float* S = Pr + c * d * d;
-      float q = 0.f;                       // (z - mu)^T S (z - mu) == (z - mu)^T G (z - mu)
-      for (int k = 0; k < d; ++k) q += (z[k] - Mu[c * d + k]) * ys[c][k];
-      (void)S;
-      V[c] = -0.5f * q + Lc[c];
-      m = fmaxf(m, V[c]);
+  // k1 of dynamics.py:126,167: the mask of the chain's current step, complemented on the backward branch
+  auto kin_of = [&](int k) {
+    const float m = Msk[s_me * d + k];
+    return isf ? m : 1.f - m;
+  };
+  auto g_elem = [&](float z, int k) {          // elementwise grad U
+    return ek == L2HMC_ENERGY_GAUSS_DIAG ? Pr[k] * (z - Mu[k]) : z - (A.eta / rw_den) * sinf(z / rw_den);
+  };
+  auto h_elem = [&](float z, int k) {          // elementwise Hessian diagonal
+    return ek == L2HMC_ENERGY_GAUSS_DIAG ? Pr[k] : 1.f - (A.eta / (rw_den * rw_den)) * cosf(z / rw_den);
+  };
+  // y_comp(k) = sum_j G_comp(k, j) (z_j - [center] mu_comp_j) for one chain row (dense / mixture kinds)
+  auto matG = [&](int comp, const float* zrow, bool center, int k) {
+    const float* mu = Mu + comp * d;
+    const float* Grow = Pr + comp * d * d + k * d;
+    float acc = 0.f;
+    for (int j = 0; j < d; ++j) acc += Grow[j] * (zrow[j] - (center ? mu[j] : 0.f));
+    return acc;
+  };
+  // mixture log-weights V_comp(z) of every chain -> WV (GMM only); ends with a barrier
+  auto gmm_logw = [&](const float* z) {
+    for (int comp = kb; comp < nc; comp += 16) {
+      const float* zrow = z + c * ldd;
+      float q = 0.f;
+      for (int k = 0; k < d; ++k) q += (zrow[k] - Mu[comp * d + k]) * matG(comp, zrow, true, k);
+      WV[c * KC + comp] = -0.5f * q + Lc[comp];
     }
-    float sum = 0.f;
-    for (int c = 0; c < nc; ++c) { wts[c] = expf(V[c] - m); sum += wts[c]; }
-    for (int c = 0; c < nc; ++c) wts[c] /= sum;
+    __syncthreads();
+  };
+  auto gmm_softmax = [&](int cc, float* w) {     // returns logsumexp
+    float m = -INFINITY, sum = 0.f;
+    for (int comp = 0; comp < nc; ++comp) m = fmaxf(m, WV[cc * KC + comp]);
+    for (int comp = 0; comp < nc; ++comp) { w[comp] = expf(WV[cc * KC + comp] - m); sum += w[comp]; }
+    for (int comp = 0; comp < nc; ++comp) w[comp] /= sum;
     return m + logf(sum);
   };
-  auto gradU = [&](const float* z, float* out) {
-    if (ek == L2HMC_ENERGY_ROUGHWELL) {
-      for (int k = 0; k < d; ++k) out[k] = z[k] - (A.eta / rw_den) * sinf(z[k] / rw_den);
-    } else if (ek == L2HMC_ENERGY_GMM) {
-      float ys[KC][DM], wts[KC];
-      gmm_parts(z, ys, wts);
-      for (int k = 0; k < d; ++k) {
-        float acc = 0.f;
-        for (int c = 0; c < nc; ++c) acc += wts[c] * ys[c][k];
-        out[k] = acc;
+  // g <- grad U(z) for the dense / mixture kinds (oracle/l2hmc_train_oracle.py *Target.grad); ends with a barrier
+  auto gradU_full = [&](const float* z, float* g) {
+    if (ek == L2HMC_ENERGY_GMM) gmm_logw(z);
+    const float* zrow = z + c * ldd;
+    float w[KC];
+    if (ek == L2HMC_ENERGY_GMM) gmm_softmax(c, w);
+    for (int k = kb; k < d; k += 16) {
+      float out = 0.f;
+      if (ek == L2HMC_ENERGY_GMM) {
+        for (int comp = 0; comp < nc; ++comp) out += w[comp] * matG(comp, zrow, true, k);
+      } else {
+        out = matG(0, zrow, true, k);
       }
-    } else {
-      matG(0, z, true, out);
+      g[c * ldd + k] = out;
     }
+    __syncthreads();
   };
-  auto energyU = [&](const float* z) {
+  // U(z) of chain cc, given g = grad U(z) (and WV of the same z for the mixture); one thread per chain
+  auto energyU = [&](const float* z, const float* g, int cc) {
+    const float* zrow = z + cc * ldd;
     float u = 0.f;
     if (ek == L2HMC_ENERGY_ROUGHWELL) {
-      for (int k = 0; k < d; ++k) u += 0.5f * z[k] * z[k] + A.eta * cosf(z[k] / rw_den);
+      for (int k = 0; k < d; ++k) u += 0.5f * zrow[k] * zrow[k] + A.eta * cosf(zrow[k] / rw_den);
     } else if (ek == L2HMC_ENERGY_GMM) {
-      float ys[KC][DM], wts[KC];
-      u = -gmm_parts(z, ys, wts);
+      float w[KC];
+      u = -gmm_softmax(cc, w);
     } else {
-      float gz[DM];
-      matG(0, z, true, gz);
-      for (int k = 0; k < d; ++k) u += 0.5f * (z[k] - Mu[k]) * gz[k];
+      for (int k = 0; k < d; ++k) u += 0.5f * (zrow[k] - Mu[k]) * g[cc * ldd + k];
     }
     return u;
   };
-  // out = H(z) vec
-  auto hessvec = [&](const float* z, const float* vec, float* out) {
-    if (ek == L2HMC_ENERGY_ROUGHWELL) {
-      for (int k = 0; k < d; ++k) out[k] = (1.f - (A.eta / (rw_den * rw_den)) * cosf(z[k] / rw_den)) * vec[k];
-    } else if (ek == L2HMC_ENERGY_GMM) {
-      float ys[KC][DM], wts[KC], gz[DM], gv = 0.f, tmpv[DM];
-      gmm_parts(z, ys, wts);
-      for (int k = 0; k < d; ++k) {
-        float acc = 0.f;
-        for (int c = 0; c < nc; ++c) acc += wts[c] * ys[c][k];
-        gz[k] = acc;
-        gv += acc * vec[k];
-      }
-      for (int k = 0; k < d; ++k) out[k] = gz[k] * gv;
-      for (int c = 0; c < nc; ++c) {
+  // out <- Hessian(z) vec for the dense / mixture kinds (needs WV of the same z); ends with a barrier
+  auto hessvec_full = [&](const float* z, const float* vec, float* out) {
+    const float* zrow = z + c * ldd;
+    const float* vrow = vec + c * ldd;
+    if (ek == L2HMC_ENERGY_GMM) {
+      for (int comp = kb; comp < nc; comp += 16) {
         float yv = 0.f;
-        for (int k = 0; k < d; ++k) yv += ys[c][k] * vec[k];
-        matG(c, vec, false, tmpv);
-        for (int k = 0; k < d; ++k) out[k] += wts[c] * (tmpv[k] - ys[c][k] * yv);
+        for (int k = 0; k < d; ++k) yv += matG(comp, zrow, true, k) * vrow[k];
+        YV[c * KC + comp] = yv;
       }
-    } else {
-      matG(0, vec, false, out);
+      __syncthreads();
     }
+    float w[KC];
+    if (ek == L2HMC_ENERGY_GMM) gmm_softmax(c, w);
+    for (int k = kb; k < d; k += 16) {
+      float o = 0.f;
+      if (ek == L2HMC_ENERGY_GMM) {
+        float gz = 0.f, gv = 0.f;
+        for (int comp = 0; comp < nc; ++comp) {
+          const float y = matG(comp, zrow, true, k);
+          gz += w[comp] * y;
+          gv += w[comp] * YV[c * KC + comp];
+          o += w[comp] * (matG(comp, vrow, false, k) - y * YV[c * KC + comp]);
+        }
+        o += gz * gv;
+      } else {
+        o = matG(0, vrow, false, k);
+      }
+      out[c * ldd + k] = o;
+    }
+    __syncthreads();
   };
 
-  float x[DM], v[DM], g1[DM], vh[DM], y[DM], xo[DM], g2[DM], kin[DM], tmp[DM];
-  NetCache<DM, HM> c1, ca, cb, c2;
-  // checkpoints: ws[(t * N + n) * 2 d + {0..d-1: x_t, d..2d-1: v_t}]
-  auto ckpt = [&](int t) { return A.ws + ((long long)t * A.N + nn) * 2 * d; };
+  float *mx = X.D(MX), *mv = X.D(MV), *mvh = X.D(MVH), *my = X.D(MY), *mxo = X.D(MXO), *mg = X.D(MG);
+  float *lx = X.D(MLX), *lv = X.D(MLV), *dvh = X.D(MDVH), *dz = X.D(MDZ), *tmp = X.D(MTMP);
+  float *dS = X.D(MDS), *dT = X.D(MDT), *dQ = X.D(MDQ), *dA = X.D(MDA), *dB = X.D(MDB), *dg = X.D(MDG);
+  const float *cTS = X.D(MTS), *cT = X.D(MT), *cTQ = X.D(MTQ);
+  float* ldm = lx;              // log-det terms of the forward trajectory (lx is free until the seeds)
+  auto ckpt = [&](int t, int slot) { return A.ws + (((long long)t * A.N + n) * CKPT + slot) * d; };
+#define EW_BEGIN for (int k = kb; k < d; k += 16) { const int q = c * ldd + k;
+#define EW_END } __syncthreads();
 
-  for (int k = 0; k < d; ++k) { x[k] = live ? A.x[nn * d + k] : 0.f; v[k] = live ? A.v[nn * d + k] : 0.f; }
-  float x0[DM], U0, K0 = 0.f, ld = 0.f;
-  for (int k = 0; k < d; ++k) { x0[k] = x[k]; K0 += 0.5f * v[k] * v[k]; }
-  U0 = energyU(x);
-
-  // one forward step from (x, v); fills vh, y, xo, g1, g2, the four caches and (x, v) <- new state
-  auto step_fwd = [&](int it, bool keep_ld) {
-    const int s = fwd ? it : (T - 1 - it);
-    const float t0 = Trg[2 * s], t1 = Trg[2 * s + 1];
-    const float* m = Msk + s * d;
-    gradU(x, g1);
-    net_fwd<DM, HM>(Wv, o, d, H, x, g1, t0, t1, c1);
-    for (int k = 0; k < d; ++k) {
-      const float ES = expf(sgn * heps * c1.S[k]), EQ = expf(eps * c1.Q[k]);
-      const float cc = heps * (c1.T[k] - EQ * g1[k]);
-      vh[k] = fwd ? v[k] * ES + cc : (v[k] - cc) * ES;
-      if (keep_ld) ld += sgn * heps * c1.S[k];
-    }
-    for (int k = 0; k < d; ++k) { kin[k] = fwd ? m[k] : 1.f - m[k]; tmp[k] = kin[k] * x[k]; }   // kin = k1
-    net_fwd<DM, HM>(Wx, o, d, H, vh, tmp, t0, t1, ca);
-    for (int k = 0; k < d; ++k) {
-      const float ES = expf(sgn * eps * ca.S[k]), EQ = expf(eps * ca.Q[k]);
-      const float tr = eps * (EQ * vh[k] + ca.T[k]);
-      const float nw = fwd ? x[k] * ES + tr : ES * (x[k] - tr);
-      y[k] = kin[k] * x[k] + (1.f - kin[k]) * nw;
-      if (keep_ld) ld += (1.f - kin[k]) * sgn * eps * ca.S[k];
-    }
-    for (int k = 0; k < d; ++k) tmp[k] = (1.f - kin[k]) * y[k];
-    net_fwd<DM, HM>(Wx, o, d, H, vh, tmp, t0, t1, cb);
-    for (int k = 0; k < d; ++k) {
-      const float ES = expf(sgn * eps * cb.S[k]), EQ = expf(eps * cb.Q[k]);
-      const float tr = eps * (EQ * vh[k] + cb.T[k]);
-      const float nw = fwd ? y[k] * ES + tr : ES * (y[k] - tr);
-      xo[k] = (1.f - kin[k]) * y[k] + kin[k] * nw;
-      if (keep_ld) ld += kin[k] * sgn * eps * cb.S[k];
-    }
-    gradU(xo, g2);
-    net_fwd<DM, HM>(Wv, o, d, H, xo, g2, t0, t1, c2);
+  // v_half (dynamics.py:129-141 / 183-196): out = v_half(vin; g, V-net caches), logging the log-det;
+  // `also_tmp`: tmp <- k1 x, the X-net's second input of the next stage
+  auto v_half_fwd = [&](const float* vin, float* out, bool also_tmp) {
+    EW_BEGIN
+      const float S = ESv[k] * cTS[q], Q = EQv[k] * cTQ[q];
+      const float ES = fexp(sg * heps * S), EQ = fexp(eps * Q);
+      const float cc = heps * (cT[q] - EQ * mg[q]);
+      out[q] = isf ? vin[q] * ES + cc : (vin[q] - cc) * ES;
+      ldm[q] += sg * heps * S;
+      if (also_tmp) tmp[q] = kin_of(k) * mx[q];
+    EW_END
   };
+  // x_half (dynamics.py:143-161 / 170-181): out = kp zin + (1 - kp) x_update(zin; vh, X-net caches);
+  // first: also tmp <- k2 y;  second: also the step's checkpoints and (elementwise kinds) g <- grad U(x')
+  auto x_half_fwd = [&](const float* zin, bool first, float* out, int it) {
+    EW_BEGIN
+      const float kin = kin_of(k), kp = first ? kin : 1.f - kin;
+      const float S = ESx[k] * cTS[q], Q = EQx[k] * cTQ[q];
+      const float ES = fexp(sg * eps * S), EQ = fexp(eps * Q);
+      const float tr = eps * (EQ * mvh[q] + cT[q]);
+      const float nw = isf ? zin[q] * ES + tr : ES * (zin[q] - tr);
+      const float o = kp * zin[q] + (1.f - kp) * nw;
+      out[q] = o;
+      ldm[q] += (1.f - kp) * sg * eps * S;
+      if (first) {
+        tmp[q] = (1.f - kin) * o;
+      } else {
+        if (alive) {
+          ckpt(it, 0)[k] = mx[q]; ckpt(it, 1)[k] = mv[q]; ckpt(it, 2)[k] = mvh[q];
+          ckpt(it, 3)[k] = my[q]; ckpt(it, 4)[k] = o;
+        }
+        if (EL) mg[q] = g_elem(o, k);
+      }
+    EW_END
+  };
+
+  // ---- load the start state -----------------------------------------------------------------------
+  set_step(0);
+  EW_BEGIN
+    mx[q] = alive ? A.x[n * d + k] : 0.f;
+    mv[q] = alive ? A.v[n * d + k] : 0.f;
+    ldm[q] = 0.f;
+    if (EL) mg[q] = g_elem(mx[q], k);
+  EW_END
+  if (!EL) gradU_full(mx, mg);
+  if (tid < TC) {
+    float K0 = 0.f;
+    for (int k = 0; k < d; ++k) K0 += 0.5f * mv[tid * ldd + k] * mv[tid * ldd + k];
+    X.cs[CS_K0 * TC + tid] = K0;
+    X.cs[CS_U0 * TC + tid] = energyU(mx, mg, tid);
+  }
+  __syncthreads();
 
   // ---- forward trajectory with checkpoints --------------------------------------------------------
   for (int it = 0; it < T; ++it) {
-    float* ck = ckpt(it);
-    if (live) for (int k = 0; k < d; ++k) { ck[k] = x[k]; ck[d + k] = v[k]; }
-    step_fwd(it, true);
-    for (int k = 0; k < d; ++k) {
-      const float ES = expf(sgn * heps * c2.S[k]), EQ = expf(eps * c2.Q[k]);
-      const float cc = heps * (c2.T[k] - EQ * g2[k]);
-      v[k] = fwd ? vh[k] * ES + cc : (vh[k] - cc) * ES;
-      ld += sgn * heps * c2.S[k];
-      x[k] = xo[k];
-    }
+    set_step(it);
+    t_net_fwd(X, Wv, mx, mg);
+    v_half_fwd(mv, mvh, true);
+    t_net_fwd(X, Wx, mvh, tmp);
+    x_half_fwd(mx, true, my, it);
+    t_net_fwd(X, Wx, mvh, tmp);
+    x_half_fwd(my, false, mxo, it);
+    if (!EL) gradU_full(mxo, mg);
+    t_net_fwd(X, Wv, mxo, mg);
+    v_half_fwd(mvh, mv, false);
+    { float* t = mx; mx = mxo; mxo = t; }            // x <- x'
   }
+
   // ---- accept probability, loss term and the adjoint seeds ------------------------------------------
-  float K1 = 0.f, sq = 0.f;
-  gradU(x, g2);
-  const float U1 = energyU(x);
-  for (int k = 0; k < d; ++k) { K1 += 0.5f * v[k] * v[k]; sq += (x0[k] - x[k]) * (x0[k] - x[k]); }
-  const float val = (U0 + K0) - (U1 + K1) + ld;
-  const float p = accept_prob(val);
-  const float v1 = sq * p + 1e-4f;
-  if (live) {
-    for (int k = 0; k < d; ++k) A.Lx[n * d + k] = x[k];
-    A.p[n] = p;
-    A.v1[n] = v1;
+  // (mg = grad U at the end point already: it was the V-net's input of the last half step)
+  if (tid < TC) {
+    const int cc = tid;
+    const long long nn = (long long)blockIdx.x * TC + cc;
+    const bool lv_ = nn < A.N;
+    float K1 = 0.f, sq = 0.f, ld = 0.f;
+    for (int k = 0; k < d; ++k) {
+      const float x0 = lv_ ? A.x[nn * d + k] : 0.f;
+      K1 += 0.5f * mv[cc * ldd + k] * mv[cc * ldd + k];
+      sq += (x0 - mx[cc * ldd + k]) * (x0 - mx[cc * ldd + k]);
+      ld += ldm[cc * ldd + k];
+    }
+    const float U1 = energyU(mx, mg, cc);
+    const float val = (X.cs[CS_U0 * TC + cc] + X.cs[CS_K0 * TC + cc]) - (U1 + K1) + ld;
+    const float p = accept_prob(val);
+    const float v1 = sq * p + 1e-4f;
+    if (lv_) { A.p[nn] = p; A.v1[nn] = v1; }
+    const float dv1 = lv_ ? (A.scale * (-1.f / (v1 * v1)) - 1.f / A.scale) * A.inv_n : 0.f;
+    const bool pfin = (val == val) && p > 0.f;   // finite branch of dynamics.py:309 actually taken
+    // (a diverged chain -- non-finite end point -- has p = 0 and contributes no gradient, instead of
+    //  the reference's 0 * NaN)
+    X.cs[CS_LAM * TC + cc] = (pfin && val < 0.f) ? dv1 * sq * p : 0.f;
+    X.cs[CS_DV1P * TC + cc] = dv1 * p * 2.f;
+    X.cs[CS_OK * TC + cc] = sq < 3.0e38f ? 1.f : 0.f;
   }
-  const float dv1 = live ? (A.scale * (-1.f / (v1 * v1)) - 1.f / A.scale) * A.inv_n : 0.f;
-  const bool pfin = (val == val) && p > 0.f;   // finite branch of dynamics.py:309 actually taken
-  const float dval = (pfin && val < 0.f) ? dv1 * sq * p : 0.f;
-  // (a diverged chain -- non-finite end point -- has p = 0 and contributes no gradient, instead of
-  //  the reference's 0 * NaN)
-  const bool okc = sq < 3.0e38f;
-  float lx[DM], lv[DM], deps = 0.f;
-  for (int k = 0; k < d; ++k) {
-    lx[k] = okc ? dv1 * p * 2.f * (x[k] - x0[k]) - dval * g2[k] : 0.f;
-    lv[k] = okc ? -dval * v[k] : 0.f;
+  __syncthreads();
+  const float lam = X.cs[CS_LAM * TC + c];
+  {
+    const bool okc = X.cs[CS_OK * TC + c] != 0.f;
+    const float dv1p = X.cs[CS_DV1P * TC + c];
+    EW_BEGIN
+      const float x0 = alive ? A.x[n * d + k] : 0.f;
+      if (alive) A.Lx[n * d + k] = mx[q];
+      lx[q] = okc ? dv1p * (mx[q] - x0) - lam * mg[q] : 0.f;
+      lv[q] = okc ? -lam * mv[q] : 0.f;
+    EW_END
   }
-  const float lam = dval;
 
   // ---- reverse sweep ------------------------------------------------------------------------------------
-  float dS[DM], dT[DM], dQ[DM], da[DM], db[DM], dvh[DM], dz[DM], dg[DM];
+  // adjoint of out = v_half(vin; g, caches): d vin -> dvin_out; leaves d zs, d zt, d zq, the lam-scale terms
+  // (MDA, MDB) for t_net_bwd, and dg
+  auto v_half_bwd = [&](const float* dout_m, const float* vin, float* dvin_out) {
+    EW_BEGIN
+      const float ts = cTS[q], tq = cTQ[q], Tt = cT[q];
+      const float S = ESv[k] * ts, Q = EQv[k] * tq;
+      const float ES = fexp(sg * heps * S), EQ = fexp(eps * Q);
+      const float gq = mg[q];
+      const float cc = heps * (Tt - EQ * gq);
+      const float dout = dout_m[q];
+      const float dES = isf ? dout * vin[q] : dout * (vin[q] - cc);
+      const float dcc = isf ? dout : -dout * ES;
+      const float ds = dES * ES + lam;
+      const float dSr = ds * sg * heps;                 // d S
+      const float dq = -dcc * heps * gq * EQ;
+      const float dQr = dq * eps;                       // d Q
+      dvin_out[q] = dout * ES;
+      dg[q] = -dcc * heps * EQ;
+      dA[q] = dSr * S;
+      dB[q] = dQr * Q;
+      dS[q] = dSr * ESv[k] * (1.f - ts * ts);
+      dT[q] = dcc * heps;
+      dQ[q] = dQr * EQv[k] * (1.f - tq * tq);
+      deps += ds * sg * 0.5f * S + dcc * 0.5f * (Tt - EQ * gq) + dq * Q;
+    EW_END
+  };
+  // adjoint of out = x_half(zin, first; vh, caches): d zin (direct part) -> dzin_out, dvh +=, same outputs
+  auto x_half_bwd = [&](const float* dout_m, const float* zin, bool first, float* dzin_out) {
+    EW_BEGIN
+      const float kin = kin_of(k), kp = first ? kin : 1.f - kin, up = 1.f - kp;
+      const float ts = cTS[q], tq = cTQ[q], Tt = cT[q];
+      const float S = ESx[k] * ts, Q = EQx[k] * tq;
+      const float ES = fexp(sg * eps * S), EQ = fexp(eps * Q);
+      const float vhq = mvh[q];
+      const float tr = eps * (EQ * vhq + Tt);
+      const float dnw = up * dout_m[q];
+      const float dES = isf ? dnw * zin[q] : dnw * (zin[q] - tr);
+      const float dtr = isf ? dnw : -dnw * ES;
+      const float dsx = dES * ES + up * lam;
+      const float dSr = dsx * sg * eps;
+      const float dq = dtr * eps * vhq * EQ;
+      const float dQr = dq * eps;
+      dzin_out[q] = kp * dout_m[q] + dnw * ES;
+      dvh[q] += dtr * eps * EQ;
+      dA[q] = dSr * S;
+      dB[q] = dQr * Q;
+      dS[q] = dSr * ESx[k] * (1.f - ts * ts);
+      dT[q] = dtr * eps;
+      dQ[q] = dQr * EQx[k] * (1.f - tq * tq);
+      deps += dsx * sg * S + dtr * (EQ * vhq + Tt) + dq * Q;
+    EW_END
+  };
+  // lx += da + Hessian(z) (dg + db): the V-net's inputs were (z, grad U(z))
+  auto through_grad = [&](const float* z) {
+    if (EL) {
+      EW_BEGIN
+        lx[q] = lx[q] + dA[q] + h_elem(z[q], k) * (dg[q] + dB[q]);
+      EW_END
+    } else {
+      EW_BEGIN
+        dg[q] += dB[q];
+      EW_END
+      hessvec_full(z, dg, dz);
+      EW_BEGIN
+        lx[q] = lx[q] + dA[q] + dz[q];
+      EW_END
+    }
+  };
+
   for (int it = T - 1; it >= 0; --it) {
-    const float* ck = ckpt(it);
-    for (int k = 0; k < d; ++k) { x[k] = live ? ck[k] : 0.f; v[k] = live ? ck[d + k] : 0.f; }
-    step_fwd(it, false);
-    const int s = fwd ? it : (T - 1 - it);
-    const float t0 = Trg[2 * s], t1 = Trg[2 * s + 1];
-    // v' = v_half(vh, g2, V(x', g2))
-    for (int k = 0; k < d; ++k) {
-      const float ES = expf(sgn * heps * c2.S[k]), EQ = expf(eps * c2.Q[k]);
-      const float cc = heps * (c2.T[k] - EQ * g2[k]);
-      const float dout = lv[k];
-      dvh[k] = dout * ES;
-      const float dES = fwd ? dout * vh[k] : dout * (vh[k] - cc);
-      const float dcc = fwd ? dout : -dout * ES;
-      const float ds = dES * ES + lam;
-      dS[k] = ds * sgn * heps;
-      deps += ds * sgn * 0.5f * c2.S[k] + dcc * 0.5f * (c2.T[k] - EQ * g2[k]);
-      dT[k] = dcc * heps;
-      const float dq = -dcc * heps * g2[k] * EQ;
-      dg[k] = -dcc * heps * EQ;
-      deps += dq * c2.Q[k];
-      dQ[k] = dq * eps;
-    }
-    net_bwd<DM, HM>(Wv, Gv, o, d, H, xo, g2, t0, t1, c2, dS, dT, dQ, da, db, lane);
-    for (int k = 0; k < d; ++k) tmp[k] = dg[k] + db[k];
-    hessvec(xo, tmp, dz);                                   // Hessian-vector product at x'
-    for (int k = 0; k < d; ++k) lx[k] = lx[k] + da[k] + dz[k];   // = d xo
-    // x' = x_half(y, k2, vh, X(vh, k2 y)),  k2 = 1 - k1
-    for (int k = 0; k < d; ++k) {
-      const float kp = 1.f - kin[k], up = kin[k];
-      const float ES = expf(sgn * eps * cb.S[k]), EQ = expf(eps * cb.Q[k]);
-      const float tr = eps * (EQ * vh[k] + cb.T[k]);
-      const float dnw = up * lx[k];
-      dz[k] = kp * lx[k] + dnw * ES;                        // d y (direct part)
-      const float dES = fwd ? dnw * y[k] : dnw * (y[k] - tr);
-      const float dtr = fwd ? dnw : -dnw * ES;
-      const float dsx = dES * ES + up * lam;
-      dS[k] = dsx * sgn * eps;
-      deps += dsx * sgn * cb.S[k] + dtr * (EQ * vh[k] + cb.T[k]);
-      dvh[k] += dtr * eps * EQ;
-      dT[k] = dtr * eps;
-      const float dq = dtr * eps * vh[k] * EQ;
-      deps += dq * cb.Q[k];
-      dQ[k] = dq * eps;
-    }
-    for (int k = 0; k < d; ++k) tmp[k] = (1.f - kin[k]) * y[k];
-    net_bwd<DM, HM>(Wx, Gx, o, d, H, vh, tmp, t0, t1, cb, dS, dT, dQ, da, db, lane);
-    for (int k = 0; k < d; ++k) { dvh[k] += da[k]; dz[k] += (1.f - kin[k]) * db[k]; }    // dz = d y
-    // y = x_half(x, k1, vh, X(vh, k1 x))
-    for (int k = 0; k < d; ++k) {
-      const float kp = kin[k], up = 1.f - kin[k];
-      const float ES = expf(sgn * eps * ca.S[k]), EQ = expf(eps * ca.Q[k]);
-      const float tr = eps * (EQ * vh[k] + ca.T[k]);
-      const float dnw = up * dz[k];
-      lx[k] = kp * dz[k] + dnw * ES;                        // d x (direct part)
-      const float dES = fwd ? dnw * x[k] : dnw * (x[k] - tr);
-      const float dtr = fwd ? dnw : -dnw * ES;
-      const float dsx = dES * ES + up * lam;
-      dS[k] = dsx * sgn * eps;
-      deps += dsx * sgn * ca.S[k] + dtr * (EQ * vh[k] + ca.T[k]);
-      dvh[k] += dtr * eps * EQ;
-      dT[k] = dtr * eps;
-      const float dq = dtr * eps * vh[k] * EQ;
-      deps += dq * ca.Q[k];
-      dQ[k] = dq * eps;
-    }
-    for (int k = 0; k < d; ++k) tmp[k] = kin[k] * x[k];
-    net_bwd<DM, HM>(Wx, Gx, o, d, H, vh, tmp, t0, t1, ca, dS, dT, dQ, da, db, lane);
-    for (int k = 0; k < d; ++k) { dvh[k] += da[k]; lx[k] += kin[k] * db[k]; }
-    // vh = v_half(v, g1, V(x, g1))
-    for (int k = 0; k < d; ++k) {
-      const float ES = expf(sgn * heps * c1.S[k]), EQ = expf(eps * c1.Q[k]);
-      const float cc = heps * (c1.T[k] - EQ * g1[k]);
-      const float dout = dvh[k];
-      lv[k] = dout * ES;
-      const float dES = fwd ? dout * v[k] : dout * (v[k] - cc);
-      const float dcc = fwd ? dout : -dout * ES;
-      const float ds = dES * ES + lam;
-      dS[k] = ds * sgn * heps;
-      deps += ds * sgn * 0.5f * c1.S[k] + dcc * 0.5f * (c1.T[k] - EQ * g1[k]);
-      dT[k] = dcc * heps;
-      const float dq = -dcc * heps * g1[k] * EQ;
-      dg[k] = -dcc * heps * EQ;
-      deps += dq * c1.Q[k];
-      dQ[k] = dq * eps;
-    }
-    net_bwd<DM, HM>(Wv, Gv, o, d, H, x, g1, t0, t1, c1, dS, dT, dQ, da, db, lane);
-    for (int k = 0; k < d; ++k) tmp[k] = dg[k] + db[k];
-    hessvec(x, tmp, dz);
-    for (int k = 0; k < d; ++k) lx[k] = lx[k] + da[k] + dz[k];
+    set_step(it);
+    EW_BEGIN
+      mx[q] = alive ? ckpt(it, 0)[k] : 0.f; mv[q] = alive ? ckpt(it, 1)[k] : 0.f;
+      mvh[q] = alive ? ckpt(it, 2)[k] : 0.f; my[q] = alive ? ckpt(it, 3)[k] : 0.f;
+      mxo[q] = alive ? ckpt(it, 4)[k] : 0.f;
+      tmp[q] = (1.f - kin_of(k)) * my[q];                    // X-net input of stage (2)
+      if (EL) mg[q] = g_elem(mxo[q], k);
+    EW_END
+    // (1) v' = v_half(vh; g(x'), V(x', g(x')))
+    if (!EL) gradU_full(mxo, mg);
+    t_net_fwd(X, Wv, mxo, mg);
+    v_half_bwd(lv, mvh, dvh);
+    t_net_bwd(X, Wv, Gv, mxo, mg);
+    through_grad(mxo);                                       // lx = d x'
+    // (2) x' = x_half(y, k2; vh, X(vh, k2 y)),  k2 = 1 - k1
+    t_net_fwd(X, Wx, mvh, tmp);
+    x_half_bwd(lx, my, false, dz);                           // dz = d y (direct part)
+    t_net_bwd(X, Wx, Gx, mvh, tmp);
+    EW_BEGIN
+      const float kin = kin_of(k);
+      dvh[q] += dA[q];
+      dz[q] += (1.f - kin) * dB[q];
+      tmp[q] = kin * mx[q];                                  // X-net input of stage (3)
+    EW_END
+    // (3) y = x_half(x, k1; vh, X(vh, k1 x))
+    t_net_fwd(X, Wx, mvh, tmp);
+    x_half_bwd(dz, mx, true, lx);                            // lx = d x (direct part)
+    t_net_bwd(X, Wx, Gx, mvh, tmp);
+    EW_BEGIN
+      dvh[q] += dA[q];
+      lx[q] += kin_of(k) * dB[q];
+      if (EL) mg[q] = g_elem(mx[q], k);
+    EW_END
+    // (4) vh = v_half(v; g(x), V(x, g(x)))
+    if (!EL) gradU_full(mx, mg);
+    t_net_fwd(X, Wv, mx, mg);
+    v_half_bwd(dvh, mv, lv);
+    t_net_bwd(X, Wv, Gv, mx, mg);
+    through_grad(mx);
   }
+#undef EW_BEGIN
+#undef EW_END
   {
     const float s = wave_sum(deps);
-    if (lane == 0) atomicAdd(Ge, s);
+    if (X.lane == 0) atomicAdd(Ge, s);
   }
   __syncthreads();
   // flat gradient: [xnet (P) | vnet (P) | eps], accumulated (+=) into the caller's buffer
-  for (int i = tid; i < 2 * P + 1; i += 256) atomicAdd(&A.grad[i], i < 2 * P ? Gx[i] : Ge[0]);
+  for (int i = tid; i < 2 * P + 1; i += TTHREADS) atomicAdd(&A.grad[i], Gx[i]);
 }
 
 }  // namespace l2hmc
@@ -476,7 +762,7 @@ extern "C" {
 
 int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t T) {
   if (n_chains < 0 || d < 1 || T < 1) return fail(L2HMC_ERR_ARG, "l2hmc_train_workspace_floats: bad argument%s");
-  return (int64_t)T * n_chains * 2 * d;
+  return (int64_t)T * n_chains * CKPT * d;
 }
 
 int64_t l2hmc_train_grad_floats(int32_t d, int32_t H) {
@@ -488,7 +774,7 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
   if (a->n_chains < 0 || a->d < 1 || a->T < 1 || a->H < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
   if (a->n_chains == 0) return L2HMC_OK;
-  if (a->d > 64 || a->H > 16) return fail(L2HMC_ERR_UNSUPPORTED, "training kernel supports d <= 64, H <= 16 (got d = %s%lld, H = %lld)", "", a->d, a->H);
+  if (a->d > 4096 || a->H > 4096) return fail(L2HMC_ERR_UNSUPPORTED, "training kernel: d / H too large (got d = %s%lld, H = %lld)", "", a->d, a->H);
   if (!a->xnet || !a->vnet || !a->masks || !a->trig || !a->x || !a->v || !a->Lx || !a->p || !a->v1 ||
       !a->grad || !a->workspace)
     return fail(L2HMC_ERR_ARG, "l2hmc_train_propose_grad: NULL pointer%s");
@@ -498,7 +784,7 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
     return fail(L2HMC_ERR_UNSUPPORTED, "training supports the Gaussian, GMM and Rough-Well targets (analytic Hessian-vector products)%s");
   if (ek != L2HMC_ENERGY_ROUGHWELL && (!a->energy.mu || !a->energy.prec))
     return fail(L2HMC_ERR_ARG, "energy needs mu and prec (RAW (d,d) precisions for the dense / GMM kinds)%s");
-  if (ek == L2HMC_ENERGY_GMM && (!a->energy.logc || a->energy.n_comp < 1 || a->energy.n_comp > 8))
+  if (ek == L2HMC_ENERGY_GMM && (!a->energy.logc || a->energy.n_comp < 1 || a->energy.n_comp > KC))
     return fail(L2HMC_ERR_ARG, "GMM training needs logc and 1 <= n_comp <= 8%s");
   if (ek == L2HMC_ENERGY_ROUGHWELL && !(a->energy.eta > 0.f)) return fail(L2HMC_ERR_ARG, "roughwell needs eta > 0%s");
   if (!(a->energy.temperature == 1.f)) return fail(L2HMC_ERR_UNSUPPORTED, "training kernel: temperature must be 1%s");
@@ -513,25 +799,18 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
   k.ncomp = ek == L2HMC_ENERGY_GMM ? a->energy.n_comp : 1; k.easy = a->energy.easy;
   k.scale = a->scale; k.inv_n = a->inv_n;
   k.Lx = a->Lx; k.p = a->p; k.v1 = a->v1; k.grad = a->grad; k.ws = a->workspace;
-  const int P = net_params(a->d, a->H);
-  const int ncs = k.ncomp;
-  const long long npr = ek == L2HMC_ENERGY_GAUSS_DIAG ? a->d : (ek == L2HMC_ENERGY_ROUGHWELL ? 0 : (long long)ncs * a->d * a->d);
-  const long long lds = 4LL * (4 * P + 4 + (long long)a->T * a->d + 2 * a->T + (long long)ncs * a->d + npr + ncs + 4);
-  if (lds > 160 * 1024) return fail(L2HMC_ERR_UNSUPPORTED, "training kernel needs %s%lld bytes of LDS", "", lds);
-  const unsigned blocks = (unsigned)((a->n_chains + 255) / 256);
+  const TLayout L = train_layout(a->d, a->H, a->T, ek, k.ncomp);
+  const long long lds = 4LL * L.total;
+  if (lds > 160 * 1024)
+    return fail(L2HMC_ERR_UNSUPPORTED, "training kernel needs %s%lld bytes of LDS (> 160 KiB): d / H too large for the 16-chain tile", "", lds);
+  const unsigned blocks = (unsigned)((a->n_chains + TC - 1) / TC);
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_TRAIN(DMv)                                                                          \
-  {                                                                                                \
-    auto kern = train_kernel<DMv, 16>;                                                             \
-    if (lds > 48 * 1024) {                                                                         \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                      \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-      if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)); \
-    }                                                                                              \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), (size_t)lds, s, k);                          \
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  if (a->d <= 8) LAUNCH_TRAIN(8) else LAUNCH_TRAIN(64)
-#undef LAUNCH_TRAIN
+  hipLaunchKernelGGL(train_kernel, dim3(blocks), dim3(TTHREADS), (size_t)lds, s, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;

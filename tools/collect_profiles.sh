@@ -41,4 +41,4 @@ rm -rf $OUT/trace/*.db $OUT/pmc_*/*.db
 
 cd $R
 timeout 300 python tools/phase_timing.py 4096 4 > $OUT/phase_timing.txt 2>&1; tail -15 $OUT/phase_timing.txt
-tools/sweep.sh "4096 4" "4096 1" "8192 4" "16384 4" "65536 4" "65536 1" "262144 4" "262144 1" "1048576 4" > $OUT/sweep.txt 2>&1; cat $OUT/sweep.txt
+tools/sweep.sh "4096 4 25" "4096 4 1" "4096 1 25" "8192 4 25" "16384 4 25" "65536 4 25" "65536 1 25" "262144 4 10" "262144 1 10" "1048576 4 5" > $OUT/sweep.txt 2>&1; cat $OUT/sweep.txt

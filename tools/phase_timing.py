@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-phase cycle breakdown of one traj_kernel workgroup (GPU box).  Builds a PROFILING copy of
-the library with -DL2HMC_PHASE_TIMING into /tmp (the product .so is untouched), runs the bench
+the library with -DL2HMC_PHASE_TIMING (`phase_timing.py build`, in the container; the product .so is
+untouched) under csrc/variants/, runs the bench
 problem once and prints s_memtime cycles per phase per leapfrog step for each wave of block 0."""
 import ctypes
 import os
@@ -14,14 +15,20 @@ PHASES = ["prologue", "step head", "VNet tail #1", "XNet L1 (a,b)", "xchg", "XNe
 
 
 def main():
+    csrc = os.path.join(ROOT, "l2hmc_amd", "csrc")
+    out = os.path.join(csrc, "variants", "libl2hmc_hip_pt.so")
+    if len(sys.argv) > 1 and sys.argv[1] == "build":      # run this in the container, NOT on the GPU box
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        srcs = [os.path.join(csrc, f) for f in ("l2hmc_abi.hip", "traj_ek1.hip", "traj_ek2.hip", "traj_ek3.hip",
+                                                "traj_ek4.hip", "traj_ek5.hip", "train.hip", "split.hip")]
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+                        "-DL2HMC_PHASE_TIMING", "-Wno-return-type", "-shared", "-o", out] + srcs
+                       + ["-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+        return
+    if not os.path.exists(out):
+        raise SystemExit("build the profiling library first: python tools/phase_timing.py build")
     chains = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     variant = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    out = "/tmp/libl2hmc_hip_pt.so"
-    csrc = os.path.join(ROOT, "l2hmc_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("l2hmc_abi.hip", "traj_ek1.hip", "traj_ek2.hip",
-                                            "traj_ek3.hip", "traj_ek4.hip", "traj_ek5.hip")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
-                    "-DL2HMC_PHASE_TIMING", "-Wno-return-type", "-shared", "-o", out] + srcs, check=True)
     from l2hmc_amd import _ffi
     _ffi.LIB_PATH = out
     import numpy as np
