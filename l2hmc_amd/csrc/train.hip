@@ -23,6 +23,23 @@
 
 namespace l2hmc {
 
+// Phase timers (profiling builds only: -DL2HMC_TRAIN_TIMING, tools/train_phase_timing.py): lane 0 of wave 0
+// of block 0 accumulates s_memtime deltas per phase kind into dbg[kind].
+#ifdef L2HMC_TRAIN_TIMING
+__device__ unsigned long long tt_acc[16];
+__device__ unsigned long long tt_t0;
+#define TT_MARK(i)                                                                      \
+  do {                                                                                  \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                          \
+      const unsigned long long tt_t1 = __builtin_amdgcn_s_memtime();                    \
+      tt_acc[i] += tt_t1 - tt_t0;                                                       \
+      tt_t0 = tt_t1;                                                                    \
+    }                                                                                   \
+  } while (0)
+#else
+#define TT_MARK(i)
+#endif
+
 struct TArgs {
   L2hmcNet xnet, vnet;
   const float *masks, *trig, *alpha;
@@ -118,16 +135,50 @@ __device__ __forceinline__ f4 mm_tile(f4 acc, const float* Ap, int a_sm, int a_s
                                       int k1, int lane) {
   const int r = lane & 15, g = lane >> 4;
   const bool mok = m0 + r < M, nok = n0 + r < N;
-  const float* ap = Ap + (m0 + r) * a_sm;
-  const float* bp = Bp + (n0 + r) * b_sn;
-  for (int ks = k0; ks < k1; ks += 4) {
-    const int kk = ks + g;
-    const bool kok = kk < k1;
-    const float a = (mok && kok) ? ap[kk * a_sk] : 0.f;
-    const float b = (nok && kok) ? bp[kk * b_sk] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  // out-of-range rows / k are read from a clamped (valid) address and zeroed by a select, so the
+  // gathers of a chunk of 4 k-steps issue back to back instead of one branch + wait per element
+  const float* ap = Ap + (mok ? m0 + r : M - 1) * a_sm;
+  const float* bp = Bp + (nok ? n0 + r : N - 1) * b_sn;
+  for (int ks = k0; ks < k1; ks += 16) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = ks + 4 * u + g;
+      const bool kok = kk < k1;
+      const int kc = kok ? kk : k1 - 1;
+      const float av = ap[kc * a_sk], bv = bp[kc * b_sk];
+      a[u] = (mok && kok) ? av : 0.f;
+      b[u] = (nok && kok) ? bv : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ks + 4 * u < k1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
   }
   return acc;
+}
+
+// G(m0 + rr, n) += acc[rr], rr = 0..3 (m < M, n < N): the four old values are loaded first
+__device__ __forceinline__ void acc_tile(float* G, int s_m, int s_n, int M, int N, int m0, int n, f4 acc) {
+  const bool nok = n < N;
+  const int nc = nok ? n : N - 1;
+  float* p[4];
+  float old[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    p[rr] = G + (m0 + rr < M ? m0 + rr : M - 1) * s_m + nc * s_n;
+    old[rr] = *p[rr];
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+    if (nok && m0 + rr < M) *p[rr] = old[rr] + acc[rr];
+}
+
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+// 4 consecutive entries of an unaligned vector of length n (indices clamped: the tail repeats the last one)
+__device__ __forceinline__ f4 ld4c(const float* p, int i0, int n) {
+  return f4{p[i0 < n ? i0 : n - 1], p[i0 + 1 < n ? i0 + 1 : n - 1], p[i0 + 2 < n ? i0 + 2 : n - 1],
+            p[i0 + 3 < n ? i0 + 3 : n - 1]};
 }
 
 struct TCtx {
@@ -169,6 +220,7 @@ __device__ __forceinline__ void t_net_fwd(const TCtx& X, const float* W, const f
     }
   }
   __syncthreads();
+  TT_MARK(1);
   {
     float* h1 = X.Hm(MH1);
     const float *p0 = X.Hm(MPART), *p1 = X.Hm(MPART + 1), *p2 = X.Hm(MPART + 2), *p3 = X.Hm(MPART + 3);
@@ -179,19 +231,20 @@ __device__ __forceinline__ void t_net_fwd(const TCtx& X, const float* W, const f
     }
   }
   __syncthreads();
+  TT_MARK(2);
   {  // layer 2
     const float* h1 = X.Hm(MH1);
     float* h2 = X.Hm(MH2);
     for (int tm = X.wave; tm < X.tH; tm += TNW) {
       f4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int j0 = 16 * tm + 4 * X.g;
+      const f4 bias = ld4c(W + o.b4, j0, H);
       acc = mm_tile(acc, W + o.W4, 1, H, H, 16 * tm, h1, 1, ldh, TC, 0, 0, H, lane);
-      for (int rr = 0; rr < 4; ++rr) {
-        const int j = 16 * tm + 4 * X.g + rr;
-        if (j < H) h2[X.r * ldh + j] = fmaxf(acc[rr] + W[o.b4 + j], 0.f);
-      }
+      if (j0 < ldh) st4(h2 + X.r * ldh + j0, relu4(acc + bias));     // (pad columns: never read)
     }
   }
   __syncthreads();
+  TT_MARK(3);
   {  // heads
     const float* h2 = X.Hm(MH2);
     for (int t = X.wave; t < 3 * X.tD; t += TNW) {
@@ -200,17 +253,15 @@ __device__ __forceinline__ void t_net_fwd(const TCtx& X, const float* W, const f
       const int bo = head == 0 ? o.bs : (head == 1 ? o.bt : o.bq);
       float* out = X.D(head == 0 ? MTS : (head == 1 ? MT : MTQ));
       f4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int k0 = 16 * tm + 4 * X.g;
+      const f4 bias = ld4c(W + bo, k0, d);
       acc = mm_tile(acc, Wh, 1, d, d, 16 * tm, h2, 1, ldh, TC, 0, 0, H, lane);
-      for (int rr = 0; rr < 4; ++rr) {
-        const int k = 16 * tm + 4 * X.g + rr;
-        if (k < d) {
-          const float z = acc[rr] + W[bo + k];
-          out[X.r * ldd + k] = head == 1 ? z : ftanh(z);
-        }
-      }
+      const f4 z = acc + bias;
+      if (k0 < ldd) st4(out + X.r * ldd + k0, head == 1 ? z : tanh4(z));
     }
   }
   __syncthreads();
+  TT_MARK(4);
 }
 
 // ---- reverse of t_net_fwd: consumes dS, dT, dQ (MDS, MDT, MDQ), accumulates parameter gradients into
@@ -229,11 +280,7 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
       float* Gh = G + (head == 0 ? o.Ws : (head == 1 ? o.Wt : o.Wq));
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = mm_tile(acc, h2, 1, ldh, H, 16 * tm, dz, ldd, 1, d, 16 * tn, 0, TC, lane);
-      const int k = 16 * tn + X.r;
-      for (int rr = 0; rr < 4; ++rr) {
-        const int j = 16 * tm + 4 * X.g + rr;
-        if (j < H && k < d) Gh[j * d + k] += acc[rr];
-      }
+      acc_tile(Gh, d, 1, H, d, 16 * tm + 4 * X.g, 16 * tn + X.r, acc);
     }
     // d h2 partial of head w:  part_w(c, j) = sum_k Wh(j, k) dz_h(c, k)      (wave 3: zero)
     {
@@ -260,6 +307,7 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
     }
   }
   __syncthreads();
+  TT_MARK(5);
   {
     const float* h2 = X.Hm(MH2);
     float* da2 = X.Hm(MDA2);
@@ -270,6 +318,7 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
     }
   }
   __syncthreads();
+  TT_MARK(6);
   {
     const float *h1 = X.Hm(MH1), *da2 = X.Hm(MDA2);
     float* da1 = X.Hm(MDA1);
@@ -279,17 +328,15 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
       if (t < nW4) {          // dW4(i, j) += sum_c h1(c, i) da2(c, j)
         const int tm = t / X.tH, tn = t - tm * X.tH;
         acc = mm_tile(acc, h1, 1, ldh, H, 16 * tm, da2, ldh, 1, H, 16 * tn, 0, TC, lane);
-        const int j = 16 * tn + X.r;
-        for (int rr = 0; rr < 4; ++rr) {
-          const int i = 16 * tm + 4 * X.g + rr;
-          if (i < H && j < H) G[o.W4 + i * H + j] += acc[rr];
-        }
+        acc_tile(G + o.W4, H, 1, H, H, 16 * tm + 4 * X.g, 16 * tn + X.r, acc);
       } else {                // da1(c, i) = [h1 > 0] sum_j W4(i, j) da2(c, j)
         const int tm = t - nW4;
         acc = mm_tile(acc, W + o.W4, H, 1, H, 16 * tm, da2, 1, ldh, TC, 0, 0, H, lane);
-        for (int rr = 0; rr < 4; ++rr) {
-          const int i = 16 * tm + 4 * X.g + rr;
-          if (i < H) da1[X.r * ldh + i] = h1[X.r * ldh + i] > 0.f ? acc[rr] : 0.f;
+        const int i0 = 16 * tm + 4 * X.g;
+        if (i0 < ldh) {
+          const f4 hh = ld4(h1 + X.r * ldh + i0);
+          st4(da1 + X.r * ldh + i0, f4{hh.x > 0.f ? acc.x : 0.f, hh.y > 0.f ? acc.y : 0.f,
+                                       hh.z > 0.f ? acc.z : 0.f, hh.w > 0.f ? acc.w : 0.f});
         }
       }
     }
@@ -301,6 +348,7 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
     }
   }
   __syncthreads();
+  TT_MARK(7);
   {
     const float* da1 = X.Hm(MDA1);
     const int nWg = X.tD * X.tH;        // tiles of one layer-1 weight gradient
@@ -310,19 +358,13 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
         const int which = t / nWg, u = t - which * nWg, tm = u / X.tH, tn = u - tm * X.tH;
         acc = mm_tile(acc, which == 0 ? a : b, 1, ldd, d, 16 * tm, da1, ldh, 1, H, 16 * tn, 0, TC, lane);
         float* Gw = G + (which == 0 ? o.W1 : o.W2);
-        const int i = 16 * tn + X.r;
-        for (int rr = 0; rr < 4; ++rr) {
-          const int k = 16 * tm + 4 * X.g + rr;
-          if (k < d && i < H) Gw[k * H + i] += acc[rr];
-        }
+        acc_tile(Gw, H, 1, d, H, 16 * tm + 4 * X.g, 16 * tn + X.r, acc);
       } else {                // da(c, k) = sum_i W1(k, i) da1(c, i);  db with W2
         const int u = t - 2 * nWg, which = u / X.tD, tm = u - which * X.tD;
         acc = mm_tile(acc, W + (which == 0 ? o.W1 : o.W2), H, 1, d, 16 * tm, da1, 1, ldh, TC, 0, 0, H, lane);
         float* out = which == 0 ? dA : dB;
-        for (int rr = 0; rr < 4; ++rr) {
-          const int k = 16 * tm + 4 * X.g + rr;
-          if (k < d) out[X.r * ldd + k] = acc[rr];
-        }
+        const int k0 = 16 * tm + 4 * X.g;
+        if (k0 < ldd) st4(out + X.r * ldd + k0, acc);
       }
     }
     for (int i = X.tid; i < H; i += TTHREADS) {
@@ -337,6 +379,7 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
     }
   }
   __syncthreads();
+  TT_MARK(8);
 }
 
 __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
@@ -401,7 +444,11 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
     for (int i = tid; i < (N_MH * TC * L.ldh); i += TTHREADS) X.mh[i] = 0.f;
     if (kb == 0) X.cs[CS_SGN * TC + c] = sg;
   }
+#ifdef L2HMC_TRAIN_TIMING
+  if (blockIdx.x == 0 && threadIdx.x == 0) tt_t0 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
+  TT_MARK(0);
 
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
@@ -523,7 +570,7 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
   float* ldm = lx;              // log-det terms of the forward trajectory (lx is free until the seeds)
   auto ckpt = [&](int t, int slot) { return A.ws + (((long long)t * A.N + n) * CKPT + slot) * d; };
 #define EW_BEGIN for (int k = kb; k < d; k += 16) { const int q = c * ldd + k;
-#define EW_END } __syncthreads();
+#define EW_END } __syncthreads(); TT_MARK(9);
 
   // v_half (dynamics.py:129-141 / 183-196): out = v_half(vin; g, V-net caches), logging the log-det;
   // `also_tmp`: tmp <- k1 x, the X-net's second input of the next stage
@@ -745,6 +792,7 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
   }
 #undef EW_BEGIN
 #undef EW_END
+  TT_MARK(10);
   {
     const float s = wave_sum(deps);
     if (X.lane == 0) atomicAdd(Ge, s);
@@ -759,6 +807,16 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
 using namespace l2hmc;
 
 extern "C" {
+
+#ifdef L2HMC_TRAIN_TIMING
+// copies the 16 phase accumulators to host and clears them
+void l2hmc_train_read_timers(unsigned long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(tt_acc), sizeof(unsigned long long) * 16);
+  unsigned long long z[16] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(tt_acc), z, sizeof(z));
+}
+#endif
 
 int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t T) {
   if (n_chains < 0 || d < 1 || T < 1) return fail(L2HMC_ERR_ARG, "l2hmc_train_workspace_floats: bad argument%s");

@@ -5,9 +5,9 @@ lines 156-181 and 254-271; `utils/losses.py:53-59` is the same per-proposal term
     v1 = |x - Lx|^2 px + 1e-4  from propose(x) (whose MH-selected state continues the chains),
     v2 likewise from propose(z), z ~ N(0, I);   Adam, lr = 1e-3 * 0.96 ** floor(step / 1000).
 
-The proposal and the gradient of its loss term w.r.t. all net parameters and alpha come from ONE
-HIP kernel (`l2hmc_train_propose_grad`, hand-derived reverse mode incl. the Hessian-vector path
-through grad U).  With chains sharded over ranks the flat gradient is all-reduced ONCE per step
+The proposals and the gradient of their loss terms w.r.t. all net parameters and alpha come from ONE
+launch of ONE HIP kernel over the 2N chains [x; z] (`l2hmc_train_propose_grad`, hand-derived reverse
+mode incl. the Hessian-vector path through grad U).  With chains sharded over ranks the flat gradient is all-reduced ONCE per step
 (RCCL on the GPU box / gloo in tests): the loss is a mean over chains, so summing per-rank
 gradients computed with inv_n = 1 / (global chain count) is exact.  torch is used for the Adam
 update of the parameter tensors and the collective only.
@@ -117,8 +117,10 @@ class Trainer(object):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         n_total = N * world
         self.flat.zero_()
-        Lx, px, v1 = self._propose_grad(x, xv, xd, n_total)
-        Lz, pz, v2 = self._propose_grad(z, zv, zd, n_total)
+        # the x- and the z-proposal are independent and their loss terms add: ONE launch over the 2N
+        # chains [x; z] (each chain's term still weighted 1 / n_total) instead of two half-empty ones
+        Lxz, pxz, v12 = self._propose_grad(torch.cat([x, z]), torch.cat([xv, zv]), torch.cat([xd, zd]), n_total)
+        Lx, px, v1, v2 = Lxz[:N], pxz[:N], v12[:N], v12[N:]
         terms = torch.stack([(1.0 / v1).sum(), (1.0 / v2).sum(), v1.sum(), v2.sum()]).double()
         if world > 1:
             dist.all_reduce(self.flat)                  # the ONE collective of a training step

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Per-phase cycle breakdown of the training kernel (block 0).  `build` (in the container) makes a
+profiling copy of the library with -DL2HMC_TRAIN_TIMING under csrc/variants/; on the GPU box
+`python tools/train_phase_timing.py scg2d|icg50 [chains]` runs one x- plus one z-proposal."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "l2hmc_amd", "csrc")
+OUT = os.path.join(CSRC, "variants", "libl2hmc_hip_tt.so")
+KINDS = ["stage", "fwd L1 partials", "fwd bias+relu", "fwd L2", "fwd heads", "bwd heads/dW/part", "bwd relu'",
+         "bwd W4 / d1", "bwd W1,W2 / da,db", "elementwise passes", "other (energy, seeds)"]
+
+
+def main():
+    if sys.argv[1] == "build":
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        srcs = [os.path.join(CSRC, f) for f in ("l2hmc_abi.hip", "traj_ek1.hip", "traj_ek2.hip", "traj_ek3.hip",
+                                                "traj_ek4.hip", "traj_ek5.hip", "train.hip", "split.hip")]
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+                        "-DL2HMC_TRAIN_TIMING", "-Wno-return-type", "-Wno-pass-failed", "-shared", "-o", OUT] + srcs
+                       + ["-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+        return
+    from l2hmc_amd import _ffi
+    _ffi.LIB_PATH = OUT
+    import torch
+    from tools.bench_train import make
+    from l2hmc_amd.training import Trainer
+    case = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    dev = torch.device("cuda", 0)
+    dyn, x, _ = make(case, n, dev)
+    tr = Trainer(dyn)
+    v = torch.randn_like(x)
+    dr = torch.randint(0, 2, (n,), device=dev, dtype=torch.uint8)
+    L = _ffi.lib()
+    buf = (ctypes.c_ulonglong * 16)()
+    for _ in range(2):
+        tr._propose_grad(x, v, dr, n)
+    L.l2hmc_train_read_timers(buf)
+    reps = 5
+    for _ in range(reps):
+        tr._propose_grad(x, v, dr, n)
+    L.l2hmc_train_read_timers(buf)
+    tot = sum(buf[i] for i in range(11))
+    print("%s, %d chains: s_memtime ticks (100 MHz) per proposal, block 0" % (case, n))
+    for i, k in enumerate(KINDS):
+        print("  %-24s %10.0f  %5.1f%%" % (k, buf[i] / reps, 100.0 * buf[i] / tot))
+    print("  %-24s %10.0f  = %.1f us" % ("total", tot / reps, tot / reps / 100.0))
+
+
+if __name__ == "__main__":
+    main()
