@@ -63,7 +63,9 @@ typedef struct L2hmcNet {
  *                (stride l2hmc_packed_gaussian_floats(d)), logc (n_comp) = log(pi_i / sqrt((2 pi)^d det Sigma_i))
  *   ROUGHWELL  : eta, easy (distributions.py:84-97: U = |x|^2/2 + eta sum cos(x / eta^2), or x / eta if easy)
  *   FUNNEL     : eta = sigma (distributions.py:155-180; clip = 4 sigma)
- * temperature divides U and grad U (dynamics.py:204-212); 1.0 when unused. */
+ * temperature divides U and grad U (dynamics.py:204-212); 1.0 when unused.
+ * anneal_beta in (0, 1): the AIS bridge of utils/ais.py:46-47 with the standard-normal initial
+ * energy its caller uses (eval_vae.py:55-56):  U := (1 - beta) |x|^2 / 2 + beta U(x);  0 (or 1) = off. */
 typedef struct L2hmcEnergy {
   int32_t kind;
   int32_t n_comp;
@@ -73,6 +75,7 @@ typedef struct L2hmcEnergy {
   float eta;
   int32_t easy;
   float temperature;
+  float anneal_beta;
 } L2hmcEnergy;
 
 /* Arguments of l2hmc_trajectory (passed by pointer; a HOST struct of device pointers). */
@@ -244,6 +247,17 @@ typedef struct L2hmcTrainArgs {
 int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t T);
 int64_t l2hmc_train_grad_floats(int32_t d, int32_t H);
 int l2hmc_train_propose_grad(const L2hmcTrainArgs* args, void* stream);
+
+/* AIS bookkeeping around one annealed HMC transition (utils/ais.py:44-66), initial energy N(0, I):
+ *   begin: w += dbeta (|x|^2 / 2 - U_final(x))                                   (ais.py:58-59)
+ *          v  = normals                          if refreshment < 0               (ais.py:57)
+ *             = v sqrt(1 - r) + normals sqrt(r)  otherwise                        (ais.py:55)
+ *   end:   accept = p - u >= 0;  x = accept ? Lx : x;  v = accept ? Lv : -Lv;  alpha_sum += p   (ais.py:62-66)
+ * The transition itself is l2hmc_trajectory in HMC mode with energy.anneal_beta = beta. */
+int l2hmc_ais_begin_step(const float* x, const float* U_final, const float* normals, float refreshment,
+                         float dbeta, float* w, float* v, int64_t n_chains, int32_t d, void* stream);
+int l2hmc_ais_end_step(const float* Lx, const float* Lv, const float* p, const float* u, float* x, float* v,
+                       float* alpha_sum, int64_t n_chains, int32_t d, void* stream);
 
 /* The draws the sampler loop would use, written out ((M,N,d) normals, (M,N) direction bits,
  * (M,N) uniforms; any output may be NULL): for tests, and for reproducing a run's randomness. */

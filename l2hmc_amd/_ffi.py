@@ -25,7 +25,7 @@ class L2hmcNet(C.Structure):
 class L2hmcEnergy(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_comp", C.c_int32), ("mu", _fp), ("prec", _fp),
                 ("logc", _fp), ("eta", C.c_float), ("easy", C.c_int32),
-                ("temperature", C.c_float)]
+                ("temperature", C.c_float), ("anneal_beta", C.c_float)]
 
 
 class L2hmcTrajectoryArgs(C.Structure):
@@ -90,6 +90,8 @@ SYMBOLS = {
     "l2hmc_train_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "l2hmc_train_grad_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_train_propose_grad": (C.c_int, [C.POINTER(L2hmcTrainArgs), _fp]),
+    "l2hmc_ais_begin_step": (C.c_int, [_fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, C.c_int64, C.c_int32, _fp]),
+    "l2hmc_ais_end_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp]),
     "l2hmc_rng_fill": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                  _fp, _fp, _fp, _fp]),
     "l2hmc_autocov": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int64, _fp, _fp, _fp]),

@@ -1,0 +1,101 @@
+"""Annealed importance sampling -- API of the reference's utils/ais.py (Wu et al. 2016).
+
+`ais_estimate` keeps the reference signature (ais.py:30-42).  The bridge is the reference's
+geometric path  U_b = (1 - b) U_init + b U_final,  b = 1/K, 2/K, .., 1  (ais.py:43,46-47), with the
+standard-normal initial energy its only caller uses (eval_vae.py:55-56).  Per anneal step
+(ais.py:48-66), all on the device:
+
+    l2hmc_energy            U_final(x)
+    l2hmc_ais_begin_step    w += db (|x|^2/2 - U_final(x));  v = fresh / partially refreshed momentum
+    l2hmc_trajectory        HMC mode (`leapfrogs` steps of size `step_size`) on U_b: energy.anneal_beta = b
+    l2hmc_ais_end_step      MH accept:  x = Lx or x;  v = Lv or -Lv (sic, ais.py:63);  alpha += p
+
+The random draws come from the library's Philox stream (`l2hmc_rng_fill`), keyed by (seed, anneal
+step, global chain index), or are injected (`draws=`, tests).  Returns what the reference returns:
+(log-mean-exp of the final log-weights, summed over `num_splits` equal chain blocks; mean accept
+probability).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .distributions import EnergyFunction, as_device_f32
+from .dynamics import Dynamics
+
+
+def _is_standard_normal(fn):
+    if not isinstance(fn, EnergyFunction) or fn.kind not in (_ffi.ENERGY_GAUSS_DIAG, _ffi.ENERGY_GAUSS_DENSE):
+        return False
+    mu, prec = np.asarray(fn._host['mu']), np.asarray(fn._host['prec'])
+    eye = np.ones(fn.x_dim) if fn.kind == _ffi.ENERGY_GAUSS_DIAG else np.eye(fn.x_dim)
+    return not mu.any() and prec.shape == eye.shape and np.array_equal(prec, eye.astype(prec.dtype))
+
+
+def ais_estimate(init_energy, final_energy, anneal_steps, initial_x, aux=None, step_size=0.5, leapfrogs=25,
+                 x_dim=5, num_splits=1, refresh=False, refreshment=0.1, *, seed=0, draws=None,
+                 chain_offset=0, return_state=False):
+    """ais.py:30-82.  Extra keyword-only arguments: `seed` / `chain_offset` (Philox stream), `draws` =
+    {'v0': (N,d), 'normals': (K,N,d), 'u': (K,N)} to inject the randomness, `return_state` to also get
+    {'x', 'w', 'alpha'} (final states, final log-weights, summed accept probabilities)."""
+    if not _is_standard_normal(init_energy):
+        raise NotImplementedError("ais_estimate: the initial energy must be the standard normal "
+                                  "`Gaussian(np.zeros(d), np.eye(d)).get_energy_function()` (eval_vae.py:55-56)")
+    if aux is not None:
+        raise NotImplementedError("ais_estimate: aux-conditioned final energies (the VAE decoder) are not "
+                                  "implemented on the fused engine")
+    K = int(anneal_steps)
+    if K < 2:
+        raise ValueError("anneal_steps must be >= 2 (ais.py:44 takes beta[1] - beta[0])")
+    dyn = Dynamics(x_dim, final_energy, T=leapfrogs, eps=step_size, hmc=True)
+    dyn.eps_override = float(step_size)
+    dev = dyn.device
+    x = as_device_f32(initial_x, dev).clone()
+    N, d = x.shape
+    if d != x_dim:
+        raise ValueError("initial_x is %d-dimensional, x_dim=%d" % (d, x_dim))
+    if N % int(num_splits):
+        raise ValueError("num_splits must divide the number of chains")
+    L = _ffi.lib()
+    s = _ffi.current_stream(dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    w, alpha = torch.zeros(N, **f32), torch.zeros(N, **f32)
+    z, u, U1 = torch.empty(N, d, **f32), torch.empty(N, **f32), torch.empty(N, **f32)
+
+    def fill(step, want_u):
+        # anneal step i uses Philox "proposal" index i (0 = the initial momentum)
+        _ffi.check(L.l2hmc_rng_fill(int(seed), int(step), int(chain_offset), N, d, 1, z.data_ptr(), None,
+                                    u.data_ptr() if want_u else None, s))
+
+    if draws is None:
+        fill(0, False)
+        v = z.clone()
+    else:
+        v = as_device_f32(draws['v0'], dev).clone()
+    # beta = linspace(0, 1, K + 1)[1:] in float32 like the graph (ais.py:43-44)
+    beta = np.linspace(0.0, 1.0, K + 1, dtype=np.float32)[1:]
+    dbeta = float(np.float32(beta[1] - beta[0]))
+    e_final = final_energy.c_struct(dev)
+    for i in range(K):
+        if draws is None:
+            fill(i + 1, True)
+            zi, ui = z, u
+        else:
+            zi, ui = as_device_f32(draws['normals'][i], dev), as_device_f32(draws['u'][i], dev)
+        _ffi.check(L.l2hmc_energy(e_final, x.data_ptr(), N, d, U1.data_ptr(), None, s))
+        _ffi.check(L.l2hmc_ais_begin_step(x.data_ptr(), U1.data_ptr(), zi.data_ptr(),
+                                          float(refreshment) if refresh else -1.0, dbeta,
+                                          w.data_ptr(), v.data_ptr(), N, d, s))
+        dyn.anneal_beta = float(beta[i])
+        Lx, Lv, px = dyn.forward(x, init_v=v)
+        _ffi.check(L.l2hmc_ais_end_step(Lx.data_ptr(), Lv.data_ptr(), px.data_ptr(), ui.data_ptr(),
+                                        x.data_ptr(), v.data_ptr(), alpha.data_ptr(), N, d, s))
+
+    def logmeanexp(t):
+        return torch.logsumexp(t, dim=0) - math.log(t.shape[0])
+    est = sum(logmeanexp(t) for t in torch.chunk(w, int(num_splits)))
+    mean_alpha = alpha.sum() / (K * N)
+    if return_state:
+        return est, mean_alpha, {'x': x, 'w': w, 'alpha': alpha}
+    return est, mean_alpha

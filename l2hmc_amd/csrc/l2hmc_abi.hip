@@ -74,6 +74,34 @@ __global__ void mh_select_kernel(const float* x, const float* Lx, const float* p
   out[i] = (px[n] - u[n] >= 0.f) ? Lx[i] : x[i];
 }
 
+// AIS bookkeeping around one annealed HMC transition (utils/ais.py:44-66); thread = chain.
+__global__ void ais_begin_kernel(const float* x, const float* U1, const float* z, float refreshment, float dbeta,
+                                 float* w, float* v, long long N, int d) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float keep = refreshment < 0.f ? 0.f : sqrtf(1.f - refreshment);
+  const float mix = refreshment < 0.f ? 1.f : sqrtf(refreshment);
+  float q = 0.f;
+  for (int k = 0; k < d; ++k) {
+    const float xv = x[n * d + k];
+    q += xv * xv;
+    v[n * d + k] = refreshment < 0.f ? z[n * d + k] : v[n * d + k] * keep + z[n * d + k] * mix;
+  }
+  w[n] = w[n] + dbeta * (-U1[n] + 0.5f * q);
+}
+__global__ void ais_end_kernel(const float* Lx, const float* Lv, const float* p, const float* u, float* x,
+                               float* v, float* alpha_sum, long long N, int d) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const bool acc = p[n] - u[n] >= 0.f;
+  for (int k = 0; k < d; ++k) {
+    const float lv = Lv[n * d + k];
+    if (acc) x[n * d + k] = Lx[n * d + k];
+    v[n * d + k] = acc ? lv : -lv;                // (rejected: the NEGATED PROPOSED momentum, ais.py:63)
+  }
+  if (alpha_sum != nullptr) alpha_sum[n] += p[n];
+}
+
 // The sampler's Philox draws written out (l2hmc_rng_fill): thread = (proposal, chain, 4-dim block).
 __global__ void rng_fill_kernel(unsigned long long seed, unsigned long long prop0, long long chain_off,
                                 long long N, int d, int M, float* v, unsigned char* dir, float* u) {
@@ -215,6 +243,7 @@ int check_energy(const L2hmcEnergy* e, int d) {
       return fail(L2HMC_ERR_ARG, "unknown energy kind %s%lld", "", e->kind);
   }
   if (!(e->temperature > 0.f)) return fail(L2HMC_ERR_ARG, "temperature must be > 0%s");
+  if (!(e->anneal_beta >= 0.f && e->anneal_beta <= 1.f)) return fail(L2HMC_ERR_ARG, "anneal_beta must be in [0, 1] (0 = off)%s");
   return L2HMC_OK;
 }
 
@@ -227,6 +256,7 @@ void fill_energy(KArgs& k, const L2hmcEnergy* e) {
   k.logc = e->logc;
   k.eta = e->eta;
   k.temperature = e->temperature;
+  k.beta = e->anneal_beta > 0.f ? e->anneal_beta : 1.f;
 }
 
 // (DT, NW) geometry for d dimensions.  NW = 4 spreads a 16-chain tile over the 4 SIMDs of
@@ -406,6 +436,30 @@ int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const floa
   const long long n = n_chains * (long long)d;
   hipLaunchKernelGGL(mh_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, x, Lx, px, u, (long long)n_chains, d, x_next);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int l2hmc_ais_begin_step(const float* x, const float* U_final, const float* normals, float refreshment,
+                         float dbeta, float* w, float* v, int64_t n_chains, int32_t d, void* stream) {
+  if (n_chains < 0 || d < 1 || !x || !U_final || !normals || !w || !v || refreshment > 1.f)
+    return fail(L2HMC_ERR_ARG, "l2hmc_ais_begin_step: bad argument%s");
+  if (n_chains == 0) return L2HMC_OK;
+  hipLaunchKernelGGL(ais_begin_kernel, dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, U_final, normals, refreshment, dbeta, w, v, (long long)n_chains, d);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int l2hmc_ais_end_step(const float* Lx, const float* Lv, const float* p, const float* u, float* x, float* v,
+                       float* alpha_sum, int64_t n_chains, int32_t d, void* stream) {
+  if (n_chains < 0 || d < 1 || !Lx || !Lv || !p || !u || !x || !v)
+    return fail(L2HMC_ERR_ARG, "l2hmc_ais_end_step: bad argument%s");
+  if (n_chains == 0) return L2HMC_OK;
+  hipLaunchKernelGGL(ais_end_kernel, dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     Lx, Lv, p, u, x, v, alpha_sum, (long long)n_chains, d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;

@@ -85,6 +85,7 @@ struct KArgs {
   int ekind, ncomp, easy;
   const float *mu, *prec, *logc;
   float eta, temperature;
+  float beta;                // AIS bridge (utils/ais.py:46-47): U := (1 - beta) |x|^2 / 2 + beta U;  1 = off
   // p_accept-only kernel inputs
   const float *x1, *v1, *logjac_in;
   float *U_out, *grad_out;
@@ -430,6 +431,15 @@ __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, 
   } else {
 #pragma unroll
     for (int t = 0; t < DT; ++t) g[t] = splat(0.f);
+  }
+  if (A.beta != 1.f) {       // annealed energy between N(0, I) and the target (wave-uniform branch)
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      q += hsum(x[t] * x[t]);
+      g[t] = x[t] * (1.f - A.beta) + g[t] * A.beta;
+    }
+    U = (1.f - A.beta) * 0.5f * q + A.beta * U;
   }
   if (A.temperature != 1.f) {
     U = U / A.temperature;

@@ -846,6 +846,8 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
     return fail(L2HMC_ERR_ARG, "GMM training needs logc and 1 <= n_comp <= 8%s");
   if (ek == L2HMC_ENERGY_ROUGHWELL && !(a->energy.eta > 0.f)) return fail(L2HMC_ERR_ARG, "roughwell needs eta > 0%s");
   if (!(a->energy.temperature == 1.f)) return fail(L2HMC_ERR_UNSUPPORTED, "training kernel: temperature must be 1%s");
+  if (a->energy.anneal_beta != 0.f && a->energy.anneal_beta != 1.f)
+    return fail(L2HMC_ERR_UNSUPPORTED, "training kernel: annealed energies are not supported%s");
   if (!a->alpha && !(a->eps_host > 0.f)) return fail(L2HMC_ERR_ARG, "eps must be > 0%s");
   if (!(a->scale > 0.f) || !(a->inv_n > 0.f)) return fail(L2HMC_ERR_ARG, "scale and inv_n must be > 0%s");
   TArgs k;

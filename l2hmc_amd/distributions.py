@@ -53,19 +53,20 @@ class EnergyFunction(object):
             self._dev[key] = buf
         return self._dev[key]
 
-    def c_struct(self, device, temperature=1.0):
+    def c_struct(self, device, temperature=1.0, anneal_beta=0.0):
         b = self._buffers(device)
         return _ffi.L2hmcEnergy(self.kind, self.n_comp, _ffi.ptr(b['mu']), _ffi.ptr(b['prec']),
-                                _ffi.ptr(b['logc']), self.eta, int(self.easy), float(temperature))
+                                _ffi.ptr(b['logc']), self.eta, int(self.easy), float(temperature),
+                                float(anneal_beta))
 
-    def evaluate(self, x, temperature=1.0, want_U=True, want_grad=False):
+    def evaluate(self, x, temperature=1.0, want_U=True, want_grad=False, anneal_beta=0.0):
         x = as_device_f32(x)
         N, d = x.shape
         if self.x_dim is not None and d != self.x_dim:
             raise ValueError("energy expects x_dim=%d, got %d" % (self.x_dim, d))
         U = torch.empty(N, dtype=torch.float32, device=x.device) if want_U else None
         g = torch.empty_like(x) if want_grad else None
-        e = self.c_struct(x.device, temperature)
+        e = self.c_struct(x.device, temperature, anneal_beta)
         _ffi.check(_ffi.lib().l2hmc_energy(e, x.data_ptr(), N, d, _ffi.ptr(U), _ffi.ptr(g),
                                            _ffi.current_stream(x.device)))
         return U, g

@@ -53,6 +53,7 @@ class Dynamics(object):
         self.generator = None           # optional torch.Generator for the momentum draws
         self.variant = 0                # kernel geometry override (0 = auto), see l2hmc.h
         self.eps_override = None        # float: bypass exp(alpha) (exact step size for parity tests)
+        self.anneal_beta = 0.0          # AIS bridge (utils/ais.py:46-47): U := (1-b) |x|^2/2 + b U; 0 = off
 
         if not isinstance(energy_function, EnergyFunction):
             raise TypeError(
@@ -304,7 +305,7 @@ class Dynamics(object):
                 raise ValueError("u must be %s" % (lead + (N,),))
         a = _ffi.L2hmcTrajectoryArgs()
         a.packed_nets = _ffi.ptr(self._packed_nets())
-        a.energy = self._fn.c_struct(x.device, self.temperature if self.use_temperature else 1.0)
+        a.energy = self._fn.c_struct(x.device, self.temperature if self.use_temperature else 1.0, self.anneal_beta)
         a.masks, a.trig = self._mask.data_ptr(), self._trig.data_ptr()
         if self.eps_override is None:
             a.alpha, a.eps_host = self.alpha.data_ptr(), 0.0
@@ -337,7 +338,8 @@ class Dynamics(object):
         self._check_aux(aux)
         if self._split:
             return self._fn.evaluate(x, aux=aux)[0]
-        return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0)[0]
+        return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
+                                 anneal_beta=self.anneal_beta)[0]
 
     def grad_energy(self, x, aux=None):
         """dynamics.py:217-218 (analytic, computed by the HIP energy kernel)."""
@@ -345,7 +347,7 @@ class Dynamics(object):
         if self._split:
             return self._fn.evaluate(x, want_U=False, want_grad=True, aux=aux)[1]
         return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
-                                 want_U=False, want_grad=True)[1]
+                                 want_U=False, want_grad=True, anneal_beta=self.anneal_beta)[1]
 
     def hamiltonian(self, x, v, aux=None):
         """dynamics.py:214-215."""
@@ -389,7 +391,7 @@ class Dynamics(object):
         lj = as_device_f32(log_jac, self.device)
         N, d = x0.shape
         p = torch.empty(N, dtype=torch.float32, device=x0.device)
-        e = self._fn.c_struct(x0.device, self.temperature if self.use_temperature else 1.0)
+        e = self._fn.c_struct(x0.device, self.temperature if self.use_temperature else 1.0, self.anneal_beta)
         _ffi.check(_ffi.lib().l2hmc_p_accept(e, x0.data_ptr(), v0.data_ptr(), x1.data_ptr(),
                                              v1.data_ptr(), lj.data_ptr(), N, d, p.data_ptr(),
                                              _ffi.current_stream(x0.device)))

@@ -375,6 +375,47 @@ class Dynamics:
 
 
 # --------------------------------------------------------------------------------------------
+# AIS  (utils/ais.py:30-82, Wu et al. 2016)
+# --------------------------------------------------------------------------------------------
+def ais_estimate(init_energy, final_energy, anneal_steps, initial_x, v0, normals, u, step_size=0.5,
+                 leapfrogs=25, num_splits=1, refresh=False, refreshment=0.1, dtype=np.float32):
+    """ais.py:30-82 with the randomness injected: v0 (N,d) is the scan's initial momentum (:72),
+    normals (K,N,d) the per-step momentum draws (:55,57), u (K,N) the accept uniforms (:62).
+    init_energy / final_energy: callables x -> (U, grad U).  Returns (estimate, mean alpha, state)."""
+    K = int(anneal_steps)
+    x = np.asarray(initial_x, dtype)
+    N, d = x.shape
+    beta = np.linspace(0.0, 1.0, K + 1, dtype=np.float32)[1:].astype(dtype)      # :43
+    dbeta = beta[1] - beta[0]                                                    # :44
+    w = np.zeros(N, dtype)
+    v = np.asarray(v0, dtype)
+    alphas = []
+    mask = np.zeros((leapfrogs, d), dtype)        # HMC mode: the nets are zero, the mask drops out
+    for i in range(K):
+        b = beta[i]
+
+        def curr(z, b=b):                                                        # :46-47
+            U0, g0 = init_energy(z)
+            U1, g1 = final_energy(z)
+            return (1 - b) * U0 + b * U1, (1 - b) * g0 + b * g1
+        z = np.asarray(normals[i], dtype)
+        rv = v * np.sqrt(dtype(1 - refreshment)) + z * np.sqrt(dtype(refreshment)) if refresh else z   # :54-57
+        w = w + dbeta * (-final_energy(x)[0] + init_energy(x)[0])                # :58-59
+        dyn = Dynamics(d, curr, leapfrogs, step_size, mask, dtype=dtype)         # :60 (hmc=True)
+        Lx, Lv, px = dyn.forward(x, rv)                                          # :61
+        acc = (px - np.asarray(u[i], dtype)) >= 0                                # :63
+        x = np.where(acc[:, None], Lx, x)
+        v = np.where(acc[:, None], Lv, -Lv)                                      # :65 (sic)
+        alphas.append(px)
+
+    def logmeanexp(t):
+        m = t.max()
+        return m + np.log(np.sum(np.exp(t - m))) - np.log(dtype(t.shape[0]))
+    est = sum(logmeanexp(t) for t in np.split(w, int(num_splits)))
+    return est, float(np.mean(alphas)), {'x': x, 'w': w, 'alpha': np.sum(alphas, axis=0)}
+
+
+# --------------------------------------------------------------------------------------------
 # Sampler  (utils/sampler.py)
 # --------------------------------------------------------------------------------------------
 def tf_accept(x, Lx, px, u):

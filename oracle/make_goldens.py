@@ -348,7 +348,67 @@ def gaussian_case(name, mu, cov, **kw):
     run_case(name, len(mu), energy_fn=dist.get_energy_function(), energy_params=params, **kw)
 
 
+def ais_case(name, d, final_fn, params, K, T, N, step_size, seed, num_splits=1, refresh=False, refreshment=0.1):
+    """utils/ais.py executed as is (ais_estimate, :30-82): init energy = the standard normal of
+    eval_vae.py:55-56; every draw it makes is recorded in call order (v0, then normal + uniform per step)."""
+    import types
+    for modname in ('tensorflow.examples', 'tensorflow.examples.tutorials', 'tensorflow.examples.tutorials.mnist'):
+        sys.modules.setdefault(modname, types.ModuleType(modname))
+    sys.modules['tensorflow.examples.tutorials.mnist'].input_data = None
+    with contextlib.redirect_stdout(io.StringIO()):
+        import ais as ref_ais                      # /root/reference/utils/ais.py
+        init = ref_distributions.Gaussian(np.zeros(d), np.eye(d)).get_energy_function()
+    tf1_stub.reset(seed)
+    np.random.seed(seed)
+    tf1_stub.VARIABLE_HOOK = None
+    rng = np.random.RandomState(seed + 1)
+    x0 = rng.randn(N, d).astype(np.float32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        est, mean_alpha = ref_ais.ais_estimate(init, final_fn, K, leaf(x0), step_size=step_size, leapfrogs=T,
+                                               x_dim=d, num_splits=num_splits, refresh=refresh,
+                                               refreshment=refreshment)
+    log = tf1_stub.RANDOM_LOG
+    kinds = [k for k, _ in log]
+    assert kinds == ['normal'] + ['normal', 'uniform'] * K, kinds
+    alpha, xs, ws, _ = tf1_stub.LAST_SCAN
+    out = dict(params)
+    out.update(case=name, x_dim=d, K=K, T=T, N=N, step_size=np.float32(step_size), num_splits=num_splits,
+               refresh=int(refresh), refreshment=np.float32(refreshment), x=x0, v0=log[0][1],
+               normals=np.stack([log[1 + 2 * i][1] for i in range(K)]),
+               u=np.stack([log[2 + 2 * i][1] for i in range(K)]),
+               estimate=npy(est), mean_alpha=npy(mean_alpha), x_final=npy(xs[-1]), w_final=npy(ws[-1]),
+               alpha_sum=npy(alpha.sum(0)))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print('%-18s AIS estimate %s  mean alpha %.4f' % (name, npy(est), float(mean_alpha)))
+
+
+def ais_cases():
+    rng = np.random.RandomState(7)
+    R = np.linalg.qr(rng.randn(8, 8))[0]
+    cov8 = R.T.dot(np.diag(np.exp(np.log(10.) * rng.uniform(-1, 1, size=8)))).dot(R)
+    mu8 = rng.randn(8) * 0.5
+    with contextlib.redirect_stdout(io.StringIO()):
+        g8 = ref_distributions.Gaussian(mu8, cov8)
+    p8 = {'energy.kind': 'gaussian', 'energy.mu': mu8.astype(np.float32), 'energy.i_sigma': g8.i_sigma.astype(np.float32)}
+    ais_case('ais_tilted8', 8, g8.get_energy_function(), p8, K=6, T=5, N=32, step_size=0.15, seed=51, num_splits=2)
+    ais_case('ais_tilted8_refresh', 8, g8.get_energy_function(), p8, K=5, T=4, N=32, step_size=0.15, seed=52,
+             refresh=True, refreshment=0.3)
+    var = np.exp(np.linspace(np.log(1e-1), np.log(1e1), 50))
+    with contextlib.redirect_stdout(io.StringIO()):
+        g50 = ref_distributions.Gaussian(np.zeros(50), np.diag(var))
+    p50 = {'energy.kind': 'gaussian', 'energy.mu': np.zeros(50, np.float32), 'energy.i_sigma': g50.i_sigma.astype(np.float32)}
+    ais_case('ais_icg50', 50, g50.get_energy_function(), p50, K=8, T=5, N=32, step_size=0.05, seed=53, num_splits=4)
+    mus = [np.array([2.0, 0.0], dtype=np.float32), np.array([-2.0, 0.0], dtype=np.float32)]
+    gmm = ref_distributions.GMM([torch.tensor(m) for m in mus], [0.5 * np.eye(2), 0.5 * np.eye(2)], [0.5, 0.5])
+    gfn = gmm.get_energy_function()
+    pg = {'energy.kind': 'gmm', 'energy.mus': np.stack(mus), 'energy.i_sigmas': np.stack(gmm.i_sigmas),
+          'energy.constants': np.array(gmm.constants, dtype=np.float32)}
+    ais_case('ais_mog2d', 2, lambda z, aux=None: gfn(z), pg, K=7, T=5, N=48, step_size=0.2, seed=54)
+
+
 def main():
+    if sys.argv[1:] == ['ais']:                  # only the AIS fixtures (leaves the other files untouched)
+        return ais_cases()
     # C1: Strongly-correlated Gaussian 2D, exactly the notebook's target (nb:103-108)
     cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
     gaussian_case('scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=11, x_scale=1.0)
@@ -450,6 +510,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'p_accept_edge.npz'), x0=x0, v0=v0, x1=x1, v1=v1,
                         logjac=lj, p=npy(p))
     print('p_accept_edge      p =', npy(p))
+    ais_cases()
 
 
 if __name__ == '__main__':

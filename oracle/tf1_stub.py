@@ -116,6 +116,13 @@ def is_finite(x, name=None): return torch.isfinite(x)
 def zeros_like(x, name=None): return torch.zeros_like(_t(x))
 def stop_gradient(x, name=None): return x.detach()
 def check_numerics(x, message=None): return x
+def sqrt(x, name=None): return torch.sqrt(_t(x))
+def linspace(start, stop, num, name=None): return torch.linspace(float(start), float(stop), int(num), dtype=float32)
+def stack(values, axis=0, name=None): return torch.stack([_t(v) for v in values], dim=axis)
+
+
+def split(value, num_or_size_splits, axis=0, name=None):
+    return list(torch.chunk(_t(value), int(num_or_size_splits), dim=axis))
 
 
 def zeros(shape, dtype=float32, name=None):
@@ -131,7 +138,8 @@ def reduce_mean(x, axis=None, name=None):
 
 
 def reduce_logsumexp(x, axis=None, name=None):
-    return torch.logsumexp(_t(x), dim=axis)
+    x = _t(x)
+    return torch.logsumexp(x.reshape(-1), dim=0) if axis is None else torch.logsumexp(x, dim=axis)
 
 
 def shape(x, name=None):
@@ -205,6 +213,20 @@ def while_loop(cond, body, loop_vars, **kw):
     while bool(cond(*vs)):
         vs = list(body(*vs))
     return vs
+
+
+LAST_SCAN = []           # outputs of the most recent tf.scan (utils/ais.py:68), for the golden generator
+
+
+def scan(fn, elems, initializer=None, **kw):
+    """tf.scan over the leading axis of one tensor `elems` with a tuple accumulator."""
+    acc, outs = tuple(initializer), []
+    for e in elems:
+        acc = tuple(fn(acc, e))
+        outs.append(acc)
+    res = tuple(torch.stack([_t(o[i]) for o in outs]) for i in range(len(acc)))
+    LAST_SCAN[:] = res
+    return res
 
 
 def _make_module():

@@ -10,8 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz"))
-               if not f.endswith("p_accept_edge.npz") and not os.path.basename(f).startswith("train_"))
+               if not f.endswith("p_accept_edge.npz") and not os.path.basename(f).startswith(("train_", "ais_")))
 TRAIN_CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "train_*.npz")))
+AIS_CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "ais_*.npz")))
 
 
 def load(case):

@@ -181,3 +181,21 @@ def test_vae_aux_branch_matches_reference_layers():
     g = load("vae_small")
     from tests.helpers import mlp_weights
     assert rel_err(O.mlp3(mlp_weights(g, "enc."), g["aux"]), g["aux_h"]) < 2e-6
+
+
+@pytest.mark.parametrize("case", __import__("tests.helpers", fromlist=["AIS_CASES"]).AIS_CASES)
+def test_ais_oracle_matches_reference(case):
+    """oracle.ais_estimate vs the reference's own utils/ais.py (run under the TF1 stub by
+    oracle/make_goldens.py) on the recorded draws: final states, log-weights, estimate, mean accept."""
+    from tests.helpers import oracle_energy
+    g = load(case)
+    d = int(g["x_dim"])
+    init = O.Gaussian(np.zeros(d), np.eye(d))
+    est, mean_alpha, st = O.ais_estimate(init, oracle_energy(g), int(g["K"]), g["x"], g["v0"], g["normals"], g["u"],
+                                         step_size=float(g["step_size"]), leapfrogs=int(g["T"]),
+                                         num_splits=int(g["num_splits"]), refresh=bool(int(g["refresh"])),
+                                         refreshment=float(g["refreshment"]))
+    assert rel_err(st["x"], g["x_final"]) < 2e-5
+    assert abs_err(st["w"], g["w_final"]) < 2e-4 * max(1.0, float(np.abs(g["w_final"]).max()))
+    assert abs(float(est) - float(g["estimate"])) < 2e-4 * max(1.0, abs(float(g["estimate"])))
+    assert abs(mean_alpha - float(g["mean_alpha"])) < 1e-5
