@@ -200,14 +200,19 @@ typedef struct L2hmcSplitArgs {
   float *x_out, *v_out, *logjac_out, *p_out, *x_next;
   float* workspace;              /* l2hmc_split_workspace_floats(...) floats                */
   int64_t workspace_floats;
+  int32_t hmc;                   /* 1: nets identically zero (dynamics.py:73-76) = plain leapfrog, forward
+                                  *    only; xnet / vnet / masks / trig / aux_encoder are ignored         */
+  float bce_scale;               /* AIS bridge from N(0, I) (ais.py:46-47, eval_vae.py:55-62): the BCE term
+                                  *    of the energy is scaled by beta in (0, 1); 0 (or 1) = off          */
 } L2hmcSplitArgs;
 
 int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,
                                      const L2hmcMlp3* aux_encoder, const L2hmcMlp3* decoder);
 int l2hmc_trajectory_split(const L2hmcSplitArgs* args, void* stream);
-/* Dynamics.energy / grad_energy for the VAE posterior; workspace as for the split trajectory. */
+/* Dynamics.energy / grad_energy for the VAE posterior; workspace as for the split trajectory;
+ * bce_scale as in L2hmcSplitArgs (0 = off). */
 int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x, int64_t n_chains,
-                     int32_t d, float* U_out, float* grad_out, float* workspace, void* stream);
+                     int32_t d, float* U_out, float* grad_out, float* workspace, float bce_scale, void* stream);
 
 /* ---- training (next-row f1): one proposal + the gradient of its loss term ------------------- */
 /* Loss of SCGExperiment.ipynb raw lines 156-169 for ONE of its two proposals:
@@ -219,7 +224,8 @@ int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x,
  * per-rank gradients simply all-reduce(sum).  The nets are the RAW reference-layout weights
  * (not the packed buffer); for the dense Gaussian `energy.prec` is the raw (d, d) precision.
  * Targets with analytic Hessian-vector products: Gaussian (diag / dense), GMM (prec = RAW (k,d,d)
- * precisions, logc, n_comp <= 8), Rough Well; d <= 64, H <= 16 in this round.  Every chain runs in
+ * precisions, logc, n_comp <= 8), Rough Well; any d, H whose 16-chain tile fits the 160 KiB LDS
+ * (d = 50, H = 10 uses 122 KiB; larger shapes return L2HMC_ERR_UNSUPPORTED).  Every chain runs in
  * its own direction. */
 typedef struct L2hmcTrainArgs {
   const L2hmcNet* xnet;

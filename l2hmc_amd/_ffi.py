@@ -57,7 +57,8 @@ class L2hmcSplitArgs(C.Structure):
                 ("n_steps", C.c_int32), ("x", _fp), ("v", _fp), ("direction", _fp),
                 ("direction_all", C.c_int32), ("u", _fp),
                 ("x_out", _fp), ("v_out", _fp), ("logjac_out", _fp), ("p_out", _fp), ("x_next", _fp),
-                ("workspace", _fp), ("workspace_floats", C.c_int64)]
+                ("workspace", _fp), ("workspace_floats", C.c_int64), ("hmc", C.c_int32),
+                ("bce_scale", C.c_float)]
 
 
 class L2hmcTrainArgs(C.Structure):
@@ -86,7 +87,7 @@ SYMBOLS = {
     "l2hmc_split_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                  C.POINTER(L2hmcMlp3), C.POINTER(L2hmcMlp3)]),
     "l2hmc_trajectory_split": (C.c_int, [C.POINTER(L2hmcSplitArgs), _fp]),
-    "l2hmc_vae_energy": (C.c_int, [C.POINTER(L2hmcMlp3), _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp]),
+    "l2hmc_vae_energy": (C.c_int, [C.POINTER(L2hmcMlp3), _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp, C.c_float, _fp]),
     "l2hmc_train_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "l2hmc_train_grad_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_train_propose_grad": (C.c_int, [C.POINTER(L2hmcTrainArgs), _fp]),

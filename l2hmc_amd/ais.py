@@ -5,9 +5,11 @@ geometric path  U_b = (1 - b) U_init + b U_final,  b = 1/K, 2/K, .., 1  (ais.py:
 standard-normal initial energy its only caller uses (eval_vae.py:55-56).  Per anneal step
 (ais.py:48-66), all on the device:
 
-    l2hmc_energy            U_final(x)
+    l2hmc_energy            U_final(x)                 (l2hmc_vae_energy for the decoder posterior)
     l2hmc_ais_begin_step    w += db (|x|^2/2 - U_final(x));  v = fresh / partially refreshed momentum
     l2hmc_trajectory        HMC mode (`leapfrogs` steps of size `step_size`) on U_b: energy.anneal_beta = b
+                            (l2hmc_trajectory_split with hmc = 1, bce_scale = b for the decoder posterior,
+                             eval_vae.py:58-64: there U_b = |z|^2/2 + b BCE)
     l2hmc_ais_end_step      MH accept:  x = Lx or x;  v = Lv or -Lv (sic, ais.py:63);  alpha += p
 
 The random draws come from the library's Philox stream (`l2hmc_rng_fill`), keyed by (seed, anneal
@@ -42,9 +44,10 @@ def ais_estimate(init_energy, final_energy, anneal_steps, initial_x, aux=None, s
     if not _is_standard_normal(init_energy):
         raise NotImplementedError("ais_estimate: the initial energy must be the standard normal "
                                   "`Gaussian(np.zeros(d), np.eye(d)).get_energy_function()` (eval_vae.py:55-56)")
-    if aux is not None:
-        raise NotImplementedError("ais_estimate: aux-conditioned final energies (the VAE decoder) are not "
-                                  "implemented on the fused engine")
+    from .vae import ENERGY_VAE
+    vae = final_energy.kind == ENERGY_VAE        # eval_vae.py:58-64: decoder posterior, aux = the images
+    if vae != (aux is not None):
+        raise ValueError("aux= goes with the image-conditioned VAE energy (eval_vae.py:58-64) and only with it")
     K = int(anneal_steps)
     if K < 2:
         raise ValueError("anneal_steps must be >= 2 (ais.py:44 takes beta[1] - beta[0])")
@@ -76,19 +79,24 @@ def ais_estimate(init_energy, final_energy, anneal_steps, initial_x, aux=None, s
     # beta = linspace(0, 1, K + 1)[1:] in float32 like the graph (ais.py:43-44)
     beta = np.linspace(0.0, 1.0, K + 1, dtype=np.float32)[1:]
     dbeta = float(np.float32(beta[1] - beta[0]))
-    e_final = final_energy.c_struct(dev)
+    e_final = None if vae else final_energy.c_struct(dev)
+    if vae:
+        aux = as_device_f32(aux, dev)
     for i in range(K):
         if draws is None:
             fill(i + 1, True)
             zi, ui = z, u
         else:
             zi, ui = as_device_f32(draws['normals'][i], dev), as_device_f32(draws['u'][i], dev)
-        _ffi.check(L.l2hmc_energy(e_final, x.data_ptr(), N, d, U1.data_ptr(), None, s))
+        if vae:
+            U1 = final_energy.evaluate(x, aux=aux)[0]              # l2hmc_vae_energy (split engine)
+        else:
+            _ffi.check(L.l2hmc_energy(e_final, x.data_ptr(), N, d, U1.data_ptr(), None, s))
         _ffi.check(L.l2hmc_ais_begin_step(x.data_ptr(), U1.data_ptr(), zi.data_ptr(),
                                           float(refreshment) if refresh else -1.0, dbeta,
                                           w.data_ptr(), v.data_ptr(), N, d, s))
         dyn.anneal_beta = float(beta[i])
-        Lx, Lv, px = dyn.forward(x, init_v=v)
+        Lx, Lv, px = dyn.forward(x, init_v=v, aux=aux)
         _ffi.check(L.l2hmc_ais_end_step(Lx.data_ptr(), Lv.data_ptr(), px.data_ptr(), ui.data_ptr(),
                                         x.data_ptr(), v.data_ptr(), alpha.data_ptr(), N, d, s))
 

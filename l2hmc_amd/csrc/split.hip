@@ -85,23 +85,42 @@ __global__ void k_layer1(float* h1, const float* tb_net, const float* aux_h, con
   h1[i] = fmaxf(h1[i] + tb_net[s * H + (int)(i % H)] + (aux_h ? aux_h[i] : 0.f), 0.f);
 }
 
-// BCE part of the VAE energy, one workgroup per chain: U[n] = sum_pix bce(logit, aux) + |z|^2 / 2;
-// the logits are overwritten by d U / d logit = sigmoid(logit) - aux.
+// BCE part of the VAE energy, one workgroup per chain: U[n] = beta sum_pix bce(logit, aux) + |z|^2 / 2;
+// the logits are overwritten by d U / d logit = beta (sigmoid(logit) - aux).  beta = 1 except on the AIS
+// bridge (utils/ais.py:46-47 with the N(0, I) initial energy of eval_vae.py:55-62: only the BCE term anneals).
 __global__ __launch_bounds__(256) void k_vae_out(float* lg, const float* aux, const float* z, int n_pix, int d,
-                                                 float* U) {
+                                                 float* U, float beta) {
   __shared__ float part[4];
   const long long n = blockIdx.x;
   float acc = 0.f;
   for (int k = threadIdx.x; k < n_pix; k += 256) {
     const float l = lg[n * n_pix + k], t = aux[n * n_pix + k];
     acc += fmaxf(l, 0.f) - l * t + log1pf(expf(-fabsf(l)));      // TF's stable form (mnist_vae.py:124)
-    lg[n * n_pix + k] = sigmoid_f(l) - t;
+    lg[n * n_pix + k] = beta * (sigmoid_f(l) - t);
   }
+  acc *= beta;
   for (int k = threadIdx.x; k < d; k += 256) acc += 0.5f * z[n * d + k] * z[n * d + k];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0 && U != nullptr) U[n] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+// HMC mode (nets identically zero, dynamics.py:73-76): the generalised step is the plain leapfrog
+//   v_h = v - (eps/2) g(x);  x' = x + eps v_h     [k_hmc_drift]      v' = v_h - (eps/2) g(x')   [k_hmc_kick]
+__global__ void k_hmc_drift(float* x, const float* v, const float* g, float* vh, const float* alpha, float eps_host,
+                            long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float eps = alpha != nullptr ? expf(*alpha) : eps_host;
+  const float h = v[i] + 0.5f * eps * (-g[i]);
+  vh[i] = h;
+  x[i] = x[i] + eps * h;
+}
+__global__ void k_hmc_kick(float* v, const float* vh, const float* g, const float* alpha, float eps_host, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float eps = alpha != nullptr ? expf(*alpha) : eps_host;
+  v[i] = vh[i] + 0.5f * eps * (-g[i]);
 }
 __global__ void k_add(float* g, const float* z, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,10 +232,10 @@ int mlp3_forward(rocblas_handle h, hipStream_t s, const L2hmcMlp3& m, const floa
 
 // U (N) and grad (N x d) of the VAE latent posterior at z; lg is an (N x n_pix) scratch
 int vae_energy(rocblas_handle h, hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, long long N,
-               int d, const Mlp3Ws& ws, float* lg, float* U, float* grad) {
+               int d, const Mlp3Ws& ws, float* lg, float* U, float* grad, float beta = 1.f) {
   int rc;
   if ((rc = mlp3_forward(h, s, dec, z, N, ws, lg))) return rc;
-  hipLaunchKernelGGL(k_vae_out, dim3((unsigned)N), dim3(256), 0, s, lg, aux, z, dec.n_out, d, U);
+  hipLaunchKernelGGL(k_vae_out, dim3((unsigned)N), dim3(256), 0, s, lg, aux, z, dec.n_out, d, U, beta);
   if (grad == nullptr) return L2HMC_OK;
   // d a2 = dl W3^T (.) sigmoid(p2);  d a1 = d a2 W2^T (.) sigmoid(p1);  d z = d a1 W1^T + z
   if ((rc = gemm_rm(h, true, (int)N, dec.n_h2, dec.n_out, lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, 0.f))) return rc;
@@ -269,10 +288,12 @@ int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int
 }
 
 int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x, int64_t n_chains, int32_t d,
-                     float* U_out, float* grad_out, float* workspace, void* stream) {
+                     float* U_out, float* grad_out, float* workspace, float bce_scale, void* stream) {
   int rc = check_mlp(decoder, "l2hmc_vae_energy");
   if (rc) return rc;
   if (!aux || !x || !workspace || n_chains < 0 || d != decoder->n_in) return fail(L2HMC_ERR_ARG, "l2hmc_vae_energy: bad argument%s");
+  if (!(bce_scale >= 0.f && bce_scale <= 1.f)) return fail(L2HMC_ERR_ARG, "bce_scale must be in [0, 1] (0 = off)%s");
+  const float beta = bce_scale > 0.f ? bce_scale : 1.f;
   if (n_chains == 0) return L2HMC_OK;
   hipStream_t s = (hipStream_t)stream;
   rocblas_handle h;
@@ -280,7 +301,7 @@ int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x,
   const SplitPlan p = plan_split(n_chains, d, 1, 1, nullptr, decoder);
   float* w = workspace;
   const Mlp3Ws ws = {w + p.p1, w + p.a1, w + p.p2, w + p.a2};
-  if ((rc = vae_energy(h, s, *decoder, aux, x, n_chains, d, ws, w + p.lg, U_out, grad_out))) return rc;
+  if ((rc = vae_energy(h, s, *decoder, aux, x, n_chains, d, ws, w + p.lg, U_out, grad_out, beta))) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;
@@ -295,8 +316,13 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   const int d = a->d, H = a->H, T = a->T;
   if (N < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
   if (N == 0) return L2HMC_OK;
-  if (!a->xnet || !a->vnet || !a->aux || !a->masks || !a->trig || !a->x || !a->v || !a->workspace)
+  const bool hmc = a->hmc != 0;
+  if ((!hmc && (!a->xnet || !a->vnet || !a->masks || !a->trig)) || !a->aux || !a->x || !a->v || !a->workspace)
     return fail(L2HMC_ERR_ARG, "l2hmc_trajectory_split: NULL pointer%s");
+  if (hmc && (a->direction != nullptr || a->direction_all == 0))
+    return fail(L2HMC_ERR_UNSUPPORTED, "HMC mode runs forward only (sampler.py:29-31, ais.py:61)%s");
+  if (!(a->bce_scale >= 0.f && a->bce_scale <= 1.f)) return fail(L2HMC_ERR_ARG, "bce_scale must be in [0, 1] (0 = off)%s");
+  const float beta = a->bce_scale > 0.f ? a->bce_scale : 1.f;
   if (a->decoder->n_in != d) return fail(L2HMC_ERR_ARG, "decoder input width != d%s");
   if (a->aux_encoder && (a->aux_encoder->n_out != H || a->aux_encoder->n_in != a->decoder->n_out))
     return fail(L2HMC_ERR_ARG, "aux_encoder must map (N, n_pix) -> (N, H)%s");
@@ -313,19 +339,20 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   float *xc = w + p.xc, *vc = w + p.vc, *g = w + p.g, *vh = w + p.vh, *y = w + p.y, *xin = w + p.xin;
   float *h1 = w + p.h1, *h2 = w + p.h2, *out3 = w + p.out3, *tb = w + p.tb, *ld = w + p.ld;
   float* aux_h = a->aux_encoder ? w + p.aux_h : nullptr;
-  const L2hmcNet &xn = *a->xnet, &vn = *a->vnet;
+  static const L2hmcNet no_net = {};
+  const L2hmcNet &xn = hmc ? no_net : *a->xnet, &vn = hmc ? no_net : *a->vnet;
   const unsigned char* dir = a->direction;
   const int dall = a->direction_all;
 
   (void)hipMemcpyAsync(xc, a->x, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
   (void)hipMemcpyAsync(vc, a->v, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
-  if (a->aux_encoder) {      // the image branch is step-invariant: once per trajectory, not 4T times
+  if (a->aux_encoder && !hmc) {      // the image branch is step-invariant: once per trajectory, not 4T times
     const Mlp3Ws ews = {w + p.e1, w + p.e1a, w + p.e2, w + p.e2a};
     if ((rc = mlp3_forward(h, s, *a->aux_encoder, a->aux, N, ews, aux_h))) return rc;
   }
-  hipLaunchKernelGGL(k_time_table, dim3(nblk(2LL * T * H)), dim3(256), 0, s, xn, vn, a->trig, T, H, tb);
+  if (!hmc) hipLaunchKernelGGL(k_time_table, dim3(nblk(2LL * T * H)), dim3(256), 0, s, xn, vn, a->trig, T, H, tb);
   hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, vc, w + p.K0, ld, N, d);
-  if ((rc = vae_energy(h, s, *a->decoder, a->aux, xc, N, d, dws, w + p.lg, w + p.U0, g))) return rc;
+  if ((rc = vae_energy(h, s, *a->decoder, a->aux, xc, N, d, dws, w + p.lg, w + p.U0, g, beta))) return rc;
   if (a->n_steps == 0) (void)hipMemcpyAsync(w + p.U1, w + p.U0, sizeof(float) * N, hipMemcpyDeviceToDevice, s);
 
   // one net evaluation: out3 = relu(relu(a W1 + b W2 + time + aux_h) W4 + b4) [Ws|Wt|Wq]
@@ -345,6 +372,13 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
 
   for (int k = 0; k < a->n_steps; ++k) {
     const int it = a->step_begin + k;
+    const bool last = k == a->n_steps - 1;
+    if (hmc) {
+      hipLaunchKernelGGL(k_hmc_drift, dim3(nblk(N * d)), dim3(256), 0, s, xc, vc, g, vh, a->alpha, a->eps_host, N * d);
+      if ((rc = vae_energy(h, s, *a->decoder, a->aux, xc, N, d, dws, w + p.lg, last ? w + p.U1 : nullptr, g, beta))) return rc;
+      hipLaunchKernelGGL(k_hmc_kick, dim3(nblk(N * d)), dim3(256), 0, s, vc, vh, g, a->alpha, a->eps_host, N * d);
+      continue;
+    }
     if ((rc = net_eval(vn, 1, xc, g, it))) return rc;
     hipLaunchKernelGGL(k_v_half, dim3(nblk(N)), dim3(256), 0, s, out3, vn, vc, g, vh, ld, dir, dall, a->alpha,
                        a->eps_host, N, d);
@@ -355,8 +389,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     if ((rc = net_eval(xn, 0, vh, xin, it))) return rc;
     hipLaunchKernelGGL(k_x_half, dim3(nblk(N)), dim3(256), 0, s, out3, xn, y, vh, xc, (float*)nullptr, ld, a->masks, dir,
                        dall, it, T, 1, a->alpha, a->eps_host, N, d);
-    const bool last = k == a->n_steps - 1;
-    if ((rc = vae_energy(h, s, *a->decoder, a->aux, xc, N, d, dws, w + p.lg, last ? w + p.U1 : nullptr, g))) return rc;
+    if ((rc = vae_energy(h, s, *a->decoder, a->aux, xc, N, d, dws, w + p.lg, last ? w + p.U1 : nullptr, g, beta))) return rc;
     if ((rc = net_eval(vn, 1, xc, g, it))) return rc;
     hipLaunchKernelGGL(k_v_half, dim3(nblk(N)), dim3(256), 0, s, out3, vn, vh, g, vc, ld, dir, dall, a->alpha,
                        a->eps_host, N, d);

@@ -102,8 +102,6 @@ class Dynamics(object):
         if not self._split and not self.hmc and (self.H > 15 or self._xw['aux_encoder'] is not None):
             raise NotImplementedError("H > 15 or an aux branch needs the split engine, which currently "
                                       "implements the VAE posterior energy only")
-        if self._split and self.hmc:
-            raise NotImplementedError("HMC mode on the split engine is not implemented")
         self._split_ws = None
 
     # ---- masks / time encoding -----------------------------------------------------------------
@@ -222,17 +220,24 @@ class Dynamics(object):
             direction = direction.to(device=x.device, dtype=torch.uint8).contiguous()
         if u is not None:
             u = as_device_f32(u, self.device)
-        xs = _ffi.L2hmcNet(*[self._xw[k].data_ptr() for k in _ffi.NET_FIELDS])
-        vs = _ffi.L2hmcNet(*[self._vw[k].data_ptr() for k in _ffi.NET_FIELDS])
         dec = mlp3_struct(self._fn.decoder)
-        enc = mlp3_struct(self._xw['aux_encoder']) if self._xw['aux_encoder'] is not None else None
+        if self.hmc:
+            if direction is not None or not direction_all:
+                raise NotImplementedError("HMC mode runs forward only")
+            xs = vs = enc = None
+        else:
+            xs = _ffi.L2hmcNet(*[self._xw[k].data_ptr() for k in _ffi.NET_FIELDS])
+            vs = _ffi.L2hmcNet(*[self._vw[k].data_ptr() for k in _ffi.NET_FIELDS])
+            enc = mlp3_struct(self._xw['aux_encoder']) if self._xw['aux_encoder'] is not None else None
         L = _ffi.lib()
-        need = _ffi.check(L.l2hmc_split_workspace_floats(N, d, self.H, self.T,
+        need = _ffi.check(L.l2hmc_split_workspace_floats(N, d, max(self.H, 1), self.T,
                                                          C.byref(enc) if enc is not None else None, C.byref(dec)))
         if self._split_ws is None or self._split_ws.numel() < need:
             self._split_ws = torch.empty(int(need), dtype=torch.float32, device=self.device)
         a = _ffi.L2hmcSplitArgs()
-        a.xnet, a.vnet, a.H = C.pointer(xs), C.pointer(vs), self.H
+        a.xnet = C.pointer(xs) if xs is not None else None
+        a.vnet = C.pointer(vs) if vs is not None else None
+        a.H, a.hmc, a.bce_scale = max(self.H, 1), int(self.hmc), float(self.anneal_beta)
         a.aux_encoder = C.pointer(enc) if enc is not None else None
         a.decoder, a.aux = C.pointer(dec), aux.data_ptr()
         a.masks, a.trig = self._mask.data_ptr(), self._trig.data_ptr()
@@ -337,7 +342,7 @@ class Dynamics(object):
         """dynamics.py:203-212."""
         self._check_aux(aux)
         if self._split:
-            return self._fn.evaluate(x, aux=aux)[0]
+            return self._fn.evaluate(x, aux=aux, anneal_beta=self.anneal_beta)[0]
         return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
                                  anneal_beta=self.anneal_beta)[0]
 
@@ -345,7 +350,7 @@ class Dynamics(object):
         """dynamics.py:217-218 (analytic, computed by the HIP energy kernel)."""
         self._check_aux(aux)
         if self._split:
-            return self._fn.evaluate(x, want_U=False, want_grad=True, aux=aux)[1]
+            return self._fn.evaluate(x, want_U=False, want_grad=True, aux=aux, anneal_beta=self.anneal_beta)[1]
         return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
                                  want_U=False, want_grad=True, anneal_beta=self.anneal_beta)[1]
 

@@ -41,7 +41,7 @@ class VAEEnergy(EnergyFunction):
             self._ws = torch.empty(int(n_floats), dtype=torch.float32, device=device)
         return self._ws
 
-    def evaluate(self, x, temperature=1.0, want_U=True, want_grad=False, aux=None):
+    def evaluate(self, x, temperature=1.0, want_U=True, want_grad=False, aux=None, anneal_beta=0.0):
         if aux is None:
             raise ValueError("the VAE posterior energy needs aux= (the conditioning images)")
         if temperature != 1.0:
@@ -58,7 +58,7 @@ class VAEEnergy(EnergyFunction):
         U = torch.empty(N, dtype=torch.float32, device=x.device) if want_U else None
         g = torch.empty_like(x) if want_grad else None
         _ffi.check(L.l2hmc_vae_energy(C.byref(dec), aux.data_ptr(), x.data_ptr(), N, d, _ffi.ptr(U), _ffi.ptr(g),
-                                      ws.data_ptr(), _ffi.current_stream(x.device)))
+                                      ws.data_ptr(), float(anneal_beta), _ffi.current_stream(x.device)))
         return U, g
 
     def __call__(self, x, aux=None, *args, **kwargs):

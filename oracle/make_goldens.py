@@ -348,7 +348,8 @@ def gaussian_case(name, mu, cov, **kw):
     run_case(name, len(mu), energy_fn=dist.get_energy_function(), energy_params=params, **kw)
 
 
-def ais_case(name, d, final_fn, params, K, T, N, step_size, seed, num_splits=1, refresh=False, refreshment=0.1):
+def ais_case(name, d, final_fn, params, K, T, N, step_size, seed, num_splits=1, refresh=False, refreshment=0.1,
+             aux=None):
     """utils/ais.py executed as is (ais_estimate, :30-82): init energy = the standard normal of
     eval_vae.py:55-56; every draw it makes is recorded in call order (v0, then normal + uniform per step)."""
     import types
@@ -366,7 +367,7 @@ def ais_case(name, d, final_fn, params, K, T, N, step_size, seed, num_splits=1, 
     with contextlib.redirect_stdout(io.StringIO()):
         est, mean_alpha = ref_ais.ais_estimate(init, final_fn, K, leaf(x0), step_size=step_size, leapfrogs=T,
                                                x_dim=d, num_splits=num_splits, refresh=refresh,
-                                               refreshment=refreshment)
+                                               refreshment=refreshment, aux=aux)
     log = tf1_stub.RANDOM_LOG
     kinds = [k for k, _ in log]
     assert kinds == ['normal'] + ['normal', 'uniform'] * K, kinds
@@ -380,6 +381,36 @@ def ais_case(name, d, final_fn, params, K, T, N, step_size, seed, num_splits=1, 
                alpha_sum=npy(alpha.sum(0)))
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print('%-18s AIS estimate %s  mean alpha %.4f' % (name, npy(est), float(mean_alpha)))
+
+
+def ais_vae_case(name, latent, dec_h, n_pix, K, T, N, step_size, seed, num_splits=1):
+    """eval_vae.py:43-64 at fixture-friendly sizes: decoder from the reference's layer classes, final energy
+    = -log p(x|z) - log p(z) with the images as aux, through the reference's ais_estimate."""
+    tf1_stub.reset(seed)
+    np.random.seed(seed)
+    tf1_stub.VARIABLE_HOOK = None
+    with tf.variable_scope('decoder'):
+        decoder = Sequential([Linear(latent, dec_h, scope='decoder_1'), tf.nn.softplus,
+                              Linear(dec_h, dec_h, scope='decoder_2'), tf.nn.softplus,
+                              Linear(dec_h, n_pix, scope='decoder_3', factor=0.5)])
+    dec_w = {}
+    for full, val in tf1_stub.VARIABLES.items():
+        parts = full.split('/')
+        if parts[0] == 'decoder':
+            dec_w['dec.%s%s' % (parts[2], parts[1][-1])] = npy(val)
+    rng = np.random.RandomState(seed + 2)
+    aux = (rng.rand(N, n_pix) < 0.3).astype(np.float32)
+    auxt = torch.tensor(aux)
+
+    def final_energy(z, aux=None):                               # eval_vae.py:58-62
+        logits = decoder(z)
+        log_posterior = -tf.reduce_sum(tf.nn.sigmoid_cross_entropy_with_logits(labels=aux, logits=logits), axis=1)
+        log_prior = -0.5 * tf.reduce_sum(tf.square(z), axis=1)
+        return -log_posterior - log_prior
+    params = dict(dec_w)
+    params.update({'energy.kind': 'vae', 'aux': aux})
+    ais_case(name, latent, final_energy, params, K=K, T=T, N=N, step_size=step_size, seed=seed + 3,
+             num_splits=num_splits, aux=auxt)
 
 
 def ais_cases():
@@ -404,6 +435,7 @@ def ais_cases():
     pg = {'energy.kind': 'gmm', 'energy.mus': np.stack(mus), 'energy.i_sigmas': np.stack(gmm.i_sigmas),
           'energy.constants': np.array(gmm.constants, dtype=np.float32)}
     ais_case('ais_mog2d', 2, lambda z, aux=None: gfn(z), pg, K=7, T=5, N=48, step_size=0.2, seed=54)
+    ais_vae_case('ais_vae', latent=10, dec_h=48, n_pix=40, K=6, T=4, N=32, step_size=0.1, seed=55, num_splits=2)
 
 
 def main():

@@ -100,6 +100,11 @@ def hip_energy(g):
         return D.RoughWell(int(g["x_dim"]), float(g["energy.eta"]), bool(g["energy.easy"])).get_energy_function()
     if kind == "funnel":
         return D.GaussianFunnel(int(g["x_dim"])).get_energy_function()
+    if kind == "vae":
+        from l2hmc_amd import vae
+        dec = vae.make_decoder(int(g["x_dim"]), g["dec.W1"].shape[1], g["dec.W3"].shape[1])
+        _load_mlp(dec, g, "dec.")
+        return vae.VAEPosterior(dec).get_energy_function()
     raise ValueError(kind)
 
 

@@ -517,12 +517,13 @@ def test_ais_matches_reference(case):
     reference's own utils/ais.py on the recorded draws."""
     from l2hmc_amd import distributions as D
     from l2hmc_amd.ais import ais_estimate
-    from tests.helpers import hip_energy
+    from tests.helpers import aux_of, hip_energy
     g = load(case)
     d = int(g["x_dim"])
     init = D.Gaussian(np.zeros(d), np.eye(d)).get_energy_function()
     draws = {"v0": g["v0"], "normals": g["normals"], "u": g["u"]}
-    est, mean_alpha, st = ais_estimate(init, hip_energy(g), int(g["K"]), g["x"], step_size=float(g["step_size"]),
+    est, mean_alpha, st = ais_estimate(init, hip_energy(g), int(g["K"]), g["x"], aux=aux_of(g),
+                                       step_size=float(g["step_size"]),
                                        leapfrogs=int(g["T"]), x_dim=d, num_splits=int(g["num_splits"]),
                                        refresh=bool(int(g["refresh"])), refreshment=float(g["refreshment"]),
                                        draws=draws, return_state=True)
