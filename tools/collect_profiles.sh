@@ -18,14 +18,21 @@ cp $OUT/trace/b_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 head -3 $OUT/kernel_stats.csv
 
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE \
-    --output-format csv -d $OUT/pmc_sq -o c -- $BENCH --steps 20 --warmup 2 --no-cpu-baseline --no-ess > /dev/null 2>&1
+    --output-format csv -d $OUT/pmc_sq -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS \
-    --output-format csv -d $OUT/pmc_sq2 -o c -- $BENCH --steps 20 --warmup 2 --no-cpu-baseline --no-ess > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c -- $BENCH --steps 20 --warmup 2 --no-cpu-baseline --no-ess > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c -- $BENCH --steps 20 --warmup 2 --no-cpu-baseline --no-ess > /dev/null 2>&1
+    --output-format csv -d $OUT/pmc_sq2 -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess > /dev/null 2>&1
+# the many-chains regime (262144 chains, 10 proposals per launch): what saturates there
+BIG="$BENCH --chains 262144 --proposals-per-launch 10 --steps 10 --warmup 10 --no-cpu-baseline --no-ess"
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
+    --output-format csv -d $OUT/pmc_big -o c -- $BIG > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS \
+    --output-format csv -d $OUT/pmc_big2 -o c -- $BIG > /dev/null 2>&1
 python - <<PY > $OUT/pmc_summary.txt
 import csv, glob, collections
-for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+print("4096-chain passes: two dispatches of 25 chained proposals each (--steps 25 --warmup 25); pmc_big*: 262144 chains, two dispatches of 10 proposals")
+for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_big", "pmc_big2"):
     fs = glob.glob("$OUT/%s/*counter_collection.csv" % d)
     if not fs:
         print(d, "no output"); continue
@@ -41,4 +48,6 @@ rm -rf $OUT/trace/*.db $OUT/pmc_*/*.db
 
 cd $R
 timeout 300 python tools/phase_timing.py 4096 4 > $OUT/phase_timing.txt 2>&1; tail -15 $OUT/phase_timing.txt
+timeout 300 python tools/bench_train.py > $OUT/train_timing.txt 2>&1; cat $OUT/train_timing.txt
+( timeout 100 python tools/train_phase_timing.py scg2d; timeout 100 python tools/train_phase_timing.py icg50 ) > $OUT/train_phase_timing.txt 2>&1
 tools/sweep.sh "4096 4 25" "4096 4 1" "4096 1 25" "8192 4 25" "16384 4 25" "65536 4 25" "65536 1 25" "262144 4 10" "262144 1 10" "1048576 4 5" > $OUT/sweep.txt 2>&1; cat $OUT/sweep.txt

@@ -46,10 +46,10 @@ def main():
         tr._propose_grad(x, v, dr, n)
     L.l2hmc_train_read_timers(buf)
     tot = sum(buf[i] for i in range(11))
-    print("%s, %d chains: s_memtime ticks (100 MHz) per proposal, block 0" % (case, n))
+    print("%s, %d chains: s_memtime ticks per launch (one proposal of 16 chains), wave 0 of block 0" % (case, n))
     for i, k in enumerate(KINDS):
         print("  %-24s %10.0f  %5.1f%%" % (k, buf[i] / reps, 100.0 * buf[i] / tot))
-    print("  %-24s %10.0f  = %.1f us" % ("total", tot / reps, tot / reps / 100.0))
+    print("  %-24s %10.0f" % ("total", tot / reps))
 
 
 if __name__ == "__main__":
