@@ -214,6 +214,11 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* args, void* stream);
 int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x, int64_t n_chains,
                      int32_t d, float* U_out, float* grad_out, float* workspace, float bce_scale, void* stream);
 
+/* Dynamics.p_accept (dynamics.py:302-309) for energies evaluated separately (l2hmc_vae_energy):
+ * p = exp(min(U0 + |v0|^2/2 - U1 - |v1|^2/2 + log_jac, 0)), non-finite -> 0. */
+int l2hmc_p_accept_energies(const float* U0, const float* v0, const float* U1, const float* v1, const float* log_jac,
+                            int64_t n_chains, int32_t d, float* p_out, void* stream);
+
 /* ---- training (next-row f1): one proposal + the gradient of its loss term ------------------- */
 /* Loss of SCGExperiment.ipynb raw lines 156-169 for ONE of its two proposals:
  *   v1_n = |x_n - Lx_n|^2 p_n + 1e-4;   term = scale * mean_n(1 / v1_n) - mean_n(v1_n) / scale

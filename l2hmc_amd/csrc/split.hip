@@ -213,6 +213,19 @@ __global__ void k_finish(const float* U0, const float* K0, const float* U1, cons
   }
 }
 
+// accept probability from precomputed energies (dynamics.py:302-309): H = U + |v|^2 / 2
+__global__ void k_accept_from_energies(const float* U0, const float* v0, const float* U1, const float* v1,
+                                       const float* lj, float* p, long long N, int d) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float K0 = 0.f, K1 = 0.f;
+  for (int k = 0; k < d; ++k) {
+    K0 += 0.5f * v0[n * d + k] * v0[n * d + k];
+    K1 += 0.5f * v1[n * d + k] * v1[n * d + k];
+  }
+  p[n] = accept_prob((U0[n] + K0) - (U1[n] + K1) + lj[n]);
+}
+
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 struct Mlp3Ws { float *p1, *a1, *p2, *a2; };
@@ -302,6 +315,18 @@ int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x,
   float* w = workspace;
   const Mlp3Ws ws = {w + p.p1, w + p.a1, w + p.p2, w + p.a2};
   if ((rc = vae_energy(h, s, *decoder, aux, x, n_chains, d, ws, w + p.lg, U_out, grad_out, beta))) return rc;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int l2hmc_p_accept_energies(const float* U0, const float* v0, const float* U1, const float* v1, const float* log_jac,
+                            int64_t n_chains, int32_t d, float* p_out, void* stream) {
+  if (!U0 || !v0 || !U1 || !v1 || !log_jac || !p_out || n_chains < 0 || d < 1)
+    return fail(L2HMC_ERR_ARG, "l2hmc_p_accept_energies: bad argument%s");
+  if (n_chains == 0) return L2HMC_OK;
+  hipLaunchKernelGGL(k_accept_from_energies, dim3(nblk(n_chains)), dim3(256), 0, (hipStream_t)stream, U0, v0, U1, v1,
+                     log_jac, p_out, (long long)n_chains, d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;

@@ -389,13 +389,16 @@ class Dynamics(object):
     def p_accept(self, x0, v0, x1, v1, log_jac, aux=None):
         """dynamics.py:302-309."""
         self._check_aux(aux)
-        if self._split:
-            raise NotImplementedError("p_accept on arbitrary end points is not implemented on the split "
-                                      "engine (forward / backward / propose return it)")
         x0, v0, x1, v1 = (as_device_f32(t, self.device) for t in (x0, v0, x1, v1))
         lj = as_device_f32(log_jac, self.device)
         N, d = x0.shape
         p = torch.empty(N, dtype=torch.float32, device=x0.device)
+        if self._split:                    # energies from the rocBLAS decoder path, then one small kernel
+            U0, U1 = self.energy(x0, aux=aux), self.energy(x1, aux=aux)
+            _ffi.check(_ffi.lib().l2hmc_p_accept_energies(U0.data_ptr(), v0.data_ptr(), U1.data_ptr(), v1.data_ptr(),
+                                                          lj.data_ptr(), N, d, p.data_ptr(),
+                                                          _ffi.current_stream(x0.device)))
+            return p
         e = self._fn.c_struct(x0.device, self.temperature if self.use_temperature else 1.0, self.anneal_beta)
         _ffi.check(_ffi.lib().l2hmc_p_accept(e, x0.data_ptr(), v0.data_ptr(), x1.data_ptr(),
                                              v1.data_ptr(), lj.data_ptr(), N, d, p.data_ptr(),

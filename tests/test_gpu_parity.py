@@ -309,9 +309,10 @@ def test_wide_dims_against_oracle(kind, d, variant):
     assert abs_err(to_np(px)[fin], rpx[fin]) < 2 * P_TOL
 
 
-@pytest.mark.parametrize("case", ["scg2d", "tilted8"])
+@pytest.mark.parametrize("case", ["scg2d", "tilted8", "vae_small"])
 def test_chain_operator_matches_oracle(case):
-    """sampler.py:57-85: nb_steps composed proposals with summed log-Jacobians, one accept."""
+    """sampler.py:57-85: nb_steps composed proposals with summed log-Jacobians, one accept
+    (vae_small: the image-conditioned form of mnist_vae.py:196, split engine)."""
     from l2hmc_amd import chain_operator
     g = load(case)
     dyn, od = hip_dynamics(g), oracle_dynamics(g)
@@ -320,7 +321,7 @@ def test_chain_operator_matches_oracle(case):
     dirs = [rng.randint(0, 2, size=N).astype(np.uint8) for _ in range(K)]
     vs = [rng.randn(N, d).astype(np.float32) for _ in range(K)]
     u = rng.rand(N).astype(np.float32)
-    fx, fv, p, outs = chain_operator(to_dev(g["x"]), dyn, K, init_v=to_dev(g["v"]), do_mh_step=True,
+    fx, fv, p, outs = chain_operator(to_dev(g["x"]), dyn, K, aux=aux_of(g), init_v=to_dev(g["v"]), do_mh_step=True,
                                      directions=[to_dev(a) for a in dirs], vs=[to_dev(a) for a in vs],
                                      u=to_dev(u))
     with np.errstate(all="ignore"):
