@@ -86,6 +86,8 @@ __host__ __device__ inline int pitch(int n) {
 
 // the (16, ldd) matrices
 enum { MX, MV, MVH, MY, MXO, MG, MLX, MLV, MDVH, MDZ, MTMP, MDS, MDT, MDQ, MDA, MDB, MDG, MTS, MT, MTQ, N_MD };
+static_assert(MDT == MDS + 1 && MDQ == MDS + 2 && MDA == MDS + 3 && MDB == MDS + 4 && MT == MTS + 1 && MTQ == MTS + 2,
+              "train.hip indexes these matrices arithmetically");
 // the (16, ldh) matrices
 enum { MH1, MH2, MDA2, MDA1, MPART, N_MH = MPART + TNW };
 
@@ -181,6 +183,13 @@ __device__ __forceinline__ f4 ld4c(const float* p, int i0, int n) {
             p[i0 + 3 < n ? i0 + 3 : n - 1]};
 }
 
+// t = a * nb + b with 0 <= b < nb, for tiny a: avoids a ~40-instruction runtime integer division per tile
+__device__ __forceinline__ void split_idx(int t, int nb, int& a, int& b) {
+  a = 0;
+  b = t;
+  while (b >= nb) { b -= nb; ++a; }
+}
+
 struct TCtx {
   int tid, lane, wave, g, r;       // g = lane >> 4, r = lane & 15
   int d, H, T, ldd, ldh, tD, tH;   // tD, tH = 16-tiles over d and H
@@ -248,10 +257,14 @@ __device__ __forceinline__ void t_net_fwd(const TCtx& X, const float* W, const f
   {  // heads
     const float* h2 = X.Hm(MH2);
     for (int t = X.wave; t < 3 * X.tD; t += TNW) {
-      const int head = t / X.tD, tm = t - head * X.tD;
-      const float* Wh = W + (head == 0 ? o.Ws : (head == 1 ? o.Wt : o.Wq));
-      const int bo = head == 0 ? o.bs : (head == 1 ? o.bt : o.bq);
-      float* out = X.D(head == 0 ? MTS : (head == 1 ? MT : MTQ));
+      int head, tm;
+      split_idx(t, X.tD, head, tm);
+      // (offsets by arithmetic: the three heads are laid out [Ws bs Wt bt Wq bq]; a 3-way select of
+      //  runtime values would be turned into a lookup table in scratch memory)
+      const int hs = H * d + d;
+      const float* Wh = W + o.Ws + head * hs;
+      const int bo = o.bs + head * hs;
+      float* out = X.D(MTS + head);
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       const int k0 = 16 * tm + 4 * X.g;
       const f4 bias = ld4c(W + bo, k0, d);
@@ -270,14 +283,15 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
   const NetOff& o = X.o;
   const int d = X.d, H = X.H, ldd = X.ldd, ldh = X.ldh, lane = X.lane;
   // on entry (written by the *_half_bwd phase): MDS, MDT, MDQ = d zs, d zt, d zq;  MDA = dS * S, MDB = dQ * Q
-  float *dS = X.D(MDS), *dT = X.D(MDT), *dQ = X.D(MDQ), *dA = X.D(MDA), *dB = X.D(MDB);
   {
     const float *h2 = X.Hm(MH2);
     // head weight gradients  dWh(j, k) += sum_c h2(c, j) dz_h(c, k)
     for (int t = X.wave; t < 3 * X.tH * X.tD; t += TNW) {
-      const int head = t / (X.tH * X.tD), u = t - head * X.tH * X.tD, tm = u / X.tD, tn = u - tm * X.tD;
-      const float* dz = head == 0 ? dS : (head == 1 ? dT : dQ);
-      float* Gh = G + (head == 0 ? o.Ws : (head == 1 ? o.Wt : o.Wq));
+      int head, u, tm, tn;
+      split_idx(t, X.tH * X.tD, head, u);
+      split_idx(u, X.tD, tm, tn);
+      const float* dz = X.D(MDS + head);
+      float* Gh = G + o.Ws + head * (H * d + d);
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = mm_tile(acc, h2, 1, ldh, H, 16 * tm, dz, ldd, 1, d, 16 * tn, 0, TC, lane);
       acc_tile(Gh, d, 1, H, d, 16 * tm + 4 * X.g, 16 * tn + X.r, acc);
@@ -285,8 +299,8 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
     // d h2 partial of head w:  part_w(c, j) = sum_k Wh(j, k) dz_h(c, k)      (wave 3: zero)
     {
       const int w = X.wave;
-      const float* dz = w == 0 ? dS : (w == 1 ? dT : dQ);
-      const float* Wh = W + (w == 0 ? o.Ws : (w == 1 ? o.Wt : o.Wq));
+      const float* dz = X.D(MDS + (w < 3 ? w : 0));
+      const float* Wh = W + o.Ws + (w < 3 ? w : 0) * (H * d + d);
       float* part = X.Hm(MPART + w);
       for (int tm = 0; tm < X.tH; ++tm) {
         f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -297,9 +311,10 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
     }
     // column sums over the chains: bs, bt, bq, lam_s, lam_q
     for (int e = X.tid; e < 5 * d; e += TTHREADS) {
-      const int which = e / d, k = e - which * d;
-      const float* src = which == 0 ? dS : (which == 1 ? dT : (which == 2 ? dQ : (which == 3 ? dA : dB)));
-      const int dst = which == 0 ? o.bs : (which == 1 ? o.bt : (which == 2 ? o.bq : (which == 3 ? o.ls : o.lq)));
+      int which, k;
+      split_idx(e, d, which, k);
+      const float* src = X.D(MDS + which);                     // MDS, MDT, MDQ, MDA, MDB are consecutive
+      const int dst = which < 3 ? o.bs + which * (H * d + d) : o.ls + (which - 3) * d;
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < TC; ++c) s += src[c * ldd + k];
@@ -326,7 +341,8 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
     for (int t = X.wave; t < nW4 + X.tH; t += TNW) {
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       if (t < nW4) {          // dW4(i, j) += sum_c h1(c, i) da2(c, j)
-        const int tm = t / X.tH, tn = t - tm * X.tH;
+        int tm, tn;
+        split_idx(t, X.tH, tm, tn);
         acc = mm_tile(acc, h1, 1, ldh, H, 16 * tm, da2, ldh, 1, H, 16 * tn, 0, TC, lane);
         acc_tile(G + o.W4, H, 1, H, H, 16 * tm + 4 * X.g, 16 * tn + X.r, acc);
       } else {                // da1(c, i) = [h1 > 0] sum_j W4(i, j) da2(c, j)
@@ -355,14 +371,17 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
     for (int t = X.wave; t < 2 * nWg + 2 * X.tD; t += TNW) {
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       if (t < 2 * nWg) {      // dW1(k, i) += sum_c a(c, k) da1(c, i);  dW2 likewise with b
-        const int which = t / nWg, u = t - which * nWg, tm = u / X.tH, tn = u - tm * X.tH;
+        int which, u, tm, tn;
+        split_idx(t, nWg, which, u);
+        split_idx(u, X.tH, tm, tn);
         acc = mm_tile(acc, which == 0 ? a : b, 1, ldd, d, 16 * tm, da1, ldh, 1, H, 16 * tn, 0, TC, lane);
-        float* Gw = G + (which == 0 ? o.W1 : o.W2);
+        float* Gw = G + o.W1 + which * (d * H + H);
         acc_tile(Gw, H, 1, d, H, 16 * tm + 4 * X.g, 16 * tn + X.r, acc);
       } else {                // da(c, k) = sum_i W1(k, i) da1(c, i);  db with W2
-        const int u = t - 2 * nWg, which = u / X.tD, tm = u - which * X.tD;
-        acc = mm_tile(acc, W + (which == 0 ? o.W1 : o.W2), H, 1, d, 16 * tm, da1, 1, ldh, TC, 0, 0, H, lane);
-        float* out = which == 0 ? dA : dB;
+        int which, tm;
+        split_idx(t - 2 * nWg, X.tD, which, tm);
+        acc = mm_tile(acc, W + o.W1 + which * (d * H + H), H, 1, d, 16 * tm, da1, 1, ldh, TC, 0, 0, H, lane);
+        float* out = X.D(MDA + which);
         const int k0 = 16 * tm + 4 * X.g;
         if (k0 < ldd) st4(out + X.r * ldd + k0, acc);
       }
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
   const int dpad = (d + 3) / 4 * 4;
   float *ESx = smem + L.Ex, *EQx = ESx + dpad, *ESv = EQx + dpad, *EQv = ESv + dpad;
   TCtx X;
-  X.tid = tid; X.lane = tid & 63; X.wave = tid >> 6; X.g = X.lane >> 4; X.r = X.lane & 15;
+  X.tid = tid; X.lane = tid & 63; X.wave = __builtin_amdgcn_readfirstlane(tid >> 6); X.g = X.lane >> 4; X.r = X.lane & 15;
   X.d = d; X.H = H; X.T = T; X.ldd = ldd; X.ldh = L.ldh; X.tD = (d + 15) / 16; X.tH = (H + 15) / 16;
   X.o = net_off(d, H);
   X.md = smem + L.md; X.mh = smem + L.mh; X.cs = smem + L.cs; X.Msk = Msk; X.Trg = Trg; X.it = 0;
@@ -410,16 +429,19 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
   // ---- stage ------------------------------------------------------------------------------------
   {
     const NetOff& o = X.o;
-    const float* const* srcs[2] = {reinterpret_cast<const float* const*>(&A.xnet),
-                                   reinterpret_cast<const float* const*>(&A.vnet)};
-    const int offs[17] = {o.W1, o.b1, o.W2, o.b2, o.W3, o.b3, o.W4, o.b4, o.Ws, o.bs, o.Wt, o.bt, o.Wq,
-                          o.bq, o.ls, o.lq, P};
-    for (int nn = 0; nn < 2; ++nn)
-      for (int f = 0; f < 16; ++f) {
-        const float* src = srcs[nn][f];
-        float* dst = (nn == 0 ? Wx : Wv) + offs[f];
-        for (int i = tid; i < offs[f + 1] - offs[f]; i += TTHREADS) dst[i] = src[i];
-      }
+    // (field by field: indexing the kernel-argument struct through a pointer table would pin the
+    //  whole struct in scratch memory and turn every later argument read into a scratch load)
+    auto stage_net = [&](const L2hmcNet& nw, float* W) {
+      auto cp = [&](const float* src, int off, int cnt) {
+        for (int i = tid; i < cnt; i += TTHREADS) W[off + i] = src[i];
+      };
+      cp(nw.W1, o.W1, d * H); cp(nw.b1, o.b1, H); cp(nw.W2, o.W2, d * H); cp(nw.b2, o.b2, H);
+      cp(nw.W3, o.W3, 2 * H); cp(nw.b3, o.b3, H); cp(nw.W4, o.W4, H * H); cp(nw.b4, o.b4, H);
+      cp(nw.Ws, o.Ws, H * d); cp(nw.bs, o.bs, d); cp(nw.Wt, o.Wt, H * d); cp(nw.bt, o.bt, d);
+      cp(nw.Wq, o.Wq, H * d); cp(nw.bq, o.bq, d); cp(nw.lam_s, o.ls, d); cp(nw.lam_q, o.lq, d);
+    };
+    stage_net(A.xnet, Wx);
+    stage_net(A.vnet, Wv);
     for (int i = tid; i < d; i += TTHREADS) {
       ESx[i] = expf(A.xnet.lam_s[i]); EQx[i] = expf(A.xnet.lam_q[i]);
       ESv[i] = expf(A.vnet.lam_s[i]); EQv[i] = expf(A.vnet.lam_q[i]);
