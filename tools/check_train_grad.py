@@ -1,4 +1,12 @@
-"""debug: training gradient from single-tile launches (16 chains each) vs one full launch vs golden"""
+#!/usr/bin/env python
+"""Training-gradient check against the committed goldens (GPU box), optionally with an alternative
+build of the library (L2HMC_DBG_LIB=path/to/lib.so):
+
+    python tools/check_train_grad.py train_scg2d:full:1 train_icg50:chunk:2 ...
+
+case:mode:dup -- mode `full` = one launch over all chains, `chunk` = one launch per 16-chain tile
+(the flat gradient is accumulated across launches); dup = replicate the chains (the gradient of the
+mean loss must not change).  Prints the worst relative error over all parameter tensors."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from l2hmc_amd import _ffi
