@@ -73,3 +73,58 @@ def test_two_rank_statistics_match_single_process():
 def test_single_process_fallthrough():
     X = np.random.RandomState(1).randn(10, 4, 2)
     assert np.allclose(sharding.acl_spectrum(X, 1.0, 4), func_utils.acl_spectrum(X, 1.0))
+
+
+def _train_worker(rank, world, port, out):
+    """One rank of a 2-process training step on the SAME GPU (gloo all-reduce of the flat gradient):
+    exercises `Trainer`'s world_size > 1 branch end to end against the reference's full-batch gradient."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import l2hmc_oracle as O
+        from l2hmc_amd.training import Trainer
+        from tests.helpers import hip_dynamics, load, to_dev, to_np
+        g = load("train_tilted8")
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        tr = Trainer(dyn)
+        N = g["x"].shape[0]
+        lo, hi = sharding.shard_range(N)
+        pick = lambda d_, f, b: np.where(d_[:, None] != 0, f, b)[lo:hi]
+        draws = {"z": g["z"][lo:hi], "x_dir": g["x.dir"][lo:hi], "z_dir": g["z.dir"][lo:hi],
+                 "x_v": pick(g["x.dir"], g["x.v_fwd"], g["x.v_bwd"]), "z_v": pick(g["z.dir"], g["z.v_fwd"], g["z.v_bwd"])}
+        loss, _, _ = tr.loss_and_grad(to_dev(g["x"][lo:hi]), draws=draws)
+        scale = max(float(np.abs(g["grad.%s.%s" % (n, k)]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+        worst = 0.0
+        for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
+            for k in O.NET_KEYS:
+                ref = g["grad.%s.%s" % (n, k)]
+                worst = max(worst, float(np.abs(to_np(w[k].grad).reshape(ref.shape) - ref).max()))
+        out.put((rank, float(loss), float(g["loss"]), worst / scale, float(dyn.alpha.grad), float(g["grad.alpha"])))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_rank_training_step_matches_the_full_batch_gradient():
+    """Trainer with chains sharded over 2 processes (both on cuda:0, gloo): every rank ends up with the
+    reference's full-batch loss and gradient after the ONE flat all-reduce."""
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(280)
+        assert pr.exitcode == 0
+    res = sorted(out.get() for _ in range(2))
+    for rank, loss, ref_loss, rel, ga, ref_ga in res:
+        assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (rank, loss, ref_loss)
+        assert rel < 2e-4, (rank, rel)
+        assert abs(ga - ref_ga) < 2e-4 * max(1.0, abs(ref_ga)), (rank, ga, ref_ga)
