@@ -158,6 +158,8 @@ def main():
                          "(1 = one launch per step); a shorter last launch covers any remainder")
     args = ap.parse_args()
 
+    # (the host driver only supports dmabuf IPC: RCCL needs this for multi-process runs)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
