@@ -109,34 +109,65 @@ def cpu_baseline(prob, budget_s=12.0):
                       "the reference's N x N product); useful chain-steps counted once; %.1f s" % (reps, n, el)}
 
 
-def ess_leg(dev):
-    """ESS/sec on the notebook's SCG-2D target (BASELINE.json configs[0] shape: 200 chains, Lf=10)
-    with the HMC(eps=0.15) sampler whose ESS the reference publishes (nb raw 388: 5.63e-3 per MH
-    step): 2000 MH steps in one persistent launch, history + autocovariance on the device."""
+def ess_leg(dev, train_steps=5000):
+    """ESS/sec on the notebook's SCG-2D target (BASELINE.json configs[0] shape: 200 chains, Lf=10):
+    (i) the HMC(eps=0.15) sampler whose ESS the reference publishes (nb raw 388: 5.63e-3 per MH step);
+    (ii) the L2HMC sampler TRAINED IN THIS RUN with the notebook's recipe (raw 156-181, 254-271: 5000 Adam
+    steps on 200 chains; published ESS 2.61e-1, ratio 46).  2000 MH steps per sampler in one persistent
+    launch each, history + autocovariance on the device."""
     import torch
-    from l2hmc_amd import Dynamics, distributions, func_utils, sample_chain
+    from l2hmc_amd import Dynamics, distributions, func_utils, layers, sample_chain
+    from l2hmc_amd.training import Trainer
     cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
+    scale = float(np.sqrt(np.trace(cov)))
     dist = distributions.Gaussian(np.zeros(2), cov)
-    dyn = Dynamics(2, dist.get_energy_function(), T=10, eps=0.15, hmc=True, device=dev)
-    dyn.generator = torch.Generator(device=dev).manual_seed(0)
     n, steps = 200, 2000
+    gen = torch.Generator(device=dev).manual_seed(0)
     x0 = torch.as_tensor(dist.get_samples(n, rng=np.random.RandomState(0)), dtype=torch.float32, device=dev)
-    v = torch.randn((steps, n, 2), device=dev, generator=dyn.generator)
-    u = torch.rand((steps, n), device=dev, generator=dyn.generator)
-    sample_chain(x0, dyn, steps, v=v, u=u, record=True)                     # warm-up
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    xf, p, hist = sample_chain(x0, dyn, steps, v=v, u=u, record=True)
-    X = torch.cat([x0[None], hist[:-1]], dim=0)
-    A = func_utils.acl_spectrum(X, float(np.sqrt(np.trace(cov))))
-    torch.cuda.synchronize(dev)
-    el = time.perf_counter() - t0
-    ess = float(func_utils.ESS(A))
-    return {"workload": "SCG-2D, HMC eps=0.15, 200 chains x 2000 MH steps, Lf=10 (nb raw 288-298, 388)",
-            "ess_per_mh_step": ess, "reference_ess_per_mh_step": 5.63e-3,
-            "mh_steps_per_sec_per_chain": steps / el, "ess_per_sec": ess * steps / el * n,
-            "chain_leapfrog_steps_per_sec": n * 10 * steps / el, "mean_accept_prob": float(p.mean()),
-            "seconds_incl_autocov": el}
+
+    def measure(dyn, direction):
+        v = torch.randn((steps, n, 2), device=dev, generator=gen)
+        u = torch.rand((steps, n), device=dev, generator=gen)
+        sample_chain(x0, dyn, steps, v=v, u=u, direction=direction, record=True)                 # warm-up
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        xf, p, hist = sample_chain(x0, dyn, steps, v=v, u=u, direction=direction, record=True)
+        X = torch.cat([x0[None], hist[:-1]], dim=0)
+        A = func_utils.acl_spectrum(X, scale)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        ess = float(func_utils.ESS(A))
+        return {"ess_per_mh_step": ess, "mh_steps_per_sec_per_chain": steps / el, "ess_per_sec": ess * steps / el * n,
+                "chain_leapfrog_steps_per_sec": n * 10 * steps / el, "mean_accept_prob": float(p.mean()),
+                "seconds_incl_autocov": el}
+
+    hmc = Dynamics(2, dist.get_energy_function(), T=10, eps=0.15, hmc=True, device=dev)
+    out = measure(hmc, None)
+    out.update({"workload": "SCG-2D, HMC eps=0.15, 200 chains x 2000 MH steps, Lf=10 (nb raw 288-298, 388)",
+                "reference_ess_per_mh_step": 5.63e-3})
+    if train_steps > 0:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        layers.set_default_device(dev)
+        dyn = Dynamics(2, dist.get_energy_function(), T=10, eps=0.1, net_factory=layers.stq_network(10), device=dev)
+        dyn.generator = gen
+        tr = Trainer(dyn)
+        xs = torch.randn(n, 2, device=dev, generator=gen)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(train_steps):
+            _, _, xs, _ = tr.step(xs)
+        torch.cuda.synchronize(dev)
+        t_train = time.perf_counter() - t0
+        l2 = measure(dyn, torch.randint(0, 2, (steps, n), device=dev, dtype=torch.uint8, generator=gen))
+        l2.update({"workload": "SCG-2D, L2HMC sampler trained in this run (%d Adam steps, 200 chains; nb raw 156-181, "
+                               "254-271), then 200 chains x 2000 MH steps" % train_steps,
+                   "train_seconds": t_train, "train_ms_per_step": 1e3 * t_train / train_steps,
+                   "reference_ess_per_mh_step": 2.61e-1,
+                   "ess_ratio_vs_hmc": l2["ess_per_mh_step"] / out["ess_per_mh_step"], "reference_ess_ratio": 46.0,
+                   "ess_per_sec_ratio_vs_hmc": l2["ess_per_sec"] / out["ess_per_sec"]})
+        out["l2hmc"] = l2
+    return out
 
 
 def main():
@@ -151,6 +182,8 @@ def main():
                          "keyed by global chain index); bank: pre-generated draws read from HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true", help="skip the SCG-2D ESS/sec leg (N=1 only)")
+    ap.add_argument("--ess-train-steps", type=int, default=5000,
+                    help="Adam steps for the L2HMC sampler of the ESS leg (0 = HMC only)")
     ap.add_argument("--bank", type=int, default=0,
                     help="distinct pre-generated random draws, cycled (0 = 2 x proposals-per-launch, min 16)")
     ap.add_argument("--proposals-per-launch", type=int, default=25,
@@ -297,7 +330,7 @@ def main():
                 out["roofline"]["traffic"] = 1024.0 * (t["fetch_kb"] + t["write_kb"])
                 out["roofline"]["traffic_source"] = t["source"]
         if world == 1 and not args.no_ess:
-            out["ess"] = ess_leg(dev)
+            out["ess"] = ess_leg(dev, args.ess_train_steps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob)
         print(json.dumps(out))
