@@ -560,3 +560,17 @@ def test_ais_estimates_the_log_normaliser_ratio_and_is_sharding_invariant():
     _, _, part = ais_estimate(init, final, K, x0[lo:2 * lo], step_size=0.25, leapfrogs=5, x_dim=d, seed=11,
                               chain_offset=lo, return_state=True)
     assert torch.equal(part["w"], st["w"][lo:2 * lo]) and torch.equal(part["x"], st["x"][lo:2 * lo])
+
+
+def test_training_kernel_reports_shapes_beyond_its_lds_tile():
+    """The training kernel keeps a 16-chain tile's matrices in LDS; a shape that does not fit must fail
+    loudly (L2HMC_ERR_UNSUPPORTED through `_ffi.check`), not silently fall back."""
+    import torch
+    from l2hmc_amd import Dynamics, distributions as D, layers
+    from l2hmc_amd.training import Trainer
+    d = 192
+    dyn = Dynamics(d, D.Gaussian(np.zeros(d), np.diag(np.linspace(0.5, 2.0, d))).get_energy_function(), T=3, eps=0.1,
+                   net_factory=layers.stq_network(10))
+    tr = Trainer(dyn)
+    with pytest.raises(RuntimeError, match="LDS"):
+        tr.loss_and_grad(torch.randn(32, d, device="cuda"))
