@@ -72,7 +72,7 @@ def main():
     distribution = distributions.Gaussian(mu, cov)
     dynamics = Dynamics(x_dim, distribution.get_energy_function(), T=10, eps=0.1, net_factory=network)
     dynamics.generator = torch.Generator(device=dev).manual_seed(args.seed)
-    trainer = Trainer(dynamics)                        # Adam, lr 1e-3 * 0.96 ** floor(step / 1000)
+    trainer = Trainer(dynamics, seed=args.seed)        # Adam, lr 1e-3 * 0.96 ** floor(step / 1000)
 
     samples = torch.randn(args.samples, x_dim, device=dev, generator=dynamics.generator)
     t0 = time.perf_counter()

@@ -259,6 +259,14 @@ int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t T);
 int64_t l2hmc_train_grad_floats(int32_t d, int32_t H);
 int l2hmc_train_propose_grad(const L2hmcTrainArgs* args, void* stream);
 
+/* One Adam update as tf.train.AdamOptimizer applies it (SCGExperiment.ipynb raw 178-181) over the flat parameter
+ * vector laid out like the gradient of l2hmc_train_propose_grad ([XNet | VNet | alpha]):
+ *   lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr_t m / (sqrt(v) + eps)
+ * step = t >= 1.  last_is_log_eps: the last parameter is alpha = log eps while grad holds d/d eps there, so its
+ * gradient is multiplied by exp(alpha) first (dynamics.py:50-58). */
+int l2hmc_adam_step(float* params, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float epsilon, int64_t step, int32_t last_is_log_eps, void* stream);
+
 /* AIS bookkeeping around one annealed HMC transition (utils/ais.py:44-66), initial energy N(0, I):
  *   begin: w += dbeta (|x|^2 / 2 - U_final(x))                                   (ais.py:58-59)
  *          v  = normals                          if refreshment < 0               (ais.py:57)

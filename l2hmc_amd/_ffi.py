@@ -92,6 +92,8 @@ SYMBOLS = {
     "l2hmc_train_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "l2hmc_train_grad_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_train_propose_grad": (C.c_int, [C.POINTER(L2hmcTrainArgs), _fp]),
+    "l2hmc_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_int64, C.c_int32, _fp]),
     "l2hmc_ais_begin_step": (C.c_int, [_fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, C.c_int64, C.c_int32, _fp]),
     "l2hmc_ais_end_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp]),
     "l2hmc_rng_fill": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,

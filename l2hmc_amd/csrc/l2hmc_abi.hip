@@ -74,6 +74,21 @@ __global__ void mh_select_kernel(const float* x, const float* Lx, const float* p
   out[i] = (px[n] - u[n] >= 0.f) ? Lx[i] : x[i];
 }
 
+// Adam as tf.train.AdamOptimizer applies it (SCGExperiment.ipynb raw 178-181), over the flat parameter vector
+// [XNet | VNet | alpha]; `grad` is the buffer l2hmc_train_propose_grad accumulates into.
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1,
+                            float b2, float eps, int last_is_log_eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  if (last_is_log_eps && i == n - 1) gi *= expf(p[i]);      // d/d alpha = eps d/d eps (dynamics.py:50-58)
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
 // AIS bookkeeping around one annealed HMC transition (utils/ais.py:44-66); thread = chain.
 __global__ void ais_begin_kernel(const float* x, const float* U1, const float* z, float refreshment, float dbeta,
                                  float* w, float* v, long long N, int d) {
@@ -436,6 +451,22 @@ int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const floa
   const long long n = n_chains * (long long)d;
   hipLaunchKernelGGL(mh_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, x, Lx, px, u, (long long)n_chains, d, x_next);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int l2hmc_adam_step(float* params, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float epsilon, int64_t step, int32_t last_is_log_eps, void* stream) {
+  if (!params || !grad || !m || !v || n < 0 || step < 1 || !(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) ||
+      !(beta2 >= 0.f && beta2 < 1.f) || !(epsilon > 0.f))
+    return fail(L2HMC_ERR_ARG, "l2hmc_adam_step: bad argument%s");
+  if (n == 0) return L2HMC_OK;
+  // lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t)   (TF1 Adam: epsilon is added to sqrt(v), uncorrected)
+  const double t = (double)step;
+  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad,
+                     m, v, (long long)n, lr_t, beta1, beta2, epsilon, last_is_log_eps);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;

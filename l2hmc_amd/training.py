@@ -7,14 +7,18 @@ lines 156-181 and 254-271; `utils/losses.py:53-59` is the same per-proposal term
 
 The proposals and the gradient of their loss terms w.r.t. all net parameters and alpha come from ONE
 launch of ONE HIP kernel over the 2N chains [x; z] (`l2hmc_train_propose_grad`, hand-derived reverse
-mode incl. the Hessian-vector path through grad U).  With chains sharded over ranks the flat gradient is all-reduced ONCE per step
-(RCCL on the GPU box / gloo in tests): the loss is a mean over chains, so summing per-rank
-gradients computed with inv_n = 1 / (global chain count) is exact.  torch is used for the Adam
-update of the parameter tensors and the collective only.
+mode incl. the Hessian-vector path through grad U).  With chains sharded over ranks the flat gradient
+is all-reduced ONCE per step (RCCL on the GPU box / gloo in tests): the loss is a mean over chains, so
+summing per-rank gradients computed with inv_n = 1 / (global chain count) is exact.
+
+A training step is five library launches and no torch optimiser: `l2hmc_rng_fill` (z, both momenta,
+both direction vectors, the accept uniforms -- one Philox call), the gradient kernel,
+`l2hmc_adam_step` (TF1's Adam over the flat parameter vector [XNet | VNet | alpha], which the
+parameter tensors of the nets are views of), `l2hmc_mh_select`.  torch provides the buffers and the
+collective.
 """
 import ctypes as C
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -31,39 +35,59 @@ def _numel(code, d, H):
 
 
 class Trainer(object):
-    def __init__(self, dynamics, lr=1e-3, decay_steps=1000, decay_rate=0.96, scale=0.1):
+    def __init__(self, dynamics, lr=1e-3, decay_steps=1000, decay_rate=0.96, scale=0.1,
+                 beta1=0.9, beta2=0.999, epsilon=1e-8, seed=0):
         if dynamics.hmc:
             raise ValueError("an HMC-mode Dynamics has nothing to train")
         self.dyn, self.scale = dynamics, float(scale)
+        self.lr0, self.decay_steps, self.decay_rate = float(lr), int(decay_steps), float(decay_rate)
+        self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
+        self.seed = int(seed)
         d, H = dynamics.x_dim, dynamics.H
+        dev = dynamics.device
         L = _ffi.lib()
         self.n_grad = _ffi.check(L.l2hmc_train_grad_floats(d, H))
-        self.flat = torch.zeros(self.n_grad, dtype=torch.float32, device=dynamics.device)
-        # (tensor, offset, numel) in the flat layout [XNet | VNet | eps]
+        self.flat = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)          # gradient
+        # flat parameter vector [XNet | VNet | alpha]; every net parameter becomes a VIEW of it, so the
+        # native Adam update is seen by the layers, by `Dynamics` and by its packed-weight cache
+        self.theta = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)
         self.slots, off = [], 0
-        for w in (dynamics._xw, dynamics._vw):
-            for name, code in _SHAPES:
-                n = _numel(code, d, H)
-                self.slots.append((w[name], off, n))
-                off += n
-        assert off + 1 == self.n_grad
-        self.params = [t for t, _, _ in self.slots] + ([dynamics.alpha] if dynamics.alpha.requires_grad else [])
-        self.opt = torch.optim.Adam(self.params, lr=lr)
-        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: decay_rate ** (s // decay_steps))
+        with torch.no_grad():
+            for w in (dynamics._xw, dynamics._vw):
+                for name, code in _SHAPES:
+                    n = _numel(code, d, H)
+                    t = w[name]
+                    view = self.theta[off:off + n].view(t.shape)
+                    view.copy_(t)
+                    t.data = view
+                    self.slots.append((t, off, n))
+                    off += n
+            assert off + 1 == self.n_grad
+            self.train_alpha = bool(getattr(dynamics.alpha, "requires_grad", False))
+            self.theta[-1].copy_(dynamics.alpha.reshape(()))
+            dynamics.alpha.data = self.theta[-1].view(dynamics.alpha.shape)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
         self.global_step = 0
         self._ws = None
+        self._io = None              # per-N buffers of step()
 
-    # ---- one proposal + its gradient (accumulated into self.flat) --------------------------------
-    def _propose_grad(self, start, v, direction, n_total):
+    # ---- learning-rate schedule (nb raw 178-180: exponential_decay(..., staircase=True)) -------------
+    def lr_at(self, step):
+        return self.lr0 * self.decay_rate ** (step // self.decay_steps)
+
+    # ---- one launch: proposals + their gradient (accumulated into self.flat) ---------------------------
+    def _propose_grad(self, start, v, direction, n_total, out=None):
         dyn = self.dyn
         N, d = start.shape
         L = _ffi.lib()
         need = _ffi.check(L.l2hmc_train_workspace_floats(N, d, dyn.T))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.float32, device=dyn.device)
-        Lx = torch.empty_like(start)
-        p = torch.empty(N, dtype=torch.float32, device=dyn.device)
-        v1 = torch.empty(N, dtype=torch.float32, device=dyn.device)
+        if out is None:
+            out = (torch.empty_like(start), torch.empty(N, dtype=torch.float32, device=dyn.device),
+                   torch.empty(N, dtype=torch.float32, device=dyn.device))
+        Lx, p, v1 = out
         xs = _ffi.L2hmcNet(*[dyn._xw[k].data_ptr() for k in _ffi.NET_FIELDS])
         vs = _ffi.L2hmcNet(*[dyn._vw[k].data_ptr() for k in _ffi.NET_FIELDS])
         fn = dyn._fn
@@ -94,6 +118,16 @@ class Trainer(object):
         _ffi.check(L.l2hmc_train_propose_grad(a, _ffi.current_stream(dyn.device)))
         return Lx, p, v1
 
+    def _world(self):
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _loss(self, v12, N, n_total, world):
+        terms = torch.stack([(1.0 / v12).sum(), v12.sum()]).double()
+        if world > 1:
+            dist.all_reduce(terms)
+        terms = terms / n_total
+        return self.scale * terms[0] - terms[1] / self.scale
+
     def loss_and_grad(self, x, z=None, draws=None):
         """Loss and gradients (left in `.grad` of every parameter) for chain states `x`.
         draws: optional dict of injected randomness {x_dir, x_v, z, z_dir, z_v} (tests)."""
@@ -114,33 +148,67 @@ class Trainer(object):
                 return torch.as_tensor(draws[key], device=dev).to(torch.uint8).contiguous()
             return torch.randint(0, 2, (N,), device=dev, dtype=torch.uint8, generator=gen)
         xd, zd = bits("x_dir"), bits("z_dir")
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        world = self._world()
         n_total = N * world
         self.flat.zero_()
         # the x- and the z-proposal are independent and their loss terms add: ONE launch over the 2N
         # chains [x; z] (each chain's term still weighted 1 / n_total) instead of two half-empty ones
         Lxz, pxz, v12 = self._propose_grad(torch.cat([x, z]), torch.cat([xv, zv]), torch.cat([xd, zd]), n_total)
-        Lx, px, v1, v2 = Lxz[:N], pxz[:N], v12[:N], v12[N:]
-        terms = torch.stack([(1.0 / v1).sum(), (1.0 / v2).sum(), v1.sum(), v2.sum()]).double()
         if world > 1:
             dist.all_reduce(self.flat)                  # the ONE collective of a training step
-            dist.all_reduce(terms)
-        terms = terms / n_total
-        loss = self.scale * (terms[0] + terms[1]) - (terms[2] + terms[3]) / self.scale
+        loss = self._loss(v12, N, n_total, world)
         for t, off, n in self.slots:
             t.grad = self.flat[off:off + n].view(t.shape)
-        if dyn.alpha.requires_grad:
-            dyn.alpha.grad = (self.flat[-1] * torch.exp(dyn.alpha.detach())).reshape(dyn.alpha.shape)
-        return loss, Lx, px
+        if self.train_alpha:
+            self.dyn.alpha.grad = (self.flat[-1] * torch.exp(dyn.alpha.detach())).reshape(dyn.alpha.shape)
+        return loss, Lxz[:N], pxz[:N]
+
+    def _buffers(self, N, d):
+        if self._io is None or self._io["N"] != N:
+            dev, f32 = self.dyn.device, torch.float32
+            self._io = {"N": N,
+                        # rows: [x | z | v_x | v_z]: the Philox fill writes rows 1..3 (three "proposals" of N chains)
+                        "W": torch.empty((4, N, d), dtype=f32, device=dev),
+                        "dir": torch.empty((3, N), dtype=torch.uint8, device=dev),
+                        "u": torch.empty((3, N), dtype=f32, device=dev),
+                        "Lx": torch.empty((2 * N, d), dtype=f32, device=dev),
+                        "p": torch.empty(2 * N, dtype=f32, device=dev),
+                        "v1": torch.empty(2 * N, dtype=f32, device=dev)}
+        return self._io
 
     def step(self, x, u=None):
         """One optimiser step like nb raw 262-268: returns (loss, px, x_next, lr) where x_next is
         the MH-selected continuation of the chains."""
-        from .sampler import tf_accept
-        loss, Lx, px = self.loss_and_grad(x)
-        lr = self.sched.get_last_lr()[0]
-        self.opt.step()
-        self.sched.step()
+        dyn = self.dyn
+        x = as_device_f32(x, dyn.device)
+        N, d = x.shape
+        L = _ffi.lib()
+        s = _ffi.current_stream(dyn.device)
+        io = self._buffers(N, d)
+        W = io["W"]
+        world = self._world()
+        rank = dist.get_rank() if world > 1 else 0
+        n_total = N * world
+        # z, v_x, v_z (rows 1..3 of W), the direction bits of both proposals (rows 1, 2 of dir) and the
+        # accept uniforms (row 0 of u): one call, stream position = (seed, 3 * global_step, global chain)
+        _ffi.check(L.l2hmc_rng_fill(self.seed, 3 * self.global_step, rank * N, N, d, 3, W[1].data_ptr(),
+                                    io["dir"].data_ptr(), io["u"].data_ptr(), s))
+        W[0].copy_(x)
+        self.flat.zero_()
+        self._propose_grad(W[0:2].view(2 * N, d), W[2:4].view(2 * N, d), io["dir"][1:3].view(2 * N), n_total,
+                           out=(io["Lx"], io["p"], io["v1"]))
+        if world > 1:
+            dist.all_reduce(self.flat)                  # the ONE collective of a training step
+        loss = self._loss(io["v1"], N, n_total, world)
+        lr = self.lr_at(self.global_step)
         self.global_step += 1
-        x_next = tf_accept(x, Lx, px, u=u, dynamics=self.dyn)
-        return loss, px, x_next, lr
+        n_par = self.n_grad if self.train_alpha else self.n_grad - 1
+        _ffi.check(L.l2hmc_adam_step(self.theta.data_ptr(), self.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                     n_par, lr, self.beta1, self.beta2, self.epsilon, self.global_step,
+                                     int(self.train_alpha), s))
+        dyn._packed_key = None                          # the weights changed under the packed-fragment cache
+        x_next = torch.empty_like(x)
+        uu = io["u"][0] if u is None else as_device_f32(u, dyn.device)
+        _ffi.check(L.l2hmc_mh_select(x.data_ptr(), io["Lx"].data_ptr(), io["p"].data_ptr(), uu.data_ptr(), N, d,
+                                     x_next.data_ptr(), s))
+        return loss, io["p"][:N].clone(), x_next, lr

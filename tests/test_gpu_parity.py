@@ -574,3 +574,26 @@ def test_training_kernel_reports_shapes_beyond_its_lds_tile():
     tr = Trainer(dyn)
     with pytest.raises(RuntimeError, match="LDS"):
         tr.loss_and_grad(torch.randn(32, d, device="cuda"))
+
+
+def test_native_adam_matches_tf1_formula():
+    """l2hmc_adam_step vs tf.train.AdamOptimizer's update rule (nb raw 178-181) in float64, 5 steps, with the
+    alpha = log(eps) chain rule on the last element."""
+    import torch
+    from l2hmc_amd import _ffi
+    rng = np.random.RandomState(0)
+    n, lr, b1, b2, eps = 1000, 1e-3, 0.9, 0.999, 1e-8
+    p0 = rng.randn(n).astype(np.float32)
+    p, m, v = to_dev(p0.copy()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    rp, rm, rv = p0.astype(np.float64), np.zeros(n), np.zeros(n)
+    L = _ffi.lib()
+    for t in range(1, 6):
+        g = rng.randn(n).astype(np.float32)
+        _ffi.check(L.l2hmc_adam_step(p.data_ptr(), to_dev(g).data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, b1, b2, eps,
+                                     t, 1, _ffi.current_stream(p.device)))
+        g64 = g.astype(np.float64)
+        g64[-1] *= np.exp(rp[-1])
+        rm = b1 * rm + (1 - b1) * g64
+        rv = b2 * rv + (1 - b2) * g64 * g64
+        rp = rp - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * rm / (np.sqrt(rv) + eps)
+    assert np.abs(to_np(p) - rp).max() < 1e-6
