@@ -386,9 +386,6 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
     if (l2hmc_packed_nets_floats(a->d, a->H) < 0) return L2HMC_ERR_UNSUPPORTED;
     KH = khid_of(a->H);
   }
-  int DT, NW;
-  if (!pick_geometry(a->d, a->n_chains, a->variant, DT, NW))
-    return fail(L2HMC_ERR_UNSUPPORTED, "d = %s%lld not supported with variant %lld", "", a->d, a->variant);
   KArgs k;
   memset(&k, 0, sizeof(k));
   k.packed = a->packed_nets; k.masks = a->masks; k.trig = a->trig; k.alpha = a->alpha;
@@ -403,8 +400,24 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   k.chain_off = a->chain_offset;
   k.dbg = L2HMC_DBG_PTR;
   fill_energy(k, &a->energy);
-  const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW, DT);
   hipStream_t s = (hipStream_t)stream;
+  // Wide targets (more than 8 dim-tiles, i.e. d > 128; `variant` 8 forces it from 4 tiles up): the
+  // register-resident kernels carry 4 or 8 tiles of state per wave there and spill (d = 512: ~1.6k VGPRs);
+  // the LDS-resident-state kernel covers the elementwise energies that exist at this width.
+  const bool wide_kind = k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL;
+  const bool wide_able = a->packed_nets != nullptr && wide_kind && !(k.M > 1 && a->x_next == nullptr) && k.NT <= 32;
+  if (a->variant == 8 && !(wide_able && k.NT >= 4))
+    return fail(L2HMC_ERR_UNSUPPORTED, "variant 8 (LDS-resident state) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target, 64 <= d <= 512 and x_next when n_proposals > 1%s");
+  if (wide_able && (a->variant == 8 || (a->variant == 0 && k.NT > 8))) {
+    KArgs kw = k;
+    const long long ldsw = plan_lds_wide(kw);
+    if (ldsw <= 160 * 1024) return launch_wide(kw, KH, ldsw, s);
+    if (a->variant == 8) return fail(L2HMC_ERR_UNSUPPORTED, "variant 8: %s%lld bytes of LDS needed (T x d too large)", "", ldsw);
+  }
+  int DT, NW;
+  if (!pick_geometry(a->d, a->n_chains, a->variant, DT, NW))
+    return fail(L2HMC_ERR_UNSUPPORTED, "d = %s%lld not supported with variant %lld", "", a->d, a->variant);
+  const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW, DT);
   return dispatch(OP_TRAJ, k, DT, NW, KH, lds, s);
 }
 

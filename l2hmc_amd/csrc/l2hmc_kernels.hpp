@@ -44,6 +44,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr bool weights_in_global(int DT) { return DT >= 4; }
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0);
+struct KArgs;
+// traj_wide.hip: the LDS-resident-state kernel for d > 256 (elementwise energies)
+long long plan_lds_wide(KArgs& k);
+int launch_wide(const KArgs& k, int KH, long long lds, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // Packed layouts (shared by host and device)
@@ -91,6 +95,7 @@ struct KArgs {
   float *U_out, *grad_out;
   // LDS offsets (floats)
   int o_mask, o_trig, o_tb, o_P, o_XB, o_red, o_mu, o_prec, o_logc, xb_stride;
+  int o_state;               // traj_wide_kernel: x, v, grad U of the tile (3 x NT x 256 floats)
   unsigned long long* dbg;   // phase-timing buffer (profiling builds only, else NULL)
 };
 

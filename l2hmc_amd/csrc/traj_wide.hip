@@ -1,0 +1,397 @@
+// traj_wide_kernel -- the fused trajectory / sampler-loop kernel for WIDE targets (d > 256).
+//
+// Same algorithm, tiling and S-layout as traj_kernel (l2hmc_kernels.hpp; dynamics.py:115-309,
+// sampler.py:28-55), but the chain state lives in LDS instead of registers: with 8 dim-tiles per wave
+// the register-resident form needs ~1000 VGPRs of state and spills.  A workgroup (4 waves) owns 16
+// chains; x, v and grad U are three (NT, 64 lanes, 4) LDS arrays in S-layout order -- lane l of the
+// wave that owns tile tg reads / writes ONE conflict-free ds_*_b128 per vector -- and every phase is a
+// loop over the wave's own tiles:
+//     heads of tile tg (9 MFMAs, fragments streamed from L2)  ->  elementwise update of that tile
+//     ->  its layer-1 contribution to the NEXT net evaluation (4-8 MFMAs), fused in the same pass.
+// Per leapfrog step: 4 tile passes, 3 LDS exchanges of one 16x16 partial (as in traj_kernel), layer 2
+// once per net evaluation.  Elementwise energies only (diagonal Gaussian, Rough Well: the targets that
+// exist at this width); the other kinds keep the register kernel.
+#include "l2hmc_kernels.hpp"
+
+namespace l2hmc {
+
+__device__ __forceinline__ f4 tl(const float* S, int tg, int lane) { return lds4(S + (tg * 64 + lane) * 4); }
+__device__ __forceinline__ void ts(float* S, int tg, int lane, f4 v) { *reinterpret_cast<f4*>(S + (tg * 64 + lane) * 4) = v; }
+
+// grad U of one tile and this lane's share of U (distributions.py:31-32,41-57 diagonal case; :84-97)
+template <int EK>
+__device__ __forceinline__ f4 wide_grad(const KArgs& A, const float* smem, int tg, int q, f4 x, float& U) {
+  f4 g;
+  float u;
+  if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
+    const f4 mu = lds4(smem + A.o_mu + 16 * tg + 4 * q), s = lds4(smem + A.o_prec + 16 * tg + 4 * q);
+    const f4 dx = x - mu;
+    g = s * dx;
+    u = 0.5f * hsum(dx * g);
+  } else {
+    const float eta = A.eta, den = A.easy ? eta : eta * eta, scale = eta / den;
+    const f4 arg = x / den;
+    g = x - scale * f4{sinf(arg.x), sinf(arg.y), sinf(arg.z), sinf(arg.w)};
+    const int dim0 = 16 * tg + 4 * q;      // padded dims hold x = 0 and would add eta * cos(0): mask them out
+    const f4 cs = f4{cosf(arg.x), cosf(arg.y), cosf(arg.z), cosf(arg.w)};
+    const f4 lv = f4{dim0 < A.d ? 1.f : 0.f, dim0 + 1 < A.d ? 1.f : 0.f, dim0 + 2 < A.d ? 1.f : 0.f,
+                     dim0 + 3 < A.d ? 1.f : 0.f};
+    u = 0.5f * hsum(x * x) + eta * hsum(lv * cs);
+  }
+  if (A.beta != 1.f) {                     // AIS bridge from N(0, I) (utils/ais.py:46-47)
+    g = x * (1.f - A.beta) + g * A.beta;
+    u = (1.f - A.beta) * 0.5f * hsum(x * x) + A.beta * u;
+  }
+  if (A.temperature != 1.f) {
+    g = g / A.temperature;
+    u = u / A.temperature;
+  }
+  U += u;
+  return g;
+}
+
+template <int EK, int KH, int NW>
+__global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NTHR = 64 * NW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const long long chain = (long long)blockIdx.x * 16 + c;
+  const bool live = chain < A.N;
+  const int NT = A.NT, DP = 16 * NT, NF = net_floats(NT);
+  const int DTW = (NT + NW - 1) / NW;
+  const int t_lo = w * DTW, t_hi = (t_lo + DTW < NT) ? t_lo + DTW : NT;     // this wave's tiles
+  const float* wx = A.packed;            // XNet fragments (global, L2-hot)
+  const float* wv = A.packed + NF;       // VNet fragments
+
+  // ---- prologue: masks / time table / energy parameters into LDS -----------------------------------
+  for (int i = tid; i < A.T * DP; i += NTHR) {
+    const int row = i / DP, dim = i % DP;
+    smem[A.o_mask + i] = dim < A.d ? A.masks[row * A.d + dim] : 0.f;
+  }
+  for (int i = tid; i < 2 * A.T; i += NTHR) smem[A.o_trig + i] = A.trig[i];
+  stage_energy<EK, true>(A, smem, tid, NTHR);
+  float* SX = smem + A.o_state;
+  float* SV = SX + NT * 256;
+  float* SG = SV + NT * 256;
+
+  // (chain, dims 16 tg + 4 q + r) of a row-major (N, d) array  <->  this lane's f4 of tile tg
+  auto gload = [&](const float* p, int tg) {
+    const int dim0 = 16 * tg + 4 * q;
+    f4 r = splat(0.f);
+    if (live && p != nullptr) {
+      const float* row = p + chain * A.d;
+      if (dim0 + 0 < A.d) r.x = row[dim0 + 0];
+      if (dim0 + 1 < A.d) r.y = row[dim0 + 1];
+      if (dim0 + 2 < A.d) r.z = row[dim0 + 2];
+      if (dim0 + 3 < A.d) r.w = row[dim0 + 3];
+    }
+    return r;
+  };
+  auto gstore = [&](float* p, int tg, f4 v) {
+    if (!live || p == nullptr) return;
+    const int dim0 = 16 * tg + 4 * q;
+    float* row = p + chain * A.d;
+    if (dim0 + 0 < A.d) row[dim0 + 0] = v.x;
+    if (dim0 + 1 < A.d) row[dim0 + 1] = v.y;
+    if (dim0 + 2 < A.d) row[dim0 + 2] = v.z;
+    if (dim0 + 3 < A.d) row[dim0 + 3] = v.w;
+  };
+  for (int tg = t_lo; tg < t_hi; ++tg) {
+    const f4 x = gload(A.x, tg);
+    ts(SX, tg, lane, x);
+    gstore(A.x_next, tg, x);             // x_next doubles as the current-state copy a rejected chain resumes from
+  }
+  const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
+  const float heps = 0.5f * eps;
+  const bool need_p = A.p_out != nullptr || A.x_next != nullptr || A.u != nullptr || (A.rng_flags & L2HMC_RNG_U) != 0;
+  __syncthreads();
+  // time-embedding table TB[net][row s][unit row i] (as in traj_kernel)
+  for (int idx = tid; idx < 2 * A.T * 16; idx += NTHR) {
+    const int net = idx / (A.T * 16), srow = (idx / 16) % A.T, i = idx & 15;
+    const float* tf = (net == 0 ? wx : wv) + (2 * NT * 64) * 4;
+    const float ct = smem[A.o_trig + 2 * srow], st = smem[A.o_trig + 2 * srow + 1];
+    smem[A.o_tb + idx] = fmaf(tf[i * 4], ct, fmaf(tf[(16 + i) * 4], st, tf[(32 + i) * 4]));
+  }
+  __syncthreads();
+
+  const f4 Z = splat(0.f), O = splat(1.f);
+  const f4 w2x = lds4(wx + ((2 * NT + 1) * 64 + lane) * 4), w2v = lds4(wv + ((2 * NT + 1) * 64 + lane) * 4);
+  int pb = 0;
+  // Weight fragments stream from L2 (several hundred cycles away) and a runtime tile loop is not
+  // software-pipelined by the compiler: every pass fetches the fragments of tile tg + 1 while it works on tg.
+  auto frag = [&](const float* wn, int grp) { return lds4(wn + (grp * 64 + lane) * 4); };
+  struct HeadW { f4 Ws, Wt, Wq, es, eq; };
+  auto head_frag = [&](const float* wn, int tg) {
+    const float* sc = wn + net_groups(NT) * 256;
+    HeadW hw;
+    hw.Ws = frag(wn, 2 * NT + 2 + 3 * tg + 0);
+    hw.Wt = frag(wn, 2 * NT + 2 + 3 * tg + 1);
+    hw.Wq = frag(wn, 2 * NT + 2 + 3 * tg + 2);
+    hw.es = lds4(sc + 16 * tg + 4 * q);
+    hw.eq = lds4(sc + 16 * NT + 16 * tg + 4 * q);
+    return hw;
+  };
+  // layer-1 contribution of one tile: acc += W^T z
+  auto l1 = [&](f4 acc, f4 W, f4 z) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = MFMA16(W[r], z[r], acc);
+    return acc;
+  };
+  // hidden activations after layer 2 from the exchanged layer-1 sum
+  auto layer2 = [&](f4 w2, f4 hpre, f4 tb) {
+    const f4 h = relu4(hpre + tb);
+    f4 acc = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) acc = MFMA16(w2[r], h[r], acc);
+    return relu4(acc);
+  };
+  // heads of tile tg: ES = 2^aS, aS = kS e^{lam_s} tanh(zs), T, EQ = 2^{kQ e^{lam_q} tanh(zq)}
+  auto heads = [&](const HeadW& hw, f4 h, float kS, float kQ, f4& ES, f4& aS, f4& Tt, f4& EQ) {
+    f4 zs = Z, zt = Z, zq = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) {
+      zs = MFMA16(hw.Ws[r], h[r], zs);
+      zq = MFMA16(hw.Wq[r], h[r], zq);
+      zt = MFMA16(hw.Wt[r], h[r], zt);
+    }
+    aS = ctanh4(hw.es * kS, zs);
+    ES = exp2_4(aS);
+    Tt = zt;
+    EQ = exp2_4(ctanh4(hw.eq * kQ, zq));
+  };
+  auto nxt = [&](int tg) { return tg + 1 < t_hi ? tg + 1 : tg; };      // tile whose fragments to prefetch
+
+  // grad U at the start state, and the VNet layer-1 partial there (shared by consecutive half-updates)
+  float U_start = 0.f;
+  f4 pv[1];
+  auto refresh = [&]() {                  // SG, U_start, pv from SX
+    U_start = 0.f;
+    f4 a0 = Z, a1 = Z;
+    f4 Wa = frag(wv, t_lo), Wb = frag(wv, NT + t_lo);
+    for (int tg = t_lo; tg < t_hi; ++tg) {
+      const f4 Wa_n = frag(wv, nxt(tg)), Wb_n = frag(wv, NT + nxt(tg));
+      const f4 x = tl(SX, tg, lane);
+      const f4 g = wide_grad<EK>(A, smem, tg, q, x, U_start);
+      ts(SG, tg, lane, g);
+      a0 = l1(a0, Wa, x);
+      a1 = l1(a1, Wb, g);
+      Wa = Wa_n; Wb = Wb_n;
+    }
+    pv[0] = a0 + a1;
+    xchg<NW, 1>(pv, A, smem, w, lane, pb);
+  };
+  refresh();
+
+  const long long gchain = A.chain_off + chain;
+  const bool rng_v = (A.rng_flags & L2HMC_RNG_V) != 0, rng_d = (A.rng_flags & L2HMC_RNG_DIR) != 0;
+  const bool rng_u = (A.rng_flags & L2HMC_RNG_U) != 0;
+  const bool have_u = A.u != nullptr || rng_u;
+  const float LOG2E = 1.4426950408889634f;
+
+  for (int m = 0; m < A.M; ++m) {
+    const long long moff = (long long)m * A.N;
+    const unsigned long long prop = A.rng_prop0 + (unsigned long long)m;
+    bool fwd = (A.dir != nullptr && !rng_d) ? (live ? A.dir[moff + chain] != 0 : true) : (A.dir_all != 0);
+    float u_m = (A.u != nullptr && !rng_u && live) ? A.u[moff + chain] : 0.f;
+    if (rng_d || rng_u) {
+      bool fr;
+      float ur;
+      philox_dir_u(A.rng_seed, gchain, prop, fr, ur);
+      if (rng_d) fwd = fr;
+      if (rng_u) u_m = ur;
+    }
+    float red[5];                          // U0, K0, U1, K1, logdet (per-lane partial sums)
+    red[0] = U_start;
+    red[1] = 0.f;
+    for (int tg = t_lo; tg < t_hi; ++tg) {
+      f4 v;
+      if (rng_v) {
+        const int dim0 = 16 * tg + 4 * q;
+        const f4 n = philox_normal4(A.rng_seed, gchain, (unsigned)(dim0 >> 2), prop);
+        v = f4{dim0 + 0 < A.d ? n.x : 0.f, dim0 + 1 < A.d ? n.y : 0.f, dim0 + 2 < A.d ? n.z : 0.f,
+               dim0 + 3 < A.d ? n.w : 0.f};
+      } else {
+        v = gload(A.v + moff * A.d, tg);
+      }
+      ts(SV, tg, lane, v);
+      red[1] += 0.5f * hsum(v * v);
+    }
+    red[2] = U_start;                      // (n_steps == 0: the end point is the start point)
+    float ld = 0.f;
+    const float sgn = fwd ? 1.f : -1.f;
+    const float kSx = sgn * eps * LOG2E, kSv = sgn * heps * LOG2E, kQ = eps * LOG2E;
+
+    for (int it = 0; it < A.n_steps; ++it) {
+      const int sf = A.step_begin + it, s = fwd ? sf : (A.T - 1 - sf);
+      const f4 tbx = lds4(smem + A.o_tb + s * 16 + 4 * q), tbv = lds4(smem + A.o_tb + (A.T + s) * 16 + 4 * q);
+      const float* mrow = smem + A.o_mask + s * DP;
+      auto k1_of = [&](int tg) {            // forward keeps m first, backward keeps 1 - m first
+        const f4 mk = lds4(mrow + 16 * tg + 4 * q);
+        return sel4(fwd, mk, O - mk);
+      };
+      // ---- momentum half-update #1 (dynamics.py:118-125 / :162-170) + the XNet layer-1 sums of (v_h, k1 x)
+      f4 h = layer2(w2v, pv[0], tbv);
+      f4 pa = Z, pq = Z;
+      HeadW hw = head_frag(wv, t_lo);
+      f4 Wa = frag(wx, t_lo), Wb = frag(wx, NT + t_lo);
+      for (int tg = t_lo; tg < t_hi; ++tg) {
+        const HeadW hw_n = head_frag(wv, nxt(tg));
+        const f4 Wa_n = frag(wx, nxt(tg)), Wb_n = frag(wx, NT + nxt(tg));
+        f4 ES, aS, Tt, EQ;
+        heads(hw, h, kSv, kQ, ES, aS, Tt, EQ);
+        const f4 vh = v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ld);
+        ts(SV, tg, lane, vh);
+        pa = l1(pa, Wa, vh);
+        pq = l1(pq, Wb, k1_of(tg) * tl(SX, tg, lane));
+        hw = hw_n; Wa = Wa_n; Wb = Wb_n;
+      }
+      f4 px[1] = {pa + pq};
+      xchg<NW, 1>(px, A, smem, w, lane, pb);
+      // ---- first masked position update (:127-137 / :172-182) + the layer-1 sum of k2 y
+      h = layer2(w2x, px[0], tbx);
+      pq = Z;
+      hw = head_frag(wx, t_lo);
+      Wb = frag(wx, NT + t_lo);
+      for (int tg = t_lo; tg < t_hi; ++tg) {
+        const HeadW hw_n = head_frag(wx, nxt(tg));
+        const f4 Wb_n = frag(wx, NT + nxt(tg));
+        f4 ES, aS, Tt, EQ;
+        heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
+        const f4 k1 = k1_of(tg);
+        const f4 y = x_half(tl(SX, tg, lane), k1, tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ld);
+        ts(SX, tg, lane, y);
+        pq = l1(pq, Wb, (O - k1) * y);
+        hw = hw_n; Wb = Wb_n;
+      }
+      f4 py[1] = {pa + pq};
+      xchg<NW, 1>(py, A, smem, w, lane, pb);
+      // ---- second masked position update (:139-145 / :184-190), grad U at x', VNet layer-1 sums there
+      h = layer2(w2x, py[0], tbx);
+      const bool lastU = need_p && it == A.n_steps - 1;
+      float Uend = 0.f;
+      f4 a0 = Z, a1 = Z;
+      hw = head_frag(wx, t_lo);
+      Wa = frag(wv, t_lo);
+      Wb = frag(wv, NT + t_lo);
+      for (int tg = t_lo; tg < t_hi; ++tg) {
+        const HeadW hw_n = head_frag(wx, nxt(tg));
+        const f4 Wa_n = frag(wv, nxt(tg)), Wb_n = frag(wv, NT + nxt(tg));
+        f4 ES, aS, Tt, EQ;
+        heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
+        const f4 xn = x_half(tl(SX, tg, lane), O - k1_of(tg), tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ld);
+        ts(SX, tg, lane, xn);
+        const f4 g = wide_grad<EK>(A, smem, tg, q, xn, Uend);
+        ts(SG, tg, lane, g);
+        a0 = l1(a0, Wa, xn);
+        a1 = l1(a1, Wb, g);
+        hw = hw_n; Wa = Wa_n; Wb = Wb_n;
+      }
+      if (lastU) red[2] = Uend;
+      pv[0] = a0 + a1;
+      xchg<NW, 1>(pv, A, smem, w, lane, pb);
+      // ---- momentum half-update #2 (:147-153 / :192-199)
+      h = layer2(w2v, pv[0], tbv);
+      hw = head_frag(wv, t_lo);
+      for (int tg = t_lo; tg < t_hi; ++tg) {
+        const HeadW hw_n = head_frag(wv, nxt(tg));
+        f4 ES, aS, Tt, EQ;
+        heads(hw, h, kSv, kQ, ES, aS, Tt, EQ);
+        ts(SV, tg, lane, v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ld));
+        hw = hw_n;
+      }
+    }
+    ld *= 0.6931471805599453f;             // the log-det was accumulated in log2 units
+
+    // ---- per-proposal epilogue: proposal, log-det, accept probability, MH select -------------------------
+    const bool last = m == A.M - 1;
+    red[3] = 0.f;
+    for (int tg = t_lo; tg < t_hi; ++tg) {
+      const f4 v = tl(SV, tg, lane);
+      red[3] += 0.5f * hsum(v * v);
+      if (last) {
+        gstore(A.x_out, tg, tl(SX, tg, lane));
+        gstore(A.v_out, tg, v);
+      }
+    }
+    red[4] = ld;
+    const float U_end = red[2];
+    chain_allreduce<NW, 5>(red, smem + A.o_red, w, lane);
+    const bool writer = live && w == 0 && lane < 16;
+    if (A.logjac_out != nullptr && writer) A.logjac_out[moff + chain] = red[4];
+    bool resumed = false;                  // some chain of this tile went back to its start point
+    if (need_p) {
+      const float val = (red[0] + red[1]) - (red[2] + red[3]) + red[4];       // dynamics.py:302-309
+      const float p = accept_prob(val);
+      if (A.p_out != nullptr && writer) A.p_out[moff + chain] = p;
+      if (have_u) {
+        const bool acc = live && (p - u_m) >= 0.f;                             // sampler.py:53-55
+        for (int tg = t_lo; tg < t_hi; ++tg) {
+          const f4 xs = sel4(acc, tl(SX, tg, lane), gload(A.x_next != nullptr ? A.x_next : A.x, tg));
+          ts(SX, tg, lane, xs);
+          gstore(A.x_next, tg, xs);
+          if (A.x_hist != nullptr) gstore(A.x_hist + moff * A.d, tg, xs);
+        }
+        resumed = true;
+        U_start = acc ? U_end : U_start;
+      } else {
+        U_start = U_end;
+      }
+    } else {
+      U_start = U_end;
+    }
+    if (!resumed && A.x_hist != nullptr)
+      for (int tg = t_lo; tg < t_hi; ++tg) gstore(A.x_hist + moff * A.d, tg, tl(SX, tg, lane));
+    // the next proposal starts from SX: grad U, U and the VNet partial there (a tile with any rejected
+    // chain must recompute them; doing it always keeps the waves in step)
+    if (!last) refresh();
+  }
+  if (!(need_p && have_u))                 // no MH step: x_next (if asked for) is the end point
+    for (int tg = t_lo; tg < t_hi; ++tg) gstore(A.x_next, tg, tl(SX, tg, lane));
+}
+
+// waves per workgroup of the wide kernel: 8 (two per SIMD hide the L2 latency of the streamed fragments) once
+// the state is so large that only one workgroup fits a CU, else 4 with two workgroups per CU
+int wide_waves(int NT) { return NT > 16 ? 8 : 4; }
+
+// shared-memory plan of the wide kernel (bytes); fills the offsets it uses
+long long plan_lds_wide(KArgs& k) {
+  const int NT = k.NT, DP = 16 * NT, NW = wide_waves(NT);
+  long long o = 0;
+  k.o_mask = (int)o; o += (long long)k.T * DP;
+  k.o_trig = (int)o; o += (2 * k.T + 3) / 4 * 4;
+  k.o_tb = (int)o; o += 2LL * k.T * 16;
+  k.o_P = (int)o; o += 2LL * NW * 256;
+  k.o_red = (int)o; o += (long long)NW * 16 * 8;
+  k.o_mu = (int)o; o += DP;
+  k.o_prec = (int)o; if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) o += DP;
+  k.o_logc = (int)o;
+  k.o_state = (int)o; o += 3LL * NT * 256;
+  return o * 4;
+}
+
+template <int EK, int KH, int NW>
+static int launch_wide_t(const KArgs& k, long long lds, hipStream_t s) {
+  auto kern = traj_wide_kernel<EK, KH, NW>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((k.N + 15) / 16)), dim3(64 * NW), (size_t)lds, s, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int launch_wide(const KArgs& k, int KH, long long lds, hipStream_t s) {
+  const bool diag = k.ekind == L2HMC_ENERGY_GAUSS_DIAG, w8 = wide_waves(k.NT) == 8;
+#define L2HMC_WIDE(EKv)                                                                      \
+  (KH == 3 ? (w8 ? launch_wide_t<EKv, 3, 8>(k, lds, s) : launch_wide_t<EKv, 3, 4>(k, lds, s)) \
+           : (w8 ? launch_wide_t<EKv, 4, 8>(k, lds, s) : launch_wide_t<EKv, 4, 4>(k, lds, s)))
+  return diag ? L2HMC_WIDE(L2HMC_ENERGY_GAUSS_DIAG) : L2HMC_WIDE(L2HMC_ENERGY_ROUGHWELL);
+#undef L2HMC_WIDE
+}
+
+}  // namespace l2hmc

@@ -283,10 +283,12 @@ def test_hmc_ess_on_scg_reproduces_notebook_number():
 @pytest.mark.parametrize("kind,d,variant", [("roughwell_easy", 512, 0), ("roughwell_easy", 200, 0),
                                             ("gauss_diag", 300, 0), ("gauss_dense", 150, 0),
                                             ("gauss_dense", 40, 1), ("gauss_dense", 40, 4),
-                                            ("gauss_diag", 64, 1), ("gauss_diag", 17, 1)])
+                                            ("gauss_diag", 64, 1), ("gauss_diag", 17, 1),
+                                            ("roughwell_easy", 200, 8), ("gauss_diag", 64, 8), ("gauss_diag", 500, 8)])
 def test_wide_dims_against_oracle(kind, d, variant):
     """BASELINE.json config 4 range (d up to 512) and the geometries the fixtures do not reach:
-    LDS-staged weights (DT <= 2) and global-memory weights (DT >= 4), every NW/DT kernel."""
+    LDS-staged weights (DT <= 2) and global-memory weights (DT >= 4), every NW/DT kernel, and the
+    LDS-resident-state kernel (auto above d = 256; `variant` 8 forces it)."""
     from l2hmc_amd import propose
     from tests.helpers import synthetic_case
     g = synthetic_case(kind, d, N=48, seed=d, head_std=0.3 if d < 100 else 0.1)
@@ -597,3 +599,43 @@ def test_native_adam_matches_tf1_formula():
         rv = b2 * rv + (1 - b2) * g64 * g64
         rp = rp - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * rm / (np.sqrt(rv) + eps)
     assert np.abs(to_np(p) - rp).max() < 1e-6
+
+
+@pytest.mark.parametrize("kind,d", [("gauss_diag", 300), ("roughwell_easy", 512)])
+def test_wide_sampler_loop_matches_single_launches_and_philox(kind, d):
+    """The LDS-resident-state kernel (d > 128) in its sampler-loop form: M chained proposals in one
+    launch == M single-proposal launches bit for bit (injected draws: exercises the reject path, where a
+    chain resumes from the current-state copy in x_next), the same with the in-kernel Philox draws, and
+    == the oracle loop where accept decisions are not fp32 ties."""
+    import torch
+    from l2hmc_amd import propose, sample_chain
+    from l2hmc_amd.sampler import philox_draws
+    from tests.helpers import synthetic_case
+    g = synthetic_case(kind, d, N=40, seed=d + 1, head_std=0.05, eps=0.02)
+    dyn, od = hip_dynamics(g), oracle_dynamics(g)
+    M, N = 4, 40
+    rng = np.random.RandomState(5)
+    vb = rng.randn(M, N, d).astype(np.float32)
+    db = rng.randint(0, 2, size=(M, N)).astype(np.uint8)
+    ub = rng.rand(M, N).astype(np.float32)
+    xf, p, xh = sample_chain(to_dev(g["x"]), dyn, M, direction=to_dev(db), v=to_dev(vb), u=to_dev(ub), record=True)
+    xs = to_dev(g["x"])
+    for m in range(M):
+        _, _, pm, outs = propose(xs, dyn, do_mh_step=True, v=to_dev(vb[m]), u=to_dev(ub[m]), direction=to_dev(db[m]))
+        assert torch.equal(pm, p[m]) and torch.equal(outs[0], xh[m]), (kind, m)
+        xs = outs[0]
+    assert torch.equal(xs, xf)
+    acc = to_np(p) >= ub
+    assert 0.05 < acc.mean() < 0.95, acc.mean()          # both the accept and the reject path ran
+    xo, ok = g["x"], np.ones(N, dtype=bool)
+    with np.errstate(all="ignore"):
+        for m in range(M):
+            _, _, po, xo = O.propose(xo, od, vb[m], vb[m], db[m], ub[m], both_directions=False)
+            ok &= np.abs(po - ub[m]) > 1e-3
+            assert abs_err(to_np(p[m])[ok], po[ok]) < 5 * P_TOL, (kind, m)
+    assert ok.mean() > 0.7 and rel_err(to_np(xf)[ok], xo[ok]) < 5 * TRAJ_TOL
+    # in-kernel Philox == the same draws written out by l2hmc_rng_fill and injected
+    xr, pr, _ = sample_chain(to_dev(g["x"]), dyn, M, seed=99)
+    v, dr, u = philox_draws(99, N, d, M)
+    xi, pi, _ = sample_chain(to_dev(g["x"]), dyn, M, v=v, u=u, direction=dr)
+    assert torch.equal(pr, pi) and torch.equal(xr, xi)

@@ -30,6 +30,7 @@ def run(name, dist, d, n, T, grad_flops, x0, M, reps):
     np.random.seed(0)
     dyn = Dynamics(d, dist.get_energy_function(), T=T, eps=0.1,
                    net_factory=layers.stq_network(10, head_factor=0.03), device=dev)
+    dyn.variant = int(os.environ.get("L2HMC_VARIANT", "0"))      # kernel geometry override (see l2hmc.h)
     x = torch.as_tensor(x0, dtype=torch.float32, device=dev)
     for _ in range(2):
         sample_chain(x, dyn, M, seed=1)
