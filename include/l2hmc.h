@@ -104,7 +104,9 @@ typedef struct L2hmcTrajectoryArgs {
   float* p_out;             /* (N) accept prob, dynamics.py:302-309                           */
   float* x_next;            /* (N, d) MH-selected state, sampler.py:53-55 (needs u and p)     */
   /* ---- tuning ---------------------------------------------------------------------------- */
-  int32_t variant;          /* 0 = auto; else waves per 16-chain tile (1 or 4)                */
+  int32_t variant;          /* 0 = auto; 1 / 4 = waves per 16-chain tile of the register-resident
+                             *   kernel; 8 = the LDS-resident-state kernel (auto for d > 128 with a
+                             *   diagonal-Gaussian or Rough-Well target)                               */
   /* ---- persistent sampler loop (the notebook's per-MH-step sess.run loop, nb raw 288-298) -- */
   int32_t n_proposals;      /* M >= 1 proposals per launch (0 = 1).  With M > 1: v is (M,N,d),  */
                             /* direction (M,N), u (M,N) [required], p_out / logjac_out (M,N);   */
