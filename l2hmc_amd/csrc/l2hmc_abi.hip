@@ -281,7 +281,11 @@ bool pick_geometry(int d, long long N, int variant, int& DT, int& NW) {
   const int NT = tiles_of(d);
   if (NT <= 1) { DT = 1; NW = 1; return variant == 0 || variant == 1; }
   if (NT <= 4) {
-    const bool want4 = variant == 4 || (variant == 0 && N <= 16LL * 256 * 16);
+    // measured (tools/bench_configs.py, 16-chain tiles on 256 CUs): with 3-4 dim-tiles the 4-wave tile wins at
+    // every chain count (1.7e9 vs 1.1e9 steps/s at d = 50..64); with 2 dim-tiles half of its waves idle, so it
+    // only pays while there are fewer tiles than wave slots (N < 8192; 2x slower than one wave per tile above).
+    // (Two waves x two tiles was tried for 3-4 dim-tiles: never faster than four waves x one tile.)
+    const bool want4 = variant == 4 || (variant == 0 && (NT >= 3 || N < 8192));
     if (want4) { DT = 1; NW = 4; } else { DT = NT <= 2 ? 2 : 4; NW = 1; }
     return variant == 0 || variant == 1 || variant == 4;
   }
