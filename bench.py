@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--rng", choices=["philox", "bank"], default="philox",
                     help="philox: momenta / direction / accept uniforms drawn in-kernel (counter-based, "
                          "keyed by global chain index); bank: pre-generated draws read from HBM")
-    ap.add_argument("--preheat", type=int, default=200,
+    ap.add_argument("--preheat", type=int, default=1000,
                     help="untimed proposals run BEFORE the --warmup steps so that the GPU clocks have ramped "
                          "whatever --warmup is (a 20-proposal warm-up lasts 0.6 ms: the timed steps would then "
                          "run 7 %% slower on cold clocks); reported in config.preheat_proposals")
