@@ -629,11 +629,12 @@ __device__ __forceinline__ void net_tail(const TailW<DT>& tw, f4 hpre, f4 tb, fl
 // One momentum half-update.  forward (dynamics.py:121-125,149-153):
 //   v' = v e^{eps S / 2} + (eps/2)(T - e^{eps Q} grad);   backward (:164-170,194-199):
 //   v' = (v - (eps/2)(T - e^{eps Q} grad)) e^{-eps S / 2}.
-// ES = e^{+-eps S / 2}, EQ = e^{eps Q}, aS = log2(ES); `ld2` accumulates log2|det|.
+// ES = e^{+-eps S / 2}, EQ = e^{eps Q}, aS = log2(ES); `ld2` accumulates log2|det| as a 4-wide partial
+// sum (one packed add per update; summed across its components once per trajectory).
 __device__ __forceinline__ f4 v_half(f4 vin, f4 g, f4 ES, f4 aS, f4 T, f4 EQ, float heps, bool fwd,
-                                     float& ld2) {
+                                     f4& ld2) {
   const f4 cc = heps * (T - EQ * g);
-  ld2 += hsum(aS);
+  ld2 += aS;
   return sel4(fwd, vin * ES + cc, (vin - cc) * ES);
 }
 
@@ -641,11 +642,11 @@ __device__ __forceinline__ f4 v_half(f4 vin, f4 g, f4 ES, f4 aS, f4 T, f4 EQ, fl
 //   z' = kp z + (1-kp)(z e^{eps S} + eps (e^{eps Q} v_h + T));   backward (:176-190):
 //   z' = kp z + (1-kp) e^{-eps S} (z - eps (e^{eps Q} v_h + T)).
 __device__ __forceinline__ f4 x_half(f4 zin, f4 kp, f4 vh, f4 ES, f4 aS, f4 T, f4 EQ, float eps,
-                                     bool fwd, float& ld2) {
+                                     bool fwd, f4& ld2) {
   const f4 up = splat(1.f) - kp;
   const f4 tr = eps * (EQ * vh + T);
   const f4 nw = sel4(fwd, zin * ES + tr, ES * (zin - tr));
-  ld2 += hsum(up * aS);
+  ld2 += up * aS;
   return kp * zin + up * nw;
 }
 
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
 #pragma unroll
   for (int t = 0; t < DT; ++t) red[1] += 0.5f * hsum(v[t] * v[t]);
   red[2] = 0.f;
-  float ld = 0.f;
+  f4 ldv = splat(0.f);
 
   // folded constants: sgn eps log2(e) scales S of XNet, sgn (eps/2) log2(e) S of VNet, eps log2(e) Q
   const float LOG2E = 1.4426950408889634f;
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
       PT_MARK(1);  // step head
       // ---- momentum half-update #1: VNet([x, grad U(x), t])  (dynamics.py:118-125 / :162-170)
       net_tail<DT, KH>(tw, pv[0], tbv, kSv, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
-        vh[t] = v_half(v[t], g[t], ES, aS, T, EQ, heps, fwd, ld);
+        vh[t] = v_half(v[t], g[t], ES, aS, T, EQ, heps, fwd, ldv);
       });
       PT_MARK(2);  // VNet tail #1
 
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
       xchg<NW, 1>(px, A, smem, w, lane, pb);
       PT_MARK(4);  // exchange
       net_tail<DT, KH>(tw, px[0], tbx, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
-        y[t] = x_half(x[t], k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ld);
+        y[t] = x_half(x[t], k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ldv);
       });
       PT_MARK(5);  // XNet tail #1
 #pragma unroll
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
       xchg<NW, 1>(py, A, smem, w, lane, pb);
       PT_MARK(7);  // exchange
       net_tail<DT, KH>(tw, py[0], tbx, kSx, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
-        x[t] = x_half(y[t], O - k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ld);
+        x[t] = x_half(y[t], O - k1[t], vh[t], ES, aS, T, EQ, eps, fwd, ldv);
       });
       PT_MARK(8);  // XNet tail #2
 
@@ -921,27 +922,27 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
       xchg<NW, 1>(pv, A, smem, w, lane, pb);
       PT_MARK(10); // exchange
       net_tail<DT, KH>(tw, pv[0], tbv, kSv, kQ, [&](int t, f4 ES, f4 aS, f4 T, f4 EQ) {
-        v[t] = v_half(vh[t], g[t], ES, aS, T, EQ, heps, fwd, ld);
+        v[t] = v_half(vh[t], g[t], ES, aS, T, EQ, heps, fwd, ldv);
       });
       PT_MARK(11); // VNet tail #2
     } else {
       // HMC mode: S = T = Q = 0 (dynamics.py:73-76)
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        vh[t] = v_half(v[t], g[t], O, Z, Z, O, heps, fwd, ld);
-        y[t] = x_half(x[t], k1[t], vh[t], O, Z, Z, O, eps, fwd, ld);
-        x[t] = x_half(y[t], O - k1[t], vh[t], O, Z, Z, O, eps, fwd, ld);
+        vh[t] = v_half(v[t], g[t], O, Z, Z, O, heps, fwd, ldv);
+        y[t] = x_half(x[t], k1[t], vh[t], O, Z, Z, O, eps, fwd, ldv);
+        x[t] = x_half(y[t], O - k1[t], vh[t], O, Z, Z, O, eps, fwd, ldv);
       }
       grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1, &er);
 #pragma unroll
-      for (int t = 0; t < DT; ++t) v[t] = v_half(vh[t], g[t], O, Z, Z, O, heps, fwd, ld);
+      for (int t = 0; t < DT; ++t) v[t] = v_half(vh[t], g[t], O, Z, Z, O, heps, fwd, ldv);
     }
     tbx = tbxn;
     tbv = tbvn;
 #pragma unroll
     for (int t = 0; t < DT; ++t) k1[t] = k1n[t];
   }
-  ld *= 0.6931471805599453f;   // the log-det was accumulated in log2 units
+  const float ld = hsum(ldv) * 0.6931471805599453f;   // the log-det was accumulated in log2 units
 
   // ---- per-proposal epilogue: proposal, log-det, accept probability, MH select ---------------
   const bool last = m == A.M - 1;

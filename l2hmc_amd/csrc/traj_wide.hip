@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       red[1] += 0.5f * hsum(v * v);
     }
     red[2] = U_start;                      // (n_steps == 0: the end point is the start point)
-    float ld = 0.f;
+    f4 ldv = splat(0.f);
     const float sgn = fwd ? 1.f : -1.f;
     const float kSx = sgn * eps * LOG2E, kSv = sgn * heps * LOG2E, kQ = eps * LOG2E;
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
         const f4 Wa_n = frag(wx, nxt(tg)), Wb_n = frag(wx, NT + nxt(tg));
         f4 ES, aS, Tt, EQ;
         heads(hw, h, kSv, kQ, ES, aS, Tt, EQ);
-        const f4 vh = v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ld);
+        const f4 vh = v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ldv);
         ts(SV, tg, lane, vh);
         pa = l1(pa, Wa, vh);
         pq = l1(pq, Wb, k1_of(tg) * tl(SX, tg, lane));
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
         f4 ES, aS, Tt, EQ;
         heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
         const f4 k1 = k1_of(tg);
-        const f4 y = x_half(tl(SX, tg, lane), k1, tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ld);
+        const f4 y = x_half(tl(SX, tg, lane), k1, tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ldv);
         ts(SX, tg, lane, y);
         pq = l1(pq, Wb, (O - k1) * y);
         hw = hw_n; Wb = Wb_n;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
         const f4 Wa_n = frag(wv, nxt(tg)), Wb_n = frag(wv, NT + nxt(tg));
         f4 ES, aS, Tt, EQ;
         heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
-        const f4 xn = x_half(tl(SX, tg, lane), O - k1_of(tg), tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ld);
+        const f4 xn = x_half(tl(SX, tg, lane), O - k1_of(tg), tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ldv);
         ts(SX, tg, lane, xn);
         const f4 g = wide_grad<EK>(A, smem, tg, q, xn, Uend);
         ts(SG, tg, lane, g);
@@ -298,11 +298,11 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
         const HeadW hw_n = head_frag(wv, nxt(tg));
         f4 ES, aS, Tt, EQ;
         heads(hw, h, kSv, kQ, ES, aS, Tt, EQ);
-        ts(SV, tg, lane, v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ld));
+        ts(SV, tg, lane, v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ldv));
         hw = hw_n;
       }
     }
-    ld *= 0.6931471805599453f;             // the log-det was accumulated in log2 units
+    const float ld = hsum(ldv) * 0.6931471805599453f;      // the log-det was accumulated in log2 units
 
     // ---- per-proposal epilogue: proposal, log-det, accept probability, MH select -------------------------
     const bool last = m == A.M - 1;
