@@ -341,7 +341,7 @@ __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, 
         }
         const f4 dx = x[t] - mu;
         g[t] = s * dx;
-        U += 0.5f * hsum(dx * g[t]);
+        U += 0.5f * hsum(dx * g[t]);      // (always: a wave-uniform `if (wantU)` here costs more than it saves)
       }
     }
   } else if constexpr (EK == L2HMC_ENERGY_GAUSS_DENSE) {

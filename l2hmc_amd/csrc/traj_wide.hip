@@ -20,27 +20,30 @@ __device__ __forceinline__ void ts(float* S, int tg, int lane, f4 v) { *reinterp
 
 // grad U of one tile and this lane's share of U (distributions.py:31-32,41-57 diagonal case; :84-97)
 template <int EK>
-__device__ __forceinline__ f4 wide_grad(const KArgs& A, const float* smem, int tg, int q, f4 x, float& U) {
+__device__ __forceinline__ f4 wide_grad(const KArgs& A, const float* smem, int tg, int q, f4 x, float& U,
+                                        bool wantU) {
   f4 g;
-  float u;
+  float u = 0.f;
   if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
     const f4 mu = lds4(smem + A.o_mu + 16 * tg + 4 * q), s = lds4(smem + A.o_prec + 16 * tg + 4 * q);
     const f4 dx = x - mu;
     g = s * dx;
-    u = 0.5f * hsum(dx * g);
+    if (wantU) u = 0.5f * hsum(dx * g);
   } else {
     const float eta = A.eta, den = A.easy ? eta : eta * eta, scale = eta / den;
     const f4 arg = x / den;
     g = x - scale * f4{sinf(arg.x), sinf(arg.y), sinf(arg.z), sinf(arg.w)};
-    const int dim0 = 16 * tg + 4 * q;      // padded dims hold x = 0 and would add eta * cos(0): mask them out
-    const f4 cs = f4{cosf(arg.x), cosf(arg.y), cosf(arg.z), cosf(arg.w)};
-    const f4 lv = f4{dim0 < A.d ? 1.f : 0.f, dim0 + 1 < A.d ? 1.f : 0.f, dim0 + 2 < A.d ? 1.f : 0.f,
-                     dim0 + 3 < A.d ? 1.f : 0.f};
-    u = 0.5f * hsum(x * x) + eta * hsum(lv * cs);
+    if (wantU) {                           // (wave-uniform: only the end points of a trajectory need U)
+      const int dim0 = 16 * tg + 4 * q;    // padded dims hold x = 0 and would add eta * cos(0): mask them out
+      const f4 cs = f4{cosf(arg.x), cosf(arg.y), cosf(arg.z), cosf(arg.w)};
+      const f4 lv = f4{dim0 < A.d ? 1.f : 0.f, dim0 + 1 < A.d ? 1.f : 0.f, dim0 + 2 < A.d ? 1.f : 0.f,
+                       dim0 + 3 < A.d ? 1.f : 0.f};
+      u = 0.5f * hsum(x * x) + eta * hsum(lv * cs);
+    }
   }
   if (A.beta != 1.f) {                     // AIS bridge from N(0, I) (utils/ais.py:46-47)
     g = x * (1.f - A.beta) + g * A.beta;
-    u = (1.f - A.beta) * 0.5f * hsum(x * x) + A.beta * u;
+    if (wantU) u = (1.f - A.beta) * 0.5f * hsum(x * x) + A.beta * u;
   }
   if (A.temperature != 1.f) {
     g = g / A.temperature;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
     for (int tg = t_lo; tg < t_hi; ++tg) {
       const f4 Wa_n = frag(wv, nxt(tg)), Wb_n = frag(wv, NT + nxt(tg));
       const f4 x = tl(SX, tg, lane);
-      const f4 g = wide_grad<EK>(A, smem, tg, q, x, U_start);
+      const f4 g = wide_grad<EK>(A, smem, tg, q, x, U_start, true);
       ts(SG, tg, lane, g);
       a0 = l1(a0, Wa, x);
       a1 = l1(a1, Wb, g);
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
         heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
         const f4 xn = x_half(tl(SX, tg, lane), O - k1_of(tg), tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ldv);
         ts(SX, tg, lane, xn);
-        const f4 g = wide_grad<EK>(A, smem, tg, q, xn, Uend);
+        const f4 g = wide_grad<EK>(A, smem, tg, q, xn, Uend, lastU);
         ts(SG, tg, lane, g);
         a0 = l1(a0, Wa, xn);
         a1 = l1(a1, Wb, g);
