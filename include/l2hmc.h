@@ -225,7 +225,9 @@ int l2hmc_p_accept_energies(const float* U0, const float* v0, const float* U1, c
 /* Loss of SCGExperiment.ipynb raw lines 156-169 for ONE of its two proposals:
  *   v1_n = |x_n - Lx_n|^2 p_n + 1e-4;   term = scale * mean_n(1 / v1_n) - mean_n(v1_n) / scale
  * (the notebook adds the term of `propose(x)` and of `propose(z), z ~ N(0, I)`; call twice).
- * `grad` (l2hmc_train_grad_floats(d, H) floats) is ACCUMULATED (+=): the flat layout is
+ * `grad` (l2hmc_train_grad_floats(d, H) floats) is ACCUMULATED (+=) without atomics -- every workgroup
+ * writes its partial gradient to the workspace and a second tiny kernel adds them in block order, so the
+ * result is bitwise reproducible --: the flat layout is
  * [XNet | VNet | d/d eps], each net in the field order of L2hmcNet (W1, b1, ..., lam_q);
  * d/d alpha = eps * d/d eps (dynamics.py:50-58).  inv_n = 1 / (chains over ALL ranks) so that
  * per-rank gradients simply all-reduce(sum).  The nets are the RAW reference-layout weights
@@ -254,10 +256,10 @@ typedef struct L2hmcTrainArgs {
   float* p;                 /* (N) accept probability                                */
   float* v1;                /* (N) per-chain loss argument                           */
   float* grad;              /* flat gradient, accumulated                            */
-  float* workspace;         /* l2hmc_train_workspace_floats(N, d, T) floats          */
+  float* workspace;         /* l2hmc_train_workspace_floats(N, d, H, T) floats       */
 } L2hmcTrainArgs;
 
-int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t T);
+int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T);
 int64_t l2hmc_train_grad_floats(int32_t d, int32_t H);
 int l2hmc_train_propose_grad(const L2hmcTrainArgs* args, void* stream);
 

@@ -89,7 +89,7 @@ SYMBOLS = {
     "l2hmc_trajectory_split": (C.c_int, [C.POINTER(L2hmcSplitArgs), _fp]),
     "l2hmc_vae_energy": (C.c_int, [C.POINTER(L2hmcMlp3), _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp, C.c_float, _fp]),
     "l2hmc_p_accept_energies": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp]),
-    "l2hmc_train_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "l2hmc_train_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "l2hmc_train_grad_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_train_propose_grad": (C.c_int, [C.POINTER(L2hmcTrainArgs), _fp]),
     "l2hmc_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -12,8 +12,9 @@
 //     input adjoints            din(c, k)  = sum_i dout(c, i) W(k, i)       K = H or d
 //     weight gradients          dW(k, i)  += sum_c in(c, k) dout(c, i)      K = 16 chains
 // Bias / scale gradients are column sums over the 16 chains.  Gradients accumulate in an LDS
-// image of the flat parameter vector (each element owned by one lane per pass: no atomics) and
-// leave with one global atomicAdd per parameter per workgroup.  The forward trajectory checkpoints
+// image of the flat parameter vector (each element owned by one lane per pass: no atomics); every
+// workgroup writes its image to the workspace and a second tiny kernel adds them to the caller's
+// buffer in block order -- the gradient is bitwise reproducible.  The forward trajectory checkpoints
 // (x, v, v_half, y, x') per step to a caller workspace; the reverse sweep re-evaluates each net
 // right before back-propagating through it, so only ONE net's activations are resident.
 // Thread t of the 256 owns chain t & 15 and dims / hidden units (t >> 4) + 16 j in every elementwise
@@ -816,12 +817,34 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
 #undef EW_END
   TT_MARK(10);
   {
+    // d loss / d eps: wave sums combined in a fixed order (no atomics anywhere in this kernel: the
+    // gradient is bitwise reproducible from run to run)
     const float s = wave_sum(deps);
-    if (X.lane == 0) atomicAdd(Ge, s);
+    if (X.lane == 0) X.cs[CS_U1 * TC + X.wave] = s;
   }
   __syncthreads();
-  // flat gradient: [xnet (P) | vnet (P) | eps], accumulated (+=) into the caller's buffer
-  for (int i = tid; i < 2 * P + 1; i += TTHREADS) atomicAdd(&A.grad[i], Gx[i]);
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < TNW; ++w) s += X.cs[CS_U1 * TC + w];
+    Ge[0] = s;
+  }
+  __syncthreads();
+  // this workgroup's flat gradient [xnet (P) | vnet (P) | eps] -> its slot of the workspace; train_reduce_kernel
+  // adds the slots to the caller's buffer in block order
+  float* slot = A.ws + (long long)T * A.N * CKPT * d + (long long)blockIdx.x * (2 * P + 1);
+  for (int i = tid; i < 2 * P + 1; i += TTHREADS) slot[i] = Gx[i];
+}
+
+// Fixed-order sum of per-workgroup partial gradients: thread (i, c) adds the slots [c * chunk, (c + 1) * chunk) of
+// parameter i in slot order; `accumulate`: dst[i] += sum (the caller's buffer), else dst[c * n_grad + i] = sum.
+constexpr int kReduceChunk = 32;
+__global__ void train_reduce_kernel(const float* part, int n_slots, int n_grad, int chunk, float* dst, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (i >= n_grad) return;
+  const int b0 = c * chunk, b1 = (b0 + chunk < n_slots) ? b0 + chunk : n_slots;
+  float s = 0.f;
+  for (int b = b0; b < b1; ++b) s += part[(long long)b * n_grad + i];
+  if (accumulate) dst[i] += s; else dst[(long long)c * n_grad + i] = s;
 }
 
 }  // namespace l2hmc
@@ -840,9 +863,11 @@ void l2hmc_train_read_timers(unsigned long long* out) {
 }
 #endif
 
-int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t T) {
-  if (n_chains < 0 || d < 1 || T < 1) return fail(L2HMC_ERR_ARG, "l2hmc_train_workspace_floats: bad argument%s");
-  return (int64_t)T * n_chains * CKPT * d;
+int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T) {
+  if (n_chains < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "l2hmc_train_workspace_floats: bad argument%s");
+  // per-step checkpoints of every chain, then one flat partial gradient per 16-chain workgroup
+  const int64_t blocks = (n_chains + TC - 1) / TC, chunks = (blocks + kReduceChunk - 1) / kReduceChunk;
+  return (int64_t)T * n_chains * CKPT * d + (blocks + chunks) * (2LL * net_params(d, H) + 1);
 }
 
 int64_t l2hmc_train_grad_floats(int32_t d, int32_t H) {
@@ -893,6 +918,19 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
     if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   hipLaunchKernelGGL(train_kernel, dim3(blocks), dim3(TTHREADS), (size_t)lds, s, k);
+  const int n_grad = 2 * net_params(a->d, a->H) + 1;
+  float* part = a->workspace + (long long)a->T * a->n_chains * CKPT * a->d;
+  if (blocks <= (unsigned)kReduceChunk) {
+    hipLaunchKernelGGL(train_reduce_kernel, dim3((n_grad + 255) / 256, 1), dim3(256), 0, s, part, (int)blocks, n_grad,
+                       (int)blocks, a->grad, 1);
+  } else {                    // two levels, both in slot order: still deterministic
+    const int chunks = (int)((blocks + kReduceChunk - 1) / kReduceChunk);
+    float* part2 = part + (long long)blocks * n_grad;
+    hipLaunchKernelGGL(train_reduce_kernel, dim3((n_grad + 255) / 256, chunks), dim3(256), 0, s, part, (int)blocks,
+                       n_grad, kReduceChunk, part2, 0);
+    hipLaunchKernelGGL(train_reduce_kernel, dim3((n_grad + 255) / 256, 1), dim3(256), 0, s, part2, chunks, n_grad,
+                       chunks, a->grad, 1);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;

@@ -81,7 +81,7 @@ class Trainer(object):
         dyn = self.dyn
         N, d = start.shape
         L = _ffi.lib()
-        need = _ffi.check(L.l2hmc_train_workspace_floats(N, d, dyn.T))
+        need = _ffi.check(L.l2hmc_train_workspace_floats(N, d, dyn.H, dyn.T))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.float32, device=dyn.device)
         if out is None:

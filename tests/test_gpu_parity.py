@@ -639,3 +639,26 @@ def test_wide_sampler_loop_matches_single_launches_and_philox(kind, d):
     v, dr, u = philox_draws(99, N, d, M)
     xi, pi, _ = sample_chain(to_dev(g["x"]), dyn, M, v=v, u=u, direction=dr)
     assert torch.equal(pr, pi) and torch.equal(xr, xi)
+
+
+def test_training_is_bitwise_reproducible():
+    """No atomics in the gradient path: the same seed gives the same parameters bit for bit after 50
+    optimiser steps (4 workgroups per launch), run twice."""
+    import torch
+    from l2hmc_amd import Dynamics, distributions as D, layers
+    from l2hmc_amd.training import Trainer
+
+    def run():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
+        dyn = Dynamics(2, D.Gaussian(np.zeros(2), cov).get_energy_function(), T=10, eps=0.1,
+                       net_factory=layers.stq_network(10))
+        tr = Trainer(dyn, seed=3)
+        x = torch.as_tensor(np.random.RandomState(1).randn(32, 2), dtype=torch.float32, device="cuda")
+        for _ in range(50):
+            _, _, x, _ = tr.step(x)
+        return tr.theta.clone(), x.clone()
+    a, xa = run()
+    b, xb = run()
+    assert torch.equal(a, b) and torch.equal(xa, xb)
