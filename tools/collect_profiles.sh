@@ -31,7 +31,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
     --output-format csv -d $OUT/pmc_big2 -o c -- $BIG > /dev/null 2>&1
 python - <<PY > $OUT/pmc_summary.txt
 import csv, glob, collections
-print("4096-chain passes: ten dispatches of 25 chained proposals each (preheat 200, --steps 25 --warmup 25); pmc_big*: 262144 chains, two dispatches of 10 proposals")
+print("4096-chain passes: ten dispatches of 25 chained proposals each (preheat 1000, --steps 25 --warmup 25); pmc_big*: 262144 chains, two dispatches of 10 proposals")
 for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_big", "pmc_big2"):
     fs = glob.glob("$OUT/%s/*counter_collection.csv" % d)
     if not fs:
