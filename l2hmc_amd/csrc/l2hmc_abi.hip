@@ -1,7 +1,7 @@
 // libl2hmc_hip.so -- C ABI (include/l2hmc.h) of the L2HMC leapfrog hot path for MI355X:
 // argument validation, LDS planning, geometry selection, weight packing kernels.
 // The fused kernels live in l2hmc_kernels.hpp, instantiated per energy kind in traj_ek*.hip.
-#include "l2hmc_kernels.hpp"
+#include "traj_fast.hpp"
 
 namespace l2hmc {
 
@@ -237,6 +237,35 @@ long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW, int DT)
   return o * 4;
 }
 
+// LDS plan of traj_fast_kernel (DT <= 2): scaled tail fragments, constant tables, schedule records, then
+// the exchange / reduction / energy areas as in plan_lds.
+long long plan_lds_fast(KArgs& k, int NW, int DT) {
+  const int NT = k.NT, DP = 16 * NT, NTp = NW * DT;
+  long long o = 0;
+  k.o_fw = (int)o;
+  o += 2LL * fast_fw_net(NTp);
+  k.o_fc = (int)o;
+  o += 2LL * fast_fc_net(NTp);
+  k.o_rec = (int)o;
+  o += 2LL * fast_rec_dir(NTp, k.T);
+  k.o_P = (int)o;
+  if (NW > 1) o += 2LL * NW * 256;
+  k.xb_stride = DP + 4;
+  k.o_XB = (int)o;
+  if (NW > 1 && (k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM)) o += 16LL * k.xb_stride;
+  k.o_red = (int)o;
+  o += (long long)NW * 16 * 8;
+  const int nc = k.ekind == L2HMC_ENERGY_GMM ? k.ncomp : 1;
+  k.o_mu = (int)o;
+  o += (long long)nc * DP;
+  k.o_prec = (int)o;
+  if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) o += DP;
+  if (k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM) o += (long long)nc * gauss_floats(NT);
+  k.o_logc = (int)o;
+  o += round4(nc);
+  return o * 4;
+}
+
 int check_energy(const L2hmcEnergy* e, int d) {
   if (e == nullptr) return fail(L2HMC_ERR_ARG, "energy is NULL%s");
   switch (e->kind) {
@@ -419,8 +448,17 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
     if (a->variant == 8) return fail(L2HMC_ERR_UNSUPPORTED, "variant 8: %s%lld bytes of LDS needed (T x d too large)", "", ldsw);
   }
   int DT, NW;
-  if (!pick_geometry(a->d, a->n_chains, a->variant, DT, NW))
+  const int geom_variant = a->variant >= 100 ? a->variant - 100 : a->variant;   // 100 + v: the round-1 kernel
+  if (!pick_geometry(a->d, a->n_chains, geom_variant, DT, NW))
     return fail(L2HMC_ERR_UNSUPPORTED, "d = %s%lld not supported with variant %lld", "", a->d, a->variant);
+  // The instruction-lean kernel (traj_fast.hpp) covers S/T/Q nets on register-resident geometries; the
+  // tempered / annealed energies (HMC-mode AIS) and zero-step calls stay on the general kernel.
+  const bool fast = a->packed_nets != nullptr && DT <= 2 && k.n_steps >= 1 && a->variant < 100 &&
+                    k.beta == 1.f && k.temperature == 1.f;
+  if (fast) {
+    const long long ldsf = plan_lds_fast(k, NW, DT);
+    if (ldsf <= 160 * 1024) return dispatch(OP_TRAJ_FAST, k, DT, NW, KH, ldsf, s);
+  }
   const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW, DT);
   return dispatch(OP_TRAJ, k, DT, NW, KH, lds, s);
 }

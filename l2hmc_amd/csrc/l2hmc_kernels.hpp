@@ -96,6 +96,7 @@ struct KArgs {
   // LDS offsets (floats)
   int o_mask, o_trig, o_tb, o_P, o_XB, o_red, o_mu, o_prec, o_logc, xb_stride;
   int o_state;               // traj_wide_kernel: x, v, grad U of the tile (3 x NT x 256 floats)
+  int o_fw, o_fc, o_rec;     // traj_fast_kernel: staged tail fragments, constant tables, schedule records
   unsigned long long* dbg;   // phase-timing buffer (profiling builds only, else NULL)
 };
 
@@ -1072,7 +1073,14 @@ int launch(K kern, const KArgs& k, int NW, long long lds_bytes, hipStream_t s) {
   else if (DTv == 8 && NWv == 4) { CALL(8, 4) }          \
   else return fail(L2HMC_ERR_UNSUPPORTED, "no kernel for this geometry%s");
 
-enum { OP_TRAJ = 0, OP_ENERGY = 1, OP_PACCEPT = 2 };
+enum { OP_TRAJ = 0, OP_ENERGY = 1, OP_PACCEPT = 2, OP_TRAJ_FAST = 3 };
+
+#define L2HMC_FAST_SWITCH(DTv, NWv, CALL)                \
+  if (DTv == 1 && NWv == 1) { CALL(1, 1) }               \
+  else if (DTv == 2 && NWv == 1) { CALL(2, 1) }          \
+  else if (DTv == 1 && NWv == 4) { CALL(1, 4) }          \
+  else if (DTv == 2 && NWv == 4) { CALL(2, 4) }          \
+  else return fail(L2HMC_ERR_UNSUPPORTED, "no fast kernel for this geometry%s");
 
 // Declared here, defined (explicitly instantiated) once per energy kind.
 template <int EK>
@@ -1085,6 +1093,8 @@ int launch_ek(int op, const KArgs& k, int DT, int NW, int KH, long long lds, hip
       _Pragma("clang diagnostic push")                                                           \
       L2HMC_GEOM_SWITCH(DT, NW, L2HMC_CALL_TRAJ_##EKv)                                           \
       _Pragma("clang diagnostic pop")                                                            \
+    } else if (op == OP_TRAJ_FAST) {                                                             \
+      L2HMC_FAST_SWITCH(DT, NW, L2HMC_CALL_FAST_##EKv)                                           \
     } else if (op == OP_ENERGY) {                                                                \
       L2HMC_GEOM_SWITCH(DT, NW, L2HMC_CALL_EN_##EKv)                                             \
     } else {                                                                                     \

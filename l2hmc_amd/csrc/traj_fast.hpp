@@ -1,0 +1,398 @@
+// traj_fast.hpp -- the instruction-lean form of the fused trajectory kernel (gfx950 / CDNA4).
+//
+// Same algorithm, tiling, S-layout, K-split exchange and sampler loop as traj_kernel
+// (l2hmc_kernels.hpp; reference: utils/dynamics.py:115-309, utils/sampler.py:28-55) for the
+// geometries whose weights are LDS/register resident (DT <= 2 dim-tiles per wave) with S/T/Q
+// nets.  On gfx950 the f32 MFMA and the f32 VALU share the SIMD's issue time (measured:
+// profiles/README.md, "many-chains regime"), so the lever is the instruction count per leapfrog
+// step.  What this form removes (profiles/r02_traj_isa_hist.txt has the before / after counts):
+//
+//   * constants folded at staging time instead of multiplied in the loop: the S and Q head
+//     fragments (weights and bias row) are scaled by 2 log2(e) when they are copied into LDS,
+//     so 2^z is the first op on the MFMA result; the T head is scaled by the step size (eps for
+//     XNet, eps/2 for VNet) and log2(step) is added to the Q exponent, so
+//     tr = eps (e^{eps Q} v_h + T) resp. (eps/2)(T - e^{eps Q} grad U) is ONE packed fma;
+//   * c tanh(z) = c + c * rcp(-(2^z + 1)/2): one per-lane constant, the sign of the direction
+//     folded into it (two tables in LDS, each lane reads the one of its direction);
+//   * no per-lane selects between the forward and the inverse update: with f = 1 (forward) / 0
+//     and nf = f - 1,   z' = ES (z + nf tr) + f tr   is the forward update for f = 1 and the
+//     inverse one for f = 0 (ES = e^{-eps S} there);
+//   * masks enter as 0/1 factors of the exponent and of tr (z' = z exactly where kept), read
+//     from per-direction tables ("forward keeps m first, backward keeps 1 - m first");
+//   * relu on the integer view (one v_max_i32; fmaxf needs a canonicalising second v_max);
+//   * the diagonal-Gaussian energy value is taken once at the end points, not every step.
+#pragma once
+#include "l2hmc_kernels.hpp"
+
+namespace l2hmc {
+
+__device__ __forceinline__ float relu_i(float a) { return __int_as_float(max(__float_as_int(a), 0)); }
+__device__ __forceinline__ f4 rcp4(f4 a) {
+  return f4{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y), __builtin_amdgcn_rcpf(a.z),
+            __builtin_amdgcn_rcpf(a.w)};
+}
+__device__ __forceinline__ f4 ex2_4(f4 a) {
+  return f4{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y), __builtin_amdgcn_exp2f(a.z),
+            __builtin_amdgcn_exp2f(a.w)};
+}
+
+// LDS geometry of the fast kernel (floats).  Host and device agree through these helpers.
+// NTp = NW * DT >= NT: every wave's tiles exist in the tables (zero-filled beyond NT), so the loop has no
+// "is this tile live" branches.
+__host__ __device__ inline int fast_fw_net(int NTp) { return (3 * NTp + 1) * 256; }   // staged tail fragments per net
+__host__ __device__ inline int fast_dpp(int NTp) { return 16 * NTp + 16; }            // padded row of a constant table
+__host__ __device__ inline int fast_fc_net(int NTp) { return 4 * fast_dpp(NTp); }     // cS(fwd) cS(bwd) cQ bQ
+__host__ __device__ inline int fast_rec(int NTp) { return 32 + 16 * NTp; }            // tbx(16) tbv(16) k1 mask
+// T rows plus one never-used row on either side (the next-row prefetch of the last step lands there)
+__host__ __device__ inline int fast_rec_dir(int NTp, int T) { return (T + 2) * fast_rec(NTp) + 16; }
+
+long long plan_lds_fast(KArgs& k, int NW, int DT);
+
+template <int DT>
+struct TailK {
+  f4 w2;
+  f4 hs[DT], ht[DT], hq[DT], cS[DT], cQ[DT], bQ[DT];
+};
+
+// fw: this net's staged fragments; fc: this net's constant tables; dofs: 0 (forward) / DPp (backward)
+template <int DT>
+__device__ __forceinline__ void load_tailk(TailK<DT>& tk, const float* fw, const float* fc, int dofs, int NTp,
+                                           int w, int lane) {
+  const int q = lane >> 4, DPp = fast_dpp(NTp);
+  tk.w2 = lds4(fw + lane * 4);
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    const int tg = w * DT + t;
+    tk.hs[t] = lds4(fw + ((1 + 3 * tg + 0) * 64 + lane) * 4);
+    tk.ht[t] = lds4(fw + ((1 + 3 * tg + 1) * 64 + lane) * 4);
+    tk.hq[t] = lds4(fw + ((1 + 3 * tg + 2) * 64 + lane) * 4);
+    tk.cS[t] = lds4(fc + dofs + 16 * tg + 4 * q);
+    tk.cQ[t] = lds4(fc + 2 * DPp + 16 * tg + 4 * q);
+    tk.bQ[t] = lds4(fc + 3 * DPp + 16 * tg + 4 * q);
+  }
+}
+
+// hsum = exchanged layer-1 sum + time/bias term.  apply(t, aS, T', EQ') with
+//   aS = log2 of the (unmasked) scale factor,  T' = step * T,  EQ' = step * e^{eps Q}.
+template <int DT, int KH, class F>
+__device__ __forceinline__ void tail_fast(const TailK<DT>& tk, f4 hs_, F&& apply) {
+  f4 h = splat(0.f);
+#pragma unroll
+  for (int r = 0; r < KH; ++r) h[r] = relu_i(hs_[r]);
+  {
+    f4 acc = splat(0.f);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) acc = MFMA16(tk.w2[r], h[r], acc);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
+  }
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    f4 zs = splat(0.f), zt = splat(0.f), zq = splat(0.f);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) {
+      zs = MFMA16(tk.hs[t][r], h[r], zs);
+      zq = MFMA16(tk.hq[t][r], h[r], zq);
+      zt = MFMA16(tk.ht[t][r], h[r], zt);
+    }
+    // c tanh(z) = c + c * rcp(-(2^{2 z log2 e} + 1) / 2); the head outputs arrive pre-scaled
+    const f4 rS = rcp4(-(ex2_4(zs) * 0.5f + 0.5f));
+    const f4 aS = rS * tk.cS[t] + tk.cS[t];
+    const f4 rQ = rcp4(-(ex2_4(zq) * 0.5f + 0.5f));
+    const f4 EQ = ex2_4(rQ * tk.cQ[t] + tk.bQ[t]);
+    apply(t, aS, zt, EQ);
+  }
+}
+
+template <int EK, int DT, int NW, int KH>
+__global__ __launch_bounds__(64 * NW, 2) void traj_fast_kernel(const KArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(DT <= 2, "the fast kernel keeps layer-1 and tail fragments in registers");
+  const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * NW;
+  const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+  const int c = lane & 15, q = lane >> 4;
+  const long long chain = (long long)blockIdx.x * 16 + c;
+  const bool live = chain < A.N;
+  const int NT = A.NT, DP = 16 * NT, NF = net_floats(NT);
+  const float LOG2E = 1.4426950408889634f;
+  const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
+  const float heps = 0.5f * eps;
+  constexpr int NTp = NW * DT;
+  const int FWN = fast_fw_net(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
+            RECD = fast_rec_dir(NTp, A.T);
+
+  // ---- prologue: stage the tail fragments (scaled), the constant tables and the schedule records ----
+  for (int i = tid; i < 2 * (FWN / 4); i += nthr) {
+    const int net = i >= FWN / 4, j = i - net * (FWN / 4), g = j >> 6;
+    float sc = 1.f;
+    if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
+    f4 src = splat(0.f);
+    if (g < 3 * NT + 1) src = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + (2 * NT + 1) * 256)[j];
+    reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src * sc;
+  }
+  for (int i = tid; i < 2 * 16 * NTp; i += nthr) {
+    const int net = i / (16 * NTp), dim = i % (16 * NTp);
+    const float* scl = A.packed + (size_t)net * NF + net_groups(NT) * 256;
+    const float epn = net == 0 ? eps : heps;
+    const float es = dim < DP ? scl[dim] : 0.f, eq = dim < DP ? scl[DP + dim] : 0.f;
+    const float cs = es * epn * LOG2E, cq = eq * eps * LOG2E;
+    float* fc = smem + A.o_fc + net * FCN;
+    fc[dim] = cs;
+    fc[DPp + dim] = -cs;
+    fc[2 * DPp + dim] = cq;
+    fc[3 * DPp + dim] = cq + log2f(epn);
+  }
+  for (int i = tid; i < 2 * A.T * R; i += nthr) {
+    const int dr = i / (A.T * R), r = (i / R) % A.T, j = i % R;
+    float val;
+    if (j < 32) {
+      const int net = j >> 4, u = j & 15;
+      const float* tf = A.packed + (size_t)net * NF + (2 * NT * 64) * 4;
+      val = fmaf(tf[u * 4], A.trig[2 * r], fmaf(tf[(16 + u) * 4], A.trig[2 * r + 1], tf[(32 + u) * 4]));
+    } else {
+      const int dim = j - 32;
+      const float m = dim < A.d ? A.masks[r * A.d + dim] : 0.f;
+      val = dr ? m : 1.f - m;              // forward keeps m first, backward keeps 1 - m first
+    }
+    smem[A.o_rec + dr * RECD + (r + 1) * R + j] = val;
+  }
+  stage_energy<EK, false>(A, smem, tid, nthr);
+
+  f4 x[DT], v[DT], g[DT];
+  load_state<DT, NW>(A.x, A, chain, live, w, q, x);
+  const bool need_p = A.p_out != nullptr || A.x_next != nullptr || A.u != nullptr ||
+                      (A.rng_flags & L2HMC_RNG_U) != 0;
+  __syncthreads();
+
+  const float* fwx = smem + A.o_fw;
+  const float* fwv = fwx + FWN;
+  const float* fcx = smem + A.o_fc;
+  const float* fcv = fcx + FCN;
+  int pb = 0;
+  const f4 Z = splat(0.f);
+  EnergyRegs<EK, DT> er;
+  load_energy_regs<EK, DT, NW>(er, A, smem, w, lane);
+  // grad U (and, at the end points only, this lane's share of U)
+  auto grad = [&](const f4 (&xx)[DT], f4 (&gg)[DT], float& Up, bool wantU) {
+    if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) gg[t] = er.prec[t] * (xx[t] - er.mu[t]);
+    } else {
+      grad_energy<EK, DT, NW>(A, smem, w, lane, xx, gg, Up, wantU, &er);
+    }
+  };
+  auto diag_U = [&](const f4 (&xx)[DT], const f4 (&gg)[DT]) {
+    float U = 0.f;
+    if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) U += 0.5f * hsum((xx[t] - er.mu[t]) * gg[t]);
+    }
+    return U;
+  };
+  float U_start = 0.f;
+  grad(x, g, U_start, need_p);
+  if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) U_start = diag_U(x, g);
+
+  L1W<DT> l1w;
+  load_l1w<DT, NW>(l1w, A.packed, A.packed + NF, A, w, lane);
+  TailK<DT> tk;
+  f4 pv[1];
+  // VNet layer 1 at (x, grad U(x)).  Diagonal Gaussian: grad U = P (x - mu) is linear in x, so
+  //   W1^T x + W2^T grad U = (W1 + P W2)^T x - W2^T P mu:
+  // the precision is folded into the register-resident W1 fragments once per launch (fragment element
+  // (lane, r) belongs to dimension 16 tg + 4 q + r -- this lane's own slice of P) and the constant goes
+  // into the VNet time/bias table: one contraction per step instead of two.
+  auto vnet_l1 = [&](const f4 (&xx)[DT], const f4 (&gg)[DT]) {
+    if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
+      return l1_part<DT, NW>(nullptr, 0, A, w, lane, xx, Z, l1w.va);
+    } else {
+      return l1_part<DT, NW>(nullptr, 0, A, w, lane, xx, Z, l1w.va) + l1_part<DT, NW>(nullptr, NT, A, w, lane, gg, Z, l1w.vb);
+    }
+  };
+  if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
+    f4 pm[DT], cv[1];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      l1w.va[t] = l1w.va[t] + er.prec[t] * l1w.vb[t];
+      pm[t] = -(er.prec[t] * er.mu[t]);
+    }
+    cv[0] = l1_part<DT, NW>(nullptr, NT, A, w, lane, pm, Z, l1w.vb);
+    xchg<NW, 1>(cv, A, smem, w, lane, pb);
+    if (w == 0 && c == 0) {
+      for (int i = 0; i < 2 * A.T; ++i) {
+        float* tb = smem + A.o_rec + (i / A.T) * RECD + (i % A.T + 1) * R + 16 + 4 * q;
+        *reinterpret_cast<f4*>(tb) = lds4(tb) + cv[0];
+      }
+    }
+    __syncthreads();
+  }
+  PT_DECL;
+  PT_MARK(0);      // prologue
+  pv[0] = vnet_l1(x, g);
+  xchg<NW, 1>(pv, A, smem, w, lane, pb);
+
+  // ---- persistent sampler loop (as traj_kernel) ------------------------------------------------------
+  const long long gchain = A.chain_off + chain;
+  const bool rng_v = (A.rng_flags & L2HMC_RNG_V) != 0, rng_d = (A.rng_flags & L2HMC_RNG_DIR) != 0;
+  const bool rng_u = (A.rng_flags & L2HMC_RNG_U) != 0;
+  f4 vn[DT];
+  if (!rng_v) load_state<DT, NW>(A.v, A, chain, live, w, q, vn);
+  bool fwd_n = (A.dir != nullptr && !rng_d) ? (live ? A.dir[chain] != 0 : true) : (A.dir_all != 0);
+  float u_n = (A.u != nullptr && !rng_u && live) ? A.u[chain] : 0.f;
+  const bool have_u = A.u != nullptr || rng_u;
+  for (int m = 0; m < A.M; ++m) {
+    const long long moff = (long long)m * A.N;
+    const unsigned long long prop = A.rng_prop0 + (unsigned long long)m;
+    if (rng_v) {
+      rng_state<DT, NW>(A, gchain, prop, w, q, v);
+    } else {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) v[t] = vn[t];
+    }
+    bool fwd = fwd_n;
+    float u_m = u_n;
+    if (rng_d || rng_u) {
+      bool fr;
+      float ur;
+      philox_dir_u(A.rng_seed, gchain, prop, fr, ur);
+      if (rng_d) fwd = fr;
+      if (rng_u) u_m = ur;
+    }
+    if (m + 1 < A.M) {
+      if (!rng_v) load_state<DT, NW>(A.v + (moff + A.N) * A.d, A, chain, live, w, q, vn);
+      if (A.dir != nullptr && !rng_d && live) fwd_n = A.dir[moff + A.N + chain] != 0;
+      if (A.u != nullptr && !rng_u && live) u_n = A.u[moff + A.N + chain];
+    }
+    // the start point: a rejected chain resumes from it (sampler.py:53-55)
+    f4 x0[DT], g0[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) { x0[t] = x[t]; g0[t] = g[t]; }
+    const f4 pv0 = pv[0];
+    float red[5];                  // U0, K0, U1, K1, logdet (per-lane partial sums)
+    red[0] = U_start;
+    red[1] = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) red[1] += 0.5f * hsum(v[t] * v[t]);
+    red[2] = 0.f;
+    f4 ldv = splat(0.f);
+
+    // per-lane direction constants and table addresses
+    const float ff = fwd ? 1.f : 0.f, nf = ff - 1.f;
+    const int dofs = fwd ? 0 : DPp;
+    const int row0 = fwd ? A.step_begin : (A.T - 1 - A.step_begin);
+    const float* rec = smem + A.o_rec + (fwd ? RECD : 0) + (row0 + 1) * R + 4 * q;   // this lane's record, + 4 q
+    const int drec = fwd ? R : -R;
+    f4 tbv = lds4(rec + 16);
+
+    load_tailk<DT>(tk, fwv, fcv, dofs, NTp, w, lane);
+    for (int it = 0; it < A.n_steps; ++it) {
+      f4 k1[DT], vh[DT], y[DT], xin[DT];
+      const f4 tbx = lds4(rec);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) k1[t] = lds4(rec + 32 + 16 * (w * DT + t));
+      rec += drec;
+      const f4 tbv_n = lds4(rec + 16);      // (the last step reads the unused pad row)
+
+      PT_MARK(1);  // step head
+      // ---- momentum half-update #1: VNet([x, grad U(x), t])  (dynamics.py:118-125 / :162-170)
+      tail_fast<DT, KH>(tk, pv[0] + tbv, [&](int t, f4 aS, f4 T, f4 EQ) {
+        const f4 ES = ex2_4(aS);
+        ldv += aS;
+        const f4 tr = T - EQ * g[t];
+        vh[t] = ES * (nf * tr + v[t]) + ff * tr;
+      });
+      PT_MARK(2);  // VNet tail #1
+
+      // ---- two masked position updates: XNet([v_h, kept * x, t])  (:127-145 / :172-190)
+      load_tailk<DT>(tk, fwx, fcx, dofs, NTp, w, lane);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) xin[t] = k1[t] * x[t];
+      const f4 pa = l1_part<DT, NW>(nullptr, 0, A, w, lane, vh, Z, l1w.xa);
+      f4 px[1];
+      px[0] = pa + l1_part<DT, NW>(nullptr, NT, A, w, lane, xin, Z, l1w.xb);
+      PT_MARK(3);  // XNet layer-1 partials (a, b)
+      xchg<NW, 1>(px, A, smem, w, lane, pb);
+      PT_MARK(4);  // exchange
+      tail_fast<DT, KH>(tk, px[0] + tbx, [&](int t, f4 aS, f4 T, f4 EQ) {
+        const f4 up = 1.f - k1[t];
+        const f4 aSm = up * aS;
+        const f4 ES = ex2_4(aSm);
+        ldv += aSm;
+        const f4 tr = up * (EQ * vh[t] + T);
+        y[t] = ES * (nf * tr + x[t]) + ff * tr;
+        xin[t] = up * y[t];
+      });
+      PT_MARK(5);  // XNet tail #1
+      f4 py[1];
+      py[0] = pa + l1_part<DT, NW>(nullptr, NT, A, w, lane, xin, Z, l1w.xb);
+      PT_MARK(6);  // XNet layer-1 partial (b only)
+      xchg<NW, 1>(py, A, smem, w, lane, pb);
+      PT_MARK(7);  // exchange
+      tail_fast<DT, KH>(tk, py[0] + tbx, [&](int t, f4 aS, f4 T, f4 EQ) {
+        const f4 aSm = k1[t] * aS;
+        const f4 ES = ex2_4(aSm);
+        ldv += aSm;
+        const f4 tr = k1[t] * (EQ * vh[t] + T);
+        x[t] = ES * (nf * tr + y[t]) + ff * tr;
+      });
+      PT_MARK(8);  // XNet tail #2
+
+      // ---- momentum half-update #2 at the new position  (:147-153 / :192-199)
+      load_tailk<DT>(tk, fwv, fcv, dofs, NTp, w, lane);
+      grad(x, g, red[2], need_p && it == A.n_steps - 1);
+      pv[0] = vnet_l1(x, g);
+      PT_MARK(9);  // grad U + VNet layer-1 partials
+      xchg<NW, 1>(pv, A, smem, w, lane, pb);
+      PT_MARK(10); // exchange
+      tail_fast<DT, KH>(tk, pv[0] + tbv, [&](int t, f4 aS, f4 T, f4 EQ) {
+        const f4 ES = ex2_4(aS);
+        ldv += aS;
+        const f4 tr = T - EQ * g[t];
+        v[t] = ES * (nf * tr + vh[t]) + ff * tr;
+      });
+      PT_MARK(11); // VNet tail #2
+      tbv = tbv_n;
+    }
+    if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) red[2] = diag_U(x, g);
+    const float ld = hsum(ldv) * 0.6931471805599453f;   // the log-det was accumulated in log2 units
+
+    // ---- per-proposal epilogue: proposal, log-det, accept probability, MH select -------------------
+    const bool last = m == A.M - 1;
+    if (last) {
+      store_state<DT, NW>(A.x_out, A, chain, live, w, q, x);
+      store_state<DT, NW>(A.v_out, A, chain, live, w, q, v);
+    }
+    red[3] = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) red[3] += 0.5f * hsum(v[t] * v[t]);
+    red[4] = ld;
+    const float U_end = red[2];
+    chain_allreduce<NW, 5>(red, smem + A.o_red, w, lane);
+    const bool writer = live && w == 0 && lane < 16;
+    if (A.logjac_out != nullptr && writer) A.logjac_out[moff + chain] = red[4];
+    if (need_p) {
+      const float val = (red[0] + red[1]) - (red[2] + red[3]) + red[4];       // dynamics.py:302-309
+      const float p = accept_prob(val);
+      if (A.p_out != nullptr && writer) A.p_out[moff + chain] = p;
+      if (have_u) {
+        const bool acc = live && (p - u_m) >= 0.f;                            // sampler.py:53-55
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          x[t] = sel4(acc, x[t], x0[t]);
+          g[t] = sel4(acc, g[t], g0[t]);
+        }
+        pv[0] = sel4(acc, pv[0], pv0);
+        U_start = acc ? U_end : U_start;
+      } else {
+        U_start = U_end;
+      }
+    } else {
+      U_start = U_end;
+    }
+    if (A.x_hist != nullptr) store_state<DT, NW>(A.x_hist + moff * A.d, A, chain, live, w, q, x);
+  }  // proposals
+  PT_FLUSH(w, lane);
+  store_state<DT, NW>(A.x_next, A, chain, live, w, q, x);
+}
+
+}  // namespace l2hmc

@@ -18,8 +18,10 @@ STEP_TOL, TRAJ_TOL, P_TOL = 3e-5, 1e-4, 1e-4
 
 
 def variants(g):
+    # 0 / 1 / 4: automatic / one / four waves per 16-chain tile (the instruction-lean kernel where it applies);
+    # 100 + v: the same geometry on the general kernel
     d = int(g["x_dim"])
-    return [0] if d <= 16 else [1, 4]
+    return [0, 100] if d <= 16 else [1, 4, 104]
 
 
 @pytest.mark.parametrize("case", CASES)
