@@ -15,9 +15,18 @@ region; the per-step random draws v / direction / u come from the in-kernel Phil
     python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torchrun)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant
-kernel = traj_kernel, MFMA-bound: algorithmic fp32 flops / launch duration vs the 157.3
-TFLOP/s fp32-MFMA peak) and `cpu_baseline` (the numpy oracle -- reference algorithm, both
-directions computed like sampler.py:35-36 -- timed on the host cores, rank 0, N=1 only).
+kernel = traj_fast_kernel, MFMA-bound: algorithmic fp32 flops / launch duration vs the 157.3
+TFLOP/s fp32-MFMA peak) and `cpu_baseline` (the reference algorithm restated op by op on torch-CPU,
+all host cores, both directions computed like sampler.py:35-36; rank 0, N=1 only).
+
+Short runs: a K-step plan that would last less than `--min-timed-ms` (20 ms) is repeated R times
+inside the timed region (R in `config.repeats`; value / ms_per_step are means over the K x R steps),
+so `--steps 20` (0.5 ms of GPU time) measures the same rate as a long run.
+
+Multi-GPU: `--gpus N` alone is weak scaling (`--chains` per GPU); `--total-chains C` is strong
+scaling (C chains split over the N ranks, e.g. the north-star 65 536).  At N > 1 the `dist` key
+reports the collectives of the path: ESS of chains sharded over the ranks (one all-reduce of the
+autocovariance partial sums + mean accept) and a timed training step (flat-gradient all-reduce).
 """
 import argparse
 import json
@@ -74,47 +83,91 @@ def make_problem(seed, n_chains, device):
     return prob
 
 
-def cpu_baseline(prob, budget_s=12.0):
-    """Reference algorithm (numpy oracle, fp32, both directions for all chains) on the host.
-    numpy's elementwise ops run on ONE thread; only the small matmuls go to the BLAS pool, which is
-    capped at 8 threads here -- `cores` reports that cap (the threads the run could actually use)."""
-    from oracle import l2hmc_oracle as O
-    threads = min(8, os.cpu_count() or 1)
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box
+    shows 256 CPUs but grants 16: 256 spinning OpenMP threads on 16 cores would take minutes per proposal)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=threads)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(float(quota) / float(period)))))
     except Exception:
-        limiter, threads = None, 1
-    n = min(CHAINS, prob["x0"].shape[0])
-    en = O.Gaussian(np.zeros(D), np.diag(1.0 / prob["var"]))
-    dyn = O.Dynamics(D, en, T, 0.1, prob["mask"], prob["nets"]["xnet"], prob["nets"]["vnet"])
-    rng = np.random.RandomState(1)
-    x = prob["x0"][:n]
-    reps, t0 = 0, time.perf_counter()
-    with np.errstate(all="ignore"):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline_subprocess(timeout_s=90.0):
+    """cpu_baseline in a child process with a hard time limit, so that a misbehaving host thread pool can
+    never hang the bench (the child imports no GPU code)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
+                           text=True, timeout=timeout_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"value": None, "error": "cpu_baseline child failed: %s" % r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": "cpu_baseline child exceeded %.0f s" % timeout_s}
+
+
+def cpu_baseline(prob, budget_s=20.0):
+    """the reference algorithm (both directions on every chain, three gradient evaluations per
+    forward step) restated op by op on torch-CPU fp32 (oracle/ref_cpu_torch.py; TF1 itself cannot be installed
+    offline), intra-op threads = every host core.  Three bounded samples: C2 (ICG-50, 4096 chains) with the
+    row-wise Gaussian energy, C2 with the reference's literal N x N energy at a chain count whose N x N
+    temporaries fit the budget, and C1 (SCG-2D, 200 chains, the config BASELINE.json names as the CPU path)."""
+    import torch
+    from oracle import ref_cpu_torch as R
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1)
+
+    def run(x_dim, cov, mask, nets, x, nxn, budget):
+        en = R.GaussianRef(np.zeros(x_dim), np.linalg.inv(cov).astype(np.float32), nxn)
+        dyn = R.DynamicsRef(x_dim, en, T, 0.1, mask, nets["xnet"], nets["vnet"])
+        x = torch.as_tensor(x)
+        n, reps, t0 = x.shape[0], 0, time.perf_counter()
         while True:
-            vf, vb = rng.randn(n, D).astype(np.float32), rng.randn(n, D).astype(np.float32)
-            dr, u = rng.randint(0, 2, n), rng.rand(n).astype(np.float32)
-            _, _, _, x = O.propose(x, dyn, vf, vb, dr, u, both_directions=True)
+            vf, vb = torch.randn(n, x_dim, generator=g), torch.randn(n, x_dim, generator=g)
+            dr, u = torch.randint(0, 2, (n,), generator=g), torch.rand(n, generator=g)
+            _, _, x = R.propose(x, dyn, vf, vb, dr, u)
             reps += 1
             el = time.perf_counter() - t0
-            if el > budget_s or reps >= 200:
+            if el > budget or reps >= 200:
                 break
-    if limiter is not None:
-        limiter.restore_original_limits()
-    return {"value": n * T * reps / el, "unit": "chain·leapfrog-steps/s", "cores": threads,
-            "kind": "port",
-            "sample": "%d proposals of %d chains (ICG d=50, T=10), numpy fp32 oracle (reference algorithm: both "
-                      "directions computed for every chain, sampler.py:35-36; row-wise Gaussian energy instead of "
-                      "the reference's N x N product); useful chain-steps counted once; %.1f s" % (reps, n, el)}
+        return n * T * reps / el, reps, el
+
+    n = min(CHAINS, prob["x0"].shape[0])
+    cov = np.diag(prob["var"])
+    row, r1, e1 = run(D, cov, prob["mask"], prob["nets"], prob["x0"][:n], False, 0.4 * budget_s)
+    n_nxn = min(1024, n)
+    nxn, r2, e2 = run(D, cov, prob["mask"], prob["nets"], prob["x0"][:n_nxn], True, 0.4 * budget_s)
+    # C1: the notebook's SCG-2D shapes (weights of the same init family; timing does not depend on their values)
+    rng = np.random.RandomState(3)
+    nets2 = {k: {kk: (0.1 * rng.randn(*((2 if s == D else s) for s in vv.shape))).astype(np.float32)
+                 for kk, vv in w.items()} for k, w in prob["nets"].items()}
+    mask2 = np.stack([np.eye(2, dtype=np.float32)[i % 2] for i in range(T)])
+    cov2 = np.array([[50.05, -49.95], [-49.95, 50.05]])
+    c1, r3, e3 = run(2, cov2, mask2, nets2, rng.randn(200, 2).astype(np.float32), True, 0.2 * budget_s)
+    return {"value": row, "unit": "chain·leapfrog-steps/s", "cores": cores, "kind": "port",
+            "sample": "torch-CPU fp32 restatement of the reference graph (oracle/ref_cpu_torch.py: both directions "
+                      "for every chain, sampler.py:35-36; useful chain-steps counted once), %d intra-op threads. "
+                      "value = C2 ICG-50/%d chains, row-wise Gaussian energy: %d proposals in %.1f s" % (cores, n, r1, e1),
+            "c2_nxn_energy": {"value": nxn, "chains": n_nxn,
+                              "sample": "C2 with the reference's literal N x N energy + autograd gradient "
+                                        "(distributions.py:31-32) at %d chains: %d proposals in %.1f s" % (n_nxn, r2, e2)},
+            "c1_scg2d": {"value": c1, "chains": 200,
+                         "sample": "C1 SCG-2D, 200 chains, N x N energy: %d proposals in %.1f s" % (r3, e3)}}
 
 
-def ess_leg(dev, train_steps=5000):
+def ess_leg(dev, train_steps=5000, seeds=5):
     """ESS/sec on the notebook's SCG-2D target (BASELINE.json configs[0] shape: 200 chains, Lf=10):
     (i) the HMC(eps=0.15) sampler whose ESS the reference publishes (nb raw 388: 5.63e-3 per MH step);
     (ii) the L2HMC sampler TRAINED IN THIS RUN with the notebook's recipe (raw 156-181, 254-271: 5000 Adam
-    steps on 200 chains; published ESS 2.61e-1, ratio 46).  2000 MH steps per sampler in one persistent
-    launch each, history + autocovariance on the device."""
+    steps on 200 chains; published ESS 2.61e-1, ratio 46) -- once per seed, `seeds` independent trainings,
+    reported as mean +- sd.  2000 MH steps per sampler in one persistent launch each, history +
+    autocovariance on the device."""
     import torch
     from l2hmc_amd import Dynamics, distributions, func_utils, layers, sample_chain
     from l2hmc_amd.training import Trainer
@@ -122,10 +175,8 @@ def ess_leg(dev, train_steps=5000):
     scale = float(np.sqrt(np.trace(cov)))
     dist = distributions.Gaussian(np.zeros(2), cov)
     n, steps = 200, 2000
-    gen = torch.Generator(device=dev).manual_seed(0)
-    x0 = torch.as_tensor(dist.get_samples(n, rng=np.random.RandomState(0)), dtype=torch.float32, device=dev)
 
-    def measure(dyn, direction):
+    def measure(dyn, direction, gen, x0):
         v = torch.randn((steps, n, 2), device=dev, generator=gen)
         u = torch.rand((steps, n), device=dev, generator=gen)
         sample_chain(x0, dyn, steps, v=v, u=u, direction=direction, record=True)                 # warm-up
@@ -141,33 +192,105 @@ def ess_leg(dev, train_steps=5000):
                 "chain_leapfrog_steps_per_sec": n * 10 * steps / el, "mean_accept_prob": float(p.mean()),
                 "seconds_incl_autocov": el}
 
+    gen = torch.Generator(device=dev).manual_seed(0)
+    x0 = torch.as_tensor(dist.get_samples(n, rng=np.random.RandomState(0)), dtype=torch.float32, device=dev)
     hmc = Dynamics(2, dist.get_energy_function(), T=10, eps=0.15, hmc=True, device=dev)
-    out = measure(hmc, None)
+    out = measure(hmc, None, gen, x0)
     out.update({"workload": "SCG-2D, HMC eps=0.15, 200 chains x 2000 MH steps, Lf=10 (nb raw 288-298, 388)",
                 "reference_ess_per_mh_step": 5.63e-3})
-    if train_steps > 0:
-        torch.manual_seed(0)
-        np.random.seed(0)
-        layers.set_default_device(dev)
-        dyn = Dynamics(2, dist.get_energy_function(), T=10, eps=0.1, net_factory=layers.stq_network(10), device=dev)
-        dyn.generator = gen
-        tr = Trainer(dyn)
-        xs = torch.randn(n, 2, device=dev, generator=gen)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(train_steps):
-            _, _, xs, _ = tr.step(xs)
-        torch.cuda.synchronize(dev)
-        t_train = time.perf_counter() - t0
-        l2 = measure(dyn, torch.randint(0, 2, (steps, n), device=dev, dtype=torch.uint8, generator=gen))
-        l2.update({"workload": "SCG-2D, L2HMC sampler trained in this run (%d Adam steps, 200 chains; nb raw 156-181, "
-                               "254-271), then 200 chains x 2000 MH steps" % train_steps,
-                   "train_seconds": t_train, "train_ms_per_step": 1e3 * t_train / train_steps,
-                   "reference_ess_per_mh_step": 2.61e-1,
-                   "ess_ratio_vs_hmc": l2["ess_per_mh_step"] / out["ess_per_mh_step"], "reference_ess_ratio": 46.0,
-                   "ess_per_sec_ratio_vs_hmc": l2["ess_per_sec"] / out["ess_per_sec"]})
+    if train_steps > 0 and seeds > 0:
+        runs = []
+        for seed in range(seeds):
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            gen = torch.Generator(device=dev).manual_seed(seed)
+            layers.set_default_device(dev)
+            dyn = Dynamics(2, dist.get_energy_function(), T=10, eps=0.1, net_factory=layers.stq_network(10), device=dev)
+            dyn.generator = gen
+            tr = Trainer(dyn, seed=seed)
+            xs = torch.randn(n, 2, device=dev, generator=gen)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(train_steps):
+                _, _, xs, _ = tr.step(xs)
+            torch.cuda.synchronize(dev)
+            t_train = time.perf_counter() - t0
+            r = measure(dyn, torch.randint(0, 2, (steps, n), device=dev, dtype=torch.uint8, generator=gen), gen, x0)
+            r.update({"seed": seed, "train_seconds": t_train})
+            runs.append(r)
+        e = np.array([r["ess_per_mh_step"] for r in runs])
+        es = np.array([r["ess_per_sec"] for r in runs])
+        l2 = {"workload": "SCG-2D, L2HMC sampler trained in this run (%d Adam steps, 200 chains; nb raw 156-181, "
+                          "254-271), then 200 chains x 2000 MH steps; %d independent seeds" % (train_steps, seeds),
+              "ess_per_mh_step": float(e.mean()), "ess_per_mh_step_sd": float(e.std(ddof=1)) if seeds > 1 else 0.0,
+              "ess_per_mh_step_by_seed": [float(v) for v in e],
+              "ess_per_sec": float(es.mean()), "mean_accept_prob": float(np.mean([r["mean_accept_prob"] for r in runs])),
+              "train_ms_per_step": 1e3 * float(np.mean([r["train_seconds"] for r in runs])) / train_steps,
+              "reference_ess_per_mh_step": 2.61e-1,
+              "ess_ratio_vs_hmc": float(e.mean()) / out["ess_per_mh_step"], "reference_ess_ratio": 46.0,
+              "ess_per_sec_ratio_vs_hmc": float(es.mean()) / out["ess_per_sec"]}
         out["l2hmc"] = l2
     return out
+
+
+def dist_leg(dev, rank, world):
+    """N > 1: the two collectives the path has (north_star), exercised over RCCL.  (i) ESS of chains SHARDED over
+    the ranks: every rank samples its own 200 SCG-2D chains (HMC eps=0.15, in-kernel Philox keyed by the GLOBAL
+    chain index), the autocovariance partial sums and the accept statistics are all-reduced once each.  (ii) a
+    training step on sharded chains: per-rank gradient kernel + ONE flat-gradient all-reduce + native Adam."""
+    import torch
+    import torch.distributed as dist
+    from l2hmc_amd import Dynamics, distributions, layers, sample_chain, sharding
+    from l2hmc_amd.training import Trainer
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
+    scale = float(np.sqrt(np.trace(cov)))
+    target = distributions.Gaussian(np.zeros(2), cov)
+    n, steps = 200, 2000
+    lo = rank * n
+    x0 = torch.as_tensor(target.get_samples(n, rng=np.random.RandomState(rank)), dtype=torch.float32, device=dev)
+    hmc = Dynamics(2, target.get_energy_function(), T=10, eps=0.15, hmc=True, device=dev)
+    sample_chain(x0, hmc, steps, seed=7, chain_offset=lo, record=True)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    t0 = time.perf_counter()
+    xf, p, hist = sample_chain(x0, hmc, steps, seed=7, chain_offset=lo, record=True)
+    X = torch.cat([x0[None], hist[:-1]], dim=0)
+    ess = sharding.ess(X, scale, n * world)
+    acc = sharding.mean_accept(p.reshape(-1))
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    # training on sharded chains
+    torch.manual_seed(0)
+    np.random.seed(0)
+    layers.set_default_device(dev)
+    dyn = Dynamics(2, target.get_energy_function(), T=10, eps=0.1, net_factory=layers.stq_network(10), device=dev)
+    tr = Trainer(dyn, seed=0)
+    xs = x0.clone()
+    for _ in range(20):
+        _, _, xs, _ = tr.step(xs)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    t1 = time.perf_counter()
+    k = 200
+    for _ in range(k):
+        loss, _, xs, _ = tr.step(xs)
+    torch.cuda.synchronize(dev)
+    t_tr = time.perf_counter() - t1
+    # every rank must hold identical parameters after identical all-reduced updates
+    chk = torch.stack([tr.theta.double().sum(), -tr.theta.double().sum()])
+    dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+    same = bool(abs(float(chk[0]) + float(chk[1])) == 0.0)
+    return {"rccl_ranks": int(ones.item()),
+            "sharded_ess": {"workload": "SCG-2D HMC eps=0.15, %d chains (200 per rank) x %d MH steps, in-kernel "
+                                        "Philox keyed by global chain; autocov partial sums + accept all-reduced" % (n * world, steps),
+                            "ess_per_mh_step": ess, "mean_accept_prob": acc, "ess_per_sec": ess * steps / el * n * world,
+                            "seconds_incl_allreduce": el},
+            "sharded_training": {"workload": "SCG-2D, %d chains (200 per rank), %d Adam steps, one flat-gradient "
+                                             "all-reduce (%d floats) per step" % (n * world, k, tr.n_grad),
+                                 "ms_per_step": 1e3 * t_tr / k, "final_loss": float(loss),
+                                 "parameters_identical_across_ranks": same}}
 
 
 def main():
@@ -175,25 +298,36 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=CHAINS, help="chains per GPU (weak scaling)")
+    ap.add_argument("--total-chains", type=int, default=0,
+                    help="strong scaling: this many chains in total, split over the ranks (north star: 65536)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--rng", choices=["philox", "bank"], default="philox",
                     help="philox: momenta / direction / accept uniforms drawn in-kernel (counter-based, "
                          "keyed by global chain index); bank: pre-generated draws read from HBM")
     ap.add_argument("--preheat", type=int, default=1000,
                     help="untimed proposals run BEFORE the --warmup steps so that the GPU clocks have ramped "
-                         "whatever --warmup is (a 20-proposal warm-up lasts 0.6 ms: the timed steps would then "
-                         "run 7 %% slower on cold clocks); reported in config.preheat_proposals")
+                         "whatever --warmup is; they also calibrate the repeat count; config.preheat_proposals")
+    ap.add_argument("--min-timed-ms", type=float, default=20.0,
+                    help="repeat the --steps plan inside the timed region until it lasts at least this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ess", action="store_true", help="skip the SCG-2D ESS/sec leg (N=1 only)")
+    ap.add_argument("--no-ess", action="store_true", help="skip the SCG-2D ESS/sec leg (N=1) / the dist leg (N>1)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 65 536-chain roofline point (N=1 only)")
     ap.add_argument("--ess-train-steps", type=int, default=5000,
                     help="Adam steps for the L2HMC sampler of the ESS leg (0 = HMC only)")
+    ap.add_argument("--ess-seeds", type=int, default=5, help="independent trainings of the ESS leg")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the `dist` leg even at N = 1 (exercises the collectives on a 1-GPU box)")
     ap.add_argument("--bank", type=int, default=0,
                     help="distinct pre-generated random draws, cycled (0 = 2 x proposals-per-launch, min 16)")
     ap.add_argument("--proposals-per-launch", type=int, default=25,
                     help="MH proposals chained inside one launch of the persistent sampler kernel "
                          "(1 = one launch per step); a shorter last launch covers any remainder")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(make_problem(0, CHAINS, None))))
+        return
 
     # (the host driver only supports dmabuf IPC: RCCL needs this for multi-process runs)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -206,16 +340,22 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
 
-    from l2hmc_amd import Dynamics, _ffi, distributions, layers
-    from oracle import l2hmc_oracle as O   # only for NET_KEYS naming + the cpu_baseline leg
+    from l2hmc_amd import Dynamics, _ffi, distributions, layers, sharding
 
-    n = args.chains
-    prob = make_problem(0, n, dev)                     # identical model on every rank
+    strong = args.total_chains > 0
+    if strong:
+        lo, hi = sharding.shard_range(args.total_chains, rank, world)
+        n, chain_off, n_total = hi - lo, lo, args.total_chains
+    else:
+        n, chain_off, n_total = args.chains, rank * args.chains, args.chains * world
+    prob = make_problem(0, min(n, CHAINS), dev)        # identical model on every rank
     layers.set_default_device(dev)
     dyn = Dynamics(D, distributions.Gaussian(np.zeros(D), np.diag(prob["var"])).get_energy_function(),
                    T=T, eps=0.1, net_factory=layers.stq_network(H), device=dev)
@@ -223,54 +363,62 @@ def main():
     dyn.variant = args.variant
     with torch.no_grad():
         for w, key in ((dyn._xw, "xnet"), (dyn._vw, "vnet")):
-            for k in O.NET_KEYS:
+            for k in _ffi.NET_FIELDS:
                 w[k].copy_(torch.as_tensor(prob["nets"][key][k]).reshape(w[k].shape))
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)   # chains differ per rank
-    xa = (torch.randn(n, D, device=dev, generator=gen) *
-          torch.as_tensor(np.sqrt(prob["var"]), dtype=torch.float32, device=dev)).contiguous()
-    xb = torch.empty_like(xa)
-    M = max(1, args.proposals_per_launch)
-    B = args.bank if args.bank > 0 else max(16, 2 * M)
-    B = (B + M - 1) // M * M
-    if args.rng == "bank":
-        v_bank = torch.randn(B, n, D, device=dev, generator=gen)
-        d_bank = torch.randint(0, 2, (B, n), device=dev, dtype=torch.uint8, generator=gen)
-        u_bank = torch.rand(B, n, device=dev, generator=gen)
-
+    sd = torch.as_tensor(np.sqrt(prob["var"]), dtype=torch.float32, device=dev)
     L = _ffi.lib()
-    a = _ffi.L2hmcTrajectoryArgs()
-    a.packed_nets = dyn._packed_nets().data_ptr()
-    a.energy = dyn._fn.c_struct(dev, 1.0)
-    a.masks, a.trig = dyn._mask.data_ptr(), dyn._trig.data_ptr()
-    a.alpha, a.eps_host = dyn.alpha.data_ptr(), 0.0
-    a.n_chains, a.d, a.H, a.T, a.step_begin, a.n_steps = n, D, H, T, 0, T
-    a.variant, a.n_proposals = args.variant, M
-    p_out = torch.empty((M, n), device=dev)
-    a.p_out = p_out.data_ptr()
     stream = torch.cuda.current_stream(dev).cuda_stream
-    bufs = [xa, xb]
+    M = max(1, args.proposals_per_launch)
 
-    state = {"flip": 0}
+    class Runner(object):
+        """`n_` chains of this rank through the persistent sampler kernel, M proposals per launch."""
 
-    def launch(first, count):
-        """proposals [first, first + count): one launch of the persistent sampler kernel"""
-        src, dst = bufs[state["flip"]], bufs[state["flip"] ^ 1]
-        state["flip"] ^= 1
-        b = first % B
-        if b + count > B:
-            b = 0
-        a.n_proposals = count
-        a.x, a.x_next = src.data_ptr(), dst.data_ptr()
-        if args.rng == "philox":
-            a.rng_flags, a.rng_seed = _ffi.RNG_V | _ffi.RNG_DIR | _ffi.RNG_U, 20260926
-            a.rng_proposal0, a.chain_offset = first, rank * n
-        else:
-            a.v = v_bank[b].data_ptr()
-            a.direction = d_bank[b].data_ptr()
-            a.u = u_bank[b].data_ptr()
-        rc = L.l2hmc_trajectory(a, stream)
-        if rc:
-            _ffi.check(rc)
+        def __init__(self, n_, chain_off_, seed):
+            gen = torch.Generator(device=dev).manual_seed(seed)
+            self.n, self.flip = n_, 0
+            xa = (torch.randn(n_, D, device=dev, generator=gen) * sd).contiguous()
+            self.bufs = [xa, torch.empty_like(xa)]
+            self.B = args.bank if args.bank > 0 else max(16, 2 * M)
+            self.B = (self.B + M - 1) // M * M
+            if args.rng == "bank":
+                self.v_bank = torch.randn(self.B, n_, D, device=dev, generator=gen)
+                self.d_bank = torch.randint(0, 2, (self.B, n_), device=dev, dtype=torch.uint8, generator=gen)
+                self.u_bank = torch.rand(self.B, n_, device=dev, generator=gen)
+            a = _ffi.L2hmcTrajectoryArgs()
+            a.packed_nets = dyn._packed_nets().data_ptr()
+            a.energy = dyn._fn.c_struct(dev, 1.0)
+            a.masks, a.trig = dyn._mask.data_ptr(), dyn._trig.data_ptr()
+            a.alpha, a.eps_host = dyn.alpha.data_ptr(), 0.0
+            a.n_chains, a.d, a.H, a.T, a.step_begin, a.n_steps = n_, D, H, T, 0, T
+            a.variant, a.n_proposals = args.variant, M
+            self.p_out = torch.empty((M, n_), device=dev)
+            a.p_out = self.p_out.data_ptr()
+            a.chain_offset = chain_off_
+            self.a = a
+
+        def launch(self, first, count):
+            """proposals [first, first + count): one launch of the persistent sampler kernel"""
+            a = self.a
+            src, dst = self.bufs[self.flip], self.bufs[self.flip ^ 1]
+            self.flip ^= 1
+            a.n_proposals = count
+            a.x, a.x_next = src.data_ptr(), dst.data_ptr()
+            if args.rng == "philox":
+                a.rng_flags, a.rng_seed = _ffi.RNG_V | _ffi.RNG_DIR | _ffi.RNG_U, 20260926
+                a.rng_proposal0 = first
+            else:
+                b = first % self.B
+                if b + count > self.B:
+                    b = 0
+                a.v, a.direction, a.u = self.v_bank[b].data_ptr(), self.d_bank[b].data_ptr(), self.u_bank[b].data_ptr()
+            rc = L.l2hmc_trajectory(a, stream)
+            if rc:
+                _ffi.check(rc)
+
+        def run(self, first, total):
+            for i in range(0, total, M):
+                self.launch(first + i, min(M, total - i))
+            return first + total
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -278,55 +426,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def plan(first, total):
-        return [(first + i, min(M, total - i)) for i in range(0, total, M)]
+    def timed(runner, first, steps, repeats):
+        """(wall seconds, HIP-event ms, launches) of `repeats` x `steps` proposals"""
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(repeats):
+            first = runner.run(first, steps)
+        ev1.record()
+        barrier()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1), repeats * ((steps + M - 1) // M), first
 
+    def calibrate(runner, first, pre):
+        """untimed clock ramp; its event time gives the per-proposal estimate the repeat count is chosen from"""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        runner.run(first, min(pre, M))              # first-touch / lazy-init outside the estimate
+        ev0.record()
+        first = runner.run(first + min(pre, M), pre)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        est = ev0.elapsed_time(ev1) / max(pre, 1)   # ms per proposal
+        if world > 1:
+            tt = torch.tensor([est], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            est = float(tt)
+        return first, est
+
+    main_run = Runner(n, chain_off, 1234 + rank)     # chains differ per rank
     pre = max(0, args.preheat)
-    for f, c in plan(0, pre):                    # clock ramp (untimed, not part of --warmup)
-        launch(f, c)
-    for f, c in plan(pre, args.warmup):
-        launch(f, c)
-    timed = plan(pre + args.warmup, args.steps)
-    nl = len(timed)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for f, c in timed:
-        launch(f, c)
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
-    mean_p = float(p_out.mean())
-    finite = bool(torch.isfinite(bufs[state["flip"]]).all())
+    nxt, est_ms = calibrate(main_run, 0, pre) if pre > 0 else (0, 0.0)
+    nxt = main_run.run(nxt, args.warmup)
+    R = 1
+    if est_ms > 0 and args.steps * est_ms < args.min_timed_ms:
+        R = int(math.ceil(args.min_timed_ms / (args.steps * est_ms)))
+    elapsed, gpu_ms, nl, nxt = timed(main_run, nxt, args.steps, R)
+    mean_p = float(main_run.p_out.mean())
+    finite = bool(torch.isfinite(main_run.bufs[main_run.flip]).all())
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
 
+    flops_cs = algorithmic_flops_per_chain_step(D, H, T, 3 * D)      # diagonal precision: 3d
+    dist_out = None
+    if use_dist and not args.no_ess:
+        dist_out = dist_leg(dev, rank, world)
+
     if rank == 0:
-        steps_total = float(n) * world * T * args.steps
-        flops_cs = algorithmic_flops_per_chain_step(D, H, T, 3 * D)      # diagonal precision: 3d
-        m_avg = args.steps / float(nl)                                   # proposals per launch (mean)
+        k_timed = args.steps * R
+        steps_total = float(n_total) * T * k_timed
+        m_avg = k_timed / float(nl)                                      # proposals per launch (mean)
         per_launch_flops = flops_cs * n * T * m_avg
         launch_s = gpu_ms * 1e-3 / nl                                    # HIP events on the launch stream
         ach = per_launch_flops / launch_s / 1e12
         out = {
             "metric": "chain_leapfrog_steps_per_sec", "value": steps_total / elapsed,
             "unit": "chain·leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / k_timed,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "ICG-50D (ill-conditioned Gaussian d=50), %d chains per GPU, Lf=10, "
-                                   "S/T/Q nets H=10, direction-mixed propose + MH per step" % n,
-                       "chains_per_gpu": n, "x_dim": D, "hidden": H, "leapfrog_steps": T,
+            "config": {"workload": "ICG-50D (ill-conditioned Gaussian d=50), %s, Lf=10, S/T/Q nets H=10, "
+                                   "direction-mixed propose + MH per step"
+                                   % ("%d chains in total over %d GPU(s)" % (n_total, world) if strong
+                                      else "%d chains per GPU" % n),
+                       "chains_per_gpu": n, "chains_total": n_total, "x_dim": D, "hidden": H, "leapfrog_steps": T,
                        "proposals_per_launch": M, "rng": args.rng, "preheat_proposals": pre,
+                       "repeats": R, "timed_steps": k_timed,
                        "parallelism": "chains sharded, no data-path collective",
                        "mean_accept_prob": mean_p, "state_finite": finite},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "traj_kernel", "flops_per_chain_step": flops_cs,
+                         "kernel": "traj_fast_kernel", "flops_per_chain_step": flops_cs,
                          "launch_us": launch_s * 1e6,
                          "hbm_frac": algorithmic_bytes_per_chain_step(D, T) * n * T * m_avg / launch_s / 1e9 / PEAK_HBM_GBS},
         }
@@ -336,12 +507,27 @@ def main():
             if t.get("workload_chains") == n and t.get("proposals_per_launch", 1) == M:
                 out["roofline"]["traffic"] = 1024.0 * (t["fetch_kb"] + t["write_kb"])
                 out["roofline"]["traffic_source"] = t["source"]
-        if world == 1 and not args.no_ess:
-            out["ess"] = ess_leg(dev, args.ess_train_steps)
+        if world == 1 and not args.no_sweep and not strong and n == CHAINS:
+            # the same kernel at the north star's chain count: what the MFMA roof fraction becomes once the
+            # chip is filled (4096 chains are ONE workgroup per CU, one wave per SIMD)
+            sweep = []
+            for nc in (65536,):
+                r2 = Runner(nc, 0, 99)
+                f2, est2 = calibrate(r2, 0, 100)
+                reps = max(1, int(math.ceil(args.min_timed_ms / (100 * est2))))
+                el2, ms2, nl2, _ = timed(r2, f2, 100, reps)
+                a2 = flops_cs * nc * T * (100 * reps / float(nl2)) / (ms2 * 1e-3 / nl2) / 1e12
+                sweep.append({"chains": nc, "value": nc * T * 100.0 * reps / el2, "achieved": a2,
+                              "frac": a2 / PEAK_F32_MFMA_TFLOPS, "launch_us": 1e3 * ms2 / nl2})
+            out["sweep"] = sweep
+        if world == 1 and not args.no_ess and not args.force_dist:
+            out["ess"] = ess_leg(dev, args.ess_train_steps, args.ess_seeds)
+        if dist_out is not None:
+            out["dist"] = dist_out
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prob)
+            out["cpu_baseline"] = cpu_baseline_subprocess()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

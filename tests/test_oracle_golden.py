@@ -199,3 +199,22 @@ def test_ais_oracle_matches_reference(case):
     assert abs_err(st["w"], g["w_final"]) < 2e-4 * max(1.0, float(np.abs(g["w_final"]).max()))
     assert abs(float(est) - float(g["estimate"])) < 2e-4 * max(1.0, abs(float(g["estimate"])))
     assert abs(mean_alpha - float(g["mean_alpha"])) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["scg2d", "icg50", "tilted8"])
+@pytest.mark.parametrize("nxn", [False, True])
+def test_torch_cpu_baseline_matches_goldens(case, nxn):
+    """The multi-threaded torch-CPU restatement timed by bench.py's cpu_baseline (both forms of the
+    Gaussian energy: the reference's literal N x N product and the row-wise one) reproduces the
+    reference's own `propose` outputs."""
+    import torch
+    from oracle import ref_cpu_torch as R
+    g = load(case)
+    nets = tuple({k: g[p + k] for k in R.NET_KEYS} for p in ("xnet.", "vnet."))
+    en = R.GaussianRef(g["energy.mu"], g["energy.i_sigma"], nxn)
+    dyn = R.DynamicsRef(int(g["x_dim"]), en, int(g["T"]), float(g["eps"]), g["mask"], *nets)
+    t = lambda k: torch.as_tensor(g[k])
+    Lx, px, x_next = R.propose(t("x"), dyn, t("prop.v_fwd"), t("prop.v_bwd"), t("prop.dir").reshape(-1), t("prop.u"))
+    assert rel_err(Lx.numpy(), g["prop.Lx"]) < TRAJ_TOL
+    assert abs_err(px.numpy(), g["prop.px"]) < P_TOL
+    check_x_next(x_next.numpy(), g["x"], g["prop.Lx"], g["prop.px"], g["prop.u"], P_TOL)
