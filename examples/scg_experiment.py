@@ -21,33 +21,8 @@ from l2hmc_amd import Dynamics, distributions, func_utils, layers, sample_chain 
 from l2hmc_amd.training import Trainer  # noqa: E402
 
 
-def network(x_dim, scope, factor):
-    """SCGExperiment.ipynb `network` (raw 51-78) with tf.* replaced by the layer kit's helpers."""
-    with layers.variable_scope(scope):
-        net = layers.Sequential([
-            layers.Zip([
-                layers.Linear(x_dim, 10, scope='embed_1', factor=1.0 / 3),
-                layers.Linear(x_dim, 10, scope='embed_2', factor=factor * 1.0 / 3),
-                layers.Linear(2, 10, scope='embed_3', factor=1.0 / 3),
-                lambda _: 0.,
-            ]),
-            sum,
-            layers.relu,
-            layers.Linear(10, 10, scope='linear_1'),
-            layers.relu,
-            layers.Parallel([
-                layers.Sequential([
-                    layers.Linear(10, x_dim, scope='linear_s', factor=0.001),
-                    layers.ScaleTanh(x_dim, scope='scale_s')
-                ]),
-                layers.Linear(10, x_dim, scope='linear_t', factor=0.001),
-                layers.Sequential([
-                    layers.Linear(10, x_dim, scope='linear_f', factor=0.001),
-                    layers.ScaleTanh(x_dim, scope='scale_f'),
-                ])
-            ])
-        ])
-    return net
+# the notebook's `network` factory (SCGExperiment.ipynb raw 51-78; H = 10, head factor 0.001)
+network = layers.stq_network(10)
 
 
 def ess_of(x0, hist, scale):

@@ -151,6 +151,19 @@ int l2hmc_pack_gaussian(const float* i_sigma, int32_t d, float* packed, void* st
  * Each chain runs only in its drawn direction (the reference runs both and discards one). */
 int l2hmc_trajectory(const L2hmcTrajectoryArgs* args, void* stream);
 
+/* ONE generalised leapfrog step straight from the reference-layout weights -- the per-step entry point
+ * SURVEY.md 8(b) names: Dynamics._forward_step (dynamics.py:115-157; dir = 1) / ._backward_step (:159-201;
+ * dir = 0) at the schedule row whose mask (dynamics.py:95-97) and time encoding (:99-105) are passed in.
+ * xnet = vnet = NULL is HMC mode (dynamics.py:73-76).  logjac_inout (N) is ACCUMULATED (+=) or NULL.
+ * `workspace`: l2hmc_workspace_bytes(n_chains, d, H) bytes of device memory (packed fragments, the schedule
+ * row, a log-det temporary); the library allocates nothing.  Callers that take many steps should pack once
+ * (l2hmc_pack_nets) and use l2hmc_trajectory, which fuses the whole trajectory. */
+int64_t l2hmc_workspace_bytes(int64_t n_chains, int32_t d, int32_t H);
+int l2hmc_step(const L2hmcNet* xnet, const L2hmcNet* vnet, const L2hmcEnergy* energy, const float* x, const float* v,
+               float* x_out, float* v_out, float* logjac_inout, const float* mask_row, float cos_t, float sin_t,
+               float eps, const uint8_t* dir_or_null, int32_t dir_all, int64_t n_chains, int32_t d, int32_t H,
+               void* workspace, void* stream);
+
 /* Dynamics.energy / Dynamics.grad_energy (dynamics.py:203-218).  U_out (N) and/or
  * grad_out (N, d) may be NULL. */
 int l2hmc_energy(const L2hmcEnergy* energy, const float* x, int64_t n_chains, int32_t d,
@@ -294,9 +307,13 @@ int l2hmc_rng_fill(uint64_t seed, uint64_t proposal0, int64_t chain_offset, int6
  * (no mean subtraction, like the reference).  sums_out (steps-1 doubles) receives the raw
  * sums S(tau) = sum_t sum_{n,k} X[t] X[t+tau] -- the quantity ranks all-reduce when the chains
  * are sharded; pass n_total = chains over ALL ranks for the normalisation of A_out (A_out may be
- * NULL when only the partial sums are wanted). */
+ * NULL when only the partial sums are wanted).
+ * `workspace`: l2hmc_autocov_workspace_doubles(steps, n_chains, d) doubles -- every block writes its partial
+ * sums there and a second kernel adds them in block order, so S (and with it the thresholded ESS) is bitwise
+ * reproducible; NULL = accumulate with double atomics instead (order-dependent in the last bits). */
+int64_t l2hmc_autocov_workspace_doubles(int64_t steps, int64_t n_chains, int32_t d);
 int l2hmc_autocov(const float* X, int64_t steps, int64_t n_chains, int32_t d, double scale,
-                  int64_t n_total, double* sums_out, double* A_out, void* stream);
+                  int64_t n_total, double* sums_out, double* A_out, double* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -98,7 +98,12 @@ SYMBOLS = {
     "l2hmc_ais_end_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp]),
     "l2hmc_rng_fill": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                  _fp, _fp, _fp, _fp]),
-    "l2hmc_autocov": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int64, _fp, _fp, _fp]),
+    "l2hmc_autocov_workspace_doubles": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32]),
+    "l2hmc_autocov": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int64, _fp, _fp, _fp, _fp]),
+    "l2hmc_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "l2hmc_step": (C.c_int, [C.POINTER(L2hmcNet), C.POINTER(L2hmcNet), C.POINTER(L2hmcEnergy), _fp, _fp, _fp, _fp, _fp,
+                             _fp, C.c_float, C.c_float, C.c_float, _fp, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                             _fp, _fp]),
 }
 
 _lib = None

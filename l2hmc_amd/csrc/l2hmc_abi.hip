@@ -57,6 +57,14 @@ __global__ void pack_net_kernel(L2hmcNet net, int d, int H, int KH, int NT, floa
   out[idx] = val;
 }
 
+__global__ void step_prep_kernel(float* trig, float c, float s) {
+  if (threadIdx.x == 0) { trig[0] = c; trig[1] = s; }
+}
+__global__ void add_inplace_kernel(float* acc, const float* inc, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) acc[i] += inc[i];
+}
+
 __global__ void pack_gauss_kernel(const float* S, int d, int NT, float* out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= gauss_floats(NT)) return;
@@ -147,7 +155,7 @@ __global__ void rng_fill_kernel(unsigned long long seed, unsigned long long prop
 // double atomicAdd per (block, lag).
 const int kLagTile = 32;
 __global__ __launch_bounds__(256) void autocov_kernel(const float* X, long long steps, long long J,
-                                                      double* S) {
+                                                      double* S, double* part_out) {
   __shared__ double part[4][kLagTile];
   const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long tau0 = (long long)blockIdx.y * kLagTile;
@@ -189,9 +197,21 @@ __global__ __launch_bounds__(256) void autocov_kernel(const float* X, long long 
     const long long tau = tau0 + threadIdx.x;
     if (tau < steps - 1) {
       const double v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-      atomicAdd(&S[tau], v);
+      // with a partial buffer the blocks' contributions are added later in block order (bitwise reproducible);
+      // without one (caller gave no workspace) they are accumulated atomically
+      if (part_out != nullptr) part_out[(long long)blockIdx.x * (steps - 1) + tau] = v;
+      else atomicAdd(&S[tau], v);
     }
   }
+}
+
+// S[tau] = sum over blocks, in block order
+__global__ void autocov_reduce_kernel(const double* part, long long nblk, long long nlag, double* S) {
+  const long long tau = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tau >= nlag) return;
+  double a = 0.0;
+  for (long long b = 0; b < nblk; ++b) a += part[b * nlag + tau];
+  S[tau] = a;
 }
 
 __global__ void autocov_finish_kernel(const double* S, long long steps, double inv, double* A) {
@@ -463,6 +483,54 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   return dispatch(OP_TRAJ, k, DT, NW, KH, lds, s);
 }
 
+int64_t l2hmc_workspace_bytes(int64_t n_chains, int32_t d, int32_t H) {
+  const int64_t pf = l2hmc_packed_nets_floats(d, H);
+  if (pf < 0) return pf;
+  if (n_chains < 0) return fail(L2HMC_ERR_ARG, "l2hmc_workspace_bytes: bad argument%s");
+  return 4 * (pf + round4(d) + 4 + ((n_chains + 3) & ~3LL));
+}
+
+int l2hmc_step(const L2hmcNet* xnet, const L2hmcNet* vnet, const L2hmcEnergy* energy, const float* x, const float* v,
+               float* x_out, float* v_out, float* logjac_inout, const float* mask_row, float cos_t, float sin_t,
+               float eps, const uint8_t* dir_or_null, int32_t dir_all, int64_t n_chains, int32_t d, int32_t H,
+               void* workspace, void* stream) {
+  if (!energy || !x || !v || !mask_row || !workspace || n_chains < 0 || d < 1)
+    return fail(L2HMC_ERR_ARG, "l2hmc_step: bad argument%s");
+  if ((xnet == nullptr) != (vnet == nullptr)) return fail(L2HMC_ERR_ARG, "l2hmc_step: give both nets or neither (HMC mode)%s");
+  if (n_chains == 0) return L2HMC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int64_t pf = xnet ? l2hmc_packed_nets_floats(d, H) : 0;
+  if (pf < 0) return (int)pf;
+  float* packed = ws;
+  float* mrow = ws + pf;
+  float* trig = mrow + round4(d);
+  float* lj = trig + 4;
+  if (xnet) {
+    int rc = l2hmc_pack_nets(xnet, vnet, d, H, packed, stream);
+    if (rc) return rc;
+  }
+  hipError_t e = hipMemcpyAsync(mrow, mask_row, sizeof(float) * (size_t)d, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(step_prep_kernel, dim3(1), dim3(64), 0, s, trig, cos_t, sin_t);
+  L2hmcTrajectoryArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed_nets = xnet ? packed : nullptr;
+  a.energy = *energy;
+  a.masks = mrow; a.trig = trig; a.alpha = nullptr; a.eps_host = eps;
+  a.n_chains = n_chains; a.d = d; a.H = H; a.T = 1; a.step_begin = 0; a.n_steps = 1;
+  a.x = x; a.v = v; a.direction = dir_or_null; a.direction_all = dir_all;
+  a.x_out = x_out; a.v_out = v_out; a.logjac_out = logjac_inout ? lj : nullptr;
+  int rc = l2hmc_trajectory(&a, stream);
+  if (rc) return rc;
+  if (logjac_inout)
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, s, logjac_inout, lj,
+                       (long long)n_chains);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
 int l2hmc_energy(const L2hmcEnergy* energy, const float* x, int64_t n_chains, int32_t d,
                  float* U_out, float* grad_out, void* stream) {
   if (n_chains < 0 || d < 1 || !x) return fail(L2HMC_ERR_ARG, "l2hmc_energy: bad argument%s");
@@ -565,8 +633,13 @@ int l2hmc_rng_fill(uint64_t seed, uint64_t proposal0, int64_t chain_offset, int6
   return L2HMC_OK;
 }
 
+int64_t l2hmc_autocov_workspace_doubles(int64_t steps, int64_t n_chains, int32_t d) {
+  if (steps < 2 || n_chains < 0 || d < 1) return fail(L2HMC_ERR_ARG, "l2hmc_autocov_workspace_doubles: bad argument%s");
+  return ((n_chains * (int64_t)d + 255) / 256) * (steps - 1);
+}
+
 int l2hmc_autocov(const float* X, int64_t steps, int64_t n_chains, int32_t d, double scale,
-                  int64_t n_total, double* sums_out, double* A_out, void* stream) {
+                  int64_t n_total, double* sums_out, double* A_out, double* workspace, void* stream) {
   if (!X || !sums_out || steps < 2 || n_chains < 0 || d < 1 || !(scale > 0.0) || n_total < 1)
     return fail(L2HMC_ERR_ARG, "l2hmc_autocov: bad argument%s");
   hipStream_t s = (hipStream_t)stream;
@@ -577,7 +650,10 @@ int l2hmc_autocov(const float* X, int64_t steps, int64_t n_chains, int32_t d, do
     const long long gx = (J + 255) / 256, gy = (steps - 1 + kLagTile - 1) / kLagTile;
     if (gx > 0x7fffffffLL || gy > 65535) return fail(L2HMC_ERR_UNSUPPORTED, "history too large%s");
     hipLaunchKernelGGL(autocov_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, X,
-                       (long long)steps, J, sums_out);
+                       (long long)steps, J, sums_out, workspace);
+    if (workspace != nullptr)
+      hipLaunchKernelGGL(autocov_reduce_kernel, dim3((unsigned)((steps - 1 + 255) / 256)), dim3(256), 0, s, workspace,
+                         gx, (long long)(steps - 1), sums_out);
   }
   if (A_out) {
     const double inv = 1.0 / ((double)n_total * scale * scale);

@@ -380,8 +380,10 @@ __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, 
         for (int t = 0; t < DT; ++t) qq[0] += hsum(dx[t] * y[t]);
         chain_allreduce<NW, 1>(qq, smem + A.o_red, w, lane);
         const float V = -(0.5f * qq[0]) + smem[A.o_logc + i];
+        // (a component with V = -inf -- zero weight, or an overflowed quadratic -- contributes nothing; without
+        //  the guards m - mn = -inf - -inf = NaN would poison the running sums: reduce_logsumexp semantics)
         const float mn = fmaxf(m, V);
-        const float sc = expf(m - mn), wi = expf(V - mn);
+        const float sc = (m == mn) ? 1.f : expf(m - mn), wi = (V == -INFINITY) ? 0.f : expf(V - mn);
         ssum = ssum * sc + wi;
 #pragma unroll
         for (int t = 0; t < DT; ++t) gacc[t] = gacc[t] * sc + wi * y[t];
@@ -659,11 +661,21 @@ __device__ __forceinline__ void load_state(const float* p, const KArgs& A, long 
     const int dim0 = 16 * (w * DT + t) + 4 * q;
     f4 r = splat(0.f);
     if (live && p != nullptr) {
+      // rows are 16-byte aligned when d % 4 == 0 (one dwordx4 per lane and tile), 8-byte aligned when d is
+      // even (two dwordx2); dim0 is a multiple of 4, so "dim0 < d" then covers the whole vector
       const float* row = p + chain * A.d + dim0;
-      if (dim0 + 0 < A.d) r.x = row[0];
-      if (dim0 + 1 < A.d) r.y = row[1];
-      if (dim0 + 2 < A.d) r.z = row[2];
-      if (dim0 + 3 < A.d) r.w = row[3];
+      if ((A.d & 3) == 0) {
+        if (dim0 < A.d) r = *reinterpret_cast<const f4*>(row);
+      } else if ((A.d & 1) == 0) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        if (dim0 < A.d) { const f2 a = *reinterpret_cast<const f2*>(row); r.x = a.x; r.y = a.y; }
+        if (dim0 + 2 < A.d) { const f2 b = *reinterpret_cast<const f2*>(row + 2); r.z = b.x; r.w = b.y; }
+      } else {
+        if (dim0 + 0 < A.d) r.x = row[0];
+        if (dim0 + 1 < A.d) r.y = row[1];
+        if (dim0 + 2 < A.d) r.z = row[2];
+        if (dim0 + 3 < A.d) r.w = row[3];
+      }
     }
     z[t] = r;
   }
@@ -677,10 +689,18 @@ __device__ __forceinline__ void store_state(float* p, const KArgs& A, long long 
   for (int t = 0; t < DT; ++t) {
     const int dim0 = 16 * (w * DT + t) + 4 * q;
     float* row = p + chain * A.d + dim0;
-    if (dim0 + 0 < A.d) row[0] = z[t].x;
-    if (dim0 + 1 < A.d) row[1] = z[t].y;
-    if (dim0 + 2 < A.d) row[2] = z[t].z;
-    if (dim0 + 3 < A.d) row[3] = z[t].w;
+    if ((A.d & 3) == 0) {
+      if (dim0 < A.d) *reinterpret_cast<f4*>(row) = z[t];
+    } else if ((A.d & 1) == 0) {
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      if (dim0 < A.d) *reinterpret_cast<f2*>(row) = f2{z[t].x, z[t].y};
+      if (dim0 + 2 < A.d) *reinterpret_cast<f2*>(row + 2) = f2{z[t].z, z[t].w};
+    } else {
+      if (dim0 + 0 < A.d) row[0] = z[t].x;
+      if (dim0 + 1 < A.d) row[1] = z[t].y;
+      if (dim0 + 2 < A.d) row[2] = z[t].z;
+      if (dim0 + 3 < A.d) row[3] = z[t].w;
+    }
   }
 }
 

@@ -88,6 +88,15 @@ class Dynamics(object):
                     "net_factory must build the S/T/Q architecture of l2hmc_amd.layers.stq_network "
                     "(SCGExperiment.ipynb `network`); other structures are not fused")
             self.H = self._xw['H']
+            # mnist_vae.py:134-150 builds ONE `encoder_sampler` and hands it to both nets; the split engine
+            # evaluates that shared image branch once per trajectory.  Two different branches (or one net
+            # with a branch and one without) would silently run VNet on XNet's encoder: refuse.
+            ax, av = self._xw['aux_encoder'], self._vw['aux_encoder']
+            if (ax is None) != (av is None) or (ax is not None and any(
+                    ax[k].data_ptr() != av[k].data_ptr() for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'))):
+                raise NotImplementedError(
+                    "XNet and VNet must share ONE aux branch (the same encoder_sampler parameters, as in "
+                    "mnist_vae.py:134-150) or have none; separate image branches per net are not implemented")
             for w in (self._xw, self._vw):
                 for k in _ffi.NET_FIELDS:
                     if w[k].device != self.device:

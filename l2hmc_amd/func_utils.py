@@ -25,9 +25,13 @@ def device_autocov(X, scale=1.0, n_total=None):
     steps, N, d = X.shape
     S = torch.empty(steps - 1, dtype=torch.float64, device=X.device)
     A = torch.empty(steps - 1, dtype=torch.float64, device=X.device)
-    _ffi.check(_ffi.lib().l2hmc_autocov(X.data_ptr(), steps, N, d, float(scale),
-                                        int(N if n_total is None else n_total), S.data_ptr(),
-                                        A.data_ptr(), _ffi.current_stream(X.device)))
+    L = _ffi.lib()
+    # per-block partial sums, added in block order: S and the thresholded ESS are bitwise reproducible
+    ws = torch.empty(max(1, _ffi.check(L.l2hmc_autocov_workspace_doubles(steps, N, d))), dtype=torch.float64,
+                     device=X.device)
+    _ffi.check(L.l2hmc_autocov(X.data_ptr(), steps, N, d, float(scale),
+                               int(N if n_total is None else n_total), S.data_ptr(),
+                               A.data_ptr(), ws.data_ptr(), _ffi.current_stream(X.device)))
     return S, A
 
 

@@ -39,6 +39,9 @@ class Trainer(object):
                  beta1=0.9, beta2=0.999, epsilon=1e-8, seed=0):
         if dynamics.hmc:
             raise ValueError("an HMC-mode Dynamics has nothing to train")
+        if (dynamics.use_temperature and float(dynamics.temperature) != 1.0) or float(dynamics.anneal_beta or 0.0) != 0.0:
+            raise NotImplementedError("the training kernel differentiates the plain energy U: a tempered "
+                                      "(temperature != 1) or annealed (anneal_beta) Dynamics is not supported")
         self.dyn, self.scale = dynamics, float(scale)
         self.lr0, self.decay_steps, self.decay_rate = float(lr), int(decay_steps), float(decay_rate)
         self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
@@ -71,6 +74,31 @@ class Trainer(object):
         self.global_step = 0
         self._ws = None
         self._io = None              # per-N buffers of step()
+        self._shard_cache = None
+
+    # ---- checkpoint (the reference saves variables with tf.train.Saver, mnist_vae.py:290,334, and has to smuggle
+    #      the masks around it, eval_sampler.py:52-59,156): everything a run needs to continue bit for bit ----
+    def state_dict(self):
+        return {"dynamics": self.dyn.state_dict(), "theta": self.theta.detach().cpu().clone(),
+                "m": self.m.cpu().clone(), "v": self.v.cpu().clone(), "global_step": int(self.global_step),
+                "seed": int(self.seed),
+                "hyper": {"lr": self.lr0, "decay_steps": self.decay_steps, "decay_rate": self.decay_rate,
+                          "scale": self.scale, "beta1": self.beta1, "beta2": self.beta2, "epsilon": self.epsilon}}
+
+    def load_state_dict(self, sd):
+        if sd["theta"].numel() != self.theta.numel():
+            raise ValueError("checkpoint has %d parameters, this sampler %d" % (sd["theta"].numel(), self.theta.numel()))
+        self.dyn.mask = sd["dynamics"]["mask"]
+        with torch.no_grad():
+            self.theta.copy_(sd["theta"].to(self.theta.device))       # the net tensors and alpha are views of theta
+            self.m.copy_(sd["m"].to(self.m.device))
+            self.v.copy_(sd["v"].to(self.v.device))
+        self.global_step, self.seed = int(sd["global_step"]), int(sd["seed"])
+        h = sd.get("hyper", {})
+        self.lr0, self.decay_steps, self.decay_rate = h.get("lr", self.lr0), h.get("decay_steps", self.decay_steps), h.get("decay_rate", self.decay_rate)
+        self.scale, self.beta1, self.beta2, self.epsilon = (h.get("scale", self.scale), h.get("beta1", self.beta1),
+                                                            h.get("beta2", self.beta2), h.get("epsilon", self.epsilon))
+        self.dyn._packed_key = None
 
     # ---- learning-rate schedule (nb raw 178-180: exponential_decay(..., staircase=True)) -------------
     def lr_at(self, step):
@@ -121,6 +149,20 @@ class Trainer(object):
     def _world(self):
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
+    def _shard(self, N):
+        """(global chain count, global index of this rank's row 0): ranks may hold different numbers of chains
+        (sharding.shard_range hands out blocks whose sizes differ by up to one), so the loss normalisation and the
+        Philox chain offsets come from the all-gathered local counts, not from N * world."""
+        world = self._world()
+        if world == 1:
+            return N, 0
+        if self._shard_cache is None or self._shard_cache[0] != N:
+            counts = [None] * world
+            dist.all_gather_object(counts, int(N))
+            rank = dist.get_rank()
+            self._shard_cache = (N, int(sum(counts)), int(sum(counts[:rank])))
+        return self._shard_cache[1], self._shard_cache[2]
+
     def _loss(self, v12, N, n_total, world):
         terms = torch.stack([(1.0 / v12).sum(), v12.sum()]).double()
         if world > 1:
@@ -149,7 +191,7 @@ class Trainer(object):
             return torch.randint(0, 2, (N,), device=dev, dtype=torch.uint8, generator=gen)
         xd, zd = bits("x_dir"), bits("z_dir")
         world = self._world()
-        n_total = N * world
+        n_total, _ = self._shard(N)
         self.flat.zero_()
         # the x- and the z-proposal are independent and their loss terms add: ONE launch over the 2N
         # chains [x; z] (each chain's term still weighted 1 / n_total) instead of two half-empty ones
@@ -187,11 +229,10 @@ class Trainer(object):
         io = self._buffers(N, d)
         W = io["W"]
         world = self._world()
-        rank = dist.get_rank() if world > 1 else 0
-        n_total = N * world
+        n_total, chain_off = self._shard(N)
         # z, v_x, v_z (rows 1..3 of W), the direction bits of both proposals (rows 1, 2 of dir) and the
         # accept uniforms (row 0 of u): one call, stream position = (seed, 3 * global_step, global chain)
-        _ffi.check(L.l2hmc_rng_fill(self.seed, 3 * self.global_step, rank * N, N, d, 3, W[1].data_ptr(),
+        _ffi.check(L.l2hmc_rng_fill(self.seed, 3 * self.global_step, chain_off, N, d, 3, W[1].data_ptr(),
                                     io["dir"].data_ptr(), io["u"].data_ptr(), s))
         W[0].copy_(x)
         self.flat.zero_()

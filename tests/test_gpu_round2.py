@@ -1,0 +1,157 @@
+"""GPU tests added in round 2: the per-step C entry point, checkpoint round trip, order-independent
+autocovariance, the GMM zero-weight guard, the shared-aux-branch check, and the RCCL leg of bench.py."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.helpers import abs_err, hip_dynamics, load, rel_err, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("case", ["icg50", "scg2d", "mog2d", "scg2d_hmc"])
+def test_l2hmc_step_entry_point_matches_reference_steps(case):
+    """l2hmc_step (raw reference-layout weights, one schedule row passed by value) against the
+    reference's recorded `_forward_step` / `_backward_step` outputs (dynamics.py:115-201)."""
+    import torch
+    from l2hmc_amd import _ffi
+    g = load(case)
+    dyn = hip_dynamics(g)
+    L = _ffi.lib()
+    N, d = g["x"].shape
+    H = max(dyn.H, 1)
+    x, v = to_dev(g["x"]), to_dev(g["v"])
+    ws = torch.empty(_ffi.check(L.l2hmc_workspace_bytes(N, d, H)) // 4 + 4, dtype=torch.float32, device=x.device)
+    en = dyn._fn.c_struct(x.device, 1.0)
+    nets = (None, None)
+    if not dyn.hmc:
+        nets = tuple(C.pointer(_ffi.L2hmcNet(*[w[k].data_ptr() for k in _ffi.NET_FIELDS])) for w in (dyn._xw, dyn._vw))
+    T = int(g["T"])
+    for s in g["steps"]:
+        s = int(s)
+        ang = np.float32(2 * np.pi) * np.float32(s) / np.float32(T)
+        mrow = dyn._mask[s].contiguous()
+        for fwd, tag in ((1, "fstep%d"), (0, "bstep%d")):
+            xo, vo = torch.empty_like(x), torch.empty_like(v)
+            lj = torch.full((N,), 0.5, dtype=torch.float32, device=x.device)          # accumulated into
+            _ffi.check(L.l2hmc_step(nets[0], nets[1], C.byref(en), x.data_ptr(), v.data_ptr(), xo.data_ptr(),
+                                    vo.data_ptr(), lj.data_ptr(), mrow.data_ptr(), float(np.cos(ang)),
+                                    float(np.sin(ang)), float(g["eps"]), None, fwd, N, d, H, ws.data_ptr(),
+                                    _ffi.current_stream(x.device)))
+            assert rel_err(to_np(xo), g[(tag % s) + ".x"]) < 3e-5, (case, s, fwd)
+            assert rel_err(to_np(vo), g[(tag % s) + ".v"]) < 3e-5, (case, s, fwd)
+            assert rel_err(to_np(lj) - 0.5, g[(tag % s) + ".logdet"]) < 3e-5, (case, s, fwd)
+
+
+def test_checkpoint_round_trip_continues_training_bit_for_bit():
+    """train 25 steps, save (parameters, Adam moments, step counter, seed, masks), reload into a FRESH sampler,
+    train 25 more == 50 straight.  (mnist_vae.py:290,334 Saver; eval_sampler.py:52-59,156 mask hack.)"""
+    import io
+    import torch
+    from l2hmc_amd import Dynamics, distributions, layers
+    from l2hmc_amd.training import Trainer
+
+    def fresh(seed_np):
+        np.random.seed(seed_np)          # masks come from numpy's global RNG like the reference's
+        torch.manual_seed(seed_np)
+        dist = distributions.Gaussian(np.zeros(2), np.array([[50.05, -49.95], [-49.95, 50.05]]))
+        dyn = Dynamics(2, dist.get_energy_function(), T=10, eps=0.1, net_factory=layers.stq_network(10))
+        return dyn, Trainer(dyn, seed=5)
+
+    x0 = torch.randn(200, 2, generator=torch.Generator().manual_seed(1)).cuda()
+    dyn_a, tr_a = fresh(0)
+    xs = x0.clone()
+    for _ in range(50):
+        _, _, xs, _ = tr_a.step(xs)
+    dyn_b, tr_b = fresh(0)
+    xb = x0.clone()
+    for _ in range(25):
+        _, _, xb, _ = tr_b.step(xb)
+    buf = io.BytesIO()
+    torch.save({"trainer": tr_b.state_dict(), "x": xb.cpu()}, buf)
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    dyn_c, tr_c = fresh(123)             # different initial weights AND masks: everything must come from the file
+    tr_c.load_state_dict(ck["trainer"])
+    xc = ck["x"].cuda()
+    for _ in range(25):
+        _, _, xc, _ = tr_c.step(xc)
+    assert torch.equal(tr_c.theta, tr_a.theta) and torch.equal(tr_c.m, tr_a.m) and torch.equal(tr_c.v, tr_a.v)
+    assert torch.equal(xc, xs) and tr_c.global_step == 50
+    assert torch.equal(dyn_c.mask, dyn_a.mask)
+    # Dynamics.state_dict alone restores a sampler (weights, alpha, masks)
+    dyn_d, _ = fresh(77)
+    dyn_d.load_state_dict(dyn_a.state_dict())
+    from l2hmc_amd import propose
+    v = torch.randn(200, 2, generator=torch.Generator().manual_seed(2)).cuda()
+    dr = torch.randint(0, 2, (200,), generator=torch.Generator().manual_seed(3)).cuda()
+    u = torch.rand(200, generator=torch.Generator().manual_seed(4)).cuda()
+    a = propose(x0, dyn_a, do_mh_step=True, direction=dr, v=v, u=u)
+    b = propose(x0, dyn_d, do_mh_step=True, direction=dr, v=v, u=u)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+
+
+def test_device_autocov_is_order_independent():
+    """per-block partial sums added in block order: bitwise identical across runs."""
+    import torch
+    from l2hmc_amd import func_utils
+    X = torch.randn(300, 2000, 3, generator=torch.Generator().manual_seed(0)).cuda()
+    S0, A0 = func_utils.device_autocov(X, 2.0)
+    for _ in range(3):
+        S1, A1 = func_utils.device_autocov(X, 2.0)
+        assert torch.equal(S0, S1) and torch.equal(A0, A1)
+
+
+def test_gmm_zero_weight_component_matches_logsumexp():
+    """a first component with pi = 0 (log c = -inf) must not poison the online softmax."""
+    import torch
+    from l2hmc_amd import Dynamics, distributions
+    mus = [np.array([-2.0, 0.0]), np.array([2.0, 0.0]), np.array([0.0, 3.0])]
+    covs = [0.1 * np.eye(2), 0.1 * np.eye(2), 0.3 * np.eye(2)]
+    with np.errstate(divide="ignore"):
+        full = distributions.GMM(mus, covs, [0.0, 0.6, 0.4])
+    live = distributions.GMM(mus[1:], covs[1:], [0.6, 0.4])
+    x = torch.randn(256, 2, generator=torch.Generator().manual_seed(0)).cuda() * 2
+    da = Dynamics(2, full.get_energy_function(), T=5, eps=0.1, hmc=True)
+    db = Dynamics(2, live.get_energy_function(), T=5, eps=0.1, hmc=True)
+    Ua, Ub = to_np(da.energy(x)), to_np(db.energy(x))
+    ga, gb = to_np(da.grad_energy(x)), to_np(db.grad_energy(x))
+    assert np.all(np.isfinite(Ua)) and np.all(np.isfinite(ga))
+    assert rel_err(Ua, Ub) < 1e-6 and rel_err(ga, gb) < 1e-6
+
+
+def test_separate_aux_branches_are_refused():
+    """mnist_vae.py:134-150 shares ONE encoder_sampler between XNet and VNet; a factory that builds one per net
+    would silently run VNet on XNet's encoder: it must raise instead."""
+    from l2hmc_amd import Dynamics, vae
+    d, H = 6, 16
+    dec = vae.make_decoder(d, 32, 20)
+    energy = vae.VAEPosterior(dec).get_energy_function()
+
+    def per_net_factory(x_dim, scope, factor):
+        return vae.sampler_net_factory(d, vae.make_encoder_sampler(20, 24, H), H, H)(x_dim, scope=scope, factor=factor)
+    with pytest.raises(NotImplementedError, match="share ONE aux branch"):
+        Dynamics(d, energy, T=3, eps=0.1, net_factory=per_net_factory)
+    shared = vae.sampler_net_factory(d, vae.make_encoder_sampler(20, 24, H), H, H)
+    Dynamics(d, energy, T=3, eps=0.1, net_factory=shared)
+
+
+def test_bench_dist_leg_over_rccl_world_size_1():
+    """bench.py --force-dist: process group on backend nccl (= RCCL), the sharded-ESS all-reduces and the
+    flat-gradient all-reduce of a training step run on the GPU box's one GPU; --steps 20 exercises the
+    short-run repeat logic."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline", "--no-sweep"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["dist"]["rccl_ranks"] == 1 and out["dist"]["sharded_training"]["parameters_identical_across_ranks"]
+    assert 4e-3 < out["dist"]["sharded_ess"]["ess_per_mh_step"] < 8e-3         # notebook: 5.63e-3
+    assert out["config"]["repeats"] > 1 and out["config"]["timed_steps"] == 20 * out["config"]["repeats"]
+    assert out["value"] > 1e8 and out["config"]["state_finite"]
