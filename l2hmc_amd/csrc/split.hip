@@ -3,66 +3,38 @@
 // (`encoder_sampler(aux)`, mnist_vae.py:134-150) and the VAE latent-posterior energy
 // (mnist_vae.py:104-126: decoder 50 -> 1024 -> 1024 -> 784, BCE + prior).  BASELINE.json config 5.
 //
-// Everything GEMM-shaped here is a PLAIN dense product over the chain batch -- (N x K)(K x M) with
-// N = thousands of chains -- so it goes to the library (rocBLAS sgemm, fp32); the glue between the
-// products (bias + softplus / relu, the BCE gradient, the masked leapfrog updates with
-// tanh / exp, log-det, accept probability, MH select) is a handful of small hand-written kernels.
+// Everything GEMM-shaped here is a dense product over the chain batch -- (N x K)(K x M) with N = thousands
+// of chains: our own fp32 MFMA GEMM (gemm_f32.hpp) with bias / softplus / sigmoid / relu / BCE-gradient /
+// chain-rule epilogues fused in; what remains between the products (the masked leapfrog updates with
+// tanh / exp, log-det, accept probability, MH select) is a handful of small kernels.  No BLAS library.
 // One C-ABI call enqueues the whole trajectory on the caller's stream; all intermediates live in
 // a caller-provided workspace.  Same per-chain direction mixing as the fused kernel: each chain
 // runs only in its drawn direction.
-#include <rocblas/rocblas.h>
-
-#include "l2hmc_kernels.hpp"
+#include "gemm_f32.hpp"
 
 namespace l2hmc {
 
-rocblas_handle g_blas = nullptr;
-
-int blas_handle(hipStream_t s, rocblas_handle* out) {
-  if (g_blas == nullptr) {
-    if (rocblas_create_handle(&g_blas) != rocblas_status_success) return fail(L2HMC_ERR_HIP, "rocblas_create_handle failed%s");
-    rocblas_set_pointer_mode(g_blas, rocblas_pointer_mode_host);
+// Wt[n][k] = W[k][n]  (W is (K, N) row-major): the forward products contract with W^T in the NT GEMM
+__global__ void k_transpose(const float* W, int K, int N, float* Wt, int ldt, int col_off) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + threadIdx.x;
+    tile[r][threadIdx.x] = (k < K && n < N) ? W[(long long)k * N + n] : 0.f;
   }
-  if (rocblas_set_stream(g_blas, s) != rocblas_status_success) return fail(L2HMC_ERR_HIP, "rocblas_set_stream failed%s");
-  *out = g_blas;
-  return L2HMC_OK;
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int n = n0 + r, k = k0 + threadIdx.x;
+    if (n < N && k < K) Wt[(long long)n * ldt + col_off + k] = tile[threadIdx.x][r];
+  }
 }
-
-// row-major C[M x N] (ldc) = A[M x K] (lda) . op(B) + beta C;  op(B) = B (K x N, ldb) or, with
-// transB, B^T for B stored (N x K, ldb).  (row-major X is the column-major X^T.)
-int gemm_rm(rocblas_handle h, bool transB, int M, int N, int K, const float* A, int lda, const float* B,
-            int ldb, float* C, int ldc, float beta) {
-  const float one = 1.f;
-  const rocblas_status st = rocblas_sgemm(h, transB ? rocblas_operation_transpose : rocblas_operation_none,
-                                          rocblas_operation_none, N, M, K, &one, B, ldb, A, lda, &beta, C, ldc);
-  if (st != rocblas_status_success) return fail(L2HMC_ERR_HIP, "rocblas_sgemm failed (status %s%lld)", "", (long long)st);
-  return L2HMC_OK;
+inline void transpose_into(hipStream_t s, const float* W, int K, int N, float* Wt, int ldt, int col_off) {
+  hipLaunchKernelGGL(k_transpose, dim3((N + 31) / 32, (K + 31) / 32), dim3(32, 8), 0, s, W, K, N, Wt, ldt, col_off);
 }
 
 __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
-// pre[n][j] += b[j]; act[n][j] = softplus(pre)      (pre kept for the backward pass)
-__global__ void k_bias_softplus(float* pre, float* act, const float* b, long long n, int w) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * w) return;
-  const float p = pre[i] + b[i % w];
-  pre[i] = p;
-  act[i] = softplus_f(p);
-}
-__global__ void k_bias_add(float* x, const float* b, long long n, int w) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n * w) x[i] += b[i % w];
-}
-__global__ void k_bias_relu(float* x, const float* b, long long n, int w) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n * w) x[i] = fmaxf(x[i] + b[i % w], 0.f);
-}
-// dh[i] *= sigmoid(pre[i])      (softplus' = sigmoid)
-__global__ void k_mul_sigmoid(float* dh, const float* pre, long long n) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dh[i] *= sigmoid_f(pre[i]);
-}
 // time-embedding table tb[net][s][j] = W3[0][j] cos_s + W3[1][j] sin_s + b1 + b2 + b3
 __global__ void k_time_table(L2hmcNet xn, L2hmcNet vn, const float* trig, int T, int H, float* tb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,94 +47,92 @@ __device__ __forceinline__ int row_of(const unsigned char* dir, int dir_all, lon
   fwd = dir != nullptr ? dir[n] != 0 : (dir_all != 0);
   return fwd ? it : (T - 1 - it);
 }
-// h1[n][j] = relu(h1pre + tb[net][row(n)][j] + aux_h[n][j])
-__global__ void k_layer1(float* h1, const float* tb_net, const float* aux_h, const unsigned char* dir,
-                         int dir_all, int it, int T, long long n, int H) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * H) return;
-  bool fwd;
-  const int s = row_of(dir, dir_all, i / H, it, T, fwd);
-  h1[i] = fmaxf(h1[i] + tb_net[s * H + (int)(i % H)] + (aux_h ? aux_h[i] : 0.f), 0.f);
-}
-
-// BCE part of the VAE energy, one workgroup per chain: U[n] = beta sum_pix bce(logit, aux) + |z|^2 / 2;
-// the logits are overwritten by d U / d logit = beta (sigmoid(logit) - aux).  beta = 1 except on the AIS
-// bridge (utils/ais.py:46-47 with the N(0, I) initial energy of eval_vae.py:55-62: only the BCE term anneals).
-__global__ __launch_bounds__(256) void k_vae_out(float* lg, const float* aux, const float* z, int n_pix, int d,
-                                                 float* U, float beta) {
-  __shared__ float part[4];
-  const long long n = blockIdx.x;
-  float acc = 0.f;
-  for (int k = threadIdx.x; k < n_pix; k += 256) {
-    const float l = lg[n * n_pix + k], t = aux[n * n_pix + k];
-    acc += fmaxf(l, 0.f) - l * t + log1pf(expf(-fabsf(l)));      // TF's stable form (mnist_vae.py:124)
-    lg[n * n_pix + k] = beta * (sigmoid_f(l) - t);
-  }
-  acc *= beta;
-  for (int k = threadIdx.x; k < d; k += 256) acc += 0.5f * z[n * d + k] * z[n * d + k];
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0 && U != nullptr) U[n] = (part[0] + part[1]) + (part[2] + part[3]);
+// U[n] = sum of the BCE row partials the logits GEMM left (fixed order) + |z|^2 / 2   (mnist_vae.py:122-126)
+// (|U| ~ 550 for MNIST-sized images: one fp32 rounding of U is 3e-5, so the partials are added in double and the
+//  trajectory keeps U0 / U1 as doubles for the energy DIFFERENCE of p_accept; the fp32 copy is for the API.)
+__global__ void k_vae_U(const float* rowsum, int np, const float* z, int ldz, int d, float* U, double* Ud,
+                        long long N) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double acc = 0.0;
+  for (int k = 0; k < np; ++k) acc += (double)rowsum[n * np + k];
+  double qd = 0.0;
+  for (int k = 0; k < d; ++k) qd += (double)z[n * ldz + k] * (double)z[n * ldz + k];
+  acc += 0.5 * qd;
+  if (U != nullptr) U[n] = (float)acc;
+  if (Ud != nullptr) Ud[n] = acc;
 }
 // HMC mode (nets identically zero, dynamics.py:73-76): the generalised step is the plain leapfrog
 //   v_h = v - (eps/2) g(x);  x' = x + eps v_h     [k_hmc_drift]      v' = v_h - (eps/2) g(x')   [k_hmc_kick]
-__global__ void k_hmc_drift(float* x, const float* v, const float* g, float* vh, const float* alpha, float eps_host,
-                            long long n) {
+__global__ void k_hmc_drift(float* x, int ldx, const float* v, const float* g, int ldg, float* vh, const float* alpha,
+                            float eps_host, long long N, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= N * d) return;
+  const long long n = i / d;
+  const int k = (int)(i % d);
   const float eps = alpha != nullptr ? expf(*alpha) : eps_host;
-  const float h = v[i] + 0.5f * eps * (-g[i]);
+  const float h = v[i] + 0.5f * eps * (-g[n * ldg + k]);
   vh[i] = h;
-  x[i] = x[i] + eps * h;
+  x[n * ldx + k] = x[n * ldx + k] + eps * h;
 }
-__global__ void k_hmc_kick(float* v, const float* vh, const float* g, const float* alpha, float eps_host, long long n) {
+__global__ void k_hmc_kick(float* v, const float* vh, const float* g, int ldg, const float* alpha, float eps_host,
+                           long long N, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= N * d) return;
   const float eps = alpha != nullptr ? expf(*alpha) : eps_host;
-  v[i] = vh[i] + 0.5f * eps * (-g[i]);
-}
-__global__ void k_add(float* g, const float* z, long long n) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) g[i] += z[i];
+  v[i] = vh[i] + 0.5f * eps * (-g[(i / d) * ldg + (i % d)]);
 }
 
-// Momentum half-update, one thread per chain (deterministic log-det sum).  out3 = h2 [Ws|Wt|Wq]
-// (no biases yet).  forward: v' = v e^{eps S/2} + (eps/2)(T - e^{eps Q} g); backward:
-// v' = (v - (eps/2)(T - e^{eps Q} g)) e^{-eps S/2}   (dynamics.py:121-125,149-153 / :164-170,194-199)
-__global__ void k_v_half(const float* out3, L2hmcNet w, const float* vin, const float* g, float* vout,
-                         float* ld, const unsigned char* dir, int dir_all, const float* alpha, float eps_host,
-                         long long N, int d) {
-  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// Update kernels: ONE WAVE PER CHAIN, lanes over the d dimensions (coalesced rows of every operand), the chain's
+// log-det contribution a fixed-order wave reduction.  Every state array carries its row stride: the engine keeps
+// [x | grad U] and [v_h | masked x] side by side (row stride 2 d) so that they ARE the K = 2 d inputs of the nets'
+// first layer.
+__device__ __forceinline__ float wave_sum(float a) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  return a;
+}
+// Momentum half-update.  out3 = h2 [Ws|Wt|Wq] (no biases yet).  forward: v' = v e^{eps S/2} + (eps/2)(T - e^{eps Q} g);
+// backward: v' = (v - (eps/2)(T - e^{eps Q} g)) e^{-eps S/2}   (dynamics.py:121-125,149-153 / :164-170,194-199)
+__global__ __launch_bounds__(256) void k_v_half(const float* out3, L2hmcNet w, const float* vin, int ldvi,
+                                                const float* g, int ldg, float* vout, int ldvo, float* ld,
+                                                const unsigned char* dir, int dir_all, const float* alpha,
+                                                float eps_host, long long N, int d) {
+  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (n >= N) return;
   const bool fwd = dir != nullptr ? dir[n] != 0 : (dir_all != 0);
   const float eps = alpha != nullptr ? expf(*alpha) : eps_host, heps = 0.5f * eps, sgn = fwd ? 1.f : -1.f;
   float acc = 0.f;
-  for (int k = 0; k < d; ++k) {
+  for (int k = lane; k < d; k += 64) {
     const float S = expf(w.lam_s[k]) * tanhf(out3[n * 3 * d + k] + w.bs[k]);
     const float T = out3[n * 3 * d + d + k] + w.bt[k];
     const float Q = expf(w.lam_q[k]) * tanhf(out3[n * 3 * d + 2 * d + k] + w.bq[k]);
     const float sv = sgn * heps * S, ES = expf(sv), EQ = expf(eps * Q);
-    const float cc = heps * (T - EQ * g[n * d + k]);
-    const float vi = vin[n * d + k];
-    vout[n * d + k] = fwd ? vi * ES + cc : (vi - cc) * ES;
+    const float cc = heps * (T - EQ * g[n * ldg + k]);
+    const float vi = vin[n * ldvi + k];
+    vout[n * ldvo + k] = fwd ? vi * ES + cc : (vi - cc) * ES;
     acc += sv;
   }
-  ld[n] += acc;
+  acc = wave_sum(acc);
+  if (lane == 0) ld[n] += acc;
 }
 // Masked position update + the masked input of the NEXT net evaluation.  second = 0: keeps
 // k1 = (fwd ? m : 1-m) and emits xin = (1-k1) z'; second = 1: keeps 1-k1.
 // (dynamics.py:131-145 / :176-190)
-__global__ void k_x_half(const float* out3, L2hmcNet w, const float* zin, const float* vh, float* zout,
-                         float* xin_next, float* ld, const float* masks, const unsigned char* dir, int dir_all,
-                         int it, int T, int second, const float* alpha, float eps_host, long long N, int d) {
-  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_x_half(const float* out3, L2hmcNet w, const float* zin, int ldzi,
+                                                const float* vh, int ldvh, float* zout, int ldzo, float* xin_next,
+                                                int ldxn, float* ld, const float* masks, const unsigned char* dir,
+                                                int dir_all, int it, int T, int second, const float* alpha,
+                                                float eps_host, long long N, int d) {
+  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (n >= N) return;
   bool fwd;
   const int s = row_of(dir, dir_all, n, it, T, fwd);
   const float eps = alpha != nullptr ? expf(*alpha) : eps_host, sgn = fwd ? 1.f : -1.f;
   float acc = 0.f;
-  for (int k = 0; k < d; ++k) {
+  for (int k = lane; k < d; k += 64) {
     const float m = masks[s * d + k];
     const float k1 = fwd ? m : 1.f - m;
     const float kp = second ? 1.f - k1 : k1, up = 1.f - kp;
@@ -170,25 +140,28 @@ __global__ void k_x_half(const float* out3, L2hmcNet w, const float* zin, const 
     const float T_ = out3[n * 3 * d + d + k] + w.bt[k];
     const float Q = expf(w.lam_q[k]) * tanhf(out3[n * 3 * d + 2 * d + k] + w.bq[k]);
     const float sx = sgn * eps * S, ES = expf(sx), EQ = expf(eps * Q);
-    const float tr = eps * (EQ * vh[n * d + k] + T_);
-    const float zi = zin[n * d + k];
+    const float tr = eps * (EQ * vh[n * ldvh + k] + T_);
+    const float zi = zin[n * ldzi + k];
     const float nw = fwd ? zi * ES + tr : ES * (zi - tr);
     const float zo = kp * zi + up * nw;
-    zout[n * d + k] = zo;
-    if (xin_next != nullptr) xin_next[n * d + k] = up * zo;      // next kept mask = this update mask
+    zout[n * ldzo + k] = zo;
+    if (xin_next != nullptr) xin_next[n * ldxn + k] = up * zo;      // next kept mask = this update mask
     acc += up * sx;
   }
-  ld[n] += acc;
+  acc = wave_sum(acc);
+  if (lane == 0) ld[n] += acc;
 }
 // xin = k1 * x for the first XNet evaluation of a step
-__global__ void k_mask_first(const float* x, float* xin, const float* masks, const unsigned char* dir, int dir_all,
-                             int it, int T, long long N, int d) {
+__global__ void k_mask_first(const float* x, int ldx, float* xin, int ldxi, const float* masks, const unsigned char* dir,
+                             int dir_all, int it, int T, long long N, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * d) return;
+  const long long n = i / d;
+  const int k = (int)(i % d);
   bool fwd;
-  const int s = row_of(dir, dir_all, i / d, it, T, fwd);
-  const float m = masks[s * d + (int)(i % d)];
-  xin[i] = (fwd ? m : 1.f - m) * x[i];
+  const int s = row_of(dir, dir_all, n, it, T, fwd);
+  const float m = masks[s * d + k];
+  xin[n * ldxi + k] = (fwd ? m : 1.f - m) * x[n * ldx + k];
 }
 __global__ void k_kinetic(const float* v, float* K, float* ld, long long N, int d) {
   const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,17 +172,17 @@ __global__ void k_kinetic(const float* v, float* K, float* ld, long long N, int 
   if (ld != nullptr) ld[n] = 0.f;
 }
 // accept probability (dynamics.py:302-309) + MH select (sampler.py:53-55)
-__global__ void k_finish(const float* U0, const float* K0, const float* U1, const float* K1, const float* ld,
-                         const float* u, const float* x0, const float* x1, float* p_out, float* logjac_out,
+__global__ void k_finish(const double* U0, const float* K0, const double* U1, const float* K1, const float* ld,
+                         const float* u, const float* x0, const float* x1, int ldx1, float* p_out, float* logjac_out,
                          float* x_next, long long N, int d) {
   const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const float p = accept_prob((U0[n] + K0[n]) - (U1[n] + K1[n]) + ld[n]);
+  const float p = accept_prob((float)((U0[n] - U1[n]) + ((double)K0[n] - (double)K1[n]) + (double)ld[n]));
   if (p_out != nullptr) p_out[n] = p;
   if (logjac_out != nullptr) logjac_out[n] = ld[n];
   if (x_next != nullptr) {
     const bool acc = (p - u[n]) >= 0.f;
-    for (int k = 0; k < d; ++k) x_next[n * d + k] = acc ? x1[n * d + k] : x0[n * d + k];
+    for (int k = 0; k < d; ++k) x_next[n * d + k] = acc ? x1[n * ldx1 + k] : x0[n * d + k];
   }
 }
 
@@ -228,55 +201,93 @@ __global__ void k_accept_from_energies(const float* U0, const float* v0, const f
 
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
-struct Mlp3Ws { float *p1, *a1, *p2, *a2; };
+// Workspace slices of one 3-layer MLP evaluation: transposed weights (forward products), activations a1 / a2
+// and their sigmoids s1 / s2 (= softplus', for the input gradient)
+struct Mlp3Ws { float *w1t, *w2t, *w3t, *a1, *s1, *a2, *s2; };
 
-// out (N x n_out) = Linear-softplus-Linear-softplus-Linear(x); pre-activations kept in ws
-int mlp3_forward(rocblas_handle h, hipStream_t s, const L2hmcMlp3& m, const float* x, long long N, const Mlp3Ws& ws,
-                 float* out) {
-  int rc;
-  if ((rc = gemm_rm(h, false, (int)N, m.n_h1, m.n_in, x, m.n_in, m.W1, m.n_h1, ws.p1, m.n_h1, 0.f))) return rc;
-  hipLaunchKernelGGL(k_bias_softplus, dim3(nblk(N * m.n_h1)), dim3(256), 0, s, ws.p1, ws.a1, m.b1, N, m.n_h1);
-  if ((rc = gemm_rm(h, false, (int)N, m.n_h2, m.n_h1, ws.a1, m.n_h1, m.W2, m.n_h2, ws.p2, m.n_h2, 0.f))) return rc;
-  hipLaunchKernelGGL(k_bias_softplus, dim3(nblk(N * m.n_h2)), dim3(256), 0, s, ws.p2, ws.a2, m.b2, N, m.n_h2);
-  if ((rc = gemm_rm(h, false, (int)N, m.n_out, m.n_h2, ws.a2, m.n_h2, m.W3, m.n_out, out, m.n_out, 0.f))) return rc;
-  hipLaunchKernelGGL(k_bias_add, dim3(nblk(N * m.n_out)), dim3(256), 0, s, out, m.b3, N, m.n_out);
-  return L2HMC_OK;
+inline GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, long long M, int N, int K) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.beta = 1.f;
+  return g;
 }
 
-// U (N) and grad (N x d) of the VAE latent posterior at z; lg is an (N x n_pix) scratch
-int vae_energy(rocblas_handle h, hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, long long N,
-               int d, const Mlp3Ws& ws, float* lg, float* U, float* grad, float beta = 1.f) {
-  int rc;
-  if ((rc = mlp3_forward(h, s, dec, z, N, ws, lg))) return rc;
-  hipLaunchKernelGGL(k_vae_out, dim3((unsigned)N), dim3(256), 0, s, lg, aux, z, dec.n_out, d, U, beta);
-  if (grad == nullptr) return L2HMC_OK;
+void mlp3_transposes(hipStream_t s, const L2hmcMlp3& m, const Mlp3Ws& ws) {
+  transpose_into(s, m.W1, m.n_in, m.n_h1, ws.w1t, m.n_in, 0);
+  transpose_into(s, m.W2, m.n_h1, m.n_h2, ws.w2t, m.n_h1, 0);
+  transpose_into(s, m.W3, m.n_h2, m.n_out, ws.w3t, m.n_h2, 0);
+}
+
+// a2 = softplus(softplus(x W1 + b1) W2 + b2)  (sigmoids kept when ws.s1 / ws.s2 are given); x has row stride ldx
+void mlp3_hidden(hipStream_t s, const L2hmcMlp3& m, const float* x, int ldx, long long N, const Mlp3Ws& ws) {
+  GemmArgs g = gemm_args(x, ldx, ws.w1t, m.n_in, ws.a1, m.n_h1, N, m.n_h1, m.n_in);
+  g.bias = m.b1; g.C2 = ws.s1; g.ldc2 = m.n_h1;
+  launch_gemm<EPI_BIAS_SOFTPLUS>(g, s, m.n_in <= 64 ? SHAPE_MID : SHAPE_BIG);
+  g = gemm_args(ws.a1, m.n_h1, ws.w2t, m.n_h1, ws.a2, m.n_h2, N, m.n_h2, m.n_h1);
+  g.bias = m.b2; g.C2 = ws.s2; g.ldc2 = m.n_h2;
+  launch_gemm<EPI_BIAS_SOFTPLUS>(g, s);
+}
+
+// out (N x n_out) = Linear-softplus-Linear-softplus-Linear(x)
+void mlp3_forward(hipStream_t s, const L2hmcMlp3& m, const float* x, long long N, const Mlp3Ws& ws, float* out) {
+  mlp3_hidden(s, m, x, m.n_in, N, ws);
+  GemmArgs g = gemm_args(ws.a2, m.n_h2, ws.w3t, m.n_h2, out, m.n_out, N, m.n_out, m.n_h2);
+  g.bias = m.b3;
+  launch_gemm<EPI_BIAS>(g, s, m.n_out <= 256 ? SHAPE_MID : SHAPE_BIG);
+}
+
+inline int bce_tiles(int n_pix) { return (n_pix + 127) / 128; }     // column tiles of the 128 x 128 shape
+
+// U (N) and grad (N x d, row stride ldg) of the VAE latent posterior at z (row stride ldz) (mnist_vae.py:122-126):
+// six GEMMs, every bias / softplus / sigmoid / BCE / chain-rule product fused into their epilogues; lg (N x n_pix)
+// and rowsum (N x 2 tiles) are scratch.  The transposed decoder weights must already be in ws (mlp3_transposes).
+void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, int ldz, long long N, int d,
+                const Mlp3Ws& ws, float* lg, float* rowsum, float* U, double* Ud, float* grad, int ldg, float beta = 1.f) {
+  mlp3_hidden(s, dec, z, ldz, N, ws);
+  GemmArgs g = gemm_args(ws.a2, dec.n_h2, ws.w3t, dec.n_h2, lg, dec.n_out, N, dec.n_out, dec.n_h2);
+  g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(dec.n_out); g.beta = beta;
+  launch_gemm<EPI_BCE>(g, s);                                     // lg := beta (sigmoid(logit) - aux)
+  if (U != nullptr || Ud != nullptr)
+    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles(dec.n_out), z, ldz, d, U, Ud, N);
+  if (grad == nullptr) return;
   // d a2 = dl W3^T (.) sigmoid(p2);  d a1 = d a2 W2^T (.) sigmoid(p1);  d z = d a1 W1^T + z
-  if ((rc = gemm_rm(h, true, (int)N, dec.n_h2, dec.n_out, lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, 0.f))) return rc;
-  hipLaunchKernelGGL(k_mul_sigmoid, dim3(nblk(N * dec.n_h2)), dim3(256), 0, s, ws.a2, ws.p2, N * dec.n_h2);
-  if ((rc = gemm_rm(h, true, (int)N, dec.n_h1, dec.n_h2, ws.a2, dec.n_h2, dec.W2, dec.n_h2, ws.a1, dec.n_h1, 0.f))) return rc;
-  hipLaunchKernelGGL(k_mul_sigmoid, dim3(nblk(N * dec.n_h1)), dim3(256), 0, s, ws.a1, ws.p1, N * dec.n_h1);
-  if ((rc = gemm_rm(h, true, (int)N, d, dec.n_h1, ws.a1, dec.n_h1, dec.W1, dec.n_h1, grad, d, 0.f))) return rc;
-  hipLaunchKernelGGL(k_add, dim3(nblk(N * d)), dim3(256), 0, s, grad, z, N * d);
-  return L2HMC_OK;
+  g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);
+  g.E = ws.s2; g.lde = dec.n_h2;
+  launch_gemm<EPI_MUL>(g, s);
+  g = gemm_args(ws.a2, dec.n_h2, dec.W2, dec.n_h2, ws.a1, dec.n_h1, N, dec.n_h1, dec.n_h2);
+  g.E = ws.s1; g.lde = dec.n_h1;
+  launch_gemm<EPI_MUL>(g, s);
+  g = gemm_args(ws.a1, dec.n_h1, dec.W1, dec.n_h1, grad, ldg, N, d, dec.n_h1);
+  g.E = z; g.lde = ldz;
+  launch_gemm<EPI_ADD>(g, s, d <= 64 ? SHAPE_SKINNY : SHAPE_MID);
 }
 
 struct SplitPlan {
   long long total;
-  long long xc, vc, g, vh, y, xin, h1, h2, out3, aux_h, tb, U0, K0, U1, K1, ld, p1, a1, p2, a2, lg, e1, e1a, e2, e2a;
+  long long abv, abx, vc, y, h1, h2, out3, aux_h, tb, U0, K0, U1, K1, ld, rowsum, lg;   // abv = [x | grad U], abx = [v_h | masked x]
+  long long dw1t, dw2t, dw3t, a1, s1, a2, s2;                    // decoder
+  long long ew1t, ew2t, ew3t, e1, e2;                            // image branch
+  long long nx12t, nx4t, nxht, nv12t, nv4t, nvht;                // S/T/Q nets: [W1; W2]^T, W4^T, [Ws | Wt | Wq]^T
 };
 
 SplitPlan plan_split(long long N, int d, int H, int T, const L2hmcMlp3* enc, const L2hmcMlp3* dec) {
   SplitPlan p;
   long long o = 0;
   auto take = [&](long long n) { const long long at = o; o += (n + 3) & ~3LL; return at; };
-  p.xc = take(N * d); p.vc = take(N * d); p.g = take(N * d); p.vh = take(N * d); p.y = take(N * d);
-  p.xin = take(N * d); p.h1 = take(N * H); p.h2 = take(N * H); p.out3 = take(N * 3 * d);
+  p.abv = take(N * 2 * d); p.abx = take(N * 2 * d); p.vc = take(N * d); p.y = take(N * d);
+  p.h1 = take(N * H); p.h2 = take(N * H); p.out3 = take(N * 3 * d);
   p.aux_h = take(enc ? N * H : 0); p.tb = take(2LL * T * H);
-  p.U0 = take(N); p.K0 = take(N); p.U1 = take(N); p.K1 = take(N); p.ld = take(N);
-  p.p1 = take(N * dec->n_h1); p.a1 = take(N * dec->n_h1); p.p2 = take(N * dec->n_h2); p.a2 = take(N * dec->n_h2);
+  p.U0 = take(2 * N); p.K0 = take(N); p.U1 = take(2 * N); p.K1 = take(N); p.ld = take(N);      // U0 / U1: doubles
+  p.rowsum = take(N * 2 * bce_tiles(dec->n_out));
   p.lg = take(N * dec->n_out);
-  p.e1 = take(enc ? N * enc->n_h1 : 0); p.e1a = take(enc ? N * enc->n_h1 : 0);
-  p.e2 = take(enc ? N * enc->n_h2 : 0); p.e2a = take(enc ? N * enc->n_h2 : 0);
+  p.dw1t = take((long long)dec->n_in * dec->n_h1); p.dw2t = take((long long)dec->n_h1 * dec->n_h2);
+  p.dw3t = take((long long)dec->n_h2 * dec->n_out);
+  p.a1 = take(N * dec->n_h1); p.s1 = take(N * dec->n_h1); p.a2 = take(N * dec->n_h2); p.s2 = take(N * dec->n_h2);
+  p.ew1t = take(enc ? (long long)enc->n_in * enc->n_h1 : 0); p.ew2t = take(enc ? (long long)enc->n_h1 * enc->n_h2 : 0);
+  p.ew3t = take(enc ? (long long)enc->n_h2 * enc->n_out : 0);
+  p.e1 = take(enc ? N * enc->n_h1 : 0); p.e2 = take(enc ? N * enc->n_h2 : 0);
+  p.nx12t = take(2LL * d * H); p.nx4t = take((long long)H * H); p.nxht = take(3LL * d * H);
+  p.nv12t = take(2LL * d * H); p.nv4t = take((long long)H * H); p.nvht = take(3LL * d * H);
   p.total = o;
   return p;
 }
@@ -309,12 +320,11 @@ int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x,
   const float beta = bce_scale > 0.f ? bce_scale : 1.f;
   if (n_chains == 0) return L2HMC_OK;
   hipStream_t s = (hipStream_t)stream;
-  rocblas_handle h;
-  if ((rc = blas_handle(s, &h))) return rc;
   const SplitPlan p = plan_split(n_chains, d, 1, 1, nullptr, decoder);
   float* w = workspace;
-  const Mlp3Ws ws = {w + p.p1, w + p.a1, w + p.p2, w + p.a2};
-  if ((rc = vae_energy(h, s, *decoder, aux, x, n_chains, d, ws, w + p.lg, U_out, grad_out, beta))) return rc;
+  const Mlp3Ws ws = {w + p.dw1t, w + p.dw2t, w + p.dw3t, w + p.a1, w + p.s1, w + p.a2, w + p.s2};
+  mlp3_transposes(s, *decoder, ws);
+  vae_energy(s, *decoder, aux, x, d, n_chains, d, ws, w + p.lg, w + p.rowsum, U_out, nullptr, grad_out, d, beta);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;
@@ -357,73 +367,92 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   const SplitPlan p = plan_split(N, d, H, T, a->aux_encoder, a->decoder);
   if (a->workspace_floats < p.total) return fail(L2HMC_ERR_ARG, "workspace too small: need %s%lld floats", "", p.total);
   hipStream_t s = (hipStream_t)stream;
-  rocblas_handle h;
-  if ((rc = blas_handle(s, &h))) return rc;
   float* w = a->workspace;
-  const Mlp3Ws dws = {w + p.p1, w + p.a1, w + p.p2, w + p.a2};
-  float *xc = w + p.xc, *vc = w + p.vc, *g = w + p.g, *vh = w + p.vh, *y = w + p.y, *xin = w + p.xin;
+  const L2hmcMlp3& dec = *a->decoder;
+  const Mlp3Ws dws = {w + p.dw1t, w + p.dw2t, w + p.dw3t, w + p.a1, w + p.s1, w + p.a2, w + p.s2};
+  // [x | grad U] and [v_h | masked x] live side by side (row stride L = 2 d): they are the first-layer inputs
+  const int L = 2 * d;
+  float *xc = w + p.abv, *g = w + p.abv + d, *vh = w + p.abx, *xin = w + p.abx + d, *vc = w + p.vc, *y = w + p.y;
   float *h1 = w + p.h1, *h2 = w + p.h2, *out3 = w + p.out3, *tb = w + p.tb, *ld = w + p.ld;
   float* aux_h = a->aux_encoder ? w + p.aux_h : nullptr;
   static const L2hmcNet no_net = {};
   const L2hmcNet &xn = hmc ? no_net : *a->xnet, &vn = hmc ? no_net : *a->vnet;
   const unsigned char* dir = a->direction;
   const int dall = a->direction_all;
+  const unsigned nw4 = (unsigned)((N + 3) / 4);                  // one wave per chain, 4 per workgroup
 
-  (void)hipMemcpyAsync(xc, a->x, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
+  (void)hipMemcpy2DAsync(xc, sizeof(float) * L, a->x, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
   (void)hipMemcpyAsync(vc, a->v, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
+  mlp3_transposes(s, dec, dws);
   if (a->aux_encoder && !hmc) {      // the image branch is step-invariant: once per trajectory, not 4T times
-    const Mlp3Ws ews = {w + p.e1, w + p.e1a, w + p.e2, w + p.e2a};
-    if ((rc = mlp3_forward(h, s, *a->aux_encoder, a->aux, N, ews, aux_h))) return rc;
+    const L2hmcMlp3& enc = *a->aux_encoder;
+    const Mlp3Ws ews = {w + p.ew1t, w + p.ew2t, w + p.ew3t, w + p.e1, nullptr, w + p.e2, nullptr};
+    mlp3_transposes(s, enc, ews);
+    mlp3_forward(s, enc, a->aux, N, ews, aux_h);
   }
-  if (!hmc) hipLaunchKernelGGL(k_time_table, dim3(nblk(2LL * T * H)), dim3(256), 0, s, xn, vn, a->trig, T, H, tb);
+  if (!hmc) {
+    hipLaunchKernelGGL(k_time_table, dim3(nblk(2LL * T * H)), dim3(256), 0, s, xn, vn, a->trig, T, H, tb);
+    // per net: [W1; W2]^T (H x 2d), W4^T (H x H), [Ws | Wt | Wq]^T (3d x H)
+    const L2hmcNet* nets[2] = {&xn, &vn};
+    float* w12t[2] = {w + p.nx12t, w + p.nv12t};
+    float* w4t[2] = {w + p.nx4t, w + p.nv4t};
+    float* wht[2] = {w + p.nxht, w + p.nvht};
+    for (int i = 0; i < 2; ++i) {
+      transpose_into(s, nets[i]->W1, d, H, w12t[i], L, 0);
+      transpose_into(s, nets[i]->W2, d, H, w12t[i], L, d);
+      transpose_into(s, nets[i]->W4, H, H, w4t[i], H, 0);
+      transpose_into(s, nets[i]->Ws, H, d, wht[i], H, 0);
+      transpose_into(s, nets[i]->Wt, H, d, wht[i] + (long long)d * H, H, 0);
+      transpose_into(s, nets[i]->Wq, H, d, wht[i] + 2LL * d * H, H, 0);
+    }
+  }
   hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, vc, w + p.K0, ld, N, d);
-  if ((rc = vae_energy(h, s, *a->decoder, a->aux, xc, N, d, dws, w + p.lg, w + p.U0, g, beta))) return rc;
-  if (a->n_steps == 0) (void)hipMemcpyAsync(w + p.U1, w + p.U0, sizeof(float) * N, hipMemcpyDeviceToDevice, s);
+  double *U0d = reinterpret_cast<double*>(w + p.U0), *U1d = reinterpret_cast<double*>(w + p.U1);
+  vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, U0d, g, L, beta);
+  if (a->n_steps == 0) (void)hipMemcpyAsync(U1d, U0d, sizeof(double) * N, hipMemcpyDeviceToDevice, s);
 
-  // one net evaluation: out3 = relu(relu(a W1 + b W2 + time + aux_h) W4 + b4) [Ws|Wt|Wq]
-  auto net_eval = [&](const L2hmcNet& nw, int net, const float* ain, const float* bin, int it) -> int {
-    int r;
-    if ((r = gemm_rm(h, false, (int)N, H, d, ain, d, nw.W1, H, h1, H, 0.f))) return r;
-    if ((r = gemm_rm(h, false, (int)N, H, d, bin, d, nw.W2, H, h1, H, 1.f))) return r;
-    hipLaunchKernelGGL(k_layer1, dim3(nblk(N * H)), dim3(256), 0, s, h1, tb + (long long)net * T * H, aux_h, dir, dall,
-                       it, T, N, H);
-    if ((r = gemm_rm(h, false, (int)N, H, H, h1, H, nw.W4, H, h2, H, 0.f))) return r;
-    hipLaunchKernelGGL(k_bias_relu, dim3(nblk(N * H)), dim3(256), 0, s, h2, nw.b4, N, H);
-    if ((r = gemm_rm(h, false, (int)N, d, H, h2, H, nw.Ws, d, out3, 3 * d, 0.f))) return r;
-    if ((r = gemm_rm(h, false, (int)N, d, H, h2, H, nw.Wt, d, out3 + d, 3 * d, 0.f))) return r;
-    if ((r = gemm_rm(h, false, (int)N, d, H, h2, H, nw.Wq, d, out3 + 2 * d, 3 * d, 0.f))) return r;
-    return L2HMC_OK;
+  // one net evaluation: out3 = relu(relu([a | b] [W1; W2] + time + aux_h) W4 + b4) [Ws|Wt|Wq]   (the head biases are
+  // added by the update kernels): three GEMMs with fused epilogues on 64 x 64 tiles (M = 8192, N = 200: 512 tiles)
+  auto net_eval = [&](const L2hmcNet& nw, int net, const float* ab, int it) {
+    GemmArgs ga = gemm_args(ab, L, w + (net == 0 ? p.nx12t : p.nv12t), L, h1, H, N, H, L);
+    ga.E = aux_h; ga.lde = H; ga.tb = tb + (long long)net * T * H; ga.dir = dir; ga.dir_all = dall; ga.it = it; ga.T = T;
+    launch_gemm<EPI_NET1>(ga, s, SHAPE_MID);
+    ga = gemm_args(h1, H, w + (net == 0 ? p.nx4t : p.nv4t), H, h2, H, N, H, H);
+    ga.bias = nw.b4;
+    launch_gemm<EPI_BIAS_RELU>(ga, s, SHAPE_MID);
+    ga = gemm_args(h2, H, w + (net == 0 ? p.nxht : p.nvht), H, out3, 3 * d, N, 3 * d, H);
+    launch_gemm<EPI_BIAS>(ga, s, SHAPE_MID);
   };
 
   for (int k = 0; k < a->n_steps; ++k) {
     const int it = a->step_begin + k;
     const bool last = k == a->n_steps - 1;
     if (hmc) {
-      hipLaunchKernelGGL(k_hmc_drift, dim3(nblk(N * d)), dim3(256), 0, s, xc, vc, g, vh, a->alpha, a->eps_host, N * d);
-      if ((rc = vae_energy(h, s, *a->decoder, a->aux, xc, N, d, dws, w + p.lg, last ? w + p.U1 : nullptr, g, beta))) return rc;
-      hipLaunchKernelGGL(k_hmc_kick, dim3(nblk(N * d)), dim3(256), 0, s, vc, vh, g, a->alpha, a->eps_host, N * d);
+      hipLaunchKernelGGL(k_hmc_drift, dim3(nblk(N * d)), dim3(256), 0, s, xc, L, vc, g, L, y, a->alpha, a->eps_host, N, d);
+      vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, last ? U1d : nullptr, g, L, beta);
+      hipLaunchKernelGGL(k_hmc_kick, dim3(nblk(N * d)), dim3(256), 0, s, vc, y, g, L, a->alpha, a->eps_host, N, d);
       continue;
     }
-    if ((rc = net_eval(vn, 1, xc, g, it))) return rc;
-    hipLaunchKernelGGL(k_v_half, dim3(nblk(N)), dim3(256), 0, s, out3, vn, vc, g, vh, ld, dir, dall, a->alpha,
+    net_eval(vn, 1, xc, it);
+    hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, out3, vn, vc, d, g, L, vh, L, ld, dir, dall, a->alpha,
                        a->eps_host, N, d);
-    hipLaunchKernelGGL(k_mask_first, dim3(nblk(N * d)), dim3(256), 0, s, xc, xin, a->masks, dir, dall, it, T, N, d);
-    if ((rc = net_eval(xn, 0, vh, xin, it))) return rc;
-    hipLaunchKernelGGL(k_x_half, dim3(nblk(N)), dim3(256), 0, s, out3, xn, xc, vh, y, xin, ld, a->masks, dir, dall, it, T,
-                       0, a->alpha, a->eps_host, N, d);
-    if ((rc = net_eval(xn, 0, vh, xin, it))) return rc;
-    hipLaunchKernelGGL(k_x_half, dim3(nblk(N)), dim3(256), 0, s, out3, xn, y, vh, xc, (float*)nullptr, ld, a->masks, dir,
-                       dall, it, T, 1, a->alpha, a->eps_host, N, d);
-    if ((rc = vae_energy(h, s, *a->decoder, a->aux, xc, N, d, dws, w + p.lg, last ? w + p.U1 : nullptr, g, beta))) return rc;
-    if ((rc = net_eval(vn, 1, xc, g, it))) return rc;
-    hipLaunchKernelGGL(k_v_half, dim3(nblk(N)), dim3(256), 0, s, out3, vn, vh, g, vc, ld, dir, dall, a->alpha,
+    hipLaunchKernelGGL(k_mask_first, dim3(nblk(N * d)), dim3(256), 0, s, xc, L, xin, L, a->masks, dir, dall, it, T, N, d);
+    net_eval(xn, 0, vh, it);
+    hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, out3, xn, xc, L, vh, L, y, d, xin, L, ld, a->masks, dir,
+                       dall, it, T, 0, a->alpha, a->eps_host, N, d);
+    net_eval(xn, 0, vh, it);
+    hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, out3, xn, y, d, vh, L, xc, L, (float*)nullptr, 0, ld,
+                       a->masks, dir, dall, it, T, 1, a->alpha, a->eps_host, N, d);
+    vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, last ? U1d : nullptr, g, L, beta);
+    net_eval(vn, 1, xc, it);
+    hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, out3, vn, vh, L, g, L, vc, d, ld, dir, dall, a->alpha,
                        a->eps_host, N, d);
   }
   hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, vc, w + p.K1, (float*)nullptr, N, d);
-  if (a->x_out) (void)hipMemcpyAsync(a->x_out, xc, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
+  if (a->x_out) (void)hipMemcpy2DAsync(a->x_out, sizeof(float) * d, xc, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
   if (a->v_out) (void)hipMemcpyAsync(a->v_out, vc, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(k_finish, dim3(nblk(N)), dim3(256), 0, s, w + p.U0, w + p.K0, w + p.U1, w + p.K1, ld, a->u, a->x,
-                     xc, a->p_out, a->logjac_out, a->x_next, N, d);
+  hipLaunchKernelGGL(k_finish, dim3(nblk(N)), dim3(256), 0, s, U0d, w + p.K0, U1d, w + p.K1, ld, a->u, a->x,
+                     xc, L, a->p_out, a->logjac_out, a->x_next, N, d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;

@@ -39,7 +39,7 @@ def build(tag, flags):
         "long long plan_lds_wide(KArgs&) { return 1LL << 40; }\n"
         "int launch_wide(const KArgs&, int, long long, hipStream_t) { return -2; }\n}\n")
     r = subprocess.run(["timeout", "600", "/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
-                        "-Wno-return-type", "-shared", "-o", out, "-L/opt/rocm/lib", "-lrocblas",
+                        "-Wno-return-type", "-shared", "-o", out,
                         "-Wl,-rpath,/opt/rocm/lib"] + flags + srcs + [stub])
     return out if r.returncode == 0 else None
 

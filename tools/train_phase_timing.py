@@ -22,7 +22,7 @@ def main():
                                                 "traj_ek4.hip", "traj_ek5.hip", "traj_wide.hip", "train.hip", "split.hip")]
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
                         "-DL2HMC_TRAIN_TIMING", "-Wno-return-type", "-Wno-pass-failed", "-shared", "-o", OUT] + srcs
-                       + ["-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+                       + [], check=True)
         return
     from l2hmc_amd import _ffi
     _ffi.LIB_PATH = OUT
