@@ -193,7 +193,8 @@ typedef struct L2hmcMlp3 {
  *   nets    the S/T/Q architecture with ANY hidden width H and, if aux_encoder != NULL, the 4th Zip
  *           branch aux_encoder(aux) added into the first hidden layer (mnist_vae.py:142-167);
  *           RAW reference-layout weights (not the packed buffer).
- * The dense products run in rocBLAS (fp32), everything else in this library's kernels. */
+ * The dense products run in this library's own fp32 MFMA GEMM (csrc/gemm_f32.hpp) with the bias / softplus /
+ * sigmoid / relu / BCE-gradient / chain-rule work fused into its epilogues; no BLAS library is used. */
 typedef struct L2hmcSplitArgs {
   const L2hmcNet* xnet;
   const L2hmcNet* vnet;
@@ -219,6 +220,10 @@ typedef struct L2hmcSplitArgs {
                                   *    only; xnet / vnet / masks / trig / aux_encoder are ignored         */
   float bce_scale;               /* AIS bridge from N(0, I) (ais.py:46-47, eval_vae.py:55-62): the BCE term
                                   *    of the energy is scaled by beta in (0, 1); 0 (or 1) = off          */
+  const L2hmcEnergy* energy;     /* NULL: the decoder posterior above.  Else one of the built-in targets of
+                                  *    utils/distributions.py (decoder / aux / aux_encoder = NULL): the S/T/Q
+                                  *    nets of ANY width H on the GEMM engine, grad U from l2hmc_energy's kernels
+                                  *    (SCGExperiment.ipynb `network` with H != 10)                       */
 } L2hmcSplitArgs;
 
 int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,

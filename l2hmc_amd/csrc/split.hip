@@ -201,6 +201,11 @@ __global__ void k_accept_from_energies(const float* U0, const float* v0, const f
 
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
+__global__ void k_f2d(const float* a, double* b, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = (double)a[i];
+}
+
 // Workspace slices of one 3-layer MLP evaluation: transposed weights (forward products), activations a1 / a2
 // and their sigmoids s1 / s2 (= softplus', for the input gradient)
 struct Mlp3Ws { float *w1t, *w2t, *w3t, *a1, *s1, *a2, *s2; };
@@ -265,6 +270,7 @@ void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const flo
 struct SplitPlan {
   long long total;
   long long abv, abx, vc, y, h1, h2, out3, aux_h, tb, U0, K0, U1, K1, ld, rowsum, lg;   // abv = [x | grad U], abx = [v_h | masked x]
+  long long xp, gp, uf;                                          // built-in energies: contiguous x, grad U, fp32 U
   long long dw1t, dw2t, dw3t, a1, s1, a2, s2;                    // decoder
   long long ew1t, ew2t, ew3t, e1, e2;                            // image branch
   long long nx12t, nx4t, nxht, nv12t, nv4t, nvht;                // S/T/Q nets: [W1; W2]^T, W4^T, [Ws | Wt | Wq]^T
@@ -278,11 +284,13 @@ SplitPlan plan_split(long long N, int d, int H, int T, const L2hmcMlp3* enc, con
   p.h1 = take(N * H); p.h2 = take(N * H); p.out3 = take(N * 3 * d);
   p.aux_h = take(enc ? N * H : 0); p.tb = take(2LL * T * H);
   p.U0 = take(2 * N); p.K0 = take(N); p.U1 = take(2 * N); p.K1 = take(N); p.ld = take(N);      // U0 / U1: doubles
-  p.rowsum = take(N * 2 * bce_tiles(dec->n_out));
-  p.lg = take(N * dec->n_out);
-  p.dw1t = take((long long)dec->n_in * dec->n_h1); p.dw2t = take((long long)dec->n_h1 * dec->n_h2);
-  p.dw3t = take((long long)dec->n_h2 * dec->n_out);
-  p.a1 = take(N * dec->n_h1); p.s1 = take(N * dec->n_h1); p.a2 = take(N * dec->n_h2); p.s2 = take(N * dec->n_h2);
+  p.rowsum = take(dec ? N * 2 * bce_tiles(dec->n_out) : 0);
+  p.lg = take(dec ? N * dec->n_out : 0);
+  p.dw1t = take(dec ? (long long)dec->n_in * dec->n_h1 : 0); p.dw2t = take(dec ? (long long)dec->n_h1 * dec->n_h2 : 0);
+  p.dw3t = take(dec ? (long long)dec->n_h2 * dec->n_out : 0);
+  p.a1 = take(dec ? N * dec->n_h1 : 0); p.s1 = take(dec ? N * dec->n_h1 : 0);
+  p.a2 = take(dec ? N * dec->n_h2 : 0); p.s2 = take(dec ? N * dec->n_h2 : 0);
+  p.xp = take(dec ? 0 : N * d); p.gp = take(dec ? 0 : N * d); p.uf = take(dec ? 0 : N);
   p.ew1t = take(enc ? (long long)enc->n_in * enc->n_h1 : 0); p.ew2t = take(enc ? (long long)enc->n_h1 * enc->n_h2 : 0);
   p.ew3t = take(enc ? (long long)enc->n_h2 * enc->n_out : 0);
   p.e1 = take(enc ? N * enc->n_h1 : 0); p.e2 = take(enc ? N * enc->n_h2 : 0);
@@ -307,7 +315,7 @@ extern "C" {
 
 int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,
                                      const L2hmcMlp3* aux_encoder, const L2hmcMlp3* decoder) {
-  if (n_chains < 0 || d < 1 || H < 1 || T < 1 || !decoder) return fail(L2HMC_ERR_ARG, "l2hmc_split_workspace_floats: bad argument%s");
+  if (n_chains < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "l2hmc_split_workspace_floats: bad argument%s");
   return plan_split(n_chains, d, H, T, aux_encoder, decoder).total;
 }
 
@@ -344,21 +352,29 @@ int l2hmc_p_accept_energies(const float* U0, const float* v0, const float* U1, c
 
 int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
-  int rc = check_mlp(a->decoder, "decoder");
-  if (rc) return rc;
+  const bool builtin = a->energy != nullptr;        // a target of utils/distributions.py instead of the decoder posterior
+  int rc;
+  if (builtin) {
+    if (a->decoder || a->aux_encoder || a->hmc)
+      return fail(L2HMC_ERR_UNSUPPORTED, "a built-in energy excludes decoder / aux_encoder / hmc (HMC mode runs on l2hmc_trajectory)%s");
+    if ((rc = check_energy(a->energy, a->d))) return rc;
+    if (a->energy->temperature != 1.f) return fail(L2HMC_ERR_UNSUPPORTED, "temperature != 1 with wide nets%s");
+  } else if ((rc = check_mlp(a->decoder, "decoder"))) {
+    return rc;
+  }
   if (a->aux_encoder && (rc = check_mlp(a->aux_encoder, "aux_encoder"))) return rc;
   const long long N = a->n_chains;
   const int d = a->d, H = a->H, T = a->T;
   if (N < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
   if (N == 0) return L2HMC_OK;
   const bool hmc = a->hmc != 0;
-  if ((!hmc && (!a->xnet || !a->vnet || !a->masks || !a->trig)) || !a->aux || !a->x || !a->v || !a->workspace)
+  if ((!hmc && (!a->xnet || !a->vnet || !a->masks || !a->trig)) || (!builtin && !a->aux) || !a->x || !a->v || !a->workspace)
     return fail(L2HMC_ERR_ARG, "l2hmc_trajectory_split: NULL pointer%s");
   if (hmc && (a->direction != nullptr || a->direction_all == 0))
     return fail(L2HMC_ERR_UNSUPPORTED, "HMC mode runs forward only (sampler.py:29-31, ais.py:61)%s");
   if (!(a->bce_scale >= 0.f && a->bce_scale <= 1.f)) return fail(L2HMC_ERR_ARG, "bce_scale must be in [0, 1] (0 = off)%s");
   const float beta = a->bce_scale > 0.f ? a->bce_scale : 1.f;
-  if (a->decoder->n_in != d) return fail(L2HMC_ERR_ARG, "decoder input width != d%s");
+  if (!builtin && a->decoder->n_in != d) return fail(L2HMC_ERR_ARG, "decoder input width != d%s");
   if (a->aux_encoder && (a->aux_encoder->n_out != H || a->aux_encoder->n_in != a->decoder->n_out))
     return fail(L2HMC_ERR_ARG, "aux_encoder must map (N, n_pix) -> (N, H)%s");
   if (a->step_begin < 0 || a->n_steps < 0 || a->step_begin + a->n_steps > T) return fail(L2HMC_ERR_ARG, "steps outside the schedule%s");
@@ -368,7 +384,8 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (a->workspace_floats < p.total) return fail(L2HMC_ERR_ARG, "workspace too small: need %s%lld floats", "", p.total);
   hipStream_t s = (hipStream_t)stream;
   float* w = a->workspace;
-  const L2hmcMlp3& dec = *a->decoder;
+  static const L2hmcMlp3 no_dec = {};
+  const L2hmcMlp3& dec = builtin ? no_dec : *a->decoder;
   const Mlp3Ws dws = {w + p.dw1t, w + p.dw2t, w + p.dw3t, w + p.a1, w + p.s1, w + p.a2, w + p.s2};
   // [x | grad U] and [v_h | masked x] live side by side (row stride L = 2 d): they are the first-layer inputs
   const int L = 2 * d;
@@ -383,7 +400,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
 
   (void)hipMemcpy2DAsync(xc, sizeof(float) * L, a->x, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
   (void)hipMemcpyAsync(vc, a->v, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
-  mlp3_transposes(s, dec, dws);
+  if (!builtin) mlp3_transposes(s, dec, dws);
   if (a->aux_encoder && !hmc) {      // the image branch is step-invariant: once per trajectory, not 4T times
     const L2hmcMlp3& enc = *a->aux_encoder;
     const Mlp3Ws ews = {w + p.ew1t, w + p.ew2t, w + p.ew3t, w + p.e1, nullptr, w + p.e2, nullptr};
@@ -408,7 +425,21 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   }
   hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, vc, w + p.K0, ld, N, d);
   double *U0d = reinterpret_cast<double*>(w + p.U0), *U1d = reinterpret_cast<double*>(w + p.U1);
-  vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, U0d, g, L, beta);
+  // U (double, optional) and grad U at the current x: the decoder posterior (six GEMMs) or one of the built-in
+  // targets (the fused kernels' own energy kernel on a contiguous copy of x)
+  auto energy_eval = [&](double* Ud) -> int {
+    if (!builtin) {
+      vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, Ud, g, L, beta);
+      return L2HMC_OK;
+    }
+    (void)hipMemcpy2DAsync(w + p.xp, sizeof(float) * d, xc, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
+    const int r = l2hmc_energy(a->energy, w + p.xp, N, d, Ud ? w + p.uf : nullptr, w + p.gp, stream);
+    if (r) return r;
+    (void)hipMemcpy2DAsync(g, sizeof(float) * L, w + p.gp, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
+    if (Ud) hipLaunchKernelGGL(k_f2d, dim3(nblk(N)), dim3(256), 0, s, w + p.uf, Ud, N);
+    return L2HMC_OK;
+  };
+  if ((rc = energy_eval(U0d))) return rc;
   if (a->n_steps == 0) (void)hipMemcpyAsync(U1d, U0d, sizeof(double) * N, hipMemcpyDeviceToDevice, s);
 
   // one net evaluation: out3 = relu(relu([a | b] [W1; W2] + time + aux_h) W4 + b4) [Ws|Wt|Wq]   (the head biases are
@@ -429,7 +460,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     const bool last = k == a->n_steps - 1;
     if (hmc) {
       hipLaunchKernelGGL(k_hmc_drift, dim3(nblk(N * d)), dim3(256), 0, s, xc, L, vc, g, L, y, a->alpha, a->eps_host, N, d);
-      vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, last ? U1d : nullptr, g, L, beta);
+      if ((rc = energy_eval(last ? U1d : nullptr))) return rc;
       hipLaunchKernelGGL(k_hmc_kick, dim3(nblk(N * d)), dim3(256), 0, s, vc, y, g, L, a->alpha, a->eps_host, N, d);
       continue;
     }
@@ -443,7 +474,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     net_eval(xn, 0, vh, it);
     hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, out3, xn, y, d, vh, L, xc, L, (float*)nullptr, 0, ld,
                        a->masks, dir, dall, it, T, 1, a->alpha, a->eps_host, N, d);
-    vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, last ? U1d : nullptr, g, L, beta);
+    if ((rc = energy_eval(last ? U1d : nullptr))) return rc;
     net_eval(vn, 1, xc, it);
     hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, out3, vn, vh, L, g, L, vc, d, ld, dir, dall, a->alpha,
                        a->eps_host, N, d);

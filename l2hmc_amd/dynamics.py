@@ -105,12 +105,15 @@ class Dynamics(object):
         self._packed_key = None
         # Engine choice: the single fused kernel covers the built-in targets with H <= 15 and no
         # image branch; everything else (VAE posterior, wide nets, encoder_sampler(aux) branch) runs
-        # on the split engine (rocBLAS products + HIP update kernels) of the same library.
+        # on the split engine (own fp32 MFMA GEMMs with fused epilogues + update kernels) of the same library.
         from .vae import ENERGY_VAE
-        self._split = energy_function.kind == ENERGY_VAE
-        if not self._split and not self.hmc and (self.H > 15 or self._xw['aux_encoder'] is not None):
-            raise NotImplementedError("H > 15 or an aux branch needs the split engine, which currently "
-                                      "implements the VAE posterior energy only")
+        # _vae: image-conditioned decoder posterior (needs aux=); _split: trajectories run on the GEMM engine
+        # (`l2hmc_trajectory_split`) -- the VAE posterior, and the built-in targets whenever the nets are wider than
+        # the fused kernel's H <= 15 (nb:51-78 with H != 10; mnist_vae.py:142-167 uses 200)
+        self._vae = energy_function.kind == ENERGY_VAE
+        self._split = self._vae or (not self.hmc and self.H > 15)
+        if not self._vae and not self.hmc and self._xw['aux_encoder'] is not None:
+            raise NotImplementedError("an aux (image) branch is only implemented together with the VAE posterior energy")
         self._split_ws = None
 
     # ---- masks / time encoding -----------------------------------------------------------------
@@ -200,7 +203,7 @@ class Dynamics(object):
 
     # ---- the fused trajectory ----------------------------------------------------------------------
     def _check_aux(self, aux):
-        if self._split:
+        if self._vae:
             if aux is None:
                 raise ValueError("this Dynamics is image-conditioned (mnist_vae.py): pass aux=")
         elif aux is not None:
@@ -212,10 +215,13 @@ class Dynamics(object):
         from .vae import mlp3_struct
         x = as_device_f32(x, self.device)
         v = as_device_f32(v, self.device)
-        aux = as_device_f32(aux, self.device)
         N, d = x.shape
-        if v.shape != x.shape or d != self.x_dim or aux.shape != (N, self._fn.n_pix):
-            raise ValueError("x, v must be (N, %d) and aux (N, %d)" % (self.x_dim, self._fn.n_pix))
+        if v.shape != x.shape or d != self.x_dim:
+            raise ValueError("x, v must be (N, %d)" % self.x_dim)
+        if self._vae:
+            aux = as_device_f32(aux, self.device)
+            if aux.shape != (N, self._fn.n_pix):
+                raise ValueError("aux must be (N, %d)" % self._fn.n_pix)
         out = {}
         for k in ('x', 'v', 'x_next'):
             if k in want:
@@ -229,7 +235,7 @@ class Dynamics(object):
             direction = direction.to(device=x.device, dtype=torch.uint8).contiguous()
         if u is not None:
             u = as_device_f32(u, self.device)
-        dec = mlp3_struct(self._fn.decoder)
+        dec = mlp3_struct(self._fn.decoder) if self._vae else None
         if self.hmc:
             if direction is not None or not direction_all:
                 raise NotImplementedError("HMC mode runs forward only")
@@ -240,7 +246,8 @@ class Dynamics(object):
             enc = mlp3_struct(self._xw['aux_encoder']) if self._xw['aux_encoder'] is not None else None
         L = _ffi.lib()
         need = _ffi.check(L.l2hmc_split_workspace_floats(N, d, max(self.H, 1), self.T,
-                                                         C.byref(enc) if enc is not None else None, C.byref(dec)))
+                                                         C.byref(enc) if enc is not None else None,
+                                                         C.byref(dec) if dec is not None else None))
         if self._split_ws is None or self._split_ws.numel() < need:
             self._split_ws = torch.empty(int(need), dtype=torch.float32, device=self.device)
         a = _ffi.L2hmcSplitArgs()
@@ -248,7 +255,13 @@ class Dynamics(object):
         a.vnet = C.pointer(vs) if vs is not None else None
         a.H, a.hmc, a.bce_scale = max(self.H, 1), int(self.hmc), float(self.anneal_beta)
         a.aux_encoder = C.pointer(enc) if enc is not None else None
-        a.decoder, a.aux = C.pointer(dec), aux.data_ptr()
+        if self._vae:
+            a.decoder, a.aux = C.pointer(dec), aux.data_ptr()
+        else:                                        # built-in target (utils/distributions.py) under wide nets
+            if self.use_temperature and float(self.temperature) != 1.0:
+                raise NotImplementedError("temperature with H > 15 nets is not implemented")
+            en = self._fn.c_struct(x.device, 1.0, self.anneal_beta)
+            a.energy = C.pointer(en)
         a.masks, a.trig = self._mask.data_ptr(), self._trig.data_ptr()
         if self.eps_override is None:
             a.alpha, a.eps_host = self.alpha.data_ptr(), 0.0
@@ -262,6 +275,55 @@ class Dynamics(object):
         a.logjac_out, a.p_out, a.x_next = _ffi.ptr(out.get('logjac')), _ffi.ptr(out.get('p')), _ffi.ptr(out.get('x_next'))
         a.workspace, a.workspace_floats = self._split_ws.data_ptr(), self._split_ws.numel()
         _ffi.check(L.l2hmc_trajectory_split(a, _ffi.current_stream(x.device)))
+        return out
+
+    def _run_split_chain(self, x, v, step_begin, n_steps, direction, direction_all, u, want, M, rng, aux):
+        """M chained proposals on the split engine (the sampler loop of mnist_vae.py:185-224 / eval_sampler.py): a
+        proposal there is milliseconds of GEMM work, so the loop stays on the host -- per proposal one
+        `l2hmc_rng_fill` (the library's Philox stream: same draws as the fused kernels' in-kernel RNG, keyed by
+        proposal index and GLOBAL chain index) and one `l2hmc_trajectory_split`; nothing is copied to the host."""
+        x = as_device_f32(x, self.device)
+        N, d = x.shape
+        L = _ffi.lib()
+        if 'x_next' not in want:
+            raise ValueError("chained proposals need want=('x_next', ...): the MH step links them")
+        need_u = u is None
+        if rng is None and (v is None or need_u):
+            raise ValueError("v and u are required unless rng= is given")
+        ps, ljs, hist = [], [], []
+        o = None
+        for m in range(M):
+            vm = None if v is None else (v[m] if M > 1 else v)
+            um = None if u is None else (u[m] if M > 1 else u)
+            dm = None if direction is None else (direction[m] if M > 1 else direction)
+            if rng is not None and (vm is None or um is None or (dm is None and not self.hmc and rng.get('direction', True))):
+                fv = torch.empty((N, d), dtype=torch.float32, device=self.device) if vm is None else None
+                fd = (torch.empty(N, dtype=torch.uint8, device=self.device)
+                      if (dm is None and not self.hmc and rng.get('direction', True)) else None)
+                fu = torch.empty(N, dtype=torch.float32, device=self.device) if um is None else None
+                _ffi.check(L.l2hmc_rng_fill(int(rng['seed']) & 0xFFFFFFFFFFFFFFFF, int(rng.get('proposal0', 0)) + m,
+                                            int(rng.get('chain_offset', 0)), N, d, 1, _ffi.ptr(fv), _ffi.ptr(fd),
+                                            _ffi.ptr(fu), _ffi.current_stream(self.device)))
+                vm = fv if vm is None else vm
+                dm = fd if fd is not None else dm
+                um = fu if um is None else um
+            o = self._run_split(x, vm, step_begin, n_steps, dm, direction_all, um,
+                                tuple(k for k in want if k != 'x_hist'), aux)
+            x = o['x_next']
+            if 'p' in o:
+                ps.append(o['p'])
+            if 'logjac' in o:
+                ljs.append(o['logjac'])
+            if 'x_hist' in want:
+                hist.append(x)
+        out = dict(o)
+        if M > 1:
+            if ps:
+                out['p'] = torch.stack(ps)
+            if ljs:
+                out['logjac'] = torch.stack(ljs)
+        if 'x_hist' in want:
+            out['x_hist'] = torch.stack(hist)
         return out
 
     def _randn_like(self, x):
@@ -278,7 +340,7 @@ class Dynamics(object):
         M = int(n_proposals)
         if self._split:
             if M != 1 or rng is not None:
-                raise NotImplementedError("the split engine runs one injected-draw proposal per call")
+                return self._run_split_chain(x, v, step_begin, n_steps, direction, direction_all, u, want, M, rng, aux)
             return self._run_split(x, v, step_begin, n_steps, direction, direction_all, u, want, aux)
         x = as_device_f32(x, self.device)
         N, d = x.shape
@@ -350,7 +412,7 @@ class Dynamics(object):
     def energy(self, x, aux=None):
         """dynamics.py:203-212."""
         self._check_aux(aux)
-        if self._split:
+        if self._vae:
             return self._fn.evaluate(x, aux=aux, anneal_beta=self.anneal_beta)[0]
         return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
                                  anneal_beta=self.anneal_beta)[0]
@@ -358,7 +420,7 @@ class Dynamics(object):
     def grad_energy(self, x, aux=None):
         """dynamics.py:217-218 (analytic, computed by the HIP energy kernel)."""
         self._check_aux(aux)
-        if self._split:
+        if self._vae:
             return self._fn.evaluate(x, want_U=False, want_grad=True, aux=aux, anneal_beta=self.anneal_beta)[1]
         return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
                                  want_U=False, want_grad=True, anneal_beta=self.anneal_beta)[1]
@@ -402,7 +464,7 @@ class Dynamics(object):
         lj = as_device_f32(log_jac, self.device)
         N, d = x0.shape
         p = torch.empty(N, dtype=torch.float32, device=x0.device)
-        if self._split:                    # energies from the rocBLAS decoder path, then one small kernel
+        if self._vae:                      # energies from the decoder GEMMs, then one small kernel
             U0, U1 = self.energy(x0, aux=aux), self.energy(x1, aux=aux)
             _ffi.check(_ffi.lib().l2hmc_p_accept_energies(U0.data_ptr(), v0.data_ptr(), U1.data_ptr(), v1.data_ptr(),
                                                           lj.data_ptr(), N, d, p.data_ptr(),

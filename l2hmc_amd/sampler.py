@@ -111,7 +111,7 @@ def chain_operator(init_x, dynamics, nb_steps, aux=None, init_v=None, do_mh_step
 
 
 def sample_chain(x, dynamics, nb_proposals, *, direction=None, v=None, u=None, record=False,
-                 seed=None, proposal0=0, chain_offset=0):
+                 seed=None, proposal0=0, chain_offset=0, aux=None):
     """`nb_proposals` chained `propose(..., do_mh_step=True)` calls -- the per-MH-step
     `sess.run` loop of the notebook (SCGExperiment.ipynb raw lines 288-298) and of
     `notebook_utils.get_hmc_samples` (:25-39) -- as ONE persistent kernel launch: weights stay
@@ -123,7 +123,10 @@ def sample_chain(x, dynamics, nb_proposals, *, direction=None, v=None, u=None, r
     index `proposal0 + m`, global chain index `chain_offset + n`: identical numbers whatever
     the kernel geometry or the sharding of chains over GPUs); else torch's generator.
     Returns (x_final (N, d), p (M, N), x_hist (M, N, d) or None); x_hist[m] is the state AFTER
-    proposal m (the notebook records the state BEFORE each step: that is [x] + x_hist[:-1])."""
+    proposal m (the notebook records the state BEFORE each step: that is [x] + x_hist[:-1]).
+    `aux=`: conditioning images of the VAE posterior (split engine: the same loop, one Philox fill and one
+    trajectory launch per proposal, state and draws never leave the device)."""
+    dynamics._check_aux(aux)
     x = as_device_f32(x, dynamics.device)
     N, d = x.shape
     M = int(nb_proposals)
@@ -150,7 +153,7 @@ def sample_chain(x, dynamics, nb_proposals, *, direction=None, v=None, u=None, r
         direction = torch.as_tensor(direction, device=dev).to(torch.uint8).reshape((M, N) if M > 1 else (N,))
     want = ('p', 'x_next') + (('x_hist',) if record else ())
     o = dynamics.run(x, v, 0, dynamics.T, direction=direction, direction_all=1, u=u, want=want,
-                     n_proposals=M, rng=rng)
+                     n_proposals=M, rng=rng, aux=aux)
     return o['x_next'], o['p'].reshape(M, N), (o['x_hist'] if record else None)
 
 

@@ -4,7 +4,7 @@
 (`Sequential([Linear, softplus, Linear, softplus, Linear])`); its energy function is
 mnist_vae.py:122-126,  U(z; x) = sum_pix BCE_with_logits(x, decoder(z)) + |z|^2 / 2,  evaluated --
 with its analytic gradient -- by the split engine of the HIP library (`l2hmc_vae_energy`,
-`l2hmc_trajectory_split`): rocBLAS for the dense products, hand-written kernels for the rest.
+`l2hmc_trajectory_split`): hand-written fp32 MFMA GEMMs with fused epilogues for the dense products, small kernels for the rest.
 `sampler_net_factory` is mnist_vae.py:142-167: the S/T/Q nets whose 4th Zip branch is the shared
 `encoder_sampler(aux)`.
 """

@@ -438,9 +438,23 @@ def ais_cases():
     ais_vae_case('ais_vae', latent=10, dec_h=48, n_pix=40, K=6, T=4, N=32, step_size=0.1, seed=55, num_splits=2)
 
 
+def wide_cases():
+    """H > 15 (nb:51-78 with H != 10; mnist_vae.py:142-167 uses 200): the nets run on the GEMM engine."""
+    var = np.exp(np.linspace(np.log(1e-2), np.log(1e2), 50))
+    rng = np.random.RandomState(5)
+    x0 = (rng.randn(64, 50) * np.sqrt(var)).astype(np.float32)
+    gaussian_case('icg50_h32', np.zeros(50), np.diag(var), H=32, T=10, eps=0.1, N=64, seed=61, head_std=0.05, x0=x0)
+    rng = np.random.RandomState(7)
+    R = np.linalg.qr(rng.randn(8, 8))[0]
+    cov8 = R.T.dot(np.diag(np.exp(np.log(10.) * rng.uniform(-1, 1, size=8)))).dot(R)
+    gaussian_case('tilted8_h24', rng.randn(8) * 0.5, cov8, H=24, T=7, eps=0.1, N=48, seed=62)
+
+
 def main():
     if sys.argv[1:] == ['ais']:                  # only the AIS fixtures (leaves the other files untouched)
         return ais_cases()
+    if sys.argv[1:] == ['wide']:                 # only the wide-net fixtures
+        return wide_cases()
     # C1: Strongly-correlated Gaussian 2D, exactly the notebook's target (nb:103-108)
     cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
     gaussian_case('scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=11, x_scale=1.0)

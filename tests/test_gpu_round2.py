@@ -155,3 +155,34 @@ def test_bench_dist_leg_over_rccl_world_size_1():
     assert 4e-3 < out["dist"]["sharded_ess"]["ess_per_mh_step"] < 8e-3         # notebook: 5.63e-3
     assert out["config"]["repeats"] > 1 and out["config"]["timed_steps"] == 20 * out["config"]["repeats"]
     assert out["value"] > 1e8 and out["config"]["state_finite"]
+
+
+def test_vae_sampler_loop_with_library_philox_matches_injected_draws_and_oracle():
+    """sample_chain on the split engine (config 5's sampler loop, mnist_vae.py:185-224): `seed=` draws every
+    proposal's momenta / direction / uniforms from the library's Philox stream -- bit-identical to injecting the
+    stream's own draws, sharding-invariant, and equal to the oracle's loop on those draws."""
+    import torch
+    from oracle import l2hmc_oracle as O
+    from l2hmc_amd import sample_chain
+    from l2hmc_amd.sampler import philox_draws
+    from tests.helpers import aux_of, oracle_dynamics
+    g = load("vae_small")
+    dyn = hip_dynamics(g)
+    x, aux = to_dev(g["x"]), aux_of(g)
+    N, d, M = g["x"].shape[0], int(g["x_dim"]), 4
+    v, dr, u = philox_draws(31, N, d, M)
+    xf, p, xh = sample_chain(x, dyn, M, seed=31, record=True, aux=aux)
+    xi, pi, xhi = sample_chain(x, dyn, M, v=v, u=u, direction=dr, record=True, aux=aux)
+    assert torch.equal(xf, xi) and torch.equal(p, pi) and torch.equal(xh, xhi)
+    lo = N // 2
+    xs, ps, _ = sample_chain(x[lo:], dyn, M, seed=31, chain_offset=lo, aux=aux[lo:])
+    assert torch.equal(xs, xf[lo:]) and torch.equal(ps, p[:, lo:])
+    od = oracle_dynamics(g)
+    xo = g["x"]
+    with np.errstate(all="ignore"):
+        for m in range(M):
+            _, _, rpx, xo_next = O.propose(xo, od, to_np(v[m]), to_np(v[m]), to_np(dr[m]), to_np(u[m]), both_directions=False)
+            assert abs_err(to_np(p[m]), rpx) < 2e-4, m
+            flip = np.abs(rpx - to_np(u[m])) < 2e-4          # ties fp32 noise may flip
+            assert rel_err(to_np(xh[m])[~flip], xo_next[~flip]) < 2e-4, m
+            xo = to_np(xh[m])                                # continue from the HIP state (no tie divergence)
