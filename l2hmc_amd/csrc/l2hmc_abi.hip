@@ -329,6 +329,7 @@ void fill_energy(KArgs& k, const L2hmcEnergy* e) {
 bool pick_geometry(int d, long long N, int variant, int& DT, int& NW) {
   const int NT = tiles_of(d);
   if (NT <= 1) { DT = 1; NW = 1; return variant == 0 || variant == 1; }
+  if (variant == 2 && NT >= 3 && NT <= 4) { DT = 2; NW = 2; return true; }   // two waves x two tiles (fast kernel only)
   if (NT <= 4) {
     // measured (tools/bench_configs.py, 16-chain tiles on 256 CUs): with 3-4 dim-tiles the 4-wave tile wins at
     // every chain count (1.7e9 vs 1.1e9 steps/s at d = 50..64); with 2 dim-tiles half of its waves idle, so it

@@ -1101,6 +1101,7 @@ enum { OP_TRAJ = 0, OP_ENERGY = 1, OP_PACCEPT = 2, OP_TRAJ_FAST = 3 };
   else if (DTv == 2 && NWv == 1) { CALL(2, 1) }          \
   else if (DTv == 1 && NWv == 4) { CALL(1, 4) }          \
   else if (DTv == 2 && NWv == 4) { CALL(2, 4) }          \
+  else if (DTv == 2 && NWv == 2) { CALL(2, 2) }          \
   else return fail(L2HMC_ERR_UNSUPPORTED, "no fast kernel for this geometry%s");
 
 // Declared here, defined (explicitly instantiated) once per energy kind.

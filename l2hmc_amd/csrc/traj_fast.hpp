@@ -105,7 +105,10 @@ __device__ __forceinline__ void tail_fast(const TailK<DT>& tk, f4 hs_, F&& apply
 }
 
 template <int EK, int DT, int NW, int KH>
-__global__ __launch_bounds__(64 * NW, 2) void traj_fast_kernel(const KArgs A) {
+#ifndef L2HMC_FAST_WAVES
+#define L2HMC_FAST_WAVES 2
+#endif
+__global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(const KArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(DT <= 2, "the fast kernel keeps layer-1 and tail fragments in registers");
   const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * NW;
