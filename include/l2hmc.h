@@ -121,6 +121,20 @@ typedef struct L2hmcTrajectoryArgs {
   uint64_t rng_seed;
   uint64_t rng_proposal0;   /* stream index of this launch's first proposal                          */
   int64_t chain_offset;     /* global index of row 0 (rank r owning rows [lo, hi) passes lo)          */
+  /* ---- AIS mode of the persistent loop (utils/ais.py:43-66; HMC mode only: packed_nets = NULL) ------------- */
+  /* ais_beta != NULL: proposal m is anneal step m.  Before its transition the log-weight takes                 */
+  /*   w += ais_dbeta (|x|^2 / 2 - U(x))  (ais.py:58-59), the momentum is the step's draw z (ais_refreshment    */
+  /*   < 0, ais.py:57) or  v sqrt(1 - r) + z sqrt(r)  (ais.py:55), the transition uses the bridge energy        */
+  /*   (1 - beta) |x|^2 / 2 + beta U  with beta = ais_beta[m] (energy.anneal_beta is ignored), and after the MH */
+  /*   step a rejected chain keeps x with the NEGATED proposed momentum (ais.py:62-65).  One launch replaces     */
+  /*   the five per-step launches of l2hmc_ais_begin_step / l2hmc_energy / l2hmc_trajectory / l2hmc_ais_end_step.*/
+  const float* ais_beta;    /* (M) bridge schedule, float32(linspace(0, 1, K + 1)[1:])                          */
+  const float* ais_v0;      /* (N, d) momentum before step 0 (read only when refreshing), or NULL: the Philox    */
+                            /*   draw of proposal index rng_proposal0 - 1                                        */
+  float ais_dbeta;          /* beta[1] - beta[0]                                                                 */
+  float ais_refreshment;    /* r in [0, 1], or < 0 for fresh momenta                                             */
+  float* ais_w;             /* (N) log-weights, accumulated (+=)                                                 */
+  float* ais_alpha;         /* (N) summed accept probabilities, accumulated (+=), or NULL                        */
 } L2hmcTrajectoryArgs;
 
 enum { L2HMC_RNG_V = 1, L2HMC_RNG_DIR = 2, L2HMC_RNG_U = 4 };

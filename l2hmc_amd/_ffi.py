@@ -38,7 +38,9 @@ class L2hmcTrajectoryArgs(C.Structure):
                 ("x_out", _fp), ("v_out", _fp), ("logjac_out", _fp), ("p_out", _fp),
                 ("x_next", _fp), ("variant", C.c_int32), ("n_proposals", C.c_int32), ("x_hist", _fp),
                 ("rng_flags", C.c_uint32), ("rng_seed", C.c_uint64), ("rng_proposal0", C.c_uint64),
-                ("chain_offset", C.c_int64)]
+                ("chain_offset", C.c_int64),
+                ("ais_beta", _fp), ("ais_v0", _fp), ("ais_dbeta", C.c_float), ("ais_refreshment", C.c_float),
+                ("ais_w", _fp), ("ais_alpha", _fp)]
 
 
 RNG_V, RNG_DIR, RNG_U = 1, 2, 4

@@ -2,8 +2,13 @@
 
 `ais_estimate` keeps the reference signature (ais.py:30-42).  The bridge is the reference's
 geometric path  U_b = (1 - b) U_init + b U_final,  b = 1/K, 2/K, .., 1  (ais.py:43,46-47), with the
-standard-normal initial energy its only caller uses (eval_vae.py:55-56).  Per anneal step
-(ais.py:48-66), all on the device:
+standard-normal initial energy its only caller uses (eval_vae.py:55-56).
+
+Built-in targets: ALL K anneal steps run in ONE persistent launch of the trajectory kernel (AIS mode of
+`l2hmc_trajectory`, include/l2hmc.h: bridge schedule in HBM, log-weight update, momentum refresh, HMC
+transition, MH step with the momentum flip, accept statistics -- the `tf.scan` of ais.py:68 without a
+single host round trip).  The decoder posterior (GEMM engine) keeps the per-step form (ais.py:48-66), all
+on the device:
 
     l2hmc_energy            U_final(x)                 (l2hmc_vae_energy for the decoder posterior)
     l2hmc_ais_begin_step    w += db (|x|^2/2 - U_final(x));  v = fresh / partially refreshed momentum
@@ -82,7 +87,27 @@ def ais_estimate(init_energy, final_energy, anneal_steps, initial_x, aux=None, s
     e_final = None if vae else final_energy.c_struct(dev)
     if vae:
         aux = as_device_f32(aux, dev)
-    for i in range(K):
+    if not vae:
+        # ONE persistent launch for all K anneal steps (`tf.scan` of ais.py:68): the bridge schedule sits in HBM,
+        # log-weight update, momentum refresh, HMC transition, MH step with the momentum flip and the accept
+        # statistics all happen in the trajectory kernel's proposal loop (AIS mode, include/l2hmc.h)
+        bt = torch.as_tensor(beta, device=dev)
+        spec = {'beta': bt, 'dbeta': dbeta, 'refreshment': float(refreshment) if refresh else -1.0, 'w': w, 'alpha': alpha}
+        dyn.anneal_beta = float(beta[0])
+        if draws is None:
+            o = dyn.run(x, None, 0, leapfrogs, direction_all=1, want=('x_next',), n_proposals=K,
+                        rng={'seed': int(seed), 'proposal0': 1, 'chain_offset': int(chain_offset), 'direction': False},
+                        ais=spec)
+        else:
+            spec['v0'] = v
+            nz = as_device_f32(np.asarray(draws['normals']), dev).reshape((K, N, d) if K > 1 else (N, d))
+            uu = as_device_f32(np.asarray(draws['u']), dev).reshape((K, N) if K > 1 else (N,))
+            o = dyn.run(x, nz, 0, leapfrogs, direction_all=1, u=uu, want=('x_next',), n_proposals=K, ais=spec)
+        x = o['x_next']
+        K_loop = 0
+    else:
+        K_loop = K
+    for i in range(K_loop):
         if draws is None:
             fill(i + 1, True)
             zi, ui = z, u

@@ -453,6 +453,15 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   k.rng_flags = a->rng_flags; k.rng_seed = a->rng_seed; k.rng_prop0 = a->rng_proposal0;
   k.chain_off = a->chain_offset;
   k.dbg = L2HMC_DBG_PTR;
+  if (a->ais_beta != nullptr) {
+    if (a->packed_nets != nullptr) return fail(L2HMC_ERR_UNSUPPORTED, "AIS mode runs HMC transitions (packed_nets must be NULL, utils/ais.py:60)%s");
+    if (!has_u || !a->ais_w) return fail(L2HMC_ERR_ARG, "AIS mode needs u (or L2HMC_RNG_U) and ais_w%s");
+    if (a->n_steps < 1 || a->ais_refreshment > 1.f) return fail(L2HMC_ERR_ARG, "AIS mode: bad n_steps / ais_refreshment%s");
+    if (a->ais_refreshment >= 0.f && !a->ais_v0 && !((a->rng_flags & L2HMC_RNG_V) && a->rng_proposal0 >= 1))
+      return fail(L2HMC_ERR_ARG, "AIS refresh needs ais_v0, or in-kernel momenta with rng_proposal0 >= 1%s");
+    k.ais_beta = a->ais_beta; k.ais_v0 = a->ais_v0; k.ais_dbeta = a->ais_dbeta; k.ais_refresh = a->ais_refreshment;
+    k.ais_w = a->ais_w; k.ais_alpha = a->ais_alpha;
+  }
   fill_energy(k, &a->energy);
   hipStream_t s = (hipStream_t)stream;
   // Wide targets (more than 8 dim-tiles, i.e. d > 128; `variant` 8 forces it from 4 tiles up): the

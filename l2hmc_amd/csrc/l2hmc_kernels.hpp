@@ -97,6 +97,11 @@ struct KArgs {
   // LDS offsets (floats)
   int o_mask, o_trig, o_tb, o_P, o_XB, o_red, o_mu, o_prec, o_logc, xb_stride;
   int o_state;               // traj_wide_kernel: x, v, grad U of the tile (3 x NT x 256 floats)
+  // AIS mode of the persistent loop (utils/ais.py:43-66): proposal m is anneal step m with beta = ais_beta[m]
+  const float* ais_beta;     // (M) or NULL
+  const float* ais_v0;       // (N, d) momentum before the first step (only read when refreshing), or NULL -> Philox
+  float ais_dbeta, ais_refresh;   // refresh < 0: fresh momenta every step (ais.py:57)
+  float *ais_w, *ais_alpha;  // (N) log-weights / summed accept probabilities, accumulated
   int o_fw, o_fc, o_rec;     // traj_fast_kernel: staged tail fragments, constant tables, schedule records
   unsigned long long* dbg;   // phase-timing buffer (profiling builds only, else NULL)
 };
@@ -321,8 +326,10 @@ __device__ __forceinline__ void load_energy_regs(EnergyRegs<EK, DT>& er, const K
 template <int EK, int DT, int NW>
 __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, int lane,
                                             const f4 (&x)[DT], f4 (&g)[DT], float& Upart,
-                                            bool wantU, const EnergyRegs<EK, DT>* er = nullptr) {
+                                            bool wantU, const EnergyRegs<EK, DT>* er = nullptr,
+                                            const float* beta_p = nullptr) {
   const int q = lane >> 4, DP = 16 * A.NT;
+  const float beta_a = beta_p != nullptr ? *beta_p : A.beta;     // (AIS loop: the bridge moves every proposal)
   float U = 0.f;
   if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
     {
@@ -441,14 +448,14 @@ __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, 
 #pragma unroll
     for (int t = 0; t < DT; ++t) g[t] = splat(0.f);
   }
-  if (A.beta != 1.f) {       // annealed energy between N(0, I) and the target (wave-uniform branch)
+  if (beta_a != 1.f) {       // annealed energy between N(0, I) and the target (wave-uniform branch)
     float q = 0.f;
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
       q += hsum(x[t] * x[t]);
-      g[t] = x[t] * (1.f - A.beta) + g[t] * A.beta;
+      g[t] = x[t] * (1.f - beta_a) + g[t] * beta_a;
     }
-    U = (1.f - A.beta) * 0.5f * q + A.beta * U;
+    U = (1.f - beta_a) * 0.5f * q + beta_a * U;
   }
   if (A.temperature != 1.f) {
     U = U / A.temperature;
@@ -828,6 +835,18 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
   bool fwd_n = (A.dir != nullptr && !rng_d) ? (live ? A.dir[chain] != 0 : true) : (A.dir_all != 0);
   float u_n = (A.u != nullptr && !rng_u && live) ? A.u[chain] : 0.f;
   const bool have_u = A.u != nullptr || rng_u;
+  // AIS mode (utils/ais.py:43-66, HMC transitions): per proposal the bridge moves to beta = ais_beta[m], the
+  // log-weight takes dbeta (|x|^2/2 - U_final(x)) at the CURRENT state, the momentum is drawn fresh or partially
+  // refreshed, and a rejected chain keeps its state with the NEGATED PROPOSED momentum (ais.py:63).
+  const bool ais = A.ais_beta != nullptr;
+  float ais_wacc = 0.f, ais_aacc = 0.f, beta_m = A.beta;
+  f4 vprev[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) vprev[t] = Z;
+  if (ais && A.ais_refresh >= 0.f) {
+    if (A.ais_v0 != nullptr) load_state<DT, NW>(A.ais_v0, A, chain, live, w, q, vprev);
+    else rng_state<DT, NW>(A, gchain, A.rng_prop0 - 1, w, q, vprev);
+  }
   for (int m = 0; m < A.M; ++m) {
   const long long moff = (long long)m * A.N;
   const unsigned long long prop = A.rng_prop0 + (unsigned long long)m;
@@ -836,6 +855,25 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
   } else {
 #pragma unroll
     for (int t = 0; t < DT; ++t) v[t] = vn[t];
+  }
+  if (ais) {
+    beta_m = A.ais_beta[m];
+    const float one = 1.f;
+    float pr[2];
+    grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, pr[0], true, &er, &one);      // U_final, grad U_final at x
+    pr[1] = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) pr[1] += 0.5f * hsum(x[t] * x[t]);
+    U_start = (1.f - beta_m) * pr[1] + beta_m * pr[0];                              // this lane's share of U_beta(x)
+#pragma unroll
+    for (int t = 0; t < DT; ++t) g[t] = x[t] * (1.f - beta_m) + g[t] * beta_m;
+    chain_allreduce<NW, 2>(pr, smem + A.o_red, w, lane);
+    ais_wacc += A.ais_dbeta * (-pr[0] + pr[1]);                                     // ais.py:58-59
+    if (A.ais_refresh >= 0.f) {                                                     // ais.py:55
+      const float keep = sqrtf(1.f - A.ais_refresh), mix = sqrtf(A.ais_refresh);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) v[t] = vprev[t] * keep + v[t] * mix;
+    }
   }
   bool fwd = fwd_n;
   float u_m = u_n;
@@ -955,7 +993,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
         y[t] = x_half(x[t], k1[t], vh[t], O, Z, Z, O, eps, fwd, ldv);
         x[t] = x_half(y[t], O - k1[t], vh[t], O, Z, Z, O, eps, fwd, ldv);
       }
-      grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1, &er);
+      grad_energy<EK, DT, NW>(A, smem, w, lane, x, g, red[2], need_p && it == A.n_steps - 1, &er, &beta_m);
 #pragma unroll
       for (int t = 0; t < DT; ++t) v[t] = v_half(vh[t], g[t], O, Z, Z, O, heps, fwd, ldv);
     }
@@ -996,6 +1034,11 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
       }
       pv[0] = sel4(acc, pv[0], pv0);
       U_start = acc ? U_end : U_start;
+      if (ais) {
+        ais_aacc += p;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) vprev[t] = acc ? v[t] : -v[t];
+      }
     } else {
       U_start = U_end;
     }
@@ -1007,6 +1050,10 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
 
   PT_FLUSH(w, lane);
   store_state<DT, NW>(A.x_next, A, chain, live, w, q, x);
+  if (ais && live && w == 0 && lane < 16) {
+    if (A.ais_w != nullptr) A.ais_w[chain] += ais_wacc;
+    if (A.ais_alpha != nullptr) A.ais_alpha[chain] += ais_aacc;
+  }
 }
 
 // energy / grad only  (Dynamics.energy, Dynamics.grad_energy)

@@ -330,7 +330,7 @@ class Dynamics(object):
         return torch.randn(x.shape, dtype=torch.float32, device=x.device, generator=self.generator)
 
     def run(self, x, v, step_begin, n_steps, direction=None, direction_all=1, u=None,
-            want=('x', 'v', 'logjac'), n_proposals=1, rng=None, aux=None):
+            want=('x', 'v', 'logjac'), n_proposals=1, rng=None, aux=None, ais=None):
         """Launch `l2hmc_trajectory` (include/l2hmc.h).  Returns a dict of the requested
         outputs among x, v, logjac, p, x_next, x_hist.  With n_proposals = M > 1 the kernel
         runs M chained proposals (persistent sampler loop): v is (M, N, d), direction and u
@@ -398,6 +398,11 @@ class Dynamics(object):
         a.x_out, a.v_out = _ffi.ptr(out.get('x')), _ffi.ptr(out.get('v'))
         a.logjac_out, a.p_out = _ffi.ptr(out.get('logjac')), _ffi.ptr(out.get('p'))
         a.x_next = _ffi.ptr(out.get('x_next'))
+        if ais is not None:          # AIS mode of the persistent loop (include/l2hmc.h): proposal m = anneal step m
+            a.ais_beta, a.ais_dbeta = ais['beta'].data_ptr(), float(ais['dbeta'])
+            a.ais_refreshment = float(ais['refreshment'])
+            a.ais_v0 = _ffi.ptr(ais.get('v0'))
+            a.ais_w, a.ais_alpha = ais['w'].data_ptr(), ais['alpha'].data_ptr()
         a.x_hist = _ffi.ptr(out.get('x_hist'))
         a.variant = int(self.variant)
         a.n_proposals = M

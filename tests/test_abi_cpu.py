@@ -49,5 +49,6 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_ffi.L2hmcEnergy) == 48
     assert _ffi.L2hmcTrajectoryArgs.energy.offset == 8
     assert _ffi.L2hmcTrajectoryArgs.n_chains.offset == 8 + 48 + 3 * 8 + 8
-    assert _ffi.L2hmcTrajectoryArgs.chain_offset.offset == ctypes.sizeof(_ffi.L2hmcTrajectoryArgs) - 8
+    assert _ffi.L2hmcTrajectoryArgs.ais_alpha.offset == ctypes.sizeof(_ffi.L2hmcTrajectoryArgs) - 8
+    assert _ffi.L2hmcTrajectoryArgs.ais_beta.offset == _ffi.L2hmcTrajectoryArgs.chain_offset.offset + 8
     assert _ffi.L2hmcTrajectoryArgs.rng_seed.offset == _ffi.L2hmcTrajectoryArgs.x_hist.offset + 16
