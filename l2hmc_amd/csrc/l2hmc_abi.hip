@@ -485,6 +485,13 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   // tempered / annealed energies (HMC-mode AIS) and zero-step calls stay on the general kernel.
   const bool fast = a->packed_nets != nullptr && DT <= 2 && k.n_steps >= 1 && a->variant < 100 &&
                     k.beta == 1.f && k.temperature == 1.f;
+  // d <= 4 (SCG-2D, MoG-2D): one dimension per lane, S/T/Q in one MFMA row block (traj_small.hpp)
+  const bool small = fast && a->d <= 4 && geom_variant == 0 && k.ekind != L2HMC_ENERGY_FUNNEL &&
+                     (k.ekind != L2HMC_ENERGY_GMM || k.ncomp <= 8);
+  if (small) {
+    const long long ldss = plan_lds_fast(k, 1, 1);
+    return dispatch(OP_TRAJ_SMALL, k, 1, 1, KH, ldss, s);
+  }
   if (fast) {
     const long long ldsf = plan_lds_fast(k, NW, DT);
     if (ldsf <= 160 * 1024) return dispatch(OP_TRAJ_FAST, k, DT, NW, KH, ldsf, s);

@@ -1,0 +1,323 @@
+// traj_small.hpp -- the fused trajectory kernel for SMALL targets, d <= 4 (gfx950 / CDNA4).
+//
+// BASELINE.json configs 1 and 3 (SCG-2D, MoG-2D) have d = 2: in the 16-wide dimension tiles of
+// traj_fast_kernel 14 of 16 MFMA rows and 3 of 4 values per lane are padding.  This form keeps the tiling
+// over chains (one wave owns 16 chains = the N of v_mfma_f32_16x16x4_f32, the persistent sampler loop, the
+// schedule records, the folded constants of traj_fast.hpp) but gives every lane ONE dimension:
+//
+//   lane l = (c = l & 15, q = l >> 4) holds chain c, dimension q (lanes with q >= d carry zeros);
+//   * layer 1: the d <= 4 dimensions are exactly ONE k-step (k = q): 1 MFMA per input instead of 4;
+//   * heads: the rows of ONE 16-row MFMA block are (dimension q', head h) at row 4 q' + h, h = S, T, Q --
+//     so after 3 MFMAs (k-steps over the hidden units) lane (c, q) holds z_S, z_T, z_Q of ITS dimension in
+//     acc[0..2]: 3 MFMAs per net evaluation instead of 9, and the elementwise update is scalar, not float4;
+//   * dense precisions (SCG, the mixture components): y = G dx as ONE MFMA whose row 4 j carries output
+//     dimension j, so y_q lands in lane q's acc[0].
+// Per leapfrog step and wave: 29 MFMAs (5 layer 1 + 12 layer 2 + 12 heads) instead of 68, 24 transcendentals
+// instead of 96.  Reference: utils/dynamics.py:115-309, utils/sampler.py:28-55 (same algorithm as traj_kernel).
+#pragma once
+#include "traj_fast.hpp"
+
+namespace l2hmc {
+
+template <int EK>
+struct SmallEnergy {
+  float mu, prec;            // diagonal Gaussian: this lane's mean / precision entry
+  float gf[8];               // dense Gaussian / GMM: A-operand of y = G dx per component (row 4 j <- G[j][q])
+  float mus[8];              // per-component mean entry of this lane's dimension
+};
+
+// grad U for this lane's dimension and this lane's share of U (summing over the chain's 4 lanes gives U)
+template <int EK>
+__device__ __forceinline__ float grad_small(const KArgs& A, const float* smem, const SmallEnergy<EK>& E, int lane,
+                                            float x, float& Upart, bool wantU) {
+  const int q = lane >> 4;
+  const bool livedim = q < A.d;
+  float g = 0.f, U = 0.f;
+  if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
+    const float dx = x - E.mu;
+    g = E.prec * dx;
+    U = 0.5f * dx * g;
+  } else if constexpr (EK == L2HMC_ENERGY_GAUSS_DENSE) {
+    const float dx = x - E.mus[0];
+    const f4 y = MFMA16(E.gf[0], dx, splat(0.f));
+    g = y.x;
+    U = 0.5f * dx * g;
+  } else if constexpr (EK == L2HMC_ENERGY_GMM) {
+    // U = -logsumexp_i(-q_i / 2 + log c_i); grad = sum_i softmax_i G_i (x - mu_i)  (online softmax, distributions.py:104-134)
+    float m = -INFINITY, ssum = 0.f, gacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < A.ncomp) {
+        const float dx = x - E.mus[i];
+        const f4 y = MFMA16(E.gf[i], dx, splat(0.f));
+        float qq = dx * y.x;
+        qq += __shfl_xor(qq, 16);
+        qq += __shfl_xor(qq, 32);
+        const float V = -(0.5f * qq) + smem[A.o_logc + i];
+        const float mn = fmaxf(m, V);
+        const float sc = (m == mn) ? 1.f : expf(m - mn), wi = (V == -INFINITY) ? 0.f : expf(V - mn);
+        ssum = ssum * sc + wi;
+        gacc = gacc * sc + wi * y.x;
+        m = mn;
+      }
+    }
+    g = gacc / ssum;
+    if (lane < 16) U = -(m + logf(ssum));
+  } else if constexpr (EK == L2HMC_ENERGY_ROUGHWELL) {
+    const float den = A.easy ? A.eta : A.eta * A.eta;
+    const float arg = x / den;
+    g = x - (A.eta / den) * sinf(arg);
+    if (wantU) U = livedim ? 0.5f * x * x + A.eta * cosf(arg) : 0.f;
+  }
+  Upart = U;
+  return livedim ? g : 0.f;
+}
+
+template <int EK, int KH>
+__global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x;
+  const int c = lane & 15, q = lane >> 4;
+  const long long chain = (long long)blockIdx.x * 16 + c;
+  const bool live = chain < A.N, livedim = q < A.d;
+  const int NF = net_floats(1);
+  const float LOG2E = 1.4426950408889634f;
+  const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
+  const float heps = 0.5f * eps;
+  constexpr int NTp = 1;
+  const int FWN = fast_fw_net(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
+            RECD = fast_rec_dir(NTp, A.T);
+
+  // ---- prologue: the same scaled tail fragments, constant tables and schedule records as traj_fast_kernel ----
+  for (int i = lane; i < 2 * (FWN / 4); i += 64) {
+    const int net = i >= FWN / 4, j = i - net * (FWN / 4), g = j >> 6;
+    float sc = 1.f;
+    if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
+    const f4 src = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + 3 * 256)[j];
+    reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src * sc;
+  }
+  for (int i = lane; i < 2 * 16; i += 64) {
+    const int net = i / 16, dim = i % 16;
+    const float* scl = A.packed + (size_t)net * NF + net_groups(1) * 256;
+    const float epn = net == 0 ? eps : heps;
+    const float cs = scl[dim] * epn * LOG2E, cq = scl[16 + dim] * eps * LOG2E;
+    float* fc = smem + A.o_fc + net * FCN;
+    fc[dim] = cs;
+    fc[DPp + dim] = -cs;
+    fc[2 * DPp + dim] = cq;
+    fc[3 * DPp + dim] = cq + log2f(epn);
+  }
+  for (int i = lane; i < 2 * A.T * R; i += 64) {
+    const int dr = i / (A.T * R), r = (i / R) % A.T, j = i % R;
+    float val;
+    if (j < 32) {
+      const int net = j >> 4, u = j & 15;
+      const float* tf = A.packed + (size_t)net * NF + (2 * 64) * 4;
+      val = fmaf(tf[u * 4], A.trig[2 * r], fmaf(tf[(16 + u) * 4], A.trig[2 * r + 1], tf[(32 + u) * 4]));
+    } else {
+      const int dim = j - 32;
+      const float m = dim < A.d ? A.masks[r * A.d + dim] : 0.f;
+      val = dr ? m : 1.f - m;
+    }
+    smem[A.o_rec + dr * RECD + (r + 1) * R + j] = val;
+  }
+  if (EK == L2HMC_ENERGY_GMM)
+    for (int i = lane; i < A.ncomp; i += 64) smem[A.o_logc + i] = A.logc[i];
+
+  // this lane's energy constants (registers for the whole launch)
+  SmallEnergy<EK> E;
+  E.mu = E.prec = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) E.gf[i] = E.mus[i] = 0.f;
+  if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
+    if (livedim) { E.mu = A.mu[q]; E.prec = A.prec[q]; }
+  } else if constexpr (EK == L2HMC_ENERGY_GAUSS_DENSE || EK == L2HMC_ENERGY_GMM) {
+    const int nc = EK == L2HMC_ENERGY_GMM ? A.ncomp : 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < nc) {
+        if (livedim) E.mus[i] = A.mu[i * A.d + q];
+        // packed precision (pack_gauss_kernel, one 16x16 tile): element (row a, col b) at ((a + 16 (b / 4)) * 4 + b % 4);
+        // A operand of lane (row i = c, k = q): G[j][q] on rows i = 4 j, zero elsewhere
+        if ((c & 3) == 0 && livedim) E.gf[i] = A.prec[(size_t)i * gauss_floats(1) + (c >> 2) * 4 + q];
+      }
+    }
+  }
+
+  // layer-1 A operands: ONE k-step whose k = q is dimension q.  Packed layer-1 group (tile 0): element (lane (i, 0), r)
+  // is W[dim r][unit row i], so this lane's scalar is component q of lane (c, 0)'s float4.
+  float xa = A.packed[(0 * 64 + c) * 4 + q], xb = A.packed[(1 * 64 + c) * 4 + q];
+  float va = A.packed[NF + (0 * 64 + c) * 4 + q], vb = A.packed[NF + (1 * 64 + c) * 4 + q];
+  if (!livedim) xa = xb = va = vb = 0.f;
+
+  float x = (live && livedim) ? A.x[chain * A.d + q] : 0.f;
+  const bool need_p = A.p_out != nullptr || A.x_next != nullptr || A.u != nullptr || (A.rng_flags & L2HMC_RNG_U) != 0;
+  __syncthreads();
+
+  const float* fwx = smem + A.o_fw;
+  const float* fwv = fwx + FWN;
+  const float* fcx = smem + A.o_fc;
+  const float* fcv = fcx + FCN;
+  const f4 Z = splat(0.f);
+  if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {      // fold P into VNet's layer 1 (as traj_fast_kernel)
+    va = va + E.prec * vb;
+    const f4 cv = MFMA16(vb, -(E.prec * E.mu), Z);
+    if (c == 0) {
+      for (int i = 0; i < 2 * A.T; ++i) {
+        float* tb = smem + A.o_rec + (i / A.T) * RECD + (i % A.T + 1) * R + 16 + 4 * q;
+        *reinterpret_cast<f4*>(tb) = lds4(tb) + cv;
+      }
+    }
+    __syncthreads();
+  }
+  auto vnet_l1 = [&](float xx, float gg) {
+    if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) return MFMA16(va, xx, Z);
+    else return MFMA16(vb, gg, MFMA16(va, xx, Z));
+  };
+  // tail of one net: hidden layers + the single (dimension, head) block; returns (z_S, z_T', z_Q) of this lane's dimension
+  struct TailS { f4 w2, hd; float cS, cQ, bQ; };
+  auto load_tail_s = [&](TailS& t, const float* fw, const float* fc, int dofs) {
+    t.w2 = lds4(fw + lane * 4);
+    // head block row c = 4 q' + h: head h (S, T, Q) of dimension q'; fragment of head group h at lane (q', q)
+    const int h = c & 3;
+    t.hd = h < 3 ? lds4(fw + ((1 + h) * 64 + (c >> 2) + 16 * q) * 4) : Z;
+    t.cS = fc[dofs + q];
+    t.cQ = fc[2 * DPp + q];
+    t.bQ = fc[3 * DPp + q];
+  };
+  auto tail_s = [&](const TailS& t, f4 hs_, float& aS, float& Tt, float& EQ) {
+    f4 h = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) h[r] = relu_i(hs_[r]);
+    f4 acc = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) acc = MFMA16(t.w2[r], h[r], acc);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
+    f4 z = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) z = MFMA16(t.hd[r], h[r], z);
+    const float rS = __builtin_amdgcn_rcpf(-(__builtin_amdgcn_exp2f(z.x) * 0.5f + 0.5f));
+    aS = rS * t.cS + t.cS;
+    const float rQ = __builtin_amdgcn_rcpf(-(__builtin_amdgcn_exp2f(z.z) * 0.5f + 0.5f));
+    EQ = __builtin_amdgcn_exp2f(rQ * t.cQ + t.bQ);
+    Tt = z.y;
+  };
+
+  float U_start = 0.f;
+  float g = grad_small<EK>(A, smem, E, lane, x, U_start, need_p);
+  f4 pv = vnet_l1(x, g);
+
+  // ---- persistent sampler loop (as traj_kernel / traj_fast_kernel) -------------------------------------------
+  const long long gchain = A.chain_off + chain;
+  const bool rng_v = (A.rng_flags & L2HMC_RNG_V) != 0, rng_d = (A.rng_flags & L2HMC_RNG_DIR) != 0;
+  const bool rng_u = (A.rng_flags & L2HMC_RNG_U) != 0;
+  const bool have_u = A.u != nullptr || rng_u;
+  TailS tk;
+  for (int m = 0; m < A.M; ++m) {
+    const long long moff = (long long)m * A.N;
+    const unsigned long long prop = A.rng_prop0 + (unsigned long long)m;
+    float v;
+    if (rng_v) {
+      const f4 n4 = philox_normal4(A.rng_seed, gchain, 0u, prop);     // dims 0..3 = components of block 0
+      v = livedim ? n4[q] : 0.f;
+    } else {
+      v = (live && livedim) ? A.v[(moff + chain) * A.d + q] : 0.f;
+    }
+    bool fwd = (A.dir != nullptr && !rng_d) ? (live ? A.dir[moff + chain] != 0 : true) : (A.dir_all != 0);
+    float u_m = (A.u != nullptr && !rng_u && live) ? A.u[moff + chain] : 0.f;
+    if (rng_d || rng_u) {
+      bool fr;
+      float ur;
+      philox_dir_u(A.rng_seed, gchain, prop, fr, ur);
+      if (rng_d) fwd = fr;
+      if (rng_u) u_m = ur;
+    }
+    const float x0 = x, g0 = g;
+    const f4 pv0 = pv;
+    float red[5];
+    red[0] = U_start;
+    red[1] = 0.5f * v * v;
+    red[2] = 0.f;
+    float ldv = 0.f;
+    const float ff = fwd ? 1.f : 0.f, nf = ff - 1.f;
+    const int dofs = fwd ? 0 : DPp;
+    const int row0 = fwd ? A.step_begin : (A.T - 1 - A.step_begin);
+    const float* rec = smem + A.o_rec + (fwd ? RECD : 0) + (row0 + 1) * R;
+    const int drec = fwd ? R : -R;
+    f4 tbv = lds4(rec + 16 + 4 * q);
+    load_tail_s(tk, fwv, fcv, dofs);
+    for (int it = 0; it < A.n_steps; ++it) {
+      const f4 tbx = lds4(rec + 4 * q);
+      const float k1 = rec[32 + q], up1 = 1.f - k1;
+      rec += drec;
+      const f4 tbv_n = lds4(rec + 16 + 4 * q);
+      float aS, T, EQ;
+      // ---- momentum half-update #1  (dynamics.py:118-125 / :162-170)
+      tail_s(tk, pv + tbv, aS, T, EQ);
+      float ES = __builtin_amdgcn_exp2f(aS);
+      ldv += aS;
+      float tr = T - EQ * g;
+      const float vh = ES * (nf * tr + v) + ff * tr;
+      // ---- two masked position updates  (:127-145 / :172-190)
+      load_tail_s(tk, fwx, fcx, dofs);
+      const f4 pa = MFMA16(xa, vh, Z);
+      tail_s(tk, MFMA16(xb, k1 * x, pa) + tbx, aS, T, EQ);
+      float aSm = up1 * aS;
+      ES = __builtin_amdgcn_exp2f(aSm);
+      ldv += aSm;
+      tr = up1 * (EQ * vh + T);
+      const float y = ES * (nf * tr + x) + ff * tr;
+      tail_s(tk, MFMA16(xb, up1 * y, pa) + tbx, aS, T, EQ);
+      aSm = k1 * aS;
+      ES = __builtin_amdgcn_exp2f(aSm);
+      ldv += aSm;
+      tr = k1 * (EQ * vh + T);
+      x = ES * (nf * tr + y) + ff * tr;
+      // ---- momentum half-update #2 at the new position  (:147-153 / :192-199)
+      load_tail_s(tk, fwv, fcv, dofs);
+      g = grad_small<EK>(A, smem, E, lane, x, red[2], need_p && it == A.n_steps - 1);
+      pv = vnet_l1(x, g);
+      tail_s(tk, pv + tbv, aS, T, EQ);
+      ES = __builtin_amdgcn_exp2f(aS);
+      ldv += aS;
+      tr = T - EQ * g;
+      v = ES * (nf * tr + vh) + ff * tr;
+      tbv = tbv_n;
+    }
+    const bool last = m == A.M - 1;
+    if (last && live && livedim) {
+      if (A.x_out != nullptr) A.x_out[chain * A.d + q] = x;
+      if (A.v_out != nullptr) A.v_out[chain * A.d + q] = v;
+    }
+    red[3] = 0.5f * v * v;
+    red[4] = ldv * 0.6931471805599453f;
+    const float U_end = red[2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      red[i] += __shfl_xor(red[i], 16);
+      red[i] += __shfl_xor(red[i], 32);
+    }
+    const bool writer = live && lane < 16;
+    if (A.logjac_out != nullptr && writer) A.logjac_out[moff + chain] = red[4];
+    if (need_p) {
+      const float p = accept_prob((red[0] + red[1]) - (red[2] + red[3]) + red[4]);     // dynamics.py:302-309
+      if (A.p_out != nullptr && writer) A.p_out[moff + chain] = p;
+      if (have_u) {
+        const bool acc = live && (p - u_m) >= 0.f;                                     // sampler.py:53-55
+        x = acc ? x : x0;
+        g = acc ? g : g0;
+        pv = sel4(acc, pv, pv0);
+        U_start = acc ? U_end : U_start;
+      } else {
+        U_start = U_end;
+      }
+    } else {
+      U_start = U_end;
+    }
+    if (A.x_hist != nullptr && live && livedim) A.x_hist[(moff + chain) * A.d + q] = x;
+  }
+  if (A.x_next != nullptr && live && livedim) A.x_next[chain * A.d + q] = x;
+}
+
+}  // namespace l2hmc

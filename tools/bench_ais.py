@@ -27,4 +27,4 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 exact = 0.5 * np.sum(np.log(var))        # log(Z_final / Z_init) of the two Gaussians
 print("AIS ICG-50: %d chains x %d anneal steps x %d leapfrogs in %.2f ms (1 kernel launch; %.3e chain-leapfrog-steps/s): "
-      "log Z ratio %.3f (exact %.3f), mean accept %.3f" % (N, K, T, 1e3 * el, N * K * T / el, float(est), exact, float(alpha)))
+      "AIS estimate of log Z ratio %.3f (a stochastic lower bound; exact %.3f), mean accept %.3f" % (N, K, T, 1e3 * el, N * K * T / el, float(est), exact, float(alpha)))
