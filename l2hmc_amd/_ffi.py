@@ -69,7 +69,7 @@ class L2hmcTrainArgs(C.Structure):
                 ("n_chains", C.c_int64), ("d", C.c_int32), ("H", C.c_int32), ("T", C.c_int32),
                 ("x", _fp), ("v", _fp), ("direction", _fp), ("direction_all", C.c_int32),
                 ("scale", C.c_float), ("inv_n", C.c_float),
-                ("Lx", _fp), ("p", _fp), ("v1", _fp), ("grad", _fp), ("workspace", _fp)]
+                ("Lx", _fp), ("p", _fp), ("v1", _fp), ("grad", _fp), ("workspace", _fp), ("variant", C.c_int32)]
 
 
 # every symbol include/l2hmc.h declares: name -> (restype, argtypes)

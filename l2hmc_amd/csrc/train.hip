@@ -847,6 +847,31 @@ __global__ void train_reduce_kernel(const float* part, int n_slots, int n_grad, 
   if (accumulate) dst[i] += s; else dst[(long long)c * n_grad + i] = s;
 }
 
+__device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.f); }
+#include "train_fast.hpp"
+
+// geometry of the register-resident kernel for this problem, or 0 if it stays on train_kernel
+inline int train_fast_waves(int ek, int d, int H) {
+  if (H > 15) return 0;
+  if (ek == L2HMC_ENERGY_GAUSS_DIAG || ek == L2HMC_ENERGY_ROUGHWELL) return d <= 16 ? 1 : (d <= 64 ? 4 : 0);
+  if (ek == L2HMC_ENERGY_GAUSS_DENSE) return d <= 16 ? 1 : 0;
+  return 0;
+}
+
+template <int EK, int NW>
+int launch_train_fast(const TArgs& k, int KH, unsigned blocks, long long lds, hipStream_t s) {
+  auto go = [&](auto kern) -> int {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), (size_t)lds, s, k);
+    return L2HMC_OK;
+  };
+  if (KH <= 3) return go(train_fast_kernel<EK, NW, 3>);
+  return go(train_fast_kernel<EK, NW, 4>);
+}
+
 }  // namespace l2hmc
 
 using namespace l2hmc;
@@ -867,7 +892,9 @@ int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int
   if (n_chains < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "l2hmc_train_workspace_floats: bad argument%s");
   // per-step checkpoints of every chain, then one flat partial gradient per 16-chain workgroup
   const int64_t blocks = (n_chains + TC - 1) / TC, chunks = (blocks + kReduceChunk - 1) / kReduceChunk;
-  return (int64_t)T * n_chains * CKPT * d + (blocks + chunks) * (2LL * net_params(d, H) + 1);
+  // checkpoints: (T, N, 5, d) for train_kernel; (blocks, T, 5, NW x 64 lanes) float4 for train_fast_kernel
+  const int64_t ck_old = (int64_t)T * n_chains * CKPT * d, ck_fast = blocks * T * TF_CK * (4 * 256);
+  return (ck_old > ck_fast ? ck_old : ck_fast) + (blocks + chunks) * (2LL * net_params(d, H) + 1);
 }
 
 int64_t l2hmc_train_grad_floats(int32_t d, int32_t H) {
@@ -906,20 +933,35 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
   k.ncomp = ek == L2HMC_ENERGY_GMM ? a->energy.n_comp : 1; k.easy = a->energy.easy;
   k.scale = a->scale; k.inv_n = a->inv_n;
   k.Lx = a->Lx; k.p = a->p; k.v1 = a->v1; k.grad = a->grad; k.ws = a->workspace;
-  const TLayout L = train_layout(a->d, a->H, a->T, ek, k.ncomp);
-  const long long lds = 4LL * L.total;
-  if (lds > 160 * 1024)
-    return fail(L2HMC_ERR_UNSUPPORTED, "training kernel needs %s%lld bytes of LDS (> 160 KiB): d / H too large for the 16-chain tile", "", lds);
   const unsigned blocks = (unsigned)((a->n_chains + TC - 1) / TC);
   hipStream_t s = (hipStream_t)stream;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  }
-  hipLaunchKernelGGL(train_kernel, dim3(blocks), dim3(TTHREADS), (size_t)lds, s, k);
   const int n_grad = 2 * net_params(a->d, a->H) + 1;
-  float* part = a->workspace + (long long)a->T * a->n_chains * CKPT * a->d;
+  float* part;
+  const int fnw = a->variant >= 100 ? 0 : train_fast_waves(ek, a->d, a->H);     // variant 100: the general tile kernel
+  const long long lds_fast = fnw ? 4LL * tf_layout(a->T, fnw).total : 0;
+  if (fnw && lds_fast <= 160 * 1024) {           // register-resident kernel (train_fast.hpp)
+    const int KH = khid_of(a->H);
+    int rc;
+    if (ek == L2HMC_ENERGY_GAUSS_DIAG) rc = fnw == 1 ? launch_train_fast<L2HMC_ENERGY_GAUSS_DIAG, 1>(k, KH, blocks, lds_fast, s)
+                                                     : launch_train_fast<L2HMC_ENERGY_GAUSS_DIAG, 4>(k, KH, blocks, lds_fast, s);
+    else if (ek == L2HMC_ENERGY_ROUGHWELL) rc = fnw == 1 ? launch_train_fast<L2HMC_ENERGY_ROUGHWELL, 1>(k, KH, blocks, lds_fast, s)
+                                                         : launch_train_fast<L2HMC_ENERGY_ROUGHWELL, 4>(k, KH, blocks, lds_fast, s);
+    else rc = launch_train_fast<L2HMC_ENERGY_GAUSS_DENSE, 1>(k, KH, blocks, lds_fast, s);
+    if (rc) return rc;
+    part = a->workspace + (long long)blocks * a->T * TF_CK * (fnw * 256);
+  } else {
+    const TLayout L = train_layout(a->d, a->H, a->T, ek, k.ncomp);
+    const long long lds = 4LL * L.total;
+    if (lds > 160 * 1024)
+      return fail(L2HMC_ERR_UNSUPPORTED, "training kernel needs %s%lld bytes of LDS (> 160 KiB): d / H too large for the 16-chain tile", "", lds);
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(train_kernel, dim3(blocks), dim3(TTHREADS), (size_t)lds, s, k);
+    part = a->workspace + (long long)a->T * a->n_chains * CKPT * a->d;
+  }
   if (blocks <= (unsigned)kReduceChunk) {
     hipLaunchKernelGGL(train_reduce_kernel, dim3((n_grad + 255) / 256, 1), dim3(256), 0, s, part, (int)blocks, n_grad,
                        (int)blocks, a->grad, 1);

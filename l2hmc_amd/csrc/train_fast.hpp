@@ -1,0 +1,543 @@
+// train_fast.hpp -- the training gradient in the register-resident layout of the forward kernel
+// (included by train.hip inside namespace l2hmc, after TArgs / NetOff / train_reduce_kernel).
+//
+// Same mathematics as train_kernel (hand-derived reverse mode of one direction-mixed proposal and its loss
+// term, SCGExperiment.ipynb raw 156-169, incl. the Hessian-vector path through grad U; derivation =
+// oracle/l2hmc_train_oracle.py), re-cast in the S-layout of traj_kernel:
+//
+//   * a workgroup of NW waves owns 16 chains, wave w the dimensions 16 w .. 16 w + 15; lane (c, q) holds the
+//     float4 {z[16 w + 4 q + r][chain c]} of every state / adjoint vector, and {h[unit(q, r)][chain c]} of every
+//     hidden vector -- the B operand and the C/D layout of v_mfma_f32_16x16x4_f32 at once;
+//   * forward layers, input adjoints (transposed weights) and the hidden-layer adjoints are MFMA chains on
+//     weight fragments staged ONCE per workgroup in both orientations (8 NT + 2 groups of 256 floats per net);
+//     the only cross-wave traffic is ONE exchange per net evaluation and one per net back-propagation
+//     (the K-split sums over dimensions), exactly as in the forward kernel;
+//   * weight gradients dW(k, i) += sum_c in(c, k) dout(c, i) contract over the 16 CHAINS of the tile: both
+//     operands are transposed through a per-wave LDS scratch (one ds_write_b128 + four ds_read_b32, no barrier:
+//     a wave's LDS operations execute in order) and the 16x16 gradient tiles ACCUMULATE IN REGISTERS over the
+//     whole reverse sweep (7 float4 per net); biases ride on the constant-1 hidden unit, so their gradients
+//     are rows of those tiles; the time-embedding gradients are one more K = chains product with (1, cos, sin);
+//   * no atomics: every workgroup writes its tiles to its slot of the workspace once, train_reduce_kernel adds
+//     the slots in block order (bitwise reproducible, as before).
+// Covers the elementwise targets (diagonal Gaussian, Rough Well) for d <= 64 and dense Gaussians for d <= 16;
+// GMM / larger shapes stay on train_kernel.
+#pragma once
+
+struct TFLayout {
+  int grp, tb, msk, trg, P, tr, red, total, NT, ng;
+};
+__host__ __device__ inline TFLayout tf_layout(int T, int NW) {
+  TFLayout L;
+  L.NT = NW;
+  L.ng = 8 * L.NT + 2;
+  int p = 0;
+  L.grp = p; p += 2 * L.ng * 256;
+  L.tb = p; p += 2 * T * 16;
+  L.msk = p; p += T * 16 * L.NT;
+  L.trg = p; p += (2 * T + 3) / 4 * 4;
+  L.P = p; p += 2 * NW * 256;
+  L.tr = p; p += NW * (320 + 32);          // per wave: 16 x 20 transpose scratch + (cos, sin) of its 16 chains
+  L.red = p; p += NW * 16 * 8 + 16;
+  L.total = p;
+  return L;
+}
+constexpr int TF_CK = 5;                   // checkpointed float4 per lane and step: x, v, v_half, y, x'
+
+template <int EK, int NW, int KH>
+__global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * NW;
+  const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+  const int c = lane & 15, q = lane >> 4;
+  const int d = A.d, H = A.H, T = A.T;
+  const TFLayout L = tf_layout(T, NW);
+  const int NT = L.NT, ng = L.ng, DP = 16 * NT;
+  const NetOff o = net_off(d, H);
+  const int P = net_params(d, H);
+  const long long n = (long long)blockIdx.x * 16 + c;
+  const bool alive = n < A.N;
+  const bool isf = A.dir != nullptr ? (alive ? A.dir[n] != 0 : true) : (A.dir_all != 0);
+  const float sg = isf ? 1.f : -1.f;
+  const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
+  const float heps = 0.5f * eps;
+  const float rw_den = A.easy ? A.eta : A.eta * A.eta;
+  const f4 Z = splat(0.f);
+
+  // unit carried by MFMA row i / by k index (q, r): rows 4 q' + r' with r' < KH are live, unit = q' KH + r'
+  auto unit_row = [&](int i) { return ((i & 3) < KH) ? (i >> 2) * KH + (i & 3) : -1; };
+
+  // ---- stage: weight fragments in both orientations, time/bias tables, masks -----------------------------------
+  for (int idx = tid; idx < 2 * ng * 256; idx += nthr) {
+    const int net = idx >= ng * 256, rem = idx - net * ng * 256;
+    const int g = rem >> 8, ln = (rem >> 2) & 63, r = rem & 3, i = ln & 15, kq = ln >> 4;
+    const int ui = unit_row(i), uk = (r < KH) ? kq * KH + r : -1;
+    const float* W4 = net ? A.vnet.W4 : A.xnet.W4;
+    float val = 0.f;
+    if (g == 0) {                                   // layer 2 forward: rows u' = ui, k = u = uk  (+ b4, + 1 -> 1)
+      const float* b4 = net ? A.vnet.b4 : A.xnet.b4;
+      if (uk >= 0 && ui >= 0) {
+        if (uk < H && ui < H) val = W4[uk * H + ui];
+        else if (uk == H && ui < H) val = b4[ui];
+        else if (uk == H && ui == H) val = 1.f;
+      }
+    } else if (g == 1) {                            // layer 2 transposed: rows u = ui, k = u' = uk
+      if (ui >= 0 && ui < H && uk >= 0 && uk < H) val = W4[ui * H + uk];
+    } else if (g < 2 + 6 * NT) {                    // heads: forward (rows = dims, k = units) / transposed
+      const bool tr = g >= 2 + 3 * NT;
+      const int hg = g - 2 - (tr ? 3 * NT : 0), tg = hg / 3, h = hg - 3 * tg;
+      const float* Wh = h == 0 ? (net ? A.vnet.Ws : A.xnet.Ws) : (h == 1 ? (net ? A.vnet.Wt : A.xnet.Wt) : (net ? A.vnet.Wq : A.xnet.Wq));
+      const float* bh = h == 0 ? (net ? A.vnet.bs : A.xnet.bs) : (h == 1 ? (net ? A.vnet.bt : A.xnet.bt) : (net ? A.vnet.bq : A.xnet.bq));
+      if (!tr) {
+        const int dim = 16 * tg + i;
+        if (dim < d && uk >= 0) {
+          if (uk < H) val = Wh[uk * d + dim];
+          else if (uk == H) val = bh[dim];
+        }
+      } else {
+        const int dim = 16 * tg + 4 * kq + r;
+        if (dim < d && ui >= 0 && ui < H) val = Wh[ui * d + dim];
+      }
+    } else {                                        // layer 1 transposed: rows = dims, k = units
+      const int lg = g - 2 - 6 * NT, tg = lg >> 1, which = lg & 1;
+      const float* W = which == 0 ? (net ? A.vnet.W1 : A.xnet.W1) : (net ? A.vnet.W2 : A.xnet.W2);
+      const int dim = 16 * tg + i;
+      if (dim < d && uk >= 0 && uk < H) val = W[dim * H + uk];
+    }
+    smem[L.grp + idx] = val;
+  }
+  for (int i = tid; i < 2 * T; i += nthr) smem[L.trg + i] = A.trig[i];
+  for (int idx = tid; idx < 2 * T * 16; idx += nthr) {
+    const int net = idx / (T * 16), srow = (idx / 16) % T, i = idx & 15;
+    const int ui = unit_row(i);
+    float val = 0.f;
+    if (ui == H) val = 1.f;
+    else if (ui >= 0 && ui < H) {
+      const float* W3 = net ? A.vnet.W3 : A.xnet.W3;
+      const float bsum = net ? (A.vnet.b1[ui] + A.vnet.b2[ui]) + A.vnet.b3[ui] : (A.xnet.b1[ui] + A.xnet.b2[ui]) + A.xnet.b3[ui];
+      val = fmaf(W3[ui], A.trig[2 * srow], fmaf(W3[H + ui], A.trig[2 * srow + 1], bsum));
+    }
+    smem[L.tb + idx] = val;
+  }
+  for (int i = tid; i < T * DP; i += nthr) {
+    const int row = i / DP, dim = i % DP;
+    smem[L.msk + i] = dim < d ? A.masks[row * d + dim] : 0.f;
+  }
+
+  // register-resident per-lane constants: layer-1 forward fragments of this wave's tile, exp(lam), energy parameters
+  const int dim0 = 16 * w + 4 * q;
+  f4 l1xa, l1xb, l1va, l1vb, esx, eqx, esv, eqv, emu = Z, epr = Z, Gf = Z;
+  {
+    const int ui = unit_row(c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dim = dim0 + r;
+      const bool ok = dim < d && ui >= 0 && ui < H;
+      l1xa[r] = ok ? A.xnet.W1[dim * H + ui] : 0.f;
+      l1xb[r] = ok ? A.xnet.W2[dim * H + ui] : 0.f;
+      l1va[r] = ok ? A.vnet.W1[dim * H + ui] : 0.f;
+      l1vb[r] = ok ? A.vnet.W2[dim * H + ui] : 0.f;
+      esx[r] = dim < d ? expf(A.xnet.lam_s[dim]) : 0.f;
+      eqx[r] = dim < d ? expf(A.xnet.lam_q[dim]) : 0.f;
+      esv[r] = dim < d ? expf(A.vnet.lam_s[dim]) : 0.f;
+      eqv[r] = dim < d ? expf(A.vnet.lam_q[dim]) : 0.f;
+      if (EK != L2HMC_ENERGY_ROUGHWELL) emu[r] = dim < d ? A.mu[dim] : 0.f;
+      if (EK == L2HMC_ENERGY_GAUSS_DIAG) epr[r] = dim < d ? A.prec[dim] : 0.f;
+      if (EK == L2HMC_ENERGY_GAUSS_DENSE)       // NW == 1: A operand of y = G dx, rows = out dims c, k = 4 q + r
+        Gf[r] = (c < d && dim < d) ? 0.5f * (A.prec[c * d + dim] + A.prec[dim * d + c]) : 0.f;
+    }
+  }
+  const f4 live4 = f4{dim0 < d ? 1.f : 0.f, dim0 + 1 < d ? 1.f : 0.f, dim0 + 2 < d ? 1.f : 0.f, dim0 + 3 < d ? 1.f : 0.f};
+  __syncthreads();
+
+  const float* grpx = smem + L.grp;
+  const float* grpv = grpx + ng * 256;
+  auto frag = [&](const float* gb, int g) { return lds4(gb + (g * 64 + lane) * 4); };
+  auto chain4 = [&](f4 Wf, f4 in, f4 acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = MFMA16(Wf[r], in[r], acc);
+    return acc;
+  };
+  auto chainK = [&](f4 Wf, f4 in, f4 acc) {
+#pragma unroll
+    for (int r = 0; r < KH; ++r) acc = MFMA16(Wf[r], in[r], acc);
+    return acc;
+  };
+  int pb = 0;
+  auto exch = [&](f4 p) {
+    if (NW == 1) return p;
+    float* Pb = smem + L.P + pb * (NW * 256);
+    *reinterpret_cast<f4*>(Pb + (w * 64 + lane) * 4) = p;
+    __syncthreads();
+    f4 s = lds4(Pb + lane * 4);
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) s += lds4(Pb + (ww * 64 + lane) * 4);
+    pb ^= 1;
+    return s;
+  };
+  // in: lane (c, q) holds val[row 4 q + r][chain c];  out: lane (i, kq) holds val[row i][chain 4 kq + r]
+  float* scr = smem + L.tr + w * (320 + 32);
+  auto transp = [&](f4 val) {
+    *reinterpret_cast<f4*>(scr + c * 20 + 4 * q) = val;
+    f4 ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = scr[(4 * q + r) * 20 + c];
+    return ov;
+  };
+  auto relu4i = [&](f4 a) {
+    f4 o = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) o[r] = relu_f(a[r]);
+    return o;
+  };
+
+  // ---- energies ------------------------------------------------------------------------------------------------
+  auto gradU = [&](f4 z) {
+    f4 g;
+    if (EK == L2HMC_ENERGY_GAUSS_DIAG) g = epr * (z - emu);
+    else if (EK == L2HMC_ENERGY_GAUSS_DENSE) g = chain4(Gf, z - emu, Z);
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[r] = z[r] - (A.eta / rw_den) * sinf(z[r] / rw_den);
+      g = g * live4;
+    }
+    return g;
+  };
+  auto hessvec = [&](f4 z, f4 vec) {
+    f4 o;
+    if (EK == L2HMC_ENERGY_GAUSS_DIAG) o = epr * vec;
+    else if (EK == L2HMC_ENERGY_GAUSS_DENSE) o = chain4(Gf, vec, Z);
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (1.f - (A.eta / (rw_den * rw_den)) * cosf(z[r] / rw_den)) * vec[r];
+      o = o * live4;
+    }
+    return o;
+  };
+  auto energy_part = [&](f4 z, f4 g) {          // this lane's share of U(z)
+    float u = 0.f;
+    if (EK == L2HMC_ENERGY_ROUGHWELL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u += live4[r] * (0.5f * z[r] * z[r] + A.eta * cosf(z[r] / rw_den));
+    } else {
+      u = 0.5f * hsum((z - emu) * g);
+    }
+    return u;
+  };
+
+  // ---- one net evaluation (forward): caches h1, h2, ts = tanh(zs), T, tq = tanh(zq) ------------------------------
+  struct Cache { f4 h1, h2, ts, Tt, tq; };
+  auto net_fwd = [&](int net, f4 a, f4 b, f4 tbrow, Cache& C) {
+    const float* gb = net ? grpv : grpx;
+    f4 p = chain4(net ? l1va : l1xa, a, Z) + chain4(net ? l1vb : l1xb, b, Z);
+    p = exch(p);
+    C.h1 = relu4i(p + tbrow);
+    C.h2 = relu4i(chainK(frag(gb, 0), C.h1, Z));
+    const f4 zs = chainK(frag(gb, 2 + 3 * w + 0), C.h2, Z);
+    const f4 zt = chainK(frag(gb, 2 + 3 * w + 1), C.h2, Z);
+    const f4 zq = chainK(frag(gb, 2 + 3 * w + 2), C.h2, Z);
+    C.ts = tanh4(zs);
+    C.Tt = zt;
+    C.tq = tanh4(zq);
+  };
+
+  // gradient tiles of one net (registers, whole reverse sweep)
+  struct Acc { f4 hS, hT, hQ, w1, w2, w4, tau, lamS, lamQ; };
+  Acc GX, GV;
+  GX.hS = GX.hT = GX.hQ = GX.w1 = GX.w2 = GX.w4 = GX.tau = GX.lamS = GX.lamQ = Z;
+  GV = GX;
+
+  // ---- back-propagation through one net: consumes dzs, dzt, dzq (+ dA, dB for the log-scales), returns the input
+  //      adjoints da, db; `cs`: this wave's (cos, sin) of the 16 chains at the current step ------------------------
+  auto net_bwd = [&](int net, const Cache& C, f4 a, f4 b, f4 dzs, f4 dzt, f4 dzq, f4 dA, f4 dB, Acc& G, f4& da, f4& db) {
+    const float* gb = net ? grpv : grpx;
+    G.lamS += dA;
+    G.lamQ += dB;
+    // d h2 (partial over this wave's dims, summed over the waves), d a2, d h1, d a1
+    f4 dh2 = chain4(frag(gb, 2 + 3 * NT + 3 * w + 0), dzs, Z);
+    dh2 = chain4(frag(gb, 2 + 3 * NT + 3 * w + 1), dzt, dh2);
+    dh2 = chain4(frag(gb, 2 + 3 * NT + 3 * w + 2), dzq, dh2);
+    dh2 = exch(dh2);
+    f4 da2 = Z, da1 = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) da2[r] = C.h2[r] > 0.f ? dh2[r] : 0.f;
+    const f4 dh1 = chainK(frag(gb, 1), da2, Z);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) da1[r] = C.h1[r] > 0.f ? dh1[r] : 0.f;
+    da = chainK(frag(gb, 2 + 6 * NT + 2 * w + 0), da1, Z);
+    db = chainK(frag(gb, 2 + 6 * NT + 2 * w + 1), da1, Z);
+    // weight gradients: contractions over the 16 chains, operands transposed through the wave's scratch
+    const f4 th2 = transp(C.h2);
+    G.hS = chain4(transp(dzs), th2, G.hS);
+    G.hT = chain4(transp(dzt), th2, G.hT);
+    G.hQ = chain4(transp(dzq), th2, G.hQ);
+    const f4 tda1 = transp(da1);
+    G.w1 = chain4(transp(a), tda1, G.w1);
+    G.w2 = chain4(transp(b), tda1, G.w2);
+    G.w4 = chain4(transp(C.h1), transp(da2), G.w4);
+    f4 tt;                                       // rows: 0 -> 1, 1 -> cos, 2 -> sin of chain 4 q + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tt[r] = c == 0 ? 1.f : (c == 1 ? scr[320 + 2 * (4 * q + r)] : (c == 2 ? scr[320 + 2 * (4 * q + r) + 1] : 0.f));
+    G.tau = chain4(tt, tda1, G.tau);
+  };
+
+  // ---- per-step schedule ------------------------------------------------------------------------------------------
+  int s_me = 0;
+  f4 k1 = Z, tbx = Z, tbv = Z;
+  auto set_step = [&](int it) {
+    s_me = isf ? it : (T - 1 - it);
+    const f4 m = lds4(smem + L.msk + s_me * DP + dim0);
+    k1 = isf ? m : (splat(1.f) - m);
+    tbx = lds4(smem + L.tb + s_me * 16 + 4 * q);
+    tbv = lds4(smem + L.tb + (T + s_me) * 16 + 4 * q);
+    if (q == 0) { scr[320 + 2 * c] = smem[L.trg + 2 * s_me]; scr[320 + 2 * c + 1] = smem[L.trg + 2 * s_me + 1]; }
+  };
+
+  // ---- half updates (forward) --------------------------------------------------------------------------------------
+  f4 ldv = Z;
+  auto v_half_f = [&](const Cache& C, f4 vin, f4 g) {
+    const f4 S = esv * C.ts, Q = eqv * C.tq;
+    const f4 ES = exp4(S * (sg * heps)), EQ = exp4(Q * eps);
+    const f4 cc = (C.Tt - EQ * g) * heps;
+    ldv += S * (sg * heps);
+    return isf ? vin * ES + cc : (vin - cc) * ES;
+  };
+  auto x_half_f = [&](const Cache& C, f4 zin, f4 kp, f4 vh) {
+    const f4 up = splat(1.f) - kp;
+    const f4 S = esx * C.ts, Q = eqx * C.tq;
+    const f4 ES = exp4(S * (sg * eps)), EQ = exp4(Q * eps);
+    const f4 tr = (EQ * vh + C.Tt) * eps;
+    const f4 nw = isf ? zin * ES + tr : ES * (zin - tr);
+    ldv += up * S * (sg * eps);
+    return kp * zin + up * nw;
+  };
+
+  // ---- load the start state ----------------------------------------------------------------------------------------
+  auto gload = [&](const float* p) {
+    f4 r = Z;
+    if (alive) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (dim0 + j < d) r[j] = p[n * d + dim0 + j];
+    }
+    return r;
+  };
+  const f4 xs = gload(A.x);
+  f4 x = xs, v = gload(A.v);
+  f4 g = gradU(x);
+  float red[6];
+  red[0] = energy_part(x, g);                    // U0
+  red[1] = 0.5f * hsum(v * v);                   // K0
+  f4* ck = reinterpret_cast<f4*>(A.ws) + ((long long)blockIdx.x * T * TF_CK) * (NW * 64) + w * 64 + lane;
+  auto ckp = [&](int it, int slot) -> f4& { return ck[((long long)it * TF_CK + slot) * (NW * 64)]; };
+
+  // ---- forward trajectory with checkpoints -----------------------------------------------------------------------------
+  Cache C;
+  for (int it = 0; it < T; ++it) {
+    set_step(it);
+    net_fwd(1, x, g, tbv, C);
+    const f4 vh = v_half_f(C, v, g);
+    net_fwd(0, vh, k1 * x, tbx, C);
+    const f4 y = x_half_f(C, x, k1, vh);
+    net_fwd(0, vh, (splat(1.f) - k1) * y, tbx, C);
+    const f4 xo = x_half_f(C, y, splat(1.f) - k1, vh);
+    ckp(it, 0) = x; ckp(it, 1) = v; ckp(it, 2) = vh; ckp(it, 3) = y; ckp(it, 4) = xo;
+    g = gradU(xo);
+    net_fwd(1, xo, g, tbv, C);
+    v = v_half_f(C, vh, g);
+    x = xo;
+  }
+
+  // ---- accept probability, loss term, adjoint seeds ----------------------------------------------------------------------
+  red[2] = energy_part(x, g);                    // U1
+  red[3] = 0.5f * hsum(v * v);                   // K1
+  red[4] = hsum((xs - x) * (xs - x));            // |x0 - Lx|^2
+  red[5] = hsum(ldv);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    red[i] += __shfl_xor(red[i], 16);
+    red[i] += __shfl_xor(red[i], 32);
+  }
+  if (NW > 1) {
+    float* R = smem + L.red;
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) R[(w * 16 + lane) * 8 + i] = red[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) s += R[(ww * 16 + c) * 8 + i];
+      red[i] = s;
+    }
+    __syncthreads();
+  }
+  const float val = (red[0] + red[1]) - (red[2] + red[3]) + red[5];
+  const float p = accept_prob(val);
+  const float sq = red[4];
+  const float v1 = sq * p + 1e-4f;
+  if (alive && w == 0 && lane < 16) { A.p[n] = p; A.v1[n] = v1; }
+  const float dv1 = alive ? (A.scale * (-1.f / (v1 * v1)) - 1.f / A.scale) * A.inv_n : 0.f;
+  const bool pfin = (val == val) && p > 0.f;      // finite branch of dynamics.py:309 actually taken
+  const float lam = (pfin && val < 0.f) ? dv1 * sq * p : 0.f;
+  const float dv1p = dv1 * p * 2.f;
+  const bool okc = sq < 3.0e38f;
+  if (alive) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (dim0 + j < d) A.Lx[n * d + dim0 + j] = x[j];
+  }
+  f4 lx = okc ? (x - xs) * dv1p - g * lam : Z;
+  f4 lv = okc ? v * (-lam) : Z;
+  float deps = 0.f;
+
+  // ---- adjoints of the half updates -----------------------------------------------------------------------------------------
+  // v_half: given dout -> d vin, dg, and (dzs, dzt, dzq, dA, dB) for net_bwd
+  auto v_half_b = [&](const Cache& C, f4 dout, f4 vin, f4 gq, f4& dvin, f4& dg, f4& dzs, f4& dzt, f4& dzq, f4& dA, f4& dB) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ts = C.ts[r], tq = C.tq[r], Tt = C.Tt[r];
+      const float S = esv[r] * ts, Q = eqv[r] * tq;
+      const float ES = fexp(sg * heps * S), EQ = fexp(eps * Q);
+      const float cc = heps * (Tt - EQ * gq[r]);
+      const float dES = isf ? dout[r] * vin[r] : dout[r] * (vin[r] - cc);
+      const float dcc = isf ? dout[r] : -dout[r] * ES;
+      const float ds = dES * ES + lam * live4[r];
+      const float dSr = ds * sg * heps;
+      const float dq = -dcc * heps * gq[r] * EQ;
+      const float dQr = dq * eps;
+      dvin[r] = dout[r] * ES;
+      dg[r] = -dcc * heps * EQ;
+      dA[r] = dSr * S;
+      dB[r] = dQr * Q;
+      dzs[r] = dSr * esv[r] * (1.f - ts * ts);
+      dzt[r] = dcc * heps;
+      dzq[r] = dQr * eqv[r] * (1.f - tq * tq);
+      deps += ds * sg * 0.5f * S + dcc * 0.5f * (Tt - EQ * gq[r]) + dq * Q;
+    }
+  };
+  // x_half: given dout -> d zin (direct part), dvh +=, and the net adjoints
+  auto x_half_b = [&](const Cache& C, f4 dout, f4 zin, f4 kp, f4 vhq, f4& dzin, f4& dvh, f4& dzs, f4& dzt, f4& dzq, f4& dA, f4& dB) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float up = 1.f - kp[r];
+      const float ts = C.ts[r], tq = C.tq[r], Tt = C.Tt[r];
+      const float S = esx[r] * ts, Q = eqx[r] * tq;
+      const float ES = fexp(sg * eps * S), EQ = fexp(eps * Q);
+      const float tr = eps * (EQ * vhq[r] + Tt);
+      const float dnw = up * dout[r];
+      const float dES = isf ? dnw * zin[r] : dnw * (zin[r] - tr);
+      const float dtr = isf ? dnw : -dnw * ES;
+      const float dsx = dES * ES + up * lam * live4[r];
+      const float dSr = dsx * sg * eps;
+      const float dq = dtr * eps * vhq[r] * EQ;
+      const float dQr = dq * eps;
+      dzin[r] = kp[r] * dout[r] + dnw * ES;
+      dvh[r] += dtr * eps * EQ;
+      dA[r] = dSr * S;
+      dB[r] = dQr * Q;
+      dzs[r] = dSr * esx[r] * (1.f - ts * ts);
+      dzt[r] = dtr * eps;
+      dzq[r] = dQr * eqx[r] * (1.f - tq * tq);
+      deps += dsx * sg * S + dtr * (EQ * vhq[r] + Tt) + dq * Q;
+    }
+  };
+
+  // ---- reverse sweep ---------------------------------------------------------------------------------------------------------
+  for (int it = T - 1; it >= 0; --it) {
+    set_step(it);
+    const f4 cx = ckp(it, 0), cv = ckp(it, 1), cvh = ckp(it, 2), cy = ckp(it, 3), cxo = ckp(it, 4);
+    const f4 one = splat(1.f);
+    f4 dvh = Z, dg, dzs, dzt, dzq, dA, dB, da, db, dz;
+    // (1) v' = v_half(vh; g(x'), V(x', g(x')))
+    f4 gq = gradU(cxo);
+    net_fwd(1, cxo, gq, tbv, C);
+    v_half_b(C, lv, cvh, gq, dvh, dg, dzs, dzt, dzq, dA, dB);
+    net_bwd(1, C, cxo, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
+    lx = lx + da + hessvec(cxo, dg + db);                         // d x'
+    // (2) x' = x_half(y, k2; vh, X(vh, k2 y)),  k2 = 1 - k1
+    const f4 k2 = one - k1;
+    net_fwd(0, cvh, k2 * cy, tbx, C);
+    x_half_b(C, lx, cy, k2, cvh, dz, dvh, dzs, dzt, dzq, dA, dB); // dz = d y (direct part)
+    net_bwd(0, C, cvh, k2 * cy, dzs, dzt, dzq, dA, dB, GX, da, db);
+    dvh += da;
+    dz += k2 * db;
+    // (3) y = x_half(x, k1; vh, X(vh, k1 x))
+    net_fwd(0, cvh, k1 * cx, tbx, C);
+    x_half_b(C, dz, cx, k1, cvh, lx, dvh, dzs, dzt, dzq, dA, dB); // lx = d x (direct part)
+    net_bwd(0, C, cvh, k1 * cx, dzs, dzt, dzq, dA, dB, GX, da, db);
+    dvh += da;
+    lx += k1 * db;
+    // (4) vh = v_half(v; g(x), V(x, g(x)))
+    gq = gradU(cx);
+    net_fwd(1, cx, gq, tbv, C);
+    v_half_b(C, dvh, cv, gq, lv, dg, dzs, dzt, dzq, dA, dB);
+    net_bwd(1, C, cx, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
+    lx = lx + da + hessvec(cx, dg + db);
+  }
+
+  // ---- this workgroup's flat gradient [xnet (P) | vnet (P) | eps] -> its slot of the workspace ------------------------------------
+  float* slot = A.ws + (long long)gridDim.x * T * TF_CK * (NW * 256) + (long long)blockIdx.x * (2 * P + 1);
+  {
+    float s = wave_sum(deps);
+    float* R = smem + L.red + NW * 16 * 8;
+    if (lane == 0) R[w] = s;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int ww = 0; ww < NW; ++ww) t += R[ww];
+      slot[2 * P] = t;
+    }
+  }
+  const int ui = unit_row(c);                    // unit on the COLUMN (lane & 15) of the weight-gradient tiles
+  auto flush = [&](const Acc& G, float* Gn) {
+    const int hs = H * d + d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dim = dim0 + r;
+      if (dim < d && ui >= 0 && ui <= H) {
+        if (ui < H) {
+          Gn[o.Ws + 0 * hs + ui * d + dim] = G.hS[r];
+          Gn[o.Ws + 1 * hs + ui * d + dim] = G.hT[r];
+          Gn[o.Ws + 2 * hs + ui * d + dim] = G.hQ[r];
+          Gn[o.W1 + dim * H + ui] = G.w1[r];
+          Gn[o.W1 + (d * H + H) + dim * H + ui] = G.w2[r];
+        } else {                                 // the constant-1 unit: head biases
+          Gn[o.bs + 0 * hs + dim] = G.hS[r];
+          Gn[o.bs + 1 * hs + dim] = G.hT[r];
+          Gn[o.bs + 2 * hs + dim] = G.hQ[r];
+        }
+      }
+    }
+    if (w == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {              // dW4[u(row 4 q + r)][u'(c)]; row u = H: b4
+        const int u = r < KH ? q * KH + r : -1;
+        if (u >= 0 && u <= H && ui >= 0 && ui < H) {
+          if (u < H) Gn[o.W4 + u * H + ui] = G.w4[r];
+          else Gn[o.b4 + ui] = G.w4[r];
+        }
+      }
+      if (q == 0 && ui >= 0 && ui < H) {         // rows 0, 1, 2 of the (1, cos, sin) product
+        Gn[o.b1 + ui] = G.tau[0]; Gn[o.b2 + ui] = G.tau[0]; Gn[o.b3 + ui] = G.tau[0];
+        Gn[o.W3 + ui] = G.tau[1];
+        Gn[o.W3 + H + ui] = G.tau[2];
+      }
+    }
+    // log-scales: sums over the 16 chains of the tile
+    f4 ls = G.lamS, lq = G.lamQ;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ls[r] += __shfl_xor(ls[r], off); lq[r] += __shfl_xor(lq[r], off); }
+    }
+    if (c == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (dim0 + r < d) { Gn[o.ls + dim0 + r] = ls[r]; Gn[o.lq + dim0 + r] = lq[r]; }
+    }
+  };
+  flush(GX, slot);
+  flush(GV, slot + P);
+}

@@ -73,6 +73,7 @@ class Trainer(object):
         self.v = torch.zeros_like(self.theta)
         self.global_step = 0
         self._ws = None
+        self.variant = 0             # 100: force the general tile kernel (l2hmc.h)
         self._io = None              # per-N buffers of step()
         self._shard_cache = None
 
@@ -143,6 +144,7 @@ class Trainer(object):
         a.scale, a.inv_n = self.scale, 1.0 / float(n_total)
         a.Lx, a.p, a.v1 = Lx.data_ptr(), p.data_ptr(), v1.data_ptr()
         a.grad, a.workspace = self.flat.data_ptr(), self._ws.data_ptr()
+        a.variant = int(self.variant)
         _ffi.check(L.l2hmc_train_propose_grad(a, _ffi.current_stream(dyn.device)))
         return Lx, p, v1
 

@@ -395,10 +395,12 @@ def test_sample_chain_with_in_kernel_rng(case):
         assert torch.equal(ps, p[:, lo:]) and torch.equal(xs, xf[lo:])
 
 
+@pytest.mark.parametrize("variant", [0, 100])
 @pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6"])
-def test_training_gradient_matches_reference_graph(case):
+def test_training_gradient_matches_reference_graph(case, variant):
     """l2hmc_train_propose_grad (HIP, hand-derived reverse mode) vs tf.gradients of the notebook
-    loss from the reference's own graph: loss, proposals, every parameter gradient and alpha."""
+    loss from the reference's own graph: loss, proposals, every parameter gradient and alpha.
+    variant 0: the register-resident kernel where it applies; 100: the general tile kernel."""
     from l2hmc_amd.training import Trainer
     g = load(case)
     dyn = hip_dynamics(g)
@@ -407,6 +409,7 @@ def test_training_gradient_matches_reference_graph(case):
     with torch.no_grad():
         dyn.alpha.fill_(float(np.log(g["eps"])))
     tr = Trainer(dyn)
+    tr.variant = variant
     draws = {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
              "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
              "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
