@@ -854,7 +854,7 @@ __device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.f); }
 inline int train_fast_waves(int ek, int d, int H) {
   if (H > 15) return 0;
   if (ek == L2HMC_ENERGY_GAUSS_DIAG || ek == L2HMC_ENERGY_ROUGHWELL) return d <= 16 ? 1 : (d <= 64 ? 4 : 0);
-  if (ek == L2HMC_ENERGY_GAUSS_DENSE) return d <= 16 ? 1 : 0;
+  if (ek == L2HMC_ENERGY_GAUSS_DENSE || ek == L2HMC_ENERGY_FUNNEL) return d <= 16 ? 1 : 0;
   return 0;
 }
 
@@ -912,9 +912,11 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
     return fail(L2HMC_ERR_ARG, "l2hmc_train_propose_grad: NULL pointer%s");
   const int ek = a->energy.kind;
   if (ek != L2HMC_ENERGY_GAUSS_DIAG && ek != L2HMC_ENERGY_GAUSS_DENSE && ek != L2HMC_ENERGY_GMM &&
-      ek != L2HMC_ENERGY_ROUGHWELL)
-    return fail(L2HMC_ERR_UNSUPPORTED, "training supports the Gaussian, GMM and Rough-Well targets (analytic Hessian-vector products)%s");
-  if (ek != L2HMC_ENERGY_ROUGHWELL && (!a->energy.mu || !a->energy.prec))
+      ek != L2HMC_ENERGY_ROUGHWELL && ek != L2HMC_ENERGY_FUNNEL)
+    return fail(L2HMC_ERR_UNSUPPORTED, "training supports the Gaussian, GMM, Rough-Well and funnel targets (analytic Hessian-vector products)%s");
+  if (ek == L2HMC_ENERGY_FUNNEL && (a->d > 16 || a->d < 2 || a->H > 15 || a->variant >= 100 || !(a->energy.eta > 0.f)))
+    return fail(L2HMC_ERR_UNSUPPORTED, "funnel training: 2 <= d <= 16, H <= 15, sigma > 0 (register-resident kernel only)%s");
+  if (ek != L2HMC_ENERGY_ROUGHWELL && ek != L2HMC_ENERGY_FUNNEL && (!a->energy.mu || !a->energy.prec))
     return fail(L2HMC_ERR_ARG, "energy needs mu and prec (RAW (d,d) precisions for the dense / GMM kinds)%s");
   if (ek == L2HMC_ENERGY_GMM && (!a->energy.logc || a->energy.n_comp < 1 || a->energy.n_comp > KC))
     return fail(L2HMC_ERR_ARG, "GMM training needs logc and 1 <= n_comp <= 8%s");
@@ -946,6 +948,7 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
                                                      : launch_train_fast<L2HMC_ENERGY_GAUSS_DIAG, 4>(k, KH, blocks, lds_fast, s);
     else if (ek == L2HMC_ENERGY_ROUGHWELL) rc = fnw == 1 ? launch_train_fast<L2HMC_ENERGY_ROUGHWELL, 1>(k, KH, blocks, lds_fast, s)
                                                          : launch_train_fast<L2HMC_ENERGY_ROUGHWELL, 4>(k, KH, blocks, lds_fast, s);
+    else if (ek == L2HMC_ENERGY_FUNNEL) rc = launch_train_fast<L2HMC_ENERGY_FUNNEL, 1>(k, KH, blocks, lds_fast, s);
     else rc = launch_train_fast<L2HMC_ENERGY_GAUSS_DENSE, 1>(k, KH, blocks, lds_fast, s);
     if (rc) return rc;
     part = a->workspace + (long long)blocks * a->T * TF_CK * (fnw * 256);

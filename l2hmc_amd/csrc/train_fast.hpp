@@ -19,8 +19,8 @@
 //     are rows of those tiles; the time-embedding gradients are one more K = chains product with (1, cos, sin);
 //   * no atomics: every workgroup writes its tiles to its slot of the workspace once, train_reduce_kernel adds
 //     the slots in block order (bitwise reproducible, as before).
-// Covers the elementwise targets (diagonal Gaussian, Rough Well) for d <= 64 and dense Gaussians for d <= 16;
-// GMM / larger shapes stay on train_kernel.
+// Covers the elementwise targets (diagonal Gaussian, Rough Well) for d <= 64, dense Gaussians and the funnel
+// (analytic Hessian-vector product through wave shuffles) for d <= 16; GMM / larger shapes stay on train_kernel.
 #pragma once
 
 struct TFLayout {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
       eqx[r] = dim < d ? expf(A.xnet.lam_q[dim]) : 0.f;
       esv[r] = dim < d ? expf(A.vnet.lam_s[dim]) : 0.f;
       eqv[r] = dim < d ? expf(A.vnet.lam_q[dim]) : 0.f;
-      if (EK != L2HMC_ENERGY_ROUGHWELL) emu[r] = dim < d ? A.mu[dim] : 0.f;
+      if (EK != L2HMC_ENERGY_ROUGHWELL && EK != L2HMC_ENERGY_FUNNEL) emu[r] = dim < d ? A.mu[dim] : 0.f;
       if (EK == L2HMC_ENERGY_GAUSS_DIAG) epr[r] = dim < d ? A.prec[dim] : 0.f;
       if (EK == L2HMC_ENERGY_GAUSS_DENSE)       // NW == 1: A operand of y = G dx, rows = out dims c, k = 4 q + r
         Gf[r] = (c < d && dim < d) ? 0.5f * (A.prec[c * d + dim] + A.prec[dim * d + c]) : 0.f;
@@ -191,8 +191,31 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   };
 
   // ---- energies ------------------------------------------------------------------------------------------------
+  // funnel (distributions.py:155-180; NW == 1): v = z_0 lives in lane (c, 0) component 0; the chain's 4 lanes share
+  // v, q = sum_{k >= 1} z_k^2 and the branch (free / clipped at +- 4 sigma) through wave shuffles
+  struct Fun { float v, qsum, inv, s; bool clipped; };
+  auto fun_parts = [&](f4 z) {
+    Fun F;
+    F.v = __shfl(z[0], c);
+    float part = hsum(z * z) - (q == 0 ? z[0] * z[0] : 0.f);
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    F.qsum = part;
+    const float clip = 4.f * A.eta;
+    const bool hi = F.v > clip, lo = -clip > F.v;
+    F.clipped = hi || lo;
+    F.s = hi ? expf(clip) : (lo ? expf(-clip) : expf(F.v));
+    F.inv = 1.f / F.s;
+    return F;
+  };
   auto gradU = [&](f4 z) {
     f4 g;
+    if (EK == L2HMC_ENERGY_FUNNEL) {
+      const Fun F = fun_parts(z);
+      g = z * F.inv;
+      if (q == 0) g[0] = F.v / (A.eta * A.eta) + (F.clipped ? 0.f : 0.5f * ((float)(d - 1) - F.qsum * F.inv));
+      return g;
+    }
     if (EK == L2HMC_ENERGY_GAUSS_DIAG) g = epr * (z - emu);
     else if (EK == L2HMC_ENERGY_GAUSS_DENSE) g = chain4(Gf, z - emu, Z);
     else {
@@ -204,6 +227,17 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   };
   auto hessvec = [&](f4 z, f4 vec) {
     f4 o;
+    if (EK == L2HMC_ENERGY_FUNNEL) {
+      const Fun F = fun_parts(z);
+      const float u0 = __shfl(vec[0], c);
+      float dot = hsum(z * vec) - (q == 0 ? z[0] * vec[0] : 0.f);
+      dot += __shfl_xor(dot, 16);
+      dot += __shfl_xor(dot, 32);
+      const float fr = F.clipped ? 0.f : 1.f;
+      o = vec * F.inv - z * (fr * u0 * F.inv);
+      if (q == 0) o[0] = u0 * (1.f / (A.eta * A.eta) + fr * 0.5f * F.qsum * F.inv) - fr * dot * F.inv;
+      return o;
+    }
     if (EK == L2HMC_ENERGY_GAUSS_DIAG) o = epr * vec;
     else if (EK == L2HMC_ENERGY_GAUSS_DENSE) o = chain4(Gf, vec, Z);
     else {
@@ -215,6 +249,11 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   };
   auto energy_part = [&](f4 z, f4 g) {          // this lane's share of U(z)
     float u = 0.f;
+    if (EK == L2HMC_ENERGY_FUNNEL) {
+      const Fun F = fun_parts(z);
+      const float lp = (F.v / A.eta) * (F.v / A.eta);
+      return lane < 16 ? 0.5f * (lp + F.qsum * F.inv + (float)(d - 1) * logf(6.283185307179586f * F.s)) : 0.f;
+    }
     if (EK == L2HMC_ENERGY_ROUGHWELL) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) u += live4[r] * (0.5f * z[r] * z[r] + A.eta * cosf(z[r] / rw_den));

@@ -125,10 +125,10 @@ class Trainer(object):
             prec = buf["prec"]
         elif fn.kind in (_ffi.ENERGY_GAUSS_DENSE, _ffi.ENERGY_GMM):
             prec = buf["_raw"]                         # RAW (k, d, d) precisions, not the MFMA packing
-        elif fn.kind == _ffi.ENERGY_ROUGHWELL:
+        elif fn.kind in (_ffi.ENERGY_ROUGHWELL, _ffi.ENERGY_FUNNEL):
             prec = None
         else:
-            raise NotImplementedError("training supports the Gaussian, GMM and Rough-Well targets")
+            raise NotImplementedError("training supports the Gaussian, GMM, Rough-Well and funnel targets")
         a = _ffi.L2hmcTrainArgs()
         a.xnet, a.vnet = C.pointer(xs), C.pointer(vs)
         a.energy = _ffi.L2hmcEnergy(fn.kind, fn.n_comp, _ffi.ptr(buf["mu"]), _ffi.ptr(prec), _ffi.ptr(buf["logc"]),

@@ -169,6 +169,46 @@ class RoughWellTarget:
         return (1.0 - (self.eta / (self.den * self.den)) * np.cos(x / self.den)) * v
 
 
+class FunnelTarget:
+    """distributions.py:155-180 (sigma = 2, clip = 4 sigma; `tf.where` selects the branch and routes its gradient).
+    Free branch, s = e^v, q = sum_{k>=1} x_k^2, n = d - 1:  U = (v^2 / sigma^2 + q / s + n log(2 pi s)) / 2;
+    grad_k = x_k / s,  grad_0 = v / sigma^2 + (n - q / s) / 2;
+    H u:  (H u)_k = u_k / s - x_k u_0 / s,   (H u)_0 = u_0 (1 / sigma^2 + q / (2 s)) - sum_k x_k u_k / s.
+    Clipped branches: s is a constant, so the cross terms and the q-term of (H u)_0 vanish."""
+
+    def __init__(self, sigma, dtype):
+        self.sigma = dtype(sigma)
+        self.clip = dtype(4 * sigma)
+        self.dtype = dtype
+
+    def _parts(self, x):
+        v = x[:, 0]
+        hi, lo = v > self.clip, -self.clip > v
+        s = np.exp(v)
+        s_eff = np.where(hi, np.exp(self.clip), np.where(lo, np.exp(-self.clip), s))
+        return v, hi | lo, s_eff, np.sum(np.square(x[:, 1:]), axis=1)
+
+    def energy(self, x):
+        v, _, s_eff, q = self._parts(x)
+        n = self.dtype(x.shape[1] - 1)
+        return 0.5 * (np.square(v / self.sigma) + q / s_eff + n * np.log(self.dtype(2.0 * np.pi) * s_eff))
+
+    def grad(self, x):
+        v, clipped, s_eff, q = self._parts(x)
+        n = self.dtype(x.shape[1] - 1)
+        g = x / s_eff[:, None]
+        g[:, 0] = v / (self.sigma * self.sigma) + np.where(clipped, 0.0, 0.5 * (n - q / s_eff))
+        return g
+
+    def hessvec(self, x, u):
+        v, clipped, s_eff, q = self._parts(x)
+        free = (~clipped).astype(x.dtype)
+        out = u / s_eff[:, None] - free[:, None] * x * (u[:, 0] / s_eff)[:, None]
+        dot = np.sum(x[:, 1:] * u[:, 1:], axis=1)
+        out[:, 0] = u[:, 0] * (1.0 / (self.sigma * self.sigma) + free * 0.5 * q / s_eff) - free * dot / s_eff
+        return out
+
+
 def target_of(g, dtype=np.float64):
     kind = str(g['energy.kind'])
     if kind == 'gaussian':
@@ -177,6 +217,8 @@ def target_of(g, dtype=np.float64):
         return GMMTarget(g['energy.mus'], g['energy.i_sigmas'], g['energy.constants'], dtype)
     if kind == 'roughwell':
         return RoughWellTarget(float(g['energy.eta']), bool(g['energy.easy']), dtype)
+    if kind == 'funnel':
+        return FunnelTarget(float(g['energy.sigma']), dtype)
     raise ValueError(kind)
 
 

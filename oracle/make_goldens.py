@@ -450,7 +450,18 @@ def wide_cases():
     gaussian_case('tilted8_h24', rng.randn(8) * 0.5, cov8, H=24, T=7, eps=0.1, N=48, seed=62)
 
 
+def train_funnel_case():
+    """training gradient through the funnel's Hessian (distributions.py:155-180), start points in the free region"""
+    with contextlib.redirect_stdout(io.StringIO()):
+        fun = ref_distributions.GaussianFunnel(dim=3)
+    train_case('train_funnel3', np.zeros(3), None, H=10, T=4, eps=0.05, N=32, seed=36, head_std=0.3, dist=fun,
+               params={'energy.kind': 'funnel', 'energy.sigma': np.float32(2.0)},
+               x_start=lambda rng: np.concatenate([rng.randn(32, 1) * 1.5, rng.randn(32, 2)], axis=1))
+
+
 def main():
+    if sys.argv[1:] == ['train_funnel']:         # only this fixture
+        return train_funnel_case()
     if sys.argv[1:] == ['ais']:                  # only the AIS fixtures (leaves the other files untouched)
         return ais_cases()
     if sys.argv[1:] == ['wide']:                 # only the wide-net fixtures

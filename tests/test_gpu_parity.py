@@ -396,12 +396,14 @@ def test_sample_chain_with_in_kernel_rng(case):
 
 
 @pytest.mark.parametrize("variant", [0, 100])
-@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6"])
+@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6", "train_funnel3"])
 def test_training_gradient_matches_reference_graph(case, variant):
     """l2hmc_train_propose_grad (HIP, hand-derived reverse mode) vs tf.gradients of the notebook
     loss from the reference's own graph: loss, proposals, every parameter gradient and alpha.
     variant 0: the register-resident kernel where it applies; 100: the general tile kernel."""
     from l2hmc_amd.training import Trainer
+    if case == "train_funnel3" and variant == 100:
+        pytest.skip("the funnel's Hessian-vector product exists in the register-resident kernel only")
     g = load(case)
     dyn = hip_dynamics(g)
     dyn.eps_override = None

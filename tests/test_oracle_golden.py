@@ -159,7 +159,7 @@ def test_philox_draws_are_sharding_invariant_and_standard():
     assert 0 <= ub.min() and ub.max() < 1 and abs(ub.mean() - 0.5) < 0.01
 
 
-@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6"])
+@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6", "train_funnel3"])
 def test_training_gradient_oracle_matches_reference_graph(case):
     """oracle/l2hmc_train_oracle.py (hand-derived reverse mode incl. the Hessian-vector path)
     vs tf.gradients of the notebook loss evaluated by the reference's own graph (stub)."""
