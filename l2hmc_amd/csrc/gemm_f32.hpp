@@ -244,6 +244,122 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// One S/T/Q net evaluation in ONE launch (the H = 200 nets of mnist_vae.py:142-167 and any H > 15):
+//   out3 = relu(relu([a | b] [W1; W2] + time/bias row + aux_h) W4 + b4) [Ws | Wt | Wq]
+// A workgroup owns a tile of 16 chains (one MFMA column block); the input tile and both hidden activations stay in
+// LDS ([row][K] with a row stride whose quarter is odd: conflict-free ds_read_b128 operand fetches), the weights
+// (K-contiguous transposed copies, rows and K zero-padded to multiples of 16 so the loops carry no guards;
+// L2-resident: 80 + 160 + 120 KB) stream straight from global memory as the MFMA A operand -- each lane fetches the
+// float4 of its own (row, k-quad) for a whole output block before the MFMAs that consume them; several workgroups
+// per CU hide that latency.  Three dependent GEMM launches + two HBM round trips of the activations become one
+// launch with two workgroup barriers.
+struct NetEvalArgs {
+  const float* AB; int ldab;        // (M, 2 d): the two first-layer inputs side by side
+  const float* W12t;                // (Hp, K1p)   Hp = ceil16(H), K1p = ceil16(2 d), zero padded
+  const float* W4t;                 // (Hp, Hp)
+  const float* Wht;                 // (N3p, Hp)   N3p = ceil16(3 d)
+  const float* b4;                  // (H)
+  const float* tb;                  // (T, H) time/bias table of this net
+  const float* auxh;                // (M, H) image-branch term or NULL
+  const unsigned char* dir; int dir_all, it, T;
+  float* out3;                      // (M, 3 d)
+  int M, d, H;
+};
+__host__ __device__ inline int ceil16(int k) { return (k + 15) / 16 * 16; }
+__host__ __device__ inline int odd_quarter_stride(int k) {   // smallest multiple of 4 >= k whose quarter is odd
+  int p = (k + 3) / 4 * 4;
+  if (((p / 4) & 1) == 0) p += 4;
+  return p;
+}
+constexpr int NE_MT = 16;
+constexpr int NE_MAXKT = 16;       // k-tiles per layer the kernel is compiled for: K <= 256
+inline size_t net_eval_lds_bytes(int d, int H) {
+  return sizeof(float) * NE_MT * (size_t)(odd_quarter_stride(ceil16(2 * d)) + 2 * odd_quarter_stride(ceil16(H)));
+}
+
+__global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int K1 = 2 * g.d, H = g.H, K1p = ceil16(K1), Hp = ceil16(H);
+  const int ld1 = odd_quarter_stride(K1p), ldh = odd_quarter_stride(Hp);
+  float* sIn = sm;
+  float* sH1 = sIn + NE_MT * ld1;
+  float* sH2 = sH1 + NE_MT * ldh;
+  const long long m0 = (long long)blockIdx.x * NE_MT;
+
+  for (int i = tid; i < NE_MT * (K1p / 4); i += 256) {        // input tile, zero padded to K1p (K1 % 4 == 0)
+    const int r = i / (K1p / 4), kq4 = (i % (K1p / 4)) * 4;
+    f4 v = splat(0.f);
+    if (m0 + r < g.M && kq4 < K1) v = *reinterpret_cast<const f4*>(g.AB + (m0 + r) * g.ldab + kq4);
+    *reinterpret_cast<f4*>(sIn + r * ld1 + kq4) = v;
+  }
+  for (int i = tid; i < NE_MT * (ldh - H) ; i += 256) {       // pad columns of the hidden activations
+    const int r = i / (ldh - H), k = H + i % (ldh - H);
+    sH1[r * ldh + k] = 0.f;
+    sH2[r * ldh + k] = 0.f;
+  }
+  __syncthreads();
+
+  // one layer: C[m][n] = sum_k As[m][k] Wt[n][k] over the padded Kp; epi(nb, acc): lane holds C[m = c][n = 16 nb + 4 q + r]
+  auto layer = [&](const float* As, int ldA, int Kp, const float* Wt, int Np, auto&& epi) {
+    const int nk = Kp >> 4;
+    for (int nb = w; nb * 16 < Np; nb += 4) {
+      const float* wrow = Wt + (long long)(nb * 16 + c) * Kp + 4 * q;
+      f4 wf[NE_MAXKT];
+#pragma unroll
+      for (int j = 0; j < NE_MAXKT; ++j)
+        if (j < nk) wf[j] = *reinterpret_cast<const f4*>(wrow + j * 16);
+      f4 acc = splat(0.f);
+#pragma unroll
+      for (int j = 0; j < NE_MAXKT; ++j) {
+        if (j < nk) {
+          const f4 af = *reinterpret_cast<const f4*>(As + c * ldA + j * 16 + 4 * q);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = MFMA16(wf[j][s], af[s], acc);
+        }
+      }
+      epi(nb, acc);
+    }
+  };
+  auto relu4f = [](f4 p) { return f4{fmaxf(p.x, 0.f), fmaxf(p.y, 0.f), fmaxf(p.z, 0.f), fmaxf(p.w, 0.f)}; };
+  const long long m = m0 + c;
+  const bool mok = m < g.M;
+  int trow = 0;
+  if (mok) {
+    const bool fwd = g.dir != nullptr ? g.dir[m] != 0 : (g.dir_all != 0);
+    trow = fwd ? g.it : (g.T - 1 - g.it);
+  }
+
+  layer(sIn, ld1, K1p, g.W12t, Hp, [&](int nb, f4 v) {
+    const int n = nb * 16 + 4 * q;
+    if (n >= H) return;                                        // (H % 4 == 0)
+    f4 t = splat(0.f), e = splat(0.f);
+    if (mok) {
+      t = *reinterpret_cast<const f4*>(g.tb + (long long)trow * H + n);
+      if (g.auxh != nullptr) e = *reinterpret_cast<const f4*>(g.auxh + m * H + n);
+    }
+    *reinterpret_cast<f4*>(sH1 + c * ldh + n) = relu4f(v + t + e);
+  });
+  __syncthreads();
+  layer(sH1, ldh, Hp, g.W4t, Hp, [&](int nb, f4 v) {
+    const int n = nb * 16 + 4 * q;
+    if (n >= H) return;
+    *reinterpret_cast<f4*>(sH2 + c * ldh + n) = relu4f(v + *reinterpret_cast<const f4*>(g.b4 + n));
+  });
+  __syncthreads();
+  const int N3 = 3 * g.d;
+  layer(sH2, ldh, Hp, g.Wht, ceil16(N3), [&](int nb, f4 v) {
+    const int n = nb * 16 + 4 * q;
+    if (!mok) return;
+    float* o = g.out3 + m * N3 + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < N3) o[r] = v[r];
+  });
+}
+
 // rowsum layout of EPI_BCE: (M, 2 * n_tiles) with n_tiles = ceil(N / (32 WNB)) of the shape the launcher picks
 template <int EPI, int WMB, int WNB>
 int launch_gemm_shape(const GemmArgs& g, hipStream_t s) {

@@ -294,8 +294,10 @@ SplitPlan plan_split(long long N, int d, int H, int T, const L2hmcMlp3* enc, con
   p.ew1t = take(enc ? (long long)enc->n_in * enc->n_h1 : 0); p.ew2t = take(enc ? (long long)enc->n_h1 * enc->n_h2 : 0);
   p.ew3t = take(enc ? (long long)enc->n_h2 * enc->n_out : 0);
   p.e1 = take(enc ? N * enc->n_h1 : 0); p.e2 = take(enc ? N * enc->n_h2 : 0);
-  p.nx12t = take(2LL * d * H); p.nx4t = take((long long)H * H); p.nxht = take(3LL * d * H);
-  p.nv12t = take(2LL * d * H); p.nv4t = take((long long)H * H); p.nvht = take(3LL * d * H);
+  // S/T/Q nets: transposed copies, rows and K zero-padded to multiples of 16 (net_eval_kernel has no guards)
+  const long long n12 = (long long)ceil16(H) * ceil16(2 * d), n4 = (long long)ceil16(H) * ceil16(H), nh = (long long)ceil16(3 * d) * ceil16(H);
+  p.nx12t = take(n12); p.nx4t = take(n4); p.nxht = take(nh);
+  p.nv12t = take(n12); p.nv4t = take(n4); p.nvht = take(nh);
   p.total = o;
   return p;
 }
@@ -414,13 +416,15 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     float* w12t[2] = {w + p.nx12t, w + p.nv12t};
     float* w4t[2] = {w + p.nx4t, w + p.nv4t};
     float* wht[2] = {w + p.nxht, w + p.nvht};
+    const int K1p = ceil16(L), Hp = ceil16(H);
+    (void)hipMemsetAsync(w + p.nx12t, 0, sizeof(float) * (size_t)(p.nvht + (long long)ceil16(3 * d) * Hp - p.nx12t), s);
     for (int i = 0; i < 2; ++i) {
-      transpose_into(s, nets[i]->W1, d, H, w12t[i], L, 0);
-      transpose_into(s, nets[i]->W2, d, H, w12t[i], L, d);
-      transpose_into(s, nets[i]->W4, H, H, w4t[i], H, 0);
-      transpose_into(s, nets[i]->Ws, H, d, wht[i], H, 0);
-      transpose_into(s, nets[i]->Wt, H, d, wht[i] + (long long)d * H, H, 0);
-      transpose_into(s, nets[i]->Wq, H, d, wht[i] + 2LL * d * H, H, 0);
+      transpose_into(s, nets[i]->W1, d, H, w12t[i], K1p, 0);
+      transpose_into(s, nets[i]->W2, d, H, w12t[i], K1p, d);
+      transpose_into(s, nets[i]->W4, H, H, w4t[i], Hp, 0);
+      transpose_into(s, nets[i]->Ws, H, d, wht[i], Hp, 0);
+      transpose_into(s, nets[i]->Wt, H, d, wht[i] + (long long)d * Hp, Hp, 0);
+      transpose_into(s, nets[i]->Wq, H, d, wht[i] + 2LL * d * Hp, Hp, 0);
     }
   }
   hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, vc, w + p.K0, ld, N, d);
@@ -443,15 +447,30 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (a->n_steps == 0) (void)hipMemcpyAsync(U1d, U0d, sizeof(double) * N, hipMemcpyDeviceToDevice, s);
 
   // one net evaluation: out3 = relu(relu([a | b] [W1; W2] + time + aux_h) W4 + b4) [Ws|Wt|Wq]   (the head biases are
-  // added by the update kernels): three GEMMs with fused epilogues on 64 x 64 tiles (M = 8192, N = 200: 512 tiles)
+  // added by the update kernels).  H % 4 == 0 and d even: ONE launch of net_eval_kernel (activations resident in
+  // LDS); otherwise three GEMMs with fused epilogues on 64 x 64 tiles.
+  const size_t ne_lds = net_eval_lds_bytes(d, H);
+  const bool ne_ok = (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(2 * d) <= 16 * NE_MAXKT && ne_lds <= 160 * 1024;
+  if (ne_ok && !hmc && ne_lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(net_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
+    if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
   auto net_eval = [&](const L2hmcNet& nw, int net, const float* ab, int it) {
-    GemmArgs ga = gemm_args(ab, L, w + (net == 0 ? p.nx12t : p.nv12t), L, h1, H, N, H, L);
+    if (ne_ok) {
+      NetEvalArgs na;
+      na.AB = ab; na.ldab = L; na.W12t = w + (net == 0 ? p.nx12t : p.nv12t); na.W4t = w + (net == 0 ? p.nx4t : p.nv4t);
+      na.Wht = w + (net == 0 ? p.nxht : p.nvht); na.b4 = nw.b4; na.tb = tb + (long long)net * T * H; na.auxh = aux_h;
+      na.dir = dir; na.dir_all = dall; na.it = it; na.T = T; na.out3 = out3; na.M = (int)N; na.d = d; na.H = H;
+      hipLaunchKernelGGL(net_eval_kernel, dim3((unsigned)((N + NE_MT - 1) / NE_MT)), dim3(256), ne_lds, s, na);
+      return;
+    }
+    GemmArgs ga = gemm_args(ab, L, w + (net == 0 ? p.nx12t : p.nv12t), ceil16(L), h1, H, N, H, L);
     ga.E = aux_h; ga.lde = H; ga.tb = tb + (long long)net * T * H; ga.dir = dir; ga.dir_all = dall; ga.it = it; ga.T = T;
     launch_gemm<EPI_NET1>(ga, s, SHAPE_MID);
-    ga = gemm_args(h1, H, w + (net == 0 ? p.nx4t : p.nv4t), H, h2, H, N, H, H);
+    ga = gemm_args(h1, H, w + (net == 0 ? p.nx4t : p.nv4t), ceil16(H), h2, H, N, H, H);
     ga.bias = nw.b4;
     launch_gemm<EPI_BIAS_RELU>(ga, s, SHAPE_MID);
-    ga = gemm_args(h2, H, w + (net == 0 ? p.nxht : p.nvht), H, out3, 3 * d, N, 3 * d, H);
+    ga = gemm_args(h2, H, w + (net == 0 ? p.nxht : p.nvht), ceil16(H), out3, 3 * d, N, 3 * d, H);
     launch_gemm<EPI_BIAS>(ga, s, SHAPE_MID);
   };
 
