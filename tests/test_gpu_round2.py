@@ -186,3 +186,61 @@ def test_vae_sampler_loop_with_library_philox_matches_injected_draws_and_oracle(
             flip = np.abs(rpx - to_np(u[m])) < 2e-4          # ties fp32 noise may flip
             assert rel_err(to_np(xh[m])[~flip], xo_next[~flip]) < 2e-4, m
             xo = to_np(xh[m])                                # continue from the HIP state (no tie divergence)
+
+
+@pytest.mark.parametrize("kind,d,H,T,N", [
+    ("gauss_diag", 1, 10, 3, 37), ("gauss_dense", 3, 15, 2, 21), ("roughwell_easy", 4, 3, 1, 16),
+    ("gauss_dense", 4, 10, 5, 50), ("gauss_diag", 5, 15, 3, 33), ("roughwell_easy", 16, 7, 2, 17),
+    ("gauss_diag", 17, 15, 3, 40), ("gauss_dense", 20, 10, 2, 19), ("roughwell_easy", 33, 4, 1, 23),
+    ("gauss_diag", 64, 12, 2, 35), ("gauss_diag", 100, 15, 2, 18)])
+def test_new_kernels_agree_with_the_general_kernel_and_the_oracle_on_odd_shapes(kind, d, H, T, N):
+    """Ragged chain counts, d not a multiple of 4 / 16, H = 15 (4 hidden k-steps), T = 1: the small (d <= 4) and the
+    instruction-lean kernels (variant 0) against the general kernel (variant 100) and the numpy oracle, direction-mixed
+    propose with MH."""
+    import torch
+    from oracle import l2hmc_oracle as O
+    from l2hmc_amd import propose
+    from tests.helpers import oracle_dynamics, synthetic_case
+    g = synthetic_case(kind, d, H=H, T=T, N=N, seed=d + H)
+    rng = np.random.RandomState(1)
+    dr, u = rng.randint(0, 2, N).astype(np.uint8), rng.rand(N).astype(np.float32)
+    outs = {}
+    for var in (0, 100):
+        dyn = hip_dynamics(g, var)
+        Lx, _, px, o = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(dr), v=to_dev(g["v"]), u=to_dev(u))
+        outs[var] = (to_np(Lx), to_np(px), to_np(o[0]))
+    with np.errstate(all="ignore"):
+        rLx, _, rpx, _ = O.propose(g["x"], oracle_dynamics(g), g["v"], g["v"], dr, u, both_directions=False)
+    for var in (0, 100):
+        assert rel_err(outs[var][0], rLx) < 1e-4 and abs_err(outs[var][1], rpx) < 1e-4, (var, kind, d, H, T)
+    assert rel_err(outs[0][0], outs[100][0]) < 5e-5 and abs_err(outs[0][1], outs[100][1]) < 5e-5
+
+
+@pytest.mark.parametrize("kind,d,H,T,N", [("gauss_diag", 5, 7, 2, 21), ("gauss_dense", 3, 15, 3, 18),
+                                          ("roughwell_easy", 17, 10, 2, 19), ("gauss_diag", 33, 15, 2, 40),
+                                          ("gauss_diag", 48, 12, 3, 16)])
+def test_training_kernels_agree_on_odd_shapes(kind, d, H, T, N):
+    """register-resident training kernel (variant 0) vs the general tile kernel (variant 100): loss, proposals and
+    every parameter gradient on shapes the goldens do not cover (ragged N, d % 4 != 0, H = 15)."""
+    import torch
+    from l2hmc_amd.training import Trainer
+    from tests.helpers import synthetic_case
+    g = synthetic_case(kind, d, H=H, T=T, N=N, seed=3 * d + H, head_std=0.2)
+    rng = np.random.RandomState(2)
+    draws = {"z": rng.randn(N, d).astype(np.float32), "x_dir": rng.randint(0, 2, N), "z_dir": rng.randint(0, 2, N),
+             "x_v": rng.randn(N, d).astype(np.float32), "z_v": rng.randn(N, d).astype(np.float32)}
+    res = {}
+    for var in (0, 100):
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        tr = Trainer(dyn)
+        tr.variant = var
+        loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+        res[var] = (float(loss), to_np(Lx), to_np(px), to_np(tr.flat).copy())
+    a, b = res[0], res[100]
+    scale = max(1.0, float(np.abs(b[3]).max()))
+    assert abs(a[0] - b[0]) < 1e-4 * max(1.0, abs(b[0]))
+    assert rel_err(a[1], b[1]) < 5e-5 and abs_err(a[2], b[2]) < 5e-5
+    assert np.abs(a[3] - b[3]).max() < 3e-4 * scale, (np.abs(a[3] - b[3]).max(), scale)
