@@ -1,7 +1,7 @@
 // libl2hmc_hip.so -- C ABI (include/l2hmc.h) of the L2HMC leapfrog hot path for MI355X:
 // argument validation, LDS planning, geometry selection, weight packing kernels.
 // The fused kernels live in l2hmc_kernels.hpp, instantiated per energy kind in traj_ek*.hip.
-#include "traj_fast.hpp"
+#include "traj_tile.hpp"
 
 namespace l2hmc {
 
@@ -286,6 +286,25 @@ long long plan_lds_fast(KArgs& k, int NW, int DT) {
   return o * 4;
 }
 
+// LDS plan of traj_tile_kernel: scaled tail fragments, layer-1 fragments (o_state), constants, records, energy vectors
+long long plan_lds_tile(KArgs& k, int DT) {
+  long long o = 0;
+  k.o_fw = (int)o;
+  o += 2LL * fast_fw_net(DT);
+  k.o_state = (int)o;
+  o += 4LL * DT * 256;
+  k.o_fc = (int)o;
+  o += 2LL * fast_fc_net(DT);
+  k.o_rec = (int)o;
+  o += 2LL * fast_rec_dir(DT, k.T);
+  k.o_mu = (int)o;
+  o += 16LL * DT;
+  k.o_prec = (int)o;
+  o += 16LL * DT;
+  k.o_logc = (int)o;
+  return o * 4;
+}
+
 int check_energy(const L2hmcEnergy* e, int d) {
   if (e == nullptr) return fail(L2HMC_ERR_ARG, "energy is NULL%s");
   switch (e->kind) {
@@ -478,7 +497,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
     if (a->variant == 8) return fail(L2HMC_ERR_UNSUPPORTED, "variant 8: %s%lld bytes of LDS needed (T x d too large)", "", ldsw);
   }
   int DT, NW;
-  const int geom_variant = a->variant >= 100 ? a->variant - 100 : a->variant;   // 100 + v: the round-1 kernel
+  const int geom_variant = a->variant >= 100 ? a->variant - 100 : (a->variant == 16 ? 0 : a->variant);   // 100 + v: the round-1 kernel
   if (!pick_geometry(a->d, a->n_chains, geom_variant, DT, NW))
     return fail(L2HMC_ERR_UNSUPPORTED, "d = %s%lld not supported with variant %lld", "", a->d, a->variant);
   // The instruction-lean kernel (traj_fast.hpp) covers S/T/Q nets on register-resident geometries; the
@@ -491,6 +510,18 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   if (small) {
     const long long ldss = plan_lds_fast(k, 1, 1);
     return dispatch(OP_TRAJ_SMALL, k, 1, 1, KH, ldss, s);
+  }
+  // many chains (>= 2 tiles per SIMD), 3-4 dimension slices, elementwise target: one wave per tile (traj_tile.hpp);
+  // variant 16 forces it
+  const bool tile_kind = k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL;
+  const bool tileable = a->packed_nets != nullptr && tile_kind && k.NT >= 3 && k.NT <= 4 && k.n_steps >= 1 &&
+                        k.beta == 1.f && k.temperature == 1.f;
+  if (a->variant == 16 && !tileable)
+    return fail(L2HMC_ERR_UNSUPPORTED, "variant 16 (one wave per tile) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target and 33 <= d <= 64%s");
+  if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 32768))) {
+    const long long ldst = plan_lds_tile(k, k.NT);
+    if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, ldst, s);
+    return launch_tile_ek<L2HMC_ENERGY_ROUGHWELL>(k, k.NT, KH, ldst, s);
   }
   if (fast) {
     const long long ldsf = plan_lds_fast(k, NW, DT);

@@ -1,0 +1,333 @@
+// traj_tile.hpp -- one wave per 16-chain tile, several tiles per workgroup: the many-chains form of the fused
+// trajectory kernel for elementwise targets with 33 <= d <= 64 (gfx950 / CDNA4).
+//
+// traj_fast_kernel spreads a tile over 4 waves (one 16-dimension slice each): right when chains are scarce (4096
+// chains = 256 tiles = one per CU), but every wave then repeats the hidden layer (12 of its 64 MFMAs per step), the
+// relu / time-table work, and pays three LDS exchanges per step.  With >= 2 tiles per SIMD available the better
+// decomposition is ONE wave per tile looping over the DT dimension slices: 220 instead of 256 MFMAs per tile-step,
+// ~20 % fewer VALU instructions, no exchange, no barrier inside the trajectory.  On gfx950 an f32 MFMA blocks the
+// SIMD's VALU (profiles/r02_ubench_issue.txt), so this instruction count IS the time.  TPW waves (tiles) share one
+// staged copy of the weights in LDS: scaled tail fragments, layer-1 fragments (the diagonal precision folded into
+// VNet's W1 as in traj_fast_kernel), constant tables and schedule records; per tile only the state lives in registers
+// and every fragment is fetched from LDS where it is used.  Same algorithm and sampler loop as traj_kernel
+// (utils/dynamics.py:115-309, utils/sampler.py:28-55).
+#pragma once
+#include "traj_fast.hpp"
+
+namespace l2hmc {
+
+long long plan_lds_tile(KArgs& k, int DT);
+
+template <int EK, int DT, int KH, int TPW>
+__global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
+  static_assert(EK == L2HMC_ENERGY_GAUSS_DIAG || EK == L2HMC_ENERGY_ROUGHWELL, "elementwise targets only");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * TPW;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int NT = A.NT, NF = net_floats(NT);
+  const float LOG2E = 1.4426950408889634f;
+  const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
+  const float heps = 0.5f * eps;
+  constexpr int NTp = DT;
+  const int FWN = fast_fw_net(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
+            RECD = fast_rec_dir(NTp, A.T);
+  const f4 Z = splat(0.f);
+
+  // ---- prologue (whole workgroup): scaled tail fragments, layer-1 fragments, constants, schedule records ----------
+  for (int i = tid; i < 2 * (FWN / 4); i += nthr) {
+    const int net = i >= FWN / 4, j = i - net * (FWN / 4), g = j >> 6;
+    float sc = 1.f;
+    if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
+    f4 src = Z;
+    if (g < 3 * NT + 1) src = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + (2 * NT + 1) * 256)[j];
+    reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src * sc;
+  }
+  stage_energy<EK, false>(A, smem, tid, nthr);
+  __syncthreads();                                               // (the fold below reads the staged precision)
+  for (int i = tid; i < 4 * DT * 64; i += nthr) {                // layer-1 groups: [net][input][tile], one float4 per lane
+    const int grp = i >> 6, ln = i & 63, net = grp / (2 * DT), inp = (grp / DT) & 1, tg = grp % DT;
+    f4 val = Z;
+    if (tg < NT) {
+      val = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF)[(inp * NT + tg) * 64 + ln];
+      if (EK == L2HMC_ENERGY_GAUSS_DIAG && net == 1 && inp == 0) {   // W1 + P W2 (traj_fast.hpp)
+        const f4 wb = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF)[(NT + tg) * 64 + ln];
+        val = val + lds4(smem + A.o_prec + 16 * tg + 4 * (ln >> 4)) * wb;
+      }
+    }
+    reinterpret_cast<f4*>(smem + A.o_state)[i] = val;
+  }
+  for (int i = tid; i < 2 * 16 * NTp; i += nthr) {
+    const int net = i / (16 * NTp), dim = i % (16 * NTp);
+    const float* scl = A.packed + (size_t)net * NF + net_groups(NT) * 256;
+    const float epn = net == 0 ? eps : heps;
+    const float es = dim < 16 * NT ? scl[dim] : 0.f, eq = dim < 16 * NT ? scl[16 * NT + dim] : 0.f;
+    const float cs = es * epn * LOG2E, cq = eq * eps * LOG2E;
+    float* fc = smem + A.o_fc + net * FCN;
+    fc[dim] = cs;
+    fc[DPp + dim] = -cs;
+    fc[2 * DPp + dim] = cq;
+    fc[3 * DPp + dim] = cq + log2f(epn);
+  }
+  for (int i = tid; i < 2 * A.T * R; i += nthr) {
+    const int dr = i / (A.T * R), r = (i / R) % A.T, j = i % R;
+    float val;
+    if (j < 32) {
+      const int net = j >> 4, u = j & 15;
+      const float* tf = A.packed + (size_t)net * NF + (2 * NT * 64) * 4;
+      val = fmaf(tf[u * 4], A.trig[2 * r], fmaf(tf[(16 + u) * 4], A.trig[2 * r + 1], tf[(32 + u) * 4]));
+    } else {
+      const int dim = j - 32;
+      const float m = dim < A.d ? A.masks[r * A.d + dim] : 0.f;
+      val = dr ? m : 1.f - m;
+    }
+    smem[A.o_rec + dr * RECD + (r + 1) * R + j] = val;
+  }
+  __syncthreads();
+  auto l1frag = [&](int net, int inp, int t) { return lds4(smem + A.o_state + (((net * 2 + inp) * DT + t) * 64 + lane) * 4); };
+  auto chain4 = [&](f4 W, f4 in, f4 acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = MFMA16(W[r], in[r], acc);
+    return acc;
+  };
+  auto mu_of = [&](int t) { return lds4(smem + A.o_mu + 16 * t + 4 * q); };
+  auto prec_of = [&](int t) { return lds4(smem + A.o_prec + 16 * t + 4 * q); };
+  if (EK == L2HMC_ENERGY_GAUSS_DIAG) {           // constant -W2^T P mu of the fold -> VNet time/bias table
+    if (wv == 0) {
+      f4 cv = Z;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const f4 wb = t < NT ? reinterpret_cast<const f4*>(A.packed + (size_t)NF)[(NT + t) * 64 + lane] : Z;
+        cv = chain4(wb, -(prec_of(t) * mu_of(t)), cv);
+      }
+      if (c == 0) {
+        for (int i = 0; i < 2 * A.T; ++i) {
+          float* tb = smem + A.o_rec + (i / A.T) * RECD + (i % A.T + 1) * R + 16 + 4 * q;
+          *reinterpret_cast<f4*>(tb) = lds4(tb) + cv;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- from here on every wave works alone on its own tile (no barriers) -------------------------------------------
+  const long long tile = (long long)blockIdx.x * TPW + wv;
+  if (tile * 16 >= A.N) return;
+  const long long chain = tile * 16 + c;
+  const bool live = chain < A.N;
+  const float* fwx = smem + A.o_fw;
+  const float* fwv = fwx + FWN;
+  const float* fcx = smem + A.o_fc;
+  const float* fcv = fcx + FCN;
+  const float rw_den = A.easy ? A.eta : A.eta * A.eta;
+
+  auto grad_t = [&](f4 xx, int t) {
+    if (EK == L2HMC_ENERGY_GAUSS_DIAG) return prec_of(t) * (xx - mu_of(t));
+    f4 g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[r] = xx[r] - (A.eta / rw_den) * sinf(xx[r] / rw_den);
+    return g;
+  };
+  auto energy_part = [&](const f4 (&xx)[DT], const f4 (&gg)[DT]) {
+    float U = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      if (EK == L2HMC_ENERGY_GAUSS_DIAG) {
+        U += 0.5f * hsum((xx[t] - mu_of(t)) * gg[t]);
+      } else {
+        const int dim0 = 16 * t + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (dim0 + r < A.d) U += 0.5f * xx[t][r] * xx[t][r] + A.eta * cosf(xx[t][r] / rw_den);
+      }
+    }
+    return U;
+  };
+  // hidden layers of one net: h2 (unit rows) from the layer-1 sum + time/bias row
+  auto hidden = [&](const float* fw, f4 hs_) {
+    const f4 w2 = lds4(fw + lane * 4);
+    f4 h = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) h[r] = relu_i(hs_[r]);
+    f4 acc = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) acc = MFMA16(w2[r], h[r], acc);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
+    return h;
+  };
+  // heads of dimension slice t: aS = log2 of the scale factor, T' = step T, EQ' = step e^{eps Q}  (traj_fast.hpp)
+  auto heads = [&](const float* fw, const float* fc, int dofs, int t, f4 h, f4& aS, f4& Tt, f4& EQ) {
+    const f4 Ws = lds4(fw + ((1 + 3 * t + 0) * 64 + lane) * 4), Wt = lds4(fw + ((1 + 3 * t + 1) * 64 + lane) * 4),
+             Wq = lds4(fw + ((1 + 3 * t + 2) * 64 + lane) * 4);
+    const f4 cS = lds4(fc + dofs + 16 * t + 4 * q), cQ = lds4(fc + 2 * DPp + 16 * t + 4 * q),
+             bQ = lds4(fc + 3 * DPp + 16 * t + 4 * q);
+    f4 zs = Z, zt = Z, zq = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) {
+      zs = MFMA16(Ws[r], h[r], zs);
+      zq = MFMA16(Wq[r], h[r], zq);
+      zt = MFMA16(Wt[r], h[r], zt);
+    }
+    const f4 rS = rcp4(-(ex2_4(zs) * 0.5f + 0.5f));
+    aS = rS * cS + cS;
+    const f4 rQ = rcp4(-(ex2_4(zq) * 0.5f + 0.5f));
+    EQ = ex2_4(rQ * cQ + bQ);
+    Tt = zt;
+  };
+
+  f4 x[DT], v[DT], g[DT];
+  load_state<DT, 1>(A.x, A, chain, live, 0, q, x);
+  const bool need_p = A.p_out != nullptr || A.x_next != nullptr || A.u != nullptr || (A.rng_flags & L2HMC_RNG_U) != 0;
+  f4 pv = Z;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    g[t] = grad_t(x[t], t);
+    pv = chain4(l1frag(1, 0, t), x[t], pv);
+    if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = chain4(l1frag(1, 1, t), g[t], pv);
+  }
+  float U_start = energy_part(x, g);
+
+  // ---- persistent sampler loop ----------------------------------------------------------------------------------------
+  const long long gchain = A.chain_off + chain;
+  const bool rng_v = (A.rng_flags & L2HMC_RNG_V) != 0, rng_d = (A.rng_flags & L2HMC_RNG_DIR) != 0;
+  const bool rng_u = (A.rng_flags & L2HMC_RNG_U) != 0;
+  const bool have_u = A.u != nullptr || rng_u;
+  for (int m = 0; m < A.M; ++m) {
+    const long long moff = (long long)m * A.N;
+    const unsigned long long prop = A.rng_prop0 + (unsigned long long)m;
+    if (rng_v) rng_state<DT, 1>(A, gchain, prop, 0, q, v);
+    else load_state<DT, 1>(A.v + moff * A.d, A, chain, live, 0, q, v);
+    bool fwd = (A.dir != nullptr && !rng_d) ? (live ? A.dir[moff + chain] != 0 : true) : (A.dir_all != 0);
+    float u_m = (A.u != nullptr && !rng_u && live) ? A.u[moff + chain] : 0.f;
+    if (rng_d || rng_u) {
+      bool fr;
+      float ur;
+      philox_dir_u(A.rng_seed, gchain, prop, fr, ur);
+      if (rng_d) fwd = fr;
+      if (rng_u) u_m = ur;
+    }
+    f4 x0[DT], g0[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) { x0[t] = x[t]; g0[t] = g[t]; }
+    const f4 pv0 = pv;
+    float red[5];
+    red[0] = U_start;
+    red[1] = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) red[1] += 0.5f * hsum(v[t] * v[t]);
+    f4 ldv = Z;
+    const float ff = fwd ? 1.f : 0.f, nf = ff - 1.f;
+    const int dofs = fwd ? 0 : DPp;
+    const int row0 = fwd ? A.step_begin : (A.T - 1 - A.step_begin);
+    const float* rec = smem + A.o_rec + (fwd ? RECD : 0) + (row0 + 1) * R + 4 * q;
+    const int drec = fwd ? R : -R;
+
+    for (int it = 0; it < A.n_steps; ++it) {
+      // (compiler barrier: the weight fragments are loop-invariant LDS loads; hoisted out of the step loop they
+      //  would need ~350 VGPRs and spill -- they are meant to be fetched where they are used)
+      asm volatile("" ::: "memory");
+      const f4 tbx = lds4(rec), tbv = lds4(rec + 16);
+      f4 k1[DT], vh[DT], y[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) k1[t] = lds4(rec + 32 + 16 * t);
+      rec += drec;
+      f4 aS, Tt, EQ;
+      // ---- momentum half-update #1 + the XNet layer-1 sums of (v_h, k1 x)  (dynamics.py:118-131 / :162-176)
+      f4 h = hidden(fwv, pv + tbv);
+      f4 pa = Z, pq = Z;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        heads(fwv, fcv, dofs, t, h, aS, Tt, EQ);
+        const f4 ES = ex2_4(aS);
+        ldv += aS;
+        const f4 tr = Tt - EQ * g[t];
+        vh[t] = ES * (nf * tr + v[t]) + ff * tr;
+        pa = chain4(l1frag(0, 0, t), vh[t], pa);
+        pq = chain4(l1frag(0, 1, t), k1[t] * x[t], pq);
+      }
+      // ---- first masked position update (:131-137 / :176-182) + the layer-1 sum of (1 - k1) y
+      asm volatile("" ::: "memory");
+      h = hidden(fwx, pa + pq + tbx);
+      pq = Z;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        heads(fwx, fcx, dofs, t, h, aS, Tt, EQ);
+        const f4 up = 1.f - k1[t];
+        const f4 aSm = up * aS;
+        const f4 ES = ex2_4(aSm);
+        ldv += aSm;
+        const f4 tr = up * (EQ * vh[t] + Tt);
+        y[t] = ES * (nf * tr + x[t]) + ff * tr;
+        pq = chain4(l1frag(0, 1, t), up * y[t], pq);
+      }
+      // ---- second masked position update (:139-145 / :184-190), grad U and VNet's layer-1 sum at the new position
+      asm volatile("" ::: "memory");
+      h = hidden(fwx, pa + pq + tbx);
+      pv = Z;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        heads(fwx, fcx, dofs, t, h, aS, Tt, EQ);
+        const f4 aSm = k1[t] * aS;
+        const f4 ES = ex2_4(aSm);
+        ldv += aSm;
+        const f4 tr = k1[t] * (EQ * vh[t] + Tt);
+        x[t] = ES * (nf * tr + y[t]) + ff * tr;
+        g[t] = grad_t(x[t], t);
+        pv = chain4(l1frag(1, 0, t), x[t], pv);
+        if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = chain4(l1frag(1, 1, t), g[t], pv);
+      }
+      // ---- momentum half-update #2  (:147-153 / :192-199)
+      asm volatile("" ::: "memory");
+      h = hidden(fwv, pv + tbv);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        heads(fwv, fcv, dofs, t, h, aS, Tt, EQ);
+        const f4 ES = ex2_4(aS);
+        ldv += aS;
+        const f4 tr = Tt - EQ * g[t];
+        v[t] = ES * (nf * tr + vh[t]) + ff * tr;
+      }
+    }
+    const bool last = m == A.M - 1;
+    if (last) {
+      store_state<DT, 1>(A.x_out, A, chain, live, 0, q, x);
+      store_state<DT, 1>(A.v_out, A, chain, live, 0, q, v);
+    }
+    red[2] = energy_part(x, g);
+    red[3] = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) red[3] += 0.5f * hsum(v[t] * v[t]);
+    red[4] = hsum(ldv) * 0.6931471805599453f;
+    const float U_end = red[2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      red[i] += __shfl_xor(red[i], 16);
+      red[i] += __shfl_xor(red[i], 32);
+    }
+    const bool writer = live && lane < 16;
+    if (A.logjac_out != nullptr && writer) A.logjac_out[moff + chain] = red[4];
+    if (need_p) {
+      const float p = accept_prob((red[0] + red[1]) - (red[2] + red[3]) + red[4]);      // dynamics.py:302-309
+      if (A.p_out != nullptr && writer) A.p_out[moff + chain] = p;
+      if (have_u) {
+        const bool acc = live && (p - u_m) >= 0.f;                                      // sampler.py:53-55
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          x[t] = sel4(acc, x[t], x0[t]);
+          g[t] = sel4(acc, g[t], g0[t]);
+        }
+        pv = sel4(acc, pv, pv0);
+        U_start = acc ? U_end : U_start;
+      } else {
+        U_start = U_end;
+      }
+    } else {
+      U_start = U_end;
+    }
+    if (A.x_hist != nullptr) store_state<DT, 1>(A.x_hist + moff * A.d, A, chain, live, 0, q, x);
+  }
+  store_state<DT, 1>(A.x_next, A, chain, live, 0, q, x);
+}
+
+}  // namespace l2hmc

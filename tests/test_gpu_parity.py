@@ -21,7 +21,13 @@ def variants(g):
     # 0 / 1 / 4: automatic / one / four waves per 16-chain tile (the instruction-lean kernel where it applies);
     # 100 + v: the same geometry on the general kernel
     d = int(g["x_dim"])
-    return [0, 100] if d <= 16 else [1, 4, 104]
+    if d <= 16:
+        return [0, 100]
+    # 16: one wave per tile (many-chains form; elementwise targets with S/T/Q nets, 33 <= d <= 64)
+    tile = 33 <= d <= 64 and not int(g["hmc"]) and int(g["H"]) <= 15 and (
+        str(g["energy.kind"]) == "roughwell" or (str(g["energy.kind"]) == "gaussian" and
+                                                  np.count_nonzero(g["energy.i_sigma"] - np.diag(np.diagonal(g["energy.i_sigma"]))) == 0))
+    return [1, 4, 104] + ([16] if tile else [])
 
 
 @pytest.mark.parametrize("case", CASES)
