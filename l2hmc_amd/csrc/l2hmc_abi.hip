@@ -518,7 +518,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
                         k.beta == 1.f && k.temperature == 1.f;
   if (a->variant == 16 && !tileable)
     return fail(L2HMC_ERR_UNSUPPORTED, "variant 16 (one wave per tile) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target and 33 <= d <= 64%s");
-  if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 32768))) {
+  if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 16384))) {
     const long long ldst = plan_lds_tile(k, k.NT);
     if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, ldst, s);
     return launch_tile_ek<L2HMC_ENERGY_ROUGHWELL>(k, k.NT, KH, ldst, s);

@@ -20,7 +20,7 @@ prob = bench.make_problem(0, n, dev)
 dyn = Dynamics(bench.D, distributions.Gaussian(np.zeros(bench.D), np.diag(prob["var"])).get_energy_function(),
                T=bench.T, eps=0.1, net_factory=layers.stq_network(bench.H), device=dev)
 dyn.mask = prob["mask"]
-dyn.variant = 4
+dyn.variant = int(os.environ.get("L2HMC_VARIANT", "4"))
 with torch.no_grad():
     for w, key in ((dyn._xw, "xnet"), (dyn._vw, "vnet")):
         for k in O.NET_KEYS:
