@@ -6,3 +6,4 @@ timeout 200 python tools/bf16_state_study.py > gpurun_out/r02/bf16_state_study.t
 cd /tmp && export TMPDIR=/tmp; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02/vae -o v -- python $GRAFT_REPO_ROOT/tools/bench_vae.py 8192 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT; cp gpurun_out/r02/vae/*kernel_stats.csv gpurun_out/r02/vae_kernel_stats.csv; rm -rf gpurun_out/r02/vae gpurun_out/r02/trace gpurun_out/r02/pmc_*/*.db
 tail -30 gpurun_out/r02_collect.log; cat gpurun_out/r02/configs.txt gpurun_out/r02/bf16_state_study.txt
+timeout 100 python tools/bench_ais.py > gpurun_out/r02/ais_timing.txt 2>&1; cat gpurun_out/r02/ais_timing.txt
