@@ -1,5 +1,6 @@
 """CPU: host-side logic that needs no GPU -- the layer kit / net recognition, distributions'
 host parameters, diagnostics vs the oracle's restatement of utils/func_utils.py."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -110,3 +111,14 @@ def test_product_refuses_cpu_tensors_and_foreign_energies():
     from l2hmc_amd import Dynamics
     with pytest.raises(TypeError, match="no eager fallback"):
         Dynamics(2, lambda x: (x * x).sum(1), T=3, eps=0.1, hmc=True, device="cpu")
+
+
+def test_bench_host_helpers():
+    """bench.py pieces that need no GPU: the usable-core count honours affinity and cgroup quota, the algorithmic
+    work per chain-step is SURVEY 8(d)'s formula, the synthetic problem is seeded."""
+    import bench
+    assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
+    assert bench.algorithmic_flops_per_chain_step(50, 10, 10, 150) == 4 * 2 * 10 * (5 * 50 + 10 + 2) + 1.1 * 150 + 30 * 50
+    a, b = bench.make_problem(0, 8, None), bench.make_problem(0, 8, None)
+    assert np.array_equal(a["mask"], b["mask"]) and np.array_equal(a["nets"]["xnet"]["W1"], b["nets"]["xnet"]["W1"])
+    assert a["mask"].shape == (bench.T, bench.D) and np.all(a["mask"].sum(axis=1) == bench.D // 2)
