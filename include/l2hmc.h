@@ -104,9 +104,13 @@ typedef struct L2hmcTrajectoryArgs {
   float* p_out;             /* (N) accept prob, dynamics.py:302-309                           */
   float* x_next;            /* (N, d) MH-selected state, sampler.py:53-55 (needs u and p)     */
   /* ---- tuning ---------------------------------------------------------------------------- */
-  int32_t variant;          /* 0 = auto; 1 / 4 = waves per 16-chain tile of the register-resident
-                             *   kernel; 8 = the LDS-resident-state kernel (auto for d > 128 with a
-                             *   diagonal-Gaussian or Rough-Well target)                               */
+  int32_t variant;          /* kernel choice.  0 = automatic (measured rules): d <= 4 the
+                             *   one-dimension-per-lane kernel; d <= 64 the instruction-lean tile kernel on 1 or 4
+                             *   waves per 16-chain tile, from 16 384 chains with 33 <= d <= 64 and an elementwise
+                             *   target one wave per tile; d > 128 the LDS-resident-state kernel.  1 / 4 = force
+                             *   that many waves per tile; 16 = one wave per tile, 4 tiles per workgroup; 8 = the
+                             *   LDS-resident-state kernel; 100 + v = geometry v on the general kernel (which also
+                             *   serves HMC mode, AIS mode and tempered energies)                                   */
   /* ---- persistent sampler loop (the notebook's per-MH-step sess.run loop, nb raw 288-298) -- */
   int32_t n_proposals;      /* M >= 1 proposals per launch (0 = 1).  With M > 1: v is (M,N,d),  */
                             /* direction (M,N), u (M,N) [required], p_out / logjac_out (M,N);   */

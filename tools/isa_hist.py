@@ -54,11 +54,6 @@ def kernel_lines(path, kernel):
 
 
 def innermost_region(lines):
-    depth, header = 0, None
-    for ln in lines:
-        m = re.search(r"Inner Loop Header: Depth=(\d+)", ln)
-        if m and int(m.group(1)) >= depth:
-            pass
     # LLVM prints the label on the line before the "=> This Inner Loop Header" comment for nested loops
     best = None
     for i, ln in enumerate(lines):
