@@ -159,10 +159,12 @@ class Trainer(object):
         if world == 1:
             return N, 0
         if self._shard_cache is None or self._shard_cache[0] != N:
-            counts = [None] * world
-            dist.all_gather_object(counts, int(N))
             rank = dist.get_rank()
-            self._shard_cache = (N, int(sum(counts)), int(sum(counts[:rank])))
+            counts = torch.zeros(world, dtype=torch.float64, device=self.dyn.device)
+            counts[rank] = float(N)
+            dist.all_reduce(counts)                  # one small collective, once per chain count
+            counts = counts.cpu()
+            self._shard_cache = (N, int(counts.sum()), int(counts[:rank].sum()))
         return self._shard_cache[1], self._shard_cache[2]
 
     def _loss(self, v12, N, n_total, world):
