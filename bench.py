@@ -318,6 +318,9 @@ def main():
     ap.add_argument("--ess-seeds", type=int, default=5, help="independent trainings of the ESS leg")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the `dist` leg even at N = 1 (exercises the collectives on a 1-GPU box)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--bank", type=int, default=0,
                     help="distinct pre-generated random draws, cycled (0 = 2 x proposals-per-launch, min 16)")
     ap.add_argument("--proposals-per-launch", type=int, default=25,
@@ -338,13 +341,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
 
     from l2hmc_amd import Dynamics, _ffi, distributions, layers, sharding
@@ -469,6 +477,11 @@ def main():
         elapsed = float(tt)
 
     flops_cs = algorithmic_flops_per_chain_step(D, H, T, 3 * D)      # diagonal precision: 3d
+
+    def kernel_for(chains):
+        """the library's dispatch for this workload (l2hmc_abi.hip): one-wave tiles once the chip is full"""
+        return "traj_tile_kernel" if chains >= 16384 else "traj_fast_kernel"
+
     dist_out = None
     if use_dist and not args.no_ess:
         dist_out = dist_leg(dev, rank, world)
@@ -497,7 +510,7 @@ def main():
                        "mean_accept_prob": mean_p, "state_finite": finite},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "traj_fast_kernel", "flops_per_chain_step": flops_cs,
+                         "kernel": kernel_for(n), "flops_per_chain_step": flops_cs,
                          "launch_us": launch_s * 1e6,
                          "hbm_frac": algorithmic_bytes_per_chain_step(D, T) * n * T * m_avg / launch_s / 1e9 / PEAK_HBM_GBS},
         }
@@ -517,7 +530,8 @@ def main():
                 reps = max(1, int(math.ceil(args.min_timed_ms / (100 * est2))))
                 el2, ms2, nl2, _ = timed(r2, f2, 100, reps)
                 a2 = flops_cs * nc * T * (100 * reps / float(nl2)) / (ms2 * 1e-3 / nl2) / 1e12
-                sweep.append({"chains": nc, "value": nc * T * 100.0 * reps / el2, "achieved": a2,
+                sweep.append({"chains": nc, "kernel": kernel_for(nc),
+                              "value": nc * T * 100.0 * reps / el2, "achieved": a2,
                               "frac": a2 / PEAK_F32_MFMA_TFLOPS, "launch_us": 1e3 * ms2 / nl2})
             out["sweep"] = sweep
         if world == 1 and not args.no_ess and not args.force_dist:
