@@ -302,6 +302,57 @@ int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int
 int64_t l2hmc_train_grad_floats(int32_t d, int32_t H);
 int l2hmc_train_propose_grad(const L2hmcTrainArgs* args, void* stream);
 
+/* ---- training on the GEMM engine (next-row f1 for config 5 and for wide nets) ----------------------------------
+ * l2hmc_train_propose_grad's contract -- ONE proposal per chain in the chain's own direction, its accept
+ * probability, the loss argument and the gradient of the loss term (accumulated into `grad`) -- for the samplers the
+ * register-resident kernels cannot hold: S/T/Q nets of any width H, the shared image branch aux_encoder(aux) in their
+ * first hidden layer, and the VAE latent-posterior energy (mnist_vae.py:104-226, the "trained sampler" of BASELINE.json
+ * config 5); or, with `energy` set, a diagonal / dense Gaussian or a Rough Well with wide nets.
+ *   v1_n = sum_k w_nk (Lx_nk - x_nk)^2 p_n + 1e-4;      term = scale * mean_n(1 / v1_n) - mean_n(v1_n) / scale
+ *   w = dist_weight (N, d) or NULL (= 1).  SCGExperiment.ipynb raw 164-169: w = 1, scale = 0.1;
+ *   mnist_vae.py:207-214 (energy_scale = 0): w = 1 / (exp(2 log_sigma) + 1e-4), scale = 1.
+ * grad layout: [XNet | VNet | d/d eps | aux_encoder (W1, b1, W2, b2, W3, b3)], each net in NET_FIELDS order;
+ * l2hmc_train_split_grad_floats(d, H, aux_encoder) floats (l2hmc_adam_step applies it, last_is_log_eps = 0 when the
+ * image branch follows -- multiply the eps entry by eps first).  The decoder is NOT trained here (the reference trains
+ * it by a separate optimiser on the ELBO, mnist_vae.py:229-262).
+ * dLx_in (N, d) or NULL: a cotangent added to d loss / d Lx -- what a LATER proposal of the same step sends back when
+ * proposals are chained without stop_gradient (mnist_vae.py:185-224); dx0_out (N, d) or NULL receives d loss / d x.
+ * inv_n = 0 with dLx_in: the proposal has no loss term of its own (an earlier link of such a chain).
+ * Every sum over chains is chunked and added in chunk order: the gradient is bitwise reproducible. */
+typedef struct L2hmcTrainSplitArgs {
+  const L2hmcNet* xnet;
+  const L2hmcNet* vnet;
+  int32_t H;
+  const L2hmcMlp3* aux_encoder;  /* (n_pix -> H) or NULL                                                   */
+  const L2hmcMlp3* decoder;      /* (d -> n_pix); NULL with `energy`                                       */
+  const float* aux;              /* (N, n_pix)                                                             */
+  const L2hmcEnergy* energy;     /* NULL: the decoder posterior.  Else GAUSS_DIAG / GAUSS_DENSE / ROUGHWELL */
+  const float* hess;             /* GAUSS_DENSE: the RAW (d, d) precision (its symmetric part is the Hessian) */
+  const float* masks;            /* (T, d) */
+  const float* trig;             /* (T, 2) */
+  const float* alpha;            /* device log(eps) or NULL -> eps_host */
+  float eps_host;
+  int64_t n_chains;
+  int32_t d, T;
+  const float* x;                /* (N, d) start points                          */
+  const float* v;                /* (N, d) momenta of each chain's own direction */
+  const uint8_t* direction;      /* (N) or NULL -> direction_all                 */
+  int32_t direction_all;
+  const float* dist_weight;      /* (N, d) or NULL */
+  float scale, inv_n;
+  const float* dLx_in;           /* (N, d) or NULL */
+  float *Lx, *p, *v1;            /* (N, d), (N), (N) */
+  float* dx0_out;                /* (N, d) or NULL */
+  float* grad;                   /* accumulated */
+  float* workspace;              /* l2hmc_train_split_workspace_floats(...) floats */
+  int64_t workspace_floats;
+} L2hmcTrainSplitArgs;
+
+int64_t l2hmc_train_split_grad_floats(int32_t d, int32_t H, const L2hmcMlp3* aux_encoder);
+int64_t l2hmc_train_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,
+                                           const L2hmcMlp3* aux_encoder, const L2hmcMlp3* decoder);
+int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* args, void* stream);
+
 /* One Adam update as tf.train.AdamOptimizer applies it (SCGExperiment.ipynb raw 178-181) over the flat parameter
  * vector laid out like the gradient of l2hmc_train_propose_grad ([XNet | VNet | alpha]):
  *   lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr_t m / (sqrt(v) + eps)

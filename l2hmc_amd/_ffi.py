@@ -72,6 +72,18 @@ class L2hmcTrainArgs(C.Structure):
                 ("Lx", _fp), ("p", _fp), ("v1", _fp), ("grad", _fp), ("workspace", _fp), ("variant", C.c_int32)]
 
 
+class L2hmcTrainSplitArgs(C.Structure):
+    _fields_ = [("xnet", C.POINTER(L2hmcNet)), ("vnet", C.POINTER(L2hmcNet)), ("H", C.c_int32),
+                ("aux_encoder", C.POINTER(L2hmcMlp3)), ("decoder", C.POINTER(L2hmcMlp3)), ("aux", _fp),
+                ("energy", C.POINTER(L2hmcEnergy)), ("hess", _fp),
+                ("masks", _fp), ("trig", _fp), ("alpha", _fp), ("eps_host", C.c_float),
+                ("n_chains", C.c_int64), ("d", C.c_int32), ("T", C.c_int32),
+                ("x", _fp), ("v", _fp), ("direction", _fp), ("direction_all", C.c_int32),
+                ("dist_weight", _fp), ("scale", C.c_float), ("inv_n", C.c_float), ("dLx_in", _fp),
+                ("Lx", _fp), ("p", _fp), ("v1", _fp), ("dx0_out", _fp), ("grad", _fp),
+                ("workspace", _fp), ("workspace_floats", C.c_int64)]
+
+
 # every symbol include/l2hmc.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "l2hmc_abi_version": (C.c_int, []),
@@ -94,6 +106,10 @@ SYMBOLS = {
     "l2hmc_train_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "l2hmc_train_grad_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_train_propose_grad": (C.c_int, [C.POINTER(L2hmcTrainArgs), _fp]),
+    "l2hmc_train_split_grad_floats": (C.c_int64, [C.c_int32, C.c_int32, C.POINTER(L2hmcMlp3)]),
+    "l2hmc_train_split_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                                       C.POINTER(L2hmcMlp3), C.POINTER(L2hmcMlp3)]),
+    "l2hmc_train_split_grad": (C.c_int, [C.POINTER(L2hmcTrainSplitArgs), _fp]),
     "l2hmc_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int64, C.c_int32, _fp]),
     "l2hmc_ais_begin_step": (C.c_int, [_fp, _fp, _fp, C.c_float, C.c_float, _fp, _fp, C.c_int64, C.c_int32, _fp]),

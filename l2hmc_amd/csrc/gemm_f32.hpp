@@ -20,7 +20,11 @@
 //   EPI_BIAS            C = acc + b
 //   EPI_BIAS_SOFTPLUS   C = softplus(acc + b),  C2 = sigmoid(acc + b)   (C2 feeds the backward pass)
 //   EPI_BIAS_RELU       C = relu(acc + b)
-//   EPI_MUL             C = acc * E[m][n]                               (backward through softplus)
+//   EPI_MUL             C = acc * E[m][n] (+ C if accum),  C2 = acc      (backward through softplus)
+//   EPI_MASK            C = E[m][n] > 0 ? acc : 0                       (backward through relu; E = the activation)
+//   EPI_TAN             C = E acc,  C2 = E (1 - E) acc E2               (tangent through softplus: E = sigmoid,
+//                       E2 = the cotangent that multiplies the sigmoid in the reverse pass -- the two terms of
+//                       the Hessian-vector product of the decoder energy, train_split.hpp)
 //   EPI_ADD             C = acc + E[m][n]                               (d/dz of the prior term)
 //   EPI_BCE             l = acc + b;  C = beta (sigmoid(l) - t),  rowsum[m][tile] = beta sum_n bce(l, t)
 //                       (mnist_vae.py:122-126, TF's stable form max(l,0) - l t + log1p(e^{-|l|}))
@@ -33,7 +37,8 @@
 
 namespace l2hmc {
 
-enum { EPI_BIAS = 0, EPI_BIAS_SOFTPLUS = 1, EPI_BIAS_RELU = 2, EPI_MUL = 3, EPI_ADD = 4, EPI_BCE = 5, EPI_NET1 = 6 };
+enum { EPI_BIAS = 0, EPI_BIAS_SOFTPLUS = 1, EPI_BIAS_RELU = 2, EPI_MUL = 3, EPI_ADD = 4, EPI_BCE = 5, EPI_NET1 = 6,
+       EPI_MASK = 7, EPI_TAN = 8 };
 
 struct GemmArgs {
   const float* A; int lda;       // (M, K)
@@ -42,7 +47,9 @@ struct GemmArgs {
   int M, N, K;
   const float* bias;             // (N) or NULL
   const float* E; int lde;       // (M, N) second operand of the epilogue (sigmoid / aux / z / auxh) or NULL
-  float* C2; int ldc2;           // second output (sigmoid) or NULL
+  float* C2; int ldc2;           // second output (sigmoid / raw product / second tangent term) or NULL
+  const float* E2; int lde2;     // EPI_TAN: third operand
+  int accum;                     // EPI_MUL: C += instead of C =
   float* rowsum; int n_tiles;    // EPI_BCE: (M, 2 * n_tiles) partial sums, one per (column tile, wave column)
   float beta;                    // EPI_BCE scale
   // EPI_NET1
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
       if (g.bias != nullptr) b = ld4(g.bias + n);
       if (g.E != nullptr) e = ld4(g.E + m * g.lde + n);
       f4 out, out2 = splat(0.f);
+      bool has2 = EPI == EPI_BIAS_SOFTPLUS;
       if (EPI == EPI_BIAS) {
         out = v + b;
       } else if (EPI == EPI_BIAS_SOFTPLUS) {
@@ -208,6 +216,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
         out = f4{fmaxf(p.x, 0.f), fmaxf(p.y, 0.f), fmaxf(p.z, 0.f), fmaxf(p.w, 0.f)};
       } else if (EPI == EPI_MUL) {
         out = v * e;
+        if (g.accum) out = out + ld4(g.C + m * g.ldc + n);
+        out2 = v;
+        has2 = true;
+      } else if (EPI == EPI_MASK) {
+        out = f4{e.x > 0.f ? v.x : 0.f, e.y > 0.f ? v.y : 0.f, e.z > 0.f ? v.z : 0.f, e.w > 0.f ? v.w : 0.f};
+      } else if (EPI == EPI_TAN) {
+        out = e * v;
+        out2 = e * (1.f - e) * v * ld4(g.E2 + m * g.lde2 + n);
+        has2 = true;
       } else if (EPI == EPI_ADD) {
         out = v + e;
       } else if (EPI == EPI_BCE) {
@@ -228,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
         out = f4{fmaxf(p.x, 0.f), fmaxf(p.y, 0.f), fmaxf(p.z, 0.f), fmaxf(p.w, 0.f)};
       }
       st4(g.C + m * g.ldc + n, out);
-      if (EPI == EPI_BIAS_SOFTPLUS && g.C2 != nullptr) st4(g.C2 + m * g.ldc2 + n, out2);
+      if (has2 && g.C2 != nullptr) st4(g.C2 + m * g.ldc2 + n, out2);
     }
   }
   if (EPI == EPI_BCE) {
@@ -358,6 +375,144 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
     for (int r = 0; r < 4; ++r)
       if (n + r < N3) o[r] = v[r];
   });
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight-gradient products of the GEMM-engine trainer (train_split.hpp): contraction over the ROWS of two
+// row-major activations ("TN" form),
+//   part[z][i][j] = sum_{r in row chunk z} A[r][i] B[r][j],        A (R x I), B (R x J), R = chains x evaluations.
+// A 256-thread workgroup owns a 64 x 64 tile of one chunk; each wave a 32 x 32 quadrant (2 x 2 MFMA tiles).  Row
+// tiles of 16 are staged in LDS exactly as they lie in memory ([r][i], row stride 68: the 4 row segments a wave
+// reads per ds_read_b32 fall into distinct banks), double buffered.  The chunks are added in chunk order by
+// tn_reduce_kernel: no atomics, the gradient is bitwise reproducible.
+struct GemmTnArgs {
+  const float* A; int lda;
+  const float* B; int ldb;
+  long long R; int I, J;
+  float* part;                   // (n_chunks, I, J)
+  long long rows_per_chunk;      // multiple of 16
+};
+constexpr int TN_P = 68;
+
+template <bool V4>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
+  __shared__ __attribute__((aligned(16))) float sA[2][16 * TN_P];
+  __shared__ __attribute__((aligned(16))) float sB[2][16 * TN_P];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const long long r_begin = (long long)blockIdx.z * g.rows_per_chunk;
+  long long r_end = r_begin + g.rows_per_chunk;
+  if (r_end > g.R) r_end = g.R;
+  const int lr = tid >> 4, lc = (tid & 15) * 4;              // this thread's (row, column quad) of a 16 x 64 tile
+  f4 ra, rb;
+  auto ldq = [&](const float* base, int ld, long long r, int col, int ncol) {
+    f4 v = splat(0.f);
+    if (r < r_end) {
+      const float* p = base + r * ld + col;
+      if (V4) {
+        if (col + 3 < ncol) return *reinterpret_cast<const f4*>(p);
+      }
+      if (col + 0 < ncol) v.x = p[0];
+      if (col + 1 < ncol) v.y = p[1];
+      if (col + 2 < ncol) v.z = p[2];
+      if (col + 3 < ncol) v.w = p[3];
+    }
+    return v;
+  };
+  auto gload = [&](long long r0) {
+    ra = ldq(g.A, g.lda, r0 + lr, i0 + lc, g.I);
+    rb = ldq(g.B, g.ldb, r0 + lr, j0 + lc, g.J);
+  };
+  auto sstore = [&](int buf) {
+    *reinterpret_cast<f4*>(&sA[buf][lr * TN_P + lc]) = ra;
+    *reinterpret_cast<f4*>(&sB[buf][lr * TN_P + lc]) = rb;
+  };
+  const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
+  f4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = splat(0.f);
+  const long long nt = (r_end - r_begin + 15) / 16;
+  if (nt > 0) {
+    gload(r_begin);
+    sstore(0);
+  }
+  __syncthreads();
+  for (long long t = 0; t < nt; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < nt) gload(r_begin + (t + 1) * 16);
+    float fa[2][4], fb[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a][s] = sA[buf][(4 * q + s) * TN_P + wi + 16 * a + c];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b][s] = sB[buf][(4 * q + s) * TN_P + wj + 16 * b + c];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(fa[a][s], fb[b][s], acc[a][b]);
+    if (t + 1 < nt) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  // lane holds D[i = i0 + wi + 16 a + 4 q + r][j = j0 + wj + 16 b + c]
+  float* out = g.part + (long long)blockIdx.z * g.I * g.J;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = j0 + wj + 16 * b + c;
+      if (j >= g.J) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi + 16 * a + 4 * q + r;
+        if (i < g.I) out[(long long)i * g.J + j] = acc[a][b][r];
+      }
+    }
+}
+
+// dst[i][j] (+)= sum_z part[z][i][j], z ascending (fixed order)
+__global__ void tn_reduce_kernel(const float* part, int n_chunks, int I, int J, float* dst, int ldd, int accumulate) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)I * J) return;
+  float s = 0.f;
+  for (int z = 0; z < n_chunks; ++z) s += part[(long long)z * I * J + e];
+  float* o = dst + (e / J) * ldd + (e % J);
+  *o = accumulate ? *o + s : s;
+}
+
+// chunking of a TN product / column sum: chunks of >= 512 rows (multiple of 16), at most 64 of them and at most
+// `part_cap` floats of partial results
+inline void tn_chunks(long long R, long long IJ, long long part_cap, int& n_chunks, long long& rows_per_chunk) {
+  long long n = (R + 511) / 512;
+  if (n > 64) n = 64;
+  if (n * IJ > part_cap) n = part_cap / IJ;
+  if (n < 1) n = 1;
+  rows_per_chunk = ((R + n - 1) / n + 15) / 16 * 16;
+  n_chunks = (int)((R + rows_per_chunk - 1) / rows_per_chunk);
+  if (n_chunks < 1) n_chunks = 1;
+}
+
+// dst (I x J, row stride ldd) (+)= A^T B; `part` holds at least part_cap floats (>= I * J)
+inline void launch_gemm_tn(hipStream_t s, const float* A, int lda, const float* B, int ldb, long long R, int I, int J,
+                           float* dst, int ldd, int accumulate, float* part, long long part_cap) {
+  if (I <= 0 || J <= 0) return;
+  GemmTnArgs g;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.R = R; g.I = I; g.J = J; g.part = part;
+  int nc;
+  tn_chunks(R, (long long)I * J, part_cap, nc, g.rows_per_chunk);
+  const dim3 grid((unsigned)((J + 63) / 64), (unsigned)((I + 63) / 64), (unsigned)nc);
+  const bool v4 = lda % 4 == 0 && ldb % 4 == 0 && ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(B)) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, s, g);
+  const long long n = (long long)I * J;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nc, I, J, dst, ldd, accumulate);
 }
 
 // rowsum layout of EPI_BCE: (M, 2 * n_tiles) with n_tiles = ceil(N / (32 WNB)) of the shape the launcher picks

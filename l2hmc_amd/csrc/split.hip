@@ -509,3 +509,5 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
 }
 
 }  // extern "C"
+
+#include "train_split.hpp"

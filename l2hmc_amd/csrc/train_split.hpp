@@ -1,0 +1,717 @@
+// train_split.hpp -- one proposal + the gradient of its loss term ON THE GEMM ENGINE: the training step for
+// samplers the register-resident training kernels (train.hip) cannot hold -- S/T/Q nets of any width H, the shared
+// image branch `encoder_sampler(aux)` and the VAE latent-posterior energy (mnist_vae.py:104-226: BASELINE.json
+// config 5's "trained sampler"), and the built-in targets with wide nets (SCGExperiment.ipynb `network`, H != 10).
+// Included at the end of split.hip (same translation unit: it reuses the forward kernels and the decoder GEMMs).
+//
+//   loss term   v1_n = sum_k w_nk (Lx_nk - x_nk)^2 p_n + 1e-4;   term = scale mean_n(1 / v1_n) - mean_n(v1_n) / scale
+//     w = 1, scale = 0.1: SCGExperiment.ipynb raw 164-169 / utils/losses.py:53-59;
+//     w = 1 / (sigma_q^2 + 1e-4), scale = 1: mnist_vae.py:207-214 (energy_scale = 0, the default).
+//   gradient w.r.t. XNet, VNet, alpha (as d/d eps) and the image branch; optionally the cotangent a later proposal sends
+//   into Lx comes in (dLx_in) and d loss / d x goes out (dx0_out): mnist_vae.py:185-224 chains MH proposals without
+//   stop_gradient.
+//
+// MI355X-first: nothing is recomputed and nothing is checkpointed sparsely -- with 288 GB of HBM the forward pass simply
+// keeps every net evaluation's inputs, both hidden activations and head products (4 T evaluations x N chains, 0.75 GB at
+// config 5), the reverse sweep leaves the three pre-activation cotangents of every evaluation next to them, and each
+// weight matrix's gradient is then ONE contraction over all (evaluation, chain) rows (gemm_tn_kernel, K = 2 T N) instead
+// of 4 T small ones.  The reverse sweep itself is, per net evaluation, one adjoint kernel of the leapfrog update (the
+// formulas of train.hip's v_half_bwd / x_half_bwd) and three NT GEMMs (d z -> d h2 -> d h1 -> d inputs, relu masks fused
+// into the epilogues); the path through grad U is a Hessian-vector product: elementwise for the diagonal Gaussian and the
+// Rough Well, a (d x d) product for the dense Gaussian, and for the decoder posterior forward-over-reverse through the
+// decoder: 3 tangent GEMMs + 3 reverse-tangent GEMMs around the 5 GEMMs that rebuild the point's activations, the
+// softplus'' terms fused into the epilogues (EPI_TAN).  No atomics anywhere: every sum over chains is chunked and added
+// in chunk order, so the gradient is bitwise reproducible.
+#pragma once
+
+namespace l2hmc {
+
+// flat parameter layout of one net == NET_FIELDS order of include/l2hmc.h (the same as train.hip's)
+struct SNetOff { long long W1, b1, W2, b2, W3, b3, W4, b4, Ws, bs, Wt, bt, Wq, bq, ls, lq, total; };
+inline SNetOff snet_off(int d, int H) {
+  SNetOff o;
+  long long p = 0;
+  o.W1 = p; p += (long long)d * H; o.b1 = p; p += H; o.W2 = p; p += (long long)d * H; o.b2 = p; p += H;
+  o.W3 = p; p += 2 * H; o.b3 = p; p += H; o.W4 = p; p += (long long)H * H; o.b4 = p; p += H;
+  o.Ws = p; p += (long long)H * d; o.bs = p; p += d; o.Wt = p; p += (long long)H * d; o.bt = p; p += d;
+  o.Wq = p; p += (long long)H * d; o.bq = p; p += d; o.ls = p; p += d; o.lq = p; p += d;
+  o.total = p;
+  return o;
+}
+inline long long mlp3_params(const L2hmcMlp3& m) {
+  return (long long)m.n_in * m.n_h1 + m.n_h1 + (long long)m.n_h1 * m.n_h2 + m.n_h2 + (long long)m.n_h2 * m.n_out + m.n_out;
+}
+
+// ---- adjoint of k_v_half (train.hip v_half_bwd).  out3 holds the head products on entry and the cotangents of the
+// three head PRE-activations (d zs | d zt | d zq) on exit; DL = (dS S | dQ Q): its column sums are d lam_s, d lam_q.
+__global__ __launch_bounds__(256) void k_tv_half_bwd(float* out3, L2hmcNet w, const float* vin, int ldvi, const float* g,
+                                                     int ldg, const float* dout, float* dvin, float* dg, float* DL,
+                                                     const float* lam, float* deps, const unsigned char* dir, int dir_all,
+                                                     const float* alpha, float eps_host, long long N, int d) {
+  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const bool fwd = dir != nullptr ? dir[n] != 0 : (dir_all != 0);
+  const float eps = alpha != nullptr ? expf(*alpha) : eps_host, heps = 0.5f * eps, sg = fwd ? 1.f : -1.f;
+  const float lm = lam[n];
+  float acc = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    float* o = out3 + n * 3 * d;
+    const float els = expf(w.lam_s[k]), elq = expf(w.lam_q[k]);
+    const float ts = tanhf(o[k] + w.bs[k]), Tt = o[d + k] + w.bt[k], tq = tanhf(o[2 * d + k] + w.bq[k]);
+    const float S = els * ts, Q = elq * tq;
+    const float ES = expf(sg * heps * S), EQ = expf(eps * Q);
+    const float gq = g[n * ldg + k], vi = vin[n * ldvi + k];
+    const float cc = heps * (Tt - EQ * gq);
+    const float dO = dout[n * d + k];
+    const float dES = fwd ? dO * vi : dO * (vi - cc);
+    const float dcc = fwd ? dO : -dO * ES;
+    const float ds = dES * ES + lm;
+    const float dSr = ds * sg * heps;
+    const float dq = -dcc * heps * gq * EQ;
+    const float dQr = dq * eps;
+    dvin[n * d + k] = dO * ES;
+    dg[n * d + k] = -dcc * heps * EQ;
+    DL[n * 2 * d + k] = dSr * S;
+    DL[n * 2 * d + d + k] = dQr * Q;
+    o[k] = dSr * els * (1.f - ts * ts);
+    o[d + k] = dcc * heps;
+    o[2 * d + k] = dQr * elq * (1.f - tq * tq);
+    acc += ds * sg * 0.5f * S + dcc * 0.5f * (Tt - EQ * gq) + dq * Q;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) deps[n] += acc;
+}
+
+// ---- adjoint of k_x_half (train.hip x_half_bwd): dzin_out = direct part of d zin, dvh += ...
+__global__ __launch_bounds__(256) void k_tx_half_bwd(float* out3, L2hmcNet w, const float* zin, int ldzi, const float* vh,
+                                                     int ldvh, const float* dout, float* dzin_out, float* dvh, float* DL,
+                                                     const float* lam, float* deps, const float* masks,
+                                                     const unsigned char* dir, int dir_all, int it, int T, int second,
+                                                     const float* alpha, float eps_host, long long N, int d) {
+  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  bool fwd;
+  const int s = row_of(dir, dir_all, n, it, T, fwd);
+  const float eps = alpha != nullptr ? expf(*alpha) : eps_host, sg = fwd ? 1.f : -1.f;
+  const float lm = lam[n];
+  float acc = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    float* o = out3 + n * 3 * d;
+    const float m = masks[s * d + k];
+    const float k1 = fwd ? m : 1.f - m;
+    const float kp = second ? 1.f - k1 : k1, up = 1.f - kp;
+    const float els = expf(w.lam_s[k]), elq = expf(w.lam_q[k]);
+    const float ts = tanhf(o[k] + w.bs[k]), Tt = o[d + k] + w.bt[k], tq = tanhf(o[2 * d + k] + w.bq[k]);
+    const float S = els * ts, Q = elq * tq;
+    const float ES = expf(sg * eps * S), EQ = expf(eps * Q);
+    const float vhq = vh[n * ldvh + k], zi = zin[n * ldzi + k];
+    const float tr = eps * (EQ * vhq + Tt);
+    const float dO = dout[n * d + k];
+    const float dnw = up * dO;
+    const float dES = fwd ? dnw * zi : dnw * (zi - tr);
+    const float dtr = fwd ? dnw : -dnw * ES;
+    const float dsx = dES * ES + up * lm;
+    const float dSr = dsx * sg * eps;
+    const float dq = dtr * eps * vhq * EQ;
+    const float dQr = dq * eps;
+    dzin_out[n * d + k] = kp * dO + dnw * ES;
+    dvh[n * d + k] += dtr * eps * EQ;
+    DL[n * 2 * d + k] = dSr * S;
+    DL[n * 2 * d + d + k] = dQr * Q;
+    o[k] = dSr * els * (1.f - ts * ts);
+    o[d + k] = dtr * eps;
+    o[2 * d + k] = dQr * elq * (1.f - tq * tq);
+    acc += dsx * sg * S + dtr * (EQ * vhq + Tt) + dq * Q;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) deps[n] += acc;
+}
+
+// after an XNet evaluation's input cotangents dAB = (d a | d b):  dvh += d a;  tgt += kept-mask * d b
+// (the net saw b = k1 x on the first position update and (1 - k1) y on the second)
+__global__ void k_comb_x(const float* dAB, float* dvh, float* tgt, const float* masks, const unsigned char* dir,
+                         int dir_all, int it, int T, int second, long long N, int d) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * d) return;
+  const long long n = i / d;
+  const int k = (int)(i % d);
+  bool fwd;
+  const int s = row_of(dir, dir_all, n, it, T, fwd);
+  const float m = masks[s * d + k];
+  const float k1 = fwd ? m : 1.f - m;
+  dvh[i] += dAB[n * 2 * d + k];
+  tgt[i] += (second ? 1.f - k1 : k1) * dAB[n * 2 * d + d + k];
+}
+// VNet evaluation at (x, grad U(x)):  u = dg + d b  is the vector of the Hessian-vector product ...
+__global__ void k_comb_v1(const float* dg, const float* dAB, float* u, long long N, int d) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * d) return;
+  u[i] = dg[i] + dAB[(i / d) * 2 * d + d + (i % d)];
+}
+// ... and  lx += d a + Hessian(x) u
+__global__ void k_comb_v2(float* lx, const float* dAB, const float* hv, long long N, int d) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * d) return;
+  lx[i] += dAB[(i / d) * 2 * d + (i % d)] + hv[i];
+}
+
+// Hessian-vector products of the built-in targets (oracle/l2hmc_train_oracle.py *Target.hessvec): diagonal Gaussian
+// P u; Rough Well (1 - (eta / den^2) cos(x / den)) u; dense Gaussian G u with G = (S + S^T) / 2 of the RAW precision
+__global__ void k_hvp_builtin(int kind, const float* x, int ldx, const float* u, float* hv, const float* prec,
+                              const float* hess, float eta, int easy, long long N, int d) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * d) return;
+  const long long n = i / d;
+  const int k = (int)(i % d);
+  float o;
+  if (kind == L2HMC_ENERGY_GAUSS_DIAG) {
+    o = prec[k] * u[i];
+  } else if (kind == L2HMC_ENERGY_ROUGHWELL) {
+    const float den = easy ? eta : eta * eta;
+    o = (1.f - (eta / (den * den)) * cosf(x[n * ldx + k] / den)) * u[i];
+  } else {
+    o = 0.f;
+    for (int j = 0; j < d; ++j) o += 0.5f * (hess[k * d + j] + hess[j * d + k]) * u[n * d + j];
+  }
+  hv[i] = o;
+}
+
+// accept probability (dynamics.py:302-309), the loss argument and the adjoint seeds of the reverse sweep
+// (train.hip "accept probability, loss term and the adjoint seeds"); one wave per chain
+__global__ __launch_bounds__(256) void k_train_seed(const float* x0, const float* x1, int ldx1, const float* v1,
+                                                    const float* g1, int ldg1, const double* U0, const double* U1,
+                                                    const float* K0, const float* ld, const float* wgt,
+                                                    const float* dLx_in, float scale, float inv_n, float* Lx, float* p_out,
+                                                    float* v1_out, float* lam, float* dv1p_out, float* lx, float* lv,
+                                                    float* deps, long long N, int d) {
+  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float K1 = 0.f, sq = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float vv = v1[n * d + k], dx = x1[n * ldx1 + k] - x0[n * d + k];
+    K1 += 0.5f * vv * vv;
+    sq += (wgt != nullptr ? wgt[n * d + k] : 1.f) * dx * dx;
+  }
+  K1 = wave_sum(K1);
+  sq = wave_sum(sq);
+  const float val = (float)((U0[n] - U1[n]) + ((double)K0[n] - (double)K1) + (double)ld[n]);
+  const float p = accept_prob(val);
+  const float v1o = sq * p + 1e-4f;
+  const float dv1 = (scale * (-1.f / (v1o * v1o)) - 1.f / scale) * inv_n;
+  const bool pfin = (val == val) && p > 0.f;          // the finite branch of dynamics.py:309 actually taken
+  const bool ok = sq < 3.0e38f;                       // a diverged chain contributes no gradient (train.hip)
+  const float lm = (ok && pfin && val < 0.f) ? dv1 * sq * p : 0.f;
+  const float dv1p = ok ? dv1 * p * 2.f : 0.f;
+  if (lane == 0) {
+    p_out[n] = p;
+    v1_out[n] = v1o;
+    lam[n] = lm;
+    dv1p_out[n] = dv1p;
+    deps[n] = 0.f;
+  }
+  for (int k = lane; k < d; k += 64) {
+    const float xe = x1[n * ldx1 + k];
+    Lx[n * d + k] = xe;
+    const float wk = wgt != nullptr ? wgt[n * d + k] : 1.f;
+    float a = ok ? dv1p * wk * (xe - x0[n * d + k]) - lm * g1[n * ldg1 + k] : 0.f;
+    if (dLx_in != nullptr) a += dLx_in[n * d + k];
+    lx[n * d + k] = a;
+    lv[n * d + k] = ok ? -lm * v1[n * d + k] : 0.f;
+  }
+}
+// d loss / d x0 = the sweep's cotangent + the direct paths through (Lx - x0) and through U(x0) of the accept ratio
+__global__ void k_train_dx0(const float* lx, const float* x0, const float* x1, int ldx1, const float* g0, int ldg0,
+                            const float* wgt, const float* lam, const float* dv1p, float* out, long long N, int d) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * d) return;
+  const long long n = i / d;
+  const int k = (int)(i % d);
+  const float wk = wgt != nullptr ? wgt[i] : 1.f;
+  out[i] = lx[i] - dv1p[n] * wk * (x1[n * ldx1 + k] - x0[i]) + lam[n] * g0[n * ldg0 + k];
+}
+
+// ---- chunked column sums (fixed order): part[chunk][col] = sum over the chunk's rows of A[r][col] ----------------
+// block = 64 columns x 4 row lanes; the 4 row lanes are added in order through LDS
+__global__ __launch_bounds__(256) void k_colsum_part(const float* A, int lda, long long R, int cols,
+                                                     long long rows_per_chunk, float* part) {
+  __shared__ float sm[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+  long long r1 = r0 + rows_per_chunk;
+  if (r1 > R) r1 = R;
+  float s = 0.f;
+  if (col < cols)
+    for (long long r = r0 + ry; r < r1; r += 4) s += A[r * lda + col];
+  sm[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < cols) part[(long long)blockIdx.y * cols + col] = ((sm[0][cx] + sm[1][cx]) + sm[2][cx]) + sm[3][cx];
+}
+// d W3 (2, H): rows are weighted with the time encoding of the row's schedule step.  Row r of a net's stash is
+// (evaluation e = r / N, chain n = r % N); evaluation e belongs to leapfrog iteration e / 2.
+__global__ __launch_bounds__(256) void k_w3_part(const float* A, int H, long long N, long long R, long long rows_per_chunk,
+                                                 const float* trig, int T, const unsigned char* dir, int dir_all,
+                                                 float* part) {
+  __shared__ float sm[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+  long long r1 = r0 + rows_per_chunk;
+  if (r1 > R) r1 = R;
+  float sc = 0.f, ss = 0.f;
+  if (col < H)
+    for (long long r = r0 + ry; r < r1; r += 4) {
+      const long long e = r / N, n = r - e * N;
+      bool fwd;
+      const int s = row_of(dir, dir_all, n, (int)(e >> 1), T, fwd);
+      const float a = A[r * H + col];
+      sc += trig[2 * s] * a;
+      ss += trig[2 * s + 1] * a;
+    }
+  sm[0][ry][cx] = sc;
+  sm[1][ry][cx] = ss;
+  __syncthreads();
+  if (ry == 0 && col < H) {
+    float* o = part + (long long)blockIdx.y * 2 * H;
+    o[col] = ((sm[0][0][cx] + sm[0][1][cx]) + sm[0][2][cx]) + sm[0][3][cx];
+    o[H + col] = ((sm[1][0][cx] + sm[1][1][cx]) + sm[1][2][cx]) + sm[1][3][cx];
+  }
+}
+// dst[i] = sum_e X[e][i] + sum_e V[e][i]  (the image branch feeds the first hidden layer of every evaluation)
+__global__ void k_sum_evals(const float* X, const float* V, int n_evals, long long stride, float* dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= stride) return;
+  float s = 0.f;
+  for (int e = 0; e < n_evals; ++e) s += X[(long long)e * stride + i];
+  for (int e = 0; e < n_evals; ++e) s += V[(long long)e * stride + i];
+  dst[i] = s;
+}
+// *dst += sum_n a[n]: one workgroup, strided partial sums combined by a fixed tree
+__global__ __launch_bounds__(256) void k_sum_chain(const float* a, long long N, float* dst) {
+  __shared__ float sm[256];
+  float s = 0.f;
+  for (long long n = threadIdx.x; n < N; n += 256) s += a[n];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *dst += sm[0];
+}
+// beta sigmoid'(logit) from the BCE epilogue's r = sigmoid(logit) - t:  sigma = r + t
+__global__ void k_sigd(const float* r, const float* t, float* out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sg = r[i] + t[i];
+  out[i] = sg * (1.f - sg);
+}
+// [W1; W2] stacked (2 d, H) and [Ws | Wt | Wq] side by side (H, 3 d): the B operands of the input-gradient products
+__global__ void k_stack_rows(const float* A, const float* B, long long nA, long long nB, float* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nA) out[i] = A[i];
+  else if (i < nA + nB) out[i] = B[i - nA];
+}
+__global__ void k_heads_side(const float* Ws, const float* Wt, const float* Wq, int H, int d, float* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)H * 3 * d) return;
+  const int h = (int)(i / (3 * d)), c = (int)(i % (3 * d)), which = c / d, k = c % d;
+  const float* W = which == 0 ? Ws : (which == 1 ? Wt : Wq);
+  out[i] = W[(long long)h * d + k];
+}
+
+inline void colsum_into(hipStream_t s, const float* A, int lda, long long R, int cols, float* dst, float* part,
+                        long long part_cap) {
+  int nc;
+  long long rpc;
+  tn_chunks(R, cols, part_cap, nc, rpc);
+  hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)((cols + 63) / 64), (unsigned)nc), dim3(256), 0, s, A, lda, R, cols, rpc, part);
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, part, nc, 1, cols, dst, cols, 1);
+}
+
+struct TrainSplitPlan {
+  long long total;
+  SplitPlan fwd;                                    // the forward engine's slices (decoder scratch, time table, ...)
+  long long base;                                   // first float after the forward plan
+  long long AB[2], H1[2], H2[2], O3[2], DA2[2], DA1[2], DL[2];   // per net [X, V]: (2 T N, .) stashes
+  long long VS, YS;                                 // (T + 1, N, d) momenta, (T, N, d) intermediate positions
+  long long lx, lv, dvh, dz, dg, u, hv, dAB;        // running cotangents
+  long long lam, dv1p, deps;
+  long long w12c[2], whc[2];                        // stacked / side-by-side weight copies per net
+  long long part;                                   // chunk partials of the TN products and column sums
+  long long part_cap;
+  long long B2, B1, HD1, HD2, M1, M2, rd, RD;       // decoder Hessian-vector product
+  long long dauxh, es1, es2, de2, de1;              // image branch reverse pass
+  long long xq;                                     // contiguous copy of a point (built-in Hessians)
+};
+
+inline TrainSplitPlan plan_train_split(long long N, int d, int H, int T, const L2hmcMlp3* enc, const L2hmcMlp3* dec) {
+  TrainSplitPlan p;
+  p.fwd = plan_split(N, d, H, T, enc, dec);
+  long long o = (p.fwd.total + 3) & ~3LL;
+  p.base = o;
+  auto take = [&](long long n) { const long long at = o; o += (n + 3) & ~3LL; return at; };
+  const long long R = 2LL * T * N;
+  for (int i = 0; i < 2; ++i) {
+    p.AB[i] = take(R * 2 * d); p.H1[i] = take(R * H); p.H2[i] = take(R * H); p.O3[i] = take(R * 3 * d);
+    p.DA2[i] = take(R * H); p.DA1[i] = take(R * H); p.DL[i] = take(R * 2 * d);
+    p.w12c[i] = take(2LL * d * H); p.whc[i] = take(3LL * d * H);
+  }
+  p.VS = take((T + 1) * N * d); p.YS = take((long long)T * N * d);
+  p.lx = take(N * d); p.lv = take(N * d); p.dvh = take(N * d); p.dz = take(N * d); p.dg = take(N * d);
+  p.u = take(N * d); p.hv = take(N * d); p.dAB = take(N * 2 * d);
+  p.lam = take(N); p.dv1p = take(N); p.deps = take(N);
+  long long big = (long long)H * H;
+  if ((long long)2 * d * H > big) big = 2LL * d * H;
+  if ((long long)3 * d * H > big) big = 3LL * d * H;
+  if (enc) {
+    if ((long long)enc->n_in * enc->n_h1 > big) big = (long long)enc->n_in * enc->n_h1;
+    if ((long long)enc->n_h1 * enc->n_h2 > big) big = (long long)enc->n_h1 * enc->n_h2;
+    if ((long long)enc->n_h2 * enc->n_out > big) big = (long long)enc->n_h2 * enc->n_out;
+  }
+  p.part_cap = 16 * big;                            // up to 16 row chunks of the largest product (>= 64 of the others)
+  if (p.part_cap < 64LL * 4096) p.part_cap = 64LL * 4096;
+  p.part = take(p.part_cap);
+  if (dec) {
+    p.B2 = take(N * dec->n_h2); p.B1 = take(N * dec->n_h1); p.HD1 = take(N * dec->n_h1); p.HD2 = take(N * dec->n_h2);
+    p.M1 = take(N * dec->n_h1); p.M2 = take(N * dec->n_h2); p.rd = take(N * dec->n_out); p.RD = take(N * dec->n_out);
+    p.xq = 0;
+  } else {
+    p.B2 = p.B1 = p.HD1 = p.HD2 = p.M1 = p.M2 = p.rd = p.RD = 0;
+    p.xq = take(N * d);
+  }
+  if (enc) {
+    p.dauxh = take(N * H); p.es1 = take(N * enc->n_h1); p.es2 = take(N * enc->n_h2);
+    p.de2 = take(N * enc->n_h2); p.de1 = take(N * enc->n_h1);
+  } else {
+    p.dauxh = p.es1 = p.es2 = p.de2 = p.de1 = 0;
+  }
+  p.total = o;
+  return p;
+}
+
+// hv = Hessian(z) u of the decoder posterior U(z) = sum_pix BCE(aux, dec(z)) + |z|^2 / 2 (mnist_vae.py:122-126).
+// Forward-over-reverse: with p_i the pre-activations, s_i = sigmoid(p_i) (= softplus'), r = sigmoid(logit) - aux and the
+// reverse pass b2 = r W3^T, c2 = s2 b2, b1 = c2 W2^T, c1 = s1 b1, grad = c1 W1^T + z, the directional derivative along u
+//   p1. = u W1,  h1. = s1 p1.,  p2. = h1. W2,  h2. = s2 p2.,  l. = h2. W3,  r. = sigma' l.
+//   c2. = s2 (1 - s2) p2. b2 + s2 (r. W3^T),   c1. = s1 (1 - s1) p1. b1 + s1 (c2. W2^T),   H u = u + c1. W1^T.
+void vae_hvp(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, int ldz, long long N, int d,
+             const Mlp3Ws& ws, float* lg, float* rowsum, const TrainSplitPlan& p, float* w, const float* u, float* hv) {
+  // the point's activations: s1, s2, r (as vae_energy), and the raw reverse products b2, b1
+  mlp3_hidden(s, dec, z, ldz, N, ws);
+  GemmArgs g = gemm_args(ws.a2, dec.n_h2, ws.w3t, dec.n_h2, lg, dec.n_out, N, dec.n_out, dec.n_h2);
+  g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(dec.n_out); g.beta = 1.f;
+  launch_gemm<EPI_BCE>(g, s);
+  const long long npix = N * dec.n_out;
+  hipLaunchKernelGGL(k_sigd, dim3(nblk(npix)), dim3(256), 0, s, lg, aux, w + p.rd, npix);
+  g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);
+  g.E = ws.s2; g.lde = dec.n_h2; g.C2 = w + p.B2; g.ldc2 = dec.n_h2;
+  launch_gemm<EPI_MUL>(g, s);
+  g = gemm_args(ws.a2, dec.n_h2, dec.W2, dec.n_h2, ws.a1, dec.n_h1, N, dec.n_h1, dec.n_h2);
+  g.E = ws.s1; g.lde = dec.n_h1; g.C2 = w + p.B1; g.ldc2 = dec.n_h1;
+  launch_gemm<EPI_MUL>(g, s);
+  // tangent forward
+  g = gemm_args(u, d, ws.w1t, dec.n_in, w + p.HD1, dec.n_h1, N, dec.n_h1, dec.n_in);
+  g.E = ws.s1; g.lde = dec.n_h1; g.E2 = w + p.B1; g.lde2 = dec.n_h1; g.C2 = w + p.M1; g.ldc2 = dec.n_h1;
+  launch_gemm<EPI_TAN>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_BIG);
+  g = gemm_args(w + p.HD1, dec.n_h1, ws.w2t, dec.n_h1, w + p.HD2, dec.n_h2, N, dec.n_h2, dec.n_h1);
+  g.E = ws.s2; g.lde = dec.n_h2; g.E2 = w + p.B2; g.lde2 = dec.n_h2; g.C2 = w + p.M2; g.ldc2 = dec.n_h2;
+  launch_gemm<EPI_TAN>(g, s);
+  g = gemm_args(w + p.HD2, dec.n_h2, ws.w3t, dec.n_h2, w + p.RD, dec.n_out, N, dec.n_out, dec.n_h2);
+  g.E = w + p.rd; g.lde = dec.n_out;
+  launch_gemm<EPI_MUL>(g, s);
+  // tangent of the reverse pass
+  g = gemm_args(w + p.RD, dec.n_out, dec.W3, dec.n_out, w + p.M2, dec.n_h2, N, dec.n_h2, dec.n_out);
+  g.E = ws.s2; g.lde = dec.n_h2; g.accum = 1;
+  launch_gemm<EPI_MUL>(g, s);
+  g = gemm_args(w + p.M2, dec.n_h2, dec.W2, dec.n_h2, w + p.M1, dec.n_h1, N, dec.n_h1, dec.n_h2);
+  g.E = ws.s1; g.lde = dec.n_h1; g.accum = 1;
+  launch_gemm<EPI_MUL>(g, s);
+  g = gemm_args(w + p.M1, dec.n_h1, dec.W1, dec.n_h1, hv, d, N, d, dec.n_h1);
+  g.E = u; g.lde = d;
+  launch_gemm<EPI_ADD>(g, s, d <= 64 ? SHAPE_SKINNY : SHAPE_MID);
+}
+
+}  // namespace l2hmc
+
+using namespace l2hmc;
+
+extern "C" {
+
+int64_t l2hmc_train_split_grad_floats(int32_t d, int32_t H, const L2hmcMlp3* aux_encoder) {
+  if (d < 1 || H < 1) return fail(L2HMC_ERR_ARG, "l2hmc_train_split_grad_floats: bad argument%s");
+  return 2 * snet_off(d, H).total + 1 + (aux_encoder ? mlp3_params(*aux_encoder) : 0);
+}
+
+int64_t l2hmc_train_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,
+                                           const L2hmcMlp3* aux_encoder, const L2hmcMlp3* decoder) {
+  if (n_chains < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "l2hmc_train_split_workspace_floats: bad argument%s");
+  return plan_train_split(n_chains, d, H, T, aux_encoder, decoder).total;
+}
+
+int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
+  if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
+  const bool builtin = a->energy != nullptr;
+  int rc;
+  const long long N = a->n_chains;
+  const int d = a->d, H = a->H, T = a->T;
+  if (N < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
+  if (N == 0) return L2HMC_OK;
+  if (builtin) {
+    if (a->decoder || a->aux_encoder || a->aux)
+      return fail(L2HMC_ERR_UNSUPPORTED, "a built-in energy excludes decoder / aux_encoder / aux%s");
+    if ((rc = check_energy(a->energy, d))) return rc;
+    const int ek = a->energy->kind;
+    if (ek != L2HMC_ENERGY_GAUSS_DIAG && ek != L2HMC_ENERGY_ROUGHWELL && ek != L2HMC_ENERGY_GAUSS_DENSE)
+      return fail(L2HMC_ERR_UNSUPPORTED, "GEMM-engine training: diagonal / dense Gaussian, Rough Well or the decoder posterior%s");
+    if (ek == L2HMC_ENERGY_GAUSS_DENSE && !a->hess) return fail(L2HMC_ERR_ARG, "dense Gaussian: hess = the RAW (d, d) precision%s");
+    if (a->energy->temperature != 1.f || (a->energy->anneal_beta != 0.f && a->energy->anneal_beta != 1.f))
+      return fail(L2HMC_ERR_UNSUPPORTED, "training differentiates the plain energy (temperature 1, no annealing)%s");
+  } else {
+    if ((rc = check_mlp(a->decoder, "decoder"))) return rc;
+    if (!a->aux) return fail(L2HMC_ERR_ARG, "the decoder posterior needs aux%s");
+    if (a->decoder->n_in != d) return fail(L2HMC_ERR_ARG, "decoder input width != d%s");
+  }
+  if (a->aux_encoder) {
+    if ((rc = check_mlp(a->aux_encoder, "aux_encoder"))) return rc;
+    if (a->aux_encoder->n_out != H || a->aux_encoder->n_in != a->decoder->n_out)
+      return fail(L2HMC_ERR_ARG, "aux_encoder must map (N, n_pix) -> (N, H)%s");
+  }
+  if (!a->xnet || !a->vnet || !a->masks || !a->trig || !a->x || !a->v || !a->Lx || !a->p || !a->v1 || !a->grad || !a->workspace)
+    return fail(L2HMC_ERR_ARG, "l2hmc_train_split_grad: NULL pointer%s");
+  if (!a->alpha && !(a->eps_host > 0.f)) return fail(L2HMC_ERR_ARG, "eps must be > 0%s");
+  if (!(a->scale > 0.f) || !(a->inv_n >= 0.f)) return fail(L2HMC_ERR_ARG, "scale must be > 0 and inv_n >= 0%s");
+  if (a->inv_n == 0.f && !a->dLx_in) return fail(L2HMC_ERR_ARG, "inv_n = 0 (no loss term of its own) needs dLx_in%s");
+  const TrainSplitPlan p = plan_train_split(N, d, H, T, a->aux_encoder, a->decoder);
+  if (a->workspace_floats < p.total) return fail(L2HMC_ERR_ARG, "workspace too small: need %s%lld floats", "", p.total);
+  hipStream_t s = (hipStream_t)stream;
+  float* w = a->workspace;
+  const SplitPlan& f = p.fwd;
+  static const L2hmcMlp3 no_dec = {};
+  const L2hmcMlp3& dec = builtin ? no_dec : *a->decoder;
+  const Mlp3Ws dws = {w + f.dw1t, w + f.dw2t, w + f.dw3t, w + f.a1, w + f.s1, w + f.a2, w + f.s2};
+  const int L = 2 * d;
+  const L2hmcNet &xn = *a->xnet, &vn = *a->vnet;
+  const L2hmcNet* nets[2] = {&xn, &vn};
+  const unsigned char* dir = a->direction;
+  const int dall = a->direction_all;
+  const unsigned nw4 = (unsigned)((N + 3) / 4);
+  float *tb = w + f.tb, *ld = w + f.ld;
+  float* aux_h = a->aux_encoder ? w + f.aux_h : nullptr;
+  double *U0d = reinterpret_cast<double*>(w + f.U0), *U1d = reinterpret_cast<double*>(w + f.U1);
+  const long long NL = N * L, NH = N * H, N3 = N * 3 * d, Nd = N * d;
+  // stash slices of evaluation `ne` (= 2 it + which) of net `net` (0 = X, 1 = V)
+  auto AB = [&](int net, int ne) { return w + p.AB[net] + ne * NL; };
+  auto H1 = [&](int net, int ne) { return w + p.H1[net] + ne * NH; };
+  auto H2 = [&](int net, int ne) { return w + p.H2[net] + ne * NH; };
+  auto O3 = [&](int net, int ne) { return w + p.O3[net] + ne * N3; };
+  auto DA2 = [&](int net, int ne) { return w + p.DA2[net] + ne * NH; };
+  auto DA1 = [&](int net, int ne) { return w + p.DA1[net] + ne * NH; };
+  auto DL = [&](int net, int ne) { return w + p.DL[net] + ne * NL; };
+  auto VS = [&](int it) { return w + p.VS + it * Nd; };
+  auto YS = [&](int it) { return w + p.YS + it * Nd; };
+
+  // ---- weights: transposed copies for the forward products, stacked copies for the input-gradient products ------
+  if (!builtin) mlp3_transposes(s, dec, dws);
+  Mlp3Ws ews = {};
+  if (a->aux_encoder) {
+    const L2hmcMlp3& enc = *a->aux_encoder;
+    ews = Mlp3Ws{w + f.ew1t, w + f.ew2t, w + f.ew3t, w + f.e1, w + p.es1, w + f.e2, w + p.es2};
+    mlp3_transposes(s, enc, ews);
+    mlp3_forward(s, enc, a->aux, N, ews, aux_h);
+  }
+  hipLaunchKernelGGL(k_time_table, dim3(nblk(2LL * T * H)), dim3(256), 0, s, xn, vn, a->trig, T, H, tb);
+  float* w12t[2] = {w + f.nx12t, w + f.nv12t};
+  float* w4t[2] = {w + f.nx4t, w + f.nv4t};
+  float* wht[2] = {w + f.nxht, w + f.nvht};
+  const int K1p = ceil16(L), Hp = ceil16(H);
+  (void)hipMemsetAsync(w + f.nx12t, 0, sizeof(float) * (size_t)(f.nvht + (long long)ceil16(3 * d) * Hp - f.nx12t), s);
+  for (int i = 0; i < 2; ++i) {
+    transpose_into(s, nets[i]->W1, d, H, w12t[i], K1p, 0);
+    transpose_into(s, nets[i]->W2, d, H, w12t[i], K1p, d);
+    transpose_into(s, nets[i]->W4, H, H, w4t[i], Hp, 0);
+    transpose_into(s, nets[i]->Ws, H, d, wht[i], Hp, 0);
+    transpose_into(s, nets[i]->Wt, H, d, wht[i] + (long long)d * Hp, Hp, 0);
+    transpose_into(s, nets[i]->Wq, H, d, wht[i] + 2LL * d * Hp, Hp, 0);
+    hipLaunchKernelGGL(k_stack_rows, dim3(nblk(2LL * d * H)), dim3(256), 0, s, nets[i]->W1, nets[i]->W2, (long long)d * H,
+                       (long long)d * H, w + p.w12c[i]);
+    hipLaunchKernelGGL(k_heads_side, dim3(nblk(3LL * d * H)), dim3(256), 0, s, nets[i]->Ws, nets[i]->Wt, nets[i]->Wq, H, d,
+                       w + p.whc[i]);
+  }
+
+  // U (double, optional) and grad U at the point in columns [0, d) of `ab` -> columns [d, 2 d)
+  auto energy_eval = [&](float* ab, double* Ud) -> int {
+    if (!builtin) {
+      vae_energy(s, dec, a->aux, ab, L, N, d, dws, w + f.lg, w + f.rowsum, nullptr, Ud, ab + d, L, 1.f);
+      return L2HMC_OK;
+    }
+    (void)hipMemcpy2DAsync(w + f.xp, sizeof(float) * d, ab, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
+    const int r = l2hmc_energy(a->energy, w + f.xp, N, d, Ud ? w + f.uf : nullptr, w + f.gp, stream);
+    if (r) return r;
+    (void)hipMemcpy2DAsync(ab + d, sizeof(float) * L, w + f.gp, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
+    if (Ud) hipLaunchKernelGGL(k_f2d, dim3(nblk(N)), dim3(256), 0, s, w + f.uf, Ud, N);
+    return L2HMC_OK;
+  };
+  // one net evaluation with everything kept: h1, h2 and the head products of evaluation (net, ne)
+  auto net_fwd = [&](int net, int ne, int it) {
+    GemmArgs ga = gemm_args(AB(net, ne), L, w12t[net], K1p, H1(net, ne), H, N, H, L);
+    ga.E = aux_h; ga.lde = H; ga.tb = tb + (long long)net * T * H; ga.dir = dir; ga.dir_all = dall; ga.it = it; ga.T = T;
+    launch_gemm<EPI_NET1>(ga, s, SHAPE_MID);
+    ga = gemm_args(H1(net, ne), H, w4t[net], Hp, H2(net, ne), H, N, H, H);
+    ga.bias = nets[net]->b4;
+    launch_gemm<EPI_BIAS_RELU>(ga, s, SHAPE_MID);
+    ga = gemm_args(H2(net, ne), H, wht[net], Hp, O3(net, ne), 3 * d, N, 3 * d, H);
+    launch_gemm<EPI_BIAS>(ga, s, SHAPE_MID);
+  };
+  // reverse of net_fwd for the data path: O3 holds (d zs | d zt | d zq) -> DA2, DA1 (kept for the weight gradients), dAB
+  auto net_bwd = [&](int net, int ne) {
+    GemmArgs ga = gemm_args(O3(net, ne), 3 * d, w + p.whc[net], 3 * d, DA2(net, ne), H, N, H, 3 * d);
+    ga.E = H2(net, ne); ga.lde = H;
+    launch_gemm<EPI_MASK>(ga, s, SHAPE_MID);
+    ga = gemm_args(DA2(net, ne), H, nets[net]->W4, H, DA1(net, ne), H, N, H, H);
+    ga.E = H1(net, ne); ga.lde = H;
+    launch_gemm<EPI_MASK>(ga, s, SHAPE_MID);
+    ga = gemm_args(DA1(net, ne), H, w + p.w12c[net], H, w + p.dAB, L, N, L, H);
+    launch_gemm<EPI_BIAS>(ga, s, SHAPE_MID);
+  };
+
+  // ---- forward trajectory, everything kept ------------------------------------------------------------------------
+  (void)hipMemcpy2DAsync(AB(1, 0), sizeof(float) * L, a->x, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
+  (void)hipMemcpyAsync(VS(0), a->v, sizeof(float) * Nd, hipMemcpyDeviceToDevice, s);
+  hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, VS(0), w + f.K0, ld, N, d);
+  if ((rc = energy_eval(AB(1, 0), U0d))) return rc;
+  for (int it = 0; it < T; ++it) {
+    const bool last = it == T - 1;
+    float *abv0 = AB(1, 2 * it), *abv1 = AB(1, 2 * it + 1), *abx0 = AB(0, 2 * it), *abx1 = AB(0, 2 * it + 1);
+    net_fwd(1, 2 * it, it);
+    hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it), vn, VS(it), d, abv0 + d, L, abx0, L, ld, dir, dall,
+                       a->alpha, a->eps_host, N, d);
+    hipLaunchKernelGGL(k_mask_first, dim3(nblk(Nd)), dim3(256), 0, s, abv0, L, abx0 + d, L, a->masks, dir, dall, it, T, N, d);
+    net_fwd(0, 2 * it, it);
+    hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it), xn, abv0, L, abx0, L, YS(it), d, abx1 + d, L, ld,
+                       a->masks, dir, dall, it, T, 0, a->alpha, a->eps_host, N, d);
+    (void)hipMemcpy2DAsync(abx1, sizeof(float) * L, abx0, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
+    net_fwd(0, 2 * it + 1, it);
+    hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it + 1), xn, YS(it), d, abx0, L, abv1, L, (float*)nullptr, 0,
+                       ld, a->masks, dir, dall, it, T, 1, a->alpha, a->eps_host, N, d);
+    if ((rc = energy_eval(abv1, last ? U1d : nullptr))) return rc;
+    net_fwd(1, 2 * it + 1, it);
+    hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it + 1), vn, abx0, L, abv1 + d, L, VS(it + 1), d, ld, dir,
+                       dall, a->alpha, a->eps_host, N, d);
+    if (!last) (void)hipMemcpyAsync(AB(1, 2 * it + 2), abv1, sizeof(float) * NL, hipMemcpyDeviceToDevice, s);
+  }
+
+  // ---- accept probability, loss argument, adjoint seeds -----------------------------------------------------------
+  float *lx = w + p.lx, *lv = w + p.lv, *dvh = w + p.dvh, *dz = w + p.dz, *dg = w + p.dg, *uu = w + p.u, *hv = w + p.hv;
+  float *lam = w + p.lam, *dv1p = w + p.dv1p, *deps = w + p.deps, *dAB = w + p.dAB;
+  {
+    const float* abe = AB(1, 2 * T - 1);
+    hipLaunchKernelGGL(k_train_seed, dim3(nw4), dim3(256), 0, s, a->x, abe, L, VS(T), abe + d, L, U0d, U1d, w + f.K0, ld,
+                       a->dist_weight, a->dLx_in, a->scale, a->inv_n, a->Lx, a->p, a->v1, lam, dv1p, lx, lv, deps, N, d);
+  }
+  // lx += d a + Hessian(x) (dg + d b) for the VNet evaluation at the point in `ab`
+  auto through_grad = [&](float* ab) -> int {
+    hipLaunchKernelGGL(k_comb_v1, dim3(nblk(Nd)), dim3(256), 0, s, dg, dAB, uu, N, d);
+    if (!builtin) {
+      vae_hvp(s, dec, a->aux, ab, L, N, d, dws, w + f.lg, w + f.rowsum, p, w, uu, hv);
+    } else {
+      hipLaunchKernelGGL(k_hvp_builtin, dim3(nblk(Nd)), dim3(256), 0, s, a->energy->kind, ab, L, uu, hv, a->energy->prec,
+                         a->hess, a->energy->eta, a->energy->easy, N, d);
+    }
+    hipLaunchKernelGGL(k_comb_v2, dim3(nblk(Nd)), dim3(256), 0, s, lx, dAB, hv, N, d);
+    return L2HMC_OK;
+  };
+
+  // ---- reverse sweep (train.hip "reverse sweep", stages (1)-(4)) ----------------------------------------------------
+  for (int it = T - 1; it >= 0; --it) {
+    float *abv0 = AB(1, 2 * it), *abv1 = AB(1, 2 * it + 1), *abx0 = AB(0, 2 * it);
+    // (1) v' = v_half(vh; g(x'), V(x', g(x')))
+    hipLaunchKernelGGL(k_tv_half_bwd, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it + 1), vn, abx0, L, abv1 + d, L, lv, dvh, dg,
+                       DL(1, 2 * it + 1), lam, deps, dir, dall, a->alpha, a->eps_host, N, d);
+    net_bwd(1, 2 * it + 1);
+    if ((rc = through_grad(abv1))) return rc;                       // lx = d x'
+    // (2) x' = x_half(y, 1 - k1; vh, X(vh, (1 - k1) y))
+    hipLaunchKernelGGL(k_tx_half_bwd, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it + 1), xn, YS(it), d, abx0, L, lx, dz, dvh,
+                       DL(0, 2 * it + 1), lam, deps, a->masks, dir, dall, it, T, 1, a->alpha, a->eps_host, N, d);
+    net_bwd(0, 2 * it + 1);
+    hipLaunchKernelGGL(k_comb_x, dim3(nblk(Nd)), dim3(256), 0, s, dAB, dvh, dz, a->masks, dir, dall, it, T, 1, N, d);
+    // (3) y = x_half(x, k1; vh, X(vh, k1 x))
+    hipLaunchKernelGGL(k_tx_half_bwd, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it), xn, abv0, L, abx0, L, dz, lx, dvh,
+                       DL(0, 2 * it), lam, deps, a->masks, dir, dall, it, T, 0, a->alpha, a->eps_host, N, d);
+    net_bwd(0, 2 * it);
+    hipLaunchKernelGGL(k_comb_x, dim3(nblk(Nd)), dim3(256), 0, s, dAB, dvh, lx, a->masks, dir, dall, it, T, 0, N, d);
+    // (4) vh = v_half(v; g(x), V(x, g(x)))
+    hipLaunchKernelGGL(k_tv_half_bwd, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it), vn, VS(it), d, abv0 + d, L, dvh, lv, dg,
+                       DL(1, 2 * it), lam, deps, dir, dall, a->alpha, a->eps_host, N, d);
+    net_bwd(1, 2 * it);
+    if ((rc = through_grad(abv0))) return rc;
+  }
+  if (a->dx0_out) {
+    const float* ab0 = AB(1, 0);
+    hipLaunchKernelGGL(k_train_dx0, dim3(nblk(Nd)), dim3(256), 0, s, lx, a->x, AB(1, 2 * T - 1), L, ab0 + d, L, a->dist_weight,
+                       lam, dv1p, a->dx0_out, N, d);
+  }
+
+  // ---- parameter gradients: one contraction over all (evaluation, chain) rows per weight matrix ---------------------
+  const SNetOff o = snet_off(d, H);
+  const long long R = 2LL * T * N;
+  float* part = w + p.part;
+  for (int net = 0; net < 2; ++net) {
+    float* G = a->grad + (long long)net * o.total;
+    const float *ab = w + p.AB[net], *h1 = w + p.H1[net], *h2 = w + p.H2[net], *dzs = w + p.O3[net];
+    const float *da2 = w + p.DA2[net], *da1 = w + p.DA1[net], *dl = w + p.DL[net];
+    launch_gemm_tn(s, ab, L, da1, H, R, d, H, G + o.W1, H, 1, part, p.part_cap);
+    launch_gemm_tn(s, ab + d, L, da1, H, R, d, H, G + o.W2, H, 1, part, p.part_cap);
+    launch_gemm_tn(s, h1, H, da2, H, R, H, H, G + o.W4, H, 1, part, p.part_cap);
+    launch_gemm_tn(s, h2, H, dzs, 3 * d, R, H, d, G + o.Ws, d, 1, part, p.part_cap);
+    launch_gemm_tn(s, h2, H, dzs + d, 3 * d, R, H, d, G + o.Wt, d, 1, part, p.part_cap);
+    launch_gemm_tn(s, h2, H, dzs + 2 * d, 3 * d, R, H, d, G + o.Wq, d, 1, part, p.part_cap);
+    colsum_into(s, da1, H, R, H, G + o.b1, part, p.part_cap);          // b1, b2, b3 enter the same sum
+    colsum_into(s, da1, H, R, H, G + o.b2, part, p.part_cap);
+    colsum_into(s, da1, H, R, H, G + o.b3, part, p.part_cap);
+    colsum_into(s, da2, H, R, H, G + o.b4, part, p.part_cap);
+    colsum_into(s, dzs, 3 * d, R, d, G + o.bs, part, p.part_cap);
+    colsum_into(s, dzs + d, 3 * d, R, d, G + o.bt, part, p.part_cap);
+    colsum_into(s, dzs + 2 * d, 3 * d, R, d, G + o.bq, part, p.part_cap);
+    colsum_into(s, dl, L, R, d, G + o.ls, part, p.part_cap);
+    colsum_into(s, dl + d, L, R, d, G + o.lq, part, p.part_cap);
+    {
+      int nc;
+      long long rpc;
+      tn_chunks(R, 2LL * H, p.part_cap, nc, rpc);
+      hipLaunchKernelGGL(k_w3_part, dim3((unsigned)((H + 63) / 64), (unsigned)nc), dim3(256), 0, s, da1, H, N, R, rpc, a->trig, T,
+                         dir, dall, part);
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((2 * H + 255) / 256)), dim3(256), 0, s, part, nc, 2, H, G + o.W3, H, 1);
+    }
+  }
+  hipLaunchKernelGGL(k_sum_chain, dim3(1), dim3(256), 0, s, deps, N, a->grad + 2 * o.total);
+  if (a->aux_encoder) {
+    // the image branch: d aux_h = sum over all 4 T evaluations of d h1_pre; reverse through the 3-layer MLP
+    const L2hmcMlp3& enc = *a->aux_encoder;
+    float* G = a->grad + 2 * o.total + 1;
+    const long long oW1 = 0, ob1 = oW1 + (long long)enc.n_in * enc.n_h1, oW2 = ob1 + enc.n_h1,
+                    ob2 = oW2 + (long long)enc.n_h1 * enc.n_h2, oW3 = ob2 + enc.n_h2, ob3 = oW3 + (long long)enc.n_h2 * enc.n_out;
+    float *dauxh = w + p.dauxh, *de2 = w + p.de2, *de1 = w + p.de1;
+    hipLaunchKernelGGL(k_sum_evals, dim3(nblk(NH)), dim3(256), 0, s, w + p.DA1[0], w + p.DA1[1], 2 * T, NH, dauxh);
+    GemmArgs ga = gemm_args(dauxh, H, enc.W3, enc.n_out, de2, enc.n_h2, N, enc.n_h2, enc.n_out);
+    ga.E = ews.s2; ga.lde = enc.n_h2;
+    launch_gemm<EPI_MUL>(ga, s, SHAPE_MID);
+    ga = gemm_args(de2, enc.n_h2, enc.W2, enc.n_h2, de1, enc.n_h1, N, enc.n_h1, enc.n_h2);
+    ga.E = ews.s1; ga.lde = enc.n_h1;
+    launch_gemm<EPI_MUL>(ga, s, SHAPE_MID);
+    launch_gemm_tn(s, ews.a2, enc.n_h2, dauxh, H, N, enc.n_h2, enc.n_out, G + oW3, enc.n_out, 1, part, p.part_cap);
+    colsum_into(s, dauxh, H, N, enc.n_out, G + ob3, part, p.part_cap);
+    launch_gemm_tn(s, ews.a1, enc.n_h1, de2, enc.n_h2, N, enc.n_h1, enc.n_h2, G + oW2, enc.n_h2, 1, part, p.part_cap);
+    colsum_into(s, de2, enc.n_h2, N, enc.n_h2, G + ob2, part, p.part_cap);
+    launch_gemm_tn(s, a->aux, enc.n_in, de1, enc.n_h1, N, enc.n_in, enc.n_h1, G + oW1, enc.n_h1, 1, part, p.part_cap);
+    colsum_into(s, de1, enc.n_h1, N, enc.n_h1, G + ob1, part, p.part_cap);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+}  // extern "C"

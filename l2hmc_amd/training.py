@@ -35,6 +35,12 @@ def _numel(code, d, H):
 
 
 class Trainer(object):
+    def __new__(cls, dynamics, *args, **kwargs):
+        # samplers that run on the GEMM engine (nets wider than H = 15, the image-conditioned VAE sampler) train there
+        if cls is Trainer and getattr(dynamics, "_split", False):
+            return object.__new__(SplitTrainer)
+        return object.__new__(cls)
+
     def __init__(self, dynamics, lr=1e-3, decay_steps=1000, decay_rate=0.96, scale=0.1,
                  beta1=0.9, beta2=0.999, epsilon=1e-8, seed=0):
         if dynamics.hmc:
@@ -257,3 +263,270 @@ class Trainer(object):
         _ffi.check(L.l2hmc_mh_select(x.data_ptr(), io["Lx"].data_ptr(), io["p"].data_ptr(), uu.data_ptr(), N, d,
                                      x_next.data_ptr(), s))
         return loss, io["p"][:N].clone(), x_next, lr
+
+
+_MLP_FIELDS = ("W1", "b1", "W2", "b2", "W3", "b3")
+
+
+class SplitTrainer(Trainer):
+    """`Trainer` on the GEMM engine (`l2hmc_train_split_grad`, csrc/train_split.hpp): S/T/Q nets of any width and, for the
+    image-conditioned VAE sampler of mnist_vae.py:128-178, the shared `encoder_sampler` branch and the decoder-posterior
+    energy.  `Trainer(dynamics)` returns one of these whenever the Dynamics runs on the split engine.
+
+    Built-in targets: same objective, schedule and `step()` as `Trainer` (SCGExperiment.ipynb raw 156-181).
+    VAE sampler: `sampler_loss_and_grad` / `sampler_step` are mnist_vae.py:185-262's sampler objective -- MH chained
+    proposals from the encoder's sample, the distance term weighted by the approximate posterior's variance, global-norm
+    clipping at 5 and Adam with the piecewise-constant rate.  The flat parameter vector is
+    [XNet | VNet | alpha | encoder_sampler]; the decoder and the VAE encoder are not this optimiser's variables
+    (mnist_vae.py:255-262 trains them with separate optimisers on the ELBO / the likelihood)."""
+
+    def __init__(self, dynamics, lr=1e-3, decay_steps=1000, decay_rate=0.96, scale=None,
+                 beta1=0.9, beta2=0.999, epsilon=1e-8, seed=0, clip_norm=None):
+        if dynamics.hmc:
+            raise ValueError("an HMC-mode Dynamics has nothing to train")
+        if (dynamics.use_temperature and float(dynamics.temperature) != 1.0) or float(dynamics.anneal_beta or 0.0) != 0.0:
+            raise NotImplementedError("training differentiates the plain energy U: a tempered or annealed Dynamics "
+                                      "is not supported")
+        from .vae import mlp3_struct
+        self._mlp3_struct = mlp3_struct
+        self.dyn = dynamics
+        self.vae = bool(dynamics._vae)
+        self.scale = float(scale) if scale is not None else (1.0 if self.vae else 0.1)
+        self.clip_norm = clip_norm if clip_norm is not None else (5.0 if self.vae else None)   # mnist_vae.py:258
+        self.lr0, self.decay_steps, self.decay_rate = float(lr), int(decay_steps), float(decay_rate)
+        self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
+        self.seed = int(seed)
+        d, H = dynamics.x_dim, dynamics.H
+        dev = dynamics.device
+        L = _ffi.lib()
+        self.enc = dynamics._xw["aux_encoder"]
+        enc_s = mlp3_struct(self.enc) if self.enc is not None else None
+        self.n_grad = _ffi.check(L.l2hmc_train_split_grad_floats(d, H, C.byref(enc_s) if enc_s is not None else None))
+        self.flat = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)
+        self.theta = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)
+        self.slots, off = [], 0
+        with torch.no_grad():
+            for w in (dynamics._xw, dynamics._vw):
+                for name, code in _SHAPES:
+                    n = _numel(code, d, H)
+                    t = w[name]
+                    view = self.theta[off:off + n].view(t.shape)
+                    view.copy_(t)
+                    t.data = view
+                    self.slots.append((t, off, n))
+                    off += n
+            self.alpha_index = off
+            self.train_alpha = bool(getattr(dynamics.alpha, "requires_grad", False))
+            self.theta[off].copy_(dynamics.alpha.reshape(()))
+            dynamics.alpha.data = self.theta[off].view(dynamics.alpha.shape)
+            off += 1
+            if self.enc is not None:
+                for name in _MLP_FIELDS:
+                    t = self.enc[name]
+                    n = t.numel()
+                    view = self.theta[off:off + n].view(t.shape)
+                    view.copy_(t)
+                    t.data = view
+                    self.slots.append((t, off, n))
+                    off += n
+            assert off == self.n_grad, (off, self.n_grad)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.global_step = 0
+        self._ws = None
+        self.variant = 0
+        self._io = None
+        self._shard_cache = None
+
+    def lr_at(self, step):
+        if self.vae and self.decay_steps <= 0:
+            return self.lr0
+        return Trainer.lr_at(self, step)
+
+    # ---- one proposal + its gradient (accumulated into self.flat) ---------------------------------------------------
+    def _propose_grad(self, start, v, direction, n_total, out=None, aux=None, dist_weight=None, dLx_in=None,
+                      dx0_out=None):
+        dyn = self.dyn
+        N, d = start.shape
+        L = _ffi.lib()
+        enc_s = self._mlp3_struct(self.enc) if self.enc is not None else None
+        dec_s = self._mlp3_struct(dyn._fn.decoder) if self.vae else None
+        need = _ffi.check(L.l2hmc_train_split_workspace_floats(N, d, dyn.H, dyn.T,
+                                                               C.byref(enc_s) if enc_s is not None else None,
+                                                               C.byref(dec_s) if dec_s is not None else None))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(int(need), dtype=torch.float32, device=dyn.device)
+        if out is None:
+            out = (torch.empty_like(start), torch.empty(N, dtype=torch.float32, device=dyn.device),
+                   torch.empty(N, dtype=torch.float32, device=dyn.device))
+        Lx, p, v1 = out
+        xs = _ffi.L2hmcNet(*[dyn._xw[k].data_ptr() for k in _ffi.NET_FIELDS])
+        vs = _ffi.L2hmcNet(*[dyn._vw[k].data_ptr() for k in _ffi.NET_FIELDS])
+        a = _ffi.L2hmcTrainSplitArgs()
+        a.xnet, a.vnet, a.H = C.pointer(xs), C.pointer(vs), dyn.H
+        a.aux_encoder = C.pointer(enc_s) if enc_s is not None else None
+        keep = None
+        if self.vae:
+            if aux is None:
+                raise ValueError("the image-conditioned sampler needs aux=")
+            aux = as_device_f32(aux, dyn.device)
+            if aux.shape != (N, dyn._fn.n_pix):
+                raise ValueError("aux must be (N, %d)" % dyn._fn.n_pix)
+            a.decoder, a.aux = C.pointer(dec_s), aux.data_ptr()
+        else:
+            fn = dyn._fn
+            if fn.kind not in (_ffi.ENERGY_GAUSS_DIAG, _ffi.ENERGY_GAUSS_DENSE, _ffi.ENERGY_ROUGHWELL):
+                raise NotImplementedError("GEMM-engine training supports the Gaussian and Rough-Well targets (and the "
+                                          "VAE posterior); mixtures and the funnel train on nets with H <= 15")
+            keep = fn.c_struct(dyn.device, 1.0, 0.0)
+            a.energy = C.pointer(keep)
+            if fn.kind == _ffi.ENERGY_GAUSS_DENSE:
+                a.hess = fn._buffers(dyn.device)["_raw"].data_ptr()
+        a.masks, a.trig = dyn._mask.data_ptr(), dyn._trig.data_ptr()
+        if dyn.eps_override is None:
+            a.alpha, a.eps_host = dyn.alpha.data_ptr(), 0.0
+        else:
+            a.alpha, a.eps_host = None, float(dyn.eps_override)
+        a.n_chains, a.d, a.T = N, d, dyn.T
+        a.x, a.v = start.data_ptr(), v.data_ptr()
+        a.direction, a.direction_all = direction.data_ptr(), 1
+        a.dist_weight = _ffi.ptr(dist_weight)
+        a.scale, a.inv_n = self.scale, 1.0 / float(n_total)
+        a.dLx_in, a.dx0_out = _ffi.ptr(dLx_in), _ffi.ptr(dx0_out)
+        a.Lx, a.p, a.v1 = Lx.data_ptr(), p.data_ptr(), v1.data_ptr()
+        a.grad, a.workspace, a.workspace_floats = self.flat.data_ptr(), self._ws.data_ptr(), self._ws.numel()
+        _ffi.check(L.l2hmc_train_split_grad(a, _ffi.current_stream(dyn.device)))
+        return Lx, p, v1
+
+    def _publish_grads(self):
+        for t, off, n in self.slots:
+            t.grad = self.flat[off:off + n].view(t.shape)
+        if self.train_alpha:
+            self.dyn.alpha.grad = (self.flat[self.alpha_index] * torch.exp(self.dyn.alpha.detach())).reshape(self.dyn.alpha.shape)
+
+    def loss_and_grad(self, x, z=None, draws=None):
+        if self.vae:
+            raise TypeError("the VAE sampler's objective needs the images: use sampler_loss_and_grad")
+        loss, Lx, px = Trainer.loss_and_grad(self, x, z, draws)
+        self._publish_grads()
+        return loss, Lx, px
+
+    def _adam(self, lr):
+        """TF1 Adam over the flat vector; alpha's entry holds d/d eps and is turned into d/d alpha first."""
+        L = _ffi.lib()
+        s = _ffi.current_stream(self.dyn.device)
+        i = self.alpha_index
+        if self.train_alpha:
+            self.flat[i] *= torch.exp(self.theta[i])
+        else:
+            self.flat[i] = 0.0
+        if self.clip_norm is not None:                    # tf.clip_by_global_norm(gradients, 5.0), mnist_vae.py:258
+            gn = torch.linalg.vector_norm(self.flat.double()).float()
+            self.flat *= torch.clamp(self.clip_norm / torch.clamp(gn, min=1e-30), max=1.0)
+        self.global_step += 1
+        if not self.train_alpha:
+            keep = (self.theta[i].clone(), self.m[i].clone(), self.v[i].clone())
+        _ffi.check(L.l2hmc_adam_step(self.theta.data_ptr(), self.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                     self.n_grad, lr, self.beta1, self.beta2, self.epsilon, self.global_step, 0, s))
+        if not self.train_alpha:
+            self.theta[i], self.m[i], self.v[i] = keep
+        self.dyn._packed_key = None
+
+    def step(self, x, u=None):
+        if self.vae:
+            raise TypeError("the VAE sampler trains with sampler_step(aux, latent_q, log_sigma)")
+        dyn = self.dyn
+        x = as_device_f32(x, dyn.device)
+        N, d = x.shape
+        L = _ffi.lib()
+        s = _ffi.current_stream(dyn.device)
+        io = self._buffers(N, d)
+        W = io["W"]
+        world = self._world()
+        n_total, chain_off = self._shard(N)
+        _ffi.check(L.l2hmc_rng_fill(self.seed, 3 * self.global_step, chain_off, N, d, 3, W[1].data_ptr(),
+                                    io["dir"].data_ptr(), io["u"].data_ptr(), s))
+        W[0].copy_(x)
+        self.flat.zero_()
+        self._propose_grad(W[0:2].view(2 * N, d), W[2:4].view(2 * N, d), io["dir"][1:3].view(2 * N), n_total,
+                           out=(io["Lx"], io["p"], io["v1"]))
+        if world > 1:
+            dist.all_reduce(self.flat)
+        loss = self._loss(io["v1"], N, n_total, world)
+        lr = self.lr_at(self.global_step)
+        self._adam(lr)
+        x_next = torch.empty_like(x)
+        uu = io["u"][0] if u is None else as_device_f32(u, dyn.device)
+        _ffi.check(L.l2hmc_mh_select(x.data_ptr(), io["Lx"].data_ptr(), io["p"].data_ptr(), uu.data_ptr(), N, d,
+                                     x_next.data_ptr(), s))
+        return loss, io["p"][:N].clone(), x_next, lr
+
+    # ---- the VAE experiment's sampler objective (mnist_vae.py:185-226) ---------------------------------------------------
+    def sampler_loss_and_grad(self, latent_q, aux, log_sigma, MH=1, stop_gradient=False, draws=None):
+        """sampler_loss of mnist_vae.py:185-226 (energy_scale = 0) and its gradient (left in `.grad` of every sampler
+        parameter and in `self.flat`).  MH proposals are chained from `latent_q` with an MH step after each
+        (:204,224); like the reference only the LAST proposal's terms enter the loss (inverse_term / other_term are
+        re-initialised inside the loop, :187-189) with weight 1 / MH, and unless `stop_gradient` their gradient flows
+        back through the earlier proposals.  draws: optional list (one dict per proposal) of injected randomness
+        {v, dir, u} (tests).  Returns (loss, latent_T, px of the last proposal)."""
+        if not self.vae:
+            raise TypeError("sampler_loss_and_grad is the VAE experiment's objective")
+        dyn = self.dyn
+        dev, gen = dyn.device, dyn.generator
+        x = as_device_f32(latent_q, dev)
+        aux = as_device_f32(aux, dev)
+        N, d = x.shape
+        wgt = (1.0 / (torch.exp(2.0 * as_device_f32(log_sigma, dev)) + 1e-4)).contiguous()
+        n_total, _ = self._shard(N)
+        world = self._world()
+        states = []
+        for t in range(MH):
+            dr = draws[t] if draws is not None else {}
+            v = as_device_f32(dr["v"], dev) if "v" in dr else torch.randn((N, d), device=dev, generator=gen)
+            dbit = (torch.as_tensor(dr["dir"], device=dev).to(torch.uint8).contiguous() if "dir" in dr
+                    else torch.randint(0, 2, (N,), device=dev, dtype=torch.uint8, generator=gen))
+            u = as_device_f32(dr["u"], dev) if "u" in dr else torch.rand(N, device=dev, generator=gen)
+            states.append((x, v, dbit, u))
+            if t + 1 < MH:                                  # the earlier proposals: forward only
+                o = dyn.run(x, v, 0, dyn.T, direction=dbit, u=u, want=("x_next", "p"), aux=aux)
+                states[-1] = (x, v, dbit, u, o["p"])
+                x = o["x_next"]
+        self.flat.zero_()
+        loss = x_T = p_last = None
+        dx_next = None                                      # cotangent on x_{t+1}
+        for t in range(MH - 1, -1, -1):
+            st = states[t]
+            last = t == MH - 1
+            dLx = None
+            if not last:
+                # x_{t+1} = where(p_t - u_t >= 0, Lx_t, x_t) (sampler.py:53-55): the accepted rows' cotangent goes into
+                # this proposal, the rejected rows' straight on to x_t
+                acc_t = ((st[4] - st[3]) >= 0)[:, None].float()
+                dLx = (dx_next * acc_t).contiguous()
+            want_dx0 = t > 0 and not stop_gradient
+            dx0 = torch.empty((N, d), dtype=torch.float32, device=dev) if want_dx0 else None
+            # only the last proposal has a loss term of its own (inv_n = 0 switches it off for the others)
+            Lx, p, v1 = self._propose_grad(st[0], st[1], st[2], n_total * MH if last else float("inf"), aux=aux,
+                                           dist_weight=wgt, dLx_in=dLx, dx0_out=dx0)
+            if last:
+                terms = torch.stack([(1.0 / v1).sum(), v1.sum()]).double()
+                if world > 1:
+                    dist.all_reduce(terms)
+                loss = (terms[0] - terms[1]) / (n_total * MH)
+                x_T = torch.where(((p - st[3]) >= 0)[:, None], Lx, st[0])
+                p_last = p
+            if not want_dx0:
+                break
+            dx_next = dx0 if last else dx0 + dx_next * (1.0 - acc_t)
+        if world > 1:
+            dist.all_reduce(self.flat)
+        self._publish_grads()
+        return loss, x_T, p_last
+
+    def sampler_step(self, latent_q, aux, log_sigma, MH=5, stop_gradient=False):
+        """One update of the sampler's variables (mnist_vae.py:255-261): clipped Adam on sampler_loss."""
+        loss, x_T, px = self.sampler_loss_and_grad(latent_q, aux, log_sigma, MH=MH, stop_gradient=stop_gradient)
+        lr = self.lr_at(self.global_step)
+        self._adam(lr)
+        return loss, x_T, px, lr

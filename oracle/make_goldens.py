@@ -340,6 +340,129 @@ def vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
         name, N, latent, T, out['fwd.p'].mean(), out['bwd.p'].mean(), np.abs(out['energy']).mean()))
 
 
+def train_vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
+    """Gradient of the VAE experiment's sampler loss (mnist_vae.py:185-226 with MH = 1, energy_scale = 0):
+        final_x, _, px, MH = propose(init_x, dynamics, aux=inp, do_mh_step=True)
+        v = sum_k (final_x - init_x)^2 / (stop_gradient(exp(2 log_sigma)) + 1e-4) * px + 1e-4
+        sampler_loss = mean(1 / v) - mean(v)
+    w.r.t. every variable of the `sampler` scope (XNet, VNet, the shared image branch encoder_sampler, alpha),
+    from the reference's own graph (decoder energy mnist_vae.py:122-126, nets :142-167) differentiated by the stub's
+    tf.gradients.  Also d loss / d init_x (what flows into the previous proposal when MH > 1 and stop_gradient is
+    off, :187-190,224) and the gradients of loss + sum(final_x * R) for a fixed R (the cotangent a later proposal
+    sends back into final_x)."""
+    tf1_stub.reset(seed)
+    np.random.seed(seed)
+    hook = variable_hook_factory(seed + 1, 0.3)
+
+    def vae_hook(full, shape, default):
+        if full.startswith('sampler/XNet') or full.startswith('sampler/VNet'):
+            return hook('/'.join(full.split('/')[1:]), shape, default)
+        return None
+    tf1_stub.VARIABLE_HOOK = vae_hook
+    with tf.variable_scope('decoder'):
+        decoder = Sequential([Linear(latent, dec_h, scope='decoder_1'), tf.nn.softplus,
+                              Linear(dec_h, dec_h, scope='decoder_2'), tf.nn.softplus,
+                              Linear(dec_h, n_pix, scope='decoder_3', factor=0.01)])
+
+    def energy(z, aux=None):                                    # mnist_vae.py:122-126
+        logits = decoder(z)
+        log_posterior = -tf.reduce_sum(tf.nn.sigmoid_cross_entropy_with_logits(labels=aux, logits=logits), axis=1)
+        log_prior = -0.5 * tf.reduce_sum(tf.square(z), axis=1)
+        return (-log_posterior - log_prior)
+
+    with tf.variable_scope('sampler'):
+        encoder_sampler = Sequential([Linear(n_pix, enc_h, scope='encoder_1'), tf.nn.softplus,
+                                      Linear(enc_h, enc_h, scope='encoder_2'), tf.nn.softplus,
+                                      Linear(enc_h, H, scope='encoder_3')])
+
+        def net_factory(x_dim, scope, factor):                  # mnist_vae.py:142-167
+            with tf.variable_scope(scope):
+                return Sequential([
+                    Zip([Linear(latent, H, scope='embed_1', factor=0.33),
+                         Linear(latent, H, scope='embed_2', factor=factor * 0.33),
+                         Linear(2, H, scope='embed_3', factor=0.33),
+                         encoder_sampler]),
+                    sum, tf.nn.relu, Linear(H, H, scope='linear_1'), tf.nn.relu,
+                    Parallel([Sequential([Linear(H, latent, scope='linear_s', factor=0.01),
+                                          ScaleTanh(latent, scope='scale_s')]),
+                              Linear(H, latent, scope='linear_t', factor=0.01),
+                              Sequential([Linear(H, latent, scope='linear_f', factor=0.01),
+                                          ScaleTanh(latent, scope='scale_f')])])])
+        with contextlib.redirect_stdout(io.StringIO()):
+            dyn = ref_dynamics.Dynamics(latent, energy, T=T, eps=eps, net_factory=net_factory)
+    out = {'energy.kind': 'vae', 'case': name, 'x_dim': latent, 'H': H, 'T': T, 'N': N, 'hmc': 0,
+           'eps': npy(dyn.eps), 'mask': npy(dyn.mask)}
+    names = []                                                   # (stub variable name, fixture key) of the trained ones
+    alpha_name = None
+    for full, val in tf1_stub.VARIABLES.items():
+        parts = full.split('/')
+        if parts[0] == 'decoder':
+            out['dec.%s%s' % (parts[2], parts[1][-1])] = npy(val)            # dec.W1 ... dec.b3
+        elif parts[0] == 'sampler' and parts[1].startswith('encoder_'):
+            key = 'enc.%s%s' % (parts[2], parts[1][-1])
+            out[key] = npy(val)
+            names.append((full, key))
+        elif parts[0] == 'sampler' and parts[1] in ('XNet', 'VNet'):
+            key = '%s.%s' % (parts[1].lower(), TF2KEY['/'.join(parts[2:])])
+            out[key] = npy(val)
+            names.append((full, key))
+        elif parts[-1] == 'alpha':
+            alpha_name = full
+    assert alpha_name is not None, list(tf1_stub.VARIABLES)
+    rng = np.random.RandomState(seed + 2)
+    x0 = rng.randn(N, latent).astype(np.float32)
+    aux = (rng.rand(N, n_pix) < 0.3).astype(np.float32)          # binarised "image" rows
+    log_sigma = (0.3 * rng.randn(N, latent) - 0.5).astype(np.float32)
+    R = (0.05 * rng.randn(N, latent)).astype(np.float32)
+    out['x'], out['aux'], out['log_sigma'], out['R'] = x0, aux, log_sigma, R
+    auxt = torch.tensor(aux)
+    del tf1_stub.RANDOM_LOG[:]
+    init_x = leaf(x0)
+    final_x, _, px, MH = ref_sampler.propose(init_x, dyn, aux=auxt, do_mh_step=True)
+    log = list(tf1_stub.RANDOM_LOG)
+    assert [k for k, _ in log] == ['randint', 'normal', 'normal', 'uniform']
+    out['prop.dir'] = log[0][1][:, 0].astype(np.uint8)
+    out['prop.v_fwd'], out['prop.v_bwd'], out['prop.u'] = log[1][1], log[2][1], log[3][1]
+    # mnist_vae.py:207-214 (MH = 1, energy_scale = 0)
+    w = 1.0 / (tf.stop_gradient(tf.exp(2 * torch.tensor(log_sigma))) + 1e-4)
+    v = tf.square(final_x - init_x) * w
+    v = tf.reduce_sum(v, 1) * px + 1e-4
+    loss = tf.reduce_mean(1.0 / v) - tf.reduce_mean(v)
+    variables = [tf1_stub.VARIABLES[full] for full, _ in names] + [tf1_stub.VARIABLES[alpha_name], init_x]
+    grads = tf.gradients(loss, variables)
+    loss2 = loss + tf.reduce_sum(final_x * torch.tensor(R))
+    grads2 = tf.gradients(loss2, variables)
+    out['loss'], out['v'] = npy(loss), npy(v)
+    out['Lx'], out['px'], out['x_next'] = npy(final_x), npy(px), npy(MH[0])
+    for pre, gs in (('grad.', grads), ('grad2.', grads2)):
+        for (full, key), gr in zip(names, gs[:-2]):
+            out[pre + key] = npy(gr)
+        out[pre + 'alpha'] = npy(gs[-2])
+        out[pre + 'x0'] = npy(gs[-1])
+    assert all(np.all(np.isfinite(out[k])) for k in out if k.startswith('grad')), 'non-finite gradient'
+    tf1_stub.VARIABLE_HOOK = None
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    gn = np.sqrt(sum(float(np.sum(out[k].astype(np.float64) ** 2)) for k in out if k.startswith('grad.')))
+    print('%-18s N=%-4d d=%-3d T=%-3d  loss %.4e  |grad| %.3e  grad.alpha %.3e  mean px %.3f  |grad.enc.W1| %.3e' % (
+        name, N, latent, T, float(out['loss']), gn, float(out['grad.alpha']), out['px'].mean(),
+        float(np.abs(out['grad.enc.W1']).max())))
+
+
+def train_wide_cases():
+    """training gradients with nets wider than the register-resident kernels take (H > 15): GEMM-engine trainer"""
+    var = np.exp(np.linspace(np.log(1e-2), np.log(1e2), 50))
+    train_case('train_icg50_h32', np.zeros(50), np.diag(var), H=32, T=4, eps=0.05, N=16, seed=37, head_std=0.05)
+    rng = np.random.RandomState(7)
+    R = np.linalg.qr(rng.randn(8, 8))[0]
+    cov8 = R.T.dot(np.diag(np.exp(np.log(10.) * rng.uniform(-1, 1, size=8)))).dot(R)
+    train_case('train_tilted8_h24', rng.randn(8) * 0.5, cov8, H=24, T=5, eps=0.1, N=32, seed=38)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rw_t = ref_distributions.RoughWell(6, 0.3, easy=True)
+    train_case('train_rough6_h20', np.zeros(6), None, H=20, T=5, eps=0.1, N=32, seed=39, head_std=0.3, dist=rw_t,
+               params={'energy.kind': 'roughwell', 'energy.eta': np.float32(0.3), 'energy.easy': np.int32(1)},
+               x_start=lambda rng: rng.randn(32, 6))
+
+
 def gaussian_case(name, mu, cov, **kw):
     with contextlib.redirect_stdout(io.StringIO()):
         dist = ref_distributions.Gaussian(np.asarray(mu, dtype=np.float64), np.asarray(cov, dtype=np.float64))
@@ -466,6 +589,10 @@ def main():
         return ais_cases()
     if sys.argv[1:] == ['wide']:                 # only the wide-net fixtures
         return wide_cases()
+    if sys.argv[1:] == ['train_vae']:            # only the VAE sampler-training fixture
+        return train_vae_case('train_vae_small', latent=10, H=24, dec_h=48, n_pix=40, enc_h=32, T=4, eps=0.1, N=32, seed=43)
+    if sys.argv[1:] == ['train_wide']:
+        return train_wide_cases()
     # C1: Strongly-correlated Gaussian 2D, exactly the notebook's target (nb:103-108)
     cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
     gaussian_case('scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=11, x_scale=1.0)

@@ -254,7 +254,11 @@ def _make_module():
 
 def install():
     """Register the stub as `tensorflow` (idempotent) and return the stub module object."""
+    import importlib.machinery
     m = _make_module()
+    # (torch's lazy `torch._dynamo` import probes importlib.util.find_spec('tensorflow'), which raises on a module
+    #  whose __spec__ is None)
+    m.__spec__ = importlib.machinery.ModuleSpec('tensorflow', None)
     sys.modules['tensorflow'] = m
     sys.modules['tensorflow.nn'] = m.nn
     sys.modules['tensorflow.contrib'] = m.contrib

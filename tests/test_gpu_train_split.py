@@ -1,0 +1,145 @@
+"""GPU tests of the GEMM-engine trainer (csrc/train_split.hpp, `l2hmc_train_split_grad`): wide nets on the built-in
+targets, and the image-conditioned VAE sampler of mnist_vae.py (BASELINE.json config 5's "trained sampler")."""
+import numpy as np
+import pytest
+
+from oracle import l2hmc_oracle as O
+from tests.helpers import abs_err, hip_dynamics, load, rel_err, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+TRAJ_TOL = 2e-4     # T steps, fp32 on the GPU vs the float32 reference graph
+P_TOL = 1e-4        # accept probability (north_star)
+
+
+def _trainer(g, force_split=False):
+    import torch
+    from l2hmc_amd.training import SplitTrainer, Trainer
+    dyn = hip_dynamics(g)
+    dyn.eps_override = None
+    with torch.no_grad():
+        dyn.alpha.fill_(float(np.log(g["eps"])))
+    tr = SplitTrainer(dyn) if force_split else Trainer(dyn)
+    assert isinstance(tr, SplitTrainer)
+    return dyn, tr
+
+
+def _check_net_grads(g, dyn, pre="grad.", tol=2e-4):
+    scale = max(float(np.abs(g[pre + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+    worst = 0.0
+    for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
+        for k in O.NET_KEYS:
+            ref = g[pre + "%s.%s" % (n, k)]
+            got = to_np(w[k].grad).reshape(ref.shape)
+            worst = max(worst, float(np.abs(got - ref).max()))
+            assert np.abs(got - ref).max() < tol * scale, (n, k, float(np.abs(got - ref).max()), scale)
+    ga = float(dyn.alpha.grad)
+    assert abs(ga - float(g[pre + "alpha"])) < tol * max(scale, abs(float(g[pre + "alpha"]))), (ga, float(g[pre + "alpha"]))
+    return worst, scale
+
+
+@pytest.mark.parametrize("case,force", [("train_icg50_h32", False), ("train_tilted8_h24", False), ("train_rough6_h20", False),
+                                        ("train_scg2d", True), ("train_tilted8", True), ("train_icg50", True),
+                                        ("train_rough6", True)])
+def test_gemm_engine_training_gradient_matches_reference_graph(case, force):
+    """tf.gradients of the notebook loss from the reference's own graph (SCGExperiment.ipynb raw 156-169) vs the
+    GEMM-engine trainer: the wide-net fixtures (H > 15: `Trainer` picks the engine itself) and, forced onto the engine,
+    the H = 10 fixtures the register-resident kernels are pinned by."""
+    g = load(case)
+    dyn, tr = _trainer(g, force)
+    draws = {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
+             "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
+             "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
+    loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    assert rel_err(to_np(Lx), g["Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["px"]) < P_TOL
+    worst, scale = _check_net_grads(g, dyn)
+    print("%s: loss %.6e  max |dgrad| %.2e (scale %.2e)" % (case, float(loss), worst, scale))
+
+
+def _vae_draws(g):
+    return {"v": np.where(g["prop.dir"][:, None] != 0, g["prop.v_fwd"], g["prop.v_bwd"]), "dir": g["prop.dir"], "u": g["prop.u"]}
+
+
+def test_vae_sampler_gradient_matches_reference_graph():
+    """mnist_vae.py:185-226's sampler loss (MH = 1) differentiated by the reference's own graph vs the HIP trainer:
+    loss, proposal, accept probability, the gradient of every sampler variable incl. the shared image branch
+    (encoder_sampler) and alpha."""
+    g = load("train_vae_small")
+    dyn, tr = _trainer(g)
+    loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(g["log_sigma"]), MH=1, draws=[_vae_draws(g)])
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    assert abs_err(to_np(px), g["px"]) < P_TOL and rel_err(to_np(x_T), g["x_next"]) < TRAJ_TOL
+    worst, scale = _check_net_grads(g, dyn)
+    enc = dyn._xw["aux_encoder"]
+    for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
+        ref = g["grad.enc." + k]
+        got = to_np(enc[k].grad).reshape(ref.shape)
+        assert np.abs(got - ref).max() < 2e-4 * max(float(np.abs(ref).max()), 1e-2 * scale), ("enc", k)
+    print("train_vae_small: loss %.6e  max |dgrad| %.2e (scale %.2e)" % (float(loss), worst, scale))
+
+
+def test_vae_sampler_cotangent_in_and_start_point_gradient_out():
+    """dLx_in / dx0_out of l2hmc_train_split_grad: the reference graph's gradients of loss + sum(final_x * R) w.r.t. the
+    sampler variables and w.r.t. init_x (what chained proposals exchange, mnist_vae.py:185-224)."""
+    import torch
+    g = load("train_vae_small")
+    dyn, tr = _trainer(g)
+    dr = _vae_draws(g)
+    N, d = g["x"].shape
+    wgt = (1.0 / (torch.exp(2.0 * to_dev(g["log_sigma"])) + 1e-4)).contiguous()
+    for pre, R in (("grad.", None), ("grad2.", to_dev(g["R"]))):
+        tr.flat.zero_()
+        dx0 = torch.empty((N, d), dtype=torch.float32, device="cuda")
+        tr._propose_grad(to_dev(g["x"]), to_dev(dr["v"]), to_dev(dr["dir"]), N, aux=to_dev(g["aux"]), dist_weight=wgt,
+                         dLx_in=R, dx0_out=dx0)
+        tr._publish_grads()
+        _check_net_grads(g, dyn, pre)
+        ref = g[pre + "x0"]
+        assert np.abs(to_np(dx0) - ref).max() < 2e-4 * float(np.abs(ref).max()), pre
+
+
+@pytest.mark.parametrize("stop", [False, True])
+def test_vae_sampler_chained_proposals_match_the_autograd_oracle(stop):
+    """MH = 3 proposals chained through MH selects (mnist_vae.py:185-224) with and without stop_gradient: the trainer's
+    reverse sweep over the chain vs torch autograd of the float64 CPU restatement (oracle/vae_train_oracle.py, itself
+    pinned by the reference-graph fixture)."""
+    from oracle import vae_train_oracle as V
+    g = load("train_vae_small")
+    dyn, tr = _trainer(g)
+    N, d = g["x"].shape
+    rng = np.random.RandomState(3)
+    od, hd = [], []
+    for t in range(3):
+        dr = {"v_fwd": rng.randn(N, d).astype(np.float32), "v_bwd": rng.randn(N, d).astype(np.float32),
+              "dir": rng.randint(0, 2, size=N).astype(np.uint8), "u": rng.rand(N).astype(np.float32)}
+        od.append(dr)
+        hd.append({"v": np.where(dr["dir"][:, None] != 0, dr["v_fwd"], dr["v_bwd"]), "dir": dr["dir"], "u": dr["u"]})
+    o = V.sampler_loss_and_grad(g, od, MH=3, stop_gradient=stop)
+    loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(g["log_sigma"]), MH=3,
+                                             stop_gradient=stop, draws=hd)
+    assert abs(float(loss) - o["loss"]) < 2e-4 * max(1.0, abs(o["loss"]))
+    assert rel_err(to_np(x_T), o["x_next"]) < 5e-4
+    gg = {"grad." + k[5:]: v for k, v in o.items() if k.startswith("grad.")}
+    _check_net_grads(gg, dyn, tol=5e-4)
+
+
+def test_gemm_engine_gradient_is_bitwise_reproducible_and_shards_add_up():
+    """no atomics: two runs give identical bits; per-shard gradients with inv_n = 1 / (global count) sum to the full one"""
+    import torch
+    g = load("train_vae_small")
+    dyn, tr = _trainer(g)
+    dr = _vae_draws(g)
+    N = g["x"].shape[0]
+    x, v, db, aux = to_dev(g["x"]), to_dev(dr["v"]), to_dev(dr["dir"]), to_dev(g["aux"])
+    wgt = (1.0 / (torch.exp(2.0 * to_dev(g["log_sigma"])) + 1e-4)).contiguous()
+    runs = []
+    for _ in range(2):
+        tr.flat.zero_()
+        tr._propose_grad(x, v, db, N, aux=aux, dist_weight=wgt)
+        runs.append(tr.flat.clone())
+    assert torch.equal(runs[0], runs[1])
+    tr.flat.zero_()
+    h = N // 2 + 3
+    tr._propose_grad(x[:h].contiguous(), v[:h].contiguous(), db[:h].contiguous(), N, aux=aux[:h].contiguous(), dist_weight=wgt[:h].contiguous())
+    tr._propose_grad(x[h:].contiguous(), v[h:].contiguous(), db[h:].contiguous(), N, aux=aux[h:].contiguous(), dist_weight=wgt[h:].contiguous())
+    assert float((tr.flat - runs[0]).abs().max()) < 2e-5 * float(runs[0].abs().max())

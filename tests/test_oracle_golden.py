@@ -159,7 +159,8 @@ def test_philox_draws_are_sharding_invariant_and_standard():
     assert 0 <= ub.min() and ub.max() < 1 and abs(ub.mean() - 0.5) < 0.01
 
 
-@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6", "train_funnel3"])
+@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6", "train_funnel3",
+                                  "train_icg50_h32", "train_tilted8_h24", "train_rough6_h20"])
 def test_training_gradient_oracle_matches_reference_graph(case):
     """oracle/l2hmc_train_oracle.py (hand-derived reverse mode incl. the Hessian-vector path)
     vs tf.gradients of the notebook loss evaluated by the reference's own graph (stub)."""
@@ -169,12 +170,36 @@ def test_training_gradient_oracle_matches_reference_graph(case):
     assert abs(loss - float(g["loss"])) < 2e-5 * max(1.0, abs(float(g["loss"])))
     assert rel_err(out["Lx"], g["Lx"]) < TRAJ_TOL and abs_err(out["px"], g["px"]) < P_TOL
     scale = max(float(np.abs(g["grad." + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+    # (the fixtures are float32 outputs; on the ill-conditioned d = 50 target with 32-wide nets the reference graph's own
+    #  rounding is 8e-5 of the gradient scale against this float64 restatement)
+    tol = 2e-4 if case == "train_icg50_h32" else 2e-5
     for n in ("xnet", "vnet"):
         for k in O.NET_KEYS:
             ref = g["grad.%s.%s" % (n, k)]
             got = np.asarray(out[n + "." + k]).reshape(ref.shape)
-            assert np.abs(got - ref).max() < 2e-5 * scale, (case, n, k)
-    assert abs(out["alpha"] - float(g["grad.alpha"])) < 2e-5 * max(scale, abs(float(g["grad.alpha"])))
+            assert np.abs(got - ref).max() < tol * scale, (case, n, k)
+    assert abs(out["alpha"] - float(g["grad.alpha"])) < tol * max(scale, abs(float(g["grad.alpha"])))
+
+
+def test_vae_sampler_objective_oracle_matches_reference_graph():
+    """oracle/vae_train_oracle.py (torch-CPU restatement of mnist_vae.py:185-226's sampler loss, float64, autograd)
+    vs tf.gradients of the reference's own graph: every sampler variable (XNet, VNet, the image branch, alpha), the
+    start point, and the variant with a cotangent R on the proposal."""
+    from oracle import vae_train_oracle as V
+    g = load("train_vae_small")
+    dr = [{"v_fwd": g["prop.v_fwd"], "v_bwd": g["prop.v_bwd"], "dir": g["prop.dir"], "u": g["prop.u"]}]
+    for pre, R in (("grad.", None), ("grad2.", g["R"])):
+        o = V.sampler_loss_and_grad(g, dr, MH=1, R=R)
+        if R is None:
+            assert abs(o["loss"] - float(g["loss"])) < 2e-5 * max(1.0, abs(float(g["loss"])))
+            assert rel_err(o["Lx"], g["Lx"]) < TRAJ_TOL and abs_err(o["px"], g["px"]) < P_TOL
+            assert rel_err(o["x_next"], g["x_next"]) < TRAJ_TOL
+        keys = [k[len(pre):] for k in g if k.startswith(pre)]
+        assert len(keys) == 2 * 16 + 6 + 2
+        for k in keys:
+            ref = g[pre + k]
+            got = np.asarray(o["grad." + k]).reshape(ref.shape)
+            assert np.abs(got - ref).max() < 2e-5 * max(float(np.abs(ref).max()), 1e-3), (pre, k)
 
 
 def test_vae_aux_branch_matches_reference_layers():
