@@ -477,13 +477,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
     }
 }
 
-// dst[i][j] (+)= sum_z part[z][i][j], z ascending (fixed order)
-__global__ void tn_reduce_kernel(const float* part, int n_chunks, int I, int J, float* dst, int ldd, int accumulate) {
+// dst (+)= sum_z part[z][i][j], z ascending (fixed order).  The (I x J) result may be a stack of row blocks and / or
+// column blocks that live apart in the destination (e.g. [W1; W2] of a net, or [Ws | Wt | Wq]):
+//   element (i, j) -> dst[(i / iblock) * istride + (j / jblock) * jstride + (i % iblock) * ldd + (j % jblock)]
+struct TnScatter { int iblock; long long istride; int jblock; long long jstride; };
+__global__ void tn_reduce_kernel(const float* part, int n_chunks, int I, int J, float* dst, int ldd, int accumulate,
+                                 TnScatter sc) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long long)I * J) return;
   float s = 0.f;
   for (int z = 0; z < n_chunks; ++z) s += part[(long long)z * I * J + e];
-  float* o = dst + (e / J) * ldd + (e % J);
+  const int i = (int)(e / J), j = (int)(e % J);
+  float* o = dst + (long long)(i / sc.iblock) * sc.istride + (long long)(j / sc.jblock) * sc.jstride +
+             (long long)(i % sc.iblock) * ldd + (j % sc.jblock);
   *o = accumulate ? *o + s : s;
 }
 
@@ -501,8 +507,10 @@ inline void tn_chunks(long long R, long long IJ, long long part_cap, int& n_chun
 
 // dst (I x J, row stride ldd) (+)= A^T B; `part` holds at least part_cap floats (>= I * J)
 inline void launch_gemm_tn(hipStream_t s, const float* A, int lda, const float* B, int ldb, long long R, int I, int J,
-                           float* dst, int ldd, int accumulate, float* part, long long part_cap) {
+                           float* dst, int ldd, int accumulate, float* part, long long part_cap,
+                           const TnScatter* scatter = nullptr) {
   if (I <= 0 || J <= 0) return;
+  const TnScatter sc = scatter ? *scatter : TnScatter{I, 0, J, 0};
   GemmTnArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.R = R; g.I = I; g.J = J; g.part = part;
   int nc;
@@ -512,7 +520,7 @@ inline void launch_gemm_tn(hipStream_t s, const float* A, int lda, const float* 
   if (v4) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, s, g);
   const long long n = (long long)I * J;
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nc, I, J, dst, ldd, accumulate);
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nc, I, J, dst, ldd, accumulate, sc);
 }
 
 // rowsum layout of EPI_BCE: (M, 2 * n_tiles) with n_tiles = ceil(N / (32 WNB)) of the shape the launcher picks

@@ -145,16 +145,19 @@ __global__ void k_comb_x(const float* dAB, float* dvh, float* tgt, const float* 
   tgt[i] += (second ? 1.f - k1 : k1) * dAB[n * 2 * d + d + k];
 }
 // VNet evaluation at (x, grad U(x)):  u = dg + d b  is the vector of the Hessian-vector product ...
-__global__ void k_comb_v1(const float* dg, const float* dAB, float* u, long long N, int d) {
+// (+ the vector parked by the point's other VNet evaluation, see through_grad)
+__global__ void k_comb_v1(const float* dg, const float* dAB, const float* carry, float* u, long long N, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * d) return;
-  u[i] = dg[i] + dAB[(i / d) * 2 * d + d + (i % d)];
+  float a = dg[i] + dAB[(i / d) * 2 * d + d + (i % d)];
+  if (carry != nullptr) a += carry[i];
+  u[i] = a;
 }
 // ... and  lx += d a + Hessian(x) u
 __global__ void k_comb_v2(float* lx, const float* dAB, const float* hv, long long N, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * d) return;
-  lx[i] += dAB[(i / d) * 2 * d + (i % d)] + hv[i];
+  lx[i] += dAB[(i / d) * 2 * d + (i % d)] + (hv != nullptr ? hv[i] : 0.f);
 }
 
 // Hessian-vector products of the built-in targets (oracle/l2hmc_train_oracle.py *Target.hessvec): diagonal Gaussian
@@ -323,13 +326,39 @@ __global__ void k_heads_side(const float* Ws, const float* Wt, const float* Wq, 
   out[i] = W[(long long)h * d + k];
 }
 
-inline void colsum_into(hipStream_t s, const float* A, int lda, long long R, int cols, float* dst, float* part,
-                        long long part_cap) {
+// column sums of A (R x cols) into up to three destinations (b1, b2, b3 of a net receive the same sum) or, with
+// jblock > 0, scattered in column blocks of jblock to dst0 + block * jstride (the three head biases, the two log-scales)
+__global__ void colsum_reduce_kernel(const float* part, int n_chunks, int cols, float* dst0, float* dst1, float* dst2,
+                                     int jblock, long long jstride) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  float s = 0.f;
+  for (int z = 0; z < n_chunks; ++z) s += part[(long long)z * cols + j];
+  if (jblock > 0) {
+    dst0[(long long)(j / jblock) * jstride + (j % jblock)] += s;
+  } else {
+    dst0[j] += s;
+    if (dst1 != nullptr) dst1[j] += s;
+    if (dst2 != nullptr) dst2[j] += s;
+  }
+}
+inline void colsum_chunks(long long R, int cols, long long part_cap, int& nc, long long& rpc) {
+  long long n = (R + 255) / 256;                       // many small chunks: this is a streaming read, fill the chip
+  if (n > 1024) n = 1024;
+  if (n * cols > part_cap) n = part_cap / cols;
+  if (n < 1) n = 1;
+  rpc = ((R + n - 1) / n + 3) / 4 * 4;
+  nc = (int)((R + rpc - 1) / rpc);
+  if (nc < 1) nc = 1;
+}
+inline void colsum_into(hipStream_t s, const float* A, int lda, long long R, int cols, float* dst0, float* dst1, float* dst2,
+                        int jblock, long long jstride, float* part, long long part_cap) {
   int nc;
   long long rpc;
-  tn_chunks(R, cols, part_cap, nc, rpc);
+  colsum_chunks(R, cols, part_cap, nc, rpc);
   hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)((cols + 63) / 64), (unsigned)nc), dim3(256), 0, s, A, lda, R, cols, rpc, part);
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, part, nc, 1, cols, dst, cols, 1);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, part, nc, cols, dst0, dst1, dst2,
+                     jblock, jstride);
 }
 
 struct TrainSplitPlan {
@@ -343,7 +372,10 @@ struct TrainSplitPlan {
   long long w12c[2], whc[2];                        // stacked / side-by-side weight copies per net
   long long part;                                   // chunk partials of the TN products and column sums
   long long part_cap;
-  long long B2, B1, HD1, HD2, M1, M2, rd, RD;       // decoder Hessian-vector product
+  long long HD1, HD2, M1, M2, RD;                   // decoder Hessian-vector product: tangents
+  long long PS1, PS2, PRD, PB2, PB1;                // ... and, per trajectory point (T + 1 of them), the decoder's
+                                                    // sigmoids, sigma' of the logits and the raw reverse products
+  long long carry;                                  // Hessian-vector input carried to the same point's other use
   long long dauxh, es1, es2, de2, de1;              // image branch reverse pass
   long long xq;                                     // contiguous copy of a point (built-in Hessians)
 };
@@ -362,7 +394,7 @@ inline TrainSplitPlan plan_train_split(long long N, int d, int H, int T, const L
   }
   p.VS = take((T + 1) * N * d); p.YS = take((long long)T * N * d);
   p.lx = take(N * d); p.lv = take(N * d); p.dvh = take(N * d); p.dz = take(N * d); p.dg = take(N * d);
-  p.u = take(N * d); p.hv = take(N * d); p.dAB = take(N * 2 * d);
+  p.u = take(N * d); p.hv = take(N * d); p.dAB = take(N * 2 * d); p.carry = take(N * d);
   p.lam = take(N); p.dv1p = take(N); p.deps = take(N);
   long long big = (long long)H * H;
   if ((long long)2 * d * H > big) big = 2LL * d * H;
@@ -373,14 +405,17 @@ inline TrainSplitPlan plan_train_split(long long N, int d, int H, int T, const L
     if ((long long)enc->n_h2 * enc->n_out > big) big = (long long)enc->n_h2 * enc->n_out;
   }
   p.part_cap = 16 * big;                            // up to 16 row chunks of the largest product (>= 64 of the others)
-  if (p.part_cap < 64LL * 4096) p.part_cap = 64LL * 4096;
+  if (p.part_cap < (1LL << 20)) p.part_cap = 1LL << 20;
   p.part = take(p.part_cap);
   if (dec) {
-    p.B2 = take(N * dec->n_h2); p.B1 = take(N * dec->n_h1); p.HD1 = take(N * dec->n_h1); p.HD2 = take(N * dec->n_h2);
-    p.M1 = take(N * dec->n_h1); p.M2 = take(N * dec->n_h2); p.rd = take(N * dec->n_out); p.RD = take(N * dec->n_out);
+    p.HD1 = take(N * dec->n_h1); p.HD2 = take(N * dec->n_h2);
+    p.M1 = take(N * dec->n_h1); p.M2 = take(N * dec->n_h2); p.RD = take(N * dec->n_out);
+    const long long P = T + 1;
+    p.PS1 = take(P * N * dec->n_h1); p.PS2 = take(P * N * dec->n_h2); p.PRD = take(P * N * dec->n_out);
+    p.PB2 = take(P * N * dec->n_h2); p.PB1 = take(P * N * dec->n_h1);
     p.xq = 0;
   } else {
-    p.B2 = p.B1 = p.HD1 = p.HD2 = p.M1 = p.M2 = p.rd = p.RD = 0;
+    p.HD1 = p.HD2 = p.M1 = p.M2 = p.RD = p.PS1 = p.PS2 = p.PRD = p.PB2 = p.PB1 = 0;
     p.xq = take(N * d);
   }
   if (enc) {
@@ -393,42 +428,56 @@ inline TrainSplitPlan plan_train_split(long long N, int d, int H, int T, const L
   return p;
 }
 
-// hv = Hessian(z) u of the decoder posterior U(z) = sum_pix BCE(aux, dec(z)) + |z|^2 / 2 (mnist_vae.py:122-126).
-// Forward-over-reverse: with p_i the pre-activations, s_i = sigmoid(p_i) (= softplus'), r = sigmoid(logit) - aux and the
-// reverse pass b2 = r W3^T, c2 = s2 b2, b1 = c2 W2^T, c1 = s1 b1, grad = c1 W1^T + z, the directional derivative along u
-//   p1. = u W1,  h1. = s1 p1.,  p2. = h1. W2,  h2. = s2 p2.,  l. = h2. W3,  r. = sigma' l.
-//   c2. = s2 (1 - s2) p2. b2 + s2 (r. W3^T),   c1. = s1 (1 - s1) p1. b1 + s1 (c2. W2^T),   H u = u + c1. W1^T.
-void vae_hvp(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, int ldz, long long N, int d,
-             const Mlp3Ws& ws, float* lg, float* rowsum, const TrainSplitPlan& p, float* w, const float* u, float* hv) {
-  // the point's activations: s1, s2, r (as vae_energy), and the raw reverse products b2, b1
+// The decoder's share of one trajectory point, kept for the reverse sweep: s1, s2 (sigmoids = softplus'), sigma' of the
+// logits, and the raw reverse products b2 = r W3^T, b1 = c2 W2^T (r = sigmoid(logit) - aux, c2 = s2 b2)
+struct DecPoint { float *s1, *s2, *rd, *b2, *b1; };
+
+// vae_energy (U, grad U at z) that leaves the point's DecPoint behind
+void vae_energy_keep(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, int ldz, long long N, int d,
+                     const Mlp3Ws& ws0, float* lg, float* rowsum, double* Ud, float* grad, int ldg, const DecPoint& pt) {
+  Mlp3Ws ws = ws0;
+  ws.s1 = pt.s1; ws.s2 = pt.s2;
   mlp3_hidden(s, dec, z, ldz, N, ws);
   GemmArgs g = gemm_args(ws.a2, dec.n_h2, ws.w3t, dec.n_h2, lg, dec.n_out, N, dec.n_out, dec.n_h2);
   g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(dec.n_out); g.beta = 1.f;
   launch_gemm<EPI_BCE>(g, s);
+  if (Ud != nullptr)
+    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles(dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
   const long long npix = N * dec.n_out;
-  hipLaunchKernelGGL(k_sigd, dim3(nblk(npix)), dim3(256), 0, s, lg, aux, w + p.rd, npix);
+  hipLaunchKernelGGL(k_sigd, dim3(nblk(npix)), dim3(256), 0, s, lg, aux, pt.rd, npix);
   g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);
-  g.E = ws.s2; g.lde = dec.n_h2; g.C2 = w + p.B2; g.ldc2 = dec.n_h2;
+  g.E = pt.s2; g.lde = dec.n_h2; g.C2 = pt.b2; g.ldc2 = dec.n_h2;
   launch_gemm<EPI_MUL>(g, s);
   g = gemm_args(ws.a2, dec.n_h2, dec.W2, dec.n_h2, ws.a1, dec.n_h1, N, dec.n_h1, dec.n_h2);
-  g.E = ws.s1; g.lde = dec.n_h1; g.C2 = w + p.B1; g.ldc2 = dec.n_h1;
+  g.E = pt.s1; g.lde = dec.n_h1; g.C2 = pt.b1; g.ldc2 = dec.n_h1;
   launch_gemm<EPI_MUL>(g, s);
-  // tangent forward
-  g = gemm_args(u, d, ws.w1t, dec.n_in, w + p.HD1, dec.n_h1, N, dec.n_h1, dec.n_in);
-  g.E = ws.s1; g.lde = dec.n_h1; g.E2 = w + p.B1; g.lde2 = dec.n_h1; g.C2 = w + p.M1; g.ldc2 = dec.n_h1;
+  g = gemm_args(ws.a1, dec.n_h1, dec.W1, dec.n_h1, grad, ldg, N, d, dec.n_h1);
+  g.E = z; g.lde = ldz;
+  launch_gemm<EPI_ADD>(g, s, d <= 64 ? SHAPE_SKINNY : SHAPE_MID);
+}
+
+// hv = Hessian(z) u of the decoder posterior U(z) = sum_pix BCE(aux, dec(z)) + |z|^2 / 2 (mnist_vae.py:122-126) from the
+// point's DecPoint.  Forward-over-reverse: with the reverse pass b2 = r W3^T, c2 = s2 b2, b1 = c2 W2^T, c1 = s1 b1,
+// grad = c1 W1^T + z, the directional derivative along u is
+//   p1. = u W1,  h1. = s1 p1.,  p2. = h1. W2,  h2. = s2 p2.,  l. = h2. W3,  r. = sigma' l.
+//   c2. = s2 (1 - s2) p2. b2 + s2 (r. W3^T),   c1. = s1 (1 - s1) p1. b1 + s1 (c2. W2^T),   H u = u + c1. W1^T:
+// three tangent GEMMs and three reverse-tangent GEMMs, the softplus'' terms in their epilogues.
+void vae_hvp(hipStream_t s, const L2hmcMlp3& dec, long long N, int d, const Mlp3Ws& ws, const DecPoint& pt,
+             const TrainSplitPlan& p, float* w, const float* u, float* hv) {
+  GemmArgs g = gemm_args(u, d, ws.w1t, dec.n_in, w + p.HD1, dec.n_h1, N, dec.n_h1, dec.n_in);
+  g.E = pt.s1; g.lde = dec.n_h1; g.E2 = pt.b1; g.lde2 = dec.n_h1; g.C2 = w + p.M1; g.ldc2 = dec.n_h1;
   launch_gemm<EPI_TAN>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_BIG);
   g = gemm_args(w + p.HD1, dec.n_h1, ws.w2t, dec.n_h1, w + p.HD2, dec.n_h2, N, dec.n_h2, dec.n_h1);
-  g.E = ws.s2; g.lde = dec.n_h2; g.E2 = w + p.B2; g.lde2 = dec.n_h2; g.C2 = w + p.M2; g.ldc2 = dec.n_h2;
+  g.E = pt.s2; g.lde = dec.n_h2; g.E2 = pt.b2; g.lde2 = dec.n_h2; g.C2 = w + p.M2; g.ldc2 = dec.n_h2;
   launch_gemm<EPI_TAN>(g, s);
   g = gemm_args(w + p.HD2, dec.n_h2, ws.w3t, dec.n_h2, w + p.RD, dec.n_out, N, dec.n_out, dec.n_h2);
-  g.E = w + p.rd; g.lde = dec.n_out;
+  g.E = pt.rd; g.lde = dec.n_out;
   launch_gemm<EPI_MUL>(g, s);
-  // tangent of the reverse pass
   g = gemm_args(w + p.RD, dec.n_out, dec.W3, dec.n_out, w + p.M2, dec.n_h2, N, dec.n_h2, dec.n_out);
-  g.E = ws.s2; g.lde = dec.n_h2; g.accum = 1;
+  g.E = pt.s2; g.lde = dec.n_h2; g.accum = 1;
   launch_gemm<EPI_MUL>(g, s);
   g = gemm_args(w + p.M2, dec.n_h2, dec.W2, dec.n_h2, w + p.M1, dec.n_h1, N, dec.n_h1, dec.n_h2);
-  g.E = ws.s1; g.lde = dec.n_h1; g.accum = 1;
+  g.E = pt.s1; g.lde = dec.n_h1; g.accum = 1;
   launch_gemm<EPI_MUL>(g, s);
   g = gemm_args(w + p.M1, dec.n_h1, dec.W1, dec.n_h1, hv, d, N, d, dec.n_h1);
   g.E = u; g.lde = d;
@@ -542,10 +591,20 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
                        w + p.whc[i]);
   }
 
-  // U (double, optional) and grad U at the point in columns [0, d) of `ab` -> columns [d, 2 d)
-  auto energy_eval = [&](float* ab, double* Ud) -> int {
+  // trajectory point j = 0 .. T (the start point and the position after each leapfrog step)
+  auto dec_point = [&](int j) {
+    DecPoint pt = {};
     if (!builtin) {
-      vae_energy(s, dec, a->aux, ab, L, N, d, dws, w + f.lg, w + f.rowsum, nullptr, Ud, ab + d, L, 1.f);
+      pt.s1 = w + p.PS1 + (long long)j * N * dec.n_h1; pt.s2 = w + p.PS2 + (long long)j * N * dec.n_h2;
+      pt.rd = w + p.PRD + (long long)j * N * dec.n_out;
+      pt.b2 = w + p.PB2 + (long long)j * N * dec.n_h2; pt.b1 = w + p.PB1 + (long long)j * N * dec.n_h1;
+    }
+    return pt;
+  };
+  // U (double, optional) and grad U at point j, held in columns [0, d) of `ab` -> columns [d, 2 d)
+  auto energy_eval = [&](float* ab, int j, double* Ud) -> int {
+    if (!builtin) {
+      vae_energy_keep(s, dec, a->aux, ab, L, N, d, dws, w + f.lg, w + f.rowsum, Ud, ab + d, L, dec_point(j));
       return L2HMC_OK;
     }
     (void)hipMemcpy2DAsync(w + f.xp, sizeof(float) * d, ab, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
@@ -582,7 +641,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   (void)hipMemcpy2DAsync(AB(1, 0), sizeof(float) * L, a->x, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
   (void)hipMemcpyAsync(VS(0), a->v, sizeof(float) * Nd, hipMemcpyDeviceToDevice, s);
   hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, VS(0), w + f.K0, ld, N, d);
-  if ((rc = energy_eval(AB(1, 0), U0d))) return rc;
+  if ((rc = energy_eval(AB(1, 0), 0, U0d))) return rc;
   for (int it = 0; it < T; ++it) {
     const bool last = it == T - 1;
     float *abv0 = AB(1, 2 * it), *abv1 = AB(1, 2 * it + 1), *abx0 = AB(0, 2 * it), *abx1 = AB(0, 2 * it + 1);
@@ -597,7 +656,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     net_fwd(0, 2 * it + 1, it);
     hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it + 1), xn, YS(it), d, abx0, L, abv1, L, (float*)nullptr, 0,
                        ld, a->masks, dir, dall, it, T, 1, a->alpha, a->eps_host, N, d);
-    if ((rc = energy_eval(abv1, last ? U1d : nullptr))) return rc;
+    if ((rc = energy_eval(abv1, it + 1, last ? U1d : nullptr))) return rc;
     net_fwd(1, 2 * it + 1, it);
     hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it + 1), vn, abx0, L, abv1 + d, L, VS(it + 1), d, ld, dir,
                        dall, a->alpha, a->eps_host, N, d);
@@ -612,11 +671,24 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     hipLaunchKernelGGL(k_train_seed, dim3(nw4), dim3(256), 0, s, a->x, abe, L, VS(T), abe + d, L, U0d, U1d, w + f.K0, ld,
                        a->dist_weight, a->dLx_in, a->scale, a->inv_n, a->Lx, a->p, a->v1, lam, dv1p, lx, lv, deps, N, d);
   }
-  // lx += d a + Hessian(x) (dg + d b) for the VNet evaluation at the point in `ab`
-  auto through_grad = [&](float* ab) -> int {
-    hipLaunchKernelGGL(k_comb_v1, dim3(nblk(Nd)), dim3(256), 0, s, dg, dAB, uu, N, d);
+  // VNet evaluation at trajectory point j (inputs (x, grad U(x)) in `ab`):  lx += d a + Hessian(x) (dg + d b).
+  // Every interior point is the input of TWO VNet evaluations (the end of one leapfrog step and the start of the next,
+  // at different times) whose Hessian-vector products add into the same lx before anything reads it: the later one in
+  // the sweep (`defer`) only adds d a and parks its vector in `carry`, the earlier one multiplies the sum -- T + 1
+  // Hessian-vector products per trajectory instead of 2 T.
+  float* carry = w + p.carry;
+  bool have_carry = false;
+  auto through_grad = [&](float* ab, int j, bool defer) -> int {
+    hipLaunchKernelGGL(k_comb_v1, dim3(nblk(Nd)), dim3(256), 0, s, dg, dAB, have_carry ? carry : (const float*)nullptr,
+                       defer ? carry : uu, N, d);
+    if (defer) {
+      hipLaunchKernelGGL(k_comb_v2, dim3(nblk(Nd)), dim3(256), 0, s, lx, dAB, (const float*)nullptr, N, d);
+      have_carry = true;
+      return L2HMC_OK;
+    }
+    have_carry = false;
     if (!builtin) {
-      vae_hvp(s, dec, a->aux, ab, L, N, d, dws, w + f.lg, w + f.rowsum, p, w, uu, hv);
+      vae_hvp(s, dec, N, d, dws, dec_point(j), p, w, uu, hv);
     } else {
       hipLaunchKernelGGL(k_hvp_builtin, dim3(nblk(Nd)), dim3(256), 0, s, a->energy->kind, ab, L, uu, hv, a->energy->prec,
                          a->hess, a->energy->eta, a->energy->easy, N, d);
@@ -632,7 +704,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     hipLaunchKernelGGL(k_tv_half_bwd, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it + 1), vn, abx0, L, abv1 + d, L, lv, dvh, dg,
                        DL(1, 2 * it + 1), lam, deps, dir, dall, a->alpha, a->eps_host, N, d);
     net_bwd(1, 2 * it + 1);
-    if ((rc = through_grad(abv1))) return rc;                       // lx = d x'
+    if ((rc = through_grad(abv1, it + 1, false))) return rc;        // lx = d x'
     // (2) x' = x_half(y, 1 - k1; vh, X(vh, (1 - k1) y))
     hipLaunchKernelGGL(k_tx_half_bwd, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it + 1), xn, YS(it), d, abx0, L, lx, dz, dvh,
                        DL(0, 2 * it + 1), lam, deps, a->masks, dir, dall, it, T, 1, a->alpha, a->eps_host, N, d);
@@ -647,7 +719,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     hipLaunchKernelGGL(k_tv_half_bwd, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it), vn, VS(it), d, abv0 + d, L, dvh, lv, dg,
                        DL(1, 2 * it), lam, deps, dir, dall, a->alpha, a->eps_host, N, d);
     net_bwd(1, 2 * it);
-    if ((rc = through_grad(abv0))) return rc;
+    if ((rc = through_grad(abv0, it, it > 0))) return rc;
   }
   if (a->dx0_out) {
     const float* ab0 = AB(1, 0);
@@ -663,28 +735,25 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     float* G = a->grad + (long long)net * o.total;
     const float *ab = w + p.AB[net], *h1 = w + p.H1[net], *h2 = w + p.H2[net], *dzs = w + p.O3[net];
     const float *da2 = w + p.DA2[net], *da1 = w + p.DA1[net], *dl = w + p.DL[net];
-    launch_gemm_tn(s, ab, L, da1, H, R, d, H, G + o.W1, H, 1, part, p.part_cap);
-    launch_gemm_tn(s, ab + d, L, da1, H, R, d, H, G + o.W2, H, 1, part, p.part_cap);
+    // [W1; W2] = [a | b]^T d h1: one product, the two row blocks land d H + H apart (b1 lies between them)
+    const TnScatter sc12 = {d, o.W2 - o.W1, H, 0};
+    launch_gemm_tn(s, ab, L, da1, H, R, L, H, G + o.W1, H, 1, part, p.part_cap, &sc12);
     launch_gemm_tn(s, h1, H, da2, H, R, H, H, G + o.W4, H, 1, part, p.part_cap);
-    launch_gemm_tn(s, h2, H, dzs, 3 * d, R, H, d, G + o.Ws, d, 1, part, p.part_cap);
-    launch_gemm_tn(s, h2, H, dzs + d, 3 * d, R, H, d, G + o.Wt, d, 1, part, p.part_cap);
-    launch_gemm_tn(s, h2, H, dzs + 2 * d, 3 * d, R, H, d, G + o.Wq, d, 1, part, p.part_cap);
-    colsum_into(s, da1, H, R, H, G + o.b1, part, p.part_cap);          // b1, b2, b3 enter the same sum
-    colsum_into(s, da1, H, R, H, G + o.b2, part, p.part_cap);
-    colsum_into(s, da1, H, R, H, G + o.b3, part, p.part_cap);
-    colsum_into(s, da2, H, R, H, G + o.b4, part, p.part_cap);
-    colsum_into(s, dzs, 3 * d, R, d, G + o.bs, part, p.part_cap);
-    colsum_into(s, dzs + d, 3 * d, R, d, G + o.bt, part, p.part_cap);
-    colsum_into(s, dzs + 2 * d, 3 * d, R, d, G + o.bq, part, p.part_cap);
-    colsum_into(s, dl, L, R, d, G + o.ls, part, p.part_cap);
-    colsum_into(s, dl + d, L, R, d, G + o.lq, part, p.part_cap);
+    // [Ws | Wt | Wq] = h2^T (d zs | d zt | d zq): one product, three column blocks
+    const TnScatter sch = {H, 0, d, o.Wt - o.Ws};
+    launch_gemm_tn(s, h2, H, dzs, 3 * d, R, H, 3 * d, G + o.Ws, d, 1, part, p.part_cap, &sch);
+    colsum_into(s, da1, H, R, H, G + o.b1, G + o.b2, G + o.b3, 0, 0, part, p.part_cap);   // b1, b2, b3 enter the same sum
+    colsum_into(s, da2, H, R, H, G + o.b4, nullptr, nullptr, 0, 0, part, p.part_cap);
+    colsum_into(s, dzs, 3 * d, R, 3 * d, G + o.bs, nullptr, nullptr, d, o.bt - o.bs, part, p.part_cap);
+    colsum_into(s, dl, L, R, L, G + o.ls, nullptr, nullptr, d, o.lq - o.ls, part, p.part_cap);
     {
       int nc;
       long long rpc;
-      tn_chunks(R, 2LL * H, p.part_cap, nc, rpc);
+      colsum_chunks(R, 2 * H, p.part_cap, nc, rpc);
       hipLaunchKernelGGL(k_w3_part, dim3((unsigned)((H + 63) / 64), (unsigned)nc), dim3(256), 0, s, da1, H, N, R, rpc, a->trig, T,
                          dir, dall, part);
-      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((2 * H + 255) / 256)), dim3(256), 0, s, part, nc, 2, H, G + o.W3, H, 1);
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((2 * H + 255) / 256)), dim3(256), 0, s, part, nc, 2, H, G + o.W3, H, 1,
+                         TnScatter{2, 0, H, 0});
     }
   }
   hipLaunchKernelGGL(k_sum_chain, dim3(1), dim3(256), 0, s, deps, N, a->grad + 2 * o.total);
@@ -703,11 +772,11 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     ga.E = ews.s1; ga.lde = enc.n_h1;
     launch_gemm<EPI_MUL>(ga, s, SHAPE_MID);
     launch_gemm_tn(s, ews.a2, enc.n_h2, dauxh, H, N, enc.n_h2, enc.n_out, G + oW3, enc.n_out, 1, part, p.part_cap);
-    colsum_into(s, dauxh, H, N, enc.n_out, G + ob3, part, p.part_cap);
+    colsum_into(s, dauxh, H, N, enc.n_out, G + ob3, nullptr, nullptr, 0, 0, part, p.part_cap);
     launch_gemm_tn(s, ews.a1, enc.n_h1, de2, enc.n_h2, N, enc.n_h1, enc.n_h2, G + oW2, enc.n_h2, 1, part, p.part_cap);
-    colsum_into(s, de2, enc.n_h2, N, enc.n_h2, G + ob2, part, p.part_cap);
+    colsum_into(s, de2, enc.n_h2, N, enc.n_h2, G + ob2, nullptr, nullptr, 0, 0, part, p.part_cap);
     launch_gemm_tn(s, a->aux, enc.n_in, de1, enc.n_h1, N, enc.n_in, enc.n_h1, G + oW1, enc.n_h1, 1, part, p.part_cap);
-    colsum_into(s, de1, enc.n_h1, N, enc.n_h1, G + ob1, part, p.part_cap);
+    colsum_into(s, de1, enc.n_h1, N, enc.n_h1, G + ob1, nullptr, nullptr, 0, 0, part, p.part_cap);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));

@@ -143,3 +143,30 @@ def test_gemm_engine_gradient_is_bitwise_reproducible_and_shards_add_up():
     tr._propose_grad(x[:h].contiguous(), v[:h].contiguous(), db[:h].contiguous(), N, aux=aux[:h].contiguous(), dist_weight=wgt[:h].contiguous())
     tr._propose_grad(x[h:].contiguous(), v[h:].contiguous(), db[h:].contiguous(), N, aux=aux[h:].contiguous(), dist_weight=wgt[h:].contiguous())
     assert float((tr.flat - runs[0]).abs().max()) < 2e-5 * float(runs[0].abs().max())
+
+
+def test_vae_sampler_gradient_at_config5_widths_matches_the_autograd_oracle():
+    """the layer widths of BASELINE.json config 5 (latent 50, H = 200, decoder 1024, 784 pixels, image branch 512, Lf = 5)
+    on a few chains: the HIP trainer vs the float64 autograd restatement"""
+    from oracle import vae_train_oracle as V
+    from tests.helpers import synthetic_vae_case
+    N = 24
+    g = synthetic_vae_case(N=N, seed=4)
+    rng = np.random.RandomState(5)
+    g["log_sigma"] = (0.3 * rng.randn(N, 50) - 0.5).astype(np.float32)
+    dyn, tr = _trainer(g)
+    dr = {"v_fwd": rng.randn(N, 50).astype(np.float32), "v_bwd": rng.randn(N, 50).astype(np.float32),
+          "dir": rng.randint(0, 2, size=N).astype(np.uint8), "u": rng.rand(N).astype(np.float32)}
+    o = V.sampler_loss_and_grad(g, [dr], MH=1)
+    hd = {"v": np.where(dr["dir"][:, None] != 0, dr["v_fwd"], dr["v_bwd"]), "dir": dr["dir"], "u": dr["u"]}
+    loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(g["log_sigma"]), MH=1, draws=[hd])
+    assert abs(float(loss) - o["loss"]) < 2e-4 * max(1.0, abs(o["loss"]))
+    assert abs_err(to_np(px), o["px"]) < P_TOL
+    gg = {k: v for k, v in o.items() if k.startswith("grad.")}
+    worst, scale = _check_net_grads(gg, dyn, tol=5e-4)
+    enc = dyn._xw["aux_encoder"]
+    for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
+        ref = o["grad.enc." + k]
+        got = to_np(enc[k].grad).reshape(ref.shape)
+        assert np.abs(got - ref).max() < 5e-4 * max(float(np.abs(ref).max()), 1e-2 * scale), ("enc", k)
+    print("config-5 widths: loss %.6e  max |dgrad| %.2e (scale %.2e), mean p %.3f" % (float(loss), worst, scale, float(px.mean())))
