@@ -538,12 +538,18 @@ int launch_gemm_shape(const GemmArgs& g, hipStream_t s) {
   return L2HMC_OK;
 }
 
-enum { SHAPE_BIG = 0, SHAPE_MID = 1, SHAPE_SKINNY = 2 };     // 128 x 128, 64 x 64, 32 x 64 workgroup tiles
+enum { SHAPE_BIG = 0, SHAPE_MID = 1, SHAPE_SKINNY = 2, SHAPE_AUTO = 3 };     // 128 x 128, 64 x 64, 32 x 64 workgroup tiles
 inline int gemm_tile_n(int shape) { return shape == SHAPE_BIG ? 128 : 64; }
+// 128 x 128 tiles when they fill the 256 CUs, else 64 x 64 (a 512-chain batch -- the reference's training batch -- gives
+// only 4 x 8 big tiles of a 1024-wide layer)
+inline int gemm_auto_shape(long long M, int N) {
+  return ((M + 127) / 128) * ((N + 127) / 128) >= 192 ? SHAPE_BIG : SHAPE_MID;
+}
 
 template <int EPI>
-int launch_gemm(const GemmArgs& g, hipStream_t s, int shape = SHAPE_BIG) {
+int launch_gemm(const GemmArgs& g, hipStream_t s, int shape = SHAPE_AUTO) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return L2HMC_OK;
+  if (shape == SHAPE_AUTO) shape = gemm_auto_shape(g.M, g.N);
   if (shape == SHAPE_BIG) return launch_gemm_shape<EPI, 4, 4>(g, s);
   if (shape == SHAPE_MID) return launch_gemm_shape<EPI, 2, 2>(g, s);
   return launch_gemm_shape<EPI, 1, 2>(g, s);

@@ -227,7 +227,7 @@ void mlp3_transposes(hipStream_t s, const L2hmcMlp3& m, const Mlp3Ws& ws) {
 void mlp3_hidden(hipStream_t s, const L2hmcMlp3& m, const float* x, int ldx, long long N, const Mlp3Ws& ws) {
   GemmArgs g = gemm_args(x, ldx, ws.w1t, m.n_in, ws.a1, m.n_h1, N, m.n_h1, m.n_in);
   g.bias = m.b1; g.C2 = ws.s1; g.ldc2 = m.n_h1;
-  launch_gemm<EPI_BIAS_SOFTPLUS>(g, s, m.n_in <= 64 ? SHAPE_MID : SHAPE_BIG);
+  launch_gemm<EPI_BIAS_SOFTPLUS>(g, s, m.n_in <= 64 ? SHAPE_MID : SHAPE_AUTO);
   g = gemm_args(ws.a1, m.n_h1, ws.w2t, m.n_h1, ws.a2, m.n_h2, N, m.n_h2, m.n_h1);
   g.bias = m.b2; g.C2 = ws.s2; g.ldc2 = m.n_h2;
   launch_gemm<EPI_BIAS_SOFTPLUS>(g, s);
@@ -238,10 +238,12 @@ void mlp3_forward(hipStream_t s, const L2hmcMlp3& m, const float* x, long long N
   mlp3_hidden(s, m, x, m.n_in, N, ws);
   GemmArgs g = gemm_args(ws.a2, m.n_h2, ws.w3t, m.n_h2, out, m.n_out, N, m.n_out, m.n_h2);
   g.bias = m.b3;
-  launch_gemm<EPI_BIAS>(g, s, m.n_out <= 256 ? SHAPE_MID : SHAPE_BIG);
+  launch_gemm<EPI_BIAS>(g, s, m.n_out <= 256 ? SHAPE_MID : SHAPE_AUTO);
 }
 
-inline int bce_tiles(int n_pix) { return (n_pix + 127) / 128; }     // column tiles of the 128 x 128 shape
+// column tiles of the logits GEMM (EPI_BCE leaves 2 row partials per tile): the shape launch_gemm picks for (N, n_pix)
+inline int bce_tiles(long long N, int n_pix) { return (n_pix + gemm_tile_n(gemm_auto_shape(N, n_pix)) - 1) / gemm_tile_n(gemm_auto_shape(N, n_pix)); }
+inline int bce_tiles_max(int n_pix) { return (n_pix + 63) / 64; }
 
 // U (N) and grad (N x d, row stride ldg) of the VAE latent posterior at z (row stride ldz) (mnist_vae.py:122-126):
 // six GEMMs, every bias / softplus / sigmoid / BCE / chain-rule product fused into their epilogues; lg (N x n_pix)
@@ -250,10 +252,10 @@ void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const flo
                 const Mlp3Ws& ws, float* lg, float* rowsum, float* U, double* Ud, float* grad, int ldg, float beta = 1.f) {
   mlp3_hidden(s, dec, z, ldz, N, ws);
   GemmArgs g = gemm_args(ws.a2, dec.n_h2, ws.w3t, dec.n_h2, lg, dec.n_out, N, dec.n_out, dec.n_h2);
-  g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(dec.n_out); g.beta = beta;
+  g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = beta;
   launch_gemm<EPI_BCE>(g, s);                                     // lg := beta (sigmoid(logit) - aux)
   if (U != nullptr || Ud != nullptr)
-    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles(dec.n_out), z, ldz, d, U, Ud, N);
+    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles(N, dec.n_out), z, ldz, d, U, Ud, N);
   if (grad == nullptr) return;
   // d a2 = dl W3^T (.) sigmoid(p2);  d a1 = d a2 W2^T (.) sigmoid(p1);  d z = d a1 W1^T + z
   g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);
@@ -284,7 +286,7 @@ SplitPlan plan_split(long long N, int d, int H, int T, const L2hmcMlp3* enc, con
   p.h1 = take(N * H); p.h2 = take(N * H); p.out3 = take(N * 3 * d);
   p.aux_h = take(enc ? N * H : 0); p.tb = take(2LL * T * H);
   p.U0 = take(2 * N); p.K0 = take(N); p.U1 = take(2 * N); p.K1 = take(N); p.ld = take(N);      // U0 / U1: doubles
-  p.rowsum = take(dec ? N * 2 * bce_tiles(dec->n_out) : 0);
+  p.rowsum = take(dec ? N * 2 * bce_tiles_max(dec->n_out) : 0);
   p.lg = take(dec ? N * dec->n_out : 0);
   p.dw1t = take(dec ? (long long)dec->n_in * dec->n_h1 : 0); p.dw2t = take(dec ? (long long)dec->n_h1 * dec->n_h2 : 0);
   p.dw3t = take(dec ? (long long)dec->n_h2 * dec->n_out : 0);

@@ -343,8 +343,8 @@ __global__ void colsum_reduce_kernel(const float* part, int n_chunks, int cols, 
   }
 }
 inline void colsum_chunks(long long R, int cols, long long part_cap, int& nc, long long& rpc) {
-  long long n = (R + 255) / 256;                       // many small chunks: this is a streaming read, fill the chip
-  if (n > 1024) n = 1024;
+  long long n = (R + 255) / 256;                       // a streaming read: enough chunks to fill the chip, few enough
+  if (n > 128) n = 128;                                // that the fixed-order second stage stays short
   if (n * cols > part_cap) n = part_cap / cols;
   if (n < 1) n = 1;
   rpc = ((R + n - 1) / n + 3) / 4 * 4;
@@ -439,10 +439,10 @@ void vae_energy_keep(hipStream_t s, const L2hmcMlp3& dec, const float* aux, cons
   ws.s1 = pt.s1; ws.s2 = pt.s2;
   mlp3_hidden(s, dec, z, ldz, N, ws);
   GemmArgs g = gemm_args(ws.a2, dec.n_h2, ws.w3t, dec.n_h2, lg, dec.n_out, N, dec.n_out, dec.n_h2);
-  g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(dec.n_out); g.beta = 1.f;
+  g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = 1.f;
   launch_gemm<EPI_BCE>(g, s);
   if (Ud != nullptr)
-    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles(dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
+    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles(N, dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
   const long long npix = N * dec.n_out;
   hipLaunchKernelGGL(k_sigd, dim3(nblk(npix)), dim3(256), 0, s, lg, aux, pt.rd, npix);
   g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);
@@ -466,7 +466,7 @@ void vae_hvp(hipStream_t s, const L2hmcMlp3& dec, long long N, int d, const Mlp3
              const TrainSplitPlan& p, float* w, const float* u, float* hv) {
   GemmArgs g = gemm_args(u, d, ws.w1t, dec.n_in, w + p.HD1, dec.n_h1, N, dec.n_h1, dec.n_in);
   g.E = pt.s1; g.lde = dec.n_h1; g.E2 = pt.b1; g.lde2 = dec.n_h1; g.C2 = w + p.M1; g.ldc2 = dec.n_h1;
-  launch_gemm<EPI_TAN>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_BIG);
+  launch_gemm<EPI_TAN>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_AUTO);
   g = gemm_args(w + p.HD1, dec.n_h1, ws.w2t, dec.n_h1, w + p.HD2, dec.n_h2, N, dec.n_h2, dec.n_h1);
   g.E = pt.s2; g.lde = dec.n_h2; g.E2 = pt.b2; g.lde2 = dec.n_h2; g.C2 = w + p.M2; g.ldc2 = dec.n_h2;
   launch_gemm<EPI_TAN>(g, s);
