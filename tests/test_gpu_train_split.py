@@ -209,3 +209,31 @@ def test_short_vae_sampler_training_run_improves_the_objective():
     print("VAE sampler training: objective %.3f -> %.3f, mean squared jump %.3f -> %.3f, eps %.3f -> %.3f"
           % (l0, l1, j0, j1, float(g["eps"]), float(torch.exp(dyn.alpha.detach()))))
     assert l1 < l0 - 0.05 * abs(l0) and j1 > j0
+
+
+@pytest.mark.parametrize("kind,d,H,T,N", [("gauss_diag", 5, 7, 2, 21), ("gauss_dense", 3, 15, 3, 18), ("roughwell_easy", 17, 10, 2, 19),
+                                          ("gauss_diag", 33, 18, 1, 37), ("gauss_dense", 7, 33, 2, 5), ("roughwell_easy", 50, 64, 3, 130)])
+def test_gemm_engine_trainer_on_odd_shapes_matches_the_numpy_reverse_mode_oracle(kind, d, H, T, N):
+    """ragged chain counts, d and H that are no multiples of 4 / 16 (unaligned rows in every GEMM form), T = 1, nets both
+    below and above the register-resident kernels' H = 15: loss, proposals and the whole flat gradient against
+    oracle/l2hmc_train_oracle.py (float64; pinned by the reference-graph fixtures)"""
+    from oracle import l2hmc_train_oracle as TO
+    from tests.helpers import synthetic_case
+    g = synthetic_case(kind, d, H=H, T=T, N=N, seed=3 * d + H, head_std=0.2)
+    rng = np.random.RandomState(2)
+    g["z"] = rng.randn(N, d).astype(np.float32)
+    for pre in ("x.", "z."):
+        g[pre + "dir"] = rng.randint(0, 2, N).astype(np.uint8)
+        g[pre + "v_fwd"] = rng.randn(N, d).astype(np.float32)
+        g[pre + "v_bwd"] = rng.randn(N, d).astype(np.float32)
+    ref_loss, ref = TO.training_loss_and_grad(g, np.float64)
+    dyn, tr = _trainer(g, force_split=True)
+    draws = {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
+             "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
+             "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
+    loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+    assert abs(float(loss) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    assert rel_err(to_np(Lx), ref["Lx"]) < TRAJ_TOL and abs_err(to_np(px), ref["px"]) < P_TOL
+    gg = {"grad.%s.%s" % (n, k): np.asarray(ref["%s.%s" % (n, k)]) for n in ("xnet", "vnet") for k in O.NET_KEYS}
+    gg["grad.alpha"] = np.float64(ref["alpha"])
+    _check_net_grads(gg, dyn, tol=3e-4)
