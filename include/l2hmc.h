@@ -307,7 +307,7 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* args, void* stream);
  * probability, the loss argument and the gradient of the loss term (accumulated into `grad`) -- for the samplers the
  * register-resident kernels cannot hold: S/T/Q nets of any width H, the shared image branch aux_encoder(aux) in their
  * first hidden layer, and the VAE latent-posterior energy (mnist_vae.py:104-226, the "trained sampler" of BASELINE.json
- * config 5); or, with `energy` set, a diagonal / dense Gaussian or a Rough Well with wide nets.
+ * config 5); or, with `energy` set, any built-in target of utils/distributions.py with wide nets.
  *   v1_n = sum_k w_nk (Lx_nk - x_nk)^2 p_n + 1e-4;      term = scale * mean_n(1 / v1_n) - mean_n(v1_n) / scale
  *   w = dist_weight (N, d) or NULL (= 1).  SCGExperiment.ipynb raw 164-169: w = 1, scale = 0.1;
  *   mnist_vae.py:207-214 (energy_scale = 0): w = 1 / (exp(2 log_sigma) + 1e-4), scale = 1.
@@ -326,8 +326,8 @@ typedef struct L2hmcTrainSplitArgs {
   const L2hmcMlp3* aux_encoder;  /* (n_pix -> H) or NULL                                                   */
   const L2hmcMlp3* decoder;      /* (d -> n_pix); NULL with `energy`                                       */
   const float* aux;              /* (N, n_pix)                                                             */
-  const L2hmcEnergy* energy;     /* NULL: the decoder posterior.  Else GAUSS_DIAG / GAUSS_DENSE / ROUGHWELL */
-  const float* hess;             /* GAUSS_DENSE: the RAW (d, d) precision (its symmetric part is the Hessian) */
+  const L2hmcEnergy* energy;     /* NULL: the decoder posterior.  Else a built-in target (as l2hmc_energy takes it)  */
+  const float* hess;             /* GAUSS_DENSE / GMM: the RAW (n_comp, d, d) precisions (Hessian-vector products)   */
   const float* masks;            /* (T, d) */
   const float* trig;             /* (T, 2) */
   const float* alpha;            /* device log(eps) or NULL -> eps_host */

@@ -181,6 +181,69 @@ __global__ void k_hvp_builtin(int kind, const float* x, int ldx, const float* u,
   hv[i] = o;
 }
 
+// Hessian-vector products that couple the dimensions of a chain (oracle/l2hmc_train_oracle.py GMMTarget / FunnelTarget
+// .hessvec); one thread per chain -- these targets live in a handful of dimensions.
+//   mixture (distributions.py:104-134): y_i = G_i (x - mu_i), w = softmax_i(-(x - mu_i)^T S_i (x - mu_i) / 2 + logc_i),
+//     g = sum_i w_i y_i,   H u = sum_i w_i (G_i u - y_i (y_i . u)) + g (g . u);   G_i = (S_i + S_i^T) / 2 of the RAW S_i
+//   funnel (distributions.py:155-180), s = e^{x_0} (constant on the clipped branches), q = sum_{k>=1} x_k^2:
+//     (H u)_k = u_k / s - [free] x_k u_0 / s,   (H u)_0 = u_0 (1 / sigma^2 + [free] q / (2 s)) - [free] sum_k x_k u_k / s
+constexpr int HVP_MAXC = 32;
+__global__ void k_hvp_chain(int kind, const float* x, int ldx, const float* u, float* hv, float* gs, const float* mu,
+                            const float* hess, const float* logc, int ncomp, float sigma, long long N, int d) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* xr = x + n * ldx;
+  const float* ur = u + n * d;
+  float* o = hv + n * d;
+  if (kind == L2HMC_ENERGY_FUNNEL) {
+    const float v = xr[0], clip = 4.f * sigma;
+    const bool hi = v > clip, lo = -clip > v;
+    const float fr = (hi || lo) ? 0.f : 1.f;
+    const float inv_s = 1.f / (hi ? expf(clip) : (lo ? expf(-clip) : expf(v)));
+    float q = 0.f, dot = 0.f;
+    for (int k = 1; k < d; ++k) { q += xr[k] * xr[k]; dot += xr[k] * ur[k]; }
+    for (int k = 1; k < d; ++k) o[k] = ur[k] * inv_s - fr * xr[k] * ur[0] * inv_s;
+    o[0] = ur[0] * (1.f / (sigma * sigma) + fr * 0.5f * q * inv_s) - fr * dot * inv_s;
+    return;
+  }
+  // mixture: y(c, k) = sum_j G_c[k][j] (x_j - mu_c[j])
+  auto Gc = [&](int c, int k, int j) { return 0.5f * (hess[((long long)c * d + k) * d + j] + hess[((long long)c * d + j) * d + k]); };
+  auto ycomp = [&](int c, int k) {
+    float a = 0.f;
+    for (int j = 0; j < d; ++j) a += Gc(c, k, j) * (xr[j] - mu[c * d + j]);
+    return a;
+  };
+  float w[HVP_MAXC];
+  float m = -INFINITY;
+  for (int c = 0; c < ncomp; ++c) {
+    float qf = 0.f;
+    for (int k = 0; k < d; ++k) qf += (xr[k] - mu[c * d + k]) * ycomp(c, k);
+    w[c] = -0.5f * qf + logc[c];
+    m = fmaxf(m, w[c]);
+  }
+  float sum = 0.f;
+  for (int c = 0; c < ncomp; ++c) { w[c] = (w[c] == -INFINITY) ? 0.f : expf(w[c] - m); sum += w[c]; }
+  for (int c = 0; c < ncomp; ++c) w[c] /= sum;
+  float* g = gs + n * d;                       // scratch row: grad U
+  float gu = 0.f;
+  for (int k = 0; k < d; ++k) {
+    float a = 0.f;
+    for (int c = 0; c < ncomp; ++c) a += w[c] * ycomp(c, k);
+    g[k] = a;
+    gu += a * ur[k];
+  }
+  for (int k = 0; k < d; ++k) o[k] = g[k] * gu;
+  for (int c = 0; c < ncomp; ++c) {
+    float yu = 0.f;
+    for (int k = 0; k < d; ++k) yu += ycomp(c, k) * ur[k];
+    for (int k = 0; k < d; ++k) {
+      float Gu = 0.f;
+      for (int j = 0; j < d; ++j) Gu += Gc(c, k, j) * ur[j];
+      o[k] += w[c] * (Gu - ycomp(c, k) * yu);
+    }
+  }
+}
+
 // accept probability (dynamics.py:302-309), the loss argument and the adjoint seeds of the reverse sweep
 // (train.hip "accept probability, loss term and the adjoint seeds"); one wave per chain
 __global__ __launch_bounds__(256) void k_train_seed(const float* x0, const float* x1, int ldx1, const float* v1,
@@ -514,9 +577,10 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
       return fail(L2HMC_ERR_UNSUPPORTED, "a built-in energy excludes decoder / aux_encoder / aux%s");
     if ((rc = check_energy(a->energy, d))) return rc;
     const int ek = a->energy->kind;
-    if (ek != L2HMC_ENERGY_GAUSS_DIAG && ek != L2HMC_ENERGY_ROUGHWELL && ek != L2HMC_ENERGY_GAUSS_DENSE)
-      return fail(L2HMC_ERR_UNSUPPORTED, "GEMM-engine training: diagonal / dense Gaussian, Rough Well or the decoder posterior%s");
-    if (ek == L2HMC_ENERGY_GAUSS_DENSE && !a->hess) return fail(L2HMC_ERR_ARG, "dense Gaussian: hess = the RAW (d, d) precision%s");
+    if ((ek == L2HMC_ENERGY_GAUSS_DENSE || ek == L2HMC_ENERGY_GMM) && !a->hess)
+      return fail(L2HMC_ERR_ARG, "dense Gaussian / mixture: hess = the RAW (n_comp, d, d) precisions%s");
+    if (ek == L2HMC_ENERGY_GMM && a->energy->n_comp > HVP_MAXC)
+      return fail(L2HMC_ERR_UNSUPPORTED, "mixture training: at most %s%lld components", "", (long long)HVP_MAXC);
     if (a->energy->temperature != 1.f || (a->energy->anneal_beta != 0.f && a->energy->anneal_beta != 1.f))
       return fail(L2HMC_ERR_UNSUPPORTED, "training differentiates the plain energy (temperature 1, no annealing)%s");
   } else {
@@ -689,6 +753,9 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     have_carry = false;
     if (!builtin) {
       vae_hvp(s, dec, N, d, dws, dec_point(j), p, w, uu, hv);
+    } else if (a->energy->kind == L2HMC_ENERGY_GMM || a->energy->kind == L2HMC_ENERGY_FUNNEL) {
+      hipLaunchKernelGGL(k_hvp_chain, dim3(nblk(N)), dim3(256), 0, s, a->energy->kind, ab, L, uu, hv, dg, a->energy->mu, a->hess,
+                         a->energy->logc, a->energy->n_comp, a->energy->eta, N, d);      // (dg is free: its sum went into uu)
     } else {
       hipLaunchKernelGGL(k_hvp_builtin, dim3(nblk(Nd)), dim3(256), 0, s, a->energy->kind, ab, L, uu, hv, a->energy->prec,
                          a->hess, a->energy->eta, a->energy->easy, N, d);

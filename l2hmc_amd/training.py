@@ -376,12 +376,9 @@ class SplitTrainer(Trainer):
             a.decoder, a.aux = C.pointer(dec_s), aux.data_ptr()
         else:
             fn = dyn._fn
-            if fn.kind not in (_ffi.ENERGY_GAUSS_DIAG, _ffi.ENERGY_GAUSS_DENSE, _ffi.ENERGY_ROUGHWELL):
-                raise NotImplementedError("GEMM-engine training supports the Gaussian and Rough-Well targets (and the "
-                                          "VAE posterior); mixtures and the funnel train on nets with H <= 15")
             keep = fn.c_struct(dyn.device, 1.0, 0.0)
             a.energy = C.pointer(keep)
-            if fn.kind == _ffi.ENERGY_GAUSS_DENSE:
+            if fn.kind in (_ffi.ENERGY_GAUSS_DENSE, _ffi.ENERGY_GMM):
                 a.hess = fn._buffers(dyn.device)["_raw"].data_ptr()
         a.masks, a.trig = dyn._mask.data_ptr(), dyn._trig.data_ptr()
         if dyn.eps_override is None:

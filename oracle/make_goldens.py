@@ -448,9 +448,15 @@ def train_vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
         float(np.abs(out['grad.enc.W1']).max())))
 
 
-def train_wide_cases():
+def train_wide_cases(only_new=False):
     """training gradients with nets wider than the register-resident kernels take (H > 15): GEMM-engine trainer"""
     var = np.exp(np.linspace(np.log(1e-2), np.log(1e2), 50))
+    if not only_new:
+        _train_wide_gaussians(var)
+    _train_wide_mixture_funnel()
+
+
+def _train_wide_gaussians(var):
     train_case('train_icg50_h32', np.zeros(50), np.diag(var), H=32, T=4, eps=0.05, N=16, seed=37, head_std=0.05)
     rng = np.random.RandomState(7)
     R = np.linalg.qr(rng.randn(8, 8))[0]
@@ -461,6 +467,24 @@ def train_wide_cases():
     train_case('train_rough6_h20', np.zeros(6), None, H=20, T=5, eps=0.1, N=32, seed=39, head_std=0.3, dist=rw_t,
                params={'energy.kind': 'roughwell', 'energy.eta': np.float32(0.3), 'energy.easy': np.int32(1)},
                x_start=lambda rng: rng.randn(32, 6))
+
+
+def _train_wide_mixture_funnel():
+    # a 3-component mixture with unequal weights and a tilted component, and the funnel, under 20-wide nets
+    mus_t = [np.array([2.0, 0.0, 0.5], dtype=np.float32), np.array([-2.0, 0.0, -0.5], dtype=np.float32),
+             np.array([0.0, 1.5, 0.0], dtype=np.float32)]
+    A = np.array([[0.6, 0.2, 0.0], [0.2, 0.5, 0.1], [0.0, 0.1, 0.4]])
+    with contextlib.redirect_stdout(io.StringIO()):
+        gmm_t = ref_distributions.GMM([torch.tensor(m) for m in mus_t], [0.5 * np.eye(3), A, 0.3 * np.eye(3)], [0.5, 0.3, 0.2])
+    train_case('train_mog3d_h20', np.zeros(3), None, H=20, T=5, eps=0.1, N=48, seed=40, head_std=0.3, dist=gmm_t,
+               params={'energy.kind': 'gmm', 'energy.mus': np.stack(mus_t), 'energy.i_sigmas': np.stack(gmm_t.i_sigmas),
+                       'energy.constants': np.array(gmm_t.constants, dtype=np.float32)},
+               x_start=lambda r: np.stack(mus_t)[r.randint(0, 3, size=48)] + np.sqrt(0.4) * r.randn(48, 3))
+    with contextlib.redirect_stdout(io.StringIO()):
+        fun = ref_distributions.GaussianFunnel(dim=4)
+    train_case('train_funnel4_h20', np.zeros(4), None, H=20, T=4, eps=0.05, N=32, seed=41, head_std=0.3, dist=fun,
+               params={'energy.kind': 'funnel', 'energy.sigma': np.float32(2.0)},
+               x_start=lambda rng: np.concatenate([rng.randn(32, 1) * 1.5, rng.randn(32, 3)], axis=1))
 
 
 def gaussian_case(name, mu, cov, **kw):
@@ -593,6 +617,8 @@ def main():
         return train_vae_case('train_vae_small', latent=10, H=24, dec_h=48, n_pix=40, enc_h=32, T=4, eps=0.1, N=32, seed=43)
     if sys.argv[1:] == ['train_wide']:
         return train_wide_cases()
+    if sys.argv[1:] == ['train_wide2']:
+        return train_wide_cases(only_new=True)
     # C1: Strongly-correlated Gaussian 2D, exactly the notebook's target (nb:103-108)
     cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
     gaussian_case('scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=11, x_scale=1.0)

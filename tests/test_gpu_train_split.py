@@ -38,6 +38,8 @@ def _check_net_grads(g, dyn, pre="grad.", tol=2e-4):
 
 
 @pytest.mark.parametrize("case,force", [("train_icg50_h32", False), ("train_tilted8_h24", False), ("train_rough6_h20", False),
+                                        ("train_mog3d_h20", False), ("train_funnel4_h20", False), ("train_mog2d", True),
+                                        ("train_funnel3", True),
                                         ("train_scg2d", True), ("train_tilted8", True), ("train_icg50", True),
                                         ("train_rough6", True)])
 def test_gemm_engine_training_gradient_matches_reference_graph(case, force):

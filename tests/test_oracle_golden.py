@@ -160,7 +160,8 @@ def test_philox_draws_are_sharding_invariant_and_standard():
 
 
 @pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6", "train_funnel3",
-                                  "train_icg50_h32", "train_tilted8_h24", "train_rough6_h20"])
+                                  "train_icg50_h32", "train_tilted8_h24", "train_rough6_h20", "train_mog3d_h20",
+                                  "train_funnel4_h20"])
 def test_training_gradient_oracle_matches_reference_graph(case):
     """oracle/l2hmc_train_oracle.py (hand-derived reverse mode incl. the Hessian-vector path)
     vs tf.gradients of the notebook loss evaluated by the reference's own graph (stub)."""
