@@ -12,9 +12,10 @@
 // 4 x 4 v_mfma_f32_16x16x4_f32 tiles (64 accumulator VGPRs).  The MFMA "A" operand carries the WEIGHT rows
 // (n) and the "B" operand the activation rows (m), so that a lane ends up with 4 CONSECUTIVE columns
 // n = n0 + 4q + r of one row m = m0 + c: bias / aux / sigmoid operands and the result move as dwordx4.
-// K is consumed in tiles of 16: both tiles are staged in LDS as [row][16 k + 4 pad] (80-byte rows: one
+// K is consumed in tiles of GK = 16: both tiles are staged in LDS as [row][16 k + 4 pad] (80-byte rows: one
 // conflict-free ds_read_b128 per lane fetches the operands of the 4 k-steps of a 16-wide tile), double
-// buffered, the next tile's global loads issued before the 64 MFMAs of the current one.
+// buffered, the next tile's global loads issued before the 64 MFMAs of the current one.  (-DL2HMC_GEMM_GK=32 -- one
+// barrier per 128 MFMAs, 74 KB of LDS per workgroup -- was measured: config 5 4.87 -> 5.34 ms per proposal; not used.)
 //
 // Epilogues (fused, so no activation makes an extra HBM round trip):
 //   EPI_BIAS            C = acc + b
@@ -57,7 +58,11 @@ struct GemmArgs {
   const unsigned char* dir; int dir_all, it, T;
 };
 
-constexpr int GK = 16, GP = 20;               // k-tile, padded LDS row (floats)
+#ifndef L2HMC_GEMM_GK
+#define L2HMC_GEMM_GK 16
+#endif
+constexpr int GK = L2HMC_GEMM_GK, GP = GK + 4;   // k-tile, padded LDS row (floats): 16 consecutive rows start in 16 distinct
+                                               // bank quads for GP = 20 and 36 alike
 
 // softplus(p) = max(p, 0) + log(1 + e^{-|p|}) and sigmoid(p) from ONE hardware exp2, one log2 and one rcp
 // (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each).  With e = e^{-|p|} in (0, 1] the argument 1 + e lies in
@@ -112,30 +117,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
   const long long m0 = (long long)blockIdx.y * TM;
   const int n0 = blockIdx.x * TN;
 
-  // global -> register staging: thread loads k quad (tid & 3) of rows (tid >> 2) + 64 i
-  const int lr = tid >> 2, lk = (tid & 3) * 4;
-  constexpr int NA = (TM + 63) / 64, NB = (TN + 63) / 64;
+  // global -> register staging: a row of the k-tile is GK / 4 quads; thread loads quad (tid % QPR) of rows
+  // (tid / QPR) + RPP i
+  constexpr int QPR = GK / 4, RPP = 256 / QPR;
+  const int lr = tid / QPR, lk = (tid % QPR) * 4;
+  constexpr int NA = (TM + RPP - 1) / RPP, NB = (TN + RPP - 1) / RPP;
   f4 ra[NA], rb[NB];
   auto gload = [&](int k0) {
     const int k = k0 + lk;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const long long m = m0 + lr + 64 * i;
-      ra[i] = (lr + 64 * i < TM && m < g.M) ? load_kquad<KV>(g.A + m * g.lda + k, k, g.K) : splat(0.f);
+      const long long m = m0 + lr + RPP * i;
+      ra[i] = (lr + RPP * i < TM && m < g.M) ? load_kquad<KV>(g.A + m * g.lda + k, k, g.K) : splat(0.f);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int n = n0 + lr + 64 * i;
-      rb[i] = (lr + 64 * i < TN && n < g.N) ? load_kquad<KV>(g.B + (long long)n * g.ldb + k, k, g.K) : splat(0.f);
+      const int n = n0 + lr + RPP * i;
+      rb[i] = (lr + RPP * i < TN && n < g.N) ? load_kquad<KV>(g.B + (long long)n * g.ldb + k, k, g.K) : splat(0.f);
     }
   };
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      if (lr + 64 * i < TM) *reinterpret_cast<f4*>(&sA[buf][(lr + 64 * i) * GP + lk]) = ra[i];
+      if (lr + RPP * i < TM) *reinterpret_cast<f4*>(&sA[buf][(lr + RPP * i) * GP + lk]) = ra[i];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      if (lr + 64 * i < TN) *reinterpret_cast<f4*>(&sB[buf][(lr + 64 * i) * GP + lk]) = rb[i];
+      if (lr + RPP * i < TN) *reinterpret_cast<f4*>(&sB[buf][(lr + RPP * i) * GP + lk]) = rb[i];
   };
 
   f4 acc[WNB][WMB];                                                // [n block][m block]
@@ -151,17 +158,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * GK);                         // in flight under the MFMAs below
-    f4 fw[WNB], fa[WMB];
+    // all fragments of the k-tile are requested up front: the second 16-wide half arrives under the MFMAs of the first
+    f4 fw[GK / 16][WNB], fa[GK / 16][WMB];
 #pragma unroll
-    for (int i = 0; i < WNB; ++i) fw[i] = *reinterpret_cast<const f4*>(&sB[buf][(wn + 16 * i + c) * GP + 4 * q]);
+    for (int h = 0; h < GK / 16; ++h) {
 #pragma unroll
-    for (int j = 0; j < WMB; ++j) fa[j] = *reinterpret_cast<const f4*>(&sA[buf][(wm + 16 * j + c) * GP + 4 * q]);
+      for (int i = 0; i < WNB; ++i) fw[h][i] = *reinterpret_cast<const f4*>(&sB[buf][(wn + 16 * i + c) * GP + 16 * h + 4 * q]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int j = 0; j < WMB; ++j) fa[h][j] = *reinterpret_cast<const f4*>(&sA[buf][(wm + 16 * j + c) * GP + 16 * h + 4 * q]);
+    }
 #pragma unroll
-      for (int i = 0; i < WNB; ++i)
+    for (int h = 0; h < GK / 16; ++h)
 #pragma unroll
-        for (int j = 0; j < WMB; ++j) acc[i][j] = MFMA16(fw[i][s], fa[j][s], acc[i][j]);
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < WNB; ++i)
+#pragma unroll
+          for (int j = 0; j < WMB; ++j) acc[i][j] = MFMA16(fw[h][i][s], fa[h][j][s], acc[i][j]);
     if (kt + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
   }

@@ -128,3 +128,66 @@ def test_two_rank_training_step_matches_the_full_batch_gradient():
         assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (rank, loss, ref_loss)
         assert rel < 2e-4, (rank, rel)
         assert abs(ga - ref_ga) < 2e-4 * max(1.0, abs(ref_ga)), (rank, ga, ref_ga)
+
+
+def _vae_train_worker(rank, world, port, out):
+    """One rank of a 2-process VAE sampler update on the SAME GPU: chains (and their images) sharded, the flat gradient
+    [XNet | VNet | d/d eps | encoder_sampler] of the GEMM-engine trainer all-reduced once (gloo), then clipped Adam."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import l2hmc_oracle as O
+        from l2hmc_amd.training import SplitTrainer, Trainer
+        from tests.helpers import hip_dynamics, load, to_dev, to_np
+        g = load("train_vae_small")
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        tr = Trainer(dyn, decay_steps=0)
+        assert isinstance(tr, SplitTrainer)
+        N = g["x"].shape[0]
+        lo, hi = sharding.shard_range(N)
+        dr = {"v": np.where(g["prop.dir"][:, None] != 0, g["prop.v_fwd"], g["prop.v_bwd"])[lo:hi],
+              "dir": g["prop.dir"][lo:hi], "u": g["prop.u"][lo:hi]}
+        loss, xT, px = tr.sampler_loss_and_grad(to_dev(g["x"][lo:hi]), to_dev(g["aux"][lo:hi]), to_dev(g["log_sigma"][lo:hi]),
+                                                MH=1, draws=[dr])
+        scale = max(float(np.abs(g["grad.%s.%s" % (n, k)]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+        worst = 0.0
+        for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
+            for k in O.NET_KEYS:
+                ref = g["grad.%s.%s" % (n, k)]
+                worst = max(worst, float(np.abs(to_np(w[k].grad).reshape(ref.shape) - ref).max()))
+        enc = dyn._xw["aux_encoder"]
+        for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
+            ref = g["grad.enc." + k]
+            worst = max(worst, float(np.abs(to_np(enc[k].grad).reshape(ref.shape) - ref).max()))
+        tr._adam(tr.lr_at(0))                       # every rank applies the same update to its replica
+        out.put((rank, float(loss), float(g["loss"]), worst / scale, float(dyn.alpha.grad), float(g["grad.alpha"]),
+                 float(tr.theta.double().sum()), float(tr.theta.double().abs().sum())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_rank_vae_sampler_update_matches_the_full_batch_gradient():
+    """the GEMM-engine trainer with chains sharded 16 + 16 over 2 processes: every rank ends up with the reference graph's
+    full-batch sampler loss and gradient (incl. the image branch), and with identical parameters after the update"""
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vae_train_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(280)
+        assert pr.exitcode == 0
+    res = sorted(out.get() for _ in range(2))
+    for rank, loss, ref_loss, rel, ga, ref_ga, s1, s2 in res:
+        assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (rank, loss, ref_loss)
+        assert rel < 2e-4, (rank, rel)
+        assert abs(ga - ref_ga) < 2e-4 * max(1.0, abs(ref_ga)), (rank, ga, ref_ga)
+    assert res[0][6] == res[1][6] and res[0][7] == res[1][7]
