@@ -242,6 +242,12 @@ typedef struct L2hmcSplitArgs {
                                   *    utils/distributions.py (decoder / aux / aux_encoder = NULL): the S/T/Q
                                   *    nets of ANY width H on the GEMM engine, grad U from l2hmc_energy's kernels
                                   *    (SCGExperiment.ipynb `network` with H != 10)                       */
+  int32_t reuse;                 /* what the SAME workspace still holds from the previous call with the same shapes
+                                  *    (the library keeps no state of its own; the caller vouches):
+                                  *    1: the prepared weights (transposed copies, time table) -- no weight changed;
+                                  *    2: the image branch aux_encoder(aux) -- aux and aux_encoder unchanged.
+                                  *    A sampling loop passes 3 from its second proposal on (mnist_vae.py:185-224:
+                                  *    weights and images are fixed while the chain runs)                  */
 } L2hmcSplitArgs;
 
 int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,

@@ -60,7 +60,7 @@ class L2hmcSplitArgs(C.Structure):
                 ("direction_all", C.c_int32), ("u", _fp),
                 ("x_out", _fp), ("v_out", _fp), ("logjac_out", _fp), ("p_out", _fp), ("x_next", _fp),
                 ("workspace", _fp), ("workspace_floats", C.c_int64), ("hmc", C.c_int32),
-                ("bce_scale", C.c_float), ("energy", C.POINTER(L2hmcEnergy))]
+                ("bce_scale", C.c_float), ("energy", C.POINTER(L2hmcEnergy)), ("reuse", C.c_int32)]
 
 
 class L2hmcTrainArgs(C.Structure):

@@ -293,8 +293,22 @@ struct NetEvalArgs {
   const float* tb;                  // (T, H) time/bias table of this net
   const float* auxh;                // (M, H) image-branch term or NULL
   const unsigned char* dir; int dir_all, it, T;
-  float* out3;                      // (M, 3 d)
+  float* out3;                      // (M, 3 d)  (upd.mode == 0)
   int M, d, H;
+  // The leapfrog half-update that consumes this evaluation, fused behind the heads (upd.mode != 0: the head products stay in
+  // LDS and out3 is not written).  Same formulas as the stand-alone update kernels of split.hip.
+  struct Update {
+    int mode;                       // 0 none, 1 momentum half-update (k_v_half), 2 masked position update (k_x_half)
+    const float *bs, *bt, *bq, *lam_s, *lam_q;   // head biases and log-scales of this net (d each)
+    const float* alpha; float eps_host;
+    float* ld;                      // (M) log-det, accumulated
+    // mode 1: v_out = v_half(v_in; g);  optionally xin = k1 x for the X-net evaluation that follows
+    const float* vin; int ldvi; const float* g; int ldg; float* vout; int ldvo;
+    const float* x; int ldx; float* xin; int ldxi;
+    // mode 2: z_out = x_half(z_in; vh), second = 0 / 1;  optionally xin_next = (1 - kept) z_out
+    const float* zin; int ldzi; const float* vh; int ldvh; float* zout; int ldzo; float* xin_next; int ldxn;
+    const float* masks; int second;
+  } upd;
 };
 __host__ __device__ inline int ceil16(int k) { return (k + 15) / 16 * 16; }
 __host__ __device__ inline int odd_quarter_stride(int k) {   // smallest multiple of 4 >= k whose quarter is odd
@@ -304,8 +318,8 @@ __host__ __device__ inline int odd_quarter_stride(int k) {   // smallest multipl
 }
 constexpr int NE_MT = 16;
 constexpr int NE_MAXKT = 16;       // k-tiles per layer the kernel is compiled for: K <= 256
-inline size_t net_eval_lds_bytes(int d, int H) {
-  return sizeof(float) * NE_MT * (size_t)(odd_quarter_stride(ceil16(2 * d)) + 2 * odd_quarter_stride(ceil16(H)));
+inline size_t net_eval_lds_bytes(int d, int H) {       // input tile, two hidden activations, head products
+  return sizeof(float) * NE_MT * (size_t)(odd_quarter_stride(ceil16(2 * d)) + 2 * odd_quarter_stride(ceil16(H)) + ceil16(3 * d));
 }
 
 __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
@@ -317,6 +331,8 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
   float* sIn = sm;
   float* sH1 = sIn + NE_MT * ld1;
   float* sH2 = sH1 + NE_MT * ldh;
+  float* sOut = sH2 + NE_MT * ldh;                       // (16, ceil16(3 d)) head products of the fused update
+  const int ldo = ceil16(3 * g.d);
   const long long m0 = (long long)blockIdx.x * NE_MT;
 
   for (int i = tid; i < NE_MT * (K1p / 4); i += 256) {        // input tile, zero padded to K1p (K1 % 4 == 0)
@@ -380,14 +396,76 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
   });
   __syncthreads();
   const int N3 = 3 * g.d;
+  const int mode = g.upd.mode;
   layer(sH2, ldh, Hp, g.Wht, ceil16(N3), [&](int nb, f4 v) {
     const int n = nb * 16 + 4 * q;
+    if (mode != 0) {                                         // (n + 3 < ceil16(3 d) = ldo always)
+      *reinterpret_cast<f4*>(sOut + c * ldo + n) = v;
+      return;
+    }
     if (!mok) return;
     float* o = g.out3 + m * N3 + n;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (n + r < N3) o[r] = v[r];
   });
+  if (mode == 0) return;
+  __syncthreads();
+  // ---- fused half-update: 16 threads per chain, dimensions strided by 16; the chain's log-det share is reduced over
+  // its 16 lanes in a fixed order
+  const NetEvalArgs::Update& U = g.upd;
+  const int r = tid >> 4, j = tid & 15;
+  const long long n = m0 + r;
+  const bool ok = n < g.M;
+  const int d = g.d;
+  bool fwd = true;
+  int srow = 0;
+  if (ok) {
+    fwd = g.dir != nullptr ? g.dir[n] != 0 : (g.dir_all != 0);
+    srow = fwd ? g.it : (g.T - 1 - g.it);
+  }
+  const float eps = U.alpha != nullptr ? expf(*U.alpha) : U.eps_host, sgn = fwd ? 1.f : -1.f;
+  const float* o3 = sOut + r * ldo;
+  float acc = 0.f;
+  if (ok) {
+    if (mode == 1) {
+      const float heps = 0.5f * eps;
+      for (int k = j; k < d; k += 16) {
+        const float S = expf(U.lam_s[k]) * tanhf(o3[k] + U.bs[k]);
+        const float T_ = o3[d + k] + U.bt[k];
+        const float Q = expf(U.lam_q[k]) * tanhf(o3[2 * d + k] + U.bq[k]);
+        const float sv = sgn * heps * S, ES = expf(sv), EQ = expf(eps * Q);
+        const float cc = heps * (T_ - EQ * U.g[n * U.ldg + k]);
+        const float vi = U.vin[n * U.ldvi + k];
+        U.vout[n * U.ldvo + k] = fwd ? vi * ES + cc : (vi - cc) * ES;
+        acc += sv;
+        if (U.xin != nullptr) {
+          const float mk = U.masks[srow * d + k];
+          U.xin[n * U.ldxi + k] = (fwd ? mk : 1.f - mk) * U.x[n * U.ldx + k];
+        }
+      }
+    } else {
+      for (int k = j; k < d; k += 16) {
+        const float mk = U.masks[srow * d + k];
+        const float k1 = fwd ? mk : 1.f - mk;
+        const float kp = U.second ? 1.f - k1 : k1, up = 1.f - kp;
+        const float S = expf(U.lam_s[k]) * tanhf(o3[k] + U.bs[k]);
+        const float T_ = o3[d + k] + U.bt[k];
+        const float Q = expf(U.lam_q[k]) * tanhf(o3[2 * d + k] + U.bq[k]);
+        const float sx = sgn * eps * S, ES = expf(sx), EQ = expf(eps * Q);
+        const float tr = eps * (EQ * U.vh[n * U.ldvh + k] + T_);
+        const float zi = U.zin[n * U.ldzi + k];
+        const float nw = fwd ? zi * ES + tr : ES * (zi - tr);
+        const float zo = kp * zi + up * nw;
+        U.zout[n * U.ldzo + k] = zo;
+        if (U.xin_next != nullptr) U.xin_next[n * U.ldxn + k] = up * zo;
+        acc += up * sx;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (ok && j == 0) U.ld[n] += acc;
 }
 
 

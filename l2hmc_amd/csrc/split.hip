@@ -404,14 +404,15 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
 
   (void)hipMemcpy2DAsync(xc, sizeof(float) * L, a->x, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
   (void)hipMemcpyAsync(vc, a->v, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
-  if (!builtin) mlp3_transposes(s, dec, dws);
+  const bool have_w = (a->reuse & 1) != 0, have_auxh = (a->reuse & 2) != 0;    // still in the workspace (caller vouches)
+  if (!builtin && !have_w) mlp3_transposes(s, dec, dws);
   if (a->aux_encoder && !hmc) {      // the image branch is step-invariant: once per trajectory, not 4T times
     const L2hmcMlp3& enc = *a->aux_encoder;
     const Mlp3Ws ews = {w + p.ew1t, w + p.ew2t, w + p.ew3t, w + p.e1, nullptr, w + p.e2, nullptr};
-    mlp3_transposes(s, enc, ews);
-    mlp3_forward(s, enc, a->aux, N, ews, aux_h);
+    if (!have_w) mlp3_transposes(s, enc, ews);
+    if (!have_auxh) mlp3_forward(s, enc, a->aux, N, ews, aux_h);
   }
-  if (!hmc) {
+  if (!hmc && !have_w) {
     hipLaunchKernelGGL(k_time_table, dim3(nblk(2LL * T * H)), dim3(256), 0, s, xn, vn, a->trig, T, H, tb);
     // per net: [W1; W2]^T (H x 2d), W4^T (H x H), [Ws | Wt | Wq]^T (3d x H)
     const L2hmcNet* nets[2] = {&xn, &vn};
@@ -457,12 +458,17 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(net_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
     if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  auto net_eval = [&](const L2hmcNet& nw, int net, const float* ab, int it) {
+  // `upd`: the half-update that consumes the evaluation; fused into net_eval_kernel when that kernel runs, else the
+  // stand-alone update kernel(s) follow the three GEMMs
+  auto net_eval = [&](const L2hmcNet& nw, int net, const float* ab, int it, NetEvalArgs::Update upd) {
+    upd.bs = nw.bs; upd.bt = nw.bt; upd.bq = nw.bq; upd.lam_s = nw.lam_s; upd.lam_q = nw.lam_q;
+    upd.alpha = a->alpha; upd.eps_host = a->eps_host; upd.ld = ld; upd.masks = a->masks;
     if (ne_ok) {
       NetEvalArgs na;
       na.AB = ab; na.ldab = L; na.W12t = w + (net == 0 ? p.nx12t : p.nv12t); na.W4t = w + (net == 0 ? p.nx4t : p.nv4t);
       na.Wht = w + (net == 0 ? p.nxht : p.nvht); na.b4 = nw.b4; na.tb = tb + (long long)net * T * H; na.auxh = aux_h;
       na.dir = dir; na.dir_all = dall; na.it = it; na.T = T; na.out3 = out3; na.M = (int)N; na.d = d; na.H = H;
+      na.upd = upd;
       hipLaunchKernelGGL(net_eval_kernel, dim3((unsigned)((N + NE_MT - 1) / NE_MT)), dim3(256), ne_lds, s, na);
       return;
     }
@@ -474,6 +480,28 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     launch_gemm<EPI_BIAS_RELU>(ga, s, SHAPE_MID);
     ga = gemm_args(h2, H, w + (net == 0 ? p.nxht : p.nvht), ceil16(H), out3, 3 * d, N, 3 * d, H);
     launch_gemm<EPI_BIAS>(ga, s, SHAPE_MID);
+    if (upd.mode == 1) {
+      hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, out3, nw, upd.vin, upd.ldvi, upd.g, upd.ldg, upd.vout, upd.ldvo, ld,
+                         dir, dall, a->alpha, a->eps_host, N, d);
+      if (upd.xin != nullptr)
+        hipLaunchKernelGGL(k_mask_first, dim3(nblk(N * d)), dim3(256), 0, s, upd.x, upd.ldx, upd.xin, upd.ldxi, a->masks, dir, dall,
+                           it, T, N, d);
+    } else {
+      hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, out3, nw, upd.zin, upd.ldzi, upd.vh, upd.ldvh, upd.zout, upd.ldzo,
+                         upd.xin_next, upd.ldxn, ld, a->masks, dir, dall, it, T, upd.second, a->alpha, a->eps_host, N, d);
+    }
+  };
+  auto v_update = [&](const float* vin, int ldvi, float* vout, int ldvo, bool with_mask) {
+    NetEvalArgs::Update u = {};
+    u.mode = 1; u.vin = vin; u.ldvi = ldvi; u.g = g; u.ldg = L; u.vout = vout; u.ldvo = ldvo;
+    if (with_mask) { u.x = xc; u.ldx = L; u.xin = xin; u.ldxi = L; }
+    return u;
+  };
+  auto x_update = [&](const float* zin, int ldzi, float* zout, int ldzo, float* xin_next, int second) {
+    NetEvalArgs::Update u = {};
+    u.mode = 2; u.zin = zin; u.ldzi = ldzi; u.vh = vh; u.ldvh = L; u.zout = zout; u.ldzo = ldzo;
+    u.xin_next = xin_next; u.ldxn = L; u.second = second;
+    return u;
   };
 
   for (int k = 0; k < a->n_steps; ++k) {
@@ -485,20 +513,11 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
       hipLaunchKernelGGL(k_hmc_kick, dim3(nblk(N * d)), dim3(256), 0, s, vc, y, g, L, a->alpha, a->eps_host, N, d);
       continue;
     }
-    net_eval(vn, 1, xc, it);
-    hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, out3, vn, vc, d, g, L, vh, L, ld, dir, dall, a->alpha,
-                       a->eps_host, N, d);
-    hipLaunchKernelGGL(k_mask_first, dim3(nblk(N * d)), dim3(256), 0, s, xc, L, xin, L, a->masks, dir, dall, it, T, N, d);
-    net_eval(xn, 0, vh, it);
-    hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, out3, xn, xc, L, vh, L, y, d, xin, L, ld, a->masks, dir,
-                       dall, it, T, 0, a->alpha, a->eps_host, N, d);
-    net_eval(xn, 0, vh, it);
-    hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, out3, xn, y, d, vh, L, xc, L, (float*)nullptr, 0, ld,
-                       a->masks, dir, dall, it, T, 1, a->alpha, a->eps_host, N, d);
+    net_eval(vn, 1, xc, it, v_update(vc, d, vh, L, true));            // v_h, and xin = k1 x for the next evaluation
+    net_eval(xn, 0, vh, it, x_update(xc, L, y, d, xin, 0));            // y, xin = (1 - k1) y
+    net_eval(xn, 0, vh, it, x_update(y, d, xc, L, nullptr, 1));        // x'
     if ((rc = energy_eval(last ? U1d : nullptr))) return rc;
-    net_eval(vn, 1, xc, it);
-    hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, out3, vn, vh, L, g, L, vc, d, ld, dir, dall, a->alpha,
-                       a->eps_host, N, d);
+    net_eval(vn, 1, xc, it, v_update(vh, L, vc, d, false));            // v'
   }
   hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, vc, w + p.K1, (float*)nullptr, N, d);
   if (a->x_out) (void)hipMemcpy2DAsync(a->x_out, sizeof(float) * d, xc, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);

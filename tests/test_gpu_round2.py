@@ -244,3 +244,54 @@ def test_training_kernels_agree_on_odd_shapes(kind, d, H, T, N):
     assert abs(a[0] - b[0]) < 1e-4 * max(1.0, abs(b[0]))
     assert rel_err(a[1], b[1]) < 5e-5 and abs_err(a[2], b[2]) < 5e-5
     assert np.abs(a[3] - b[3]).max() < 3e-4 * scale, (np.abs(a[3] - b[3]).max(), scale)
+
+
+def test_split_engine_workspace_reuse_is_invisible():
+    """L2hmcSplitArgs.reuse: repeated launches skip the weight preparation and the image branch while nothing changed --
+    and redo them as soon as a parameter or the images change (in place, or a new tensor)"""
+    import torch
+    from l2hmc_amd import propose
+    g = load("vae_small")
+    N = g["x"].shape[0]
+    x, v, aux = to_dev(g["x"]), to_dev(g["v"]), to_dev(g["aux"])
+    dr, u = to_dev(g["prop.dir"]), to_dev(g["prop.u"])
+
+    def run(dyn, aux_t):
+        Lx, _, px, o = propose(x, dyn, do_mh_step=True, aux=aux_t, direction=dr, v=v, u=u)
+        return Lx.clone(), px.clone(), o[0].clone()
+
+    def same(a, b):
+        return all(torch.equal(p, q) for p, q in zip(a, b))
+    dyn = hip_dynamics(g)
+    first = run(dyn, aux)
+    assert dyn._split_key is not None
+    assert same(run(dyn, aux), first) and same(run(dyn, aux), first)          # reuse = 3 on these
+    with torch.no_grad():
+        dyn._xw["W1"].mul_(1.25)                                               # a parameter changes (version counter)
+        dyn._xw["aux_encoder"]["W3"].mul_(0.5)
+    fresh = hip_dynamics(g)
+    with torch.no_grad():
+        fresh._xw["W1"].mul_(1.25)
+        fresh._xw["aux_encoder"]["W3"].mul_(0.5)
+    want = run(fresh, aux)
+    assert not same(want, first)
+    assert same(run(dyn, aux), want)
+    aux2 = aux.clone()
+    aux2[:, ::3] = 1.0 - aux2[:, ::3]                                          # other images, another tensor
+    want2 = run(fresh, aux2)
+    assert not same(want2, want) and same(run(dyn, aux2), want2)
+    aux2[:, 1::3] = 1.0 - aux2[:, 1::3]                                        # ... and the same tensor modified in place
+    assert same(run(dyn, aux2), run(hip_dynamics_like(fresh, g), aux2))
+
+
+def hip_dynamics_like(src, g):
+    """a fresh Dynamics with the weights `src` holds now"""
+    import torch
+    dyn = hip_dynamics(g)
+    with torch.no_grad():
+        for a, b in ((dyn._xw, src._xw), (dyn._vw, src._vw)):
+            for k in ("W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4", "Ws", "bs", "Wt", "bt", "Wq", "bq", "lam_s", "lam_q"):
+                a[k].copy_(b[k])
+        for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
+            dyn._xw["aux_encoder"][k].copy_(src._xw["aux_encoder"][k])
+    return dyn
