@@ -51,7 +51,7 @@ struct GemmArgs {
   float* C2; int ldc2;           // second output (sigmoid / raw product / second tangent term) or NULL
   const float* E2; int lde2;     // EPI_TAN: third operand
   int accum;                     // EPI_MUL: C += instead of C =
-  float* rowsum; int n_tiles;    // EPI_BCE: (M, 2 * n_tiles) partial sums, one per (column tile, wave column)
+  float* rowsum; int n_tiles;    // EPI_BCE: (M, bce_partials) partial sums, one per (column tile, wave column)
   float beta;                    // EPI_BCE scale
   // EPI_NET1
   const float* tb;               // (T, N) time/bias table of this net
@@ -106,14 +106,17 @@ __device__ __forceinline__ f4 load_kquad(const float* p, int k, int K) {
 // WMB x WNB: 16 x 16 MFMA tiles per wave along m and n; the 2 x 2 waves of a workgroup cover a
 // (32 WMB) x (32 WNB) tile of C.  4 x 4 (128 x 128) for the big decoder products, 2 x 2 (64 x 64) for the
 // H = 200 net layers (fills the chip at M = 8192), 1 x 2 (32 x 64) for the N = d = 50 latent gradient.
-template <int EPI, int KV, int WMB, int WNB>
+// WAVES_N: how the 4 waves tile the workgroup's block -- 2 x 2 (default) or 4 x 1 (each wave spans the whole width
+// 16 WNB: the 112-wide tiles that divide the decoder's 784 logits exactly)
+template <int EPI, int KV, int WMB, int WNB, int WAVES_N = 2>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
-  constexpr int TM = 32 * WMB, TN = 32 * WNB;
+  constexpr int WAVES_M = 4 / WAVES_N;
+  constexpr int TM = 16 * WMB * WAVES_M, TN = 16 * WNB * WAVES_N;
   __shared__ __attribute__((aligned(16))) float sA[2][TM * GP];   // activations  [m][k]
   __shared__ __attribute__((aligned(16))) float sB[2][TN * GP];   // weights      [n][k]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int wm = (w >> 1) * 16 * WMB, wn = (w & 1) * 16 * WNB;    // this wave's quadrant
+  const int wm = (w / WAVES_N) * 16 * WMB, wn = (w % WAVES_N) * 16 * WNB;    // this wave's block
   const long long m0 = (long long)blockIdx.y * TM;
   const int n0 = blockIdx.x * TN;
 
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
       const long long m = m0 + wm + 16 * j + c;
-      if (q == 0 && m < g.M) g.rowsum[m * (2 * g.n_tiles) + 2 * blockIdx.x + (w & 1)] = g.beta * s;
+      if (q == 0 && m < g.M) g.rowsum[m * (WAVES_N * g.n_tiles) + WAVES_N * blockIdx.x + (w % WAVES_N)] = g.beta * s;
     }
   }
 }
@@ -615,32 +618,41 @@ inline void launch_gemm_tn(hipStream_t s, const float* A, int lda, const float* 
 }
 
 // rowsum layout of EPI_BCE: (M, 2 * n_tiles) with n_tiles = ceil(N / (32 WNB)) of the shape the launcher picks
-template <int EPI, int WMB, int WNB>
+template <int EPI, int WMB, int WNB, int WAVES_N = 2>
 int launch_gemm_shape(const GemmArgs& g, hipStream_t s) {
-  const dim3 grid((unsigned)((g.N + 32 * WNB - 1) / (32 * WNB)), (unsigned)((g.M + 32 * WMB - 1) / (32 * WMB)));
+  constexpr int TM = 16 * WMB * (4 / WAVES_N), TN = 16 * WNB * WAVES_N;
+  const dim3 grid((unsigned)((g.N + TN - 1) / TN), (unsigned)((g.M + TM - 1) / TM));
   const bool al16 = ((reinterpret_cast<size_t>(g.A) | reinterpret_cast<size_t>(g.B)) & 15) == 0;
   const bool al8 = ((reinterpret_cast<size_t>(g.A) | reinterpret_cast<size_t>(g.B)) & 7) == 0;
   if (g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && al16)
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, WMB, WNB>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, WMB, WNB, WAVES_N>), grid, dim3(256), 0, s, g);
   else if (g.K % 2 == 0 && g.lda % 2 == 0 && g.ldb % 2 == 0 && al8)
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, WMB, WNB>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, WMB, WNB, WAVES_N>), grid, dim3(256), 0, s, g);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, 1, WMB, WNB>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, 1, WMB, WNB, WAVES_N>), grid, dim3(256), 0, s, g);
   return L2HMC_OK;
 }
 
-enum { SHAPE_BIG = 0, SHAPE_MID = 1, SHAPE_SKINNY = 2, SHAPE_AUTO = 3 };     // 128 x 128, 64 x 64, 32 x 64 workgroup tiles
-inline int gemm_tile_n(int shape) { return shape == SHAPE_BIG ? 128 : 64; }
+// 128 x 128, 64 x 64, 32 x 64 workgroup tiles; SHAPE_W112: 128 x 112 (4 x 1 waves of 2 x 7 MFMA tiles) for widths that
+// are multiples of 112 but not of 128 -- the decoder's 784 = 7 x 112 logits, where 128-wide tiles waste 1/8 of the work
+enum { SHAPE_BIG = 0, SHAPE_MID = 1, SHAPE_SKINNY = 2, SHAPE_AUTO = 3, SHAPE_W112 = 4 };
+inline int gemm_tile_n(int shape) { return shape == SHAPE_BIG ? 128 : (shape == SHAPE_W112 ? 112 : 64); }
+inline int gemm_waves_n(int shape) { return shape == SHAPE_W112 ? 1 : 2; }
 // 128 x 128 tiles when they fill the 256 CUs, else 64 x 64 (a 512-chain batch -- the reference's training batch -- gives
 // only 4 x 8 big tiles of a 1024-wide layer)
 inline int gemm_auto_shape(long long M, int N) {
-  return ((M + 127) / 128) * ((N + 127) / 128) >= 192 ? SHAPE_BIG : SHAPE_MID;
+  if (((M + 127) / 128) * ((N + 127) / 128) < 192) return SHAPE_MID;
+  return (N % 112 == 0 && N % 128 != 0) ? SHAPE_W112 : SHAPE_BIG;
 }
 
 template <int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t s, int shape = SHAPE_AUTO) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return L2HMC_OK;
   if (shape == SHAPE_AUTO) shape = gemm_auto_shape(g.M, g.N);
+  if (shape == SHAPE_W112) {
+    if (EPI == EPI_BCE || EPI == EPI_MUL) return launch_gemm_shape<EPI == EPI_BCE ? EPI_BCE : EPI_MUL, 2, 7, 1>(g, s);
+    shape = SHAPE_BIG;                      // (only the logits-shaped products are instantiated for it)
+  }
   if (shape == SHAPE_BIG) return launch_gemm_shape<EPI, 4, 4>(g, s);
   if (shape == SHAPE_MID) return launch_gemm_shape<EPI, 2, 2>(g, s);
   return launch_gemm_shape<EPI, 1, 2>(g, s);

@@ -243,6 +243,7 @@ void mlp3_forward(hipStream_t s, const L2hmcMlp3& m, const float* x, long long N
 
 // column tiles of the logits GEMM (EPI_BCE leaves 2 row partials per tile): the shape launch_gemm picks for (N, n_pix)
 inline int bce_tiles(long long N, int n_pix) { return (n_pix + gemm_tile_n(gemm_auto_shape(N, n_pix)) - 1) / gemm_tile_n(gemm_auto_shape(N, n_pix)); }
+inline int bce_partials(long long N, int n_pix) { return gemm_waves_n(gemm_auto_shape(N, n_pix)) * bce_tiles(N, n_pix); }   // per chain
 inline int bce_tiles_max(int n_pix) { return (n_pix + 63) / 64; }
 
 // U (N) and grad (N x d, row stride ldg) of the VAE latent posterior at z (row stride ldz) (mnist_vae.py:122-126):
@@ -255,7 +256,7 @@ void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const flo
   g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = beta;
   launch_gemm<EPI_BCE>(g, s);                                     // lg := beta (sigmoid(logit) - aux)
   if (U != nullptr || Ud != nullptr)
-    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles(N, dec.n_out), z, ldz, d, U, Ud, N);
+    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, bce_partials(N, dec.n_out), z, ldz, d, U, Ud, N);
   if (grad == nullptr) return;
   // d a2 = dl W3^T (.) sigmoid(p2);  d a1 = d a2 W2^T (.) sigmoid(p1);  d z = d a1 W1^T + z
   g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);

@@ -505,7 +505,7 @@ void vae_energy_keep(hipStream_t s, const L2hmcMlp3& dec, const float* aux, cons
   g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = 1.f;
   launch_gemm<EPI_BCE>(g, s);
   if (Ud != nullptr)
-    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles(N, dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
+    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, bce_partials(N, dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
   const long long npix = N * dec.n_out;
   hipLaunchKernelGGL(k_sigd, dim3(nblk(npix)), dim3(256), 0, s, lg, aux, pt.rd, npix);
   g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);
