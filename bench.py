@@ -161,6 +161,65 @@ def cpu_baseline(prob, budget_s=20.0):
                          "sample": "C1 SCG-2D, 200 chains, N x N energy: %d proposals in %.1f s" % (r3, e3)}}
 
 
+def config5_leg(dev, chains=8192):
+    """BASELINE.json config 5 on the GEMM engine, inside the bench run (an extra key, not the bench line): the VAE latent
+    posterior (decoder 50 -> 1024 -> 1024 -> 784, mnist_vae.py:104-126) under the H = 200 S/T/Q nets with the shared
+    image branch (:128-178), Lf = 5, 8192 chains, random weights / Bernoulli(0.13) images (no checkpoint or MNIST
+    offline).  (i) sampling: propose + MH per step; (ii) the sampler's training step of mnist_vae.py:185-262 with one
+    differentiated proposal (`l2hmc_train_split_grad` + clipped Adam).  HIP-event times on torch's stream, which is the
+    stream these launches go to."""
+    import torch
+    from l2hmc_amd import Dynamics, propose, vae
+    from l2hmc_amd.training import Trainer
+    d, H, T = 50, 200, 5
+    torch.manual_seed(0)
+    np.random.seed(0)
+    decoder = vae.make_decoder(d, 1024, 784)
+    enc = vae.make_encoder_sampler(784, 512, H)
+    dyn = Dynamics(d, vae.VAEPosterior(decoder).get_energy_function(), T=T, eps=0.1,
+                   net_factory=vae.sampler_net_factory(d, enc, H, H))
+    gen = torch.Generator(device=dev).manual_seed(0)
+    dyn.generator = gen
+    aux = (torch.rand((chains, 784), device=dev, generator=gen) < 0.13).float()
+    x = torch.randn((chains, d), device=dev, generator=gen)
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+
+    state = {"x": x, "p": None}
+
+    def one_proposal():
+        _, _, px, out = propose(state["x"], dyn, do_mh_step=True, aux=aux)
+        state["x"], state["p"] = out[0], px
+    ms_prop = timed(one_proposal, 3, 12)
+    f_net = 2 * (2 * d * H + H * H + 3 * d * H)
+    f_dec = 2 * (d * 1024 + 1024 * 1024 + 1024 * 784)
+    flops_step = 4 * f_net + (1 + 1.0 / T) * 2 * f_dec                      # SURVEY 8(d): per chain . leapfrog step
+    ach = chains * T * flops_step / (ms_prop * 1e-3) / 1e12
+    tr = Trainer(dyn, decay_steps=0)
+    log_sigma = torch.full((chains, d), -0.5, device=dev)
+    ms_train = timed(lambda: tr.sampler_step(state["x"], aux, log_sigma, MH=1), 2, 4)
+    flops_train = 3 * 4 * T * f_net + (T + 1) * 4 * f_dec                      # forward + input & weight gradients + HVPs
+    return {"workload": "config 5: VAE latent posterior d=50, decoder 1024/1024/784, H=200 nets + image branch, "
+                        "%d chains, Lf=5, random weights, synthetic images" % chains,
+            "kernels": "gemm_nt_kernel (fused epilogues), net_eval_kernel (+ fused half-updates), gemm_tn_kernel (training)",
+            "ms_per_proposal": ms_prop, "value": chains * T / (ms_prop * 1e-3), "unit": "chain\u00b7leapfrog-steps/s",
+            "flops_per_chain_step": flops_step, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "frac": ach / PEAK_F32_MFMA_TFLOPS,
+            "mean_accept_prob": float(state["p"].mean()),
+            "train": {"workload": "sampler update of mnist_vae.py:185-262, one differentiated proposal per step",
+                      "ms_per_step": ms_train, "flops_per_chain": flops_train,
+                      "achieved": chains * flops_train / (ms_train * 1e-3) / 1e12,
+                      "frac": chains * flops_train / (ms_train * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
+
+
 def ess_leg(dev, train_steps=5000, seeds=5):
     """ESS/sec on the notebook's SCG-2D target (BASELINE.json configs[0] shape: 200 chains, Lf=10):
     (i) the HMC(eps=0.15) sampler whose ESS the reference publishes (nb raw 388: 5.63e-3 per MH step);
@@ -313,6 +372,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true", help="skip the SCG-2D ESS/sec leg (N=1) / the dist leg (N>1)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 65 536-chain roofline point (N=1 only)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (VAE engine) extra key (N=1 only)")
     ap.add_argument("--ess-train-steps", type=int, default=5000,
                     help="Adam steps for the L2HMC sampler of the ESS leg (0 = HMC only)")
     ap.add_argument("--ess-seeds", type=int, default=5, help="independent trainings of the ESS leg")
@@ -534,6 +594,8 @@ def main():
                               "value": nc * T * 100.0 * reps / el2, "achieved": a2,
                               "frac": a2 / PEAK_F32_MFMA_TFLOPS, "launch_us": 1e3 * ms2 / nl2})
             out["sweep"] = sweep
+        if world == 1 and not args.no_config5 and not strong and n == CHAINS and not args.force_dist:
+            out["config5"] = config5_leg(dev)
         if world == 1 and not args.no_ess and not args.force_dist:
             out["ess"] = ess_leg(dev, args.ess_train_steps, args.ess_seeds)
         if dist_out is not None:
