@@ -319,14 +319,16 @@ __host__ __device__ inline int odd_quarter_stride(int k) {   // smallest multipl
   if (((p / 4) & 1) == 0) p += 4;
   return p;
 }
-constexpr int NE_MT = 16;
 constexpr int NE_MAXKT = 16;       // k-tiles per layer the kernel is compiled for: K <= 256
-inline size_t net_eval_lds_bytes(int d, int H) {       // input tile, two hidden activations, head products
-  return sizeof(float) * NE_MT * (size_t)(odd_quarter_stride(ceil16(2 * d)) + 2 * odd_quarter_stride(ceil16(H)) + ceil16(3 * d));
+// CB = chain blocks (of 16) per workgroup: every weight fragment fetched from L2 feeds CB MFMAs
+inline size_t net_eval_lds_bytes(int d, int H, int CB = 1) {       // input tile, two hidden activations, head products
+  return sizeof(float) * 16 * CB * (size_t)(odd_quarter_stride(ceil16(2 * d)) + 2 * odd_quarter_stride(ceil16(H)) + ceil16(3 * d));
 }
 
-__global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
+template <int CB>
+__global__ __launch_bounds__(256, CB == 1 ? 2 : 1) void net_eval_kernel(const NetEvalArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NE_MT = 16 * CB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int K1 = 2 * g.d, H = g.H, K1p = ceil16(K1), Hp = ceil16(H);
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
   float* sIn = sm;
   float* sH1 = sIn + NE_MT * ld1;
   float* sH2 = sH1 + NE_MT * ldh;
-  float* sOut = sH2 + NE_MT * ldh;                       // (16, ceil16(3 d)) head products of the fused update
+  float* sOut = sH2 + NE_MT * ldh;                       // (NE_MT, ceil16(3 d)) head products of the fused update
   const int ldo = ceil16(3 * g.d);
   const long long m0 = (long long)blockIdx.x * NE_MT;
 
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
   }
   __syncthreads();
 
-  // one layer: C[m][n] = sum_k As[m][k] Wt[n][k] over the padded Kp; epi(nb, acc): lane holds C[m = c][n = 16 nb + 4 q + r]
+  // one layer: C[m][n] = sum_k As[m][k] Wt[n][k] over the padded Kp; epi(nb, cb, acc): lane holds
+  // C[m = 16 cb + c][n = 16 nb + 4 q + r]
   auto layer = [&](const float* As, int ldA, int Kp, const float* Wt, int Np, auto&& epi) {
     const int nk = Kp >> 4;
     for (int nb = w; nb * 16 < Np; nb += 4) {
@@ -360,64 +363,76 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
 #pragma unroll
       for (int j = 0; j < NE_MAXKT; ++j)
         if (j < nk) wf[j] = *reinterpret_cast<const f4*>(wrow + j * 16);
-      f4 acc = splat(0.f);
+      f4 acc[CB];
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[cb] = splat(0.f);
 #pragma unroll
       for (int j = 0; j < NE_MAXKT; ++j) {
         if (j < nk) {
-          const f4 af = *reinterpret_cast<const f4*>(As + c * ldA + j * 16 + 4 * q);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = MFMA16(wf[j][s], af[s], acc);
+          for (int cb = 0; cb < CB; ++cb) {
+            const f4 af = *reinterpret_cast<const f4*>(As + (16 * cb + c) * ldA + j * 16 + 4 * q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[cb] = MFMA16(wf[j][s], af[s], acc[cb]);
+          }
         }
       }
-      epi(nb, acc);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) epi(nb, cb, acc[cb]);
     }
   };
   auto relu4f = [](f4 p) { return f4{fmaxf(p.x, 0.f), fmaxf(p.y, 0.f), fmaxf(p.z, 0.f), fmaxf(p.w, 0.f)}; };
-  const long long m = m0 + c;
-  const bool mok = m < g.M;
-  int trow = 0;
-  if (mok) {
-    const bool fwd = g.dir != nullptr ? g.dir[m] != 0 : (g.dir_all != 0);
-    trow = fwd ? g.it : (g.T - 1 - g.it);
+  bool mok[CB];
+  int trow[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const long long m = m0 + 16 * cb + c;
+    mok[cb] = m < g.M;
+    trow[cb] = 0;
+    if (mok[cb]) {
+      const bool fwd = g.dir != nullptr ? g.dir[m] != 0 : (g.dir_all != 0);
+      trow[cb] = fwd ? g.it : (g.T - 1 - g.it);
+    }
   }
 
-  layer(sIn, ld1, K1p, g.W12t, Hp, [&](int nb, f4 v) {
+  layer(sIn, ld1, K1p, g.W12t, Hp, [&](int nb, int cb, f4 v) {
     const int n = nb * 16 + 4 * q;
     if (n >= H) return;                                        // (H % 4 == 0)
     f4 t = splat(0.f), e = splat(0.f);
-    if (mok) {
-      t = *reinterpret_cast<const f4*>(g.tb + (long long)trow * H + n);
-      if (g.auxh != nullptr) e = *reinterpret_cast<const f4*>(g.auxh + m * H + n);
+    if (mok[cb]) {
+      t = *reinterpret_cast<const f4*>(g.tb + (long long)trow[cb] * H + n);
+      if (g.auxh != nullptr) e = *reinterpret_cast<const f4*>(g.auxh + (m0 + 16 * cb + c) * H + n);
     }
-    *reinterpret_cast<f4*>(sH1 + c * ldh + n) = relu4f(v + t + e);
+    *reinterpret_cast<f4*>(sH1 + (16 * cb + c) * ldh + n) = relu4f(v + t + e);
   });
   __syncthreads();
-  layer(sH1, ldh, Hp, g.W4t, Hp, [&](int nb, f4 v) {
+  layer(sH1, ldh, Hp, g.W4t, Hp, [&](int nb, int cb, f4 v) {
     const int n = nb * 16 + 4 * q;
     if (n >= H) return;
-    *reinterpret_cast<f4*>(sH2 + c * ldh + n) = relu4f(v + *reinterpret_cast<const f4*>(g.b4 + n));
+    *reinterpret_cast<f4*>(sH2 + (16 * cb + c) * ldh + n) = relu4f(v + *reinterpret_cast<const f4*>(g.b4 + n));
   });
   __syncthreads();
   const int N3 = 3 * g.d;
   const int mode = g.upd.mode;
-  layer(sH2, ldh, Hp, g.Wht, ceil16(N3), [&](int nb, f4 v) {
+  layer(sH2, ldh, Hp, g.Wht, ceil16(N3), [&](int nb, int cb, f4 v) {
     const int n = nb * 16 + 4 * q;
     if (mode != 0) {                                         // (n + 3 < ceil16(3 d) = ldo always)
-      *reinterpret_cast<f4*>(sOut + c * ldo + n) = v;
+      *reinterpret_cast<f4*>(sOut + (16 * cb + c) * ldo + n) = v;
       return;
     }
-    if (!mok) return;
-    float* o = g.out3 + m * N3 + n;
+    if (!mok[cb]) return;
+    float* o = g.out3 + (m0 + 16 * cb + c) * N3 + n;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (n + r < N3) o[r] = v[r];
   });
   if (mode == 0) return;
   __syncthreads();
-  // ---- fused half-update: 16 threads per chain, dimensions strided by 16; the chain's log-det share is reduced over
-  // its 16 lanes in a fixed order
+  // ---- fused half-update: TPC = 16 / CB threads per chain, dimensions strided by TPC; the chain's log-det share is
+  // reduced over its TPC lanes in a fixed order
   const NetEvalArgs::Update& U = g.upd;
-  const int r = tid >> 4, j = tid & 15;
+  constexpr int TPC = 16 / CB;
+  const int r = tid / TPC, j = tid % TPC;
   const long long n = m0 + r;
   const bool ok = n < g.M;
   const int d = g.d;
@@ -433,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
   if (ok) {
     if (mode == 1) {
       const float heps = 0.5f * eps;
-      for (int k = j; k < d; k += 16) {
+      for (int k = j; k < d; k += TPC) {
         const float S = expf(U.lam_s[k]) * tanhf(o3[k] + U.bs[k]);
         const float T_ = o3[d + k] + U.bt[k];
         const float Q = expf(U.lam_q[k]) * tanhf(o3[2 * d + k] + U.bq[k]);
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
         }
       }
     } else {
-      for (int k = j; k < d; k += 16) {
+      for (int k = j; k < d; k += TPC) {
         const float mk = U.masks[srow * d + k];
         const float k1 = fwd ? mk : 1.f - mk;
         const float kp = U.second ? 1.f - k1 : k1, up = 1.f - kp;
@@ -467,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
     }
   }
 #pragma unroll
-  for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  for (int off = TPC / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if (ok && j == 0) U.ld[n] += acc;
 }
 

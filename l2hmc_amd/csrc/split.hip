@@ -453,10 +453,14 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   // one net evaluation: out3 = relu(relu([a | b] [W1; W2] + time + aux_h) W4 + b4) [Ws|Wt|Wq]   (the head biases are
   // added by the update kernels).  H % 4 == 0 and d even: ONE launch of net_eval_kernel (activations resident in
   // LDS); otherwise three GEMMs with fused epilogues on 64 x 64 tiles.
-  const size_t ne_lds = net_eval_lds_bytes(d, H);
+  // (32 chains per workgroup -- every weight fragment streamed from L2 feeding two MFMAs, net_eval_kernel<2> -- was
+  //  measured at 8192 chains: 88 KB of LDS leave one workgroup per CU and the evaluation gets 25 % slower: 16 it is)
+  const int ne_cb = 1;
+  const size_t ne_lds = net_eval_lds_bytes(d, H, ne_cb);
   const bool ne_ok = (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(2 * d) <= 16 * NE_MAXKT && ne_lds <= 160 * 1024;
   if (ne_ok && !hmc && ne_lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(net_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
+    hipError_t e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_eval_kernel<2>) : reinterpret_cast<const void*>(net_eval_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
     if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   // `upd`: the half-update that consumes the evaluation; fused into net_eval_kernel when that kernel runs, else the
@@ -470,7 +474,9 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
       na.Wht = w + (net == 0 ? p.nxht : p.nvht); na.b4 = nw.b4; na.tb = tb + (long long)net * T * H; na.auxh = aux_h;
       na.dir = dir; na.dir_all = dall; na.it = it; na.T = T; na.out3 = out3; na.M = (int)N; na.d = d; na.H = H;
       na.upd = upd;
-      hipLaunchKernelGGL(net_eval_kernel, dim3((unsigned)((N + NE_MT - 1) / NE_MT)), dim3(256), ne_lds, s, na);
+      const unsigned blocks = (unsigned)((N + 16 * ne_cb - 1) / (16 * ne_cb));
+      if (ne_cb == 2) hipLaunchKernelGGL(net_eval_kernel<2>, dim3(blocks), dim3(256), ne_lds, s, na);
+      else hipLaunchKernelGGL(net_eval_kernel<1>, dim3(blocks), dim3(256), ne_lds, s, na);
       return;
     }
     GemmArgs ga = gemm_args(ab, L, w + (net == 0 ? p.nx12t : p.nv12t), ceil16(L), h1, H, N, H, L);
