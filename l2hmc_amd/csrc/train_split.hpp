@@ -300,50 +300,85 @@ __global__ void k_train_dx0(const float* lx, const float* x0, const float* x1, i
 }
 
 // ---- chunked column sums (fixed order): part[chunk][col] = sum over the chunk's rows of A[r][col] ----------------
-// block = 64 columns x 4 row lanes; the 4 row lanes are added in order through LDS
+// block = 16 column quads (64 columns) x 16 row lanes; a thread adds its rows of one column quad (dwordx4 when the
+// rows are 16-byte aligned), the 16 row lanes are then added in lane order through LDS.  A streaming read: the
+// chunking (colsum_chunks) makes enough blocks to pull it at HBM speed.
+template <bool V4>
 __global__ __launch_bounds__(256) void k_colsum_part(const float* A, int lda, long long R, int cols,
                                                      long long rows_per_chunk, float* part) {
-  __shared__ float sm[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cx;
+  __shared__ f4 sm[16][16];
+  const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cq;
   const long long r0 = (long long)blockIdx.y * rows_per_chunk;
   long long r1 = r0 + rows_per_chunk;
   if (r1 > R) r1 = R;
-  float s = 0.f;
-  if (col < cols)
-    for (long long r = r0 + ry; r < r1; r += 4) s += A[r * lda + col];
-  sm[ry][cx] = s;
+  f4 s = splat(0.f);
+  if (col < cols) {
+    if (V4 && col + 3 < cols) {
+#pragma unroll 4
+      for (long long r = r0 + ry; r < r1; r += 16) s = s + *reinterpret_cast<const f4*>(A + r * lda + col);
+    } else {
+      for (long long r = r0 + ry; r < r1; r += 16) {
+        const float* p = A + r * lda + col;
+        s.x += p[0];
+        if (col + 1 < cols) s.y += p[1];
+        if (col + 2 < cols) s.z += p[2];
+        if (col + 3 < cols) s.w += p[3];
+      }
+    }
+  }
+  sm[ry][cq] = s;
   __syncthreads();
-  if (ry == 0 && col < cols) part[(long long)blockIdx.y * cols + col] = ((sm[0][cx] + sm[1][cx]) + sm[2][cx]) + sm[3][cx];
+  if (ry == 0 && col < cols) {
+    f4 t = sm[0][cq];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) t = t + sm[i][cq];
+    float* o = part + (long long)blockIdx.y * cols + col;
+    o[0] = t.x;
+    if (col + 1 < cols) o[1] = t.y;
+    if (col + 2 < cols) o[2] = t.z;
+    if (col + 3 < cols) o[3] = t.w;
+  }
 }
-// d W3 (2, H): rows are weighted with the time encoding of the row's schedule step.  Row r of a net's stash is
-// (evaluation e = r / N, chain n = r % N); evaluation e belongs to leapfrog iteration e / 2.
-__global__ __launch_bounds__(256) void k_w3_part(const float* A, int H, long long N, long long R, long long rows_per_chunk,
+// d W3 (2, H): the rows of A = d h1_pre are weighted with the time encoding of their schedule step.  A net's stash is
+// (evaluation e, chain n); evaluation e belongs to leapfrog iteration e / 2, whose schedule row depends on the chain's
+// direction only: blockIdx.y = e * cpe + (row chunk within the evaluation).  part[blockIdx.y][2][H].
+__global__ __launch_bounds__(256) void k_w3_part(const float* A, int H, long long N, int cpe, long long rows_per_chunk,
                                                  const float* trig, int T, const unsigned char* dir, int dir_all,
                                                  float* part) {
-  __shared__ float sm[2][4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cx;
-  const long long r0 = (long long)blockIdx.y * rows_per_chunk;
-  long long r1 = r0 + rows_per_chunk;
-  if (r1 > R) r1 = R;
-  float sc = 0.f, ss = 0.f;
+  __shared__ f4 sm[2][16][16];
+  const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cq;                 // (H % 4 == 0 is not assumed: tail columns are guarded)
+  const int e = blockIdx.y / cpe, ch = blockIdx.y % cpe, it = e >> 1;
+  const long long n0 = (long long)ch * rows_per_chunk;
+  long long n1 = n0 + rows_per_chunk;
+  if (n1 > N) n1 = N;
+  const float cf = trig[2 * it], sf = trig[2 * it + 1], cb = trig[2 * (T - 1 - it)], sb = trig[2 * (T - 1 - it) + 1];
+  f4 sc = splat(0.f), ss = splat(0.f);
   if (col < H)
-    for (long long r = r0 + ry; r < r1; r += 4) {
-      const long long e = r / N, n = r - e * N;
-      bool fwd;
-      const int s = row_of(dir, dir_all, n, (int)(e >> 1), T, fwd);
-      const float a = A[r * H + col];
-      sc += trig[2 * s] * a;
-      ss += trig[2 * s + 1] * a;
+    for (long long n = n0 + ry; n < n1; n += 16) {
+      const bool fwd = dir != nullptr ? dir[n] != 0 : (dir_all != 0);
+      const float* p = A + ((long long)e * N + n) * H + col;
+      f4 a = splat(0.f);
+      a.x = p[0];
+      if (col + 1 < H) a.y = p[1];
+      if (col + 2 < H) a.z = p[2];
+      if (col + 3 < H) a.w = p[3];
+      sc = sc + (fwd ? cf : cb) * a;
+      ss = ss + (fwd ? sf : sb) * a;
     }
-  sm[0][ry][cx] = sc;
-  sm[1][ry][cx] = ss;
+  sm[0][ry][cq] = sc;
+  sm[1][ry][cq] = ss;
   __syncthreads();
-  if (ry == 0 && col < H) {
-    float* o = part + (long long)blockIdx.y * 2 * H;
-    o[col] = ((sm[0][0][cx] + sm[0][1][cx]) + sm[0][2][cx]) + sm[0][3][cx];
-    o[H + col] = ((sm[1][0][cx] + sm[1][1][cx]) + sm[1][2][cx]) + sm[1][3][cx];
+  if (ry < 2 && col < H) {
+    f4 t = sm[ry][0][cq];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) t = t + sm[ry][i][cq];
+    float* o = part + ((long long)blockIdx.y * 2 + ry) * H + col;
+    o[0] = t.x;
+    if (col + 1 < H) o[1] = t.y;
+    if (col + 2 < H) o[2] = t.z;
+    if (col + 3 < H) o[3] = t.w;
   }
 }
 // dst[i] = sum_e X[e][i] + sum_e V[e][i]  (the image branch feeds the first hidden layer of every evaluation)
@@ -419,7 +454,9 @@ inline void colsum_into(hipStream_t s, const float* A, int lda, long long R, int
   int nc;
   long long rpc;
   colsum_chunks(R, cols, part_cap, nc, rpc);
-  hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)((cols + 63) / 64), (unsigned)nc), dim3(256), 0, s, A, lda, R, cols, rpc, part);
+  const bool v4 = lda % 4 == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(k_colsum_part<true>, dim3((unsigned)((cols + 63) / 64), (unsigned)nc), dim3(256), 0, s, A, lda, R, cols, rpc, part);
+  else hipLaunchKernelGGL(k_colsum_part<false>, dim3((unsigned)((cols + 63) / 64), (unsigned)nc), dim3(256), 0, s, A, lda, R, cols, rpc, part);
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, part, nc, cols, dst0, dst1, dst2,
                      jblock, jstride);
 }
@@ -814,10 +851,13 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     colsum_into(s, dzs, 3 * d, R, 3 * d, G + o.bs, nullptr, nullptr, d, o.bt - o.bs, part, p.part_cap);
     colsum_into(s, dl, L, R, L, G + o.ls, nullptr, nullptr, d, o.lq - o.ls, part, p.part_cap);
     {
-      int nc;
-      long long rpc;
-      colsum_chunks(R, 2 * H, p.part_cap, nc, rpc);
-      hipLaunchKernelGGL(k_w3_part, dim3((unsigned)((H + 63) / 64), (unsigned)nc), dim3(256), 0, s, da1, H, N, R, rpc, a->trig, T,
+      // chunks per evaluation: ~ 128 blocks x column blocks in total, within the partial buffer
+      int cpe = (int)((128 + 2 * T - 1) / (2 * T));
+      if ((long long)cpe * 2 * T * 2 * H > p.part_cap) cpe = (int)(p.part_cap / (4LL * T * H));
+      if (cpe < 1) cpe = 1;
+      const long long rpc = (N + cpe - 1) / cpe;
+      const int nc = 2 * T * cpe;
+      hipLaunchKernelGGL(k_w3_part, dim3((unsigned)((H + 63) / 64), (unsigned)nc), dim3(256), 0, s, da1, H, N, cpe, rpc, a->trig, T,
                          dir, dall, part);
       hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((2 * H + 255) / 256)), dim3(256), 0, s, part, nc, 2, H, G + o.W3, H, 1,
                          TnScatter{2, 0, H, 0});
