@@ -2,7 +2,8 @@
 (`accept` :33-42, `autocovariance` :45-54, `acl_spectrum` :114-116, `ESS` :118-120) on recorded
 chains of shape (steps, chains, dim).  numpy input -> numpy arithmetic exactly like the
 reference; a ROCm tensor (e.g. the `x_hist` of `sample_chain`) -> the HIP kernel `l2hmc_autocov`,
-the history never leaves the GPU.  The MNIST/VAE helpers of that file are out of scope."""
+the history never leaves the GPU.  Also the small host-side helpers the VAE programs import from that file (`binarize`,
+`binarize_and_shuffle`, `normal_kl`, `get_log_likelihood`, `tf_accept`); `get_data` (MNIST download) is out of scope."""
 import numpy as np
 
 
@@ -65,3 +66,43 @@ def ESS(A):
     A = np.asarray(A)
     kept = np.where(A > 0.05, A, 0.0)
     return 1. / (1. + 2 * np.sum(kept[1:]))
+
+
+# ---- the small host-side helpers of utils/func_utils.py the VAE programs import (mnist_vae.py:29-30) ----------------
+def binarize(x, rng=None):
+    """func_utils.py:69-71: Bernoulli draw of every pixel intensity in [0, 1]."""
+    x = np.asarray(x)
+    if x.size and x.max() > 1.:
+        raise ValueError("binarize expects intensities in [0, 1]")
+    return ((np.random if rng is None else rng).random_sample(x.shape) < x).astype(np.float32)
+
+
+def binarize_and_shuffle(x, rng=None):
+    """func_utils.py:98-109: rows permuted, then binarized."""
+    r = np.random if rng is None else rng
+    x = np.asarray(x)
+    return binarize(x[r.permutation(x.shape[0]), :], rng)
+
+
+def normal_kl(q_means, q_stddevs, p_means, p_stddevs):
+    """func_utils.py:77-96: KL(q || p) of diagonal normals, summed over the last dimension (torch tensors or numpy)."""
+    import torch
+    t = torch if any(isinstance(a, torch.Tensor) for a in (q_means, q_stddevs, p_means, p_stddevs)) else np
+    as_t = (lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(a, dtype=torch.float32)) if t is torch \
+        else (lambda a: np.asarray(a, dtype=np.float64))
+    qm, qs, pm, ps = (as_t(a) for a in (q_means, q_stddevs, p_means, p_stddevs))
+    q_entropy = 0.5 + t.log(qs)
+    cross = 0.5 * (qs / ps) ** 2 + 0.5 * ((qm - pm) / ps) ** 2 + t.log(ps)
+    return (cross - q_entropy).sum(-1)
+
+
+def get_log_likelihood(X, gaussian):
+    """func_utils.py:59-61: mean log-density of the rows of X under the target Gaussian."""
+    from scipy.stats import multivariate_normal
+    return multivariate_normal(mean=gaussian.mu, cov=gaussian.sigma).logpdf(np.asarray(X)).mean()
+
+
+def tf_accept(x, Lx, px, u=None, dynamics=None):
+    """func_utils.py:73-75 (the same function as utils/sampler.py:53-55)."""
+    from .sampler import tf_accept as _tf_accept
+    return _tf_accept(x, Lx, px, u=u, dynamics=dynamics)

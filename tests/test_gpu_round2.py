@@ -295,3 +295,19 @@ def hip_dynamics_like(src, g):
         for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
             dyn._xw["aux_encoder"][k].copy_(src._xw["aux_encoder"][k])
     return dyn
+
+
+def test_get_hmc_samples_is_the_notebook_baseline_loop():
+    """utils/notebook_utils.py:25-39 on one persistent launch: shape, the states BEFORE each step, and the ESS of
+    HMC(eps = 0.15) on the notebook's target (raw 388: 5.63e-3 per MH step)"""
+    from l2hmc_amd import distributions as D, func_utils
+    from l2hmc_amd.notebook_utils import get_hmc_samples
+    cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
+    dist = D.Gaussian(np.zeros(2), cov)
+    np.random.seed(0)
+    start = dist.get_samples(n=200)
+    S = get_hmc_samples(2, 0.15, dist.get_energy_function(), None, T=10, steps=2000, samples=start)
+    assert S.shape == (2000, 200, 2) and np.array_equal(S[0], start.astype(np.float32))
+    ess = func_utils.ESS(func_utils.acl_spectrum(S, float(np.sqrt(np.trace(cov)))))
+    assert 4.5e-3 < ess < 7.0e-3, ess
+    assert get_hmc_samples(2, 0.15, dist.get_energy_function(), None, steps=0, samples=start).shape == (0, 200, 2)

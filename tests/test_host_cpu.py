@@ -122,3 +122,34 @@ def test_bench_host_helpers():
     a, b = bench.make_problem(0, 8, None), bench.make_problem(0, 8, None)
     assert np.array_equal(a["mask"], b["mask"]) and np.array_equal(a["nets"]["xnet"]["W1"], b["nets"]["xnet"]["W1"])
     assert a["mask"].shape == (bench.T, bench.D) and np.all(a["mask"].sum(axis=1) == bench.D // 2)
+
+
+def test_small_func_utils_and_losses_helpers():
+    """utils/func_utils.py:59-109 and utils/losses.py:26-59 as values: closed forms on small inputs"""
+    import torch
+    from l2hmc_amd import func_utils as F, losses
+    rng = np.random.RandomState(0)
+    qm, qs, pm, ps = rng.randn(5, 3), np.exp(0.3 * rng.randn(5, 3)), rng.randn(5, 3), np.exp(0.2 * rng.randn(5, 3))
+    kl = F.normal_kl(qm, qs, pm, ps)
+    ref = (np.log(ps / qs) + (qs ** 2 + (qm - pm) ** 2) / (2 * ps ** 2) - 0.5).sum(-1)
+    assert np.allclose(kl, ref, rtol=1e-12)
+    klt = F.normal_kl(torch.tensor(qm, dtype=torch.float32), torch.tensor(qs, dtype=torch.float32), 0., 1.)
+    assert np.allclose(klt.numpy(), (-np.log(qs) + (qs ** 2 + qm ** 2) / 2 - 0.5).sum(-1), rtol=1e-5)
+    x = rng.rand(200, 50)
+    b = F.binarize(x, np.random.RandomState(1))
+    assert b.dtype == np.float32 and set(np.unique(b)) <= {0.0, 1.0} and abs(b.mean() - x.mean()) < 0.02
+    with pytest.raises(ValueError):
+        F.binarize(2.0 * x)
+    sh = F.binarize_and_shuffle(np.eye(6), np.random.RandomState(2))
+    assert sh.shape == (6, 6) and np.all(sh.sum(0) == 1) and np.all(sh.sum(1) == 1)
+    xs, Xs, p = torch.tensor(rng.randn(7, 2)), torch.tensor(rng.randn(7, 2)), torch.tensor(rng.rand(7))
+    v = ((Xs - xs) ** 2).sum(1) * p + 1e-4
+    assert torch.allclose(losses.loss_vec(xs, Xs, p), v)
+    assert torch.allclose(losses.get_loss('mixed')(xs, Xs, p, scale=0.1), (0.1 / v).mean() - (v / 0.1).mean())
+    assert torch.allclose(losses.get_loss('standard')(xs, Xs, p), -v.mean())
+    assert torch.allclose(losses.get_loss('inverse')(xs, Xs, p), -1.0 / (1.0 / (v + 1e-4)).mean())
+    assert torch.allclose(losses.get_loss('logsumexp')(xs, Xs, p), torch.logsumexp(-v, 0) - np.log(7.0))
+
+    class G(object):
+        mu, sigma = np.zeros(2), np.eye(2)
+    assert abs(F.get_log_likelihood(np.zeros((3, 2)), G) + np.log(2 * np.pi)) < 1e-12
