@@ -1,7 +1,9 @@
 // libl2hmc_hip.so -- C ABI (include/l2hmc.h) of the L2HMC leapfrog hot path for MI355X:
 // argument validation, LDS planning, geometry selection, weight packing kernels.
 // The fused kernels live in l2hmc_kernels.hpp, instantiated per energy kind in traj_ek*.hip.
+#include <cstdlib>
 #include "traj_tile.hpp"
+#include "traj_lane.hpp"
 
 namespace l2hmc {
 
@@ -53,6 +55,47 @@ __global__ void pack_net_kernel(L2hmcNet net, int d, int H, int KH, int NT, floa
     const int j = idx - ngf, which = j / (16 * NT), dim = j % (16 * NT);
     const float* lam = which == 0 ? net.lam_s : net.lam_q;
     if (dim < d) val = expf(lam[dim]);
+  }
+  out[idx] = val;
+}
+
+// lane layout of one net from its reference-layout weights (l2hmc_pack_nets): zero padded to the compiled dimension count
+// and hidden width (traj_lane.hpp)
+__global__ void pack_lane_kernel(L2hmcNet net, int d, int H, float* out) {
+  const LaneLayout L = lane_layout(d, H);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= L.total) return;
+  float val = 0.f;
+  if (idx < L.tb) {
+    const int which = idx >= L.l1b, r = (idx - (which ? L.l1b : 0)) / L.RS, j = (idx - (which ? L.l1b : 0)) % L.RS;
+    if (r < d && j < H) val = (which ? net.W2 : net.W1)[r * H + j];
+  } else if (idx < L.l2) {
+    const int r = (idx - L.tb) / L.RS, j = (idx - L.tb) % L.RS;
+    if (j < H) val = r == 0 ? net.W3[j] : (r == 1 ? net.W3[H + j] : (net.b1[j] + net.b2[j]) + net.b3[j]);
+  } else if (idx < L.b4) {
+    const int r = (idx - L.l2) / L.RS, j = (idx - L.l2) % L.RS;
+    if (r < H && j < H) val = net.W4[r * H + j];
+  } else if (idx < L.hd) {
+    const int j = idx - L.b4;
+    if (j < H) val = net.b4[j];
+  } else {
+    const int p = (idx - L.hd) / L.HB, o = (idx - L.hd) % L.HB;
+    if (p < L.DP / 2) {
+      if (o < 6 * L.HU) {
+        const int head = o / (2 * L.HU), j = (o % (2 * L.HU)) / 2, k = 2 * p + (o & 1);
+        const float* Wh = head == 0 ? net.Ws : (head == 1 ? net.Wt : net.Wq);
+        if (k < d && j < H) val = Wh[j * d + k];
+      } else {
+        const int c = (o - 6 * L.HU) / 2, k = 2 * p + ((o - 6 * L.HU) & 1);
+        if (k < d) {
+          if (c == 0) val = net.bs[k];
+          else if (c == 1) val = net.bt[k];
+          else if (c == 2) val = net.bq[k];
+          else if (c == 3) val = expf(net.lam_s[k]);
+          else if (c == 4) val = expf(net.lam_q[k]);
+        }
+      }
+    }
   }
   out[idx] = val;
 }
@@ -400,7 +443,7 @@ int64_t l2hmc_packed_nets_floats(int32_t d, int32_t H) {
   if (d < 1 || H < 1) return fail(L2HMC_ERR_ARG, "d and H must be >= 1%s");
   if (H > 15) return fail(L2HMC_ERR_UNSUPPORTED, "fused nets support H <= 15 (got %s%lld)", "", H);
   if (d > 512) return fail(L2HMC_ERR_UNSUPPORTED, "fused nets support d <= 512 (got %s%lld)", "", d);
-  return 2LL * net_floats(tiles_of(d));
+  return 2LL * net_floats(tiles_of(d)) + 2LL * lane_layout(d, H).total;     // MFMA fragments, then the lane layout
 }
 
 int l2hmc_pack_nets(const L2hmcNet* xnet, const L2hmcNet* vnet, int32_t d, int32_t H,
@@ -416,6 +459,9 @@ int l2hmc_pack_nets(const L2hmcNet* xnet, const L2hmcNet* vnet, int32_t d, int32
       if (p[j] == nullptr) return fail(L2HMC_ERR_ARG, "l2hmc_pack_nets: NULL weight pointer%s");
     hipLaunchKernelGGL(pack_net_kernel, dim3((NF + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        *nets[i], d, H, KH, NT, packed + (size_t)i * NF);
+    const int LT = lane_layout(d, H).total;                     // traj_lane.hpp: wave-uniform rows for the scalar loads
+    hipLaunchKernelGGL(pack_lane_kernel, dim3((LT + 255) / 256), dim3(256), 0, (hipStream_t)stream, *nets[i], d, H,
+                       packed + 2 * (size_t)NF + (size_t)i * LT);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "pack launch: %s", hipGetErrorString(e));
@@ -486,6 +532,19 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   // Wide targets (more than 8 dim-tiles, i.e. d > 128; `variant` 8 forces it from 4 tiles up): the
   // register-resident kernels carry 4 or 8 tiles of state per wave there and spill (d = 512: ~1.6k VGPRs);
   // the LDS-resident-state kernel covers the elementwise energies that exist at this width.
+  // One chain per lane (traj_lane.hpp): when the chains alone fill the chip -- a wave is 64 of them -- the padding-free
+  // VALU form beats the MFMA tiles (variant 32 forces it: tests).  Measured (tools/bench_lane.py): d <= 2 from 65 536
+  // chains, d <= 4 from 131 072; wider states lose to the scalar-load latency of their larger nets.
+  {
+    const bool has_u_ = a->u != nullptr || (a->rng_flags & L2HMC_RNG_U);
+    const bool lane_able = a->packed_nets != nullptr && a->ais_beta == nullptr && k.beta == 1.f && k.n_steps >= 1 &&
+                           lane_supported(k.ekind, a->d, a->H, k.ncomp) && (a->d <= 16 || a->x_next != nullptr || !has_u_);
+    if (a->variant == 32 && !lane_able)
+      return fail(L2HMC_ERR_UNSUPPORTED, "variant 32 (one chain per lane) needs S/T/Q nets and a Gaussian / mixture / Rough-Well target with d <= 4%s");
+    const bool lane_auto = ((a->d <= 2 && a->n_chains >= 65536) || (a->d <= 4 && a->n_chains >= 131072));
+    if (lane_able && (a->variant == 32 || (a->variant == 0 && lane_auto)))
+      return launch_lane(k, s);
+  }
   const bool wide_kind = k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL;
   const bool wide_able = a->packed_nets != nullptr && wide_kind && !(k.M > 1 && a->x_next == nullptr) && k.NT <= 32;
   if (a->variant == 8 && !(wide_able && k.NT >= 4))
@@ -497,7 +556,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
     if (a->variant == 8) return fail(L2HMC_ERR_UNSUPPORTED, "variant 8: %s%lld bytes of LDS needed (T x d too large)", "", ldsw);
   }
   int DT, NW;
-  const int geom_variant = a->variant >= 100 ? a->variant - 100 : (a->variant == 16 ? 0 : a->variant);   // 100 + v: the round-1 kernel
+  const int geom_variant = a->variant >= 100 ? a->variant - 100 : ((a->variant == 16 || a->variant == 33) ? 0 : a->variant);   // 100 + v: the round-1 kernel
   if (!pick_geometry(a->d, a->n_chains, geom_variant, DT, NW))
     return fail(L2HMC_ERR_UNSUPPORTED, "d = %s%lld not supported with variant %lld", "", a->d, a->variant);
   // The instruction-lean kernel (traj_fast.hpp) covers S/T/Q nets on register-resident geometries; the

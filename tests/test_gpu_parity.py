@@ -21,13 +21,17 @@ def variants(g):
     # 0 / 1 / 4: automatic / one / four waves per 16-chain tile (the instruction-lean kernel where it applies);
     # 100 + v: the same geometry on the general kernel
     d = int(g["x_dim"])
+    # 32: one chain per lane (traj_lane.hpp: the many-chain VALU form; forced here on the fixtures' few chains)
+    kind = str(g["energy.kind"])
+    diag = kind == "gaussian" and np.count_nonzero(g["energy.i_sigma"] - np.diag(np.diagonal(g["energy.i_sigma"]))) == 0
+    lane = not int(g["hmc"]) and int(g["H"]) <= 15 and kind in ("gaussian", "gmm", "roughwell") and d <= 4
     if d <= 16:
-        return [0, 100]
+        return [0, 100] + ([32] if lane else [])
     # 16: one wave per tile (many-chains form; elementwise targets with S/T/Q nets, 33 <= d <= 64)
     tile = 33 <= d <= 64 and not int(g["hmc"]) and int(g["H"]) <= 15 and (
         str(g["energy.kind"]) == "roughwell" or (str(g["energy.kind"]) == "gaussian" and
                                                   np.count_nonzero(g["energy.i_sigma"] - np.diag(np.diagonal(g["energy.i_sigma"]))) == 0))
-    return [1, 4, 104] + ([16] if tile else [])
+    return [1, 4, 104] + ([16] if tile else []) + ([32] if lane else [])
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -145,8 +149,8 @@ def _big_case(case, N, seed):
     return g
 
 
-@pytest.mark.parametrize("case,N", [("scg2d", 200), ("icg50", 4096), ("mog2d", 65536)])
-def test_full_size_configs_against_oracle(case, N):
+@pytest.mark.parametrize("case,N,variant", [("scg2d", 200, 0), ("icg50", 4096, 4), ("mog2d", 65536, 33), ("mog2d", 65536, 32)])
+def test_full_size_configs_against_oracle(case, N, variant):
     """BASELINE.json configs C1/C2/C3 at full chain counts: direction-mixed propose vs the
     oracle on the same seeded draws, plus sharding invariance (two half-batches == one batch,
     bit for bit: chains never interact)."""
@@ -156,8 +160,9 @@ def test_full_size_configs_against_oracle(case, N):
     rng = np.random.RandomState(7)
     direction = rng.randint(0, 2, size=N).astype(np.uint8)
     u = rng.rand(N).astype(np.float32)
-    # pin the kernel geometry so that N and N/2 chains run the very same code path
-    dyn = hip_dynamics(g, variant=4 if int(g["x_dim"]) > 16 else 0)
+    # pin the kernel so that N and N/2 chains run the very same code path (33: the MFMA kernels' own choice,
+    # 32: one chain per lane -- what `variant = 0` takes for 65 536 two-dimensional chains)
+    dyn = hip_dynamics(g, variant=variant)
     x, v = to_dev(g["x"]), to_dev(g["v"])
     Lx, _, px, outs = propose(x, dyn, do_mh_step=True, direction=to_dev(direction), v=v, u=to_dev(u))
     od = oracle_dynamics(g)
