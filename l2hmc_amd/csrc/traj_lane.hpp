@@ -81,6 +81,9 @@ __device__ __forceinline__ f2 tanh2(f2 z) { return 1.f - 2.f * rcp2(1.f + ex2_2(
 #ifndef LANE_COARSE_DP
 #define LANE_COARSE_DP 4
 #endif
+// (a single fence per leapfrog step was tried for d = 2: the scheduler then hoists across evaluations and spills SGPRs
+//  through v_readlane again -- 272 cross-lane moves per step)
+#define LANE_EVAL_FENCE() LANE_NO_HOIST()
 
 // grad U (and U) of one chain held by one lane; every parameter is wave-uniform.  prec / mu as the fused kernels get
 // them: diagonal precisions (d); MFMA-packed symmetric precisions (pack_gauss_kernel) for the dense kinds.
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(64, DP <= 8 ? 4 : 2) void traj_lane_kernel(const KA
       };
       // momentum half-update with V(z, grad U(z)) (dynamics.py:118-125,147-153 / :162-170,192-199)
       auto v_half = [&]() {
-        LANE_NO_HOIST();
+        LANE_EVAL_FENCE();
         lane_hidden<DP, HPR>(WV, [&](int k) { return x[k]; }, g_of, tc, ts, h2);
 #pragma unroll
         for (int p = 0; p < DP / 2; ++p) {
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(64, DP <= 8 ? 4 : 2) void traj_lane_kernel(const KA
           const float k1 = k1_of(k);
           kq[k] = first ? k1 : 1.f - k1;
         }
-        LANE_NO_HOIST();
+        LANE_EVAL_FENCE();
         lane_hidden<DP, HPR>(WX, [&](int k) { return v[k]; }, [&](int k) { return kq[k] * x[k]; }, tc, ts, h2);
 #pragma unroll
         for (int p = 0; p < DP / 2; ++p) {
