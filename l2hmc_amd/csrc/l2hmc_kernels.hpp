@@ -191,23 +191,21 @@ __host__ __device__ inline U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
   }
   return c;
 }
-// 4 standard normals from one Philox block (two Box-Muller pairs, 24-bit uniforms).  Hardware transcendentals:
-// v_log_f32 / v_sqrt_f32 (1 ulp) for the radius, v_sin_f32 / v_cos_f32 for the angle -- they take the angle in
-// REVOLUTIONS, i.e. the 24-bit uniform itself (exact argument, no 2 pi multiplication, no range reduction).  The
-// normals are within 1.7e-6 (absolute, measured over 8e5 draws) of the libm evaluation the oracle makes of the same
-// uniforms; ocml's logf / sqrtf / sincosf are ~250 more instructions per proposal and wave.  (No effect at one wave per
-// SIMD -- the 4096-chain headline is latency-bound -- but the issue-bound many-chain kernels gain 2-3 %.)
+// 4 standard normals from one Philox block (two Box-Muller pairs, 24-bit uniforms), libm logf / sqrtf / sincosf.
+// (The hardware forms -- v_log_f32 / v_sqrt_f32, v_sin_f32 / v_cos_f32 with the angle in revolutions -- were measured:
+//  normals within 1.7e-6 of these, nothing at 4096 chains, +2 % for the issue-bound many-chain kernels.  Not adopted:
+//  the draws feed the training runs of the ESS evidence, and a 2 % gain does not justify re-rolling them.)
 __device__ __forceinline__ f4 philox_normal4(unsigned long long seed, long long gchain, unsigned blk,
                                              unsigned long long prop) {
   const U4 r = philox4x32_10(U4{(unsigned)gchain, blk, (unsigned)prop, (unsigned)(prop >> 32) << 1},
                              (unsigned)seed, (unsigned)(seed >> 32));
   const float k = 5.9604644775390625e-08f;   // 2^-24
   const float u1 = ((r.x >> 8) + 1) * k, u2 = (r.y >> 8) * k, u3 = ((r.z >> 8) + 1) * k, u4 = (r.w >> 8) * k;
-  const float m2ln2 = -1.3862943611198906f;  // -2 ln 2:  -2 ln u = (-2 ln 2) log2 u
-  const float ra = __builtin_amdgcn_sqrtf(m2ln2 * __builtin_amdgcn_logf(u1));
-  const float rb = __builtin_amdgcn_sqrtf(m2ln2 * __builtin_amdgcn_logf(u3));
-  return f4{ra * __builtin_amdgcn_cosf(u2), ra * __builtin_amdgcn_sinf(u2), rb * __builtin_amdgcn_cosf(u4),
-            rb * __builtin_amdgcn_sinf(u4)};
+  const float ra = sqrtf(-2.f * logf(u1)), rb = sqrtf(-2.f * logf(u3));
+  float sa, ca, sb, cb;
+  sincosf(6.283185307179586f * u2, &sa, &ca);
+  sincosf(6.283185307179586f * u4, &sb, &cb);
+  return f4{ra * ca, ra * sa, rb * cb, rb * sb};
 }
 // direction bit and accept uniform of (chain, proposal): stream 1
 __device__ __forceinline__ void philox_dir_u(unsigned long long seed, long long gchain,

@@ -373,14 +373,13 @@ def test_l2hmc_sampler_leaves_target_invariant():
 
 
 def test_in_kernel_philox_matches_oracle_stream():
-    """K6: the draws of the in-kernel stream == the oracle's Philox restatement (integers exact; the Box-Muller normals
-    use the hardware log2 / sqrt / sin / cos -- angle passed in revolutions -- and lie within 1.7e-6 of the oracle's libm
-    evaluation of the same uniforms), for any sharding of the chains."""
+    """K6: the draws of the in-kernel stream == the oracle's Philox restatement (integers exact,
+    Box-Muller normals to float32 rounding), for any sharding of the chains."""
     from l2hmc_amd.sampler import philox_draws
     v, dr, u = philox_draws(99, 200, 50, 4)
     rv, rd, ru = O.philox_draws(99, 200, 50, 4)
     assert np.array_equal(to_np(dr), rd) and np.array_equal(to_np(u), ru)
-    assert np.allclose(to_np(v), rv, rtol=0, atol=5e-6)
+    assert np.allclose(to_np(v), rv, rtol=0, atol=2e-6)
     v2, d2, u2 = philox_draws(99, 100, 50, 2, proposal0=2, chain_offset=100)
     assert np.array_equal(to_np(v2), to_np(v)[2:, 100:]) and np.array_equal(to_np(u2), to_np(u)[2:, 100:])
 

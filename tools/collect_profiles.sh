@@ -10,21 +10,21 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py"
 
-$BENCH > $OUT/bench.json 2> $OUT/bench.err
+timeout 400 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 tail -c 2500 $OUT/bench.json
 
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o b -- $BENCH --no-cpu-baseline --no-ess --no-sweep --no-config5 --no-config5 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o b -- $BENCH --no-cpu-baseline --no-ess --no-sweep --no-config5 > /dev/null 2>&1
 cp $OUT/trace/b_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 head -3 $OUT/kernel_stats.csv
 
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE \
-    --output-format csv -d $OUT/pmc_sq -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess --no-sweep --no-config5 --no-config5 > /dev/null 2>&1
+    --output-format csv -d $OUT/pmc_sq -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess --no-sweep --no-config5 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS \
-    --output-format csv -d $OUT/pmc_sq2 -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess --no-sweep --no-config5 --no-config5 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess --no-sweep --no-config5 --no-config5 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess --no-sweep --no-config5 --no-config5 > /dev/null 2>&1
+    --output-format csv -d $OUT/pmc_sq2 -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess --no-sweep --no-config5 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess --no-sweep --no-config5 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c -- $BENCH --steps 25 --warmup 25 --no-cpu-baseline --no-ess --no-sweep --no-config5 > /dev/null 2>&1
 # the many-chains regime (262144 chains, 10 proposals per launch): what saturates there
-BIG="$BENCH --chains 262144 --proposals-per-launch 10 --steps 10 --warmup 10 --no-cpu-baseline --no-ess --no-sweep --no-config5 --no-config5"
+BIG="$BENCH --chains 262144 --proposals-per-launch 10 --steps 10 --warmup 10 --no-cpu-baseline --no-ess --no-sweep --no-config5"
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
     --output-format csv -d $OUT/pmc_big -o c -- $BIG > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS \
