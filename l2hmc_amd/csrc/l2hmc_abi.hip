@@ -537,7 +537,8 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   // chains, d <= 4 from 131 072; wider states lose to the scalar-load latency of their larger nets.
   {
     const bool has_u_ = a->u != nullptr || (a->rng_flags & L2HMC_RNG_U);
-    const bool lane_able = a->packed_nets != nullptr && a->ais_beta == nullptr && k.beta == 1.f && k.n_steps >= 1 &&
+    const bool lane_able = a->packed_nets != nullptr && a->ais_beta == nullptr && k.beta == 1.f && k.temperature == 1.f &&
+                           k.n_steps >= 1 &&
                            lane_supported(k.ekind, a->d, a->H, k.ncomp) && (a->d <= 16 || a->x_next != nullptr || !has_u_);
     if (a->variant == 32 && !lane_able)
       return fail(L2HMC_ERR_UNSUPPORTED, "variant 32 (one chain per lane) needs S/T/Q nets and a Gaussian / mixture / Rough-Well target with d <= 4%s");
