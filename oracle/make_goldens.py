@@ -3,7 +3,9 @@
 TEST INFRASTRUCTURE.  Run here (never on the GPU box -- /root/reference does not exist
 there):
 
-    python oracle/make_goldens.py            # writes tests/golden/*.npz
+    python oracle/make_goldens.py            # writes ALL of tests/golden/*.npz (32 files; bit-reproducible)
+    python oracle/make_goldens.py ais|wide|train_funnel|train_vae|train_wide   # only that group
+    L2HMC_GOLDEN_OUT=/tmp/gold python oracle/make_goldens.py                  # elsewhere, to diff against the committed set
 
 How: ``oracle/tf1_stub.py`` is registered as ``tensorflow``; ``/root/reference/utils`` is
 put on ``sys.path`` at run time and ``dynamics``, ``layers``, ``distributions`` are imported
@@ -29,7 +31,7 @@ sys.path.insert(0, HERE)
 import tf1_stub  # noqa: E402
 
 REF = '/root/reference/utils'
-OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+OUT = os.environ.get('L2HMC_GOLDEN_OUT') or os.path.join(os.path.dirname(HERE), 'tests', 'golden')   # (override: verification runs)
 
 tf = tf1_stub.install()
 sys.path.insert(0, REF)
@@ -720,7 +722,12 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'p_accept_edge.npz'), x0=x0, v0=v0, x1=x1, v1=v1,
                         logjac=lj, p=npy(p))
     print('p_accept_edge      p =', npy(p))
+    # the groups that can also be regenerated on their own (see the modes at the top of main)
     ais_cases()
+    wide_cases()
+    train_funnel_case()
+    train_vae_case('train_vae_small', latent=10, H=24, dec_h=48, n_pix=40, enc_h=32, T=4, eps=0.1, N=32, seed=43)
+    train_wide_cases()
 
 
 if __name__ == '__main__':
