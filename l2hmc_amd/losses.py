@@ -1,36 +1,54 @@
-"""The named objectives of the reference's utils/losses.py as VALUES of device tensors (`get_loss(name)(x, Lx, px)`).
+"""Values of the reference's named sampler objectives (`utils/losses.py`) on device tensors.
 
-The reference differentiates them through its TF graph; here the gradient of the one that is actually used --
-`loss_mixed`, SCGExperiment.ipynb raw 164-169 and mnist_vae.py:207-214 -- comes from the native trainers
-(`l2hmc_amd.training`), so these functions are for monitoring / evaluation: plain torch arithmetic on whatever
-device the arguments live on.  Per-chain argument: v_n = |x_n - X_n|^2 p_n + 1e-4 (losses.py:36-37).
+The reference differentiates these through its TF graph.  Here the gradient of the one objective its programs use --
+the `mixed` form, SCGExperiment.ipynb raw 164-169 and mnist_vae.py:207-214 -- is produced natively by
+`l2hmc_amd.training`; this module only EVALUATES the objectives (monitoring, tests): plain torch arithmetic on
+whatever device the arguments live on.
+
+Everything is a reduction of one per-chain quantity, the expected squared jump (losses.py:36-37)
+
+    jump_n = p_n * |proposal_n - state_n|^2 + 1e-4
+
+    mixed      mean(scale / jump) - mean(jump / scale)          (:53-59)
+    standard   -mean(jump)                                       (:49-51)
+    inverse    -1 / mean(1 / (jump + 1e-4))                      (:44-47)
+    logsumexp  log mean exp(-jump)                               (:39-42)
 """
 import math
 
 import torch
 
 
-def loss_vec(x, X, p):
-    return ((X - x) ** 2).sum(dim=1) * p + 1e-4
+def expected_jump(state, proposal, accept_prob):
+    sq = torch.sum((proposal - state) * (proposal - state), dim=1)
+    return accept_prob * sq + 1e-4
 
 
-def loss_logsumexp(x, X, p):                      # losses.py:39-42
-    v = loss_vec(x, X, p)
-    return torch.logsumexp(-v, dim=0) - math.log(v.shape[0])
+_REDUCERS = {
+    'mixed': lambda j, scale: torch.mean(scale / j) - torch.mean(j / scale),
+    'standard': lambda j, scale: -torch.mean(j, dim=0),
+    'inverse': lambda j, scale: -torch.reciprocal(torch.mean(torch.reciprocal(j + 1e-4))),
+    'logsumexp': lambda j, scale: torch.logsumexp(-j, dim=0) - math.log(j.shape[0]),
+}
 
 
-def loss_inverse(x, X, p):                        # losses.py:44-47
-    return -1.0 / (1.0 / (loss_vec(x, X, p) + 1e-4)).mean()
+def _named(name):
+    reduce_ = _REDUCERS[name]
+
+    def objective(x, Lx, px, scale=1.0):
+        return reduce_(expected_jump(x, Lx, px), scale)
+    objective.__name__ = 'loss_' + name
+    return objective
 
 
-def loss_std(x, X, p):                            # losses.py:49-51
-    return -loss_vec(x, X, p).mean(dim=0)
+# the reference's names
+loss_vec = expected_jump
+loss_mixed = _named('mixed')
+loss_std = _named('standard')
+loss_inverse = _named('inverse')
+loss_logsumexp = _named('logsumexp')
 
 
-def loss_mixed(x, Lx, px, scale=1.0):             # losses.py:53-59
-    v1 = loss_vec(x, Lx, px) / scale
-    return (1.0 / v1).mean() - v1.mean()
-
-
-def get_loss(name):                               # losses.py:26-34
+def get_loss(name):
+    """`utils/losses.py:26-34`: 'mixed' | 'standard' | 'inverse' | 'logsumexp' -> callable(x, Lx, px[, scale])."""
     return {'mixed': loss_mixed, 'standard': loss_std, 'inverse': loss_inverse, 'logsumexp': loss_logsumexp}[name]
