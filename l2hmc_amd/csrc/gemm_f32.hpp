@@ -321,12 +321,16 @@ __host__ __device__ inline int odd_quarter_stride(int k) {   // smallest multipl
 }
 constexpr int NE_MAXKT = 16;       // k-tiles per layer the kernel is compiled for: K <= 256
 // CB = chain blocks (of 16) per workgroup: every weight fragment fetched from L2 feeds CB MFMAs
-inline size_t net_eval_lds_bytes(int d, int H, int CB = 1) {       // input tile, two hidden activations, head products
-  return sizeof(float) * 16 * CB * (size_t)(odd_quarter_stride(ceil16(2 * d)) + 2 * odd_quarter_stride(ceil16(H)) + ceil16(3 * d));
+// input tile, two hidden activations, head products -- the head products take the place of the FIRST hidden activation
+// (dead once layer 2 is done) whenever their rows fit: 3 d <= the hidden row stride
+inline bool net_eval_out_aliases_h1(int d, int H) { return ceil16(3 * d) <= odd_quarter_stride(ceil16(H)); }
+inline size_t net_eval_lds_bytes(int d, int H, int CB = 1) {
+  return sizeof(float) * 16 * CB * (size_t)(odd_quarter_stride(ceil16(2 * d)) + 2 * odd_quarter_stride(ceil16(H)) +
+                                           (net_eval_out_aliases_h1(d, H) ? 0 : ceil16(3 * d)));
 }
 
 template <int CB>
-__global__ __launch_bounds__(256, CB == 1 ? 2 : 1) void net_eval_kernel(const NetEvalArgs g) {
+__global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int NE_MT = 16 * CB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -336,8 +340,8 @@ __global__ __launch_bounds__(256, CB == 1 ? 2 : 1) void net_eval_kernel(const Ne
   float* sIn = sm;
   float* sH1 = sIn + NE_MT * ld1;
   float* sH2 = sH1 + NE_MT * ldh;
-  float* sOut = sH2 + NE_MT * ldh;                       // (NE_MT, ceil16(3 d)) head products of the fused update
   const int ldo = ceil16(3 * g.d);
+  float* sOut = ldo <= ldh ? sH1 : sH2 + NE_MT * ldh;    // (NE_MT, ceil16(3 d)) head products of the fused update
   const long long m0 = (long long)blockIdx.x * NE_MT;
 
   for (int i = tid; i < NE_MT * (K1p / 4); i += 256) {        // input tile, zero padded to K1p (K1 % 4 == 0)

@@ -454,7 +454,9 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   // added by the update kernels).  H % 4 == 0 and d even: ONE launch of net_eval_kernel (activations resident in
   // LDS); otherwise three GEMMs with fused epilogues on 64 x 64 tiles.
   // (32 chains per workgroup -- every weight fragment streamed from L2 feeding two MFMAs, net_eval_kernel<2> -- was
-  //  measured at 8192 chains: 88 KB of LDS leave one workgroup per CU and the evaluation gets 25 % slower: 16 it is)
+  //  measured twice at 8192 chains: with one workgroup per CU (88 KB of LDS) the evaluation is 25 % slower than with 16
+  //  chains, with two per CU (69 KB after the head products moved into the dead first activation) still 8 % slower:
+  //  occupancy, not L2 traffic, is what this kernel lives on)
   const int ne_cb = 1;
   const size_t ne_lds = net_eval_lds_bytes(d, H, ne_cb);
   const bool ne_ok = (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(2 * d) <= 16 * NE_MAXKT && ne_lds <= 160 * 1024;
