@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define L2HMC_ABI_VERSION 1
+#define L2HMC_ABI_VERSION 2
 
 enum {
   L2HMC_OK = 0,
@@ -400,6 +400,16 @@ int l2hmc_rng_fill(uint64_t seed, uint64_t proposal0, int64_t chain_offset, int6
 int64_t l2hmc_autocov_workspace_doubles(int64_t steps, int64_t n_chains, int32_t d);
 int l2hmc_autocov(const float* X, int64_t steps, int64_t n_chains, int32_t d, double scale,
                   int64_t n_total, double* sums_out, double* A_out, double* workspace, void* stream);
+
+/* Binding check.  The argument structs grow by trailing fields from one ABI version to the next (and
+ * l2hmc_pack_nets' buffer by the lane layout: always size it with l2hmc_packed_nets_floats).  A binding built
+ * against an older header would pass shorter structs, so besides comparing l2hmc_abi_version() with the
+ * L2HMC_ABI_VERSION it was written for, a binding compares sizeof() of its own mirror of every struct with
+ * what the library was compiled with (l2hmc_amd/_ffi.py does both when it loads the library).
+ * which: one of L2HMC_STRUCT_*; returns sizeof in bytes, or L2HMC_ERR_ARG. */
+enum { L2HMC_STRUCT_NET = 0, L2HMC_STRUCT_ENERGY = 1, L2HMC_STRUCT_TRAJECTORY_ARGS = 2, L2HMC_STRUCT_MLP3 = 3,
+       L2HMC_STRUCT_SPLIT_ARGS = 4, L2HMC_STRUCT_TRAIN_ARGS = 5, L2HMC_STRUCT_TRAIN_SPLIT_ARGS = 6 };
+int64_t l2hmc_struct_bytes(int32_t which);
 
 #ifdef __cplusplus
 }

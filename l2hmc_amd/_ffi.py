@@ -84,10 +84,13 @@ class L2hmcTrainSplitArgs(C.Structure):
                 ("workspace", _fp), ("workspace_floats", C.c_int64)]
 
 
+STRUCTS = (L2hmcNet, L2hmcEnergy, L2hmcTrajectoryArgs, L2hmcMlp3, L2hmcSplitArgs, L2hmcTrainArgs, L2hmcTrainSplitArgs)
+
 # every symbol include/l2hmc.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "l2hmc_abi_version": (C.c_int, []),
     "l2hmc_last_error": (C.c_char_p, []),
+    "l2hmc_struct_bytes": (C.c_int64, [C.c_int32]),
     "l2hmc_packed_nets_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_pack_nets": (C.c_int, [C.POINTER(L2hmcNet), C.POINTER(L2hmcNet), C.c_int32, C.c_int32,
                                   _fp, _fp]),
@@ -124,6 +127,7 @@ SYMBOLS = {
                              _fp, _fp]),
 }
 
+ABI_VERSION = 2          # L2HMC_ABI_VERSION this binding was written against
 _lib = None
 
 
@@ -139,8 +143,13 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.l2hmc_abi_version() != 1:
-            raise RuntimeError("l2hmc_amd: ABI version mismatch")
+        if handle.l2hmc_abi_version() != ABI_VERSION:
+            raise RuntimeError("l2hmc_amd: ABI version mismatch (library %d, binding %d): rebuild with "
+                               "`make -C l2hmc_amd/csrc`" % (handle.l2hmc_abi_version(), ABI_VERSION))
+        for which, mirror in enumerate(STRUCTS):        # include/l2hmc.h: L2HMC_STRUCT_* in this order
+            if handle.l2hmc_struct_bytes(which) != C.sizeof(mirror):
+                raise RuntimeError("l2hmc_amd: %s is %d bytes in the library, %d in the binding -- stale build?"
+                                   % (mirror.__name__, handle.l2hmc_struct_bytes(which), C.sizeof(mirror)))
         _lib = handle
     return _lib
 

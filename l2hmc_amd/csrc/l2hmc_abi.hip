@@ -439,6 +439,19 @@ int l2hmc_abi_version(void) { return L2HMC_ABI_VERSION; }
 
 const char* l2hmc_last_error(void) { return g_err; }
 
+int64_t l2hmc_struct_bytes(int32_t which) {
+  switch (which) {
+    case L2HMC_STRUCT_NET: return sizeof(L2hmcNet);
+    case L2HMC_STRUCT_ENERGY: return sizeof(L2hmcEnergy);
+    case L2HMC_STRUCT_TRAJECTORY_ARGS: return sizeof(L2hmcTrajectoryArgs);
+    case L2HMC_STRUCT_MLP3: return sizeof(L2hmcMlp3);
+    case L2HMC_STRUCT_SPLIT_ARGS: return sizeof(L2hmcSplitArgs);
+    case L2HMC_STRUCT_TRAIN_ARGS: return sizeof(L2hmcTrainArgs);
+    case L2HMC_STRUCT_TRAIN_SPLIT_ARGS: return sizeof(L2hmcTrainSplitArgs);
+  }
+  return fail(L2HMC_ERR_ARG, "l2hmc_struct_bytes: unknown struct id%s");
+}
+
 int64_t l2hmc_packed_nets_floats(int32_t d, int32_t H) {
   if (d < 1 || H < 1) return fail(L2HMC_ERR_ARG, "d and H must be >= 1%s");
   if (H > 15) return fail(L2HMC_ERR_UNSUPPORTED, "fused nets support H <= 15 (got %s%lld)", "", H);
@@ -569,7 +582,8 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
                      (k.ekind != L2HMC_ENERGY_GMM || k.ncomp <= 8);
   if (small) {
     const long long ldss = plan_lds_fast(k, 1, 1);
-    return dispatch(OP_TRAJ_SMALL, k, 1, 1, KH, ldss, s);
+    // (the per-step schedule records grow with T: past 160 KiB fall through to the fast / general kernel)
+    if (ldss <= 160 * 1024) return dispatch(OP_TRAJ_SMALL, k, 1, 1, KH, ldss, s);
   }
   // many chains (>= 2 tiles per SIMD), 3-4 dimension slices, elementwise target: one wave per tile (traj_tile.hpp);
   // variant 16 forces it
@@ -580,8 +594,12 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
     return fail(L2HMC_ERR_UNSUPPORTED, "variant 16 (one wave per tile) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target and 33 <= d <= 64%s");
   if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 16384))) {
     const long long ldst = plan_lds_tile(k, k.NT);
-    if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, ldst, s);
-    return launch_tile_ek<L2HMC_ENERGY_ROUGHWELL>(k, k.NT, KH, ldst, s);
+    if (ldst <= 160 * 1024) {
+      if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, ldst, s);
+      return launch_tile_ek<L2HMC_ENERGY_ROUGHWELL>(k, k.NT, KH, ldst, s);
+    }
+    if (a->variant == 16)
+      return fail(L2HMC_ERR_UNSUPPORTED, "variant 16: %s%lld bytes of LDS needed (T too large for the one-wave-per-tile kernel)", "", ldst);
   }
   if (fast) {
     const long long ldsf = plan_lds_fast(k, NW, DT);

@@ -953,6 +953,9 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
     if (rc) return rc;
     part = a->workspace + (long long)blocks * a->T * TF_CK * (fnw * 256);
   } else {
+    if (ek == L2HMC_ENERGY_FUNNEL)               // the general tile kernel has no funnel Hessian-vector product
+      return fail(L2HMC_ERR_UNSUPPORTED, "funnel training runs on the register-resident kernel only (d <= 16, H <= 15, "
+                  "its LDS plan <= 160 KiB; needs %s%lld bytes here)", "", lds_fast);
     const TLayout L = train_layout(a->d, a->H, a->T, ek, k.ncomp);
     const long long lds = 4LL * L.total;
     if (lds > 160 * 1024)

@@ -140,6 +140,17 @@ class Dynamics(object):
         if value is None:
             self.__dict__['_split_key'] = None
 
+    def invalidate_caches(self):
+        """Forget every prepared copy of the parameters (the packed MFMA fragments of the fused kernels, the transposed
+        weights / time table / `encoder_sampler(aux)` rows in the GEMM engine's workspace).  The caches are keyed on each
+        parameter tensor's storage address and torch version counter and on the identity + version of `aux`: writes
+        that bypass the version counters -- `p.data.copy_()`, `p.data.add_()`, a DLPack consumer or a foreign kernel
+        writing into the weights, `aux.data[...] = ...` -- are NOT seen; call this after them.  (The library's own
+        optimiser does; in-place torch ops on the parameters themselves, `p.copy_()`, `p.add_()`, bump the counters and
+        need nothing.)"""
+        self._packed_key = None
+        self._split_aux = (None, -1)
+
     @property
     def mask(self):
         return self._mask

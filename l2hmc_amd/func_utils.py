@@ -74,7 +74,9 @@ def binarize(x, rng=None):
     x = np.asarray(x)
     if x.size and x.max() > 1.:
         raise ValueError("binarize expects intensities in [0, 1]")
-    return ((np.random if rng is None else rng).random_sample(x.shape) < x).astype(np.float32)
+    r = np.random if rng is None else rng
+    draw = getattr(r, "random_sample", None) or r.random       # RandomState / np.random | a np.random.Generator
+    return (draw(x.shape) < x).astype(np.float32)
 
 
 def binarize_and_shuffle(x, rng=None):

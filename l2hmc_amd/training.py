@@ -81,7 +81,7 @@ class Trainer(object):
         self._ws = None
         self.variant = 0             # 100: force the general tile kernel (l2hmc.h)
         self._io = None              # per-N buffers of step()
-        self._shard_cache = None
+        self._layout = None
 
     # ---- checkpoint (the reference saves variables with tf.train.Saver, mnist_vae.py:290,334, and has to smuggle
     #      the masks around it, eval_sampler.py:52-59,156): everything a run needs to continue bit for bit ----
@@ -157,21 +157,30 @@ class Trainer(object):
     def _world(self):
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
+    def set_sharding(self, n_total, chain_offset):
+        """Declare this rank's place in the global chain batch: `n_total` chains over all ranks, this rank's row 0 is
+        global chain `chain_offset` (e.g. from `sharding.shard_range`).  With a declared layout a step issues no
+        collective besides the flat-gradient all-reduce; `set_sharding(None, None)` returns to the discovered layout."""
+        self._layout = None if n_total is None else (int(n_total), int(chain_offset))
+
     def _shard(self, N):
         """(global chain count, global index of this rank's row 0): ranks may hold different numbers of chains
         (sharding.shard_range hands out blocks whose sizes differ by up to one), so the loss normalisation and the
-        Philox chain offsets come from the all-gathered local counts, not from N * world."""
+        Philox chain offsets come from the ranks' local counts, not from N * world.  Unless the layout was declared
+        (`set_sharding`), the counts are all-reduced on EVERY call -- unconditionally and by every rank, so the
+        collective sequence is the same on all ranks whatever happens to their local counts (a cache keyed on the
+        LOCAL count would let one rank skip the collective another rank enters)."""
         world = self._world()
         if world == 1:
             return N, 0
-        if self._shard_cache is None or self._shard_cache[0] != N:
-            rank = dist.get_rank()
-            counts = torch.zeros(world, dtype=torch.float64, device=self.dyn.device)
-            counts[rank] = float(N)
-            dist.all_reduce(counts)                  # one small collective, once per chain count
-            counts = counts.cpu()
-            self._shard_cache = (N, int(counts.sum()), int(counts[:rank].sum()))
-        return self._shard_cache[1], self._shard_cache[2]
+        if getattr(self, "_layout", None) is not None:
+            return self._layout
+        rank = dist.get_rank()
+        counts = torch.zeros(world, dtype=torch.float64, device=self.dyn.device)
+        counts[rank] = float(N)
+        dist.all_reduce(counts)
+        counts = counts.cpu()
+        return int(counts.sum()), int(counts[:rank].sum())
 
     def _loss(self, v12, N, n_total, world):
         terms = torch.stack([(1.0 / v12).sum(), v12.sum()]).double()
@@ -336,7 +345,7 @@ class SplitTrainer(Trainer):
         self._ws = None
         self.variant = 0
         self._io = None
-        self._shard_cache = None
+        self._layout = None
 
     def lr_at(self, step):
         if self.vae and self.decay_steps <= 0:

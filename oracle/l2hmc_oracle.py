@@ -461,11 +461,17 @@ def propose(x, dyn, v_fwd, v_bwd=None, direction=None, u=None, log_jac=False,
 def chain_operator(init_x, dyn, nb_steps, init_v, v_fwd_list, v_bwd_list, directions, u=None):
     """sampler.py:57-85.  Quirk kept: in L2HMC mode propose() ignores the
     momentum handed to it -- every composed proposal draws fresh momenta (v_*_list[k]);
-    only the returned Lv is threaded on, and p_accept uses the caller's init_v."""
+    only the returned Lv is threaded on, and p_accept uses the caller's init_v.  In HMC mode
+    (:29-31) propose DOES start from the threaded momentum and ignores `log_jac`: the summed
+    "log-Jacobian" is then a sum of accept probabilities (the lists may be None there).
+    Pinned by the `chainop.*` keys of the goldens (the reference's own chain_operator)."""
     x, v = init_x, init_v
     lj = np.zeros((init_x.shape[0],), dtype=dyn.dtype)
     for k in range(int(nb_steps)):
-        x, v, px, _ = propose(x, dyn, v_fwd_list[k], v_bwd_list[k], directions[k], log_jac=True)
+        if dyn.hmc:
+            x, v, px, _ = propose(x, dyn, v, log_jac=True)
+        else:
+            x, v, px, _ = propose(x, dyn, v_fwd_list[k], v_bwd_list[k], directions[k], log_jac=True)
         lj = lj + px
     p = dyn.p_accept(init_x, init_v, x, v, lj)
     return x, v, p, (tf_accept(init_x, x, p, u) if u is not None else None)

@@ -3,8 +3,8 @@
 TEST INFRASTRUCTURE.  Run here (never on the GPU box -- /root/reference does not exist
 there):
 
-    python oracle/make_goldens.py            # writes ALL of tests/golden/*.npz (32 files; bit-reproducible)
-    python oracle/make_goldens.py ais|wide|train_funnel|train_vae|train_wide   # only that group
+    python oracle/make_goldens.py            # writes ALL of tests/golden/*.npz (34 files; bit-reproducible)
+    python oracle/make_goldens.py ais|wide|train_funnel|train_vae|train_wide|ess   # only that group
     L2HMC_GOLDEN_OUT=/tmp/gold python oracle/make_goldens.py                  # elsewhere, to diff against the committed set
 
 How: ``oracle/tf1_stub.py`` is registered as ``tensorflow``; ``/root/reference/utils`` is
@@ -121,14 +121,19 @@ def leaf(a):
 
 
 def run_case(name, x_dim, H, T, eps, N, energy_fn, energy_params, seed, hmc=False,
-             head_std=1.0, x_scale=1.0, steps_to_check=(0, 3, None), x0=None):
+             head_std=1.0, x_scale=1.0, steps_to_check=(0, 3, None), x0=None, temperature=None, chainop=0):
     tf1_stub.reset(seed)
     np.random.seed(seed)                      # masks come from numpy's global RNG (dynamics.py:88)
     tf1_stub.VARIABLE_HOOK = variable_hook_factory(seed + 1, head_std)
     with contextlib.redirect_stdout(io.StringIO()):
         dyn = ref_dynamics.Dynamics(x_dim, energy_fn, T=T, eps=eps, hmc=hmc,
-                                    net_factory=None if hmc else make_network(H))
+                                    net_factory=None if hmc else make_network(H),
+                                    use_temperature=temperature is not None)
     out = dict(energy_params)
+    if temperature is not None:
+        # dynamics.py:47,204-205: `temperature` is a placeholder the caller feeds; feeding = assigning here
+        dyn.temperature = torch.tensor(float(temperature), dtype=torch.float32)
+        out['temperature'] = np.float32(temperature)
     out.update(case=name, x_dim=x_dim, H=H, T=T, N=N, hmc=int(hmc),
                eps=npy(dyn.eps), mask=npy(dyn.mask))
     if not hmc:
@@ -181,6 +186,8 @@ def run_case(name, x_dim, H, T, eps, N, energy_fn, energy_params, seed, hmc=Fals
         out['prop.v_fwd'], out['prop.v_bwd'], out['prop.u'] = log[1][1], log[2][1], log[3][1]
     out['prop.Lx'], out['prop.px'], out['prop.x_next'] = npy(Lx), npy(px), npy(outs[0])
     assert Lv is None or hmc
+    if chainop:
+        chain_operator_block(out, dyn, x0, chainop, hmc=hmc)
 
     for k, v in out.items():
         if isinstance(v, np.ndarray) and v.dtype == np.float64:
@@ -189,6 +196,30 @@ def run_case(name, x_dim, H, T, eps, N, energy_fn, energy_params, seed, hmc=Fals
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print('%-18s N=%-4d d=%-3d T=%-3d  mean p fwd %.3f bwd %.3f  |x|max %.2f' % (
         name, N, x_dim, T, out['fwd.p'].mean(), out['bwd.p'].mean(), np.abs(out['fwd.x']).max()))
+
+
+def chain_operator_block(out, dyn, x0, nb_steps, hmc=False, aux=None):
+    """The reference's own `chain_operator` (sampler.py:57-85) on the case's sampler: `nb_steps` composed
+    `propose(..., log_jac=True)` calls, one accept against (init_x, init_v), MH select.  `init_v=None` (the only
+    form the reference's callers use, eval_sampler.py:162 / mnist_vae.py:196; `if not init_v` on a tensor would
+    raise, :58): the start momentum is the first logged normal draw.  Every draw is stored in call order."""
+    del tf1_stub.RANDOM_LOG[:]
+    fx, fv, p, outs = ref_sampler.chain_operator(leaf(x0), dyn, nb_steps, aux=aux, do_mh_step=True)
+    log = list(tf1_stub.RANDOM_LOG)
+    # HMC mode (sampler.py:29-31): propose threads `init_v` into forward(), ignores `log_jac` (the summed
+    # "log-Jacobian" is a sum of accept probabilities) and always draws one MH uniform, which is discarded
+    per = ['uniform'] if hmc else ['randint', 'normal', 'normal']
+    assert [k for k, _ in log] == ['normal'] + per * nb_steps + ['uniform'], [k for k, _ in log]
+    out['chainop.K'] = np.int32(nb_steps)
+    out['chainop.init_v'] = log[0][1]
+    body = log[1:-1]
+    if not hmc:
+        out['chainop.dir'] = np.stack([body[3 * k][1][:, 0] for k in range(nb_steps)]).astype(np.uint8)
+        out['chainop.v_fwd'] = np.stack([body[3 * k + 1][1] for k in range(nb_steps)])
+        out['chainop.v_bwd'] = np.stack([body[3 * k + 2][1] for k in range(nb_steps)])
+    out['chainop.u'] = log[-1][1]
+    out['chainop.x'], out['chainop.v'], out['chainop.p'] = npy(fx), npy(fv), npy(p)
+    out['chainop.x_next'] = npy(outs[0])
 
 
 def train_case(name, mu, cov, H, T, eps, N, seed, head_std=0.3, dist=None, params=None, x_start=None):
@@ -336,6 +367,7 @@ def vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
     out['prop.dir'] = log[0][1][:, 0].astype(np.uint8)
     out['prop.v_fwd'], out['prop.v_bwd'], out['prop.u'] = log[1][1], log[2][1], log[3][1]
     out['prop.Lx'], out['prop.px'], out['prop.x_next'] = npy(Lx), npy(px), npy(outs[0])
+    chain_operator_block(out, dyn, x0, 3, aux=auxt)          # mnist_vae.py:196's image-conditioned form
     tf1_stub.VARIABLE_HOOK = None
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print('%-18s N=%-4d d=%-3d T=%-3d  mean p fwd %.3f bwd %.3f  |U| %.1f' % (
@@ -608,7 +640,36 @@ def train_funnel_case():
                x_start=lambda rng: np.concatenate([rng.randn(32, 1) * 1.5, rng.randn(32, 2)], axis=1))
 
 
+def ess_case():
+    """The reference's own diagnostics (utils/func_utils.py:45-54,114-120), imported unchanged (its
+    `tensorflow.examples...input_data` import is satisfied by an empty stub module), on a seeded AR(1)
+    history of 8 chains x 3 dims: autocovariance at a few lags, the acl spectrum and the ESS."""
+    import types
+    for nm in ('tensorflow.examples', 'tensorflow.examples.tutorials', 'tensorflow.examples.tutorials.mnist',
+               'tensorflow.examples.tutorials.mnist.input_data'):
+        sys.modules.setdefault(nm, types.ModuleType(nm))
+    sys.modules['tensorflow.examples.tutorials.mnist'].input_data = sys.modules['tensorflow.examples.tutorials.mnist.input_data']
+    import func_utils as ref_func_utils         # /root/reference/utils/func_utils.py
+    rng = np.random.RandomState(61)
+    Tm, N, d, rho = 80, 8, 3, 0.8
+    X = np.zeros((Tm, N, d))
+    X[0] = rng.randn(N, d)
+    for t in range(1, Tm):
+        X[t] = rho * X[t - 1] + np.sqrt(1 - rho ** 2) * rng.randn(N, d)
+    X = X.astype(np.float32)
+    scale = np.float64(np.sqrt(d))
+    out = {'X': X, 'scale': scale,
+           'taus': np.array([0, 1, 5, 40], dtype=np.int32),
+           'autocov': np.array([ref_func_utils.autocovariance(X, tau=t) for t in (0, 1, 5, 40)]),
+           'acl': ref_func_utils.acl_spectrum(X, scale)}
+    out['ess'] = np.float64(ref_func_utils.ESS(out['acl']))
+    np.savez_compressed(os.path.join(OUT, 'ess_funcutils.npz'), **out)
+    print('ess_funcutils      Tm=%d N=%d d=%d  ESS %.5f' % (Tm, N, d, out['ess']))
+
+
 def main():
+    if sys.argv[1:] == ['ess']:
+        return ess_case()
     if sys.argv[1:] == ['train_funnel']:         # only this fixture
         return train_funnel_case()
     if sys.argv[1:] == ['ais']:                  # only the AIS fixtures (leaves the other files untouched)
@@ -623,8 +684,8 @@ def main():
         return train_wide_cases(only_new=True)
     # C1: Strongly-correlated Gaussian 2D, exactly the notebook's target (nb:103-108)
     cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
-    gaussian_case('scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=11, x_scale=1.0)
-    gaussian_case('scg2d_hmc', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=12, hmc=True)
+    gaussian_case('scg2d', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=11, x_scale=1.0, chainop=3)
+    gaussian_case('scg2d_hmc', np.zeros(2), cov, H=10, T=10, eps=0.1, N=200, seed=12, hmc=True, chainop=2)
 
     # C2 (subset of chains): ill-conditioned Gaussian d=50, variances log-spaced 1e-2..1e2
     var = np.exp(np.linspace(np.log(1e-2), np.log(1e2), 50))
@@ -640,7 +701,9 @@ def main():
     R = np.linalg.qr(rng.randn(8, 8))[0]
     cov8 = R.T.dot(np.diag(np.exp(np.log(10.) * rng.uniform(-1, 1, size=8)))).dot(R)
     rng8_mu = rng.randn(8) * 0.5
-    gaussian_case('tilted8', rng8_mu, cov8, H=10, T=7, eps=0.1, N=48, seed=15)
+    gaussian_case('tilted8', rng8_mu, cov8, H=10, T=7, eps=0.1, N=48, seed=15, chainop=3)
+    # the same target tempered: use_temperature=True with the placeholder fed 2.5 (dynamics.py:47,203-212)
+    gaussian_case('tilted8_temp', rng8_mu, cov8, H=10, T=7, eps=0.1, N=48, seed=25, temperature=2.5)
 
     # C3 shape: 2-component MoG in 2D (paper-style: centres (+-2,0), var 0.1), T=25
     mus = [np.array([2.0, 0.0], dtype=np.float32), np.array([-2.0, 0.0], dtype=np.float32)]
@@ -722,6 +785,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'p_accept_edge.npz'), x0=x0, v0=v0, x1=x1, v1=v1,
                         logjac=lj, p=npy(p))
     print('p_accept_edge      p =', npy(p))
+    ess_case()
     # the groups that can also be regenerated on their own (see the modes at the top of main)
     ais_cases()
     wide_cases()

@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz"))
-               if not f.endswith("p_accept_edge.npz") and not os.path.basename(f).startswith(("train_", "ais_")))
+               if not f.endswith("p_accept_edge.npz") and not os.path.basename(f).startswith(("train_", "ais_", "ess_")))
+CHAINOP_CASES = ["scg2d", "scg2d_hmc", "tilted8", "vae_small"]     # goldens that carry `chainop.*` keys
 TRAIN_CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "train_*.npz")))
 AIS_CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "ais_*.npz")))
 
@@ -50,8 +51,9 @@ def oracle_dynamics(g, dtype=np.float32):
     if str(g["energy.kind"]) == "vae":        # shared encoder_sampler(aux) branch, mnist_vae.py:134-150
         w = {k: v.astype(dtype) for k, v in mlp_weights(g, "enc.").items()}
         aux_h = O.mlp3(w, g["aux"].astype(dtype))
+    temp = float(g["temperature"]) if "temperature" in g else 1.0     # fed placeholder, dynamics.py:47,204-205
     return O.Dynamics(int(g["x_dim"]), oracle_energy(g, dtype), int(g["T"]), g["eps"], g["mask"],
-                      xn, vn, dtype=dtype, aux_h=aux_h)
+                      xn, vn, temperature=temp, dtype=dtype, aux_h=aux_h)
 
 
 def rel_err(a, b):
@@ -137,7 +139,10 @@ def hip_dynamics(g, variant=0):
         energy, factory = vae.VAEPosterior(dec).get_energy_function(), vae.sampler_net_factory(d, enc, H, H)
     else:
         energy, factory = hip_energy(g), (None if hmc else layers.stq_network(int(g["H"])))
-    dyn = Dynamics(int(g["x_dim"]), energy, T=int(g["T"]), eps=float(g["eps"]), hmc=hmc, net_factory=factory)
+    dyn = Dynamics(int(g["x_dim"]), energy, T=int(g["T"]), eps=float(g["eps"]), hmc=hmc, net_factory=factory,
+                   use_temperature="temperature" in g)
+    if "temperature" in g:
+        dyn.temperature = float(g["temperature"])
     dyn.mask = g["mask"]
     dyn.eps_override = float(g["eps"])
     dyn.variant = variant

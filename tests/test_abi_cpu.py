@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_size_queries():
     L = _ffi.lib()
-    assert L.l2hmc_abi_version() == 1
+    assert L.l2hmc_abi_version() == 2
     # MFMA fragments (5 NT + 2 groups of 256 + 32 NT scales per net) + the lane layout (traj_lane.hpp: rows of RS = 12)
     lane = (2 * 50 * 12 + 3 * 12 + 10 * 12 + 12 + 25 * (6 * 10 + 12) + 3) // 4 * 4      # DP = 50 rows, 10 units
     assert L.l2hmc_packed_nets_floats(50, 10) == 2 * ((5 * 4 + 2) * 256 + 32 * 4) + 2 * lane
@@ -55,3 +55,12 @@ def test_struct_layout_matches_header():
     assert _ffi.L2hmcTrajectoryArgs.ais_alpha.offset == ctypes.sizeof(_ffi.L2hmcTrajectoryArgs) - 8
     assert _ffi.L2hmcTrajectoryArgs.ais_beta.offset == _ffi.L2hmcTrajectoryArgs.chain_offset.offset + 8
     assert _ffi.L2hmcTrajectoryArgs.rng_seed.offset == _ffi.L2hmcTrajectoryArgs.x_hist.offset + 16
+
+
+def test_struct_sizes_are_checked_against_the_library():
+    """include/l2hmc.h `l2hmc_struct_bytes`: the binding's mirrors and the compiled structs agree (checked at load too),
+    an unknown id is an argument error."""
+    L = _ffi.lib()
+    for which, mirror in enumerate(_ffi.STRUCTS):
+        assert L.l2hmc_struct_bytes(which) == ctypes.sizeof(mirror), mirror.__name__
+    assert L.l2hmc_struct_bytes(99) == -1

@@ -149,7 +149,10 @@ def _big_case(case, N, seed):
     return g
 
 
-@pytest.mark.parametrize("case,N,variant", [("scg2d", 200, 0), ("icg50", 4096, 4), ("mog2d", 65536, 33), ("mog2d", 65536, 32)])
+@pytest.mark.parametrize("case,N,variant", [("scg2d", 200, 0), ("icg50", 4096, 4), ("mog2d", 65536, 33), ("mog2d", 65536, 32),
+                                            # the one-wave-per-tile kernel (what `variant = 0` takes from 16 384 chains for
+                                            # 33 <= d <= 64) over many workgroups: 1024 / 256 four-tile workgroups
+                                            ("icg50", 65536, 16), ("rough50_easy", 16384, 16), ("icg50", 65536, 0)])
 def test_full_size_configs_against_oracle(case, N, variant):
     """BASELINE.json configs C1/C2/C3 at full chain counts: direction-mixed propose vs the
     oracle on the same seeded draws, plus sharding invariance (two half-batches == one batch,

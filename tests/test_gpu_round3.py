@@ -1,0 +1,129 @@
+"""GPU, round 3: the parity holes the round-2 review named.
+
+* `chain_operator` (utils/sampler.py:57-85) against the reference's OWN run of it (goldens' `chainop.*` keys), not only
+  against the oracle;
+* training gradients at chain counts that go through many workgroups and the two-level reduction (1024 and 4096 chains:
+  128 / 512 workgroups) against the float64 reverse-mode oracle (itself pinned by the reference-graph fixtures);
+* the tempered energy (`use_temperature`, dynamics.py:203-212) through trajectories, propose and the energy entry points
+  (the generic per-case tests of test_gpu_parity.py pick `tilted8_temp` up as well; here the bigger-d kernels).
+"""
+import numpy as np
+import pytest
+
+from oracle import l2hmc_oracle as O
+from tests.helpers import (CHAINOP_CASES, abs_err, aux_of, check_x_next, hip_dynamics, load, oracle_dynamics, rel_err,
+                           synthetic_case, to_dev, to_np)
+
+pytestmark = pytest.mark.gpu
+
+TRAJ_TOL, P_TOL = 1e-4, 1e-4
+
+
+@pytest.mark.parametrize("case", CHAINOP_CASES)
+def test_chain_operator_matches_the_reference_run(case):
+    """HIP `chain_operator` on the draws the reference's chain_operator made (init_v = its first normal draw; per
+    composed proposal the direction bits and BOTH momentum draws; the final MH uniform): final state, final momentum,
+    accept probability and MH-selected state.  K composed trajectories => 3x the single-trajectory tolerances."""
+    from l2hmc_amd import chain_operator
+    g = load(case)
+    dyn = hip_dynamics(g)
+    K = int(g["chainop.K"])
+    kw = {}
+    if not int(g["hmc"]):
+        kw = dict(directions=[to_dev(a) for a in g["chainop.dir"]],
+                  vs=[(to_dev(a), to_dev(b)) for a, b in zip(g["chainop.v_fwd"], g["chainop.v_bwd"])])
+    fx, fv, p, outs = chain_operator(to_dev(g["x"]), dyn, K, aux=aux_of(g), init_v=to_dev(g["chainop.init_v"]),
+                                     do_mh_step=True, u=to_dev(g["chainop.u"]), **kw)
+    rx, rv, rp, u = g["chainop.x"], g["chainop.v"], g["chainop.p"], g["chainop.u"]
+    fin = np.all(np.isfinite(rx), axis=1) & (np.abs(rx).max(axis=1) < 1e3)
+    assert fin.mean() > 0.9
+    print("%s: chain_operator K=%d  x %.2e  v %.2e  p %.2e" % (case, K, rel_err(to_np(fx)[fin], rx[fin]),
+                                                               rel_err(to_np(fv)[fin], rv[fin]), abs_err(to_np(p)[fin], rp[fin])))
+    assert rel_err(to_np(fx)[fin], rx[fin]) < 3 * TRAJ_TOL
+    assert rel_err(to_np(fv)[fin], rv[fin]) < 3 * TRAJ_TOL
+    assert abs_err(to_np(p)[fin], rp[fin]) < 3 * P_TOL
+    assert np.all(to_np(p)[~fin] == 0)
+    check_x_next(to_np(outs[0])[fin], g["x"][fin], rx[fin], rp[fin], u[fin], 3 * P_TOL)
+
+
+def _train_case(N, T, seed):
+    """ICG-50 weights/target of the `train_icg50` fixture with N chains in the typical set and fresh draws."""
+    g = dict(load("train_icg50"))
+    rng = np.random.RandomState(seed)
+    d = int(g["x_dim"])
+    var = 1.0 / np.diagonal(g["energy.i_sigma"])
+    g["x"] = (rng.randn(N, d) * np.sqrt(var)).astype(np.float32)
+    g["z"] = rng.randn(N, d).astype(np.float32)
+    g["T"], g["N"] = T, N
+    g["mask"] = O.init_mask(T, d, rng)
+    for pre in ("x.", "z."):
+        g[pre + "dir"] = rng.randint(0, 2, N).astype(np.uint8)
+        g[pre + "v_fwd"] = rng.randn(N, d).astype(np.float32)
+        g[pre + "v_bwd"] = rng.randn(N, d).astype(np.float32)
+    return g
+
+
+@pytest.mark.parametrize("N,T,variant", [(1024, 4, 0), (1024, 4, 100), (4096, 10, 0)])
+def test_training_gradient_at_scale_matches_the_float64_oracle(N, T, variant):
+    """2N chain-trajectories ([x; z]) = 128 / 512 sixteen-chain workgroups through the per-workgroup gradient slots and
+    the second-level reduction, against oracle/l2hmc_train_oracle.py in float64 (the fixtures stop at 64 chains).  The
+    4096-chain, Lf = 10 case is the training step `profiles/*_train_timing.txt` times."""
+    import torch
+    from oracle import l2hmc_train_oracle as TO
+    from l2hmc_amd.training import Trainer
+    g = _train_case(N, T, 17)
+    ref_loss, ref = TO.training_loss_and_grad(g, np.float64)
+    dyn = hip_dynamics(g)
+    dyn.eps_override = None
+    with torch.no_grad():
+        dyn.alpha.fill_(float(np.log(g["eps"])))
+    tr = Trainer(dyn)
+    tr.variant = variant
+    draws = {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
+             "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
+             "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
+    loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+    assert abs(float(loss) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (float(loss), ref_loss)
+    assert rel_err(to_np(Lx), ref["Lx"]) < TRAJ_TOL and abs_err(to_np(px), ref["px"]) < P_TOL
+    scale = max(float(np.abs(ref[n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+    worst = 0.0
+    for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
+        for k in O.NET_KEYS:
+            r = np.asarray(ref["%s.%s" % (n, k)])
+            got = to_np(w[k].grad).reshape(r.shape)
+            worst = max(worst, float(np.abs(got - r).max()))
+            assert np.abs(got - r).max() < 2e-4 * scale, (n, k, np.abs(got - r).max(), scale)
+    ga = float(dyn.alpha.grad)
+    print("N=%d T=%d variant %d: loss %.6e (ref %.6e)  max |dgrad| %.2e (scale %.2e)  alpha %.5e vs %.5e"
+          % (N, T, variant, float(loss), ref_loss, worst, scale, ga, float(ref["alpha"])))
+    assert abs(ga - float(ref["alpha"])) < 2e-4 * max(scale, abs(float(ref["alpha"])))
+    # bitwise reproducible at this size too (fixed-order slot reduction, no atomics)
+    flat1 = tr.flat.clone()
+    tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+    assert torch.equal(flat1, tr.flat)
+
+
+@pytest.mark.parametrize("kind,d,variant", [("gauss_diag", 50, 0), ("gauss_diag", 50, 16), ("gauss_dense", 24, 0),
+                                            ("roughwell_easy", 40, 0), ("gauss_diag", 200, 0), ("gauss_diag", 2, 32)])
+def test_tempered_energy_on_every_kernel_family(kind, d, variant):
+    """use_temperature=True, T = 2.5 (dynamics.py:203-212: U and grad U divided by the fed temperature) -- the fast /
+    tile / dense / wide / lane kernels must either honour it or hand over to a kernel that does: propose vs the oracle,
+    energy and gradient entry points vs the oracle."""
+    from l2hmc_amd import propose
+    N = 96
+    g = synthetic_case(kind, d, H=10, T=5, N=N, seed=d)
+    g["temperature"] = np.float32(2.5)
+    rng = np.random.RandomState(4)
+    dr, u = rng.randint(0, 2, N).astype(np.uint8), rng.rand(N).astype(np.float32)
+    dyn, od = hip_dynamics(g, variant), oracle_dynamics(g)
+    assert dyn.use_temperature and dyn.temperature == 2.5
+    Lx, _, px, o = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(dr), v=to_dev(g["v"]), u=to_dev(u))
+    with np.errstate(all="ignore"):
+        rLx, _, rpx, _ = O.propose(g["x"], od, g["v"], g["v"], dr, u, both_directions=False)
+        cold = O.propose(g["x"], oracle_dynamics({k: v for k, v in g.items() if k != "temperature"}), g["v"], g["v"],
+                         dr, u, both_directions=False)
+    assert rel_err(cold[0], rLx) > 1e-2          # the temperature really changes the trajectory
+    assert rel_err(to_np(Lx), rLx) < TRAJ_TOL and abs_err(to_np(px), rpx) < P_TOL, (kind, d, variant)
+    check_x_next(to_np(o[0]), g["x"], rLx, rpx, u, P_TOL)
+    assert rel_err(to_np(dyn.energy(to_dev(g["x"]))), od.energy(g["x"])) < 1e-5
+    assert rel_err(to_np(dyn.grad_energy(to_dev(g["x"]))), od.grad_energy(g["x"])) < 1e-5

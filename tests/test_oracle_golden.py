@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import l2hmc_oracle as O
-from tests.helpers import CASES, abs_err, check_x_next, load, oracle_dynamics, rel_err
+from tests.helpers import CASES, CHAINOP_CASES, abs_err, check_x_next, load, oracle_dynamics, rel_err
 
 STEP_TOL = 3e-5     # one generalised leapfrog step (funnel's |grad| ~ 5e3 amplifies: 1.3e-5 seen)
 TRAJ_TOL = 1e-4     # T steps
@@ -74,6 +74,43 @@ def test_propose(case, both):
     check_x_next(g["prop.x_next"], x, g["prop.Lx"], g["prop.px"], g["prop.u"], 1e-4)
 
 
+def chainop_inputs(g):
+    """(init_v, v_fwd list, v_bwd list, directions list, u) of the recorded chain_operator run."""
+    K = int(g["chainop.K"])
+    if int(g["hmc"]):
+        return K, g["chainop.init_v"], None, None, None, g["chainop.u"]
+    return (K, g["chainop.init_v"], list(g["chainop.v_fwd"]), list(g["chainop.v_bwd"]), list(g["chainop.dir"]),
+            g["chainop.u"])
+
+
+@pytest.mark.parametrize("case", CHAINOP_CASES)
+def test_chain_operator(case):
+    """sampler.py:57-85 -- the reference's own `chain_operator` run on its recorded draws (init_v = its first
+    normal draw): composed proposals with summed log-Jacobians, one accept against the start point, MH select."""
+    g = load(case)
+    d = oracle_dynamics(g)
+    K, init_v, vf, vb, dirs, u = chainop_inputs(g)
+    with np.errstate(all="ignore"):
+        fx, fv, p, xn = O.chain_operator(g["x"], d, K, init_v, vf, vb, dirs, u)
+    fin = np.all(np.isfinite(g["chainop.x"]), axis=1)
+    assert fin.mean() > 0.9
+    assert rel_err(fx[fin], g["chainop.x"][fin]) < 3 * TRAJ_TOL
+    assert rel_err(fv[fin], g["chainop.v"][fin]) < 3 * TRAJ_TOL
+    assert abs_err(p[fin], g["chainop.p"][fin]) < 3 * P_TOL
+    assert np.all(p[~fin] == 0) and np.all(g["chainop.p"][~fin] == 0)
+    check_x_next(xn[fin], g["x"][fin], g["chainop.x"][fin], g["chainop.p"][fin], u[fin], 3e-4)
+    check_x_next(g["chainop.x_next"][fin], g["x"][fin], g["chainop.x"][fin], g["chainop.p"][fin], u[fin], 3e-4)
+
+
+def test_tempered_case_is_really_tempered():
+    """`tilted8_temp` was produced with use_temperature=True and the placeholder fed 2.5 (dynamics.py:203-212):
+    its energy is the plain Gaussian energy / 2.5."""
+    g = load("tilted8_temp")
+    assert float(g["temperature"]) == 2.5
+    U, _ = O.Gaussian(g["energy.mu"], g["energy.i_sigma"])(g["x"])
+    assert rel_err(U / np.float32(2.5), g["energy"]) < 1e-6
+
+
 def test_p_accept_edge_cases():
     """dynamics.py:302-309: non-finite accept probabilities become 0."""
     g = load("p_accept_edge")
@@ -136,6 +173,25 @@ def test_ess_helpers():
     assert A.shape == (49,)
     assert abs(A[0] - np.mean(np.sum(X * X, axis=(1, 2)) / 8)) < 1e-12
     assert 0 < O.ESS(A / A[0]) <= 1.0 + 1e-9
+
+
+def test_ess_helpers_match_the_reference_func_utils():
+    """utils/func_utils.py:45-54,114-120 executed unchanged (oracle/make_goldens.py `ess_case`) on a seeded
+    AR(1) history: autocovariance at four lags, the whole acl spectrum and the ESS."""
+    g = load("ess_funcutils")
+    # scale as the generator passed it: an np.float64 scalar (under numpy 2 `X / scale` is then float64; the
+    # numpy-1.x value-based casting of the reference's day kept float32 -- covered by the 1e-6 check below)
+    X, scale = g["X"], np.float64(g["scale"])
+    for tau, ref in zip(g["taus"], g["autocov"]):
+        assert abs(O.autocovariance(X, int(tau)) - ref) <= 1e-12 * max(1.0, abs(ref))
+    A = O.acl_spectrum(X, scale)
+    assert A.shape == g["acl"].shape and np.max(np.abs(A - g["acl"])) < 1e-12
+    assert abs(O.ESS(A) - float(g["ess"])) < 1e-12
+    assert np.max(np.abs(O.acl_spectrum(X, float(scale)) - g["acl"])) < 1e-6          # float32 arithmetic
+    # the product's host-side mirror (numpy path) is the same arithmetic
+    from l2hmc_amd import func_utils as F
+    assert np.max(np.abs(np.asarray(F.acl_spectrum(X, scale)) - g["acl"])) < 1e-6
+    assert abs(float(F.ESS(np.asarray(g["acl"]))) - float(g["ess"])) < 1e-9
 
 
 def test_philox_known_answers():

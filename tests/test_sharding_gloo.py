@@ -75,6 +75,48 @@ def test_single_process_fallthrough():
     assert np.allclose(sharding.acl_spectrum(X, 1.0, 4), func_utils.acl_spectrum(X, 1.0))
 
 
+def _layout_worker(rank, world, port, out):
+    """The host logic of `Trainer._shard` on CPU tensors: between two steps only rank 0's local chain count changes
+    (501 -> 500; rank 1 stays at 500).  Every rank must enter the same collectives in the same order -- the counts
+    exchange, then a differently-sized "flat gradient" all-reduce -- and see the new global layout."""
+    import types
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from l2hmc_amd.training import Trainer
+        tr = types.SimpleNamespace(dyn=types.SimpleNamespace(device=torch.device("cpu")), _layout=None,
+                                   _world=lambda: world)
+        seen = []
+        for n_local in ((501, 500), (500, 500), (500, 499)):
+            n_total, off = Trainer._shard(tr, n_local[rank])
+            flat = torch.full((7,), float(rank + 1))
+            dist.all_reduce(flat)                                   # the step's gradient all-reduce
+            seen.append((n_total, off, float(flat[0])))
+        Trainer.set_sharding(tr, 1234, 617 * rank)                  # declared layout: no collective at all
+        seen.append(Trainer._shard(tr, 617) + (0.0,))
+        out.put((rank, seen))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_shard_layout_is_rediscovered_when_only_one_ranks_count_changes():
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_layout_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(100)
+        assert pr.exitcode == 0
+    res = dict(out.get() for _ in range(2))
+    assert res[0] == [(1001, 0, 3.0), (1000, 0, 3.0), (999, 0, 3.0), (1234, 0, 0.0)]
+    assert res[1] == [(1001, 501, 3.0), (1000, 500, 3.0), (999, 500, 3.0), (1234, 617, 0.0)]
+
+
 def _train_worker(rank, world, port, out):
     """One rank of a 2-process training step on the SAME GPU (gloo all-reduce of the flat gradient):
     exercises `Trainer`'s world_size > 1 branch end to end against the reference's full-batch gradient."""
