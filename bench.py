@@ -12,7 +12,11 @@ Synthetic inputs (seeded weights, masks, start points) are resident in HBM befor
 region; the per-step random draws v / direction / u come from the in-kernel Philox stream
 (`--rng bank`: pre-generated in HBM instead).
 
-    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torchrun)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1 either way: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) every process is one rank; a plain `python bench.py --gpus N` (no WORLD_SIZE) re-executes
+itself through torch.distributed.run with N ranks on 127.0.0.1 -- one process per GPU over RCCL in both cases.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant
 kernel = traj_fast_kernel, MFMA-bound: algorithmic fp32 flops / launch duration vs the 157.3
@@ -23,9 +27,10 @@ Short runs: a K-step plan that would last less than `--min-timed-ms` (20 ms) is 
 inside the timed region (R in `config.repeats`; value / ms_per_step are means over the K x R steps),
 so `--steps 20` (0.5 ms of GPU time) measures the same rate as a long run.
 
-Multi-GPU: `--gpus N` alone is weak scaling (`--chains` per GPU); `--total-chains C` is strong
-scaling (C chains split over the N ranks, e.g. the north-star 65 536).  At N > 1 the `dist` key
-reports the collectives of the path: ESS of chains sharded over the ranks (one all-reduce of the
+Multi-GPU: `--gpus N` alone is weak scaling (`--chains` per GPU; the bench line); `--total-chains C` makes the line
+strong scaling (C chains split over the N ranks).  At N > 1 two extra keys: `strong65536` = the north star's operating
+point, ICG-50 with 65 536 chains IN TOTAL split over the ranks (value, rank 0's roofline fraction, ratio to the committed
+N = 1 rate), and `dist` = the collectives of the path: ESS of chains sharded over the ranks (one all-reduce of the
 autocovariance partial sums + mean accept) and a timed training step (flat-gradient all-reduce).
 """
 import argparse
@@ -213,7 +218,7 @@ def config5_leg(dev, chains=8192):
             "kernels": "gemm_nt_kernel (fused epilogues), net_eval_kernel (+ fused half-updates), gemm_tn_kernel (training)",
             "ms_per_proposal": ms_prop, "value": chains * T / (ms_prop * 1e-3), "unit": "chain\u00b7leapfrog-steps/s",
             "flops_per_chain_step": flops_step, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "frac": ach / PEAK_F32_MFMA_TFLOPS,
-            "mean_accept_prob": float(state["p"].mean()),
+            "mean_accept_prob": float(state["p"].mean()), "state_finite": bool(torch.isfinite(state["x"]).all()),
             "train": {"workload": "sampler update of mnist_vae.py:185-262, one differentiated proposal per step",
                       "ms_per_step": ms_train, "flops_per_chain": flops_train,
                       "achieved": chains * flops_train / (ms_train * 1e-3) / 1e12,
@@ -302,11 +307,19 @@ def ess_leg(dev, train_steps=5000, seeds=5):
         e1.record()
         torch.cuda.synchronize(dev)
         rate = nb * 10 * 3 * M / (e0.elapsed_time(e1) * 1e-3)
-        out["l2hmc_65536_chains"] = {"workload": "SCG-2D, the trained L2HMC sampler on 65 536 chains, Lf=10",
+        # ESS per MH step MEASURED at this chain count: 400 recorded MH steps of all 65 536 chains (the history and
+        # its autocovariance stay on the device), not the 200-chain figure carried over
+        Mh = 400
+        xs0 = xb.clone()
+        _, ph, hist = sample_chain(xs0, dyn, Mh, seed=11, record=True)
+        Xh = torch.cat([xs0[None], hist[:-1]], dim=0)
+        ess_b = float(func_utils.ESS(func_utils.acl_spectrum(Xh, scale)))
+        out["l2hmc_65536_chains"] = {"workload": "SCG-2D, the trained L2HMC sampler (last seed) on 65 536 chains, Lf=10; "
+                                                 "ESS from %d recorded MH steps of all chains (device autocovariance)" % Mh,
                                      "chain_leapfrog_steps_per_sec": rate, "mean_accept_prob": float(pb.mean()),
-                                     # ESS/s at this chain count = (MH steps/s summed over chains) x the ESS per MH step
-                                     # measured above on the notebook's 200 chains (mean over the seeds)
-                                     "ess_per_sec": rate / 10.0 * l2["ess_per_mh_step"]}
+                                     "ess_per_mh_step": ess_b, "state_finite": bool(torch.isfinite(xb).all()),
+                                     # ESS/s = (MH steps/s summed over the chains) x the ESS per MH step measured here
+                                     "ess_per_sec": rate / 10.0 * ess_b}
     return out
 
 
@@ -412,6 +425,17 @@ def main():
 
     # (the host driver only supports dmabuf IPC: RCCL needs this for multi-process runs)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- N ranks of this very script, one per GPU
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -431,7 +455,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch `python bench.py --gpus N` (it spawns its ranks itself) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
 
     from l2hmc_amd import Dynamics, _ffi, distributions, layers, sharding
 
@@ -560,6 +586,40 @@ def main():
         """the library's dispatch for this workload (l2hmc_abi.hip): one-wave tiles once the chip is full"""
         return "traj_tile_kernel" if chains >= 16384 else "traj_fast_kernel"
 
+    def point(nc, chain_off_, seed, steps=100):
+        """one extra roofline point: `nc` chains on this rank through the same sampler loop, timed like the main
+        run (barrier, max over ranks) -> (wall s, HIP-event ms, launches, proposals, mean accept, state finite)"""
+        r2 = Runner(nc, chain_off_, seed)
+        f2, est2 = calibrate(r2, 0, steps)
+        reps = max(1, int(math.ceil(args.min_timed_ms / (steps * est2))))
+        el2, ms2, nl2, _ = timed(r2, f2, steps, reps)
+        if world > 1:
+            t2 = torch.tensor([el2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            el2 = float(t2)
+        return (el2, ms2, nl2, steps * reps, float(r2.p_out.mean()),
+                bool(torch.isfinite(r2.bufs[r2.flip]).all()))
+
+    strong_out = None
+    if world > 1 and not strong and not args.no_sweep:
+        # the north star's operating point: ICG-50, 65 536 chains IN TOTAL over the ranks (every rank takes part)
+        tot = 65536
+        lo, hi = sharding.shard_range(tot, rank, world)
+        el2, ms2, nl2, k2, p2, fin2 = point(hi - lo, lo, 4321 + rank)
+        a2 = flops_cs * (hi - lo) * T * (k2 / float(nl2)) / (ms2 * 1e-3 / nl2) / 1e12
+        strong_out = {"workload": "ICG-50D, %d chains in total = %d per GPU, Lf=10 (north_star: >= 1e8 on 8 GPUs, "
+                                  ">= 6x 1 -> 8)" % (tot, hi - lo),
+                      "value": tot * T * float(k2) / el2, "unit": "chain·leapfrog-steps/s", "scaling": "strong",
+                      "chains_per_gpu": hi - lo, "kernel": kernel_for(hi - lo), "rank0_achieved": a2,
+                      "rank0_frac": a2 / PEAK_F32_MFMA_TFLOPS, "rank0_launch_us": 1e3 * ms2 / nl2,
+                      "mean_accept_prob": p2, "state_finite": fin2}
+        ref = os.path.join(ROOT, "profiles", "n1_sweep65536.json")
+        if os.path.exists(ref):           # the committed N = 1 rate of the same 65 536 chains on one GPU
+            v1 = json.load(open(ref))
+            strong_out["n1_value"] = v1["value"]
+            strong_out["n1_source"] = v1["source"]
+            strong_out["speedup_vs_n1"] = strong_out["value"] / v1["value"]
+
     dist_out = None
     if use_dist and not args.no_ess:
         dist_out = dist_leg(dev, rank, world)
@@ -582,7 +642,8 @@ def main():
                                    % ("%d chains in total over %d GPU(s)" % (n_total, world) if strong
                                       else "%d chains per GPU" % n),
                        "chains_per_gpu": n, "chains_total": n_total, "x_dim": D, "hidden": H, "leapfrog_steps": T,
-                       "proposals_per_launch": M, "rng": args.rng, "preheat_proposals": pre,
+                       "proposals_per_launch": m_avg, "proposals_per_launch_max": M, "rng": args.rng,
+                       "preheat_proposals": pre,
                        "repeats": R, "timed_steps": k_timed,
                        "parallelism": "chains sharded, no data-path collective",
                        "mean_accept_prob": mean_p, "state_finite": finite},
@@ -595,27 +656,31 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):          # HBM bytes per launch from the committed PMC passes
             t = json.load(open(tj))
-            if t.get("workload_chains") == n and t.get("proposals_per_launch", 1) == M:
-                out["roofline"]["traffic"] = 1024.0 * (t["fetch_kb"] + t["write_kb"])
-                out["roofline"]["traffic_source"] = t["source"]
+            if t.get("workload_chains") == n:
+                # counters were collected on launches of t[proposals_per_launch] proposals; per launch x, x_next move
+                # once and only p (n floats per proposal) scales with the proposals actually chained here
+                m_ref = float(t.get("proposals_per_launch", 1))
+                out["roofline"]["traffic"] = 1024.0 * (t["fetch_kb"] + t["write_kb"]) + (m_avg - m_ref) * 4.0 * n
+                out["roofline"]["traffic_source"] = t["source"] + (
+                    "" if m_avg == m_ref else "; p_out bytes rescaled from %g to %g proposals per launch" % (m_ref, m_avg))
         if world == 1 and not args.no_sweep and not strong and n == CHAINS:
             # the same kernel at the north star's chain count: what the MFMA roof fraction becomes once the
             # chip is filled (4096 chains are ONE workgroup per CU, one wave per SIMD)
             sweep = []
-            for nc in (65536,):
-                r2 = Runner(nc, 0, 99)
-                f2, est2 = calibrate(r2, 0, 100)
-                reps = max(1, int(math.ceil(args.min_timed_ms / (100 * est2))))
-                el2, ms2, nl2, _ = timed(r2, f2, 100, reps)
-                a2 = flops_cs * nc * T * (100 * reps / float(nl2)) / (ms2 * 1e-3 / nl2) / 1e12
+            for nc in (8192, 65536):      # 8192 = one GPU's share of the north star's 65 536 chains on 8 GPUs
+                el2, ms2, nl2, k2, p2, fin2 = point(nc, 0, 99)
+                a2 = flops_cs * nc * T * (k2 / float(nl2)) / (ms2 * 1e-3 / nl2) / 1e12
                 sweep.append({"chains": nc, "kernel": kernel_for(nc),
-                              "value": nc * T * 100.0 * reps / el2, "achieved": a2,
-                              "frac": a2 / PEAK_F32_MFMA_TFLOPS, "launch_us": 1e3 * ms2 / nl2})
+                              "value": nc * T * float(k2) / el2, "achieved": a2,
+                              "frac": a2 / PEAK_F32_MFMA_TFLOPS, "launch_us": 1e3 * ms2 / nl2,
+                              "mean_accept_prob": p2, "state_finite": fin2})
             out["sweep"] = sweep
         if world == 1 and not args.no_config5 and not strong and n == CHAINS and not args.force_dist:
             out["config5"] = config5_leg(dev)
         if world == 1 and not args.no_ess and not args.force_dist:
             out["ess"] = ess_leg(dev, args.ess_train_steps, args.ess_seeds)
+        if strong_out is not None:
+            out["strong65536"] = strong_out
         if dist_out is not None:
             out["dist"] = dist_out
         if world == 1 and not args.no_cpu_baseline:

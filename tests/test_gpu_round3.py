@@ -136,3 +136,39 @@ def test_tempered_energy_on_every_kernel_family(kind, d, variant):
         bv, bd = np.tile(g["v"], (171, 1))[:16384], np.tile(dr, 171)[:16384]
         bLx, _, bpx, _ = propose(to_dev(big), dyn, direction=to_dev(bd), v=to_dev(bv))
         assert rel_err(to_np(bLx)[:N], rLx) < TRAJ_TOL and abs_err(to_np(bpx)[:N], rpx) < P_TOL
+
+
+@pytest.mark.timeout(600)
+def test_bench_launches_its_own_ranks_the_way_the_driver_calls_it():
+    """`python bench.py --gpus 2` with NO torchrun and no WORLD_SIZE (the driver's plain invocation): bench.py becomes the
+    launcher, two ranks start through torch.distributed.run, rank 0 prints ONE JSON line.  Rehearsed on the 1-GPU box with
+    both ranks on cuda:0 over gloo (`--one-device --backend gloo`; on the 8-GPU node the same path runs one rank per GPU
+    over RCCL).  Checks the weak-scaling headline, the `strong65536` key (65 536 chains in total over the ranks) and the
+    `dist` key (sharded ESS + flat-gradient all-reduce)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo",
+                        "--steps", "20", "--warmup", "5"], capture_output=True, text=True, timeout=560, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 20 and out["warmup"] == 5
+    assert out["config"]["chains_per_gpu"] == 4096 and out["config"]["chains_total"] == 8192
+    assert out["config"]["state_finite"] and out["value"] > 1e8
+    s = out["strong65536"]
+    assert s["chains_per_gpu"] == 32768 and s["scaling"] == "strong" and s["state_finite"] and s["value"] > 1e8
+    assert 0.0 < s["rank0_frac"] < 1.0 and 0.01 < s["mean_accept_prob"] <= 1.0
+    d = out["dist"]
+    assert d["rccl_ranks"] == 2 and d["sharded_training"]["parameters_identical_across_ranks"]
+    assert 4e-3 < d["sharded_ess"]["ess_per_mh_step"] < 8e-3
+    # a mismatching --gpus / WORLD_SIZE is a clear error, not an assert deep inside
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                        timeout=120, env=env2)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
