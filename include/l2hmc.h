@@ -216,6 +216,21 @@ typedef struct L2hmcMlp3 {
  *           RAW reference-layout weights (not the packed buffer).
  * The dense products run in this library's own fp32 MFMA GEMM (csrc/gemm_f32.hpp) with the bias / softplus /
  * sigmoid / relu / BCE-gradient / chain-rule work fused into its epilogues; no BLAS library is used. */
+/* A caller-supplied target energy: the `energy_function` protocol of utils/dynamics.py:203-218 (`self._fn(x[, aux])`
+ * and tf.gradients of it) for energies OUTSIDE the fused set -- e.g. a closure like mnist_vae.py:122-126 or any density
+ * the caller can differentiate.  The library calls it on the HOST, between kernel launches, whenever the trajectory
+ * needs grad U (once per leapfrog step + once at the start) and U (at the two end points):
+ *   x        (n_chains, d) current positions, row stride ldx floats (device memory inside the workspace)
+ *   U_out    NULL, or (n_chains) DOUBLES to fill with U(x) (|U| can be ~1e3: the accept probability takes a
+ *            difference of two of them)
+ *   grad_out (n_chains, d) floats, row stride ldg, to fill with grad U(x)
+ * All work must be enqueued on `stream` (no synchronisation needed); return 0, or non-zero to abort the trajectory
+ * (l2hmc_trajectory_split then returns L2HMC_ERR_ARG).  Tempering / annealing of a user energy is the callback's own
+ * business.  This is the SLOW path by construction (a host round trip per gradient); the leapfrog half-updates and the
+ * S/T/Q nets stay on the library's kernels. */
+typedef int (*L2hmcEnergyCallback)(void* user, const float* x, int64_t ldx, int64_t n_chains, int32_t d,
+                                   double* U_out, float* grad_out, int64_t ldg, void* stream);
+
 typedef struct L2hmcSplitArgs {
   const L2hmcNet* xnet;
   const L2hmcNet* vnet;
@@ -251,6 +266,10 @@ typedef struct L2hmcSplitArgs {
                                   *    2: the image branch aux_encoder(aux) -- aux and aux_encoder unchanged.
                                   *    A sampling loop passes 3 from its second proposal on (mnist_vae.py:185-224:
                                   *    weights and images are fixed while the chain runs)                  */
+  L2hmcEnergyCallback energy_cb; /* non-NULL: the caller's energy (see L2hmcEnergyCallback); decoder = energy = NULL.
+                                  *    aux_encoder + aux may still be given (image-conditioned nets,
+                                  *    mnist_vae.py:134-150: aux is (N, aux_encoder->n_in)); HMC mode is allowed  */
+  void* energy_cb_user;          /* passed back as the callback's first argument                              */
 } L2hmcSplitArgs;
 
 int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,

@@ -357,9 +357,14 @@ int l2hmc_p_accept_energies(const float* U0, const float* v0, const float* U1, c
 
 int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
+  const bool user = a->energy_cb != nullptr;        // the caller's own energy, evaluated on the host between launches
   const bool builtin = a->energy != nullptr;        // a target of utils/distributions.py instead of the decoder posterior
   int rc;
-  if (builtin) {
+  if (user) {
+    if (a->decoder || a->energy) return fail(L2HMC_ERR_ARG, "energy_cb excludes decoder and energy%s");
+    if (a->bce_scale != 0.f) return fail(L2HMC_ERR_UNSUPPORTED, "bce_scale with a caller-supplied energy (anneal it in the callback)%s");
+    if (a->aux_encoder && !a->aux) return fail(L2HMC_ERR_ARG, "aux_encoder needs aux%s");
+  } else if (builtin) {
     if (a->decoder || a->aux_encoder || a->hmc)
       return fail(L2HMC_ERR_UNSUPPORTED, "a built-in energy excludes decoder / aux_encoder / hmc (HMC mode runs on l2hmc_trajectory)%s");
     if ((rc = check_energy(a->energy, a->d))) return rc;
@@ -373,14 +378,14 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (N < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
   if (N == 0) return L2HMC_OK;
   const bool hmc = a->hmc != 0;
-  if ((!hmc && (!a->xnet || !a->vnet || !a->masks || !a->trig)) || (!builtin && !a->aux) || !a->x || !a->v || !a->workspace)
+  if ((!hmc && (!a->xnet || !a->vnet || !a->masks || !a->trig)) || (!builtin && !user && !a->aux) || !a->x || !a->v || !a->workspace)
     return fail(L2HMC_ERR_ARG, "l2hmc_trajectory_split: NULL pointer%s");
   if (hmc && (a->direction != nullptr || a->direction_all == 0))
     return fail(L2HMC_ERR_UNSUPPORTED, "HMC mode runs forward only (sampler.py:29-31, ais.py:61)%s");
   if (!(a->bce_scale >= 0.f && a->bce_scale <= 1.f)) return fail(L2HMC_ERR_ARG, "bce_scale must be in [0, 1] (0 = off)%s");
   const float beta = a->bce_scale > 0.f ? a->bce_scale : 1.f;
-  if (!builtin && a->decoder->n_in != d) return fail(L2HMC_ERR_ARG, "decoder input width != d%s");
-  if (a->aux_encoder && (a->aux_encoder->n_out != H || a->aux_encoder->n_in != a->decoder->n_out))
+  if (!builtin && !user && a->decoder->n_in != d) return fail(L2HMC_ERR_ARG, "decoder input width != d%s");
+  if (a->aux_encoder && (a->aux_encoder->n_out != H || (!user && a->aux_encoder->n_in != a->decoder->n_out)))
     return fail(L2HMC_ERR_ARG, "aux_encoder must map (N, n_pix) -> (N, H)%s");
   if (a->step_begin < 0 || a->n_steps < 0 || a->step_begin + a->n_steps > T) return fail(L2HMC_ERR_ARG, "steps outside the schedule%s");
   if (a->x_next && !a->u) return fail(L2HMC_ERR_ARG, "x_next needs u%s");
@@ -390,7 +395,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   float* w = a->workspace;
   static const L2hmcMlp3 no_dec = {};
-  const L2hmcMlp3& dec = builtin ? no_dec : *a->decoder;
+  const L2hmcMlp3& dec = (builtin || user) ? no_dec : *a->decoder;
   const Mlp3Ws dws = {w + p.dw1t, w + p.dw2t, w + p.dw3t, w + p.a1, w + p.s1, w + p.a2, w + p.s2};
   // [x | grad U] and [v_h | masked x] live side by side (row stride L = 2 d): they are the first-layer inputs
   const int L = 2 * d;
@@ -406,7 +411,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   (void)hipMemcpy2DAsync(xc, sizeof(float) * L, a->x, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
   (void)hipMemcpyAsync(vc, a->v, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
   const bool have_w = (a->reuse & 1) != 0, have_auxh = (a->reuse & 2) != 0;    // still in the workspace (caller vouches)
-  if (!builtin && !have_w) mlp3_transposes(s, dec, dws);
+  if (!builtin && !user && !have_w) mlp3_transposes(s, dec, dws);
   if (a->aux_encoder && !hmc) {      // the image branch is step-invariant: once per trajectory, not 4T times
     const L2hmcMlp3& enc = *a->aux_encoder;
     const Mlp3Ws ews = {w + p.ew1t, w + p.ew2t, w + p.ew3t, w + p.e1, nullptr, w + p.e2, nullptr};
@@ -436,6 +441,10 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   // U (double, optional) and grad U at the current x: the decoder posterior (six GEMMs) or one of the built-in
   // targets (the fused kernels' own energy kernel on a contiguous copy of x)
   auto energy_eval = [&](double* Ud) -> int {
+    if (user) {      // the caller enqueues U / grad U of the (N, d) block at xc (row stride L) on this stream
+      const int r = a->energy_cb(a->energy_cb_user, xc, L, N, d, Ud, g, L, stream);
+      return r ? fail(L2HMC_ERR_ARG, "the energy callback failed (returned %s%lld)", "", (long long)r) : L2HMC_OK;
+    }
     if (!builtin) {
       vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, Ud, g, L, beta);
       return L2HMC_OK;

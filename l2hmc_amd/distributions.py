@@ -75,6 +75,72 @@ class EnergyFunction(object):
         return self.evaluate(x)[0]
 
 
+ENERGY_USER = 100     # python-side tag: a caller-supplied energy (L2hmcSplitArgs.energy_cb)
+
+
+class UserEnergy(EnergyFunction):
+    """A caller-supplied target: ANY callable `fn(x[, aux=...]) -> (N,)` on ROCm tensors that torch can differentiate
+    (the `energy_function` protocol of the reference's Dynamics, utils/dynamics.py:203-218: `self._fn(x[, aux])` and
+    `tf.gradients` of it) -- e.g. the closure of mnist_vae.py:122-126, or a density that is not in
+    utils/distributions.py.  `Dynamics(x_dim, fn)` wraps a plain callable in one of these by itself.
+
+    This is the SLOW path, by construction: U and grad U are computed by the caller's torch code between kernel
+    launches (`grad_fn(x[, aux=...]) -> (N, d)` if given, else autograd of `fn`), one host round trip per leapfrog step;
+    the leapfrog half-updates, the S/T/Q nets, the log-determinant, the accept probability and the MH select stay on
+    the library's HIP kernels (GEMM engine, `l2hmc_trajectory_split`).  Training the sampler on such a target would
+    need Hessian-vector products of U and is not implemented."""
+
+    def __init__(self, fn, grad_fn=None, x_dim=None):
+        EnergyFunction.__init__(self, ENERGY_USER, x_dim=x_dim)
+        if not callable(fn) or (grad_fn is not None and not callable(grad_fn)):
+            raise TypeError("UserEnergy needs callables")
+        self.fn, self.grad_fn = fn, grad_fn
+
+    def _buffers(self, device):
+        raise NotImplementedError("a caller-supplied energy has no fused-kernel parameters")
+
+    def c_struct(self, device, temperature=1.0, anneal_beta=0.0):
+        raise NotImplementedError("a caller-supplied energy runs through L2hmcSplitArgs.energy_cb, not L2hmcEnergy")
+
+    def _call(self, f, x, aux):
+        return f(x) if aux is None else f(x, aux=aux)
+
+    def evaluate(self, x, temperature=1.0, want_U=True, want_grad=False, aux=None, anneal_beta=0.0):
+        """(U, grad U) of  [(1 - b) |x|^2 / 2 + b] U(x) / temperature  (b = anneal_beta, 0 = off: utils/ais.py:46-47;
+        temperature: dynamics.py:203-212) -- U as float64 (the caller's own precision kept as far as it goes)."""
+        x = as_device_f32(x)
+        U = g = None
+        if want_grad and self.grad_fn is None:
+            with torch.enable_grad():
+                xr = x.clone().requires_grad_(True)
+                Ur = self._call(self.fn, xr, aux)
+                if Ur.shape != (x.shape[0],):
+                    raise ValueError("the energy function must return shape (N,), got %s" % (tuple(Ur.shape),))
+                g, = torch.autograd.grad(Ur.sum(), xr)         # dynamics.py:217-218: tf.gradients sums over the batch
+            U = Ur.detach()
+        else:
+            with torch.no_grad():
+                if want_U:
+                    U = self._call(self.fn, x, aux)
+                    if U.shape != (x.shape[0],):
+                        raise ValueError("the energy function must return shape (N,), got %s" % (tuple(U.shape),))
+                if want_grad:
+                    g = self._call(self.grad_fn, x, aux)
+        b = float(anneal_beta)
+        if b > 0.0 and b != 1.0:
+            if U is not None:
+                U = (1.0 - b) * 0.5 * x.double().square().sum(1) + b * U.double()
+            if g is not None:
+                g = (1.0 - b) * x + b * g
+        if temperature != 1.0:
+            U = None if U is None else U.double() / float(temperature)
+            g = None if g is None else g / float(temperature)
+        return (U.double() if (U is not None and want_U) else None), (g.to(torch.float32) if g is not None else None)
+
+    def __call__(self, x, aux=None, *args, **kwargs):
+        return self.evaluate(x, aux=aux)[0].to(torch.float32)
+
+
 def as_device_f32(x, device=None):
     """numpy / torch input -> contiguous float32 tensor on the GPU."""
     if not isinstance(x, torch.Tensor):

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _ffi
-from .distributions import EnergyFunction, as_device_f32
+from .distributions import ENERGY_USER, EnergyFunction, UserEnergy, as_device_f32
 from .layers import default_device, extract_stq
 
 TF_FLOAT = torch.float32
@@ -43,7 +43,13 @@ class Dynamics(object):
                  net_factory=None,
                  eps_trainable=True,
                  use_temperature=False,
-                 device=None):
+                 device=None,
+                 grad_energy=None):
+        """utils/dynamics.py:35-43 (+ `device`, `grad_energy`).  `energy_function`: an energy of
+        l2hmc_amd.distributions / l2hmc_amd.vae (fused into the kernels), or ANY callable `fn(x[, aux=]) -> (N,)` on
+        ROCm tensors (a target outside that set, e.g. the closure of mnist_vae.py:122-126): then U and grad U come from
+        the caller's torch code between launches (`grad_energy(x[, aux=]) -> (N, d)` if given, else autograd) -- the
+        slow path, see distributions.UserEnergy."""
         self.x_dim = int(x_dim)
         self.T = int(T)
         self.hmc = bool(hmc)
@@ -56,9 +62,12 @@ class Dynamics(object):
         self.anneal_beta = 0.0          # AIS bridge (utils/ais.py:46-47): U := (1-b) |x|^2/2 + b U; 0 = off
 
         if not isinstance(energy_function, EnergyFunction):
-            raise TypeError(
-                "Dynamics needs an energy from l2hmc_amd.distributions (got %r): only those are "
-                "fused into the HIP leapfrog kernel and there is no eager fallback" % (energy_function,))
+            if not callable(energy_function):
+                raise TypeError("Dynamics needs an energy function (got %r): one of l2hmc_amd.distributions / "
+                                "l2hmc_amd.vae, or a callable fn(x[, aux=]) -> (N,)" % (energy_function,))
+            energy_function = UserEnergy(energy_function, grad_energy, self.x_dim)
+        elif grad_energy is not None:
+            raise TypeError("grad_energy= only goes with a caller-supplied energy callable")
         if energy_function.x_dim is not None and energy_function.x_dim != self.x_dim:
             raise ValueError("energy is %d-dimensional, Dynamics x_dim=%d" % (energy_function.x_dim, x_dim))
         self._fn = energy_function
@@ -111,9 +120,12 @@ class Dynamics(object):
         # (`l2hmc_trajectory_split`) -- the VAE posterior, and the built-in targets whenever the nets are wider than
         # the fused kernel's H <= 15 (nb:51-78 with H != 10; mnist_vae.py:142-167 uses 200)
         self._vae = energy_function.kind == ENERGY_VAE
-        self._split = self._vae or (not self.hmc and self.H > 15)
-        if not self._vae and not self.hmc and self._xw['aux_encoder'] is not None:
-            raise NotImplementedError("an aux (image) branch is only implemented together with the VAE posterior energy")
+        self._user = energy_function.kind == ENERGY_USER          # caller's torch code supplies U, grad U (slow path)
+        self._split = self._vae or self._user or (not self.hmc and self.H > 15)
+        self._aux_nets = (not self.hmc) and self._xw['aux_encoder'] is not None
+        if not (self._vae or self._user) and self._aux_nets:
+            raise NotImplementedError("an aux (image) branch is only implemented together with the VAE posterior energy "
+                                      "or a caller-supplied energy")
         self._split_ws = None
         self._split_key, self._split_aux = None, (None, -1)
 
@@ -227,9 +239,11 @@ class Dynamics(object):
 
     # ---- the fused trajectory ----------------------------------------------------------------------
     def _check_aux(self, aux):
-        if self._vae:
+        if self._vae or (self._user and self._aux_nets):
             if aux is None:
                 raise ValueError("this Dynamics is image-conditioned (mnist_vae.py): pass aux=")
+        elif self._user:
+            pass                   # forwarded to the caller's energy function when given
         elif aux is not None:
             raise ValueError("aux= is only meaningful for an aux-conditioned model (mnist_vae.py)")
 
@@ -246,6 +260,10 @@ class Dynamics(object):
             aux = as_device_f32(aux, self.device)
             if aux.shape != (N, self._fn.n_pix):
                 raise ValueError("aux must be (N, %d)" % self._fn.n_pix)
+        elif self._user and self._aux_nets:
+            aux = as_device_f32(aux, self.device)
+            if aux.shape != (N, self._xw['aux_encoder']['dims'][0]):
+                raise ValueError("aux must be (N, %d)" % self._xw['aux_encoder']['dims'][0])
         out = {}
         for k in ('x', 'v', 'x_next'):
             if k in want:
@@ -279,8 +297,33 @@ class Dynamics(object):
         a.vnet = C.pointer(vs) if vs is not None else None
         a.H, a.hmc, a.bce_scale = max(self.H, 1), int(self.hmc), float(self.anneal_beta)
         a.aux_encoder = C.pointer(enc) if enc is not None else None
+        cb_error = []
         if self._vae:
             a.decoder, a.aux = C.pointer(dec), aux.data_ptr()
+        elif self._user:
+            ws, temp, beta = self._split_ws, (float(self.temperature) if self.use_temperature else 1.0), float(self.anneal_beta)
+            base = ws.data_ptr()
+
+            def energy_cb(_user, xp, ldx, n, dd, Up, gp, ldg, _stream):
+                # (the library hands over addresses inside the workspace tensor: view them, no copies besides the
+                #  results; torch enqueues on its current stream, which is the stream the library was given)
+                try:
+                    xv = ws.as_strided((n, dd), (ldx, 1), (xp - base) // 4)
+                    U, g = self._fn.evaluate(xv, temp, want_U=bool(Up), want_grad=True, aux=aux, anneal_beta=beta)
+                    if tuple(g.shape) != (n, dd):
+                        raise ValueError("grad_energy must return shape (N, d), got %s" % (tuple(g.shape),))
+                    ws.as_strided((n, dd), (ldg, 1), (gp - base) // 4).copy_(g)
+                    if Up:
+                        o = (Up - base) // 4
+                        ws[o:o + 2 * n].view(torch.float64).copy_(U)
+                    return 0
+                except Exception as e:                       # never let an exception cross the C frame
+                    cb_error.append(e)
+                    return 1
+            cb = _ffi.ENERGY_CALLBACK(energy_cb)             # (kept alive by this frame for the duration of the call)
+            a.energy_cb = C.cast(cb, C.c_void_p)
+            if self._aux_nets:
+                a.aux = aux.data_ptr()
         else:                                        # built-in target (utils/distributions.py) under wide nets
             if self.use_temperature and float(self.temperature) != 1.0:
                 raise NotImplementedError("temperature with H > 15 nets is not implemented")
@@ -303,6 +346,7 @@ class Dynamics(object):
         # clears this too), the image branch while the very same `aux` tensor object is passed again unmodified (a
         # reference to it is kept, so its address cannot be recycled for other data).
         wkey = None
+        img = self._vae or (self._user and self._aux_nets)          # an image branch whose result can be reused
         if not self.hmc:
             ws_ = [self._xw[k] for k in _ffi.NET_FIELDS] + [self._vw[k] for k in _ffi.NET_FIELDS]
             for m3 in (self._xw['aux_encoder'], self._fn.decoder if self._vae else None):
@@ -312,12 +356,15 @@ class Dynamics(object):
         reuse = 0
         if wkey is not None and wkey == self._split_key:
             reuse |= 1
-            if self._vae and aux is self._split_aux[0] and aux._version == self._split_aux[1]:
+            if img and aux is self._split_aux[0] and aux._version == self._split_aux[1]:
                 reuse |= 2
         a.reuse = reuse
-        _ffi.check(L.l2hmc_trajectory_split(a, _ffi.current_stream(x.device)))
+        rc = L.l2hmc_trajectory_split(a, _ffi.current_stream(x.device))
+        if cb_error:
+            raise cb_error[0]
+        _ffi.check(rc)
         self._split_key = wkey
-        self._split_aux = (aux, aux._version) if (self._vae and aux is not None) else (None, -1)
+        self._split_aux = (aux, aux._version) if (img and aux is not None) else (None, -1)
         return out
 
     def _run_split_chain(self, x, v, step_begin, n_steps, direction, direction_all, u, want, M, rng, aux):
@@ -462,6 +509,9 @@ class Dynamics(object):
         self._check_aux(aux)
         if self._vae:
             return self._fn.evaluate(x, aux=aux, anneal_beta=self.anneal_beta)[0]
+        if self._user:
+            return self._fn.evaluate(as_device_f32(x, self.device), self.temperature if self.use_temperature else 1.0,
+                                     aux=aux, anneal_beta=self.anneal_beta)[0].to(torch.float32)
         return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
                                  anneal_beta=self.anneal_beta)[0]
 
@@ -470,6 +520,9 @@ class Dynamics(object):
         self._check_aux(aux)
         if self._vae:
             return self._fn.evaluate(x, want_U=False, want_grad=True, aux=aux, anneal_beta=self.anneal_beta)[1]
+        if self._user:
+            return self._fn.evaluate(as_device_f32(x, self.device), self.temperature if self.use_temperature else 1.0,
+                                     want_U=False, want_grad=True, aux=aux, anneal_beta=self.anneal_beta)[1]
         return self._fn.evaluate(x, self.temperature if self.use_temperature else 1.0,
                                  want_U=False, want_grad=True, anneal_beta=self.anneal_beta)[1]
 
@@ -512,8 +565,8 @@ class Dynamics(object):
         lj = as_device_f32(log_jac, self.device)
         N, d = x0.shape
         p = torch.empty(N, dtype=torch.float32, device=x0.device)
-        if self._vae:                      # energies from the decoder GEMMs, then one small kernel
-            U0, U1 = self.energy(x0, aux=aux), self.energy(x1, aux=aux)
+        if self._vae or self._user:        # energies from the decoder GEMMs / the caller's code, then one small kernel
+            U0, U1 = self.energy(x0, aux=aux).contiguous(), self.energy(x1, aux=aux).contiguous()
             _ffi.check(_ffi.lib().l2hmc_p_accept_energies(U0.data_ptr(), v0.data_ptr(), U1.data_ptr(), v1.data_ptr(),
                                                           lj.data_ptr(), N, d, p.data_ptr(),
                                                           _ffi.current_stream(x0.device)))

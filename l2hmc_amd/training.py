@@ -36,6 +36,10 @@ def _numel(code, d, H):
 
 class Trainer(object):
     def __new__(cls, dynamics, *args, **kwargs):
+        if getattr(dynamics, "_user", False):
+            raise NotImplementedError("training differentiates through grad U (Hessian-vector products of the target): "
+                                      "implemented for the built-in targets and the decoder posterior, not for a "
+                                      "caller-supplied energy callable")
         # samplers that run on the GEMM engine (nets wider than H = 15, the image-conditioned VAE sampler) train there
         if cls is Trainer and getattr(dynamics, "_split", False):
             return object.__new__(SplitTrainer)

@@ -172,3 +172,155 @@ def test_bench_launches_its_own_ranks_the_way_the_driver_calls_it():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                         timeout=120, env=env2)
     assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
+# ---- caller-supplied energies (the slow path: U / grad U from the caller's torch code between launches) --------------
+def _banana_np(x, b=0.3, s=2.0):
+    """U(x) = x0^2 / (2 s^2) + 1/2 sum_{k>=1} (x_k + b x0^2 - s^2 b)^2 and its gradient (numpy; dtype of x)."""
+    t = x[:, 1:] + b * x[:, :1] ** 2 - s * s * b
+    U = 0.5 * x[:, 0] ** 2 / (s * s) + 0.5 * np.sum(t * t, axis=1)
+    g = np.empty_like(x)
+    g[:, 0] = x[:, 0] / (s * s) + 2 * b * x[:, 0] * np.sum(t, axis=1)
+    g[:, 1:] = t
+    return U, g
+
+
+def _banana_torch(x, b=0.3, s=2.0):
+    t = x[:, 1:] + b * x[:, :1] ** 2 - s * s * b
+    return 0.5 * x[:, 0] ** 2 / (s * s) + 0.5 * (t * t).sum(1)
+
+
+@pytest.mark.parametrize("H,hmc,explicit_grad", [(10, False, False), (24, False, True), (10, True, False)])
+def test_user_energy_banana_matches_the_oracle(H, hmc, explicit_grad):
+    """A target that is NOT in utils/distributions.py (a banana density), given to `Dynamics` as a plain torch callable:
+    propose + MH, single steps, energy / grad_energy / p_accept against `O.Dynamics` with the same density in numpy --
+    nets and half-updates on the HIP kernels, U / grad U from autograd (or the caller's own gradient function)."""
+    import torch
+    from l2hmc_amd import Dynamics, layers, propose, sample_chain
+    from tests.helpers import golden_nets
+    d, T, N = 6, 5, 80
+    g = synthetic_case("roughwell_easy", d, H=H, T=T, N=N, seed=H, head_std=0.3)
+    rng = np.random.RandomState(5)
+    x0 = (rng.randn(N, d) * np.array([2.0] + [1.0] * (d - 1))).astype(np.float32)
+    v0 = rng.randn(N, d).astype(np.float32)
+    dr, u = rng.randint(0, 2, N).astype(np.uint8), rng.rand(N).astype(np.float32)
+    grad_fn = None
+    if explicit_grad:
+        def grad_fn(x):
+            t = x[:, 1:] + 0.3 * x[:, :1] ** 2 - 4 * 0.3
+            return torch.cat([x[:, :1] / 4 + 0.6 * x[:, :1] * t.sum(1, keepdim=True), t], dim=1)
+    dyn = Dynamics(d, _banana_torch, T=T, eps=float(g["eps"]), hmc=hmc,
+                   net_factory=None if hmc else layers.stq_network(H), grad_energy=grad_fn)
+    dyn.mask = g["mask"]
+    dyn.eps_override = float(g["eps"])
+    xn = vn = None
+    if not hmc:
+        xn, vn = golden_nets(g)
+        with torch.no_grad():
+            for w, pre in ((dyn._xw, "xnet."), (dyn._vw, "vnet.")):
+                for k in O.NET_KEYS:
+                    w[k].copy_(torch.as_tensor(g[pre + k]).reshape(w[k].shape))
+    od = O.Dynamics(d, _banana_np, T, g["eps"], g["mask"], xn, vn)
+    od64 = O.Dynamics(d, _banana_np, T, g["eps"], g["mask"], xn, vn, dtype=np.float64)
+    # energy / gradient entry points
+    assert rel_err(to_np(dyn.energy(to_dev(x0))), od.energy(x0)) < 1e-5
+    assert rel_err(to_np(dyn.grad_energy(to_dev(x0))), od.grad_energy(x0)) < 1e-5
+    # one step in each direction, a whole proposal with MH
+    for name, hip, orc in (("fwd", dyn._forward_step, od.forward_step), ("bwd", dyn._backward_step, od.backward_step)):
+        if hmc and name == "bwd":          # HMC mode on the GEMM engine runs forward only (sampler.py:29-31 never goes back)
+            with pytest.raises(NotImplementedError):
+                hip(to_dev(x0), to_dev(v0), 2)
+            continue
+        hx, hv, hl = hip(to_dev(x0), to_dev(v0), 2)
+        rx, rv, rl = orc(x0, v0, 2)
+        assert rel_err(to_np(hx), rx) < 3e-5 and rel_err(to_np(hv), rv) < 3e-5 and rel_err(to_np(hl), rl) < 3e-5, name
+    if hmc:
+        Lx, Lv, px, outs = propose(to_dev(x0), dyn, init_v=to_dev(v0), do_mh_step=True, u=to_dev(u))
+        rLx, rLv, rpx, _ = O.propose(x0, od, v0, u=u)
+        tLx, _, tpx, _ = O.propose(x0.astype(np.float64), od64, v0.astype(np.float64), u=u.astype(np.float64))
+    else:
+        Lx, Lv, px, outs = propose(to_dev(x0), dyn, init_v=to_dev(v0), do_mh_step=True, direction=to_dev(dr),
+                                   v=to_dev(v0), u=to_dev(u))
+        rLx, rLv, rpx, _ = O.propose(x0, od, v0, v0, dr, u, both_directions=False)
+        tLx, _, tpx, _ = O.propose(x0.astype(np.float64), od64, v0.astype(np.float64), v0.astype(np.float64), dr,
+                                   u.astype(np.float64), both_directions=False)
+    print("banana H=%d hmc=%d: x %.2e v %.2e p %.2e (vs fp64: x %.2e p %.2e)"
+          % (H, hmc, rel_err(to_np(Lx), rLx), rel_err(to_np(Lv), rLv), abs_err(to_np(px), rpx),
+             rel_err(to_np(Lx), tLx), abs_err(to_np(px), tpx)))
+    assert rel_err(to_np(Lx), rLx) < TRAJ_TOL and rel_err(to_np(Lv), rLv) < TRAJ_TOL
+    assert abs_err(to_np(px), rpx) < P_TOL and abs_err(to_np(px), tpx) < P_TOL
+    check_x_next(to_np(outs[0]), x0, rLx, rpx, u, P_TOL)
+    # p_accept on arbitrary end points; the sampler loop with the library's Philox stream == the same draws injected
+    pa = dyn.p_accept(to_dev(x0), to_dev(v0), Lx, Lv, torch.zeros(N, device="cuda"))
+    assert abs_err(to_np(pa), od.p_accept(x0, v0, to_np(Lx), to_np(Lv), np.zeros(N, np.float32))) < P_TOL
+    xf, p3, _ = sample_chain(to_dev(x0), dyn, 3, seed=9)
+    from l2hmc_amd.sampler import philox_draws
+    pv, pd, pu = philox_draws(9, N, d, 3)
+    xi, pi, _ = sample_chain(to_dev(x0), dyn, 3, v=pv, u=pu, direction=None if hmc else pd)
+    assert torch.equal(xf, xi) and torch.equal(p3, pi)
+    assert bool(torch.isfinite(xf).all()) and 0.0 < float(p3.mean()) <= 1.0
+
+
+def test_user_energy_errors_surface_as_python_exceptions():
+    """An exception inside the caller's energy (here: a wrong output shape) aborts the trajectory and is re-raised."""
+    from l2hmc_amd import Dynamics, propose
+    dyn = Dynamics(3, lambda x: (x * x).sum(), T=2, eps=0.1, hmc=True)          # returns a scalar, not (N,)
+    with pytest.raises(ValueError, match="shape"):
+        propose(to_dev(np.zeros((8, 3), np.float32)), dyn)
+
+    def boom(x):
+        raise KeyError("inside the callback")
+    dyn2 = Dynamics(3, lambda x: (x * x).sum(1), T=2, eps=0.1, hmc=True, grad_energy=boom)
+    with pytest.raises(KeyError, match="inside the callback"):
+        propose(to_dev(np.zeros((8, 3), np.float32)), dyn2)
+
+
+def test_the_vae_posterior_as_a_plain_closure_matches_the_reference_golden():
+    """mnist_vae.py:122-126's `energy(z, aux)` written as the reference writes it -- a closure over a decoder built from
+    the layer kit, BCE-with-logits + prior in torch ops -- handed to `Dynamics` unchanged, with the image-conditioned
+    nets of :134-167: trajectories, the log-Jacobian, accept probabilities and `propose` against the fixture the
+    reference's own graph produced (`vae_small`), and against the built-in decoder-posterior path."""
+    import torch
+    import torch.nn.functional as F
+    from l2hmc_amd import Dynamics, propose, vae
+    from tests.helpers import _load_mlp
+    g = load("vae_small")
+    d, H = int(g["x_dim"]), int(g["H"])
+    dec = vae.make_decoder(d, g["dec.W1"].shape[1], g["dec.W3"].shape[1])
+    enc = vae.make_encoder_sampler(g["enc.W1"].shape[0], g["enc.W1"].shape[1], H)
+    _load_mlp(dec, g, "dec.")
+    _load_mlp(enc, g, "enc.")
+
+    def energy(z, aux=None):                                        # mnist_vae.py:122-126
+        logits = dec(z)
+        log_posterior = -F.binary_cross_entropy_with_logits(logits, aux, reduction="none").sum(1)
+        log_prior = -0.5 * (z * z).sum(1)
+        return -log_posterior - log_prior
+
+    dyn = Dynamics(d, energy, T=int(g["T"]), eps=float(g["eps"]), net_factory=vae.sampler_net_factory(d, enc, H, H))
+    dyn.mask = g["mask"]
+    dyn.eps_override = float(g["eps"])
+    with torch.no_grad():
+        for w, pre in ((dyn._xw, "xnet."), (dyn._vw, "vnet.")):
+            for k in O.NET_KEYS:
+                w[k].copy_(torch.as_tensor(g[pre + k]).reshape(w[k].shape))
+    aux = to_dev(g["aux"])
+    x, v = to_dev(g["x"]), to_dev(g["v"])
+    assert rel_err(to_np(dyn.energy(x, aux=aux)), g["energy"]) < 1e-5
+    assert rel_err(to_np(dyn.grad_energy(x, aux=aux)), g["grad_energy"]) < 1e-5
+    for nm, fn in (("fwd", dyn.forward), ("bwd", dyn.backward)):
+        X, V, lj = fn(x, init_v=v, aux=aux, log_jac=True)
+        _, _, p = fn(x, init_v=v, aux=aux)
+        assert rel_err(to_np(X), g[nm + ".x"]) < TRAJ_TOL and rel_err(to_np(V), g[nm + ".v"]) < TRAJ_TOL, nm
+        assert rel_err(to_np(lj), g[nm + ".logjac"]) < TRAJ_TOL and abs_err(to_np(p), g[nm + ".p"]) < P_TOL, nm
+    Lx, _, px, outs = propose(x, dyn, aux=aux, do_mh_step=True, direction=to_dev(g["prop.dir"]),
+                              v=(to_dev(g["prop.v_fwd"]), to_dev(g["prop.v_bwd"])), u=to_dev(g["prop.u"]))
+    assert rel_err(to_np(Lx), g["prop.Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["prop.px"]) < P_TOL
+    check_x_next(to_np(outs[0]), g["x"], g["prop.Lx"], g["prop.px"], g["prop.u"], P_TOL)
+    # ... and the built-in (GEMM-engine) decoder posterior gives the same proposal
+    bd = hip_dynamics(g)
+    bLx, _, bpx, _ = propose(x, bd, aux=aux, do_mh_step=True, direction=to_dev(g["prop.dir"]),
+                             v=(to_dev(g["prop.v_fwd"]), to_dev(g["prop.v_bwd"])), u=to_dev(g["prop.u"]))
+    assert rel_err(to_np(Lx), to_np(bLx)) < 5e-5 and abs_err(to_np(px), to_np(bpx)) < 5e-5
+    with pytest.raises(ValueError, match="aux"):
+        propose(x, dyn)

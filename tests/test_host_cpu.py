@@ -105,12 +105,23 @@ def test_diagnostics_match_oracle_restatement():
     assert np.array_equal(out[:, 0], [1, 0, 1, 0])
 
 
-def test_product_refuses_cpu_tensors_and_foreign_energies():
+def test_product_refuses_cpu_tensors_and_non_callable_energies():
     with pytest.raises(RuntimeError, match="no CPU path"):
         D.as_device_f32(torch.zeros(2, 2))
     from l2hmc_amd import Dynamics
-    with pytest.raises(TypeError, match="no eager fallback"):
-        Dynamics(2, lambda x: (x * x).sum(1), T=3, eps=0.1, hmc=True, device="cpu")
+    with pytest.raises(TypeError, match="energy function"):
+        Dynamics(2, "not an energy", T=3, eps=0.1, hmc=True, device="cpu")
+    with pytest.raises(TypeError, match="grad_energy"):
+        Dynamics(2, D.Gaussian(np.zeros(2), np.eye(2)).get_energy_function(), T=3, eps=0.1, hmc=True, device="cpu",
+                 grad_energy=lambda x: x)
+    # a plain callable is wrapped as the caller-supplied (slow-path) energy -- and still has no CPU path
+    dyn = Dynamics(2, lambda x: (x * x).sum(1), T=3, eps=0.1, hmc=True, device="cpu")
+    assert isinstance(dyn._fn, D.UserEnergy) and dyn._split and dyn._user
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        dyn.energy(torch.zeros(2, 2))
+    from l2hmc_amd.training import Trainer
+    with pytest.raises(NotImplementedError, match="caller-supplied"):
+        Trainer(dyn)
 
 
 def test_bench_host_helpers():

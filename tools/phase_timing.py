@@ -19,8 +19,8 @@ def main():
     out = os.path.join(csrc, "variants", "libl2hmc_hip_pt.so")
     if len(sys.argv) > 1 and sys.argv[1] == "build":      # run this in the container, NOT on the GPU box
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        srcs = [os.path.join(csrc, f) for f in ("l2hmc_abi.hip", "traj_ek1.hip", "traj_ek2.hip", "traj_ek3.hip",
-                                                "traj_ek4.hip", "traj_ek5.hip", "traj_wide.hip", "train.hip", "split.hip")]
+        import glob
+        srcs = sorted(glob.glob(os.path.join(csrc, "*.hip")))
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
                         "-DL2HMC_PHASE_TIMING", "-Wno-return-type", "-shared", "-o", out] + srcs
                        + [], check=True)
