@@ -374,6 +374,18 @@ typedef struct L2hmcTrainSplitArgs {
   float* grad;                   /* accumulated */
   float* workspace;              /* l2hmc_train_split_workspace_floats(...) floats */
   int64_t workspace_floats;
+  /* ---- the rest of mnist_vae.py:185-226's sampler objective ---------------------------------------------------- */
+  float energy_scale;            /* es >= 0 (0 = off): + es inv_n sum_n (1 / ed_n - ed_n) with
+                                  *    ed = (U(Lx) - U(x))^2 p + 1e-4   (mnist_vae.py:214,218,224)               */
+  float* ediff_out;              /* (N) ed_n, or NULL                                                          */
+  /* links of chain_operator (sampler.py:57-85; mnist_vae.py:193-196 `random_lf_composition`): the composed proposals
+   * run with log_jac = True and have no accept probability of their own; the ONE accept probability of the
+   * composition (and the loss) is formed by the caller from the links' outputs, its cotangents come back in here */
+  int32_t no_accept;             /* 1: no p / v1 / loss term; seeds = dLx_in (required), dLv_in, dlogjac_in     */
+  const float* dLv_in;           /* (N, d) or NULL: cotangent on the proposal's momentum Lv                     */
+  const float* dlogjac_in;       /* (N) or NULL: cotangent on the proposal's summed log-Jacobian                */
+  float* Lv_out;                 /* (N, d) or NULL                                                              */
+  float* logjac_out;             /* (N) or NULL                                                                 */
 } L2hmcTrainSplitArgs;
 
 int64_t l2hmc_train_split_grad_floats(int32_t d, int32_t H, const L2hmcMlp3* aux_encoder);

@@ -87,7 +87,9 @@ class L2hmcTrainSplitArgs(C.Structure):
                 ("x", _fp), ("v", _fp), ("direction", _fp), ("direction_all", C.c_int32),
                 ("dist_weight", _fp), ("scale", C.c_float), ("inv_n", C.c_float), ("dLx_in", _fp),
                 ("Lx", _fp), ("p", _fp), ("v1", _fp), ("dx0_out", _fp), ("grad", _fp),
-                ("workspace", _fp), ("workspace_floats", C.c_int64)]
+                ("workspace", _fp), ("workspace_floats", C.c_int64),
+                ("energy_scale", C.c_float), ("ediff_out", _fp), ("no_accept", C.c_int32), ("dLv_in", _fp),
+                ("dlogjac_in", _fp), ("Lv_out", _fp), ("logjac_out", _fp)]
 
 
 STRUCTS = (L2hmcNet, L2hmcEnergy, L2hmcTrajectoryArgs, L2hmcMlp3, L2hmcSplitArgs, L2hmcTrainArgs, L2hmcTrainSplitArgs)

@@ -245,16 +245,37 @@ __global__ void k_hvp_chain(int kind, const float* x, int ldx, const float* u, f
 }
 
 // accept probability (dynamics.py:302-309), the loss argument and the adjoint seeds of the reverse sweep
-// (train.hip "accept probability, loss term and the adjoint seeds"); one wave per chain
+// (train.hip "accept probability, loss term and the adjoint seeds"); one wave per chain.
+//   es > 0: + es inv_n sum_n (1 / ed_n - ed_n),  ed = (U(Lx) - U(x))^2 p + 1e-4   (mnist_vae.py:214-224, energy_scale)
+//   no_accept: a link of chain_operator (sampler.py:57-85, propose(log_jac=True)): no accept probability and no loss
+//   term of its own -- the seeds are the caller's cotangents on Lx / Lv / the summed log-Jacobian.
 __global__ __launch_bounds__(256) void k_train_seed(const float* x0, const float* x1, int ldx1, const float* v1,
                                                     const float* g1, int ldg1, const double* U0, const double* U1,
                                                     const float* K0, const float* ld, const float* wgt,
-                                                    const float* dLx_in, float scale, float inv_n, float* Lx, float* p_out,
-                                                    float* v1_out, float* lam, float* dv1p_out, float* lx, float* lv,
-                                                    float* deps, long long N, int d) {
+                                                    const float* dLx_in, const float* dLv_in, const float* dlj_in,
+                                                    int no_accept, float scale, float inv_n, float es, float* Lx,
+                                                    float* Lv_out, float* lj_out, float* p_out, float* v1_out,
+                                                    float* ed_out, float* lam, float* lamU, float* dv1p_out, float* lx,
+                                                    float* lv, float* deps, long long N, int d) {
   const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
+  if (no_accept) {
+    if (lane == 0) {
+      lam[n] = dlj_in != nullptr ? dlj_in[n] : 0.f;
+      lamU[n] = 0.f;
+      dv1p_out[n] = 0.f;
+      deps[n] = 0.f;
+      if (lj_out != nullptr) lj_out[n] = ld[n];
+    }
+    for (int k = lane; k < d; k += 64) {
+      Lx[n * d + k] = x1[n * ldx1 + k];
+      if (Lv_out != nullptr) Lv_out[n * d + k] = v1[n * d + k];
+      lx[n * d + k] = dLx_in != nullptr ? dLx_in[n * d + k] : 0.f;
+      lv[n * d + k] = dLv_in != nullptr ? dLv_in[n * d + k] : 0.f;
+    }
+    return;
+  }
   float K1 = 0.f, sq = 0.f;
   for (int k = lane; k < d; k += 64) {
     const float vv = v1[n * d + k], dx = x1[n * ldx1 + k] - x0[n * d + k];
@@ -269,34 +290,44 @@ __global__ __launch_bounds__(256) void k_train_seed(const float* x0, const float
   const float dv1 = (scale * (-1.f / (v1o * v1o)) - 1.f / scale) * inv_n;
   const bool pfin = (val == val) && p > 0.f;          // the finite branch of dynamics.py:309 actually taken
   const bool ok = sq < 3.0e38f;                       // a diverged chain contributes no gradient (train.hip)
-  const float lm = (ok && pfin && val < 0.f) ? dv1 * sq * p : 0.f;
+  // energy term: ed = dU^2 p + 1e-4
+  const float dU = (float)(U1[n] - U0[n]);
+  const bool eok = es > 0.f && ok && fabsf(dU) < 1.0e18f;
+  const float ed = eok ? dU * dU * p + 1e-4f : 1.f;
+  const float de = eok ? es * inv_n * (-1.f / (ed * ed) - 1.f) : 0.f;
+  const float eu = de * 2.f * dU * p;                 // d term / d U(Lx) through dU  (= - d term / d U(x))
+  const float lm = (ok && pfin && val < 0.f) ? (dv1 * sq + de * dU * dU) * p : 0.f;
   const float dv1p = ok ? dv1 * p * 2.f : 0.f;
   if (lane == 0) {
     p_out[n] = p;
     v1_out[n] = v1o;
-    lam[n] = lm;
+    if (ed_out != nullptr) ed_out[n] = eok ? ed : 0.f;
+    if (lj_out != nullptr) lj_out[n] = ld[n];
+    lam[n] = lm + (dlj_in != nullptr ? dlj_in[n] : 0.f);
+    lamU[n] = lm - eu;
     dv1p_out[n] = dv1p;
     deps[n] = 0.f;
   }
   for (int k = lane; k < d; k += 64) {
     const float xe = x1[n * ldx1 + k];
     Lx[n * d + k] = xe;
+    if (Lv_out != nullptr) Lv_out[n * d + k] = v1[n * d + k];
     const float wk = wgt != nullptr ? wgt[n * d + k] : 1.f;
-    float a = ok ? dv1p * wk * (xe - x0[n * d + k]) - lm * g1[n * ldg1 + k] : 0.f;
+    float a = ok ? dv1p * wk * (xe - x0[n * d + k]) + (eu - lm) * g1[n * ldg1 + k] : 0.f;
     if (dLx_in != nullptr) a += dLx_in[n * d + k];
     lx[n * d + k] = a;
-    lv[n * d + k] = ok ? -lm * v1[n * d + k] : 0.f;
+    lv[n * d + k] = (ok ? -lm * v1[n * d + k] : 0.f) + (dLv_in != nullptr ? dLv_in[n * d + k] : 0.f);
   }
 }
-// d loss / d x0 = the sweep's cotangent + the direct paths through (Lx - x0) and through U(x0) of the accept ratio
+// d loss / d x0 = the sweep's cotangent + the direct paths through (Lx - x0) and through U(x0) (accept ratio, energy term)
 __global__ void k_train_dx0(const float* lx, const float* x0, const float* x1, int ldx1, const float* g0, int ldg0,
-                            const float* wgt, const float* lam, const float* dv1p, float* out, long long N, int d) {
+                            const float* wgt, const float* lamU, const float* dv1p, float* out, long long N, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * d) return;
   const long long n = i / d;
   const int k = (int)(i % d);
   const float wk = wgt != nullptr ? wgt[i] : 1.f;
-  out[i] = lx[i] - dv1p[n] * wk * (x1[n * ldx1 + k] - x0[i]) + lam[n] * g0[n * ldg0 + k];
+  out[i] = lx[i] - dv1p[n] * wk * (x1[n * ldx1 + k] - x0[i]) + lamU[n] * g0[n * ldg0 + k];
 }
 
 // ---- chunked column sums (fixed order): part[chunk][col] = sum over the chunk's rows of A[r][col] ----------------
@@ -468,7 +499,7 @@ struct TrainSplitPlan {
   long long AB[2], H1[2], H2[2], O3[2], DA2[2], DA1[2], DL[2];   // per net [X, V]: (2 T N, .) stashes
   long long VS, YS;                                 // (T + 1, N, d) momenta, (T, N, d) intermediate positions
   long long lx, lv, dvh, dz, dg, u, hv, dAB;        // running cotangents
-  long long lam, dv1p, deps;
+  long long lam, lamU, dv1p, deps;
   long long w12c[2], whc[2];                        // stacked / side-by-side weight copies per net
   long long part;                                   // chunk partials of the TN products and column sums
   long long part_cap;
@@ -495,7 +526,7 @@ inline TrainSplitPlan plan_train_split(long long N, int d, int H, int T, const L
   p.VS = take((T + 1) * N * d); p.YS = take((long long)T * N * d);
   p.lx = take(N * d); p.lv = take(N * d); p.dvh = take(N * d); p.dz = take(N * d); p.dg = take(N * d);
   p.u = take(N * d); p.hv = take(N * d); p.dAB = take(N * 2 * d); p.carry = take(N * d);
-  p.lam = take(N); p.dv1p = take(N); p.deps = take(N);
+  p.lam = take(N); p.lamU = take(N); p.dv1p = take(N); p.deps = take(N);
   long long big = (long long)H * H;
   if ((long long)2 * d * H > big) big = 2LL * d * H;
   if ((long long)3 * d * H > big) big = 3LL * d * H;
@@ -630,11 +661,14 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     if (a->aux_encoder->n_out != H || a->aux_encoder->n_in != a->decoder->n_out)
       return fail(L2HMC_ERR_ARG, "aux_encoder must map (N, n_pix) -> (N, H)%s");
   }
-  if (!a->xnet || !a->vnet || !a->masks || !a->trig || !a->x || !a->v || !a->Lx || !a->p || !a->v1 || !a->grad || !a->workspace)
+  if (!a->xnet || !a->vnet || !a->masks || !a->trig || !a->x || !a->v || !a->Lx || (!a->no_accept && (!a->p || !a->v1)) ||
+      !a->grad || !a->workspace)
     return fail(L2HMC_ERR_ARG, "l2hmc_train_split_grad: NULL pointer%s");
   if (!a->alpha && !(a->eps_host > 0.f)) return fail(L2HMC_ERR_ARG, "eps must be > 0%s");
   if (!(a->scale > 0.f) || !(a->inv_n >= 0.f)) return fail(L2HMC_ERR_ARG, "scale must be > 0 and inv_n >= 0%s");
   if (a->inv_n == 0.f && !a->dLx_in) return fail(L2HMC_ERR_ARG, "inv_n = 0 (no loss term of its own) needs dLx_in%s");
+  if (a->no_accept && !a->dLx_in) return fail(L2HMC_ERR_ARG, "no_accept (a link of chain_operator) needs dLx_in%s");
+  if (!(a->energy_scale >= 0.f)) return fail(L2HMC_ERR_ARG, "energy_scale must be >= 0%s");
   const TrainSplitPlan p = plan_train_split(N, d, H, T, a->aux_encoder, a->decoder);
   if (a->workspace_floats < p.total) return fail(L2HMC_ERR_ARG, "workspace too small: need %s%lld floats", "", p.total);
   hipStream_t s = (hipStream_t)stream;
@@ -766,11 +800,13 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
 
   // ---- accept probability, loss argument, adjoint seeds -----------------------------------------------------------
   float *lx = w + p.lx, *lv = w + p.lv, *dvh = w + p.dvh, *dz = w + p.dz, *dg = w + p.dg, *uu = w + p.u, *hv = w + p.hv;
-  float *lam = w + p.lam, *dv1p = w + p.dv1p, *deps = w + p.deps, *dAB = w + p.dAB;
+  float *lam = w + p.lam, *lamU = w + p.lamU, *dv1p = w + p.dv1p, *deps = w + p.deps, *dAB = w + p.dAB;
   {
     const float* abe = AB(1, 2 * T - 1);
     hipLaunchKernelGGL(k_train_seed, dim3(nw4), dim3(256), 0, s, a->x, abe, L, VS(T), abe + d, L, U0d, U1d, w + f.K0, ld,
-                       a->dist_weight, a->dLx_in, a->scale, a->inv_n, a->Lx, a->p, a->v1, lam, dv1p, lx, lv, deps, N, d);
+                       a->dist_weight, a->dLx_in, a->dLv_in, a->dlogjac_in, a->no_accept, a->scale, a->inv_n,
+                       a->energy_scale, a->Lx, a->Lv_out, a->logjac_out, a->p, a->v1, a->ediff_out, lam, lamU, dv1p, lx, lv,
+                       deps, N, d);
   }
   // VNet evaluation at trajectory point j (inputs (x, grad U(x)) in `ab`):  lx += d a + Hessian(x) (dg + d b).
   // Every interior point is the input of TWO VNet evaluations (the end of one leapfrog step and the start of the next,
@@ -828,7 +864,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   if (a->dx0_out) {
     const float* ab0 = AB(1, 0);
     hipLaunchKernelGGL(k_train_dx0, dim3(nblk(Nd)), dim3(256), 0, s, lx, a->x, AB(1, 2 * T - 1), L, ab0 + d, L, a->dist_weight,
-                       lam, dv1p, a->dx0_out, N, d);
+                       lamU, dv1p, a->dx0_out, N, d);
   }
 
   // ---- parameter gradients: one contraction over all (evaluation, chain) rows per weight matrix ---------------------

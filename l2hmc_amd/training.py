@@ -19,6 +19,8 @@ collective.
 """
 import ctypes as C
 
+import numpy as np
+
 import torch
 import torch.distributed as dist
 
@@ -358,7 +360,8 @@ class SplitTrainer(Trainer):
 
     # ---- one proposal + its gradient (accumulated into self.flat) ---------------------------------------------------
     def _propose_grad(self, start, v, direction, n_total, out=None, aux=None, dist_weight=None, dLx_in=None,
-                      dx0_out=None):
+                      dx0_out=None, energy_scale=0.0, ediff_out=None, no_accept=False, dLv_in=None, dlogjac_in=None,
+                      Lv_out=None, logjac_out=None):
         dyn = self.dyn
         N, d = start.shape
         L = _ffi.lib()
@@ -406,6 +409,9 @@ class SplitTrainer(Trainer):
         a.dLx_in, a.dx0_out = _ffi.ptr(dLx_in), _ffi.ptr(dx0_out)
         a.Lx, a.p, a.v1 = Lx.data_ptr(), p.data_ptr(), v1.data_ptr()
         a.grad, a.workspace, a.workspace_floats = self.flat.data_ptr(), self._ws.data_ptr(), self._ws.numel()
+        a.energy_scale, a.ediff_out, a.no_accept = float(energy_scale), _ffi.ptr(ediff_out), int(bool(no_accept))
+        a.dLv_in, a.dlogjac_in = _ffi.ptr(dLv_in), _ffi.ptr(dlogjac_in)
+        a.Lv_out, a.logjac_out = _ffi.ptr(Lv_out), _ffi.ptr(logjac_out)
         _ffi.check(L.l2hmc_train_split_grad(a, _ffi.current_stream(dyn.device)))
         return Lx, p, v1
 
@@ -473,13 +479,21 @@ class SplitTrainer(Trainer):
         return loss, io["p"][:N].clone(), x_next, lr
 
     # ---- the VAE experiment's sampler objective (mnist_vae.py:185-226) ---------------------------------------------------
-    def sampler_loss_and_grad(self, latent_q, aux, log_sigma, MH=1, stop_gradient=False, draws=None):
-        """sampler_loss of mnist_vae.py:185-226 (energy_scale = 0) and its gradient (left in `.grad` of every sampler
-        parameter and in `self.flat`).  MH proposals are chained from `latent_q` with an MH step after each
-        (:204,224); like the reference only the LAST proposal's terms enter the loss (inverse_term / other_term are
-        re-initialised inside the loop, :187-189) with weight 1 / MH, and unless `stop_gradient` their gradient flows
-        back through the earlier proposals.  draws: optional list (one dict per proposal) of injected randomness
-        {v, dir, u} (tests).  Returns (loss, latent_T, px of the last proposal)."""
+    def sampler_loss_and_grad(self, latent_q, aux, log_sigma, MH=1, stop_gradient=False, draws=None, energy_scale=0.0,
+                              random_lf_composition=0):
+        """sampler_loss of mnist_vae.py:185-226 and its gradient (left in `.grad` of every sampler parameter and in
+        `self.flat`).  MH proposals are chained from `latent_q` with an MH step after each (:204,220); like the
+        reference only the LAST proposal's terms enter the loss (inverse_term / other_term / energy_loss are
+        re-initialised inside the loop, :186-188) with weight 1 / MH, and unless `stop_gradient` their gradient flows
+        back through the earlier proposals.
+          energy_scale (:54,214,218,224): + energy_scale / MH * (mean(1 / ed) - mean(ed)),
+              ed = (U(final_x) - U(init_x))^2 px + 1e-4.
+          random_lf_composition = R > 0 (:50,193-196): every MH iteration is `chain_operator(init_x, dynamics, nb_steps,
+              aux, do_mh_step=True)` with nb_steps ~ U{1, ..., R - 1} -- nb_steps composed `propose(log_jac=True)` links
+              and ONE accept probability against (init_x, a fresh init_v) (sampler.py:57-85, its quirks included).
+        draws: optional list (one dict per MH iteration) of injected randomness (tests): {v, dir, u} for a plain
+        proposal; {nb_steps, init_v, v: [..], dir: [..], u} for a composition.
+        Returns (loss, latent_T, px of the last iteration)."""
         if not self.vae:
             raise TypeError("sampler_loss_and_grad is the VAE experiment's objective")
         dyn = self.dyn
@@ -490,53 +504,139 @@ class SplitTrainer(Trainer):
         wgt = (1.0 / (torch.exp(2.0 * as_device_f32(log_sigma, dev)) + 1e-4)).contiguous()
         n_total, _ = self._shard(N)
         world = self._world()
-        states = []
+        R = int(random_lf_composition)
+        es = float(energy_scale)
+
+        def normal():
+            return torch.randn((N, d), device=dev, generator=gen)
+
+        def bits():
+            return torch.randint(0, 2, (N,), device=dev, dtype=torch.uint8, generator=gen)
+
+        def dirs_of(a):
+            return torch.as_tensor(a, device=dev).to(torch.uint8).contiguous()
+
+        # ---- forward: every MH iteration but the last one runs forward only -------------------------------------------
+        its = []
         for t in range(MH):
             dr = draws[t] if draws is not None else {}
-            v = as_device_f32(dr["v"], dev) if "v" in dr else torch.randn((N, d), device=dev, generator=gen)
-            dbit = (torch.as_tensor(dr["dir"], device=dev).to(torch.uint8).contiguous() if "dir" in dr
-                    else torch.randint(0, 2, (N,), device=dev, dtype=torch.uint8, generator=gen))
             u = as_device_f32(dr["u"], dev) if "u" in dr else torch.rand(N, device=dev, generator=gen)
-            states.append((x, v, dbit, u))
-            if t + 1 < MH:                                  # the earlier proposals: forward only
-                o = dyn.run(x, v, 0, dyn.T, direction=dbit, u=u, want=("x_next", "p"), aux=aux)
-                states[-1] = (x, v, dbit, u, o["p"])
-                x = o["x_next"]
+            it = {"x0": x, "u": u}
+            if R > 0:
+                if R < 2:
+                    raise ValueError("random_lf_composition must be 0 or >= 2 (nb_steps ~ U{1..R-1}, mnist_vae.py:194)")
+                # nb_steps ~ U{1..R-1} (:194): ONE draw for the whole batch, from a host stream keyed by (seed, step, t)
+                # so that every rank of a sharded run composes the same number of links
+                K = int(dr["nb_steps"]) if "nb_steps" in dr else int(np.random.RandomState(
+                    (self.seed * 1000003 + self.global_step * 7919 + t) % (2 ** 32)).randint(1, R))
+                it["init_v"] = as_device_f32(dr["init_v"], dev) if "init_v" in dr else normal()
+                it["links"] = []
+                xs, lj = x, torch.zeros(N, dtype=torch.float32, device=dev)
+                for k in range(K):
+                    vk = as_device_f32(dr["v"][k], dev) if "v" in dr else normal()
+                    dk = dirs_of(dr["dir"][k]) if "dir" in dr else bits()
+                    it["links"].append((xs, vk, dk))
+                    o = dyn.run(xs, vk, 0, dyn.T, direction=dk, want=("x", "v", "logjac"), aux=aux)
+                    xs, vK, lj = o["x"], o["v"], lj + o["logjac"]
+                it.update(Lx=xs, Lv=vK, logjac=lj)
+                # the ONE accept probability of the composition (sampler.py:79) against (init_x, init_v)
+                U0, U1 = dyn.energy(x, aux=aux).double(), dyn.energy(xs, aux=aux).double()
+                val = (U0 + 0.5 * it["init_v"].double().square().sum(1)) - (U1 + 0.5 * vK.double().square().sum(1)) + lj.double()
+                p = torch.exp(torch.clamp(val, max=0.0))
+                p = torch.where(torch.isfinite(p), p, torch.zeros_like(p))          # dynamics.py:309 (NaN -> 0)
+                it.update(U0=U0, U1=U1, val=val, p=p.float())
+            else:
+                it["v"] = as_device_f32(dr["v"], dev) if "v" in dr else normal()
+                it["dir"] = dirs_of(dr["dir"]) if "dir" in dr else bits()
+                if t + 1 < MH:
+                    o = dyn.run(x, it["v"], 0, dyn.T, direction=it["dir"], u=u, want=("x", "p"), aux=aux)
+                    it.update(Lx=o["x"], p=o["p"])
+            if t + 1 < MH or R > 0:
+                it["acc"] = ((it["p"] - u) >= 0)[:, None]
+                x = torch.where(it["acc"], it["Lx"], it["x0"])                       # sampler.py:53-55
+            its.append(it)
+
+        # a composition's links, last to first: cotangents on the composition's end point -> d loss / d init_x
+        def links_backward(it, dLx, dLv, dlj, want_dx0):
+            links, cot = it["links"], dLx
+            for k in range(len(links) - 1, -1, -1):
+                xk, vk, dk = links[k]
+                need = want_dx0 or k > 0
+                dx0 = torch.empty((N, d), dtype=torch.float32, device=dev) if need else None
+                # (only the LAST link's momentum reaches p_accept: the earlier links' Lv are dropped by propose, :35-36)
+                self._propose_grad(xk, vk, dk, float("inf"), aux=aux, dLx_in=cot.contiguous(), dx0_out=dx0, no_accept=True,
+                                   dLv_in=dLv if k == len(links) - 1 else None, dlogjac_in=dlj)
+                cot = dx0
+            return cot
+
         self.flat.zero_()
-        loss = x_T = p_last = None
-        dx_next = None                                      # cotangent on x_{t+1}
-        for t in range(MH - 1, -1, -1):
-            st = states[t]
-            last = t == MH - 1
-            dLx = None
-            if not last:
-                # x_{t+1} = where(p_t - u_t >= 0, Lx_t, x_t) (sampler.py:53-55): the accepted rows' cotangent goes into
-                # this proposal, the rejected rows' straight on to x_t
-                acc_t = ((st[4] - st[3]) >= 0)[:, None].float()
-                dLx = (dx_next * acc_t).contiguous()
-            want_dx0 = t > 0 and not stop_gradient
+        inv = 1.0 / float(n_total * MH)
+        last = its[-1]
+        # ---- the last iteration: loss terms and their cotangents ---------------------------------------------------------
+        want_dx0 = MH > 1 and not stop_gradient
+        if R > 0:
+            x0, xe, p64, val = last["x0"], last["Lx"], last["p"].double(), last["val"]
+            g0, g1 = dyn.grad_energy(x0, aux=aux), dyn.grad_energy(xe, aux=aux)
+            dx = xe - x0
+            sq = (wgt * dx * dx).sum(1).double()
+            v1 = sq * p64 + 1e-4
+            dv1 = (-1.0 / (v1 * v1) - 1.0) * inv
+            dU = last["U1"] - last["U0"]
+            ed = dU * dU * p64 + 1e-4
+            de = (-1.0 / (ed * ed) - 1.0) * inv * es
+            live = ((val < 0) & torch.isfinite(val) & (p64 > 0)).double()
+            lm = ((dv1 * sq + de * dU * dU) * p64 * live).float()
+            eu = (de * 2.0 * dU * p64).float()
+            dv1p = (dv1 * p64 * 2.0).float()
+            dLx = dv1p[:, None] * wgt * dx + (eu - lm)[:, None] * g1
+            dLv = (-lm)[:, None] * last["Lv"]
+            cot = links_backward(last, dLx, dLv.contiguous(), lm.contiguous(), want_dx0)
+            if want_dx0:
+                cot = cot - dv1p[:, None] * wgt * dx + (lm - eu)[:, None] * g0
+            terms = torch.stack([(1.0 / v1).sum() - v1.sum(), (1.0 / ed).sum() - ed.sum()])
+            p_last = last["p"]
+        else:
             dx0 = torch.empty((N, d), dtype=torch.float32, device=dev) if want_dx0 else None
-            # only the last proposal has a loss term of its own (inv_n = 0 switches it off for the others)
-            Lx, p, v1 = self._propose_grad(st[0], st[1], st[2], n_total * MH if last else float("inf"), aux=aux,
-                                           dist_weight=wgt, dLx_in=dLx, dx0_out=dx0)
-            if last:
-                terms = torch.stack([(1.0 / v1).sum(), v1.sum()]).double()
-                if world > 1:
-                    dist.all_reduce(terms)
-                loss = (terms[0] - terms[1]) / (n_total * MH)
-                x_T = torch.where(((p - st[3]) >= 0)[:, None], Lx, st[0])
-                p_last = p
-            if not want_dx0:
+            ed = torch.empty(N, dtype=torch.float32, device=dev) if es > 0 else None
+            Lx, p_last, v1 = self._propose_grad(last["x0"], last["v"], last["dir"], n_total * MH, aux=aux, dist_weight=wgt,
+                                                dx0_out=dx0, energy_scale=es, ediff_out=ed)
+            last.update(Lx=Lx, p=p_last)
+            last["acc"] = ((p_last - last["u"]) >= 0)[:, None]
+            x = torch.where(last["acc"], Lx, last["x0"])
+            cot = dx0
+            v1 = v1.double()
+            terms = torch.stack([(1.0 / v1).sum() - v1.sum(),
+                                 ((1.0 / ed.double()).sum() - ed.double().sum()) if es > 0 else torch.zeros((), dtype=torch.float64, device=dev)])
+        if world > 1:
+            dist.all_reduce(terms)
+        loss = (terms[0] + es * terms[1]) * inv
+        # ---- the earlier iterations, last to first: x_{t+1} = where(p_t - u_t >= 0, Lx_t, x_t) (sampler.py:53-55): the
+        #      accepted rows' cotangent goes into iteration t's proposal, the rejected rows' straight on to x_t
+        for t in range(MH - 2, -1, -1):
+            if stop_gradient:
                 break
-            dx_next = dx0 if last else dx0 + dx_next * (1.0 - acc_t)
+            it = its[t]
+            acc = it["acc"].float()
+            dLx = (cot * acc).contiguous()
+            need = t > 0
+            if R > 0:
+                through = links_backward(it, dLx, None, None, need)
+            else:
+                through = torch.empty((N, d), dtype=torch.float32, device=dev) if need else None
+                self._propose_grad(it["x0"], it["v"], it["dir"], float("inf"), aux=aux, dist_weight=wgt, dLx_in=dLx,
+                                   dx0_out=through)
+            if not need:
+                break
+            cot = through + cot * (1.0 - acc)
         if world > 1:
             dist.all_reduce(self.flat)
         self._publish_grads()
-        return loss, x_T, p_last
+        return loss, x, p_last
 
-    def sampler_step(self, latent_q, aux, log_sigma, MH=5, stop_gradient=False):
+    def sampler_step(self, latent_q, aux, log_sigma, MH=5, stop_gradient=False, energy_scale=0.0, random_lf_composition=0):
         """One update of the sampler's variables (mnist_vae.py:255-261): clipped Adam on sampler_loss."""
-        loss, x_T, px = self.sampler_loss_and_grad(latent_q, aux, log_sigma, MH=MH, stop_gradient=stop_gradient)
+        loss, x_T, px = self.sampler_loss_and_grad(latent_q, aux, log_sigma, MH=MH, stop_gradient=stop_gradient,
+                                                   energy_scale=energy_scale, random_lf_composition=random_lf_composition)
         lr = self.lr_at(self.global_step)
         self._adam(lr)
         return loss, x_T, px, lr

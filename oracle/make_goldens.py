@@ -3,8 +3,8 @@
 TEST INFRASTRUCTURE.  Run here (never on the GPU box -- /root/reference does not exist
 there):
 
-    python oracle/make_goldens.py            # writes ALL of tests/golden/*.npz (34 files; bit-reproducible)
-    python oracle/make_goldens.py ais|wide|train_funnel|train_vae|train_wide|ess   # only that group
+    python oracle/make_goldens.py            # writes ALL of tests/golden/*.npz (36 files; bit-reproducible)
+    python oracle/make_goldens.py ais|wide|train_funnel|train_vae|train_vae_extra|train_wide|ess   # only that group
     L2HMC_GOLDEN_OUT=/tmp/gold python oracle/make_goldens.py                  # elsewhere, to diff against the committed set
 
 How: ``oracle/tf1_stub.py`` is registered as ``tensorflow``; ``/root/reference/utils`` is
@@ -374,7 +374,7 @@ def vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
         name, N, latent, T, out['fwd.p'].mean(), out['bwd.p'].mean(), np.abs(out['energy']).mean()))
 
 
-def train_vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
+def train_vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed, energy_scale=0.0, rlc=0):
     """Gradient of the VAE experiment's sampler loss (mnist_vae.py:185-226 with MH = 1, energy_scale = 0):
         final_x, _, px, MH = propose(init_x, dynamics, aux=inp, do_mh_step=True)
         v = sum_k (final_x - init_x)^2 / (stop_gradient(exp(2 log_sigma)) + 1e-4) * px + 1e-4
@@ -383,7 +383,10 @@ def train_vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
     from the reference's own graph (decoder energy mnist_vae.py:122-126, nets :142-167) differentiated by the stub's
     tf.gradients.  Also d loss / d init_x (what flows into the previous proposal when MH > 1 and stop_gradient is
     off, :187-190,224) and the gradients of loss + sum(final_x * R) for a fixed R (the cotangent a later proposal
-    sends back into final_x)."""
+    sends back into final_x).
+    energy_scale != 0: + energy_scale * (mean(1 / ed) - mean(ed)), ed = (energy(final_x) - energy(init_x))^2 px + 1e-4
+    (:214,218,224).  rlc > 0 (`random_lf_composition`, :193-196): the proposal is
+    chain_operator(init_x, dynamics, nb_steps ~ U{1..rlc-1}, aux, do_mh_step=True) instead of propose."""
     tf1_stub.reset(seed)
     np.random.seed(seed)
     hook = variable_hook_factory(seed + 1, 0.3)
@@ -452,16 +455,34 @@ def train_vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
     auxt = torch.tensor(aux)
     del tf1_stub.RANDOM_LOG[:]
     init_x = leaf(x0)
-    final_x, _, px, MH = ref_sampler.propose(init_x, dyn, aux=auxt, do_mh_step=True)
-    log = list(tf1_stub.RANDOM_LOG)
-    assert [k for k, _ in log] == ['randint', 'normal', 'normal', 'uniform']
-    out['prop.dir'] = log[0][1][:, 0].astype(np.uint8)
-    out['prop.v_fwd'], out['prop.v_bwd'], out['prop.u'] = log[1][1], log[2][1], log[3][1]
-    # mnist_vae.py:207-214 (MH = 1, energy_scale = 0)
+    if rlc > 0:                                                   # mnist_vae.py:193-196
+        nb_steps = tf.random_uniform((), minval=1, maxval=rlc, dtype=tf.int32)
+        final_x, _, px, MH = ref_sampler.chain_operator(init_x, dyn, nb_steps, aux=auxt, do_mh_step=True)
+        log = list(tf1_stub.RANDOM_LOG)
+        K = int(nb_steps)
+        assert [k for k, _ in log] == ['randint', 'normal'] + ['randint', 'normal', 'normal'] * K + ['uniform']
+        out['chain.nb_steps'] = np.int32(K)
+        out['chain.init_v'] = log[1][1]
+        body = log[2:-1]
+        out['chain.dir'] = np.stack([body[3 * k][1][:, 0] for k in range(K)]).astype(np.uint8)
+        out['chain.v_fwd'] = np.stack([body[3 * k + 1][1] for k in range(K)])
+        out['chain.v_bwd'] = np.stack([body[3 * k + 2][1] for k in range(K)])
+        out['prop.u'] = log[-1][1]
+    else:
+        final_x, _, px, MH = ref_sampler.propose(init_x, dyn, aux=auxt, do_mh_step=True)
+        log = list(tf1_stub.RANDOM_LOG)
+        assert [k for k, _ in log] == ['randint', 'normal', 'normal', 'uniform']
+        out['prop.dir'] = log[0][1][:, 0].astype(np.uint8)
+        out['prop.v_fwd'], out['prop.v_bwd'], out['prop.u'] = log[1][1], log[2][1], log[3][1]
+    # mnist_vae.py:207-224 (MH = 1)
     w = 1.0 / (tf.stop_gradient(tf.exp(2 * torch.tensor(log_sigma))) + 1e-4)
     v = tf.square(final_x - init_x) * w
     v = tf.reduce_sum(v, 1) * px + 1e-4
     loss = tf.reduce_mean(1.0 / v) - tf.reduce_mean(v)
+    if energy_scale != 0.0:
+        energy_diff = tf.square(energy(final_x, aux=auxt) - energy(init_x, aux=auxt)) * px + 1e-4
+        loss = loss + energy_scale * (tf.reduce_mean(1.0 / energy_diff) - tf.reduce_mean(energy_diff))
+        out['energy_scale'], out['ediff'] = np.float32(energy_scale), npy(energy_diff)
     variables = [tf1_stub.VARIABLES[full] for full, _ in names] + [tf1_stub.VARIABLES[alpha_name], init_x]
     grads = tf.gradients(loss, variables)
     loss2 = loss + tf.reduce_sum(final_x * torch.tensor(R))
@@ -480,6 +501,14 @@ def train_vae_case(name, latent, H, dec_h, n_pix, enc_h, T, eps, N, seed):
     print('%-18s N=%-4d d=%-3d T=%-3d  loss %.4e  |grad| %.3e  grad.alpha %.3e  mean px %.3f  |grad.enc.W1| %.3e' % (
         name, N, latent, T, float(out['loss']), gn, float(out['grad.alpha']), out['px'].mean(),
         float(np.abs(out['grad.enc.W1']).max())))
+
+
+def train_vae_extra_cases():
+    """the two optional terms of the VAE experiment's sampler objective, from the reference's own graph"""
+    train_vae_case('train_vae_small_es', latent=10, H=24, dec_h=48, n_pix=40, enc_h=32, T=4, eps=0.1, N=32, seed=44,
+                   energy_scale=0.5)
+    train_vae_case('train_vae_small_rlc', latent=10, H=24, dec_h=48, n_pix=40, enc_h=32, T=3, eps=0.1, N=32, seed=47,
+                   energy_scale=0.25, rlc=4)
 
 
 def train_wide_cases(only_new=False):
@@ -678,6 +707,8 @@ def main():
         return wide_cases()
     if sys.argv[1:] == ['train_vae']:            # only the VAE sampler-training fixture
         return train_vae_case('train_vae_small', latent=10, H=24, dec_h=48, n_pix=40, enc_h=32, T=4, eps=0.1, N=32, seed=43)
+    if sys.argv[1:] == ['train_vae_extra']:
+        return train_vae_extra_cases()
     if sys.argv[1:] == ['train_wide']:
         return train_wide_cases()
     if sys.argv[1:] == ['train_wide2']:
@@ -791,6 +822,7 @@ def main():
     wide_cases()
     train_funnel_case()
     train_vae_case('train_vae_small', latent=10, H=24, dec_h=48, n_pix=40, enc_h=32, T=4, eps=0.1, N=32, seed=43)
+    train_vae_extra_cases()
     train_wide_cases()
 
 

@@ -6,7 +6,8 @@ Only tests/ may import this.  It restates, in torch on the CPU (float64 by defau
   * the S/T/Q nets with the shared image branch       mnist_vae.py:134-167, utils/layers.py:29-37,81-95
   * the generalised leapfrog, both directions         utils/dynamics.py:115-201,246-309
   * propose + MH select                               utils/sampler.py:28-55
-  * the sampler loss, chained over MH proposals       mnist_vae.py:185-226 (energy_scale = 0)
+  * the sampler loss, chained over MH proposals       mnist_vae.py:185-226 (incl. energy_scale and the
+                                                      random_lf_composition branch = sampler.py:57-85)
 
 and differentiates the loss with torch autograd (the energy gradient inside the dynamics is itself an
 autograd call with create_graph=True, i.e. the Hessian-vector products the HIP trainer derives by hand are
@@ -113,11 +114,13 @@ class _Dyn(object):
         return torch.where(torch.isfinite(p), p, torch.zeros_like(p))
 
 
-def sampler_loss_and_grad(g, draws, MH=1, stop_gradient=False, R=None, dtype=torch.float64):
+def sampler_loss_and_grad(g, draws, MH=1, stop_gradient=False, R=None, dtype=torch.float64, energy_scale=0.0):
     """g: fixture-style dict (dec.*, enc.*, xnet.*, vnet.*, eps, mask, T, x, aux, log_sigma);
     draws: list of MH dicts {v_fwd, v_bwd, dir, u} (sampler.py:34-36 draws both momenta; each chain uses its
-    direction's).  R: optional (N, d) -- adds sum(final_x * R) to the loss (the cotangent a later proposal would
-    send).  Returns loss, per-parameter gradients ('xnet.W1', ..., 'enc.b3', 'alpha'), grad of the start point
+    direction's) -- or, for the `random_lf_composition` branch (mnist_vae.py:193-196 = chain_operator,
+    sampler.py:57-85), {nb_steps, init_v, v_fwd: (K, N, d), v_bwd, dir: (K, N), u}.
+    R: optional (N, d) -- adds sum(final_x * R) to the loss (the cotangent a later proposal would
+    send).  energy_scale: mnist_vae.py:214,218,224.  Returns loss, per-parameter gradients ('xnet.W1', ..., 'enc.b3', 'alpha'), grad of the start point
     ('x0'), and the last proposal's Lx / px / x_next / v."""
     def T_(a, grad=False):
         t = torch.tensor(np.asarray(a, dtype=np.float64), dtype=dtype)
@@ -142,15 +145,32 @@ def sampler_loss_and_grad(g, draws, MH=1, stop_gradient=False, R=None, dtype=tor
         dr = draws[t]
         if stop_gradient:
             init_x = init_x.detach()
-        dbit = T_(np.asarray(dr["dir"]).astype(np.float64)).reshape(-1, 1)
-        X1, V1, j1 = dyn.run(init_x, T_(dr["v_fwd"]), True)
-        X2, V2, j2 = dyn.run(init_x, T_(dr["v_bwd"]), False)
-        p1 = dyn.p_accept(init_x, T_(dr["v_fwd"]), X1, V1, j1)
-        p2 = dyn.p_accept(init_x, T_(dr["v_bwd"]), X2, V2, j2)
-        final_x = dbit * X1 + (1.0 - dbit) * X2            # sampler.py:38
-        px = dbit[:, 0] * p1 + (1.0 - dbit[:, 0]) * p2     # sampler.py:44
+        if "nb_steps" in dr:                               # chain_operator (sampler.py:57-85)
+            init_v = T_(dr["init_v"])                      # :58-59 -- NOT the momentum any link starts from (:35-36)
+            xs, vs, lj = init_x, init_v, 0.0
+            for k in range(int(dr["nb_steps"])):
+                dbit = T_(np.asarray(dr["dir"][k]).astype(np.float64)).reshape(-1, 1)
+                X1, V1, j1 = dyn.run(xs, T_(dr["v_fwd"][k]), True)
+                X2, V2, j2 = dyn.run(xs, T_(dr["v_bwd"][k]), False)
+                xs = dbit * X1 + (1.0 - dbit) * X2         # sampler.py:38
+                vs = dbit * V1 + (1.0 - dbit) * V2         # :40-41 (init_v was passed, so Lv is mixed and threaded on)
+                lj = lj + dbit[:, 0] * j1 + (1.0 - dbit[:, 0]) * j2      # :44 with log_jac=True, summed at :66
+            final_x = xs
+            px = dyn.p_accept(init_x, init_v, xs, vs, lj)  # :79
+        else:
+            dbit = T_(np.asarray(dr["dir"]).astype(np.float64)).reshape(-1, 1)
+            X1, V1, j1 = dyn.run(init_x, T_(dr["v_fwd"]), True)
+            X2, V2, j2 = dyn.run(init_x, T_(dr["v_bwd"]), False)
+            p1 = dyn.p_accept(init_x, T_(dr["v_fwd"]), X1, V1, j1)
+            p2 = dyn.p_accept(init_x, T_(dr["v_bwd"]), X2, V2, j2)
+            final_x = dbit * X1 + (1.0 - dbit) * X2            # sampler.py:38
+            px = dbit[:, 0] * p1 + (1.0 - dbit[:, 0]) * p2     # sampler.py:44
         v = ((final_x - init_x) ** 2 * w).sum(1) * px + 1e-4
         loss = (1.0 / MH) * ((1.0 / v).mean() - v.mean())  # only the last iteration's terms survive (:187-189)
+        ed = None
+        if energy_scale != 0.0:                            # :214,218,224
+            ed = (dyn.energy(final_x) - dyn.energy(init_x)) ** 2 * px + 1e-4
+            loss = loss + energy_scale * (1.0 / MH) * ((1.0 / ed).mean() - ed.mean())
         prev_x = init_x
         acc = (px - T_(dr["u"])) >= 0                       # sampler.py:53-55
         init_x = torch.where(acc.reshape(-1, 1), final_x, init_x)
@@ -159,7 +179,8 @@ def sampler_loss_and_grad(g, draws, MH=1, stop_gradient=False, R=None, dtype=tor
     names = sorted(par)
     grads = torch.autograd.grad(loss, [par[n] for n in names] + [x0], allow_unused=True)
     out = {"loss": float(loss.detach()), "v": v.detach().numpy(), "Lx": final_x.detach().numpy(), "px": px.detach().numpy(),
-           "x_next": init_x.detach().numpy(), "x_last_start": prev_x.detach().numpy()}
+           "x_next": init_x.detach().numpy(), "x_last_start": prev_x.detach().numpy(),
+           "ediff": None if ed is None else ed.detach().numpy()}
     for n, gr in zip(names + ["x0"], grads):
         out["grad." + n] = (gr if gr is not None else torch.zeros(())).detach().numpy()
     return out

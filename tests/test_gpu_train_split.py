@@ -125,6 +125,70 @@ def test_vae_sampler_chained_proposals_match_the_autograd_oracle(stop):
     _check_net_grads(gg, dyn, tol=5e-4)
 
 
+def _hip_vae_draws(od):
+    """oracle-format draws (both momenta per direction) -> the HIP trainer's (each chain's own direction only)"""
+    if "nb_steps" in od:
+        K = int(od["nb_steps"])
+        return {"nb_steps": K, "init_v": od["init_v"], "u": od["u"], "dir": [od["dir"][k] for k in range(K)],
+                "v": [np.where(od["dir"][k][:, None] != 0, od["v_fwd"][k], od["v_bwd"][k]) for k in range(K)]}
+    return {"v": np.where(od["dir"][:, None] != 0, od["v_fwd"], od["v_bwd"]), "dir": od["dir"], "u": od["u"]}
+
+
+@pytest.mark.parametrize("case", ["train_vae_small_es", "train_vae_small_rlc"])
+def test_vae_sampler_optional_terms_match_reference_graph(case):
+    """mnist_vae.py's `energy_scale` term (:214,218,224) and its `random_lf_composition` branch (:193-196, the proposal is
+    `chain_operator` with a drawn number of composed links, sampler.py:57-85): tf.gradients of the reference's own graph
+    vs the HIP trainer -- loss, accept probability, next state, every sampler variable's gradient."""
+    from tests.test_oracle_golden import vae_train_draws
+    g = load(case)
+    dyn, tr = _trainer(g)
+    R = 4 if "chain.nb_steps" in g else 0
+    loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(g["log_sigma"]), MH=1,
+                                             draws=[_hip_vae_draws(vae_train_draws(g)[0])],
+                                             energy_scale=float(g["energy_scale"]), random_lf_composition=R)
+    assert abs(float(loss) - float(g["loss"])) < 5e-4 * max(1.0, abs(float(g["loss"]))), (float(loss), float(g["loss"]))
+    assert abs_err(to_np(px), g["px"]) < P_TOL and rel_err(to_np(x_T), g["x_next"]) < 3 * TRAJ_TOL
+    keys = [k[5:] for k in g if k.startswith("grad.") and k not in ("grad.alpha", "grad.x0")]
+    scale = max(float(np.abs(g["grad." + k]).max()) for k in keys)
+    worst = 0.0
+    enc = dyn._xw["aux_encoder"]
+    for k in keys:
+        net, leaf = k.split(".")
+        t = (dyn._xw if net == "xnet" else dyn._vw if net == "vnet" else enc)[leaf]
+        ref = g["grad." + k]
+        err = float(np.abs(to_np(t.grad).reshape(ref.shape) - ref).max())
+        worst = max(worst, err)
+        assert err < 5e-4 * scale, (k, err, scale)
+    ga = float(dyn.alpha.grad)
+    assert abs(ga - float(g["grad.alpha"])) < 5e-4 * max(scale, abs(float(g["grad.alpha"])))
+    print("%s: loss %.6e (ref %.6e)  max |dgrad| %.2e (scale %.2e)" % (case, float(loss), float(g["loss"]), worst, scale))
+
+
+@pytest.mark.parametrize("stop", [False, True])
+def test_vae_sampler_compositions_chained_over_mh_iterations_match_the_autograd_oracle(stop):
+    """MH = 2 iterations, each a composition of a different number of links (2, then 3), energy_scale = 0.3, with and without
+    stop_gradient: the reverse pass walks the links of both compositions and the MH select between them; float64 autograd
+    of the CPU restatement is the checker (pinned by the two reference-graph fixtures above)."""
+    from oracle import vae_train_oracle as V
+    g = load("train_vae_small_rlc")
+    dyn, tr = _trainer(g)
+    N, d = g["x"].shape
+    rng = np.random.RandomState(8)
+    od = []
+    for K in (2, 3):
+        od.append({"nb_steps": K, "init_v": rng.randn(N, d).astype(np.float32),
+                   "v_fwd": rng.randn(K, N, d).astype(np.float32), "v_bwd": rng.randn(K, N, d).astype(np.float32),
+                   "dir": rng.randint(0, 2, size=(K, N)).astype(np.uint8), "u": rng.rand(N).astype(np.float32)})
+    o = V.sampler_loss_and_grad(g, od, MH=2, stop_gradient=stop, energy_scale=0.3)
+    loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(g["log_sigma"]), MH=2,
+                                             stop_gradient=stop, draws=[_hip_vae_draws(x) for x in od], energy_scale=0.3,
+                                             random_lf_composition=4)
+    assert abs(float(loss) - o["loss"]) < 5e-4 * max(1.0, abs(o["loss"])), (float(loss), o["loss"])
+    assert rel_err(to_np(x_T), o["x_next"]) < 1e-3 and abs_err(to_np(px), o["px"]) < 2 * P_TOL
+    gg = {"grad." + k[5:]: v for k, v in o.items() if k.startswith("grad.")}
+    _check_net_grads(gg, dyn, tol=1e-3)
+
+
 def test_gemm_engine_gradient_is_bitwise_reproducible_and_shards_add_up():
     """no atomics: two runs give identical bits; per-shard gradients with inv_n = 1 / (global count) sum to the full one"""
     import torch

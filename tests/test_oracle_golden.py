@@ -259,6 +259,36 @@ def test_vae_sampler_objective_oracle_matches_reference_graph():
             assert np.abs(got - ref).max() < 2e-5 * max(float(np.abs(ref).max()), 1e-3), (pre, k)
 
 
+def vae_train_draws(g):
+    """the recorded randomness of a train_vae_* fixture in the oracle's format (one MH iteration)"""
+    if "chain.nb_steps" in g:
+        return [{"nb_steps": int(g["chain.nb_steps"]), "init_v": g["chain.init_v"], "v_fwd": g["chain.v_fwd"],
+                 "v_bwd": g["chain.v_bwd"], "dir": g["chain.dir"], "u": g["prop.u"]}]
+    return [{"v_fwd": g["prop.v_fwd"], "v_bwd": g["prop.v_bwd"], "dir": g["prop.dir"], "u": g["prop.u"]}]
+
+
+@pytest.mark.parametrize("case", ["train_vae_small_es", "train_vae_small_rlc"])
+def test_vae_sampler_objective_optional_terms_match_reference_graph(case):
+    """mnist_vae.py's `energy_scale` term (:214,218,224) and its `random_lf_composition` branch (:193-196: the proposal is
+    the reference's chain_operator with a drawn number of composed links) -- oracle vs tf.gradients of the reference's
+    own graph for every sampler variable and the start point."""
+    from oracle import vae_train_oracle as V
+    g = load(case)
+    o = V.sampler_loss_and_grad(g, vae_train_draws(g), MH=1, energy_scale=float(g["energy_scale"]))
+    assert abs(o["loss"] - float(g["loss"])) < 5e-5 * max(1.0, abs(float(g["loss"])))
+    assert rel_err(o["Lx"], g["Lx"]) < 3 * TRAJ_TOL and abs_err(o["px"], g["px"]) < P_TOL
+    assert rel_err(o["ediff"], g["ediff"]) < 1e-3
+    keys = [k[len("grad."):] for k in g if k.startswith("grad.")]
+    assert len(keys) == 2 * 16 + 6 + 2
+    # the reference side is float32: a few chains with v ~ 1e-4 carry 1 / v^2 ~ 1e8 weights, so compare on the scale of
+    # the whole gradient rather than per array
+    scale = max(float(np.abs(g["grad." + k]).max()) for k in keys)
+    for k in keys:
+        ref = g["grad." + k]
+        got = np.asarray(o["grad." + k]).reshape(ref.shape)
+        assert np.abs(got - ref).max() < 2e-4 * scale, (k, np.abs(got - ref).max(), scale)
+
+
 def test_vae_aux_branch_matches_reference_layers():
     g = load("vae_small")
     from tests.helpers import mlp_weights
