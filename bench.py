@@ -404,6 +404,8 @@ def main():
     ap.add_argument("--no-ess", action="store_true", help="skip the SCG-2D ESS/sec leg (N=1) / the dist leg (N>1)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 65 536-chain roofline point (N=1 only)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (VAE engine) extra key (N=1 only)")
+    ap.add_argument("--no-config5-trained", action="store_true",
+                    help="skip the trained-sampler part of the config-5 key (200 sampler updates + ESS vs HMC, ~15 s)")
     ap.add_argument("--ess-train-steps", type=int, default=5000,
                     help="Adam steps for the L2HMC sampler of the ESS leg (0 = HMC only)")
     ap.add_argument("--ess-seeds", type=int, default=5, help="independent trainings of the ESS leg")
@@ -677,6 +679,13 @@ def main():
             out["sweep"] = sweep
         if world == 1 and not args.no_config5 and not strong and n == CHAINS and not args.force_dist:
             out["config5"] = config5_leg(dev)
+            if not args.no_config5_trained:
+                # config 5 as BASELINE.json words it ("trained sampler"): train the sampler with the reference's update, then
+                # MH steps/s, accept and ESS/s of the trained sampler vs HMC on the posterior (eval_sampler.py:145-204)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_config5_trained
+                out["config5"]["trained"] = bench_config5_trained.run(dev, updates=200, mh_steps=250,
+                                                                       hmc_eps=(0.075, 0.1, 0.175))
         if world == 1 and not args.no_ess and not args.force_dist:
             out["ess"] = ess_leg(dev, args.ess_train_steps, args.ess_seeds)
         if strong_out is not None:
