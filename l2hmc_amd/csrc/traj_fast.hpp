@@ -36,6 +36,10 @@ __device__ __forceinline__ f4 ex2_4(f4 a) {
             __builtin_amdgcn_exp2f(a.w)};
 }
 
+// (Measured and not kept, profiles/r03_exchange_variants.txt: moving the K-split partial as 96 bits -- only r < KH of the
+//  float4 are live hidden units -- and keeping a wave's own partial in registers, 3 x ds_read_b96 instead of
+//  4 x ds_read_b128 per wave.  The exchange is latency-, not LDS-bandwidth-bound: b96 is neutral, and the wave-uniform
+//  switch that keeps the canonical summation order costs 2.5-6 % at 4096 chains.)
 // LDS geometry of the fast kernel (floats).  Host and device agree through these helpers.
 // NTp = NW * DT >= NT: every wave's tiles exist in the tables (zero-filled beyond NT), so the loop has no
 // "is this tile live" branches.
@@ -95,6 +99,12 @@ __device__ __forceinline__ void tail_fast(const TailK<DT>& tk, f4 hs_, F&& apply
       zq = MFMA16(tk.hq[t][r], h[r], zq);
       zt = MFMA16(tk.ht[t][r], h[r], zt);
     }
+#ifndef L2HMC_NO_HEAD_FENCE
+    // all nine head MFMAs first: by the time they have issued, zs (whose chain ended two MFMAs ago) is readable
+    // without hazard nops, then zq; zt is used last (the compiler otherwise starts the exps after two chains and pays
+    // the MFMA -> VALU wait states in front of them)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // c tanh(z) = c + c * rcp(-(2^{2 z log2 e} + 1) / 2); the head outputs arrive pre-scaled
     const f4 rS = rcp4(-(ex2_4(zs) * 0.5f + 0.5f));
     const f4 aS = rS * tk.cS[t] + tk.cS[t];
