@@ -270,6 +270,12 @@ typedef struct L2hmcSplitArgs {
                                   *    aux_encoder + aux may still be given (image-conditioned nets,
                                   *    mnist_vae.py:134-150: aux is (N, aux_encoder->n_in)); HMC mode is allowed  */
   void* energy_cb_user;          /* passed back as the callback's first argument                              */
+  int32_t gemm_mode;             /* arithmetic of the decoder-sized dense products (M x 1024 x 1024 ...):
+                                  *    0: f32-input MFMA (v_mfma_f32_16x16x4_f32), bit-exact fp32 FMA chains;
+                                  *    1: "bf16x3" -- every fp32 operand split EXACTLY into three bf16 terms, the six
+                                  *       significant cross products on the bf16 MFMA (16x the f32 MFMA rate), fp32
+                                  *       accumulation: dropped terms <= 3 x 2^-24 |x y| per product, i.e. fp32-level
+                                  *       accuracy (measured against float64 in profiles/ and the config-5 parity tests) */
 } L2hmcSplitArgs;
 
 int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,
@@ -386,6 +392,7 @@ typedef struct L2hmcTrainSplitArgs {
   const float* dlogjac_in;       /* (N) or NULL: cotangent on the proposal's summed log-Jacobian                */
   float* Lv_out;                 /* (N, d) or NULL                                                              */
   float* logjac_out;             /* (N) or NULL                                                                 */
+  int32_t gemm_mode;             /* as L2hmcSplitArgs.gemm_mode                                                 */
 } L2hmcTrainSplitArgs;
 
 int64_t l2hmc_train_split_grad_floats(int32_t d, int32_t H, const L2hmcMlp3* aux_encoder);

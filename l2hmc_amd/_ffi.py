@@ -61,7 +61,7 @@ class L2hmcSplitArgs(C.Structure):
                 ("x_out", _fp), ("v_out", _fp), ("logjac_out", _fp), ("p_out", _fp), ("x_next", _fp),
                 ("workspace", _fp), ("workspace_floats", C.c_int64), ("hmc", C.c_int32),
                 ("bce_scale", C.c_float), ("energy", C.POINTER(L2hmcEnergy)), ("reuse", C.c_int32),
-                ("energy_cb", _fp), ("energy_cb_user", _fp)]
+                ("energy_cb", _fp), ("energy_cb_user", _fp), ("gemm_mode", C.c_int32)]
 
 
 # include/l2hmc.h L2hmcEnergyCallback: (user, x, ldx, n_chains, d, U_out, grad_out, ldg, stream) -> int
@@ -89,7 +89,7 @@ class L2hmcTrainSplitArgs(C.Structure):
                 ("Lx", _fp), ("p", _fp), ("v1", _fp), ("dx0_out", _fp), ("grad", _fp),
                 ("workspace", _fp), ("workspace_floats", C.c_int64),
                 ("energy_scale", C.c_float), ("ediff_out", _fp), ("no_accept", C.c_int32), ("dLv_in", _fp),
-                ("dlogjac_in", _fp), ("Lv_out", _fp), ("logjac_out", _fp)]
+                ("dlogjac_in", _fp), ("Lv_out", _fp), ("logjac_out", _fp), ("gemm_mode", C.c_int32)]
 
 
 STRUCTS = (L2hmcNet, L2hmcEnergy, L2hmcTrajectoryArgs, L2hmcMlp3, L2hmcSplitArgs, L2hmcTrainArgs, L2hmcTrainSplitArgs)

@@ -56,6 +56,7 @@ struct GemmArgs {
   // EPI_NET1
   const float* tb;               // (T, N) time/bias table of this net
   const unsigned char* dir; int dir_all, it, T;
+  int bf3;                       // 1: the product runs on the bf16 MFMA with 3-way split operands (see gemm_nt_kernel)
 };
 
 #ifndef L2HMC_GEMM_GK
@@ -103,15 +104,63 @@ __device__ __forceinline__ f4 load_kquad(const float* p, int k, int K) {
   return v;
 }
 
+// ---- error-compensated bf16 MFMA ("bf16x3") ---------------------------------------------------------------------------
+// gfx950's bf16 MFMA runs at 16x the f32-input MFMA rate.  Every fp32 operand is split into three bf16 terms
+// x = h + m + l (round-to-nearest at each level: 24+ significand bits in all, i.e. the split is EXACT for fp32 inputs), and
+// of the nine cross products the six with weight >= 2^-16 are kept:  h h + (h m + m h) + (h l + m m + l h).  The dropped ones
+// are <= 3 x 2^-24 |x y| -- the size of ONE fp32 rounding; products of bf16 terms are exact in the MFMA's fp32 datapath and
+// the accumulation is fp32 as before.  Six v_mfma_f32_16x16x32_bf16 (K = 32, ~16 cycles each) replace eight
+// v_mfma_f32_16x16x4_f32 (K = 4 each, 32 cycles each) per 16 x 16 x 32 block: 96 instead of 256 matrix-pipe cycles, and unlike
+// the f32-input MFMA the bf16 one leaves the VALU free for the split (v_cvt_pk_bf16_f32 + shift / and + v_pk_add_f32:
+// 4.5 VALU per operand element, done by the consuming wave right after its LDS read -- the staging path and the LDS layout
+// are those of the fp32 kernel).  Same D layout as the 16x16x4 form, so the epilogues are shared.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+struct Split3 { u4v h, m, l; };
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 r = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ Split3 split3(f4 x0, f4 x1) {       // 8 consecutive k of one row
+  const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  Split3 o;
+#ifdef L2HMC_BF3_ABL_NOSPLIT      // timing ablation only (wrong numbers): no VALU split
+  o.h = u4v{__float_as_uint(x0.x), __float_as_uint(x0.y), __float_as_uint(x0.z), __float_as_uint(x0.w)};
+  o.m = u4v{__float_as_uint(x1.x), __float_as_uint(x1.y), __float_as_uint(x1.z), __float_as_uint(x1.w)};
+  o.l = o.h;
+  return o;
+#endif
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = xs[2 * i], b = xs[2 * i + 1];
+    const unsigned ph = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(ph << 16), rb = b - __uint_as_float(ph & 0xffff0000u);
+    const unsigned pm = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(pm << 16), sb = rb - __uint_as_float(pm & 0xffff0000u);
+    o.h[i] = ph; o.m[i] = pm; o.l[i] = pk_bf16(sa, sb);
+  }
+  return o;
+}
+__device__ __forceinline__ f4 mfma_bf16(u4v a, u4v b, f4 c) {
+#ifdef L2HMC_BF3_ABL_NOMFMA       // timing ablation only: the split results are consumed by one VALU op instead
+  c.x += __uint_as_float(a.x ^ b.y);
+  return c;
+#endif
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+
 // WMB x WNB: 16 x 16 MFMA tiles per wave along m and n; the 2 x 2 waves of a workgroup cover a
 // (32 WMB) x (32 WNB) tile of C.  4 x 4 (128 x 128) for the big decoder products, 2 x 2 (64 x 64) for the
 // H = 200 net layers (fills the chip at M = 8192), 1 x 2 (32 x 64) for the N = d = 50 latent gradient.
 // WAVES_N: how the 4 waves tile the workgroup's block -- 2 x 2 (default) or 4 x 1 (each wave spans the whole width
 // 16 WNB: the 112-wide tiles that divide the decoder's 784 logits exactly)
-template <int EPI, int KV, int WMB, int WNB, int WAVES_N = 2>
+// BF3 = 1: the bf16x3 inner product above on k-tiles of 32 (one barrier per 96 bf16 MFMAs of a 64 x 64 wave block).
+template <int EPI, int KV, int WMB, int WNB, int WAVES_N = 2, int BF3 = 0>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
   constexpr int WAVES_M = 4 / WAVES_N;
   constexpr int TM = 16 * WMB * WAVES_M, TN = 16 * WNB * WAVES_N;
+  constexpr int GK = BF3 ? 32 : l2hmc::GK, GP = GK + 4;          // (shadow the file-level k-tile for this kernel)
   __shared__ __attribute__((aligned(16))) float sA[2][TM * GP];   // activations  [m][k]
   __shared__ __attribute__((aligned(16))) float sB[2][TN * GP];   // weights      [n][k]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -161,6 +210,58 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * GK);                         // in flight under the MFMAs below
+    if constexpr (BF3 != 0) {
+      // lane (c, q) takes k = 8 q .. 8 q + 7 of its row for BOTH operands (any k permutation common to A and B is a valid
+      // contraction order): two ds_read_b128 per fragment, split in registers
+      // Software pipeline inside the k-tile: the fp32 fragments are all requested up front; block i's 24 MFMAs (six
+      // products x WMB independent accumulators, product-major so consecutive MFMAs never wait on each other) issue while
+      // the VALU splits weight fragment i + 1 -- sched_group_barrier pins that interleaving (2 MFMA : 3 VALU).
+      f4 ra_[WMB][2], rw_[WNB][2];
+#pragma unroll
+      for (int j = 0; j < WMB; ++j) {
+        const float* pa = &sA[buf][(wm + 16 * j + c) * GP + 8 * q];
+        ra_[j][0] = *reinterpret_cast<const f4*>(pa); ra_[j][1] = *reinterpret_cast<const f4*>(pa + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < WNB; ++i) {
+        const float* pw = &sB[buf][(wn + 16 * i + c) * GP + 8 * q];
+        rw_[i][0] = *reinterpret_cast<const f4*>(pw); rw_[i][1] = *reinterpret_cast<const f4*>(pw + 4);
+      }
+      Split3 sa[WMB];
+#pragma unroll
+      for (int j = 0; j < WMB; ++j) sa[j] = split3(ra_[j][0], ra_[j][1]);
+      Split3 sw = split3(rw_[0][0], rw_[0][1]);
+#pragma unroll
+      for (int i = 0; i < WNB; ++i) {
+        Split3 nx = sw;
+        if (i + 1 < WNB) nx = split3(rw_[i + 1][0], rw_[i + 1][1]);
+#pragma unroll
+        for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.l, sa[j].h, acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.h, sa[j].l, acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.m, sa[j].m, acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.m, sa[j].h, acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.h, sa[j].m, acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.h, sa[j].h, acc[i][j]);
+#ifndef L2HMC_BF3_NO_SGB
+        if (i + 1 < WNB) {
+#pragma unroll
+          for (int rep = 0; rep < 3 * WMB; ++rep) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // 3 VALU
+          }
+        }
+#endif
+        sw = nx;
+      }
+      if (kt + 1 < nk) sstore(buf ^ 1);
+      __syncthreads();
+      continue;
+    }
     // all fragments of the k-tile are requested up front: the second 16-wide half arrives under the MFMAs of the first
     f4 fw[GK / 16][WNB], fa[GK / 16][WMB];
 #pragma unroll
@@ -643,9 +744,17 @@ int launch_gemm_shape(const GemmArgs& g, hipStream_t s) {
   const dim3 grid((unsigned)((g.N + TN - 1) / TN), (unsigned)((g.M + TM - 1) / TM));
   const bool al16 = ((reinterpret_cast<size_t>(g.A) | reinterpret_cast<size_t>(g.B)) & 15) == 0;
   const bool al8 = ((reinterpret_cast<size_t>(g.A) | reinterpret_cast<size_t>(g.B)) & 7) == 0;
-  if (g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && al16)
+  constexpr bool bf3_shape = (WMB == 4 && WNB == 4) || (WMB == 2 && WNB == 7);      // the decoder-sized products only
+  constexpr bool bf3_epi = EPI == EPI_BIAS_SOFTPLUS || EPI == EPI_BCE || EPI == EPI_MUL || EPI == EPI_TAN || EPI == EPI_BIAS;
+  if (g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && al16) {
+    if constexpr (bf3_shape && bf3_epi) {
+      if (g.bf3) {
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, WMB, WNB, WAVES_N, 1>), grid, dim3(256), 0, s, g);
+        return L2HMC_OK;
+      }
+    }
     hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, WMB, WNB, WAVES_N>), grid, dim3(256), 0, s, g);
-  else if (g.K % 2 == 0 && g.lda % 2 == 0 && g.ldb % 2 == 0 && al8)
+  } else if (g.K % 2 == 0 && g.lda % 2 == 0 && g.ldb % 2 == 0 && al8)
     hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, WMB, WNB, WAVES_N>), grid, dim3(256), 0, s, g);
   else
     hipLaunchKernelGGL((gemm_nt_kernel<EPI, 1, WMB, WNB, WAVES_N>), grid, dim3(256), 0, s, g);

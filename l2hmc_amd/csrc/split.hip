@@ -210,9 +210,14 @@ __global__ void k_f2d(const float* a, double* b, long long n) {
 // and their sigmoids s1 / s2 (= softplus', for the input gradient)
 struct Mlp3Ws { float *w1t, *w2t, *w3t, *a1, *s1, *a2, *s2; };
 
+// L2hmcSplitArgs.gemm_mode / L2hmcTrainSplitArgs.gemm_mode of the call being served on this thread (set at the top of every
+// entry point, so no state survives a call): 1 = the decoder-sized products run as bf16x3 (gemm_f32.hpp)
+thread_local int t_gemm_bf3 = 0;
+
 inline GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, long long M, int N, int K) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.bf3 = t_gemm_bf3;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.beta = 1.f;
   return g;
 }
@@ -326,6 +331,7 @@ int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int
 
 int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x, int64_t n_chains, int32_t d,
                      float* U_out, float* grad_out, float* workspace, float bce_scale, void* stream) {
+  t_gemm_bf3 = 0;
   int rc = check_mlp(decoder, "l2hmc_vae_energy");
   if (rc) return rc;
   if (!aux || !x || !workspace || n_chains < 0 || d != decoder->n_in) return fail(L2HMC_ERR_ARG, "l2hmc_vae_energy: bad argument%s");
@@ -357,6 +363,8 @@ int l2hmc_p_accept_energies(const float* U0, const float* v0, const float* U1, c
 
 int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
+  if (a->gemm_mode != 0 && a->gemm_mode != 1) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA) or 1 (bf16x3)%s");
+  t_gemm_bf3 = a->gemm_mode;
   const bool user = a->energy_cb != nullptr;        // the caller's own energy, evaluated on the host between launches
   const bool builtin = a->energy != nullptr;        // a target of utils/distributions.py instead of the decoder posterior
   int rc;

@@ -633,6 +633,8 @@ int64_t l2hmc_train_split_workspace_floats(int64_t n_chains, int32_t d, int32_t 
 }
 
 int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
+  if (a && a->gemm_mode != 0 && a->gemm_mode != 1) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA) or 1 (bf16x3)%s");
+  t_gemm_bf3 = a ? a->gemm_mode : 0;
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
   const bool builtin = a->energy != nullptr;
   int rc;

@@ -60,6 +60,8 @@ class Dynamics(object):
         self.variant = 0                # kernel geometry override (0 = auto), see l2hmc.h
         self.eps_override = None        # float: bypass exp(alpha) (exact step size for parity tests)
         self.anneal_beta = 0.0          # AIS bridge (utils/ais.py:46-47): U := (1-b) |x|^2/2 + b U; 0 = off
+        self.gemm_mode = 1              # GEMM engine, decoder-sized products: 1 = bf16x3 (exact 3-way bf16 split of every
+        #                                 fp32 operand on the bf16 MFMA, fp32-level accuracy), 0 = f32-input MFMA
 
         if not isinstance(energy_function, EnergyFunction):
             if not callable(energy_function):
@@ -359,6 +361,7 @@ class Dynamics(object):
             if img and aux is self._split_aux[0] and aux._version == self._split_aux[1]:
                 reuse |= 2
         a.reuse = reuse
+        a.gemm_mode = int(self.gemm_mode)
         rc = L.l2hmc_trajectory_split(a, _ffi.current_stream(x.device))
         if cb_error:
             raise cb_error[0]

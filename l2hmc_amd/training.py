@@ -412,6 +412,7 @@ class SplitTrainer(Trainer):
         a.energy_scale, a.ediff_out, a.no_accept = float(energy_scale), _ffi.ptr(ediff_out), int(bool(no_accept))
         a.dLv_in, a.dlogjac_in = _ffi.ptr(dLv_in), _ffi.ptr(dlogjac_in)
         a.Lv_out, a.logjac_out = _ffi.ptr(Lv_out), _ffi.ptr(logjac_out)
+        a.gemm_mode = int(getattr(dyn, "gemm_mode", 0))
         _ffi.check(L.l2hmc_train_split_grad(a, _ffi.current_stream(dyn.device)))
         return Lx, p, v1
 

@@ -324,3 +324,66 @@ def test_the_vae_posterior_as_a_plain_closure_matches_the_reference_golden():
     assert rel_err(to_np(Lx), to_np(bLx)) < 5e-5 and abs_err(to_np(px), to_np(bpx)) < 5e-5
     with pytest.raises(ValueError, match="aux"):
         propose(x, dyn)
+
+
+@pytest.mark.parametrize("gemm_mode", [0, 1])
+def test_config5_at_a_chain_count_that_takes_the_big_gemm_tiles(gemm_mode):
+    """Config 5's widths (decoder 50 -> 1024 -> 1024 -> 784, H = 200 nets + image branch, Lf = 5) at 3072 chains -- the
+    smallest batch whose decoder products take the 128 x 128 (and 128 x 112) workgroup tiles, i.e. the kernels the 8192-chain
+    numbers are quoted on; `test_config5_full_size_against_oracle` (192 chains) only reaches the 64 x 64 form.  Both
+    arithmetic modes of those products: 0 = f32-input MFMA, 1 = bf16x3 (exact three-way bf16 split of every fp32 operand, six
+    products on the bf16 MFMA, fp32 accumulation).  SAME tolerances for both, against the float64 evaluation of the same
+    map: positions 2e-4 relative, accept probability 1e-4 absolute (north_star)."""
+    from l2hmc_amd import propose
+    from tests.helpers import synthetic_vae_case
+    N = 3072
+    g = synthetic_vae_case(N=N, seed=5)
+    dyn = hip_dynamics(g)
+    dyn.gemm_mode = gemm_mode
+    rng = np.random.RandomState(2)
+    direction = rng.randint(0, 2, size=N).astype(np.uint8)
+    u = rng.rand(N).astype(np.float32)
+    aux = aux_of(g)
+    Lx, _, px, outs = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(g["v"]),
+                              u=to_dev(u), aux=aux)
+    od64 = oracle_dynamics(g, np.float64)
+    with np.errstate(all="ignore"):
+        tLx, _, tpx, _ = O.propose(g["x"].astype(np.float64), od64, g["v"].astype(np.float64), g["v"].astype(np.float64),
+                                   direction, u.astype(np.float64), both_directions=False)
+    ex, ep = rel_err(to_np(Lx), tLx), abs_err(to_np(px), tpx)
+    print("config 5 @ %d chains, gemm_mode %d: mean p %.3f  max rel err x %.2e  |p - p64| max %.2e  99.9%% %.2e"
+          % (N, gemm_mode, float(tpx.mean()), ex, ep, np.quantile(np.abs(to_np(px) - tpx), 0.999)))
+    assert ex < 2e-4 and ep < 1e-4, (gemm_mode, ex, ep)
+    check_x_next(to_np(outs[0]), g["x"], tLx, tpx, u, 5e-4)
+
+
+def test_bf16x3_training_gradient_agrees_with_the_f32_mfma_one_at_big_tile_sizes():
+    """The sampler-training gradient (l2hmc_train_split_grad: forward with everything kept, reverse sweep, decoder
+    Hessian-vector products) at 3072 chains of config 5's widths, decoder-sized products as bf16x3 vs as f32-input MFMA:
+    loss, accept probabilities and the whole flat gradient [XNet | VNet | eps | image branch] agree to fp32 rounding level
+    (the f32 form is pinned against the reference graph / the float64 autograd oracle at fixture sizes)."""
+    import torch
+    from l2hmc_amd.training import Trainer
+    from tests.helpers import synthetic_vae_case
+    N = 3072
+    g = synthetic_vae_case(N=N, seed=7)
+    rng = np.random.RandomState(4)
+    dr = {"v": rng.randn(N, 50).astype(np.float32), "dir": rng.randint(0, 2, N).astype(np.uint8), "u": rng.rand(N).astype(np.float32)}
+    ls = np.full((N, 50), -0.5, np.float32)
+    res = {}
+    for mode in (0, 1):
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        dyn.gemm_mode = mode
+        tr = Trainer(dyn, decay_steps=0)
+        loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(ls), MH=1, draws=[dr], energy_scale=0.2)
+        res[mode] = (float(loss), to_np(px), to_np(tr.flat).copy())
+    a, b = res[0], res[1]
+    scale = float(np.abs(a[2]).max())
+    print("loss %.6e vs %.6e   |dp| %.2e   |dgrad| %.2e (scale %.2e)" % (a[0], b[0], np.abs(a[1] - b[1]).max(),
+                                                                         np.abs(a[2] - b[2]).max(), scale))
+    assert abs(a[0] - b[0]) < 1e-4 * max(1.0, abs(a[0]))
+    assert np.abs(a[1] - b[1]).max() < 5e-5
+    assert np.abs(a[2] - b[2]).max() < 2e-4 * scale
