@@ -430,10 +430,13 @@ inline size_t net_eval_lds_bytes(int d, int H, int CB = 1) {
                                            (net_eval_out_aliases_h1(d, H) ? 0 : ceil16(3 * d)));
 }
 
-template <int CB>
-__global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
+// NWV = waves per workgroup (the waves share out the 16-wide output blocks of every layer): <1, 4> = 16 chains on 4 waves,
+// two workgroups per CU; <2, 8> = 32 chains on 8 waves, one workgroup per CU -- the same 8 waves per CU, but every weight
+// fragment streamed from L2 now feeds two MFMAs (half the L2 traffic of a net evaluation).
+template <int CB, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(const NetEvalArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int NE_MT = 16 * CB;
+  constexpr int NE_MT = 16 * CB, NTHR = 64 * NWV;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int K1 = 2 * g.d, H = g.H, K1p = ceil16(K1), Hp = ceil16(H);
@@ -445,13 +448,13 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
   float* sOut = ldo <= ldh ? sH1 : sH2 + NE_MT * ldh;    // (NE_MT, ceil16(3 d)) head products of the fused update
   const long long m0 = (long long)blockIdx.x * NE_MT;
 
-  for (int i = tid; i < NE_MT * (K1p / 4); i += 256) {        // input tile, zero padded to K1p (K1 % 4 == 0)
+  for (int i = tid; i < NE_MT * (K1p / 4); i += NTHR) {        // input tile, zero padded to K1p (K1 % 4 == 0)
     const int r = i / (K1p / 4), kq4 = (i % (K1p / 4)) * 4;
     f4 v = splat(0.f);
     if (m0 + r < g.M && kq4 < K1) v = *reinterpret_cast<const f4*>(g.AB + (m0 + r) * g.ldab + kq4);
     *reinterpret_cast<f4*>(sIn + r * ld1 + kq4) = v;
   }
-  for (int i = tid; i < NE_MT * (ldh - H) ; i += 256) {       // pad columns of the hidden activations
+  for (int i = tid; i < NE_MT * (ldh - H) ; i += NTHR) {       // pad columns of the hidden activations
     const int r = i / (ldh - H), k = H + i % (ldh - H);
     sH1[r * ldh + k] = 0.f;
     sH2[r * ldh + k] = 0.f;
@@ -462,7 +465,9 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
   // C[m = 16 cb + c][n = 16 nb + 4 q + r]
   auto layer = [&](const float* As, int ldA, int Kp, const float* Wt, int Np, auto&& epi) {
     const int nk = Kp >> 4;
-    for (int nb = w; nb * 16 < Np; nb += 4) {
+    // (requesting block nb + NWV's weight fragments before block nb's MFMAs -- two register stages -- was measured: 3.84 vs
+    //  3.79 ms per config-5 proposal; the eight waves of a CU already cover the L2 latency)
+    for (int nb = w; nb * 16 < Np; nb += NWV) {
       const float* wrow = Wt + (long long)(nb * 16 + c) * Kp + 4 * q;
       f4 wf[NE_MAXKT];
 #pragma unroll
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void net_eval_kernel(const NetEvalArgs g) {
   // ---- fused half-update: TPC = 16 / CB threads per chain, dimensions strided by TPC; the chain's log-det share is
   // reduced over its TPC lanes in a fixed order
   const NetEvalArgs::Update& U = g.upd;
-  constexpr int TPC = 16 / CB;
+  constexpr int TPC = NTHR / NE_MT;
   const int r = tid / TPC, j = tid % TPC;
   const long long n = m0 + r;
   const bool ok = n < g.M;

@@ -474,11 +474,15 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   //  measured twice at 8192 chains: with one workgroup per CU (88 KB of LDS) the evaluation is 25 % slower than with 16
   //  chains, with two per CU (69 KB after the head products moved into the dead first activation) still 8 % slower:
   //  occupancy, not L2 traffic, is what this kernel lives on)
-  const int ne_cb = 1;
+  // 32 chains on 8 waves (one workgroup per CU, half the L2 weight traffic) once that still fills the chip
+#ifndef L2HMC_NE_CB2_MIN
+#define L2HMC_NE_CB2_MIN 8192
+#endif
+  const int ne_cb = N >= L2HMC_NE_CB2_MIN ? 2 : 1;
   const size_t ne_lds = net_eval_lds_bytes(d, H, ne_cb);
   const bool ne_ok = (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(2 * d) <= 16 * NE_MAXKT && ne_lds <= 160 * 1024;
   if (ne_ok && !hmc && ne_lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_eval_kernel<2>) : reinterpret_cast<const void*>(net_eval_kernel<1>),
+    hipError_t e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_eval_kernel<2, 8>) : reinterpret_cast<const void*>(net_eval_kernel<1, 4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
     if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
@@ -494,8 +498,8 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
       na.dir = dir; na.dir_all = dall; na.it = it; na.T = T; na.out3 = out3; na.M = (int)N; na.d = d; na.H = H;
       na.upd = upd;
       const unsigned blocks = (unsigned)((N + 16 * ne_cb - 1) / (16 * ne_cb));
-      if (ne_cb == 2) hipLaunchKernelGGL(net_eval_kernel<2>, dim3(blocks), dim3(256), ne_lds, s, na);
-      else hipLaunchKernelGGL(net_eval_kernel<1>, dim3(blocks), dim3(256), ne_lds, s, na);
+      if (ne_cb == 2) hipLaunchKernelGGL((net_eval_kernel<2, 8>), dim3(blocks), dim3(512), ne_lds, s, na);
+      else hipLaunchKernelGGL((net_eval_kernel<1, 4>), dim3(blocks), dim3(256), ne_lds, s, na);
       return;
     }
     GemmArgs ga = gemm_args(ab, L, w + (net == 0 ? p.nx12t : p.nv12t), ceil16(L), h1, H, N, H, L);
