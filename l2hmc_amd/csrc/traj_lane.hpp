@@ -107,8 +107,8 @@ __device__ __forceinline__ float lane_grad(const KArgs& A, const float* __restri
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
       const float arg = x[k] / den, lv = k < d ? 1.f : 0.f;
-      g[k] = x[k] - scale * sinf(arg);        // (a padded dimension holds x = 0: g = 0)
-      if (wantU) U += 0.5f * x[k] * x[k] + lv * eta * cosf(arg);
+      g[k] = x[k] - scale * rw_sin1(arg);        // (a padded dimension holds x = 0: g = 0)
+      if (wantU) U += 0.5f * x[k] * x[k] + lv * eta * rw_cos1(arg);
     }
   } else {
     // dense Gaussian / mixture, DP <= 16 (one 16 x 16 zero-padded tile of the packed symmetric precision per component):

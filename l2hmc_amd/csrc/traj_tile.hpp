@@ -123,10 +123,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
 
   auto grad_t = [&](f4 xx, int t) {
     if (EK == L2HMC_ENERGY_GAUSS_DIAG) return prec_of(t) * (xx - mu_of(t));
-    f4 g;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) g[r] = xx[r] - (A.eta / rw_den) * sinf(xx[r] / rw_den);
-    return g;
+    return xx - (A.eta / rw_den) * rw_sin4(xx / rw_den);
   };
   auto energy_part = [&](const f4 (&xx)[DT], const f4 (&gg)[DT]) {
     float U = 0.f;

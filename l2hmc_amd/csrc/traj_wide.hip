@@ -32,10 +32,10 @@ __device__ __forceinline__ f4 wide_grad(const KArgs& A, const float* smem, int t
   } else {
     const float eta = A.eta, den = A.easy ? eta : eta * eta, scale = eta / den;
     const f4 arg = x / den;
-    g = x - scale * f4{sinf(arg.x), sinf(arg.y), sinf(arg.z), sinf(arg.w)};
+    g = x - scale * rw_sin4(arg);
     if (wantU) {                           // (wave-uniform: only the end points of a trajectory need U)
       const int dim0 = 16 * tg + 4 * q;    // padded dims hold x = 0 and would add eta * cos(0): mask them out
-      const f4 cs = f4{cosf(arg.x), cosf(arg.y), cosf(arg.z), cosf(arg.w)};
+      const f4 cs = rw_cos4(arg);
       const f4 lv = f4{dim0 < A.d ? 1.f : 0.f, dim0 + 1 < A.d ? 1.f : 0.f, dim0 + 2 < A.d ? 1.f : 0.f,
                        dim0 + 3 < A.d ? 1.f : 0.f};
       u = 0.5f * hsum(x * x) + eta * hsum(lv * cs);
