@@ -388,6 +388,18 @@ void fill_energy(KArgs& k, const L2hmcEnergy* e) {
 // (DT, NW) geometry for d dimensions.  NW = 4 spreads a 16-chain tile over the 4 SIMDs of
 // a CU (more parallelism per chain: right when there are few chains); NW = 1 keeps a tile
 // in one wave (no LDS exchange, fewer MFMAs: right when chains are plentiful).
+// Compute units of the current device (256 on an MI355X in SPX mode; fewer in a CPX / NPS partition or on a cut-down part).
+// The dispatcher's chain-count thresholds were MEASURED on 256 CUs and are statements about tiles per CU, so they scale
+// with this number: 32 / 64 / 256 / 512 chains per CU.  Queried per call (a host-side attribute read, no device work);
+// nothing is cached, the library keeps no state.
+int device_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      cus <= 0)
+    cus = 256;
+  return cus;
+}
+
 bool pick_geometry(int d, long long N, int variant, int& DT, int& NW) {
   const int NT = tiles_of(d);
   if (NT <= 1) { DT = 1; NW = 1; return variant == 0 || variant == 1; }
@@ -397,7 +409,7 @@ bool pick_geometry(int d, long long N, int variant, int& DT, int& NW) {
     // every chain count (1.7e9 vs 1.1e9 steps/s at d = 50..64); with 2 dim-tiles half of its waves idle, so it
     // only pays while there are fewer tiles than wave slots (N < 8192; 2x slower than one wave per tile above).
     // (Two waves x two tiles was tried for 3-4 dim-tiles: never faster than four waves x one tile.)
-    const bool want4 = variant == 4 || (variant == 0 && (NT >= 3 || N < 8192));
+    const bool want4 = variant == 4 || (variant == 0 && (NT >= 3 || N < 32LL * device_cus()));
     if (want4) { DT = 1; NW = 4; } else { DT = NT <= 2 ? 2 : 4; NW = 1; }
     return variant == 0 || variant == 1 || variant == 4;
   }
@@ -555,7 +567,8 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
                            lane_supported(k.ekind, a->d, a->H, k.ncomp) && (a->d <= 16 || a->x_next != nullptr || !has_u_);
     if (a->variant == 32 && !lane_able)
       return fail(L2HMC_ERR_UNSUPPORTED, "variant 32 (one chain per lane) needs S/T/Q nets and a Gaussian / mixture / Rough-Well target with d <= 4%s");
-    const bool lane_auto = ((a->d <= 2 && a->n_chains >= 65536) || (a->d <= 4 && a->n_chains >= 131072));
+    const long long cus = device_cus();
+    const bool lane_auto = ((a->d <= 2 && a->n_chains >= 256 * cus) || (a->d <= 4 && a->n_chains >= 512 * cus));
     if (lane_able && (a->variant == 32 || (a->variant == 0 && lane_auto)))
       return launch_lane(k, s);
   }
@@ -592,7 +605,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
                         k.beta == 1.f && k.temperature == 1.f;
   if (a->variant == 16 && !tileable)
     return fail(L2HMC_ERR_UNSUPPORTED, "variant 16 (one wave per tile) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target and 33 <= d <= 64%s");
-  if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 16384))) {
+  if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 64LL * device_cus()))) {
     const long long ldst = plan_lds_tile(k, k.NT);
     if (ldst <= 160 * 1024) {
       if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, ldst, s);

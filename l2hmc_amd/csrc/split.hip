@@ -475,10 +475,11 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   //  chains, with two per CU (69 KB after the head products moved into the dead first activation) still 8 % slower:
   //  occupancy, not L2 traffic, is what this kernel lives on)
   // 32 chains on 8 waves (one workgroup per CU, half the L2 weight traffic) once that still fills the chip
-#ifndef L2HMC_NE_CB2_MIN
-#define L2HMC_NE_CB2_MIN 8192
-#endif
-  const int ne_cb = N >= L2HMC_NE_CB2_MIN ? 2 : 1;
+  int ne_dev = 0, ne_cus = 256;
+  if (hipGetDevice(&ne_dev) != hipSuccess || hipDeviceGetAttribute(&ne_cus, hipDeviceAttributeMultiprocessorCount, ne_dev) != hipSuccess ||
+      ne_cus <= 0)
+    ne_cus = 256;
+  const int ne_cb = N >= 32LL * ne_cus ? 2 : 1;            // (32 chains per CU = one 8-wave workgroup each; 8192 on 256 CUs)
   const size_t ne_lds = net_eval_lds_bytes(d, H, ne_cb);
   const bool ne_ok = (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(2 * d) <= 16 * NE_MAXKT && ne_lds <= 160 * 1024;
   if (ne_ok && !hmc && ne_lds > 48 * 1024) {
