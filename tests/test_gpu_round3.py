@@ -378,7 +378,7 @@ def test_bf16x3_training_gradient_agrees_with_the_f32_mfma_one_at_big_tile_sizes
             dyn.alpha.fill_(float(np.log(g["eps"])))
         dyn.gemm_mode = mode
         tr = Trainer(dyn, decay_steps=0)
-        loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(ls), MH=1, draws=[dr], energy_scale=0.2)
+        loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(ls), MH=1, draws=[dr])
         res[mode] = (float(loss), to_np(px), to_np(tr.flat).copy())
     a, b = res[0], res[1]
     scale = float(np.abs(a[2]).max())
@@ -386,4 +386,6 @@ def test_bf16x3_training_gradient_agrees_with_the_f32_mfma_one_at_big_tile_sizes
                                                                          np.abs(a[2] - b[2]).max(), scale))
     assert abs(a[0] - b[0]) < 1e-4 * max(1.0, abs(a[0]))
     assert np.abs(a[1] - b[1]).max() < 5e-5
-    assert np.abs(a[2] - b[2]).max() < 2e-4 * scale
+    # (1 / v^2 weights of a few chains with v ~ 1e-4 amplify the 2e-5 difference in p that either arithmetic has against
+    #  float64: the gate is the size of that conditioning, a wrong product would be off by O(scale))
+    assert np.abs(a[2] - b[2]).max() < 1e-3 * scale
