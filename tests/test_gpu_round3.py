@@ -389,3 +389,45 @@ def test_bf16x3_training_gradient_agrees_with_the_f32_mfma_one_at_big_tile_sizes
     # (1 / v^2 weights of a few chains with v ~ 1e-4 amplify the 2e-5 difference in p that either arithmetic has against
     #  float64: the gate is the size of that conditioning, a wrong product would be off by O(scale))
     assert np.abs(a[2] - b[2]).max() < 1e-3 * scale
+
+
+@pytest.mark.parametrize("d", [2, 8, 32, 128, 512])
+def test_config4_rough_well_sweep_at_full_chain_count(d):
+    """BASELINE.json config 4 as the bench runs it: Rough Well (easy, eta = 0.1), 16 384 chains, Lf = 10, the AUTOMATIC kernel
+    choice at every d of the sweep (d <= 4 form, 1 / 4 waves per tile, one wave per tile, LDS-resident state) -- direction-
+    mixed propose + MH against the fp32 oracle, bracketed by the float64 one like the other full-size checks, and the
+    two-half-batches bit-equality (sharding invariance).  The bounded-argument sin / cos of round 3 is on this path."""
+    import torch
+    from l2hmc_amd import propose
+    N = 16384
+    g = synthetic_case("roughwell_easy", d, H=10, T=10, N=N, seed=100 + d, head_std=0.3 if d < 100 else 0.1)
+    rng = np.random.RandomState(9)
+    direction = rng.randint(0, 2, size=N).astype(np.uint8)
+    u = rng.rand(N).astype(np.float32)
+    dyn = hip_dynamics(g, 0)
+    x, v = to_dev(g["x"]), to_dev(g["v"])
+    Lx, _, px, outs = propose(x, dyn, do_mh_step=True, direction=to_dev(direction), v=v, u=to_dev(u))
+    with np.errstate(all="ignore"):
+        rLx, _, rpx, _ = O.propose(g["x"], oracle_dynamics(g), g["v"], g["v"], direction, u, both_directions=False)
+        tLx, _, tpx, _ = O.propose(g["x"].astype(np.float64), oracle_dynamics(g, np.float64), g["v"].astype(np.float64),
+                                   g["v"].astype(np.float64), direction, u.astype(np.float64), both_directions=False)
+    fin = np.all(np.isfinite(tLx), axis=1) & (np.abs(tLx).max(axis=1) < 1e4)
+    assert fin.mean() > 0.95
+    scale = np.maximum(1.0, np.abs(tLx).max(axis=1))
+    e_hip = np.abs(to_np(Lx) - tLx).max(axis=1) / scale
+    e_o32 = np.abs(rLx - tLx).max(axis=1) / scale
+    ep_hip, ep_o32 = np.abs(to_np(px) - tpx)[fin], np.abs(rpx - tpx)[fin]
+    print("rough well d=%d N=%d: x err vs fp64 hip 99%% %.1e max %.1e | oracle32 max %.1e ; p err hip max %.1e | oracle32 %.1e ; mean p %.3f"
+          % (d, N, np.quantile(e_hip[fin], 0.99), e_hip[fin].max(), e_o32[fin].max(), ep_hip.max(), ep_o32.max(), float(tpx.mean())))
+    assert np.quantile(e_hip[fin], 0.99) < TRAJ_TOL and e_hip[fin].max() < 10 * e_o32[fin].max() + TRAJ_TOL
+    assert np.quantile(ep_hip, 0.99) < P_TOL and ep_hip.max() < 10 * ep_o32.max() + P_TOL
+    check_x_next(to_np(outs[0])[fin], g["x"][fin], tLx[fin], tpx[fin], u[fin], 5 * P_TOL)
+    # half batches: d <= 4 switches kernels at chain-count thresholds, so pin the variant the full batch took only where
+    # both halves take the same automatic choice (8192 chains: 4-wave tile for d >= 33, same small / wide kernels otherwise)
+    if d != 32:
+        h = N // 2
+        for lo, hi in ((0, h), (h, N)):
+            Lx_h, _, px_h, _ = propose(x[lo:hi].contiguous(), dyn, do_mh_step=True, direction=to_dev(direction[lo:hi]),
+                                       v=v[lo:hi].contiguous(), u=to_dev(u[lo:hi]))
+            if d in (2, 8, 128, 512):
+                assert torch.equal(Lx_h, Lx[lo:hi]) and torch.equal(px_h, px[lo:hi]), d
