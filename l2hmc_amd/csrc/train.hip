@@ -849,6 +849,18 @@ __global__ void train_reduce_kernel(const float* part, int n_slots, int n_grad, 
 
 __device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.f); }
 #include "train_fast.hpp"
+#include "train_small.hpp"
+
+// d <= 4 targets (the notebook's own SCG-2D training among them): one dimension per lane (train_small.hpp)
+inline bool train_small_ok(int ek, int d, int H) {
+  return d <= 4 && H <= 15 && (ek == L2HMC_ENERGY_GAUSS_DIAG || ek == L2HMC_ENERGY_GAUSS_DENSE || ek == L2HMC_ENERGY_ROUGHWELL);
+}
+template <int EK>
+int launch_train_small(const TArgs& k, int KH, unsigned blocks, long long lds, hipStream_t s) {
+  if (KH <= 3) hipLaunchKernelGGL((train_small_kernel<EK, 3>), dim3(blocks), dim3(64), (size_t)lds, s, k);
+  else hipLaunchKernelGGL((train_small_kernel<EK, 4>), dim3(blocks), dim3(64), (size_t)lds, s, k);
+  return L2HMC_OK;
+}
 
 // geometry of the register-resident kernel for this problem, or 0 if it stays on train_kernel
 inline int train_fast_waves(int ek, int d, int H) {
@@ -941,7 +953,14 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
   float* part;
   const int fnw = a->variant >= 100 ? 0 : train_fast_waves(ek, a->d, a->H);     // variant 100: the general tile kernel
   const long long lds_fast = fnw ? 4LL * tf_layout(a->T, fnw).total : 0;
-  if (fnw && lds_fast <= 160 * 1024) {           // register-resident kernel (train_fast.hpp)
+  const long long lds_small = 4LL * ts_layout(a->T).total;
+  if (a->variant == 0 && train_small_ok(ek, a->d, a->H) && lds_small <= 48 * 1024) {     // d <= 4: one dimension per lane
+    const int KH = khid_of(a->H);
+    if (ek == L2HMC_ENERGY_GAUSS_DIAG) launch_train_small<L2HMC_ENERGY_GAUSS_DIAG>(k, KH, blocks, lds_small, s);
+    else if (ek == L2HMC_ENERGY_GAUSS_DENSE) launch_train_small<L2HMC_ENERGY_GAUSS_DENSE>(k, KH, blocks, lds_small, s);
+    else launch_train_small<L2HMC_ENERGY_ROUGHWELL>(k, KH, blocks, lds_small, s);
+    part = a->workspace + (long long)blocks * a->T * TF_CK * 256;
+  } else if (fnw && lds_fast <= 160 * 1024) {    // register-resident kernel (train_fast.hpp)
     const int KH = khid_of(a->H);
     int rc;
     if (ek == L2HMC_ENERGY_GAUSS_DIAG) rc = fnw == 1 ? launch_train_fast<L2HMC_ENERGY_GAUSS_DIAG, 1>(k, KH, blocks, lds_fast, s)

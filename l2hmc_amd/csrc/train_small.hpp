@@ -1,0 +1,440 @@
+// train_small.hpp -- the training gradient for SMALL targets, d <= 4 (included by train.hip inside namespace l2hmc, after
+// train_fast.hpp).  The notebook's own training configuration (SCGExperiment.ipynb raw 156-181: SCG-2D, 200 chains) has
+// d = 2: in the 16-wide dimension tiles of train_fast_kernel 14 of 16 MFMA rows and 3 of 4 values per lane are padding.
+//
+// Same mathematics as train_fast_kernel / train_kernel (hand-derived reverse mode of one direction-mixed proposal and its
+// loss term incl. the Hessian-vector path through grad U; derivation = oracle/l2hmc_train_oracle.py), in the layout of
+// traj_small.hpp: ONE wave owns 16 chains, lane l = (c = l & 15, q = l >> 4) holds chain c, DIMENSION q -- every state and
+// adjoint vector is a scalar per lane; hidden vectors stay float4 {h[unit(q, r)][chain c]}.  Per net evaluation:
+//   * layer 1: the d <= 4 dimensions are ONE k-step (k = q): 1 MFMA per input instead of 4;
+//   * heads: ONE 16-row block whose row 4 q' + h is (dimension q', head h = S, T, Q): KH MFMAs instead of 3 KH, and lane
+//     (c, q) finds z_S, z_T, z_Q of its own dimension in acc[0..2];
+//   * reverse: (dz_S, dz_T, dz_Q, 0) of a lane IS the B operand of the transposed head product (k-step h <-> head h);
+//     the input adjoints come back on rows 4 j (dimension j) so that lane q reads its own in acc[0];
+//   * weight gradients: the same transposes through a per-wave LDS scratch and 16 x 16 register tiles as train_fast, but
+//     ONE head tile per net (rows = (dimension, head)) instead of three.
+// 48 MFMAs per net evaluation + back-propagation instead of 69 + 20 recomputed ... per leapfrog step and wave: 192 instead
+// of 356 MFMAs, and every elementwise update is scalar instead of float4.  No barriers after staging (one wave), no atomics:
+// the workgroup's flat gradient goes to its workspace slot, train_reduce_kernel adds the slots in block order.
+// Targets: diagonal and dense Gaussians, Rough Well (the funnel and the mixtures stay on train_fast / train_kernel).
+#pragma once
+
+struct TSLayout { int grp, tb, msk, trg, tr, total, ng; };
+__host__ __device__ inline TSLayout ts_layout(int T) {
+  TSLayout L;
+  L.ng = 6;                                   // layer 2 fwd / transposed, heads fwd / transposed, layer 1 transposed (a, b)
+  int p = 0;
+  L.grp = p; p += 2 * L.ng * 256;
+  L.tb = p; p += 2 * T * 16;
+  L.msk = p; p += (T * 4 + 3) / 4 * 4;
+  L.trg = p; p += (2 * T + 3) / 4 * 4;
+  L.tr = p; p += 7 * 320 + 32;                // seven 16 x 20 transpose scratches (one per operand of a back-propagation:
+                                              // written together, read together) + (cos, sin) of the 16 chains
+  L.total = p;
+  return L;
+}
+constexpr int TS_CK = 5;                      // checkpointed scalars per lane and step: x, v, v_half, y, x'
+
+template <int EK, int KH>
+__global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x;
+  const int c = lane & 15, q = lane >> 4;
+  const int d = A.d, H = A.H, T = A.T;
+  const TSLayout L = ts_layout(T);
+  const int ng = L.ng;
+  const NetOff o = net_off(d, H);
+  const int P = net_params(d, H);
+  const long long n = (long long)blockIdx.x * 16 + c;
+  const bool alive = n < A.N, livedim = q < d;
+  const bool isf = A.dir != nullptr ? (alive ? A.dir[n] != 0 : true) : (A.dir_all != 0);
+  const float sg = isf ? 1.f : -1.f;
+  const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
+  const float heps = 0.5f * eps;
+  const float rw_den = A.easy ? A.eta : A.eta * A.eta;
+  const f4 Z = splat(0.f);
+  const float live1 = livedim ? 1.f : 0.f;
+
+  // unit carried by MFMA row i / by k index (kq, r): rows 4 q' + r' with r' < KH are live, unit = q' KH + r'
+  auto unit_row = [&](int i) { return ((i & 3) < KH) ? (i >> 2) * KH + (i & 3) : -1; };
+
+  // ---- stage: weight fragments (A operands; element (lane (i, kq), r): row i, k-step r, k = kq), tables ------------------
+  for (int idx = lane; idx < 2 * ng * 256; idx += 64) {
+    const int net = idx >= ng * 256, rem = idx - net * ng * 256;
+    const int g = rem >> 8, ln = (rem >> 2) & 63, r = rem & 3, i = ln & 15, kq = ln >> 4;
+    const int ui = unit_row(i), uk = (r < KH) ? kq * KH + r : -1;
+    const L2hmcNet& W = net ? A.vnet : A.xnet;
+    float val = 0.f;
+    if (g == 0) {                                   // layer 2 forward: rows u' = ui, k = u = uk  (+ b4, 1 -> 1)
+      if (uk >= 0 && ui >= 0) {
+        if (uk < H && ui < H) val = W.W4[uk * H + ui];
+        else if (uk == H && ui < H) val = W.b4[ui];
+        else if (uk == H && ui == H) val = 1.f;
+      }
+    } else if (g == 1) {                            // layer 2 transposed: rows u = ui, k = u' = uk
+      if (ui >= 0 && ui < H && uk >= 0 && uk < H) val = W.W4[ui * H + uk];
+    } else if (g == 2) {                            // heads forward: row i = (dimension i >> 2, head i & 3), k = unit uk
+      const int dim = i >> 2, h = i & 3;
+      if (h < 3 && dim < d && uk >= 0) {
+        const float* Wh = h == 0 ? W.Ws : (h == 1 ? W.Wt : W.Wq);
+        const float* bh = h == 0 ? W.bs : (h == 1 ? W.bt : W.bq);
+        if (uk < H) val = Wh[uk * d + dim];
+        else if (uk == H) val = bh[dim];
+      }
+    } else if (g == 3) {                            // heads transposed: rows = units ui, k (kq, r) = block row 4 kq + r
+      const int dim = kq, h = r;                    //   = (dimension kq, head r)
+      if (h < 3 && dim < d && ui >= 0 && ui < H) {
+        const float* Wh = h == 0 ? W.Ws : (h == 1 ? W.Wt : W.Wq);
+        val = Wh[ui * d + dim];
+      }
+    } else {                                        // layer 1 transposed: row 4 j = dimension j, k = unit uk
+      const float* W1 = g == 4 ? W.W1 : W.W2;
+      const int dim = i >> 2;
+      if ((i & 3) == 0 && dim < d && uk >= 0 && uk < H) val = W1[dim * H + uk];
+    }
+    smem[L.grp + idx] = val;
+  }
+  for (int i = lane; i < 2 * T; i += 64) smem[L.trg + i] = A.trig[i];
+  for (int idx = lane; idx < 2 * T * 16; idx += 64) {
+    const int net = idx / (T * 16), srow = (idx / 16) % T, i = idx & 15;
+    const int ui = unit_row(i);
+    const L2hmcNet& W = net ? A.vnet : A.xnet;
+    float val = 0.f;
+    if (ui == H) val = 1.f;
+    else if (ui >= 0 && ui < H)
+      val = fmaf(W.W3[ui], A.trig[2 * srow], fmaf(W.W3[H + ui], A.trig[2 * srow + 1], (W.b1[ui] + W.b2[ui]) + W.b3[ui]));
+    smem[L.tb + idx] = val;
+  }
+  for (int i = lane; i < T * 4; i += 64) smem[L.msk + i] = (i & 3) < d ? A.masks[(i >> 2) * d + (i & 3)] : 0.f;
+
+  // per-lane constants: layer-1 forward operands (row c <-> unit, k = q <-> dimension), exp(lam), energy parameters
+  float l1xa = 0.f, l1xb = 0.f, l1va = 0.f, l1vb = 0.f, esx = 0.f, eqx = 0.f, esv = 0.f, eqv = 0.f, emu = 0.f, epr = 0.f, Gf = 0.f;
+  {
+    const int ui = unit_row(c);
+    if (livedim) {
+      if (ui >= 0 && ui < H) {
+        l1xa = A.xnet.W1[q * H + ui]; l1xb = A.xnet.W2[q * H + ui];
+        l1va = A.vnet.W1[q * H + ui]; l1vb = A.vnet.W2[q * H + ui];
+      }
+      esx = expf(A.xnet.lam_s[q]); eqx = expf(A.xnet.lam_q[q]);
+      esv = expf(A.vnet.lam_s[q]); eqv = expf(A.vnet.lam_q[q]);
+      if (EK != L2HMC_ENERGY_ROUGHWELL) emu = A.mu[q];
+      if (EK == L2HMC_ENERGY_GAUSS_DIAG) epr = A.prec[q];
+      if (EK == L2HMC_ENERGY_GAUSS_DENSE) {         // A operand of y = G dx: row 4 j <- G[j][q] (symmetrised), else 0
+        const int j = c >> 2;
+        if ((c & 3) == 0 && j < d) Gf = 0.5f * (A.prec[j * d + q] + A.prec[q * d + j]);
+      }
+    }
+  }
+  __syncthreads();
+
+  const float* grpx = smem + L.grp;
+  const float* grpv = grpx + ng * 256;
+  auto frag = [&](const float* gb, int g) { return lds4(gb + (g * 64 + lane) * 4); };
+  auto chain4 = [&](f4 Wf, f4 in, f4 acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = MFMA16(Wf[r], in[r], acc);
+    return acc;
+  };
+  auto chainK = [&](f4 Wf, f4 in, f4 acc) {
+#pragma unroll
+    for (int r = 0; r < KH; ++r) acc = MFMA16(Wf[r], in[r], acc);
+    return acc;
+  };
+  // in: lane (c, q) holds val[row 4 q + r][chain c];  out: lane (i, kq) holds val[row i][chain 4 kq + r]
+  float* scr = smem + L.tr;
+  float* csr = scr + 7 * 320;                    // (cos, sin) of the current step, per chain
+  auto transp_put = [&](int slot, f4 val) { *reinterpret_cast<f4*>(scr + slot * 320 + c * 20 + 4 * q) = val; };
+  auto transp_get = [&](int slot) {
+    f4 ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = scr[slot * 320 + (4 * q + r) * 20 + c];
+    return ov;
+  };
+  auto relu4i = [&](f4 a) {
+    f4 o_ = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) o_[r] = relu_f(a[r]);
+    return o_;
+  };
+
+  // ---- energies (this lane's dimension) -----------------------------------------------------------------------------------
+  auto gradU = [&](float z) {
+    if (EK == L2HMC_ENERGY_GAUSS_DIAG) return epr * (z - emu);
+    if (EK == L2HMC_ENERGY_GAUSS_DENSE) { const f4 y = MFMA16(Gf, z - emu, Z); return y.x * live1; }
+    return live1 * (z - (A.eta / rw_den) * sinf(z / rw_den));
+  };
+  auto hessvec = [&](float z, float vec) {
+    if (EK == L2HMC_ENERGY_GAUSS_DIAG) return epr * vec;
+    if (EK == L2HMC_ENERGY_GAUSS_DENSE) { const f4 y = MFMA16(Gf, vec, Z); return y.x * live1; }
+    return live1 * (1.f - (A.eta / (rw_den * rw_den)) * cosf(z / rw_den)) * vec;
+  };
+  auto energy_part = [&](float z, float g) {        // this lane's share of U(z)
+    if (EK == L2HMC_ENERGY_ROUGHWELL) return live1 * (0.5f * z * z + A.eta * cosf(z / rw_den));
+    return 0.5f * (z - emu) * g;
+  };
+
+  // ---- one net evaluation (forward): caches h1, h2, ts = tanh(zs), T, tq = tanh(zq) ------------------------------------------
+  struct Cache { f4 h1, h2; float ts, Tt, tq; };
+  auto net_fwd = [&](int net, float a, float b, f4 tbrow, Cache& C) {
+    const float* gb = net ? grpv : grpx;
+    const f4 p = MFMA16(net ? l1vb : l1xb, b, MFMA16(net ? l1va : l1xa, a, Z));
+    C.h1 = relu4i(p + tbrow);
+    C.h2 = relu4i(chainK(frag(gb, 0), C.h1, Z));
+    const f4 z = chainK(frag(gb, 2), C.h2, Z);
+    C.ts = ftanh(z.x);
+    C.Tt = z.y;
+    C.tq = ftanh(z.z);
+  };
+
+  // gradient tiles of one net (registers, whole reverse sweep)
+  struct Acc { f4 hd, w1, w2, w4, tau; float lamS, lamQ; };
+  Acc GX, GV;
+  GX.hd = GX.w1 = GX.w2 = GX.w4 = GX.tau = Z;
+  GX.lamS = GX.lamQ = 0.f;
+  GV = GX;
+
+  // ---- back-propagation through one net: consumes dzs, dzt, dzq (+ dA, dB for the log-scales), returns da, db -------------
+  auto net_bwd = [&](int net, const Cache& C, float a, float b, float dzs, float dzt, float dzq, float dA, float dB, Acc& G,
+                     float& da, float& db) {
+    const float* gb = net ? grpv : grpx;
+    G.lamS += dA;
+    G.lamQ += dB;
+    const f4 dz = f4{dzs, dzt, dzq, 0.f};
+    const f4 hT = frag(gb, 3);
+    f4 dh2 = MFMA16(hT[0], dz[0], Z);
+    dh2 = MFMA16(hT[1], dz[1], dh2);
+    dh2 = MFMA16(hT[2], dz[2], dh2);
+    f4 da2 = Z, da1 = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) da2[r] = C.h2[r] > 0.f ? dh2[r] : 0.f;
+    const f4 dh1 = chainK(frag(gb, 1), da2, Z);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) da1[r] = C.h1[r] > 0.f ? dh1[r] : 0.f;
+    da = chainK(frag(gb, 4), da1, Z).x;
+    db = chainK(frag(gb, 5), da1, Z).x;
+    // weight gradients: contractions over the 16 chains; the seven operands are transposed through seven scratch slots --
+    // all writes, then all reads: one LDS round trip per back-propagation instead of seven
+    transp_put(0, C.h2); transp_put(1, dz); transp_put(2, da1); transp_put(3, f4{a, 0.f, 0.f, 0.f});
+    transp_put(4, f4{b, 0.f, 0.f, 0.f}); transp_put(5, C.h1); transp_put(6, da2);
+    const f4 th2 = transp_get(0), tdz = transp_get(1), tda1 = transp_get(2), ta = transp_get(3), tb_ = transp_get(4),
+             th1 = transp_get(5), tda2 = transp_get(6);
+    f4 tt;                                       // rows: 0 -> 1, 1 -> cos, 2 -> sin of chain 4 q + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tt[r] = c == 0 ? 1.f : (c == 1 ? csr[2 * (4 * q + r)] : (c == 2 ? csr[2 * (4 * q + r) + 1] : 0.f));
+    G.hd = chain4(tdz, th2, G.hd);
+    G.w1 = chain4(ta, tda1, G.w1);
+    G.w2 = chain4(tb_, tda1, G.w2);
+    G.w4 = chain4(th1, tda2, G.w4);
+    G.tau = chain4(tt, tda1, G.tau);
+  };
+
+  // ---- per-step schedule ---------------------------------------------------------------------------------------------------
+  int s_me = 0;
+  float k1 = 0.f;
+  f4 tbx = Z, tbv = Z;
+  auto set_step = [&](int it) {
+    s_me = isf ? it : (T - 1 - it);
+    const float m = smem[L.msk + s_me * 4 + q];
+    k1 = isf ? m : (1.f - m);
+    tbx = lds4(smem + L.tb + s_me * 16 + 4 * q);
+    tbv = lds4(smem + L.tb + (T + s_me) * 16 + 4 * q);
+    if (q == 0) { csr[2 * c] = smem[L.trg + 2 * s_me]; csr[2 * c + 1] = smem[L.trg + 2 * s_me + 1]; }
+  };
+
+  // ---- half updates (forward) ------------------------------------------------------------------------------------------------
+  float ldv = 0.f;
+  auto v_half_f = [&](const Cache& C, float vin, float g) {
+    const float S = esv * C.ts, Q = eqv * C.tq;
+    const float ES = fexp(S * (sg * heps)), EQ = fexp(Q * eps);
+    const float cc = (C.Tt - EQ * g) * heps;
+    ldv += S * (sg * heps);
+    return isf ? vin * ES + cc : (vin - cc) * ES;
+  };
+  auto x_half_f = [&](const Cache& C, float zin, float kp, float vh) {
+    const float up = 1.f - kp;
+    const float S = esx * C.ts, Q = eqx * C.tq;
+    const float ES = fexp(S * (sg * eps)), EQ = fexp(Q * eps);
+    const float tr = (EQ * vh + C.Tt) * eps;
+    const float nw = isf ? zin * ES + tr : ES * (zin - tr);
+    ldv += up * S * (sg * eps);
+    return kp * zin + up * nw;
+  };
+
+  // ---- load the start state ---------------------------------------------------------------------------------------------------
+  const float xs = (alive && livedim) ? A.x[n * d + q] : 0.f;
+  float x = xs, v = (alive && livedim) ? A.v[n * d + q] : 0.f;
+  float g = gradU(x);
+  float red[6];
+  red[0] = energy_part(x, g);                    // U0
+  red[1] = 0.5f * v * v;                         // K0
+  float* ck = A.ws + ((long long)blockIdx.x * T * TS_CK) * 64 + lane;
+  auto ckp = [&](int it, int slot) -> float& { return ck[((long long)it * TS_CK + slot) * 64]; };
+
+  // ---- forward trajectory with checkpoints ------------------------------------------------------------------------------------------
+  Cache C;
+  for (int it = 0; it < T; ++it) {
+    set_step(it);
+    net_fwd(1, x, g, tbv, C);
+    const float vh = v_half_f(C, v, g);
+    net_fwd(0, vh, k1 * x, tbx, C);
+    const float y = x_half_f(C, x, k1, vh);
+    net_fwd(0, vh, (1.f - k1) * y, tbx, C);
+    const float xo = x_half_f(C, y, 1.f - k1, vh);
+    ckp(it, 0) = x; ckp(it, 1) = v; ckp(it, 2) = vh; ckp(it, 3) = y; ckp(it, 4) = xo;
+    g = gradU(xo);
+    net_fwd(1, xo, g, tbv, C);
+    v = v_half_f(C, vh, g);
+    x = xo;
+  }
+
+  // ---- accept probability, loss term, adjoint seeds ----------------------------------------------------------------------------------
+  red[2] = energy_part(x, g);                    // U1
+  red[3] = 0.5f * v * v;                         // K1
+  red[4] = (xs - x) * (xs - x);                  // |x0 - Lx|^2
+  red[5] = ldv * live1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    red[i] += __shfl_xor(red[i], 16);
+    red[i] += __shfl_xor(red[i], 32);
+  }
+  const float val = (red[0] + red[1]) - (red[2] + red[3]) + red[5];
+  const float p = accept_prob(val);
+  const float sq = red[4];
+  const float v1 = sq * p + 1e-4f;
+  if (alive && lane < 16) { A.p[n] = p; A.v1[n] = v1; }
+  const float dv1 = alive ? (A.scale * (-1.f / (v1 * v1)) - 1.f / A.scale) * A.inv_n : 0.f;
+  const bool pfin = (val == val) && p > 0.f;      // finite branch of dynamics.py:309 actually taken
+  const float lam = (pfin && val < 0.f) ? dv1 * sq * p : 0.f;
+  const float dv1p = dv1 * p * 2.f;
+  const bool okc = sq < 3.0e38f;
+  if (alive && livedim) A.Lx[n * d + q] = x;
+  float lx = okc ? (x - xs) * dv1p - g * lam : 0.f;
+  float lv = okc ? v * (-lam) : 0.f;
+  float deps = 0.f;
+
+  // ---- adjoints of the half updates (the formulas of train_fast.hpp, scalar) ---------------------------------------------------------
+  auto v_half_b = [&](const Cache& C, float dout, float vin, float gq, float& dvin, float& dg, float& dzs, float& dzt,
+                      float& dzq, float& dA, float& dB) {
+    const float ts = C.ts, tq = C.tq, Tt = C.Tt;
+    const float S = esv * ts, Q = eqv * tq;
+    const float ES = fexp(sg * heps * S), EQ = fexp(eps * Q);
+    const float cc = heps * (Tt - EQ * gq);
+    const float dES = isf ? dout * vin : dout * (vin - cc);
+    const float dcc = isf ? dout : -dout * ES;
+    const float ds = dES * ES + lam * live1;
+    const float dSr = ds * sg * heps;
+    const float dq = -dcc * heps * gq * EQ;
+    const float dQr = dq * eps;
+    dvin = dout * ES;
+    dg = -dcc * heps * EQ;
+    dA = dSr * S;
+    dB = dQr * Q;
+    dzs = dSr * esv * (1.f - ts * ts);
+    dzt = dcc * heps;
+    dzq = dQr * eqv * (1.f - tq * tq);
+    deps += ds * sg * 0.5f * S + dcc * 0.5f * (Tt - EQ * gq) + dq * Q;
+  };
+  auto x_half_b = [&](const Cache& C, float dout, float zin, float kp, float vhq, float& dzin, float& dvh, float& dzs,
+                      float& dzt, float& dzq, float& dA, float& dB) {
+    const float up = 1.f - kp;
+    const float ts = C.ts, tq = C.tq, Tt = C.Tt;
+    const float S = esx * ts, Q = eqx * tq;
+    const float ES = fexp(sg * eps * S), EQ = fexp(eps * Q);
+    const float tr = eps * (EQ * vhq + Tt);
+    const float dnw = up * dout;
+    const float dES = isf ? dnw * zin : dnw * (zin - tr);
+    const float dtr = isf ? dnw : -dnw * ES;
+    const float dsx = dES * ES + up * lam * live1;
+    const float dSr = dsx * sg * eps;
+    const float dq = dtr * eps * vhq * EQ;
+    const float dQr = dq * eps;
+    dzin = kp * dout + dnw * ES;
+    dvh += dtr * eps * EQ;
+    dA = dSr * S;
+    dB = dQr * Q;
+    dzs = dSr * esx * (1.f - ts * ts);
+    dzt = dtr * eps;
+    dzq = dQr * eqx * (1.f - tq * tq);
+    deps += dsx * sg * S + dtr * (EQ * vhq + Tt) + dq * Q;
+  };
+
+  // ---- reverse sweep ---------------------------------------------------------------------------------------------------------------
+  float nx = ckp(T - 1, 0), nv = ckp(T - 1, 1), nvh = ckp(T - 1, 2), ny = ckp(T - 1, 3), nxo = ckp(T - 1, 4);
+  for (int it = T - 1; it >= 0; --it) {
+    set_step(it);
+    const float cx = nx, cv = nv, cvh = nvh, cy = ny, cxo = nxo;
+    if (it > 0) {                                // the next iteration's checkpoints: an L2 round trip taken a whole step early
+      nx = ckp(it - 1, 0); nv = ckp(it - 1, 1); nvh = ckp(it - 1, 2); ny = ckp(it - 1, 3); nxo = ckp(it - 1, 4);
+    }
+    float dvh = 0.f, dg, dzs, dzt, dzq, dA, dB, da, db, dz;
+    // (1) v' = v_half(vh; g(x'), V(x', g(x')))
+    float gq = gradU(cxo);
+    net_fwd(1, cxo, gq, tbv, C);
+    v_half_b(C, lv, cvh, gq, dvh, dg, dzs, dzt, dzq, dA, dB);
+    net_bwd(1, C, cxo, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
+    lx = lx + da + hessvec(cxo, dg + db);                         // d x'
+    // (2) x' = x_half(y, k2; vh, X(vh, k2 y)),  k2 = 1 - k1
+    const float k2 = 1.f - k1;
+    net_fwd(0, cvh, k2 * cy, tbx, C);
+    x_half_b(C, lx, cy, k2, cvh, dz, dvh, dzs, dzt, dzq, dA, dB); // dz = d y (direct part)
+    net_bwd(0, C, cvh, k2 * cy, dzs, dzt, dzq, dA, dB, GX, da, db);
+    dvh += da;
+    dz += k2 * db;
+    // (3) y = x_half(x, k1; vh, X(vh, k1 x))
+    net_fwd(0, cvh, k1 * cx, tbx, C);
+    x_half_b(C, dz, cx, k1, cvh, lx, dvh, dzs, dzt, dzq, dA, dB); // lx = d x (direct part)
+    net_bwd(0, C, cvh, k1 * cx, dzs, dzt, dzq, dA, dB, GX, da, db);
+    dvh += da;
+    lx += k1 * db;
+    // (4) vh = v_half(v; g(x), V(x, g(x)))
+    gq = gradU(cx);
+    net_fwd(1, cx, gq, tbv, C);
+    v_half_b(C, dvh, cv, gq, lv, dg, dzs, dzt, dzq, dA, dB);
+    net_bwd(1, C, cx, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
+    lx = lx + da + hessvec(cx, dg + db);
+  }
+
+  // ---- this workgroup's flat gradient [xnet (P) | vnet (P) | eps] -> its slot of the workspace ----------------------------------------
+  float* slot = A.ws + (long long)gridDim.x * T * TF_CK * 256 + (long long)blockIdx.x * (2 * P + 1);
+  {
+    const float s = wave_sum(deps * live1);
+    if (lane == 0) slot[2 * P] = s;
+  }
+  const int ui = unit_row(c);                    // unit on the COLUMN (lane & 15) of the weight-gradient tiles
+  auto flush = [&](const Acc& G, float* Gn) {
+    const int hs = H * d + d;
+    if (livedim && ui >= 0 && ui <= H) {         // tile rows 4 q + r: (dimension q, head r) / row 4 q: dimension q
+      if (ui < H) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Gn[o.Ws + r * hs + ui * d + q] = G.hd[r];
+        Gn[o.W1 + q * H + ui] = G.w1[0];
+        Gn[o.W1 + (d * H + H) + q * H + ui] = G.w2[0];
+      } else {                                   // the constant-1 unit: head biases
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Gn[o.bs + r * hs + q] = G.hd[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                // dW4[u(row 4 q + r)][u'(c)]; row u = H: b4
+      const int u = r < KH ? q * KH + r : -1;
+      if (u >= 0 && u <= H && ui >= 0 && ui < H) {
+        if (u < H) Gn[o.W4 + u * H + ui] = G.w4[r];
+        else Gn[o.b4 + ui] = G.w4[r];
+      }
+    }
+    if (q == 0 && ui >= 0 && ui < H) {           // rows 0, 1, 2 of the (1, cos, sin) product
+      Gn[o.b1 + ui] = G.tau[0]; Gn[o.b2 + ui] = G.tau[0]; Gn[o.b3 + ui] = G.tau[0];
+      Gn[o.W3 + ui] = G.tau[1];
+      Gn[o.W3 + H + ui] = G.tau[2];
+    }
+    // log-scales: sums over the 16 chains of the tile
+    float ls = G.lamS, lq = G.lamQ;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { ls += __shfl_xor(ls, off); lq += __shfl_xor(lq, off); }
+    if (c == 0 && livedim) { Gn[o.ls + q] = ls; Gn[o.lq + q] = lq; }
+  };
+  // (slots are not pre-zeroed: write every entry of [xnet | vnet] -- the tiles above cover all of them for d <= 4)
+  flush(GX, slot);
+  flush(GV, slot + P);
+}
