@@ -175,8 +175,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
   const int lr = tid / QPR, lk = (tid % QPR) * 4;
   constexpr int NA = (TM + RPP - 1) / RPP, NB = (TN + RPP - 1) / RPP;
   f4 ra[NA], rb[NB];
+  // interior tiles (every row of both operand tiles exists, K a multiple of the k-tile, 16-byte rows): plain dwordx4 loads
+  // without the per-load bounds branches -- wave-uniform, decided once (bf16x3 kernel: -10 %; the f32 kernel is 3 % slower with it)
+  const bool interior = BF3 != 0 && KV == 4 && TM % RPP == 0 && TN % RPP == 0 && m0 + TM <= g.M && n0 + TN <= g.N && g.K % GK == 0;
   auto gload = [&](int k0) {
     const int k = k0 + lk;
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f4*>(g.A + (m0 + lr + RPP * i) * g.lda + k);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f4*>(g.B + (long long)(n0 + lr + RPP * i) * g.ldb + k);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const long long m = m0 + lr + RPP * i;
