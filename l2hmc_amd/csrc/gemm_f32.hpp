@@ -150,6 +150,105 @@ __device__ __forceinline__ f4 mfma_bf16(u4v a, u4v b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
 }
 
+// The shared epilogue: lane (c, q) of wave w holds acc[i][j] = C[m = m0 + wm + 16 j + c][n = n0 + wn + 16 i + 4 q + (0..3)].
+template <int EPI, int WMB, int WNB, int WAVES_N>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f4 (&acc)[WNB][WMB], long long m0, int n0, int wm, int wn,
+                                              int w, int c, int q) {
+  // ---- epilogue: lane holds C[m = m0 + wm + 16 j + c][n = n0 + wn + 16 i + 4 q + (0..3)] -------------------
+  float rs[WMB];                                                    // EPI_BCE: per m-block row partial
+#pragma unroll
+  for (int j = 0; j < WMB; ++j) rs[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < WMB; ++j) {
+    const long long m = m0 + wm + 16 * j + c;
+    const bool mok = m < g.M;
+    int trow = 0;
+    if (EPI == EPI_NET1 && mok) {
+      const bool fwd = g.dir != nullptr ? g.dir[m] != 0 : (g.dir_all != 0);
+      trow = fwd ? g.it : (g.T - 1 - g.it);
+    }
+#pragma unroll
+    for (int i = 0; i < WNB; ++i) {
+      const int n = n0 + wn + 16 * i + 4 * q;
+      if (!mok || n >= g.N) continue;
+      const bool full = n + 3 < g.N;
+      f4 v = acc[i][j];
+      f4 b = splat(0.f), e = splat(0.f);
+      auto ld4 = [&](const float* p) {
+        if (full && ((reinterpret_cast<size_t>(p) & 15) == 0)) return *reinterpret_cast<const f4*>(p);
+        f4 r = splat(0.f);
+        r.x = p[0];
+        if (n + 1 < g.N) r.y = p[1];
+        if (n + 2 < g.N) r.z = p[2];
+        if (n + 3 < g.N) r.w = p[3];
+        return r;
+      };
+      auto st4 = [&](float* p, f4 r) {
+        if (full && ((reinterpret_cast<size_t>(p) & 15) == 0)) { *reinterpret_cast<f4*>(p) = r; return; }
+        p[0] = r.x;
+        if (n + 1 < g.N) p[1] = r.y;
+        if (n + 2 < g.N) p[2] = r.z;
+        if (n + 3 < g.N) p[3] = r.w;
+      };
+      if (g.bias != nullptr) b = ld4(g.bias + n);
+      if (g.E != nullptr) e = ld4(g.E + m * g.lde + n);
+      f4 out, out2 = splat(0.f);
+      bool has2 = EPI == EPI_BIAS_SOFTPLUS;
+      if (EPI == EPI_BIAS) {
+        out = v + b;
+      } else if (EPI == EPI_BIAS_SOFTPLUS) {
+        const f4 p = v + b;
+        out = softplus4(p, out2);
+      } else if (EPI == EPI_BIAS_RELU) {
+        const f4 p = v + b;
+        out = f4{fmaxf(p.x, 0.f), fmaxf(p.y, 0.f), fmaxf(p.z, 0.f), fmaxf(p.w, 0.f)};
+      } else if (EPI == EPI_MUL) {
+        out = v * e;
+        if (g.accum) out = out + ld4(g.C + m * g.ldc + n);
+        out2 = v;
+        has2 = true;
+      } else if (EPI == EPI_MASK) {
+        out = f4{e.x > 0.f ? v.x : 0.f, e.y > 0.f ? v.y : 0.f, e.z > 0.f ? v.z : 0.f, e.w > 0.f ? v.w : 0.f};
+      } else if (EPI == EPI_TAN) {
+        out = e * v;
+        out2 = e * (1.f - e) * v * ld4(g.E2 + m * g.lde2 + n);
+        has2 = true;
+      } else if (EPI == EPI_ADD) {
+        out = v + e;
+      } else if (EPI == EPI_BCE) {
+        const f4 l = v + b;
+        f4 sg;
+        const f4 sp = softplus4(l, sg);
+        // bce = max(l, 0) - l t + log1p(e^{-|l|}) = softplus(l) - l t
+        const f4 bce = sp - l * e;
+        float s = bce.x;
+        if (n + 1 < g.N) s += bce.y;
+        if (n + 2 < g.N) s += bce.z;
+        if (n + 3 < g.N) s += bce.w;
+        rs[j] += s;
+        out = g.beta * (sg - e);
+      } else {  // EPI_NET1
+        const f4 t = ld4(g.tb + (long long)trow * g.N + n);
+        const f4 p = v + t + e;
+        out = f4{fmaxf(p.x, 0.f), fmaxf(p.y, 0.f), fmaxf(p.z, 0.f), fmaxf(p.w, 0.f)};
+      }
+      st4(g.C + m * g.ldc + n, out);
+      if (has2 && g.C2 != nullptr) st4(g.C2 + m * g.ldc2 + n, out2);
+    }
+  }
+  if (EPI == EPI_BCE) {
+    // per chain m: sum over this wave's 64 columns = over the 4 lanes (q) that share column c, fixed order
+#pragma unroll
+    for (int j = 0; j < WMB; ++j) {
+      float s = rs[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const long long m = m0 + wm + 16 * j + c;
+      if (q == 0 && m < g.M) g.rowsum[m * (WAVES_N * g.n_tiles) + WAVES_N * blockIdx.x + (w % WAVES_N)] = g.beta * s;
+    }
+  }
+}
+
 // WMB x WNB: 16 x 16 MFMA tiles per wave along m and n; the 2 x 2 waves of a workgroup cover a
 // (32 WMB) x (32 WNB) tile of C.  4 x 4 (128 x 128) for the big decoder products, 2 x 2 (64 x 64) for the
 // H = 200 net layers (fills the chip at M = 8192), 1 x 2 (32 x 64) for the N = d = 50 latent gradient.
@@ -293,101 +392,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds C[m = m0 + wm + 16 j + c][n = n0 + wn + 16 i + 4 q + (0..3)] -------------------
-  float rs[WMB];                                                    // EPI_BCE: per m-block row partial
-#pragma unroll
-  for (int j = 0; j < WMB; ++j) rs[j] = 0.f;
-#pragma unroll
-  for (int j = 0; j < WMB; ++j) {
-    const long long m = m0 + wm + 16 * j + c;
-    const bool mok = m < g.M;
-    int trow = 0;
-    if (EPI == EPI_NET1 && mok) {
-      const bool fwd = g.dir != nullptr ? g.dir[m] != 0 : (g.dir_all != 0);
-      trow = fwd ? g.it : (g.T - 1 - g.it);
-    }
-#pragma unroll
-    for (int i = 0; i < WNB; ++i) {
-      const int n = n0 + wn + 16 * i + 4 * q;
-      if (!mok || n >= g.N) continue;
-      const bool full = n + 3 < g.N;
-      f4 v = acc[i][j];
-      f4 b = splat(0.f), e = splat(0.f);
-      auto ld4 = [&](const float* p) {
-        if (full && ((reinterpret_cast<size_t>(p) & 15) == 0)) return *reinterpret_cast<const f4*>(p);
-        f4 r = splat(0.f);
-        r.x = p[0];
-        if (n + 1 < g.N) r.y = p[1];
-        if (n + 2 < g.N) r.z = p[2];
-        if (n + 3 < g.N) r.w = p[3];
-        return r;
-      };
-      auto st4 = [&](float* p, f4 r) {
-        if (full && ((reinterpret_cast<size_t>(p) & 15) == 0)) { *reinterpret_cast<f4*>(p) = r; return; }
-        p[0] = r.x;
-        if (n + 1 < g.N) p[1] = r.y;
-        if (n + 2 < g.N) p[2] = r.z;
-        if (n + 3 < g.N) p[3] = r.w;
-      };
-      if (g.bias != nullptr) b = ld4(g.bias + n);
-      if (g.E != nullptr) e = ld4(g.E + m * g.lde + n);
-      f4 out, out2 = splat(0.f);
-      bool has2 = EPI == EPI_BIAS_SOFTPLUS;
-      if (EPI == EPI_BIAS) {
-        out = v + b;
-      } else if (EPI == EPI_BIAS_SOFTPLUS) {
-        const f4 p = v + b;
-        out = softplus4(p, out2);
-      } else if (EPI == EPI_BIAS_RELU) {
-        const f4 p = v + b;
-        out = f4{fmaxf(p.x, 0.f), fmaxf(p.y, 0.f), fmaxf(p.z, 0.f), fmaxf(p.w, 0.f)};
-      } else if (EPI == EPI_MUL) {
-        out = v * e;
-        if (g.accum) out = out + ld4(g.C + m * g.ldc + n);
-        out2 = v;
-        has2 = true;
-      } else if (EPI == EPI_MASK) {
-        out = f4{e.x > 0.f ? v.x : 0.f, e.y > 0.f ? v.y : 0.f, e.z > 0.f ? v.z : 0.f, e.w > 0.f ? v.w : 0.f};
-      } else if (EPI == EPI_TAN) {
-        out = e * v;
-        out2 = e * (1.f - e) * v * ld4(g.E2 + m * g.lde2 + n);
-        has2 = true;
-      } else if (EPI == EPI_ADD) {
-        out = v + e;
-      } else if (EPI == EPI_BCE) {
-        const f4 l = v + b;
-        f4 sg;
-        const f4 sp = softplus4(l, sg);
-        // bce = max(l, 0) - l t + log1p(e^{-|l|}) = softplus(l) - l t
-        const f4 bce = sp - l * e;
-        float s = bce.x;
-        if (n + 1 < g.N) s += bce.y;
-        if (n + 2 < g.N) s += bce.z;
-        if (n + 3 < g.N) s += bce.w;
-        rs[j] += s;
-        out = g.beta * (sg - e);
-      } else {  // EPI_NET1
-        const f4 t = ld4(g.tb + (long long)trow * g.N + n);
-        const f4 p = v + t + e;
-        out = f4{fmaxf(p.x, 0.f), fmaxf(p.y, 0.f), fmaxf(p.z, 0.f), fmaxf(p.w, 0.f)};
-      }
-      st4(g.C + m * g.ldc + n, out);
-      if (has2 && g.C2 != nullptr) st4(g.C2 + m * g.ldc2 + n, out2);
-    }
-  }
-  if (EPI == EPI_BCE) {
-    // per chain m: sum over this wave's 64 columns = over the 4 lanes (q) that share column c, fixed order
-#pragma unroll
-    for (int j = 0; j < WMB; ++j) {
-      float s = rs[j];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      const long long m = m0 + wm + 16 * j + c;
-      if (q == 0 && m < g.M) g.rowsum[m * (WAVES_N * g.n_tiles) + WAVES_N * blockIdx.x + (w % WAVES_N)] = g.beta * s;
-    }
-  }
+  gemm_epilogue<EPI, WMB, WNB, WAVES_N>(g, acc, m0, n0, wm, wn, w, c, q);
 }
 
+// (A warp-specialised form -- four producer waves split every element once per workgroup into three bf16 LDS planes, four
+//  consumer waves issue nothing but the MFMAs; 120 KB of double-buffered planes, one 512-thread workgroup per CU -- was built
+//  and measured in round 3: identical results, 142.7 us against 123.4 us for the split in the consumer on 8192 x 1024 x 1024
+//  (profiles/r03_gemm_bf16x3.txt): 144 KB of plane traffic per k-tile through the 128 B/clk LDS pipe is as long as the k-tile's
+//  matrix-pipe time.  Not kept.)
 // ------------------------------------------------------------------------------------------------------------
 // One S/T/Q net evaluation in ONE launch (the H = 200 nets of mnist_vae.py:142-167 and any H > 15):
 //   out3 = relu(relu([a | b] [W1; W2] + time/bias row + aux_h) W4 + b4) [Ws | Wt | Wq]
