@@ -166,6 +166,8 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       zq = MFMA16(Wq[r], h[r], zq);
       zt = MFMA16(Wt[r], h[r], zt);
     }
+    // (all nine head MFMAs before the first transcendental, as in traj_fast.hpp: +1 % at 65 536 chains)
+    __builtin_amdgcn_sched_barrier(0);
     const f4 rS = rcp4(-(ex2_4(zs) * 0.5f + 0.5f));
     aS = rS * cS + cS;
     const f4 rQ = rcp4(-(ex2_4(zq) * 0.5f + 0.5f));
