@@ -327,7 +327,7 @@ typedef struct L2hmcTrainArgs {
   float* v1;                /* (N) per-chain loss argument                           */
   float* grad;              /* flat gradient, accumulated                            */
   float* workspace;         /* l2hmc_train_workspace_floats(N, d, H, T) floats       */
-  int32_t variant;          /* 0 = auto: d <= 4 (Gaussians, Rough Well) the one-dimension-per-lane kernel; else the
+  int32_t variant;          /* 0 = auto: d <= 4 (Gaussians, GMM, Rough Well) the one-dimension-per-lane kernel; else the
                              *   register-resident kernel (elementwise targets d <= 64, dense Gaussians d <= 16,
                              *   H <= 15); else the general LDS-matrix tile kernel.  1 = as 0 without the d <= 4
                              *   form; 100 = always the general kernel                                      */

@@ -853,7 +853,8 @@ __device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.f); }
 
 // d <= 4 targets (the notebook's own SCG-2D training among them): one dimension per lane (train_small.hpp)
 inline bool train_small_ok(int ek, int d, int H) {
-  return d <= 4 && H <= 15 && (ek == L2HMC_ENERGY_GAUSS_DIAG || ek == L2HMC_ENERGY_GAUSS_DENSE || ek == L2HMC_ENERGY_ROUGHWELL);
+  return d <= 4 && H <= 15 && (ek == L2HMC_ENERGY_GAUSS_DIAG || ek == L2HMC_ENERGY_GAUSS_DENSE || ek == L2HMC_ENERGY_ROUGHWELL ||
+                               ek == L2HMC_ENERGY_GMM);
 }
 template <int EK>
 int launch_train_small(const TArgs& k, int KH, unsigned blocks, long long lds, hipStream_t s) {
@@ -958,6 +959,7 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
     const int KH = khid_of(a->H);
     if (ek == L2HMC_ENERGY_GAUSS_DIAG) launch_train_small<L2HMC_ENERGY_GAUSS_DIAG>(k, KH, blocks, lds_small, s);
     else if (ek == L2HMC_ENERGY_GAUSS_DENSE) launch_train_small<L2HMC_ENERGY_GAUSS_DENSE>(k, KH, blocks, lds_small, s);
+    else if (ek == L2HMC_ENERGY_GMM) launch_train_small<L2HMC_ENERGY_GMM>(k, KH, blocks, lds_small, s);
     else launch_train_small<L2HMC_ENERGY_ROUGHWELL>(k, KH, blocks, lds_small, s);
     part = a->workspace + (long long)blocks * a->T * TF_CK * 256;
   } else if (fnw && lds_fast <= 160 * 1024) {    // register-resident kernel (train_fast.hpp)

@@ -16,7 +16,7 @@
 // 48 MFMAs per net evaluation + back-propagation instead of 69 + 20 recomputed ... per leapfrog step and wave: 192 instead
 // of 356 MFMAs, and every elementwise update is scalar instead of float4.  No barriers after staging (one wave), no atomics:
 // the workgroup's flat gradient goes to its workspace slot, train_reduce_kernel adds the slots in block order.
-// Targets: diagonal and dense Gaussians, Rough Well (the funnel and the mixtures stay on train_fast / train_kernel).
+// Targets: diagonal and dense Gaussians, Rough Well, mixtures of Gaussians (<= 8 components); the funnel stays on train_fast.
 #pragma once
 
 struct TSLayout { int grp, tb, msk, trg, tr, total, ng; };
@@ -118,11 +118,28 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
       }
       esx = expf(A.xnet.lam_s[q]); eqx = expf(A.xnet.lam_q[q]);
       esv = expf(A.vnet.lam_s[q]); eqv = expf(A.vnet.lam_q[q]);
-      if (EK != L2HMC_ENERGY_ROUGHWELL) emu = A.mu[q];
+      if (EK != L2HMC_ENERGY_ROUGHWELL && EK != L2HMC_ENERGY_GMM) emu = A.mu[q];
       if (EK == L2HMC_ENERGY_GAUSS_DIAG) epr = A.prec[q];
       if (EK == L2HMC_ENERGY_GAUSS_DENSE) {         // A operand of y = G dx: row 4 j <- G[j][q] (symmetrised), else 0
         const int j = c >> 2;
         if ((c & 3) == 0 && j < d) Gf = 0.5f * (A.prec[j * d + q] + A.prec[q * d + j]);
+      }
+    }
+  }
+  // mixture of Gaussians (distributions.py:104-134): per component the mean of this lane's dimension, the A operand of
+  // y_k = G_k (z - mu_k) (as Gf above) and the log-weight constant; KC = 8 components at most, all in registers
+  float gmu[KC], gGf[KC], glc[KC];
+  if (EK == L2HMC_ENERGY_GMM) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      gmu[k] = 0.f; gGf[k] = 0.f; glc[k] = 0.f;
+      if (k < A.ncomp) {
+        glc[k] = A.logc[k];
+        if (livedim) {
+          gmu[k] = A.mu[k * d + q];
+          const int j = c >> 2;
+          if ((c & 3) == 0 && j < d) gGf[k] = 0.5f * (A.prec[(k * d + j) * d + q] + A.prec[(k * d + q) * d + j]);
+        }
       }
     }
   }
@@ -159,18 +176,64 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
   };
 
   // ---- energies (this lane's dimension) -----------------------------------------------------------------------------------
+  auto qsum = [&](float a) {                        // sum over the chain's four dimension lanes
+    a += __shfl_xor(a, 16);
+    a += __shfl_xor(a, 32);
+    return a;
+  };
+  // GMM: responsibilities r_k, y_k = G_k (z - mu_k) (this lane's dimension), g = sum_k r_k y_k and log sum_k e^{V_k} of the
+  // point gradU was last called on -- hessvec / energy_part of the same point reuse them (oracle/l2hmc_train_oracle.py GMMTarget)
+  struct GmmParts { float r[KC], y[KC], g, lse; };
+  GmmParts GP;
+  auto gmm_parts = [&](float z) {
+    float V[KC], mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      GP.y[k] = 0.f; GP.r[k] = 0.f; V[k] = -3.0e38f;
+      if (k < A.ncomp) {
+        const float dx = (z - gmu[k]) * live1;
+        const f4 y = MFMA16(gGf[k], dx, Z);
+        GP.y[k] = y.x * live1;
+        V[k] = glc[k] - 0.5f * qsum(dx * GP.y[k]);
+        mx = fmaxf(mx, V[k]);
+      }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < A.ncomp) { GP.r[k] = expf(V[k] - mx); se += GP.r[k]; }
+    const float inv = 1.f / se;
+    GP.g = 0.f;
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < A.ncomp) { GP.r[k] *= inv; GP.g += GP.r[k] * GP.y[k]; }
+    GP.lse = logf(se) + mx;
+  };
   auto gradU = [&](float z) {
     if (EK == L2HMC_ENERGY_GAUSS_DIAG) return epr * (z - emu);
     if (EK == L2HMC_ENERGY_GAUSS_DENSE) { const f4 y = MFMA16(Gf, z - emu, Z); return y.x * live1; }
+    if (EK == L2HMC_ENERGY_GMM) { gmm_parts(z); return GP.g; }
     return live1 * (z - (A.eta / rw_den) * sinf(z / rw_den));
   };
-  auto hessvec = [&](float z, float vec) {
+  auto hessvec = [&](float z, float vec) {           // GMM: at the point of the last gradU call
     if (EK == L2HMC_ENERGY_GAUSS_DIAG) return epr * vec;
     if (EK == L2HMC_ENERGY_GAUSS_DENSE) { const f4 y = MFMA16(Gf, vec, Z); return y.x * live1; }
+    if (EK == L2HMC_ENERGY_GMM) {
+      const float u = vec * live1;
+      float out = GP.g * qsum(GP.g * u);
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        if (k < A.ncomp) {
+          const f4 Gu = MFMA16(gGf[k], u, Z);
+          out += GP.r[k] * (Gu.x * live1 - GP.y[k] * qsum(GP.y[k] * u));
+        }
+      return out;
+    }
     return live1 * (1.f - (A.eta / (rw_den * rw_den)) * cosf(z / rw_den)) * vec;
   };
-  auto energy_part = [&](float z, float g) {        // this lane's share of U(z)
+  auto energy_part = [&](float z, float g) {        // this lane's share of U(z)  (GMM: of the last gradU point)
     if (EK == L2HMC_ENERGY_ROUGHWELL) return live1 * (0.5f * z * z + A.eta * cosf(z / rw_den));
+    if (EK == L2HMC_ENERGY_GMM) return q == 0 ? -GP.lse : 0.f;
     return 0.5f * (z - emu) * g;
   };
 

@@ -194,6 +194,18 @@ def synthetic_case(kind, d, H=10, T=10, N=64, seed=0, eps=0.1, head_std=0.3):
                   "energy.i_sigma": prec.astype(np.float32)})
     elif kind == "roughwell_easy":
         g.update({"energy.kind": "roughwell", "energy.eta": np.float32(0.1), "energy.easy": np.int32(1)})
+    elif kind.startswith("gmm"):                     # "gmm<K>": K components, slightly non-symmetric raw precisions
+        K = int(kind[3:] or 2)
+        mus, i_sigmas, consts = [], [], []
+        for k in range(K):
+            R = np.linalg.qr(rng.randn(d, d))[0]
+            prec = (R.T * np.exp(rng.uniform(-0.7, 0.7, size=d))) @ R
+            consts.append((1.0 + 0.3 * k) / K * np.sqrt(np.linalg.det(prec) / (2 * np.pi) ** d))
+            i_sigmas.append(prec + 0.05 * np.triu(rng.randn(d, d), 1))
+            mus.append(1.5 * rng.randn(d))
+        g.update({"energy.kind": "gmm", "energy.mus": np.asarray(mus, np.float32),
+                  "energy.i_sigmas": np.asarray(i_sigmas, np.float32), "energy.constants": np.asarray(consts, np.float32)})
+        scale = 1.5 * scale
     else:
         raise ValueError(kind)
     g["x"] = (rng.randn(N, d) * scale).astype(np.float32)

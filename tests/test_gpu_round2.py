@@ -218,7 +218,8 @@ def test_new_kernels_agree_with_the_general_kernel_and_the_oracle_on_odd_shapes(
 
 @pytest.mark.parametrize("kind,d,H,T,N", [("gauss_diag", 5, 7, 2, 21), ("gauss_dense", 3, 15, 3, 18),
                                           ("roughwell_easy", 17, 10, 2, 19), ("gauss_diag", 33, 15, 2, 40),
-                                          ("gauss_diag", 48, 12, 3, 16)])
+                                          ("gauss_diag", 48, 12, 3, 16), ("gmm2", 2, 10, 3, 37), ("gmm5", 4, 15, 2, 21),
+                                          ("gmm8", 3, 12, 2, 16), ("gmm3", 1, 9, 2, 20)])
 def test_training_kernels_agree_on_odd_shapes(kind, d, H, T, N):
     """register-resident training kernel (variant 0) vs the general tile kernel (variant 100): loss, proposals and
     every parameter gradient on shapes the goldens do not cover (ragged N, d % 4 != 0, H = 15)."""

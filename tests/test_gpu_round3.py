@@ -103,6 +103,53 @@ def test_training_gradient_at_scale_matches_the_float64_oracle(N, T, variant):
     assert torch.equal(flat1, tr.flat)
 
 
+@pytest.mark.parametrize("kind,d,N,T", [("gmm4", 2, 1024, 5), ("gmm2", 2, 200, 10), ("gmm8", 4, 333, 3)])
+def test_gmm_training_gradient_on_the_d4_kernel_matches_the_float64_oracle(kind, d, N, T):
+    """Mixture-of-Gaussians targets (config 3's energy, distributions.py:104-134) on the one-dimension-per-lane trainer
+    (`train_small_kernel`: responsibilities and Hessian-vector product through the chain's four lanes) against
+    oracle/l2hmc_train_oracle.py in float64, and against the general tile kernel."""
+    import torch
+    from oracle import l2hmc_train_oracle as TO
+    from l2hmc_amd.training import Trainer
+    from tests.helpers import synthetic_case
+    g = synthetic_case(kind, d, H=10, T=T, N=N, seed=41 + d, head_std=0.2)
+    rng = np.random.RandomState(5)
+    g["z"] = rng.randn(N, d).astype(np.float32)
+    for pre in ("x.", "z."):
+        g[pre + "dir"] = rng.randint(0, 2, N).astype(np.uint8)
+        g[pre + "v_fwd"] = rng.randn(N, d).astype(np.float32)
+        g[pre + "v_bwd"] = rng.randn(N, d).astype(np.float32)
+    ref_loss, ref = TO.training_loss_and_grad(g, np.float64)
+    draws = {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
+             "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
+             "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
+    flats = {}
+    for variant in (0, 100):
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        tr = Trainer(dyn)
+        tr.variant = variant
+        loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+        assert abs(float(loss) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (variant, float(loss), ref_loss)
+        assert rel_err(to_np(Lx), ref["Lx"]) < TRAJ_TOL and abs_err(to_np(px), ref["px"]) < P_TOL
+        scale = max(float(np.abs(ref[n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+        worst = 0.0
+        for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
+            for k in O.NET_KEYS:
+                r = np.asarray(ref["%s.%s" % (n, k)])
+                worst = max(worst, float(np.abs(to_np(w[k].grad).reshape(r.shape) - r).max()))
+        ga = float(dyn.alpha.grad)
+        print("%s d=%d N=%d variant %d: loss %.6e (ref %.6e)  max |dgrad| %.2e (scale %.2e)  alpha %.5e vs %.5e"
+              % (kind, d, N, variant, float(loss), ref_loss, worst, scale, ga, float(ref["alpha"])))
+        assert worst < 2e-4 * scale
+        assert abs(ga - float(ref["alpha"])) < 2e-4 * max(scale, abs(float(ref["alpha"])))
+        flats[variant] = tr.flat.clone()
+        tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+        assert torch.equal(flats[variant], tr.flat)             # fixed-order slot reduction: bitwise reproducible
+
+
 @pytest.mark.parametrize("kind,d,variant", [("gauss_diag", 50, 0), ("gauss_diag", 50, 4), ("gauss_dense", 24, 0),
                                             ("roughwell_easy", 40, 0), ("gauss_diag", 200, 0), ("gauss_diag", 2, 0)])
 def test_tempered_energy_on_every_kernel_family(kind, d, variant):
