@@ -64,6 +64,7 @@ def main():
     for case, n, steps in (("scg2d", 200, 200), ("mog2d", 200, 200), ("icg50", 200, 50), ("icg50", 4096, 20)):
         dyn, x, cov = make(case, n, dev)
         tr = Trainer(dyn)
+        tr.variant = int(os.environ.get("L2HMC_TRAIN_VARIANT", "0"))      # kernel-choice experiments (include/l2hmc.h)
         v = torch.randn_like(x)
         dr = torch.randint(0, 2, (n,), device=dev, dtype=torch.uint8)
         for _ in range(3):
