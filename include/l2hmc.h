@@ -335,6 +335,10 @@ typedef struct L2hmcTrainArgs {
 
 int64_t l2hmc_train_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T);
 int64_t l2hmc_train_grad_floats(int32_t d, int32_t H);
+/* LDS bytes of the fused training kernel l2hmc_train_propose_grad would launch for this shape (> 0), or
+ * L2HMC_ERR_UNSUPPORTED when no fused kernel holds it (d / H beyond the 16-chain tile's 160 KiB plan, the funnel beyond
+ * d = 16): the host then trains on the GEMM engine (l2hmc_train_split_grad below), which takes any d and H. */
+int64_t l2hmc_train_fused_lds_bytes(int32_t energy_kind, int32_t n_comp, int32_t d, int32_t H, int32_t T);
 int l2hmc_train_propose_grad(const L2hmcTrainArgs* args, void* stream);
 
 /* ---- training on the GEMM engine (next-row f1 for config 5 and for wide nets) ----------------------------------

@@ -116,6 +116,7 @@ SYMBOLS = {
     "l2hmc_p_accept_energies": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp]),
     "l2hmc_train_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "l2hmc_train_grad_floats": (C.c_int64, [C.c_int32, C.c_int32]),
+    "l2hmc_train_fused_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "l2hmc_train_propose_grad": (C.c_int, [C.POINTER(L2hmcTrainArgs), _fp]),
     "l2hmc_train_split_grad_floats": (C.c_int64, [C.c_int32, C.c_int32, C.POINTER(L2hmcMlp3)]),
     "l2hmc_train_split_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32,

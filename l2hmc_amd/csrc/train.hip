@@ -915,6 +915,24 @@ int64_t l2hmc_train_grad_floats(int32_t d, int32_t H) {
   return 2LL * net_params(d, H) + 1;
 }
 
+int64_t l2hmc_train_fused_lds_bytes(int32_t ek, int32_t n_comp, int32_t d, int32_t H, int32_t T) {
+  if (d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "l2hmc_train_fused_lds_bytes: bad argument%s");
+  if (ek != L2HMC_ENERGY_GAUSS_DIAG && ek != L2HMC_ENERGY_GAUSS_DENSE && ek != L2HMC_ENERGY_GMM &&
+      ek != L2HMC_ENERGY_ROUGHWELL && ek != L2HMC_ENERGY_FUNNEL)
+    return fail(L2HMC_ERR_UNSUPPORTED, "no fused training kernel for this energy kind%s");
+  if (d > 4096 || H > 4096) return fail(L2HMC_ERR_UNSUPPORTED, "fused training kernel: d / H too large%s");
+  const long long lds_small = 4LL * ts_layout(T).total;
+  if (train_small_ok(ek, d, H) && lds_small <= 48 * 1024) return lds_small;
+  const int fnw = train_fast_waves(ek, d, H);
+  const long long lds_fast = fnw ? 4LL * tf_layout(T, fnw).total : 0;
+  if (fnw && lds_fast <= 160 * 1024) return lds_fast;
+  if (ek == L2HMC_ENERGY_FUNNEL) return fail(L2HMC_ERR_UNSUPPORTED, "funnel: the fused trainer holds 2 <= d <= 16, H <= 15%s");
+  const long long lds = 4LL * train_layout(d, H, T, ek, ek == L2HMC_ENERGY_GMM ? (n_comp < 1 ? 1 : n_comp) : 1).total;
+  if (lds > 160 * 1024)
+    return fail(L2HMC_ERR_UNSUPPORTED, "fused training kernel needs %s%lld bytes of LDS (> 160 KiB)", "", lds);
+  return lds;
+}
+
 int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
   if (a->n_chains < 0 || a->d < 1 || a->T < 1 || a->H < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");

@@ -45,6 +45,13 @@ class Trainer(object):
         # samplers that run on the GEMM engine (nets wider than H = 15, the image-conditioned VAE sampler) train there
         if cls is Trainer and getattr(dynamics, "_split", False):
             return object.__new__(SplitTrainer)
+        # ... and so do shapes no fused training kernel holds (d beyond the 16-chain tile's LDS plan: Rough Well d >= ~190)
+        if cls is Trainer and hasattr(dynamics, "_fn"):
+            fn = dynamics._fn
+            rc = _ffi.lib().l2hmc_train_fused_lds_bytes(int(fn.kind), int(fn.n_comp or 1), int(dynamics.x_dim),
+                                                        int(dynamics.H), int(dynamics.T))
+            if rc == -2:                                   # L2HMC_ERR_UNSUPPORTED (include/l2hmc.h)
+                return object.__new__(SplitTrainer)
         return object.__new__(cls)
 
     def __init__(self, dynamics, lr=1e-3, decay_steps=1000, decay_rate=0.96, scale=0.1,

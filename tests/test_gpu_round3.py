@@ -103,6 +103,55 @@ def test_training_gradient_at_scale_matches_the_float64_oracle(N, T, variant):
     assert torch.equal(flat1, tr.flat)
 
 
+@pytest.mark.parametrize("kind,d,N,T", [("roughwell_easy", 128, 48, 3), ("roughwell_easy", 300, 33, 2), ("gauss_diag", 96, 40, 3)])
+def test_training_beyond_the_fused_kernels_runs_on_the_gemm_engine(kind, d, N, T):
+    """Shapes no fused training kernel holds (d > 64 with H = 10: l2hmc_train_fused_lds_bytes says UNSUPPORTED) --
+    `Trainer(dynamics)` hands them to the GEMM-engine trainer by itself; its gradient against the float64 oracle."""
+    import torch
+    from oracle import l2hmc_train_oracle as TO
+    from l2hmc_amd import _ffi
+    from l2hmc_amd.training import SplitTrainer, Trainer
+    from tests.helpers import synthetic_case
+    g = synthetic_case(kind, d, H=10, T=T, N=N, seed=d, head_std=0.1)
+    rng = np.random.RandomState(9)
+    g["z"] = rng.randn(N, d).astype(np.float32)
+    for pre in ("x.", "z."):
+        g[pre + "dir"] = rng.randint(0, 2, N).astype(np.uint8)
+        g[pre + "v_fwd"] = rng.randn(N, d).astype(np.float32)
+        g[pre + "v_bwd"] = rng.randn(N, d).astype(np.float32)
+    ref_loss, ref = TO.training_loss_and_grad(g, np.float64)
+    dyn = hip_dynamics(g)
+    assert _ffi.lib().l2hmc_train_fused_lds_bytes(int(dyn._fn.kind), 1, d, 10, T) == -2
+    dyn.eps_override = None
+    with torch.no_grad():
+        dyn.alpha.fill_(float(np.log(g["eps"])))
+    tr = Trainer(dyn)
+    assert isinstance(tr, SplitTrainer)
+    draws = {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
+             "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
+             "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
+    loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+    assert abs(float(loss) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (float(loss), ref_loss)
+    assert rel_err(to_np(Lx), ref["Lx"]) < TRAJ_TOL and abs_err(to_np(px), ref["px"]) < P_TOL
+    scale = max(float(np.abs(ref[n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+    worst = 0.0
+    for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
+        for k in O.NET_KEYS:
+            r = np.asarray(ref["%s.%s" % (n, k)])
+            worst = max(worst, float(np.abs(to_np(w[k].grad).reshape(r.shape) - r).max()))
+    ga = float(dyn.alpha.grad)
+    print("%s d=%d: loss %.6e (ref %.6e)  max |dgrad| %.2e (scale %.2e)  alpha %.5e vs %.5e"
+          % (kind, d, float(loss), ref_loss, worst, scale, ga, float(ref["alpha"])))
+    assert worst < 2e-4 * scale
+    assert abs(ga - float(ref["alpha"])) < 2e-4 * max(scale, abs(float(ref["alpha"])))
+    # and a few optimiser steps run (sampling on the fused wide-state kernels, gradient on the engine)
+    x = to_dev(g["x"])
+    for _ in range(3):
+        out = tr.step(x)
+        x = out[2]
+    assert torch.isfinite(x).all()
+
+
 @pytest.mark.parametrize("kind,d,N,T", [("gmm4", 2, 1024, 5), ("gmm2", 2, 200, 10), ("gmm8", 4, 333, 3)])
 def test_gmm_training_gradient_on_the_d4_kernel_matches_the_float64_oracle(kind, d, N, T):
     """Mixture-of-Gaussians targets (config 3's energy, distributions.py:104-134) on the one-dimension-per-lane trainer

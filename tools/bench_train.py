@@ -29,6 +29,12 @@ def make(case, n, dev):
         dyn = Dynamics(d, dist.get_energy_function(), T=10, eps=0.1, net_factory=layers.stq_network(10), device=dev)
         dyn.generator = torch.Generator(device=dev).manual_seed(0)
         return dyn, torch.as_tensor(dist.get_samples(n, rng).astype(np.float32), device=dev), None
+    if case.startswith("rough"):                   # config 4's target at a dimension beyond the fused trainers: GEMM engine
+        d = int(case[5:])
+        dist = D.RoughWell(d, 0.1, easy=True)
+        dyn = Dynamics(d, dist.get_energy_function(), T=10, eps=0.1, net_factory=layers.stq_network(10), device=dev)
+        dyn.generator = torch.Generator(device=dev).manual_seed(0)
+        return dyn, torch.as_tensor(rng.randn(n, d).astype(np.float32), device=dev), None
     if case == "scg2d":
         d, cov = 2, np.array([[50.05, -49.95], [-49.95, 50.05]])
     else:
@@ -61,7 +67,8 @@ def cpu_reference(dyn, x, cov, reps):
 
 def main():
     dev = torch.device("cuda", 0)
-    for case, n, steps in (("scg2d", 200, 200), ("mog2d", 200, 200), ("icg50", 200, 50), ("icg50", 4096, 20)):
+    for case, n, steps in (("scg2d", 200, 200), ("mog2d", 200, 200), ("icg50", 200, 50), ("icg50", 4096, 20),
+                           ("rough128", 4096, 10), ("rough512", 4096, 5)):
         dyn, x, cov = make(case, n, dev)
         tr = Trainer(dyn)
         tr.variant = int(os.environ.get("L2HMC_TRAIN_VARIANT", "0"))      # kernel-choice experiments (include/l2hmc.h)
