@@ -508,6 +508,12 @@ int l2hmc_pack_gaussian(const float* i_sigma, int32_t d, float* packed, void* st
   return L2HMC_OK;
 }
 
+// dense Gaussian on the LDS-resident-state kernel from the same width as the elementwise targets (measured, tools/probe_dense_wide.py:
+// x1.2-1.7 over the register-resident kernel at d = 160 ... 256, x6-8 at d = 384 / 512 where that one spills)
+#ifndef WIDE_DENSE_MIN_NT
+#define WIDE_DENSE_MIN_NT 8
+#endif
+
 int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
   if (a->n_chains < 0 || a->d < 1 || a->T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / T%s");
@@ -572,11 +578,12 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
     if (lane_able && (a->variant == 32 || (a->variant == 0 && lane_auto)))
       return launch_lane(k, s);
   }
-  const bool wide_kind = k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL;
+  const bool wide_dense = k.ekind == L2HMC_ENERGY_GAUSS_DENSE;      // (its precision fragments stream from L2: k.prec is the packed buffer)
+  const bool wide_kind = k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL || wide_dense;
   const bool wide_able = a->packed_nets != nullptr && wide_kind && !(k.M > 1 && a->x_next == nullptr) && k.NT <= 32;
   if (a->variant == 8 && !(wide_able && k.NT >= 4))
-    return fail(L2HMC_ERR_UNSUPPORTED, "variant 8 (LDS-resident state) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target, 64 <= d <= 512 and x_next when n_proposals > 1%s");
-  if (wide_able && (a->variant == 8 || (a->variant == 0 && k.NT > 8))) {
+    return fail(L2HMC_ERR_UNSUPPORTED, "variant 8 (LDS-resident state) needs S/T/Q nets, a Gaussian or Rough-Well target, 64 <= d <= 512 and x_next when n_proposals > 1%s");
+  if (wide_able && (a->variant == 8 || (a->variant == 0 && k.NT > (wide_dense ? WIDE_DENSE_MIN_NT : 8)))) {
     KArgs kw = k;
     const long long ldsw = plan_lds_wide(kw);
     if (ldsw <= 160 * 1024) return launch_wide(kw, KH, ldsw, s);

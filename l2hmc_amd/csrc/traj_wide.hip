@@ -9,14 +9,29 @@
 //     heads of tile tg (9 MFMAs, fragments streamed from L2)  ->  elementwise update of that tile
 //     ->  its layer-1 contribution to the NEXT net evaluation (4-8 MFMAs), fused in the same pass.
 // Per leapfrog step: 4 tile passes, 3 LDS exchanges of one 16x16 partial (as in traj_kernel), layer 2
-// once per net evaluation.  Elementwise energies only (diagonal Gaussian, Rough Well: the targets that
-// exist at this width); the other kinds keep the register kernel.
+// once per net evaluation.  Elementwise energies (diagonal Gaussian, Rough Well) evaluate grad U inside the
+// position pass; the DENSE Gaussian (distributions.py:41-57) needs the whole new position first: after a barrier
+// every wave forms G (x' - mu) for its own tiles as NT x 4 MFMAs per tile, the packed precision fragments
+// (l2hmc_pack_gaussian) streamed from L2 four tiles ahead, the other waves' x' tiles read from the LDS state.
 #include "l2hmc_kernels.hpp"
 
 namespace l2hmc {
 
 __device__ __forceinline__ f4 tl(const float* S, int tg, int lane) { return lds4(S + (tg * 64 + lane) * 4); }
 __device__ __forceinline__ void ts(float* S, int tg, int lane, f4 v) { *reinterpret_cast<f4*>(S + (tg * 64 + lane) * 4) = v; }
+
+// AIS bridge / temperature on a raw (grad U, U) pair (utils/ais.py:46-47, dynamics.py:203-212)
+__device__ __forceinline__ f4 wide_finish(const KArgs& A, f4 x, f4 g, float& u, bool wantU) {
+  if (A.beta != 1.f) {
+    g = x * (1.f - A.beta) + g * A.beta;
+    if (wantU) u = (1.f - A.beta) * 0.5f * hsum(x * x) + A.beta * u;
+  }
+  if (A.temperature != 1.f) {
+    g = g / A.temperature;
+    u = u / A.temperature;
+  }
+  return g;
+}
 
 // grad U of one tile and this lane's share of U (distributions.py:31-32,41-57 diagonal case; :84-97)
 template <int EK>
@@ -41,20 +56,14 @@ __device__ __forceinline__ f4 wide_grad(const KArgs& A, const float* smem, int t
       u = 0.5f * hsum(x * x) + eta * hsum(lv * cs);
     }
   }
-  if (A.beta != 1.f) {                     // AIS bridge from N(0, I) (utils/ais.py:46-47)
-    g = x * (1.f - A.beta) + g * A.beta;
-    if (wantU) u = (1.f - A.beta) * 0.5f * hsum(x * x) + A.beta * u;
-  }
-  if (A.temperature != 1.f) {
-    g = g / A.temperature;
-    u = u / A.temperature;
-  }
+  g = wide_finish(A, x, g, u, wantU);
   U += u;
   return g;
 }
 
 template <int EK, int KH, int NW>
 __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
+  constexpr bool DENSE = EK == L2HMC_ENERGY_GAUSS_DENSE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTHR = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -166,6 +175,34 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
   };
   auto nxt = [&](int tg) { return tg + 1 < t_hi ? tg + 1 : tg; };      // tile whose fragments to prefetch
 
+  // DENSE: grad U = G (x - mu) of this wave's tiles from the complete position in SX (barrier first), into SG; adds this
+  // lane's share of U and the VNet layer-1 contribution of grad U (a1)
+  auto dense_pass = [&](float& U, bool wantU, f4& a1) {
+    __syncthreads();
+    const float* mu = smem + A.o_mu;
+    for (int tg = t_lo; tg < t_hi; ++tg) {
+      const float* Grow = A.prec + (size_t)tg * NT * 256;
+      const f4 Wb = frag(wv, NT + tg);
+      auto gfrag = [&](int ti) { return lds4(Grow + ((ti < NT ? ti : NT - 1) * 64 + lane) * 4); };
+      f4 acc = Z;
+      f4 G0 = gfrag(0), G1 = gfrag(1), G2 = gfrag(2), G3 = gfrag(3);
+      for (int t0 = 0; t0 < NT; t0 += 4) {
+        const f4 N0 = gfrag(t0 + 4), N1 = gfrag(t0 + 5), N2 = gfrag(t0 + 6), N3 = gfrag(t0 + 7);
+        acc = l1(acc, G0, tl(SX, t0, lane) - lds4(mu + 16 * t0 + 4 * q));
+        if (t0 + 1 < NT) acc = l1(acc, G1, tl(SX, t0 + 1, lane) - lds4(mu + 16 * (t0 + 1) + 4 * q));
+        if (t0 + 2 < NT) acc = l1(acc, G2, tl(SX, t0 + 2, lane) - lds4(mu + 16 * (t0 + 2) + 4 * q));
+        if (t0 + 3 < NT) acc = l1(acc, G3, tl(SX, t0 + 3, lane) - lds4(mu + 16 * (t0 + 3) + 4 * q));
+        G0 = N0; G1 = N1; G2 = N2; G3 = N3;
+      }
+      const f4 x = tl(SX, tg, lane);
+      float u = wantU ? 0.5f * hsum((x - lds4(mu + 16 * tg + 4 * q)) * acc) : 0.f;
+      const f4 g = wide_finish(A, x, acc, u, wantU);
+      U += u;
+      ts(SG, tg, lane, g);
+      a1 = l1(a1, Wb, g);
+    }
+  };
+
   // grad U at the start state, and the VNet layer-1 partial there (shared by consecutive half-updates)
   float U_start = 0.f;
   f4 pv[1];
@@ -176,12 +213,15 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
     for (int tg = t_lo; tg < t_hi; ++tg) {
       const f4 Wa_n = frag(wv, nxt(tg)), Wb_n = frag(wv, NT + nxt(tg));
       const f4 x = tl(SX, tg, lane);
-      const f4 g = wide_grad<EK>(A, smem, tg, q, x, U_start, true);
-      ts(SG, tg, lane, g);
       a0 = l1(a0, Wa, x);
-      a1 = l1(a1, Wb, g);
+      if (!DENSE) {
+        const f4 g = wide_grad<EK>(A, smem, tg, q, x, U_start, true);
+        ts(SG, tg, lane, g);
+        a1 = l1(a1, Wb, g);
+      }
       Wa = Wa_n; Wb = Wb_n;
     }
+    if (DENSE) dense_pass(U_start, true, a1);
     pv[0] = a0 + a1;
     xchg<NW, 1>(pv, A, smem, w, lane, pb);
   };
@@ -285,12 +325,15 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
         heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
         const f4 xn = x_half(tl(SX, tg, lane), O - k1_of(tg), tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ldv);
         ts(SX, tg, lane, xn);
-        const f4 g = wide_grad<EK>(A, smem, tg, q, xn, Uend, lastU);
-        ts(SG, tg, lane, g);
         a0 = l1(a0, Wa, xn);
-        a1 = l1(a1, Wb, g);
+        if (!DENSE) {
+          const f4 g = wide_grad<EK>(A, smem, tg, q, xn, Uend, lastU);
+          ts(SG, tg, lane, g);
+          a1 = l1(a1, Wb, g);
+        }
         hw = hw_n; Wa = Wa_n; Wb = Wb_n;
       }
+      if (DENSE) dense_pass(Uend, lastU, a1);
       if (lastU) red[2] = Uend;
       pv[0] = a0 + a1;
       xchg<NW, 1>(pv, A, smem, w, lane, pb);
@@ -389,10 +432,11 @@ static int launch_wide_t(const KArgs& k, long long lds, hipStream_t s) {
 }
 
 int launch_wide(const KArgs& k, int KH, long long lds, hipStream_t s) {
-  const bool diag = k.ekind == L2HMC_ENERGY_GAUSS_DIAG, w8 = wide_waves(k.NT) == 8;
+  const bool diag = k.ekind == L2HMC_ENERGY_GAUSS_DIAG, dense = k.ekind == L2HMC_ENERGY_GAUSS_DENSE, w8 = wide_waves(k.NT) == 8;
 #define L2HMC_WIDE(EKv)                                                                      \
   (KH == 3 ? (w8 ? launch_wide_t<EKv, 3, 8>(k, lds, s) : launch_wide_t<EKv, 3, 4>(k, lds, s)) \
            : (w8 ? launch_wide_t<EKv, 4, 8>(k, lds, s) : launch_wide_t<EKv, 4, 4>(k, lds, s)))
+  if (dense) return L2HMC_WIDE(L2HMC_ENERGY_GAUSS_DENSE);
   return diag ? L2HMC_WIDE(L2HMC_ENERGY_GAUSS_DIAG) : L2HMC_WIDE(L2HMC_ENERGY_ROUGHWELL);
 #undef L2HMC_WIDE
 }

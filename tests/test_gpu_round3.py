@@ -200,7 +200,8 @@ def test_gmm_training_gradient_on_the_d4_kernel_matches_the_float64_oracle(kind,
 
 
 @pytest.mark.parametrize("kind,d,variant", [("gauss_diag", 50, 0), ("gauss_diag", 50, 4), ("gauss_dense", 24, 0),
-                                            ("roughwell_easy", 40, 0), ("gauss_diag", 200, 0), ("gauss_diag", 2, 0)])
+                                            ("roughwell_easy", 40, 0), ("gauss_diag", 200, 0), ("gauss_diag", 2, 0),
+                                            ("gauss_dense", 200, 0)])
 def test_tempered_energy_on_every_kernel_family(kind, d, variant):
     """use_temperature=True, T = 2.5 (dynamics.py:203-212: U and grad U divided by the fed temperature) -- the fast /
     tile / dense / wide / lane kernels must either honour it or hand over to a kernel that does: propose vs the oracle,
