@@ -578,8 +578,8 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
     if (lane_able && (a->variant == 32 || (a->variant == 0 && lane_auto)))
       return launch_lane(k, s);
   }
-  const bool wide_dense = k.ekind == L2HMC_ENERGY_GAUSS_DENSE;      // (its precision fragments stream from L2: k.prec is the packed buffer)
-  const bool wide_kind = k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL || wide_dense;
+  const bool wide_dense = k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM;      // (its precision fragments stream from L2: k.prec is the packed buffer)
+  const bool wide_kind = k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL || wide_dense;   // (mixtures: <= 4 tiles per wave)
   const bool wide_able = a->packed_nets != nullptr && wide_kind && !(k.M > 1 && a->x_next == nullptr) && k.NT <= 32;
   if (a->variant == 8 && !(wide_able && k.NT >= 4))
     return fail(L2HMC_ERR_UNSUPPORTED, "variant 8 (LDS-resident state) needs S/T/Q nets, a Gaussian or Rough-Well target, 64 <= d <= 512 and x_next when n_proposals > 1%s");

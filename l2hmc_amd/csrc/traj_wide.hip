@@ -12,7 +12,8 @@
 // once per net evaluation.  Elementwise energies (diagonal Gaussian, Rough Well) evaluate grad U inside the
 // position pass; the DENSE Gaussian (distributions.py:41-57) needs the whole new position first: after a barrier
 // every wave forms G (x' - mu) for its own tiles as NT x 4 MFMAs per tile, the packed precision fragments
-// (l2hmc_pack_gaussian) streamed from L2 four tiles ahead, the other waves' x' tiles read from the LDS state.
+// (l2hmc_pack_gaussian) streamed from L2 four tiles ahead, the other waves' x' tiles read from the LDS state.  The
+// mixture of Gaussians (:104-134) does that per component, with the online softmax of traj_kernel.
 #include "l2hmc_kernels.hpp"
 
 namespace l2hmc {
@@ -63,7 +64,8 @@ __device__ __forceinline__ f4 wide_grad(const KArgs& A, const float* smem, int t
 
 template <int EK, int KH, int NW>
 __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
-  constexpr bool DENSE = EK == L2HMC_ENERGY_GAUSS_DENSE;
+  constexpr bool GMMK = EK == L2HMC_ENERGY_GMM;                 // (both: grad U couples all dimensions)
+  constexpr bool DENSE = EK == L2HMC_ENERGY_GAUSS_DENSE || GMMK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTHR = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -175,25 +177,31 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
   };
   auto nxt = [&](int tg) { return tg + 1 < t_hi ? tg + 1 : tg; };      // tile whose fragments to prefetch
 
-  // DENSE: grad U = G (x - mu) of this wave's tiles from the complete position in SX (barrier first), into SG; adds this
-  // lane's share of U and the VNet layer-1 contribution of grad U (a1)
+  // y = G (x - mu) of tile tg from the complete position in SX: NT x 4 MFMAs, the packed fragments of row-tile tg
+  // (l2hmc_pack_gaussian order) streamed from L2 four tiles ahead
+  auto matvec_tile = [&](const float* Gp, const float* mu, int tg) {
+    const float* Grow = Gp + (size_t)tg * NT * 256;
+    auto gfrag = [&](int ti) { return lds4(Grow + ((ti < NT ? ti : NT - 1) * 64 + lane) * 4); };
+    f4 acc = Z;
+    f4 G0 = gfrag(0), G1 = gfrag(1), G2 = gfrag(2), G3 = gfrag(3);
+    for (int t0 = 0; t0 < NT; t0 += 4) {
+      const f4 N0 = gfrag(t0 + 4), N1 = gfrag(t0 + 5), N2 = gfrag(t0 + 6), N3 = gfrag(t0 + 7);
+      acc = l1(acc, G0, tl(SX, t0, lane) - lds4(mu + 16 * t0 + 4 * q));
+      if (t0 + 1 < NT) acc = l1(acc, G1, tl(SX, t0 + 1, lane) - lds4(mu + 16 * (t0 + 1) + 4 * q));
+      if (t0 + 2 < NT) acc = l1(acc, G2, tl(SX, t0 + 2, lane) - lds4(mu + 16 * (t0 + 2) + 4 * q));
+      if (t0 + 3 < NT) acc = l1(acc, G3, tl(SX, t0 + 3, lane) - lds4(mu + 16 * (t0 + 3) + 4 * q));
+      G0 = N0; G1 = N1; G2 = N2; G3 = N3;
+    }
+    return acc;
+  };
+  // DENSE: grad U = G (x - mu) of this wave's tiles (barrier first: every wave's tiles of the new position), into SG; adds
+  // this lane's share of U and the VNet layer-1 contribution of grad U (a1)
   auto dense_pass = [&](float& U, bool wantU, f4& a1) {
     __syncthreads();
     const float* mu = smem + A.o_mu;
     for (int tg = t_lo; tg < t_hi; ++tg) {
-      const float* Grow = A.prec + (size_t)tg * NT * 256;
       const f4 Wb = frag(wv, NT + tg);
-      auto gfrag = [&](int ti) { return lds4(Grow + ((ti < NT ? ti : NT - 1) * 64 + lane) * 4); };
-      f4 acc = Z;
-      f4 G0 = gfrag(0), G1 = gfrag(1), G2 = gfrag(2), G3 = gfrag(3);
-      for (int t0 = 0; t0 < NT; t0 += 4) {
-        const f4 N0 = gfrag(t0 + 4), N1 = gfrag(t0 + 5), N2 = gfrag(t0 + 6), N3 = gfrag(t0 + 7);
-        acc = l1(acc, G0, tl(SX, t0, lane) - lds4(mu + 16 * t0 + 4 * q));
-        if (t0 + 1 < NT) acc = l1(acc, G1, tl(SX, t0 + 1, lane) - lds4(mu + 16 * (t0 + 1) + 4 * q));
-        if (t0 + 2 < NT) acc = l1(acc, G2, tl(SX, t0 + 2, lane) - lds4(mu + 16 * (t0 + 2) + 4 * q));
-        if (t0 + 3 < NT) acc = l1(acc, G3, tl(SX, t0 + 3, lane) - lds4(mu + 16 * (t0 + 3) + 4 * q));
-        G0 = N0; G1 = N1; G2 = N2; G3 = N3;
-      }
+      const f4 acc = matvec_tile(A.prec, mu, tg);
       const f4 x = tl(SX, tg, lane);
       float u = wantU ? 0.5f * hsum((x - lds4(mu + 16 * tg + 4 * q)) * acc) : 0.f;
       const f4 g = wide_finish(A, x, acc, u, wantU);
@@ -201,6 +209,54 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       ts(SG, tg, lane, g);
       a1 = l1(a1, Wb, g);
     }
+  };
+  // MIXTURE (distributions.py:104-134): per component y_i = G_i (x - mu_i) of this wave's (<= 4) tiles, the quadratic form
+  // summed over the chain (all waves), online softmax of V_i = log c_i - q_i / 2 exactly as traj_kernel does
+  auto gmm_pass = [&](float& U, bool wantU, f4& a1) {
+    __syncthreads();
+    float m = -INFINITY, ssum = 0.f;
+    f4 gacc[4] = {Z, Z, Z, Z};
+    for (int i = 0; i < A.ncomp; ++i) {
+      const float* mu = smem + A.o_mu + i * DP;
+      const float* Gp = A.prec + (size_t)i * gauss_floats(NT);
+      f4 y[4];
+      float qq[1] = {0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = Z;
+        const int tg = t_lo + j;
+        if (tg < t_hi) {
+          y[j] = matvec_tile(Gp, mu, tg);
+          qq[0] += hsum((tl(SX, tg, lane) - lds4(mu + 16 * tg + 4 * q)) * y[j]);
+        }
+      }
+      chain_allreduce<NW, 1>(qq, smem + A.o_red, w, lane);
+      const float V = -(0.5f * qq[0]) + smem[A.o_logc + i];
+      const float mn = fmaxf(m, V);
+      const float sc = (m == mn) ? 1.f : expf(m - mn), wi = (V == -INFINITY) ? 0.f : expf(V - mn);
+      ssum = ssum * sc + wi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gacc[j] = gacc[j] * sc + wi * y[j];
+      m = mn;
+    }
+    const float inv = 1.f / ssum;
+    const float it = 1.f / A.temperature;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tg = t_lo + j;
+      if (tg < t_hi) {
+        const f4 x = tl(SX, tg, lane);
+        f4 g = gacc[j] * inv;
+        if (A.beta != 1.f) {
+          g = x * (1.f - A.beta) + g * A.beta;
+          if (wantU) U += (1.f - A.beta) * 0.5f * hsum(x * x) * it;
+        }
+        g = g * it;
+        ts(SG, tg, lane, g);
+        a1 = l1(a1, frag(wv, NT + tg), g);
+      }
+    }
+    if (wantU && w == 0 && lane < 16) U += A.beta * -(m + logf(ssum)) * it;      // once per chain
   };
 
   // grad U at the start state, and the VNet layer-1 partial there (shared by consecutive half-updates)
@@ -221,7 +277,8 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       }
       Wa = Wa_n; Wb = Wb_n;
     }
-    if (DENSE) dense_pass(U_start, true, a1);
+    if (GMMK) gmm_pass(U_start, true, a1);
+    else if (DENSE) dense_pass(U_start, true, a1);
     pv[0] = a0 + a1;
     xchg<NW, 1>(pv, A, smem, w, lane, pb);
   };
@@ -333,7 +390,8 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
         }
         hw = hw_n; Wa = Wa_n; Wb = Wb_n;
       }
-      if (DENSE) dense_pass(Uend, lastU, a1);
+      if (GMMK) gmm_pass(Uend, lastU, a1);
+      else if (DENSE) dense_pass(Uend, lastU, a1);
       if (lastU) red[2] = Uend;
       pv[0] = a0 + a1;
       xchg<NW, 1>(pv, A, smem, w, lane, pb);
@@ -410,9 +468,9 @@ long long plan_lds_wide(KArgs& k) {
   k.o_tb = (int)o; o += 2LL * k.T * 16;
   k.o_P = (int)o; o += 2LL * NW * 256;
   k.o_red = (int)o; o += (long long)NW * 16 * 8;
-  k.o_mu = (int)o; o += DP;
+  k.o_mu = (int)o; o += (long long)(k.ekind == L2HMC_ENERGY_GMM ? k.ncomp : 1) * DP;
   k.o_prec = (int)o; if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) o += DP;
-  k.o_logc = (int)o;
+  k.o_logc = (int)o; if (k.ekind == L2HMC_ENERGY_GMM) o += (k.ncomp + 3) / 4 * 4;
   k.o_state = (int)o; o += 3LL * NT * 256;
   return o * 4;
 }
@@ -437,6 +495,7 @@ int launch_wide(const KArgs& k, int KH, long long lds, hipStream_t s) {
   (KH == 3 ? (w8 ? launch_wide_t<EKv, 3, 8>(k, lds, s) : launch_wide_t<EKv, 3, 4>(k, lds, s)) \
            : (w8 ? launch_wide_t<EKv, 4, 8>(k, lds, s) : launch_wide_t<EKv, 4, 4>(k, lds, s)))
   if (dense) return L2HMC_WIDE(L2HMC_ENERGY_GAUSS_DENSE);
+  if (k.ekind == L2HMC_ENERGY_GMM) return L2HMC_WIDE(L2HMC_ENERGY_GMM);
   return diag ? L2HMC_WIDE(L2HMC_ENERGY_GAUSS_DIAG) : L2HMC_WIDE(L2HMC_ENERGY_ROUGHWELL);
 #undef L2HMC_WIDE
 }

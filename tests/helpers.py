@@ -199,16 +199,23 @@ def synthetic_case(kind, d, H=10, T=10, N=64, seed=0, eps=0.1, head_std=0.3):
         mus, i_sigmas, consts = [], [], []
         for k in range(K):
             R = np.linalg.qr(rng.randn(d, d))[0]
-            prec = (R.T * np.exp(rng.uniform(-0.7, 0.7, size=d))) @ R
-            consts.append((1.0 + 0.3 * k) / K * np.sqrt(np.linalg.det(prec) / (2 * np.pi) ** d))
+            if d <= 8:
+                ev = np.exp(rng.uniform(-0.7, 0.7, size=d))
+            else:      # the reference keeps c_i = pi_i / sqrt((2 pi)^d det Sigma_i) in float32 (distributions.py:117-124): it
+                ev = np.exp(rng.uniform(np.log(4.0), np.log(10.0), size=d))   # only exists for precisions around 2 pi at this d
+            prec = (R.T * ev) @ R
+            consts.append((1.0 + 0.3 * k) / K * np.exp(0.5 * (np.sum(np.log(ev)) - d * np.log(2 * np.pi))))
             i_sigmas.append(prec + 0.05 * np.triu(rng.randn(d, d), 1))
-            mus.append(1.5 * rng.randn(d))
+            mus.append(1.5 * rng.randn(d) / max(1.0, np.sqrt(d / 4.0)))     # components overlap at any d
         g.update({"energy.kind": "gmm", "energy.mus": np.asarray(mus, np.float32),
                   "energy.i_sigmas": np.asarray(i_sigmas, np.float32), "energy.constants": np.asarray(consts, np.float32)})
         scale = 1.5 * scale
     else:
         raise ValueError(kind)
     g["x"] = (rng.randn(N, d) * scale).astype(np.float32)
+    if kind.startswith("gmm") and d > 8:             # start in the typical set of a component
+        pick = rng.randint(0, K, size=N)
+        g["x"] = (g["energy.mus"][pick] + 0.4 * rng.randn(N, d)).astype(np.float32)
     g["v"] = rng.randn(N, d).astype(np.float32)
     return g
 

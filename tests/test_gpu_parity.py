@@ -302,7 +302,8 @@ def test_hmc_ess_on_scg_reproduces_notebook_number():
                                             ("gauss_diag", 64, 1), ("gauss_diag", 17, 1),
                                             ("roughwell_easy", 200, 8), ("gauss_diag", 64, 8), ("gauss_diag", 500, 8),
                                             ("gauss_dense", 70, 8), ("gauss_dense", 150, 8), ("gauss_dense", 300, 0),
-                                            ("gauss_dense", 512, 0), ("gauss_dense", 200, 4)])
+                                            ("gauss_dense", 512, 0), ("gauss_dense", 200, 4),
+                                            ("gmm3", 70, 8), ("gmm2", 150, 0), ("gmm4", 300, 0), ("gmm2", 150, 4)])
 def test_wide_dims_against_oracle(kind, d, variant):
     """BASELINE.json config 4 range (d up to 512) and the geometries the fixtures do not reach:
     LDS-staged weights (DT <= 2) and global-memory weights (DT >= 4), every NW/DT kernel, and the
@@ -633,7 +634,7 @@ def test_native_adam_matches_tf1_formula():
     assert np.abs(to_np(p) - rp).max() < 1e-6
 
 
-@pytest.mark.parametrize("kind,d", [("gauss_diag", 300), ("roughwell_easy", 512), ("gauss_dense", 290)])
+@pytest.mark.parametrize("kind,d", [("gauss_diag", 300), ("roughwell_easy", 512), ("gauss_dense", 290), ("gmm3", 200)])
 def test_wide_sampler_loop_matches_single_launches_and_philox(kind, d):
     """The LDS-resident-state kernel (d > 128) in its sampler-loop form: M chained proposals in one
     launch == M single-proposal launches bit for bit (injected draws: exercises the reject path, where a
