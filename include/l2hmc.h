@@ -107,7 +107,7 @@ typedef struct L2hmcTrajectoryArgs {
   int32_t variant;          /* kernel choice.  0 = automatic (measured rules): d <= 4 the
                              *   one-dimension-per-lane kernel; d <= 64 the instruction-lean tile kernel on 1 or 4
                              *   waves per 16-chain tile, from 16 384 chains with 33 <= d <= 64 and an elementwise
-                             *   target one wave per tile; d > 128 the LDS-resident-state kernel; d <= 2 from 65 536
+                             *   target one wave per tile; d > 128 the LDS-resident-state kernel (Gaussians incl. dense, mixtures, Rough Well); d <= 2 from 65 536
                              *   chains (d <= 4 from 131 072) ONE CHAIN PER LANE: the nets on packed VALU FMAs with
                              *   wave-uniform weights, no MFMA padding.  32 = force one chain per lane (d <= 4);
                              *   33 = the automatic choice among the MFMA kernels only.  1 / 4 = force

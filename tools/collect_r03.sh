@@ -64,4 +64,6 @@ timeout 200 python tools/bench_vae_train.py 2>&1 | grep -v amdgpu > $OUT/vae_tra
 timeout 100 python tools/bench_vae.py 8192 0 2>&1 | grep -v amdgpu > $OUT/vae_modes.txt
 timeout 100 python tools/bench_vae.py 8192 1 2>&1 | grep -v amdgpu >> $OUT/vae_modes.txt
 timeout 100 python tools/bench_vae.py 512 1 2>&1 | grep -v amdgpu >> $OUT/vae_modes.txt
+timeout 400 python tools/bench_configs.py 2>&1 | grep -v amdgpu > $OUT/configs.txt
+timeout 300 python tools/probe_dense_wide.py 2>&1 | grep -v amdgpu > $OUT/dense_wide.txt
 tail -c 1500 $OUT/bench.json; cat $OUT/pmc_summary.txt $OUT/train_timing.txt $OUT/vae_train_timing.txt $OUT/vae_modes.txt; head -5 $OUT/kernel_stats.csv
