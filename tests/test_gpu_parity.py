@@ -598,17 +598,25 @@ def test_ais_estimates_the_log_normaliser_ratio_and_is_sharding_invariant():
 
 
 def test_training_kernel_reports_shapes_beyond_its_lds_tile():
-    """The training kernel keeps a 16-chain tile's matrices in LDS; a shape that does not fit must fail
-    loudly (L2HMC_ERR_UNSUPPORTED through `_ffi.check`), not silently fall back."""
+    """The fused training kernels keep a 16-chain tile's matrices in LDS; `l2hmc_train_propose_grad` on a shape that
+    does not fit fails loudly (L2HMC_ERR_UNSUPPORTED through `_ffi.check`) -- and `Trainer(dynamics)`, which asks
+    `l2hmc_train_fused_lds_bytes` first, trains such a shape on the GEMM engine instead (round 3)."""
     import torch
     from l2hmc_amd import Dynamics, distributions as D, layers
-    from l2hmc_amd.training import Trainer
+    from l2hmc_amd.training import SplitTrainer, Trainer
     d = 192
-    dyn = Dynamics(d, D.Gaussian(np.zeros(d), np.diag(np.linspace(0.5, 2.0, d))).get_energy_function(), T=3, eps=0.1,
-                   net_factory=layers.stq_network(10))
-    tr = Trainer(dyn)
+
+    def make():
+        return Dynamics(d, D.Gaussian(np.zeros(d), np.diag(np.linspace(0.5, 2.0, d))).get_energy_function(), T=3, eps=0.1,
+                        net_factory=layers.stq_network(10))
+    fused = object.__new__(Trainer)                 # the fused engine, bypassing the engine choice of Trainer.__new__
+    fused.__init__(make())
     with pytest.raises(RuntimeError, match="LDS"):
-        tr.loss_and_grad(torch.randn(32, d, device="cuda"))
+        fused.loss_and_grad(torch.randn(32, d, device="cuda"))
+    tr = Trainer(make())
+    assert isinstance(tr, SplitTrainer)
+    loss, Lx, px = tr.loss_and_grad(torch.randn(32, d, device="cuda"))
+    assert torch.isfinite(Lx).all() and 0.0 <= float(px.min()) and float(px.max()) <= 1.0
 
 
 def test_native_adam_matches_tf1_formula():
