@@ -9,7 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from l2hmc_amd import propose
+from l2hmc_amd import _ffi, propose
+if os.environ.get("L2HMC_LIB"):          # kernel experiments: an alternative build of the library
+    _ffi.LIB_PATH = os.path.abspath(os.environ["L2HMC_LIB"])
 from tests.helpers import hip_dynamics, synthetic_vae_case, to_dev
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
