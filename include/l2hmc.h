@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define L2HMC_ABI_VERSION 2
+#define L2HMC_ABI_VERSION 3
 
 enum {
   L2HMC_OK = 0,
@@ -231,6 +231,14 @@ typedef struct L2hmcMlp3 {
 typedef int (*L2hmcEnergyCallback)(void* user, const float* x, int64_t ldx, int64_t n_chains, int32_t d,
                                    double* U_out, float* grad_out, int64_t ldg, void* stream);
 
+/* Hessian-vector product of a caller-supplied energy, for TRAINING on it (l2hmc_train_split_grad): the loss
+ * back-propagates through grad U (utils/dynamics.py:218 inside the differentiated graph), so the reverse sweep needs
+ *   hv_out (n_chains, d; row stride ldhv) = (d^2 U / dx^2)(x) u      for x (row stride ldx) and u (row stride ldu)
+ * once per leapfrog step -- e.g. torch.autograd.grad of sum(grad U * u) in a binding.  Same rules as
+ * L2hmcEnergyCallback (enqueue on `stream`, return 0 or non-zero to abort). */
+typedef int (*L2hmcHvpCallback)(void* user, const float* x, int64_t ldx, const float* u, int64_t ldu, int64_t n_chains,
+                                int32_t d, float* hv_out, int64_t ldhv, void* stream);
+
 typedef struct L2hmcSplitArgs {
   const L2hmcNet* xnet;
   const L2hmcNet* vnet;
@@ -398,6 +406,10 @@ typedef struct L2hmcTrainSplitArgs {
   float* Lv_out;                 /* (N, d) or NULL                                                              */
   float* logjac_out;             /* (N) or NULL                                                                 */
   int32_t gemm_mode;             /* as L2hmcSplitArgs.gemm_mode                                                 */
+  /* ---- training on a caller-supplied energy (energy = decoder = NULL; aux only feeds aux_encoder, if any) ------- */
+  L2hmcEnergyCallback energy_cb; /* U / grad U at a trajectory point (as in L2hmcSplitArgs), or NULL              */
+  L2hmcHvpCallback hvp_cb;       /* its Hessian-vector product; required with energy_cb                          */
+  void* energy_cb_user;          /* first argument of both callbacks                                              */
 } L2hmcTrainSplitArgs;
 
 int64_t l2hmc_train_split_grad_floats(int32_t d, int32_t H, const L2hmcMlp3* aux_encoder);

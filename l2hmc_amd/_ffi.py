@@ -67,6 +67,9 @@ class L2hmcSplitArgs(C.Structure):
 # include/l2hmc.h L2hmcEnergyCallback: (user, x, ldx, n_chains, d, U_out, grad_out, ldg, stream) -> int
 ENERGY_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_int64, C.c_void_p)
+# L2hmcHvpCallback(user, x, ldx, u, ldu, n_chains, d, hv_out, ldhv, stream)
+HVP_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                           C.c_void_p, C.c_int64, C.c_void_p)
 
 
 class L2hmcTrainArgs(C.Structure):
@@ -89,7 +92,8 @@ class L2hmcTrainSplitArgs(C.Structure):
                 ("Lx", _fp), ("p", _fp), ("v1", _fp), ("dx0_out", _fp), ("grad", _fp),
                 ("workspace", _fp), ("workspace_floats", C.c_int64),
                 ("energy_scale", C.c_float), ("ediff_out", _fp), ("no_accept", C.c_int32), ("dLv_in", _fp),
-                ("dlogjac_in", _fp), ("Lv_out", _fp), ("logjac_out", _fp), ("gemm_mode", C.c_int32)]
+                ("dlogjac_in", _fp), ("Lv_out", _fp), ("logjac_out", _fp), ("gemm_mode", C.c_int32),
+                ("energy_cb", C.c_void_p), ("hvp_cb", C.c_void_p), ("energy_cb_user", C.c_void_p)]
 
 
 STRUCTS = (L2hmcNet, L2hmcEnergy, L2hmcTrajectoryArgs, L2hmcMlp3, L2hmcSplitArgs, L2hmcTrainArgs, L2hmcTrainSplitArgs)
@@ -136,7 +140,7 @@ SYMBOLS = {
                              _fp, _fp]),
 }
 
-ABI_VERSION = 2          # L2HMC_ABI_VERSION this binding was written against
+ABI_VERSION = 3          # L2HMC_ABI_VERSION this binding was written against
 _lib = None
 
 

@@ -637,12 +637,18 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   t_gemm_bf3 = a ? a->gemm_mode : 0;
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
   const bool builtin = a->energy != nullptr;
+  const bool user = a->energy_cb != nullptr;       // the caller's energy: U / grad U and Hessian-vector products by callback
+  const bool vae = !builtin && !user;              // the decoder posterior
   int rc;
   const long long N = a->n_chains;
   const int d = a->d, H = a->H, T = a->T;
   if (N < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
   if (N == 0) return L2HMC_OK;
-  if (builtin) {
+  if (user) {
+    if (builtin || a->decoder) return fail(L2HMC_ERR_ARG, "energy_cb excludes energy and decoder%s");
+    if (!a->hvp_cb) return fail(L2HMC_ERR_ARG, "training on a caller-supplied energy needs hvp_cb (the loss differentiates through grad U)%s");
+    if (a->aux_encoder && !a->aux) return fail(L2HMC_ERR_ARG, "aux_encoder needs aux%s");
+  } else if (builtin) {
     if (a->decoder || a->aux_encoder || a->aux)
       return fail(L2HMC_ERR_UNSUPPORTED, "a built-in energy excludes decoder / aux_encoder / aux%s");
     if ((rc = check_energy(a->energy, d))) return rc;
@@ -660,7 +666,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   }
   if (a->aux_encoder) {
     if ((rc = check_mlp(a->aux_encoder, "aux_encoder"))) return rc;
-    if (a->aux_encoder->n_out != H || a->aux_encoder->n_in != a->decoder->n_out)
+    if (a->aux_encoder->n_out != H || (vae && a->aux_encoder->n_in != a->decoder->n_out))
       return fail(L2HMC_ERR_ARG, "aux_encoder must map (N, n_pix) -> (N, H)%s");
   }
   if (!a->xnet || !a->vnet || !a->masks || !a->trig || !a->x || !a->v || !a->Lx || (!a->no_accept && (!a->p || !a->v1)) ||
@@ -677,7 +683,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   float* w = a->workspace;
   const SplitPlan& f = p.fwd;
   static const L2hmcMlp3 no_dec = {};
-  const L2hmcMlp3& dec = builtin ? no_dec : *a->decoder;
+  const L2hmcMlp3& dec = vae ? *a->decoder : no_dec;
   const Mlp3Ws dws = {w + f.dw1t, w + f.dw2t, w + f.dw3t, w + f.a1, w + f.s1, w + f.a2, w + f.s2};
   const int L = 2 * d;
   const L2hmcNet &xn = *a->xnet, &vn = *a->vnet;
@@ -701,7 +707,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   auto YS = [&](int it) { return w + p.YS + it * Nd; };
 
   // ---- weights: transposed copies for the forward products, stacked copies for the input-gradient products ------
-  if (!builtin) mlp3_transposes(s, dec, dws);
+  if (vae) mlp3_transposes(s, dec, dws);
   Mlp3Ws ews = {};
   if (a->aux_encoder) {
     const L2hmcMlp3& enc = *a->aux_encoder;
@@ -731,7 +737,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   // trajectory point j = 0 .. T (the start point and the position after each leapfrog step)
   auto dec_point = [&](int j) {
     DecPoint pt = {};
-    if (!builtin) {
+    if (vae) {
       pt.s1 = w + p.PS1 + (long long)j * N * dec.n_h1; pt.s2 = w + p.PS2 + (long long)j * N * dec.n_h2;
       pt.rd = w + p.PRD + (long long)j * N * dec.n_out;
       pt.b2 = w + p.PB2 + (long long)j * N * dec.n_h2; pt.b1 = w + p.PB1 + (long long)j * N * dec.n_h1;
@@ -740,7 +746,11 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   };
   // U (double, optional) and grad U at point j, held in columns [0, d) of `ab` -> columns [d, 2 d)
   auto energy_eval = [&](float* ab, int j, double* Ud) -> int {
-    if (!builtin) {
+    if (user) {      // the caller enqueues U / grad U of the (N, d) block at ab (row stride L) on this stream
+      const int r = a->energy_cb(a->energy_cb_user, ab, L, N, d, Ud, ab + d, L, stream);
+      return r ? fail(L2HMC_ERR_ARG, "the energy callback failed (returned %s%lld)", "", (long long)r) : L2HMC_OK;
+    }
+    if (vae) {
       vae_energy_keep(s, dec, a->aux, ab, L, N, d, dws, w + f.lg, w + f.rowsum, Ud, ab + d, L, dec_point(j));
       return L2HMC_OK;
     }
@@ -826,7 +836,10 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
       return L2HMC_OK;
     }
     have_carry = false;
-    if (!builtin) {
+    if (user) {
+      const int r = a->hvp_cb(a->energy_cb_user, ab, L, uu, d, N, d, hv, d, stream);
+      if (r) return fail(L2HMC_ERR_ARG, "the Hessian-vector callback failed (returned %s%lld)", "", (long long)r);
+    } else if (vae) {
       vae_hvp(s, dec, N, d, dws, dec_point(j), p, w, uu, hv);
     } else if (a->energy->kind == L2HMC_ENERGY_GMM || a->energy->kind == L2HMC_ENERGY_FUNNEL) {
       hipLaunchKernelGGL(k_hvp_chain, dim3(nblk(N)), dim3(256), 0, s, a->energy->kind, ab, L, uu, hv, dg, a->energy->mu, a->hess,

@@ -87,8 +87,9 @@ class UserEnergy(EnergyFunction):
     This is the SLOW path, by construction: U and grad U are computed by the caller's torch code between kernel
     launches (`grad_fn(x[, aux=...]) -> (N, d)` if given, else autograd of `fn`), one host round trip per leapfrog step;
     the leapfrog half-updates, the S/T/Q nets, the log-determinant, the accept probability and the MH select stay on
-    the library's HIP kernels (GEMM engine, `l2hmc_trajectory_split`).  Training the sampler on such a target would
-    need Hessian-vector products of U and is not implemented."""
+    the library's HIP kernels (GEMM engine, `l2hmc_trajectory_split`).  Training the sampler on such a target
+    (`Trainer(dynamics)`: the GEMM-engine trainer) additionally asks for Hessian-vector products of U, one per leapfrog
+    step -- `hvp()` below: double backward through `fn`, or one backward through a differentiable `grad_fn`."""
 
     def __init__(self, fn, grad_fn=None, x_dim=None):
         EnergyFunction.__init__(self, ENERGY_USER, x_dim=x_dim)
@@ -136,6 +137,24 @@ class UserEnergy(EnergyFunction):
             U = None if U is None else U.double() / float(temperature)
             g = None if g is None else g / float(temperature)
         return (U.double() if (U is not None and want_U) else None), (g.to(torch.float32) if g is not None else None)
+
+    def hvp(self, x, u, aux=None):
+        """(d^2 U / dx^2)(x) u, shape (N, d): what the training loss needs where it back-propagates through grad U
+        (utils/dynamics.py:218 inside the differentiated graph)."""
+        x, u = as_device_f32(x), as_device_f32(u)
+        with torch.enable_grad():
+            xr = x.clone().requires_grad_(True)
+            if self.grad_fn is None:
+                Ur = self._call(self.fn, xr, aux)
+                g, = torch.autograd.grad(Ur.sum(), xr, create_graph=True)
+            else:
+                g = self._call(self.grad_fn, xr, aux)
+                if not g.requires_grad:
+                    raise NotImplementedError("training needs Hessian-vector products: grad_energy must be torch code "
+                                              "that autograd can differentiate (or leave it out and pass a differentiable "
+                                              "energy function)")
+            hv, = torch.autograd.grad((g * u).sum(), xr)
+        return hv.to(torch.float32)
 
     def __call__(self, x, aux=None, *args, **kwargs):
         return self.evaluate(x, aux=aux)[0].to(torch.float32)

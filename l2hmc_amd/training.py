@@ -38,10 +38,8 @@ def _numel(code, d, H):
 
 class Trainer(object):
     def __new__(cls, dynamics, *args, **kwargs):
-        if getattr(dynamics, "_user", False):
-            raise NotImplementedError("training differentiates through grad U (Hessian-vector products of the target): "
-                                      "implemented for the built-in targets and the decoder posterior, not for a "
-                                      "caller-supplied energy callable")
+        if getattr(dynamics, "_user", False) and cls is not SplitTrainer and cls is not Trainer:
+            raise NotImplementedError("a caller-supplied energy trains on the GEMM engine: use Trainer(dynamics)")
         # samplers that run on the GEMM engine (nets wider than H = 15, the image-conditioned VAE sampler) train there
         if cls is Trainer and getattr(dynamics, "_split", False):
             return object.__new__(SplitTrainer)
@@ -313,8 +311,12 @@ class SplitTrainer(Trainer):
         self._mlp3_struct = mlp3_struct
         self.dyn = dynamics
         self.vae = bool(dynamics._vae)
-        self.scale = float(scale) if scale is not None else (1.0 if self.vae else 0.1)
-        self.clip_norm = clip_norm if clip_norm is not None else (5.0 if self.vae else None)   # mnist_vae.py:258
+        self.user = bool(getattr(dynamics, "_user", False))     # U, grad U and Hessian-vector products by callback (slow path)
+        # the VAE experiment's sampler (mnist_vae.py:185-262): the built-in decoder posterior, or the same model handed
+        # over as a plain closure energy(z, aux) with the image-conditioned nets
+        self.image_sampler = self.vae or (self.user and dynamics._xw["aux_encoder"] is not None)
+        self.scale = float(scale) if scale is not None else (1.0 if self.image_sampler else 0.1)
+        self.clip_norm = clip_norm if clip_norm is not None else (5.0 if self.image_sampler else None)   # mnist_vae.py:258
         self.lr0, self.decay_steps, self.decay_rate = float(lr), int(decay_steps), float(decay_rate)
         self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
         self.seed = int(seed)
@@ -361,7 +363,7 @@ class SplitTrainer(Trainer):
         self._layout = None
 
     def lr_at(self, step):
-        if self.vae and self.decay_steps <= 0:
+        if self.image_sampler and self.decay_steps <= 0:
             return self.lr0
         return Trainer.lr_at(self, step)
 
@@ -390,7 +392,43 @@ class SplitTrainer(Trainer):
         a.xnet, a.vnet, a.H = C.pointer(xs), C.pointer(vs), dyn.H
         a.aux_encoder = C.pointer(enc_s) if enc_s is not None else None
         keep = None
-        if self.vae:
+        cb_error = []
+        if self.user:
+            fn, ws = dyn._fn, self._ws
+            base = ws.data_ptr()
+            if self.enc is not None:
+                if aux is None:
+                    raise ValueError("the image-conditioned sampler needs aux=")
+                aux = as_device_f32(aux, dyn.device)
+                a.aux = aux.data_ptr()
+
+            def view(ptr, n, dd, ld):             # an (n, dd) block of the workspace the library points at
+                return ws.as_strided((n, dd), (ld, 1), (ptr - base) // 4)
+
+            def energy_cb(_user, xp, ldx, n, dd, Up, gp, ldg, _stream):
+                try:
+                    U, g = fn.evaluate(view(xp, n, dd, ldx), 1.0, want_U=bool(Up), want_grad=True, aux=aux)
+                    if tuple(g.shape) != (n, dd):
+                        raise ValueError("grad_energy must return shape (N, d), got %s" % (tuple(g.shape),))
+                    view(gp, n, dd, ldg).copy_(g)
+                    if Up:
+                        o = (Up - base) // 4
+                        ws[o:o + 2 * n].view(torch.float64).copy_(U)
+                    return 0
+                except Exception as e:            # never let an exception cross the C frame
+                    cb_error.append(e)
+                    return 1
+
+            def hvp_cb(_user, xp, ldx, up, ldu, n, dd, hp, ldh, _stream):
+                try:
+                    view(hp, n, dd, ldh).copy_(fn.hvp(view(xp, n, dd, ldx), view(up, n, dd, ldu), aux=aux))
+                    return 0
+                except Exception as e:
+                    cb_error.append(e)
+                    return 1
+            keep = (_ffi.ENERGY_CALLBACK(energy_cb), _ffi.HVP_CALLBACK(hvp_cb))     # alive for the duration of the call
+            a.energy_cb, a.hvp_cb = C.cast(keep[0], C.c_void_p), C.cast(keep[1], C.c_void_p)
+        elif self.vae:
             if aux is None:
                 raise ValueError("the image-conditioned sampler needs aux=")
             aux = as_device_f32(aux, dyn.device)
@@ -420,7 +458,10 @@ class SplitTrainer(Trainer):
         a.dLv_in, a.dlogjac_in = _ffi.ptr(dLv_in), _ffi.ptr(dlogjac_in)
         a.Lv_out, a.logjac_out = _ffi.ptr(Lv_out), _ffi.ptr(logjac_out)
         a.gemm_mode = int(getattr(dyn, "gemm_mode", 0))
-        _ffi.check(L.l2hmc_train_split_grad(a, _ffi.current_stream(dyn.device)))
+        rc = L.l2hmc_train_split_grad(a, _ffi.current_stream(dyn.device))
+        if cb_error:
+            raise cb_error[0]
+        _ffi.check(rc)
         return Lx, p, v1
 
     def _publish_grads(self):
@@ -430,7 +471,7 @@ class SplitTrainer(Trainer):
             self.dyn.alpha.grad = (self.flat[self.alpha_index] * torch.exp(self.dyn.alpha.detach())).reshape(self.dyn.alpha.shape)
 
     def loss_and_grad(self, x, z=None, draws=None):
-        if self.vae:
+        if self.image_sampler:
             raise TypeError("the VAE sampler's objective needs the images: use sampler_loss_and_grad")
         loss, Lx, px = Trainer.loss_and_grad(self, x, z, draws)
         self._publish_grads()
@@ -458,7 +499,7 @@ class SplitTrainer(Trainer):
         self.dyn._packed_key = None
 
     def step(self, x, u=None):
-        if self.vae:
+        if self.image_sampler:
             raise TypeError("the VAE sampler trains with sampler_step(aux, latent_q, log_sigma)")
         dyn = self.dyn
         x = as_device_f32(x, dyn.device)
@@ -502,8 +543,8 @@ class SplitTrainer(Trainer):
         draws: optional list (one dict per MH iteration) of injected randomness (tests): {v, dir, u} for a plain
         proposal; {nb_steps, init_v, v: [..], dir: [..], u} for a composition.
         Returns (loss, latent_T, px of the last iteration)."""
-        if not self.vae:
-            raise TypeError("sampler_loss_and_grad is the VAE experiment's objective")
+        if not self.image_sampler:
+            raise TypeError("sampler_loss_and_grad is the VAE experiment's objective (an image-conditioned sampler)")
         dyn = self.dyn
         dev, gen = dyn.device, dyn.generator
         x = as_device_f32(latent_q, dev)

@@ -311,16 +311,17 @@ def propose_loss_and_grad(x0, v0, direction, target, xnet, vnet, eps, mask, T, s
     return loss, x, p, {'xnet': gx, 'vnet': gv, 'eps': float(np.sum(deps))}
 
 
-def training_loss_and_grad(g, dtype=np.float64):
+def training_loss_and_grad(g, dtype=np.float64, target=None):
     """Full notebook loss on a golden-shaped dict `g` (x with its draws + z with its draws):
-    returns (loss, grads keyed like the golden: 'xnet.W1', ..., 'alpha')."""
+    returns (loss, grads keyed like the golden: 'xnet.W1', ..., 'alpha').  `target`: an object with energy / grad /
+    hessvec (like the classes above) instead of the one `g` names -- tests of caller-supplied energies."""
     xn = {k: g['xnet.' + k] for k in NET_KEYS}
     vn = {k: g['vnet.' + k] for k in NET_KEYS}
     total, out = 0.0, {}
     for tag, start in (('x', g['x']), ('z', g['z'])):
         dr = g[tag + '.dir']
         v0 = np.where(dr[:, None] != 0, g[tag + '.v_fwd'], g[tag + '.v_bwd'])
-        loss, Lx, p, gr = propose_loss_and_grad(start, v0, dr, target_of(g, dtype), xn, vn,
+        loss, Lx, p, gr = propose_loss_and_grad(start, v0, dr, target if target is not None else target_of(g, dtype), xn, vn,
                                                 g['eps'], g['mask'], int(g['T']), dtype=dtype)
         total += loss
         for net in ('xnet', 'vnet'):

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_size_queries():
     L = _ffi.lib()
-    assert L.l2hmc_abi_version() == 2
+    assert L.l2hmc_abi_version() == 3 == _ffi.ABI_VERSION
     # MFMA fragments (5 NT + 2 groups of 256 + 32 NT scales per net) + the lane layout (traj_lane.hpp: rows of RS = 12)
     lane = (2 * 50 * 12 + 3 * 12 + 10 * 12 + 12 + 25 * (6 * 10 + 12) + 3) // 4 * 4      # DP = 50 rows, 10 units
     assert L.l2hmc_packed_nets_floats(50, 10) == 2 * ((5 * 4 + 2) * 256 + 32 * 4) + 2 * lane

@@ -287,6 +287,93 @@ def _banana_torch(x, b=0.3, s=2.0):
     return 0.5 * x[:, 0] ** 2 / (s * s) + 0.5 * (t * t).sum(1)
 
 
+class _BananaTarget:
+    """The banana density above with its Hessian-vector product, for oracle/l2hmc_train_oracle.py (dtype of the inputs)."""
+
+    def __init__(self, b=0.3, s=2.0):
+        self.b, self.s = b, s
+
+    def energy(self, x):
+        return _banana_np(x, self.b, self.s)[0]
+
+    def grad(self, x):
+        return _banana_np(x, self.b, self.s)[1]
+
+    def hessvec(self, x, u):
+        b, s = self.b, self.s
+        t = x[:, 1:] + b * x[:, :1] ** 2 - s * s * b
+        out = np.empty_like(x)
+        h00 = 1.0 / (s * s) + 2 * b * np.sum(t, axis=1) + 4 * b * b * x[:, 0] ** 2 * (x.shape[1] - 1)
+        out[:, 0] = u[:, 0] * h00 + 2 * b * x[:, 0] * np.sum(u[:, 1:], axis=1)
+        out[:, 1:] = 2 * b * x[:, :1] * u[:, :1] + u[:, 1:]
+        return out
+
+
+@pytest.mark.parametrize("H,explicit_grad", [(10, False), (24, True)])
+def test_training_on_a_user_energy_matches_the_float64_oracle(H, explicit_grad):
+    """The notebook loss on a target that is NOT in utils/distributions.py, given as a plain torch callable: `Trainer`
+    runs on the GEMM engine, U / grad U / Hessian-vector products come from autograd through the caller's code
+    (double backward, or one backward through the caller's own gradient function) -- loss, proposals and every
+    parameter gradient against oracle/l2hmc_train_oracle.py with the same density in numpy float64; then a few
+    optimiser steps."""
+    import torch
+    from oracle import l2hmc_train_oracle as TO
+    from l2hmc_amd import Dynamics, layers
+    from l2hmc_amd.training import SplitTrainer, Trainer
+    d, T, N = 5, 4, 52
+    g = synthetic_case("roughwell_easy", d, H=H, T=T, N=N, seed=7 + H, head_std=0.2)
+    rng = np.random.RandomState(11)
+    g["x"] = (rng.randn(N, d) * np.array([2.0] + [1.0] * (d - 1))).astype(np.float32)
+    g["z"] = rng.randn(N, d).astype(np.float32)
+    for pre in ("x.", "z."):
+        g[pre + "dir"] = rng.randint(0, 2, N).astype(np.uint8)
+        g[pre + "v_fwd"] = rng.randn(N, d).astype(np.float32)
+        g[pre + "v_bwd"] = rng.randn(N, d).astype(np.float32)
+    ref_loss, ref = TO.training_loss_and_grad(g, np.float64, target=_BananaTarget())
+    grad_fn = None
+    if explicit_grad:
+        def grad_fn(x):
+            t = x[:, 1:] + 0.3 * x[:, :1] ** 2 - 4 * 0.3
+            return torch.cat([x[:, :1] / 4 + 0.6 * x[:, :1] * t.sum(1, keepdim=True), t], dim=1)
+    dyn = Dynamics(d, _banana_torch, T=T, eps=float(g["eps"]), net_factory=layers.stq_network(H), grad_energy=grad_fn)
+    dyn.mask = g["mask"]
+    with torch.no_grad():
+        dyn.alpha.fill_(float(np.log(g["eps"])))
+        for w, pre in ((dyn._xw, "xnet."), (dyn._vw, "vnet.")):
+            for k in O.NET_KEYS:
+                w[k].copy_(torch.as_tensor(g[pre + k]).reshape(w[k].shape))
+    tr = Trainer(dyn)
+    assert isinstance(tr, SplitTrainer) and tr.user
+    draws = {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
+             "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
+             "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
+    loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+    assert abs(float(loss) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (float(loss), ref_loss)
+    assert rel_err(to_np(Lx), ref["Lx"]) < TRAJ_TOL and abs_err(to_np(px), ref["px"]) < P_TOL
+    scale = max(float(np.abs(ref[n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+    worst = 0.0
+    for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
+        for k in O.NET_KEYS:
+            r = np.asarray(ref["%s.%s" % (n, k)])
+            worst = max(worst, float(np.abs(to_np(w[k].grad).reshape(r.shape) - r).max()))
+    ga = float(dyn.alpha.grad)
+    print("banana training H=%d: loss %.6e (ref %.6e)  max |dgrad| %.2e (scale %.2e)  alpha %.5e vs %.5e"
+          % (H, float(loss), ref_loss, worst, scale, ga, float(ref["alpha"])))
+    assert worst < 2e-4 * scale
+    assert abs(ga - float(ref["alpha"])) < 2e-4 * max(scale, abs(float(ref["alpha"])))
+    x = to_dev(g["x"])
+    for _ in range(3):
+        x = tr.step(x)[2]
+    assert torch.isfinite(x).all()
+
+    # an exception inside the caller's code surfaces as itself, not as a crash in the C frame
+    def bad(x):
+        raise ValueError("boom in the user's energy")
+    dyn2 = Dynamics(d, bad, T=T, eps=0.1, net_factory=layers.stq_network(H))
+    with pytest.raises(ValueError, match="boom"):
+        Trainer(dyn2).loss_and_grad(to_dev(g["x"]), draws=draws)
+
+
 @pytest.mark.parametrize("H,hmc,explicit_grad", [(10, False, False), (24, False, True), (10, True, False)])
 def test_user_energy_banana_matches_the_oracle(H, hmc, explicit_grad):
     """A target that is NOT in utils/distributions.py (a banana density), given to `Dynamics` as a plain torch callable:
@@ -421,6 +508,56 @@ def test_the_vae_posterior_as_a_plain_closure_matches_the_reference_golden():
     assert rel_err(to_np(Lx), to_np(bLx)) < 5e-5 and abs_err(to_np(px), to_np(bpx)) < 5e-5
     with pytest.raises(ValueError, match="aux"):
         propose(x, dyn)
+
+
+def test_training_the_vae_sampler_on_a_plain_closure_matches_the_reference_graph():
+    """mnist_vae.py:185-226's sampler objective with the model handed over as the reference hands it over -- the closure
+    energy(z, aux) of :122-126 over a decoder from the layer kit, no bespoke energy class: loss, proposal, accept
+    probability and the gradient of every sampler variable (image branch and alpha included) against `tf.gradients` of
+    the reference's own graph (fixture `train_vae_small`); U, grad U and the Hessian-vector products come from autograd
+    through the closure."""
+    import torch
+    import torch.nn.functional as F
+    from l2hmc_amd import Dynamics, vae
+    from l2hmc_amd.training import SplitTrainer, Trainer
+    from tests.helpers import _load_mlp
+    g = load("train_vae_small")
+    d, H = int(g["x_dim"]), int(g["H"])
+    dec = vae.make_decoder(d, g["dec.W1"].shape[1], g["dec.W3"].shape[1])
+    enc = vae.make_encoder_sampler(g["enc.W1"].shape[0], g["enc.W1"].shape[1], H)
+    _load_mlp(dec, g, "dec.")
+    _load_mlp(enc, g, "enc.")
+
+    def energy(z, aux=None):                                        # mnist_vae.py:122-126
+        logits = dec(z)
+        return F.binary_cross_entropy_with_logits(logits, aux, reduction="none").sum(1) + 0.5 * (z * z).sum(1)
+
+    dyn = Dynamics(d, energy, T=int(g["T"]), eps=float(g["eps"]), net_factory=vae.sampler_net_factory(d, enc, H, H))
+    dyn.mask = g["mask"]
+    with torch.no_grad():
+        dyn.alpha.fill_(float(np.log(g["eps"])))
+        for w, pre in ((dyn._xw, "xnet."), (dyn._vw, "vnet.")):
+            for k in O.NET_KEYS:
+                w[k].copy_(torch.as_tensor(g[pre + k]).reshape(w[k].shape))
+    tr = Trainer(dyn)
+    assert isinstance(tr, SplitTrainer) and tr.user and tr.image_sampler and not tr.vae
+    draws = {"v": np.where(g["prop.dir"][:, None] != 0, g["prop.v_fwd"], g["prop.v_bwd"]), "dir": g["prop.dir"], "u": g["prop.u"]}
+    loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(g["log_sigma"]), MH=1, draws=[draws])
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    assert abs_err(to_np(px), g["px"]) < P_TOL and rel_err(to_np(x_T), g["x_next"]) < TRAJ_TOL
+    scale = max(float(np.abs(g["grad." + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+    worst = 0.0
+    for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
+        for k in O.NET_KEYS:
+            ref = g["grad.%s.%s" % (n, k)]
+            worst = max(worst, float(np.abs(to_np(w[k].grad).reshape(ref.shape) - ref).max()))
+    assert worst < 2e-4 * scale, (worst, scale)
+    e = dyn._xw["aux_encoder"]
+    for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
+        ref = g["grad.enc." + k]
+        assert np.abs(to_np(e[k].grad).reshape(ref.shape) - ref).max() < 2e-4 * max(float(np.abs(ref).max()), 1e-2 * scale), ("enc", k)
+    assert abs(float(dyn.alpha.grad) - float(g["grad.alpha"])) < 2e-4 * max(scale, abs(float(g["grad.alpha"])))
+    print("closure-trained VAE sampler: loss %.6e (ref %.6e)  max |dgrad| %.2e (scale %.2e)" % (float(loss), float(g["loss"]), worst, scale))
 
 
 @pytest.mark.parametrize("gemm_mode", [0, 1])

@@ -119,9 +119,8 @@ def test_product_refuses_cpu_tensors_and_non_callable_energies():
     assert isinstance(dyn._fn, D.UserEnergy) and dyn._split and dyn._user
     with pytest.raises(RuntimeError, match="no CPU path"):
         dyn.energy(torch.zeros(2, 2))
-    from l2hmc_amd.training import Trainer
-    with pytest.raises(NotImplementedError, match="caller-supplied"):
-        Trainer(dyn)
+    with pytest.raises(RuntimeError, match="no CPU path"):          # ... nor do its Hessian-vector products (training)
+        dyn._fn.hvp(torch.zeros(2, 2), torch.ones(2, 2))
 
 
 def test_bench_host_helpers():
