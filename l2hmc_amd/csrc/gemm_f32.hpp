@@ -244,7 +244,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f4 (&acc)
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
       const long long m = m0 + wm + 16 * j + c;
-      if (q == 0 && m < g.M) g.rowsum[m * (WAVES_N * g.n_tiles) + WAVES_N * blockIdx.x + (w % WAVES_N)] = g.beta * s;
+      if (q == 0 && m < g.M) g.rowsum[m * (WAVES_N * g.n_tiles) + WAVES_N * (n0 / (16 * WNB * WAVES_N)) + (w % WAVES_N)] = g.beta * s;
     }
   }
 }
@@ -265,8 +265,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int wm = (w / WAVES_N) * 16 * WMB, wn = (w % WAVES_N) * 16 * WNB;    // this wave's block
-  const long long m0 = (long long)blockIdx.y * TM;
-  const int n0 = blockIdx.x * TN;
+  // Tile of this workgroup.  Workgroups are dispatched round-robin over the 8 XCDs in linear order (x fastest), each XCD
+  // with its own L2: with the plain (n-tile, m-tile) = (blockIdx.x, blockIdx.y) mapping and 8 n-tiles per row every XCD
+  // reads ALL activation rows.  XCD-aware form (m-tile count a multiple of 8): XCD j owns the m-tiles j, j + 8, ... and
+  // walks their n-tiles -- an activation tile is fetched into one L2 only.
+  int bx = blockIdx.x, by = blockIdx.y;
+#ifndef L2HMC_GEMM_NO_XCD_MAP
+  if ((gridDim.y & 7) == 0 && gridDim.y >= 16) {
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, k = lin >> 3;
+    by = (int)((k / gridDim.x) * 8 + xcd);
+    bx = (int)(k % gridDim.x);
+  }
+#endif
+  const long long m0 = (long long)by * TM;
+  const int n0 = bx * TN;
 
   // global -> register staging: a row of the k-tile is GK / 4 quads; thread loads quad (tid % QPR) of rows
   // (tid / QPR) + RPP i
