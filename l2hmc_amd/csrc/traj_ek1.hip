@@ -1,6 +1,6 @@
 // Fused L2HMC kernels specialised for energy kind 1 (gauss_diag); see l2hmc_kernels.hpp.
 #include "traj_small.hpp"
-#include "traj_tile.hpp"
+#include "traj_fast.hpp"
 
 namespace l2hmc {
 #define L2HMC_CALL_TRAJ_1(DTc, NWc)                                              \
@@ -16,22 +16,4 @@ namespace l2hmc {
 #define L2HMC_CALL_PA_1(DTc, NWc) return launch(paccept_kernel<1, DTc, NWc>, k, NWc, lds, s);
 L2HMC_DEFINE_LAUNCH_EK(1)
 
-template <class K>
-static int launch_tile(K kern, const KArgs& k, long long lds, hipStream_t s) {
-  if (lds > kMaxLdsBytes) return fail(L2HMC_ERR_UNSUPPORTED, "tile kernel: %s%lld bytes of LDS needed", "", lds);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  }
-  const long long blocks = (k.N + 63) / 64;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), (size_t)lds, s, k);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
-  return L2HMC_OK;
-}
-template <>
-int launch_tile_ek<1>(const KArgs& k, int DT, int KH, long long lds, hipStream_t s) {
-  if (DT == 3) return KH <= 3 ? launch_tile(traj_tile_kernel<1, 3, 3, 4>, k, lds, s) : launch_tile(traj_tile_kernel<1, 3, 4, 4>, k, lds, s);
-  return KH <= 3 ? launch_tile(traj_tile_kernel<1, 4, 3, 4>, k, lds, s) : launch_tile(traj_tile_kernel<1, 4, 4, 4>, k, lds, s);
-}
 }  // namespace l2hmc

@@ -1,0 +1,32 @@
+// The one-wave-per-tile kernels (traj_tile.hpp) of both elementwise targets, in a translation unit of their own: the
+// instruction-lean 4-wave kernels next door (traj_ek1) are compiled with LLVM's max-ILP scheduling strategy
+// (+1 % on the headline configuration), which costs this kernel registers it does not have (256 VGPRs + scratch, -2 % at
+// 16 384 chains: profiles/r03_exchange_variants.txt).
+#include "traj_tile.hpp"
+
+namespace l2hmc {
+
+template <class K>
+static int launch_tile(K kern, const KArgs& k, long long lds, hipStream_t s) {
+  if (lds > kMaxLdsBytes) return fail(L2HMC_ERR_UNSUPPORTED, "tile kernel: %s%lld bytes of LDS needed", "", lds);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const long long blocks = (k.N + 63) / 64;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), (size_t)lds, s, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+template <>
+int launch_tile_ek<1>(const KArgs& k, int DT, int KH, long long lds, hipStream_t s) {
+  if (DT == 3) return KH <= 3 ? launch_tile(traj_tile_kernel<1, 3, 3, 4>, k, lds, s) : launch_tile(traj_tile_kernel<1, 3, 4, 4>, k, lds, s);
+  return KH <= 3 ? launch_tile(traj_tile_kernel<1, 4, 3, 4>, k, lds, s) : launch_tile(traj_tile_kernel<1, 4, 4, 4>, k, lds, s);
+}
+template <>
+int launch_tile_ek<4>(const KArgs& k, int DT, int KH, long long lds, hipStream_t s) {
+  if (DT == 3) return KH <= 3 ? launch_tile(traj_tile_kernel<4, 3, 3, 4>, k, lds, s) : launch_tile(traj_tile_kernel<4, 3, 4, 4>, k, lds, s);
+  return KH <= 3 ? launch_tile(traj_tile_kernel<4, 4, 3, 4>, k, lds, s) : launch_tile(traj_tile_kernel<4, 4, 4, 4>, k, lds, s);
+}
+}  // namespace l2hmc
