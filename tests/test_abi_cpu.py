@@ -24,6 +24,8 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_size_queries():
     L = _ffi.lib()
     assert L.l2hmc_abi_version() == 3 == _ffi.ABI_VERSION
+    hdr = open(os.path.join(ROOT, "include", "l2hmc.h")).read()
+    assert int(re.search(r"#define L2HMC_ABI_VERSION (\d+)", hdr).group(1)) == _ffi.ABI_VERSION
     # MFMA fragments (5 NT + 2 groups of 256 + 32 NT scales per net) + the lane layout (traj_lane.hpp: rows of RS = 12)
     lane = (2 * 50 * 12 + 3 * 12 + 10 * 12 + 12 + 25 * (6 * 10 + 12) + 3) // 4 * 4      # DP = 50 rows, 10 units
     assert L.l2hmc_packed_nets_floats(50, 10) == 2 * ((5 * 4 + 2) * 256 + 32 * 4) + 2 * lane
@@ -64,3 +66,10 @@ def test_struct_sizes_are_checked_against_the_library():
     for which, mirror in enumerate(_ffi.STRUCTS):
         assert L.l2hmc_struct_bytes(which) == ctypes.sizeof(mirror), mirror.__name__
     assert L.l2hmc_struct_bytes(99) == -1
+
+
+def test_graft_entry_build_is_consistent_with_the_library():
+    """The driver's build check: `__graft_entry__.build()` (make is a no-op on an up-to-date tree) must accept the
+    library it has just built -- its ABI assertion follows the binding's version."""
+    import __graft_entry__ as ge
+    ge.build()
