@@ -1,5 +1,5 @@
 // The one-wave-per-tile kernels (traj_tile.hpp) of both elementwise targets, in a translation unit of their own: the
-// instruction-lean 4-wave kernels next door (traj_ek1) are compiled with LLVM's max-ILP scheduling strategy
+// instruction-lean 4-wave kernels next door (traj_ek1, traj_ek4) are compiled with LLVM's max-ILP scheduling strategy
 // (+1 % on the headline configuration), which costs this kernel registers it does not have (256 VGPRs + scratch, -2 % at
 // 16 384 chains: profiles/r03_exchange_variants.txt).
 #include "traj_tile.hpp"

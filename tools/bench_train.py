@@ -17,6 +17,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
+from l2hmc_amd import _ffi
+if os.environ.get("L2HMC_LIB"):          # kernel experiments: an alternative build of the library
+    _ffi.LIB_PATH = os.path.abspath(os.environ["L2HMC_LIB"])
 from l2hmc_amd import Dynamics, distributions as D, layers
 from l2hmc_amd.training import Trainer
 
