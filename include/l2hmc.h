@@ -199,6 +199,12 @@ int l2hmc_p_accept(const L2hmcEnergy* energy, const float* x0, const float* v0,
 int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const float* u,
                     int64_t n_chains, int32_t d, float* x_next, void* stream);
 
+/* The notebook loss from the per-chain arguments v1 the training entry points leave behind (SCGExperiment.ipynb raw 156-169:
+ * loss = scale * mean(1 / v1) - mean(v1) / scale over x- and z-proposals): out3 = { sum 1 / v1, sum v1,
+ * inv_n * (scale * out3[0] - out3[1] / scale) } in double, one fixed-order reduction (bitwise reproducible) -- ONE launch
+ * instead of a dozen elementwise framework kernels per optimiser step.  Sharded runs all-reduce out3[0..1] themselves. */
+int l2hmc_loss_terms(const float* v1, int64_t n, float scale, double inv_n, double* out3, void* stream);
+
 /* ---- split engine: wide / image-conditioned nets + VAE latent-posterior energy (config 5) ------ */
 /* Linear-softplus-Linear-softplus-Linear with reference-layout weights W (in, out), b (out):
  * the VAE decoder (mnist_vae.py:104-111) and the sampler's image branch `encoder_sampler`

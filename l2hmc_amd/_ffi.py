@@ -113,6 +113,7 @@ SYMBOLS = {
     "l2hmc_p_accept": (C.c_int, [C.POINTER(L2hmcEnergy), _fp, _fp, _fp, _fp, _fp, C.c_int64,
                                  C.c_int32, _fp, _fp]),
     "l2hmc_mh_select": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp]),
+    "l2hmc_loss_terms": (C.c_int, [_fp, C.c_int64, C.c_float, C.c_double, _fp, _fp]),
     "l2hmc_split_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                  C.POINTER(L2hmcMlp3), C.POINTER(L2hmcMlp3)]),
     "l2hmc_trajectory_split": (C.c_int, [C.POINTER(L2hmcSplitArgs), _fp]),

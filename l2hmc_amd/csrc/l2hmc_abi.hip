@@ -117,6 +117,27 @@ __global__ void pack_gauss_kernel(const float* S, int d, int NT, float* out) {
   out[idx] = (a < d && b < d) ? 0.5f * (S[a * d + b] + S[b * d + a]) : 0.f;
 }
 
+// sum 1 / v and sum v in double: one workgroup, fixed order (thread t takes elements t, t + 256, ...; LDS tree)
+__global__ __launch_bounds__(256) void loss_terms_kernel(const float* v1, long long n, float scale, double inv_n, double* out3) {
+  __shared__ double sa[256], sb[256];
+  double a = 0.0, b = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) {
+    const double v = (double)v1[i];
+    a += 1.0 / v;
+    b += v;
+  }
+  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out3[0] = sa[0]; out3[1] = sb[0];
+    out3[2] = inv_n * ((double)scale * sa[0] - sb[0] / (double)scale);
+  }
+}
+
 __global__ void mh_select_kernel(const float* x, const float* Lx, const float* px, const float* u,
                                  long long N, int d, float* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -720,6 +741,14 @@ int l2hmc_mh_select(const float* x, const float* Lx, const float* px, const floa
   const long long n = n_chains * (long long)d;
   hipLaunchKernelGGL(mh_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, x, Lx, px, u, (long long)n_chains, d, x_next);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int l2hmc_loss_terms(const float* v1, int64_t n, float scale, double inv_n, double* out3, void* stream) {
+  if (!v1 || !out3 || n < 0 || !(scale > 0.f)) return fail(L2HMC_ERR_ARG, "l2hmc_loss_terms: bad argument%s");
+  hipLaunchKernelGGL(loss_terms_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v1, (long long)n, scale, inv_n, out3);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;

@@ -37,8 +37,13 @@ __device__ unsigned long long tt_t0;
       tt_t0 = tt_t1;                                                                    \
     }                                                                                   \
   } while (0)
+#define TT_START()                                                                      \
+  do {                                                                                  \
+    if (blockIdx.x == 0 && threadIdx.x == 0) tt_t0 = __builtin_amdgcn_s_memtime();     \
+  } while (0)
 #else
 #define TT_MARK(i)
+#define TT_START()
 #endif
 
 struct TArgs {
@@ -858,8 +863,8 @@ inline bool train_small_ok(int ek, int d, int H) {
 }
 template <int EK>
 int launch_train_small(const TArgs& k, int KH, unsigned blocks, long long lds, hipStream_t s) {
-  if (KH <= 3) hipLaunchKernelGGL((train_small_kernel<EK, 3>), dim3(blocks), dim3(64), (size_t)lds, s, k);
-  else hipLaunchKernelGGL((train_small_kernel<EK, 4>), dim3(blocks), dim3(64), (size_t)lds, s, k);
+  if (KH <= 3) hipLaunchKernelGGL((train_small_kernel<EK, 3>), dim3(blocks), dim3(128), (size_t)lds, s, k);
+  else hipLaunchKernelGGL((train_small_kernel<EK, 4>), dim3(blocks), dim3(128), (size_t)lds, s, k);
   return L2HMC_OK;
 }
 

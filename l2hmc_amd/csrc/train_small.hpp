@@ -28,17 +28,43 @@ __host__ __device__ inline TSLayout ts_layout(int T) {
   L.tb = p; p += 2 * T * 16;
   L.msk = p; p += (T * 4 + 3) / 4 * 4;
   L.trg = p; p += (2 * T + 3) / 4 * 4;
-  L.tr = p; p += 7 * 320 + 32;                // seven 16 x 20 transpose scratches (one per operand of a back-propagation:
-                                              // written together, read together) + (cos, sin) of the 16 chains
+  L.tr = p; p += 2 * 7 * 320;                 // two buffers of seven 16 x 20 transpose scratches (one per operand of a
+                                              // back-propagation): wave 0 writes them, wave 1 reads them one barrier later
   L.total = p;
   return L;
 }
+// Phase timers of profiling builds (-DL2HMC_TRAIN_TIMING, tools/train_phase_timing.py): accumulated in REGISTERS and written
+// once at the end (a global read-modify-write per mark would cost more than the phases it brackets).
+#ifdef L2HMC_TRAIN_TIMING
+#define TS_DECL unsigned long long ts_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ts_t0 = __builtin_amdgcn_s_memtime()
+#define TS_MARK(i)                                                          \
+  do {                                                                      \
+    const unsigned long long ts_t1 = __builtin_amdgcn_s_memtime();          \
+    ts_acc[i] += ts_t1 - ts_t0;                                             \
+    ts_t0 = ts_t1;                                                          \
+  } while (0)
+#define TS_FLUSH()                                                          \
+  do {                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                                \
+      for (int ts_i = 0; ts_i < 9; ++ts_i) tt_acc[ts_i] += ts_acc[ts_i];    \
+  } while (0)
+#else
+#define TS_DECL
+#define TS_MARK(i)
+#define TS_FLUSH()
+#endif
 constexpr int TS_CK = 5;                      // checkpointed scalars per lane and step: x, v, v_half, y, x'
 
 template <int EK, int KH>
-__global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
+__global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x;
+  TS_DECL;
+  // Two waves per 16-chain tile.  Wave 0 runs the trajectory and the adjoint recursion (the dependency chain of the step);
+  // wave 1 only accumulates the weight-gradient tiles: after every back-propagation wave 0 leaves the seven operands in LDS
+  // (double-buffered) and both waves meet at one barrier -- the operand transposes and the 20 MFMAs of the chain-contractions
+  // (40 % of a single-wave launch, tools/train_phase_timing.py) are off the critical path.  Same arithmetic, same order.
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, q = lane >> 4;
   const int d = A.d, H = A.H, T = A.T;
   const TSLayout L = ts_layout(T);
@@ -59,91 +85,108 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
   auto unit_row = [&](int i) { return ((i & 3) < KH) ? (i >> 2) * KH + (i & 3) : -1; };
 
   // ---- stage: weight fragments (A operands; element (lane (i, kq), r): row i, k-step r, k = kq), tables ------------------
-  for (int idx = lane; idx < 2 * ng * 256; idx += 64) {
-    const int net = idx >= ng * 256, rem = idx - net * ng * 256;
-    const int g = rem >> 8, ln = (rem >> 2) & 63, r = rem & 3, i = ln & 15, kq = ln >> 4;
-    const int ui = unit_row(i), uk = (r < KH) ? kq * KH + r : -1;
-    const L2hmcNet& W = net ? A.vnet : A.xnet;
-    float val = 0.f;
-    if (g == 0) {                                   // layer 2 forward: rows u' = ui, k = u = uk  (+ b4, 1 -> 1)
-      if (uk >= 0 && ui >= 0) {
-        if (uk < H && ui < H) val = W.W4[uk * H + ui];
-        else if (uk == H && ui < H) val = W.b4[ui];
-        else if (uk == H && ui == H) val = 1.f;
+  // One wave stages everything, so the loads must not wait for one another: every lane's (i, kq) is fixed, the 6 groups x 4
+  // k-steps of a net are straight-line code with clamped indices (every load is issued, invalid ones are discarded by a
+  // select) -- 28 independent loads per net in flight instead of 48 dependent loop trips (the staging was 17 % of a launch).
+  {
+    const int li = lane & 15, lkq = lane >> 4, ui = unit_row(li);
+    const bool uiH = ui >= 0 && ui < H;
+    const int uic = uiH ? ui : 0;
+    const int hd = li & 3, dm = li >> 2;                      // heads forward: row li = (dimension dm, head hd)
+    const bool okd = hd < 3 && dm < d;
+    const int dmc = dm < d ? dm : 0, kqc = lkq < d ? lkq : 0;
+    auto stage_net = [&](float* dst, float* tbd, const float* W1, const float* W2, const float* W3, const float* W4, const float* b1,
+                         const float* b2, const float* b3, const float* b4, const float* Ws, const float* Wt, const float* Wq,
+                         const float* bs, const float* bt, const float* bq) {
+      const float* Wh = hd == 0 ? Ws : (hd == 1 ? Wt : Wq);
+      const float* bh = hd == 0 ? bs : (hd == 1 ? bt : bq);
+      f4 G[6];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int uk = r < KH ? lkq * KH + r : -1;
+        const bool ukH = uk >= 0 && uk < H, ukB = uk == H;
+        const int ukc = ukH ? uk : 0;
+        const float* Wr = r == 0 ? Ws : (r == 1 ? Wt : Wq);
+        // (all loads first: clamped addresses are always valid)
+        const float v0 = ukB ? b4[uic] : W4[ukc * H + uic];      // layer 2 forward: rows u' = ui, k = u = uk (+ b4, 1 -> 1)
+        const float v1 = W4[uic * H + ukc];                      // layer 2 transposed: rows u = ui, k = u' = uk
+        const float v2 = ukB ? bh[dmc] : Wh[ukc * d + dmc];      // heads forward: row (dimension, head), k = unit uk
+        const float v3 = Wr[uic * d + kqc];                      // heads transposed: rows = units ui, k = (dimension kq, head r)
+        const float v4 = W1[dmc * H + ukc], v5 = W2[dmc * H + ukc];   // layer 1 transposed: row 4 j = dimension j, k = unit uk
+        G[0][r] = ((ukH || ukB) && uiH) ? v0 : ((ukB && ui == H) ? 1.f : 0.f);
+        G[1][r] = (ukH && uiH) ? v1 : 0.f;
+        G[2][r] = (okd && (ukH || ukB)) ? v2 : 0.f;
+        G[3][r] = (r < 3 && lkq < d && uiH) ? v3 : 0.f;
+        G[4][r] = (hd == 0 && dm < d && ukH) ? v4 : 0.f;
+        G[5][r] = (hd == 0 && dm < d && ukH) ? v5 : 0.f;
       }
-    } else if (g == 1) {                            // layer 2 transposed: rows u = ui, k = u' = uk
-      if (ui >= 0 && ui < H && uk >= 0 && uk < H) val = W.W4[ui * H + uk];
-    } else if (g == 2) {                            // heads forward: row i = (dimension i >> 2, head i & 3), k = unit uk
-      const int dim = i >> 2, h = i & 3;
-      if (h < 3 && dim < d && uk >= 0) {
-        const float* Wh = h == 0 ? W.Ws : (h == 1 ? W.Wt : W.Wq);
-        const float* bh = h == 0 ? W.bs : (h == 1 ? W.bt : W.bq);
-        if (uk < H) val = Wh[uk * d + dim];
-        else if (uk == H) val = bh[dim];
+#pragma unroll
+      for (int g = 0; g < 6; ++g) *reinterpret_cast<f4*>(dst + (g * 64 + lane) * 4) = G[g];
+      // time / bias table of this net: row srow, unit row li
+      const float w3c = W3[uic], w3s = W3[H + uic], bsum = (b1[uic] + b2[uic]) + b3[uic];
+      for (int s0 = 0; s0 < T; s0 += 4) {
+        const int srow = s0 + lkq;
+        if (srow < T) {
+          const float v = fmaf(w3c, A.trig[2 * srow], fmaf(w3s, A.trig[2 * srow + 1], bsum));
+          tbd[srow * 16 + li] = ui == H ? 1.f : (uiH ? v : 0.f);
+        }
       }
-    } else if (g == 3) {                            // heads transposed: rows = units ui, k (kq, r) = block row 4 kq + r
-      const int dim = kq, h = r;                    //   = (dimension kq, head r)
-      if (h < 3 && dim < d && ui >= 0 && ui < H) {
-        const float* Wh = h == 0 ? W.Ws : (h == 1 ? W.Wt : W.Wq);
-        val = Wh[ui * d + dim];
-      }
-    } else {                                        // layer 1 transposed: row 4 j = dimension j, k = unit uk
-      const float* W1 = g == 4 ? W.W1 : W.W2;
-      const int dim = i >> 2;
-      if ((i & 3) == 0 && dim < d && uk >= 0 && uk < H) val = W1[dim * H + uk];
-    }
-    smem[L.grp + idx] = val;
+    };
+    if (wv == 0)
+      stage_net(smem + L.grp, smem + L.tb, A.xnet.W1, A.xnet.W2, A.xnet.W3, A.xnet.W4, A.xnet.b1, A.xnet.b2, A.xnet.b3, A.xnet.b4,
+                A.xnet.Ws, A.xnet.Wt, A.xnet.Wq, A.xnet.bs, A.xnet.bt, A.xnet.bq);
+    else
+      stage_net(smem + L.grp + ng * 256, smem + L.tb + T * 16, A.vnet.W1, A.vnet.W2, A.vnet.W3, A.vnet.W4, A.vnet.b1, A.vnet.b2,
+              A.vnet.b3, A.vnet.b4, A.vnet.Ws, A.vnet.Wt, A.vnet.Wq, A.vnet.bs, A.vnet.bt, A.vnet.bq);
   }
-  for (int i = lane; i < 2 * T; i += 64) smem[L.trg + i] = A.trig[i];
-  for (int idx = lane; idx < 2 * T * 16; idx += 64) {
-    const int net = idx / (T * 16), srow = (idx / 16) % T, i = idx & 15;
-    const int ui = unit_row(i);
-    const L2hmcNet& W = net ? A.vnet : A.xnet;
-    float val = 0.f;
-    if (ui == H) val = 1.f;
-    else if (ui >= 0 && ui < H)
-      val = fmaf(W.W3[ui], A.trig[2 * srow], fmaf(W.W3[H + ui], A.trig[2 * srow + 1], (W.b1[ui] + W.b2[ui]) + W.b3[ui]));
-    smem[L.tb + idx] = val;
-  }
-  for (int i = lane; i < T * 4; i += 64) smem[L.msk + i] = (i & 3) < d ? A.masks[(i >> 2) * d + (i & 3)] : 0.f;
+  for (int i = threadIdx.x; i < 2 * T; i += 128) smem[L.trg + i] = A.trig[i];
+  for (int i = threadIdx.x; i < T * 4; i += 128) smem[L.msk + i] = (i & 3) < d ? A.masks[(i >> 2) * d + (i & 3)] : 0.f;
 
   // per-lane constants: layer-1 forward operands (row c <-> unit, k = q <-> dimension), exp(lam), energy parameters
   float l1xa = 0.f, l1xb = 0.f, l1va = 0.f, l1vb = 0.f, esx = 0.f, eqx = 0.f, esv = 0.f, eqv = 0.f, emu = 0.f, epr = 0.f, Gf = 0.f;
-  {
+  {                                                 // (clamped addresses, all loads issued, selects afterwards: see above)
     const int ui = unit_row(c);
-    if (livedim) {
-      if (ui >= 0 && ui < H) {
-        l1xa = A.xnet.W1[q * H + ui]; l1xb = A.xnet.W2[q * H + ui];
-        l1va = A.vnet.W1[q * H + ui]; l1vb = A.vnet.W2[q * H + ui];
-      }
-      esx = expf(A.xnet.lam_s[q]); eqx = expf(A.xnet.lam_q[q]);
-      esv = expf(A.vnet.lam_s[q]); eqv = expf(A.vnet.lam_q[q]);
-      if (EK != L2HMC_ENERGY_ROUGHWELL && EK != L2HMC_ENERGY_GMM) emu = A.mu[q];
-      if (EK == L2HMC_ENERGY_GAUSS_DIAG) epr = A.prec[q];
-      if (EK == L2HMC_ENERGY_GAUSS_DENSE) {         // A operand of y = G dx: row 4 j <- G[j][q] (symmetrised), else 0
-        const int j = c >> 2;
-        if ((c & 3) == 0 && j < d) Gf = 0.5f * (A.prec[j * d + q] + A.prec[q * d + j]);
-      }
-    }
+    const bool uok = livedim && ui >= 0 && ui < H;
+    const int qc = livedim ? q : 0, o1 = qc * H + (uok ? ui : 0);
+    const float a0 = A.xnet.W1[o1], a1 = A.xnet.W2[o1], a2 = A.vnet.W1[o1], a3 = A.vnet.W2[o1];
+    const float s0 = A.xnet.lam_s[qc], s1 = A.xnet.lam_q[qc], s2 = A.vnet.lam_s[qc], s3 = A.vnet.lam_q[qc];
+    float m0 = 0.f, p0 = 0.f, ga = 0.f, gb = 0.f;
+    const int j = c >> 2, jc = j < d ? j : 0;
+    if (EK != L2HMC_ENERGY_ROUGHWELL && EK != L2HMC_ENERGY_GMM) m0 = A.mu[qc];
+    if (EK == L2HMC_ENERGY_GAUSS_DIAG) p0 = A.prec[qc];
+    if (EK == L2HMC_ENERGY_GAUSS_DENSE) { ga = A.prec[jc * d + qc]; gb = A.prec[qc * d + jc]; }
+    l1xa = uok ? a0 : 0.f; l1xb = uok ? a1 : 0.f; l1va = uok ? a2 : 0.f; l1vb = uok ? a3 : 0.f;
+    esx = livedim ? expf(s0) : 0.f; eqx = livedim ? expf(s1) : 0.f;
+    esv = livedim ? expf(s2) : 0.f; eqv = livedim ? expf(s3) : 0.f;
+    emu = livedim ? m0 : 0.f;
+    epr = livedim ? p0 : 0.f;
+    // dense Gaussian: A operand of y = G dx: row 4 j <- G[j][q] (symmetrised), else 0
+    if (EK == L2HMC_ENERGY_GAUSS_DENSE) Gf = (livedim && (c & 3) == 0 && j < d) ? 0.5f * (ga + gb) : 0.f;
   }
   // mixture of Gaussians (distributions.py:104-134): per component the mean of this lane's dimension, the A operand of
   // y_k = G_k (z - mu_k) (as Gf above) and the log-weight constant; KC = 8 components at most, all in registers
   float gmu[KC], gGf[KC], glc[KC];
   if (EK == L2HMC_ENERGY_GMM) {
+    const int qc = livedim ? q : 0, j = c >> 2, jc = j < d ? j : 0;
+    float lc[KC], mu_[KC], pa[KC], pb[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {                  // all loads first (component index clamped), selects afterwards
+      const int kc = k < A.ncomp ? k : 0;
+      lc[k] = A.logc[kc];
+      mu_[k] = A.mu[kc * d + qc];
+      pa[k] = A.prec[(kc * d + jc) * d + qc];
+      pb[k] = A.prec[(kc * d + qc) * d + jc];
+    }
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
-      gmu[k] = 0.f; gGf[k] = 0.f; glc[k] = 0.f;
-      if (k < A.ncomp) {
-        glc[k] = A.logc[k];
-        if (livedim) {
-          gmu[k] = A.mu[k * d + q];
-          const int j = c >> 2;
-          if ((c & 3) == 0 && j < d) gGf[k] = 0.5f * (A.prec[(k * d + j) * d + q] + A.prec[(k * d + q) * d + j]);
-        }
-      }
+      const bool on = k < A.ncomp;
+      glc[k] = on ? lc[k] : 0.f;
+      gmu[k] = (on && livedim) ? mu_[k] : 0.f;
+      gGf[k] = (on && livedim && (c & 3) == 0 && j < d) ? 0.5f * (pa[k] + pb[k]) : 0.f;
     }
   }
   __syncthreads();
+  TS_MARK(0);      // (profiling builds only, tools/train_phase_timing.py) staging
 
   const float* grpx = smem + L.grp;
   const float* grpv = grpx + ng * 256;
@@ -159,15 +202,72 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
     return acc;
   };
   // in: lane (c, q) holds val[row 4 q + r][chain c];  out: lane (i, kq) holds val[row i][chain 4 kq + r]
-  float* scr = smem + L.tr;
-  float* csr = scr + 7 * 320;                    // (cos, sin) of the current step, per chain
-  auto transp_put = [&](int slot, f4 val) { *reinterpret_cast<f4*>(scr + slot * 320 + c * 20 + 4 * q) = val; };
-  auto transp_get = [&](int slot) {
+  float* scr = smem + L.tr;                      // operand buffer of back-propagation n: scr + (n & 1) * 7 * 320
+  auto transp_put = [&](float* sb, int slot, f4 val) { *reinterpret_cast<f4*>(sb + slot * 320 + c * 20 + 4 * q) = val; };
+  auto transp_get = [&](const float* sb, int slot) {
     f4 ov;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ov[r] = scr[slot * 320 + (4 * q + r) * 20 + c];
+    for (int r = 0; r < 4; ++r) ov[r] = sb[slot * 320 + (4 * q + r) * 20 + c];
     return ov;
   };
+  // gradient tiles of one net (registers of wave 1, whole reverse sweep)
+  struct Acc { f4 hd, w1, w2, w4, tau; };
+  float* const slot = A.ws + (long long)gridDim.x * T * TF_CK * 256 + (long long)blockIdx.x * (2 * P + 1);
+
+  if (wv == 1) {
+    // ---- wave 1: weight gradients = contractions over the 16 chains of the operands wave 0 left in LDS -------------------------
+    Acc GX, GV;
+    GX.hd = GX.w1 = GX.w2 = GX.w4 = GX.tau = Z;
+    GV = GX;
+    for (int nb = 0; nb < 4 * T; ++nb) {            // per step: V, X, X, V (the order of the reverse sweep)
+      __syncthreads();
+      const float* sb = scr + (nb & 1) * (7 * 320);
+      const f4 th2 = transp_get(sb, 0), tdz = transp_get(sb, 1), tda1 = transp_get(sb, 2), t3 = transp_get(sb, 3),
+               tb_ = transp_get(sb, 4), th1 = transp_get(sb, 5), tda2 = transp_get(sb, 6);
+      // slot 3 carries (a, cos, sin, 0) of dimension 0: columns 1, 2 are the chain's (cos, sin) of its schedule row
+      const f4 ta = (c & 3) == 0 ? t3 : Z;
+      const f4 tt = c == 0 ? splat(1.f) : ((c == 1 || c == 2) ? t3 : Z);      // rows: 0 -> 1, 1 -> cos, 2 -> sin
+      const int k = nb & 3;
+      Acc& G = (k == 0 || k == 3) ? GV : GX;
+      G.hd = chain4(tdz, th2, G.hd);
+      G.w1 = chain4(ta, tda1, G.w1);
+      G.w2 = chain4(tb_, tda1, G.w2);
+      G.w4 = chain4(th1, tda2, G.w4);
+      G.tau = chain4(tt, tda1, G.tau);
+    }
+    const int ui = unit_row(c);                    // unit on the COLUMN (lane & 15) of the weight-gradient tiles
+    auto flush_tiles = [&](const Acc& G, float* Gn) {
+      const int hs = H * d + d;
+      if (livedim && ui >= 0 && ui <= H) {         // tile rows 4 q + r: (dimension q, head r) / row 4 q: dimension q
+        if (ui < H) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) Gn[o.Ws + r * hs + ui * d + q] = G.hd[r];
+          Gn[o.W1 + q * H + ui] = G.w1[0];
+          Gn[o.W1 + (d * H + H) + q * H + ui] = G.w2[0];
+        } else {                                   // the constant-1 unit: head biases
+#pragma unroll
+          for (int r = 0; r < 3; ++r) Gn[o.bs + r * hs + q] = G.hd[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                // dW4[u(row 4 q + r)][u'(c)]; row u = H: b4
+        const int u = r < KH ? q * KH + r : -1;
+        if (u >= 0 && u <= H && ui >= 0 && ui < H) {
+          if (u < H) Gn[o.W4 + u * H + ui] = G.w4[r];
+          else Gn[o.b4 + ui] = G.w4[r];
+        }
+      }
+      if (q == 0 && ui >= 0 && ui < H) {           // rows 0, 1, 2 of the (1, cos, sin) product
+        Gn[o.b1 + ui] = G.tau[0]; Gn[o.b2 + ui] = G.tau[0]; Gn[o.b3 + ui] = G.tau[0];
+        Gn[o.W3 + ui] = G.tau[1];
+        Gn[o.W3 + H + ui] = G.tau[2];
+      }
+    };
+    // (slots are not pre-zeroed: the tiles + wave 0's log-scale sums cover every entry of [xnet | vnet] for d <= 4)
+    flush_tiles(GX, slot);
+    flush_tiles(GV, slot + P);
+    return;
+  }
   auto relu4i = [&](f4 a) {
     f4 o_ = Z;
 #pragma unroll
@@ -250,15 +350,14 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
     C.tq = ftanh(z.z);
   };
 
-  // gradient tiles of one net (registers, whole reverse sweep)
-  struct Acc { f4 hd, w1, w2, w4, tau; float lamS, lamQ; };
-  Acc GX, GV;
-  GX.hd = GX.w1 = GX.w2 = GX.w4 = GX.tau = Z;
-  GX.lamS = GX.lamQ = 0.f;
-  GV = GX;
+  // log-scale gradients of one net (this wave's share of the gradient; the weight tiles live in wave 1)
+  struct Lam { float lamS, lamQ; };
+  Lam GX = {0.f, 0.f}, GV = {0.f, 0.f};
+  int nbp = 0;                                     // back-propagations so far: selects the operand buffer
+  float cs_c = 0.f, sn_c = 0.f;                    // (cos, sin) of this chain's schedule row at the current step
 
   // ---- back-propagation through one net: consumes dzs, dzt, dzq (+ dA, dB for the log-scales), returns da, db -------------
-  auto net_bwd = [&](int net, const Cache& C, float a, float b, float dzs, float dzt, float dzq, float dA, float dB, Acc& G,
+  auto net_bwd = [&](int net, const Cache& C, float a, float b, float dzs, float dzt, float dzq, float dA, float dB, Lam& G,
                      float& da, float& db) {
     const float* gb = net ? grpv : grpx;
     G.lamS += dA;
@@ -276,20 +375,16 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
     for (int r = 0; r < KH; ++r) da1[r] = C.h1[r] > 0.f ? dh1[r] : 0.f;
     da = chainK(frag(gb, 4), da1, Z).x;
     db = chainK(frag(gb, 5), da1, Z).x;
-    // weight gradients: contractions over the 16 chains; the seven operands are transposed through seven scratch slots --
-    // all writes, then all reads: one LDS round trip per back-propagation instead of seven
-    transp_put(0, C.h2); transp_put(1, dz); transp_put(2, da1); transp_put(3, f4{a, 0.f, 0.f, 0.f});
-    transp_put(4, f4{b, 0.f, 0.f, 0.f}); transp_put(5, C.h1); transp_put(6, da2);
-    const f4 th2 = transp_get(0), tdz = transp_get(1), tda1 = transp_get(2), ta = transp_get(3), tb_ = transp_get(4),
-             th1 = transp_get(5), tda2 = transp_get(6);
-    f4 tt;                                       // rows: 0 -> 1, 1 -> cos, 2 -> sin of chain 4 q + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tt[r] = c == 0 ? 1.f : (c == 1 ? csr[2 * (4 * q + r)] : (c == 2 ? csr[2 * (4 * q + r) + 1] : 0.f));
-    G.hd = chain4(tdz, th2, G.hd);
-    G.w1 = chain4(ta, tda1, G.w1);
-    G.w2 = chain4(tb_, tda1, G.w2);
-    G.w4 = chain4(th1, tda2, G.w4);
-    G.tau = chain4(tt, tda1, G.tau);
+    TS_MARK(5);    // back-propagation, critical path (adjoints of the hidden layers and of the inputs)
+    // weight gradients: contractions over the 16 chains, done by wave 1 -- the seven operands go to the LDS buffer of this
+    // back-propagation (slot 3 also carries the chain's (cos, sin) for the time-embedding product), then one barrier
+    float* sb = scr + (nbp & 1) * (7 * 320);
+    transp_put(sb, 0, C.h2); transp_put(sb, 1, dz); transp_put(sb, 2, da1);
+    transp_put(sb, 3, f4{a, q == 0 ? cs_c : 0.f, q == 0 ? sn_c : 0.f, 0.f});
+    transp_put(sb, 4, f4{b, 0.f, 0.f, 0.f}); transp_put(sb, 5, C.h1); transp_put(sb, 6, da2);
+    ++nbp;
+    __syncthreads();
+    TS_MARK(6);    // operands to LDS + hand-over barrier
   };
 
   // ---- per-step schedule ---------------------------------------------------------------------------------------------------
@@ -302,7 +397,8 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
     k1 = isf ? m : (1.f - m);
     tbx = lds4(smem + L.tb + s_me * 16 + 4 * q);
     tbv = lds4(smem + L.tb + (T + s_me) * 16 + 4 * q);
-    if (q == 0) { csr[2 * c] = smem[L.trg + 2 * s_me]; csr[2 * c + 1] = smem[L.trg + 2 * s_me + 1]; }
+    cs_c = smem[L.trg + 2 * s_me];
+    sn_c = smem[L.trg + 2 * s_me + 1];
   };
 
   // ---- half updates (forward) ------------------------------------------------------------------------------------------------
@@ -351,6 +447,7 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
     x = xo;
   }
 
+  TS_MARK(1);      // forward trajectory with checkpoints
   // ---- accept probability, loss term, adjoint seeds ----------------------------------------------------------------------------------
   red[2] = energy_part(x, g);                    // U1
   red[3] = 0.5f * v * v;                         // K1
@@ -422,6 +519,7 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
     deps += dsx * sg * S + dtr * (EQ * vhq + Tt) + dq * Q;
   };
 
+  TS_MARK(2);      // reductions, accept probability, adjoint seeds
   // ---- reverse sweep ---------------------------------------------------------------------------------------------------------------
   float nx = ckp(T - 1, 0), nv = ckp(T - 1, 1), nvh = ckp(T - 1, 2), ny = ckp(T - 1, 3), nxo = ckp(T - 1, 4);
   for (int it = T - 1; it >= 0; --it) {
@@ -431,73 +529,58 @@ __global__ __launch_bounds__(64, 2) void train_small_kernel(const TArgs A) {
       nx = ckp(it - 1, 0); nv = ckp(it - 1, 1); nvh = ckp(it - 1, 2); ny = ckp(it - 1, 3); nxo = ckp(it - 1, 4);
     }
     float dvh = 0.f, dg, dzs, dzt, dzq, dA, dB, da, db, dz;
+    TS_MARK(8);    // step head: schedule record, checkpoint hand-over
     // (1) v' = v_half(vh; g(x'), V(x', g(x')))
     float gq = gradU(cxo);
     net_fwd(1, cxo, gq, tbv, C);
+    TS_MARK(3);    // re-evaluation of the net (+ grad U)
     v_half_b(C, lv, cvh, gq, dvh, dg, dzs, dzt, dzq, dA, dB);
+    TS_MARK(4);    // adjoint of the half update
     net_bwd(1, C, cxo, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
     lx = lx + da + hessvec(cxo, dg + db);                         // d x'
     // (2) x' = x_half(y, k2; vh, X(vh, k2 y)),  k2 = 1 - k1
     const float k2 = 1.f - k1;
+    TS_MARK(8);
     net_fwd(0, cvh, k2 * cy, tbx, C);
+    TS_MARK(3);
     x_half_b(C, lx, cy, k2, cvh, dz, dvh, dzs, dzt, dzq, dA, dB); // dz = d y (direct part)
+    TS_MARK(4);
     net_bwd(0, C, cvh, k2 * cy, dzs, dzt, dzq, dA, dB, GX, da, db);
     dvh += da;
     dz += k2 * db;
     // (3) y = x_half(x, k1; vh, X(vh, k1 x))
+    TS_MARK(8);
     net_fwd(0, cvh, k1 * cx, tbx, C);
+    TS_MARK(3);
     x_half_b(C, dz, cx, k1, cvh, lx, dvh, dzs, dzt, dzq, dA, dB); // lx = d x (direct part)
+    TS_MARK(4);
     net_bwd(0, C, cvh, k1 * cx, dzs, dzt, dzq, dA, dB, GX, da, db);
     dvh += da;
     lx += k1 * db;
     // (4) vh = v_half(v; g(x), V(x, g(x)))
+    TS_MARK(8);
     gq = gradU(cx);
     net_fwd(1, cx, gq, tbv, C);
+    TS_MARK(3);
     v_half_b(C, dvh, cv, gq, lv, dg, dzs, dzt, dzq, dA, dB);
+    TS_MARK(4);
     net_bwd(1, C, cx, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
     lx = lx + da + hessvec(cx, dg + db);
   }
+  TS_MARK(8);
 
-  // ---- this workgroup's flat gradient [xnet (P) | vnet (P) | eps] -> its slot of the workspace ----------------------------------------
-  float* slot = A.ws + (long long)gridDim.x * T * TF_CK * 256 + (long long)blockIdx.x * (2 * P + 1);
+  // ---- this wave's part of the workgroup's flat gradient [xnet (P) | vnet (P) | eps]: the step size and the log-scales ---------------
   {
-    const float s = wave_sum(deps * live1);
-    if (lane == 0) slot[2 * P] = s;
+    const float s_ = wave_sum(deps * live1);
+    if (lane == 0) slot[2 * P] = s_;
   }
-  const int ui = unit_row(c);                    // unit on the COLUMN (lane & 15) of the weight-gradient tiles
-  auto flush = [&](const Acc& G, float* Gn) {
-    const int hs = H * d + d;
-    if (livedim && ui >= 0 && ui <= H) {         // tile rows 4 q + r: (dimension q, head r) / row 4 q: dimension q
-      if (ui < H) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Gn[o.Ws + r * hs + ui * d + q] = G.hd[r];
-        Gn[o.W1 + q * H + ui] = G.w1[0];
-        Gn[o.W1 + (d * H + H) + q * H + ui] = G.w2[0];
-      } else {                                   // the constant-1 unit: head biases
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Gn[o.bs + r * hs + q] = G.hd[r];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {                // dW4[u(row 4 q + r)][u'(c)]; row u = H: b4
-      const int u = r < KH ? q * KH + r : -1;
-      if (u >= 0 && u <= H && ui >= 0 && ui < H) {
-        if (u < H) Gn[o.W4 + u * H + ui] = G.w4[r];
-        else Gn[o.b4 + ui] = G.w4[r];
-      }
-    }
-    if (q == 0 && ui >= 0 && ui < H) {           // rows 0, 1, 2 of the (1, cos, sin) product
-      Gn[o.b1 + ui] = G.tau[0]; Gn[o.b2 + ui] = G.tau[0]; Gn[o.b3 + ui] = G.tau[0];
-      Gn[o.W3 + ui] = G.tau[1];
-      Gn[o.W3 + H + ui] = G.tau[2];
-    }
-    // log-scales: sums over the 16 chains of the tile
+  auto flush_lam = [&](const Lam& G, float* Gn) {  // sums over the 16 chains of the tile
     float ls = G.lamS, lq = G.lamQ;
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) { ls += __shfl_xor(ls, off); lq += __shfl_xor(lq, off); }
     if (c == 0 && livedim) { Gn[o.ls + q] = ls; Gn[o.lq + q] = lq; }
   };
-  // (slots are not pre-zeroed: write every entry of [xnet | vnet] -- the tiles above cover all of them for d <= 4)
-  flush(GX, slot);
-  flush(GV, slot + P);
+  flush_lam(GX, slot);
+  flush_lam(GV, slot + P);
+  TS_FLUSH();
 }

@@ -194,11 +194,17 @@ class Trainer(object):
         return int(counts.sum()), int(counts[:rank].sum())
 
     def _loss(self, v12, N, n_total, world):
-        terms = torch.stack([(1.0 / v12).sum(), v12.sum()]).double()
+        # one fixed-order double reduction on the device (l2hmc_loss_terms) instead of a dozen elementwise framework kernels
+        if getattr(self, "_lt", None) is None or self._lt.device != v12.device:
+            self._lt = torch.empty(3, dtype=torch.float64, device=v12.device)
+        _ffi.check(_ffi.lib().l2hmc_loss_terms(v12.data_ptr(), v12.numel(), self.scale, 1.0 / float(n_total),
+                                               self._lt.data_ptr(), _ffi.current_stream(v12.device)))
         if world > 1:
+            terms = self._lt[:2].clone()
             dist.all_reduce(terms)
-        terms = terms / n_total
-        return self.scale * terms[0] - terms[1] / self.scale
+            terms = terms / n_total
+            return self.scale * terms[0] - terms[1] / self.scale
+        return self._lt[2].clone()
 
     def loss_and_grad(self, x, z=None, draws=None):
         """Loss and gradients (left in `.grad` of every parameter) for chain states `x`.

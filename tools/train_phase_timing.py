@@ -18,8 +18,8 @@ KINDS = ["stage", "fwd L1 partials", "fwd bias+relu", "fwd L2", "fwd heads", "bw
 def main():
     if sys.argv[1] == "build":
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        srcs = [os.path.join(CSRC, f) for f in ("l2hmc_abi.hip", "traj_ek1.hip", "traj_ek2.hip", "traj_ek3.hip",
-                                                "traj_ek4.hip", "traj_ek5.hip", "traj_wide.hip", "train.hip", "split.hip")]
+        import glob
+        srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
                         "-DL2HMC_TRAIN_TIMING", "-Wno-return-type", "-Wno-pass-failed", "-shared", "-o", OUT] + srcs
                        + [], check=True)
@@ -47,7 +47,12 @@ def main():
     L.l2hmc_train_read_timers(buf)
     tot = sum(buf[i] for i in range(11))
     print("%s, %d chains: s_memtime ticks per launch (one proposal of 16 chains), wave 0 of block 0" % (case, n))
-    for i, k in enumerate(KINDS):
+    kinds = KINDS
+    if case in ("scg2d", "mog2d"):       # train_small_kernel (d <= 4): its own phases
+        kinds = ["stage", "forward trajectory", "reductions / seeds", "rev: net re-evaluation (+ grad U)", "rev: half-update adjoint",
+                 "rev: net back-propagation (critical path)", "rev: operand transposes (LDS)", "rev: weight-gradient MFMAs",
+                 "rev: step head / hessvec / hand-over", "-", "-"]
+    for i, k in enumerate(kinds):
         print("  %-24s %10.0f  %5.1f%%" % (k, buf[i] / reps, 100.0 * buf[i] / tot))
     print("  %-24s %10.0f" % ("total", tot / reps))
 
