@@ -4,8 +4,9 @@
 
     python tools/bench_train.py [--no-cpu]
 
-Prints, per configuration: the `l2hmc_train_propose_grad` kernel time (HIP events, one x- plus one
-z-proposal = the device work of a training step), the whole `Trainer.step` wall time (kernel + RNG
+Prints, per configuration: the `l2hmc_train_propose_grad` call rate (HIP events around back-to-back calls, one x- plus one
+z-proposal = the device work of a training step; for the d <= 4 kernel this loop is HOST-bound -- the kernel itself is
+46 us on the notebook config by `rocprofv3 --kernel-trace`, profiles/r03_train_timing.txt), the whole `Trainer.step` wall time (kernel + RNG
 + Adam + MH select), and -- as the CPU reference point -- the numpy restatement of the same
 loss-and-gradient (oracle/l2hmc_train_oracle.py, float32) on the same inputs."""
 import os
