@@ -853,6 +853,26 @@ __global__ void train_reduce_kernel(const float* part, int n_slots, int n_grad, 
 }
 
 __device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.f); }
+// Phase timers of profiling builds (-DL2HMC_TRAIN_TIMING, tools/train_phase_timing.py): accumulated in REGISTERS and written
+// once at the end (a global read-modify-write per mark would cost more than the phases it brackets).
+#ifdef L2HMC_TRAIN_TIMING
+#define TS_DECL unsigned long long ts_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ts_t0 = __builtin_amdgcn_s_memtime()
+#define TS_MARK(i)                                                          \
+  do {                                                                      \
+    const unsigned long long ts_t1 = __builtin_amdgcn_s_memtime();          \
+    ts_acc[i] += ts_t1 - ts_t0;                                             \
+    ts_t0 = ts_t1;                                                          \
+  } while (0)
+#define TS_FLUSH()                                                          \
+  do {                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                                \
+      for (int ts_i = 0; ts_i < 9; ++ts_i) tt_acc[ts_i] += ts_acc[ts_i];    \
+  } while (0)
+#else
+#define TS_DECL
+#define TS_MARK(i)
+#define TS_FLUSH()
+#endif
 #include "train_fast.hpp"
 #include "train_small.hpp"
 

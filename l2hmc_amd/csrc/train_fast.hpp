@@ -46,6 +46,7 @@ constexpr int TF_CK = 5;                   // checkpointed float4 per lane and s
 template <int EK, int NW, int KH>
 __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  TS_DECL;
   const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * NW;
   const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
   const int c = lane & 15, q = lane >> 4;
@@ -67,57 +68,70 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   auto unit_row = [&](int i) { return ((i & 3) < KH) ? (i >> 2) * KH + (i & 3) : -1; };
 
   // ---- stage: weight fragments in both orientations, time/bias tables, masks -----------------------------------
-  for (int idx = tid; idx < 2 * ng * 256; idx += nthr) {
-    const int net = idx >= ng * 256, rem = idx - net * ng * 256;
-    const int g = rem >> 8, ln = (rem >> 2) & 63, r = rem & 3, i = ln & 15, kq = ln >> 4;
-    const int ui = unit_row(i), uk = (r < KH) ? kq * KH + r : -1;
-    const float* W4 = net ? A.vnet.W4 : A.xnet.W4;
-    float val = 0.f;
-    if (g == 0) {                                   // layer 2 forward: rows u' = ui, k = u = uk  (+ b4, + 1 -> 1)
-      const float* b4 = net ? A.vnet.b4 : A.xnet.b4;
-      if (uk >= 0 && ui >= 0) {
-        if (uk < H && ui < H) val = W4[uk * H + ui];
-        else if (uk == H && ui < H) val = b4[ui];
-        else if (uk == H && ui == H) val = 1.f;
-      }
-    } else if (g == 1) {                            // layer 2 transposed: rows u = ui, k = u' = uk
-      if (ui >= 0 && ui < H && uk >= 0 && uk < H) val = W4[ui * H + uk];
-    } else if (g < 2 + 6 * NT) {                    // heads: forward (rows = dims, k = units) / transposed
-      const bool tr = g >= 2 + 3 * NT;
-      const int hg = g - 2 - (tr ? 3 * NT : 0), tg = hg / 3, h = hg - 3 * tg;
-      const float* Wh = h == 0 ? (net ? A.vnet.Ws : A.xnet.Ws) : (h == 1 ? (net ? A.vnet.Wt : A.xnet.Wt) : (net ? A.vnet.Wq : A.xnet.Wq));
-      const float* bh = h == 0 ? (net ? A.vnet.bs : A.xnet.bs) : (h == 1 ? (net ? A.vnet.bt : A.xnet.bt) : (net ? A.vnet.bq : A.xnet.bq));
-      if (!tr) {
-        const int dim = 16 * tg + i;
-        if (dim < d && uk >= 0) {
-          if (uk < H) val = Wh[uk * d + dim];
-          else if (uk == H) val = bh[dim];
+  // Straight-line staging (the loop form -- one element per trip, its load waited for before the next trip -- was 20 % of
+  // a launch): a lane's fragment position (row i, k-group kq) is fixed, wave w stages the groups of ITS dimension tile
+  // (heads forward / transposed, layer 1 transposed) of both nets plus, for waves 0 and 1, one net's layer-2 pair; every
+  // address is clamped into range, all ~40 loads per net are issued back to back and the invalid ones dropped by selects.
+  {
+    const int li = lane & 15, lkq = lane >> 4, ui = unit_row(li);
+    const bool uiH = ui >= 0 && ui < H;
+    const int uic = uiH ? ui : 0;
+    const int dimr = 16 * w + li;                               // the dimension on this lane's fragment ROW
+    const bool drok = dimr < d;
+    const int dimrc = drok ? dimr : 0;
+    auto stage_tile = [&](float* gb, bool do_l2, const float* W1, const float* W2, const float* W4, const float* b4,
+                          const float* Ws, const float* Wt, const float* Wq, const float* bs, const float* bt, const float* bq) {
+      f4 G0 = Z, G1 = Z, HF[3], HT[3], LT[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int uk = r < KH ? lkq * KH + r : -1;
+        const bool ukH = uk >= 0 && uk < H, ukB = uk == H;
+        const int ukc = ukH ? uk : 0;
+        const int dimk = 16 * w + 4 * lkq + r;                  // the dimension on this element's K index
+        const bool dkok = dimk < d;
+        const int dimkc = dkok ? dimk : 0;
+        float v0 = 0.f, v1 = 0.f;
+        if (do_l2) {                                            // (wave-uniform)
+          v0 = ukB ? b4[uic] : W4[ukc * H + uic];               // layer 2 forward: rows u' = ui, k = u = uk  (+ b4, + 1 -> 1)
+          v1 = W4[uic * H + ukc];                               // layer 2 transposed: rows u = ui, k = u' = uk
         }
-      } else {
-        const int dim = 16 * tg + 4 * kq + r;
-        if (dim < d && ui >= 0 && ui < H) val = Wh[ui * d + dim];
+        const float f0 = ukB ? bs[dimrc] : Ws[ukc * d + dimrc]; // heads forward: rows = dims, k = units (bias on unit H)
+        const float f1 = ukB ? bt[dimrc] : Wt[ukc * d + dimrc];
+        const float f2 = ukB ? bq[dimrc] : Wq[ukc * d + dimrc];
+        const float t0 = Ws[uic * d + dimkc], t1 = Wt[uic * d + dimkc], t2 = Wq[uic * d + dimkc];   // heads transposed
+        const float l0 = W1[dimrc * H + ukc], l1 = W2[dimrc * H + ukc];                             // layer 1 transposed
+        G0[r] = ((ukH || ukB) && uiH) ? v0 : ((ukB && ui == H) ? 1.f : 0.f);
+        G1[r] = (ukH && uiH) ? v1 : 0.f;
+        const bool hf = drok && (ukH || ukB), ht = dkok && uiH, lt = drok && ukH;
+        HF[0][r] = hf ? f0 : 0.f; HF[1][r] = hf ? f1 : 0.f; HF[2][r] = hf ? f2 : 0.f;
+        HT[0][r] = ht ? t0 : 0.f; HT[1][r] = ht ? t1 : 0.f; HT[2][r] = ht ? t2 : 0.f;
+        LT[0][r] = lt ? l0 : 0.f; LT[1][r] = lt ? l1 : 0.f;
       }
-    } else {                                        // layer 1 transposed: rows = dims, k = units
-      const int lg = g - 2 - 6 * NT, tg = lg >> 1, which = lg & 1;
-      const float* W = which == 0 ? (net ? A.vnet.W1 : A.xnet.W1) : (net ? A.vnet.W2 : A.xnet.W2);
-      const int dim = 16 * tg + i;
-      if (dim < d && uk >= 0 && uk < H) val = W[dim * H + uk];
+      auto put = [&](int g, f4 v) { *reinterpret_cast<f4*>(gb + (g * 64 + lane) * 4) = v; };
+      if (do_l2) { put(0, G0); put(1, G1); }
+#pragma unroll
+      for (int h = 0; h < 3; ++h) { put(2 + 3 * w + h, HF[h]); put(2 + 3 * NT + 3 * w + h, HT[h]); }
+      put(2 + 6 * NT + 2 * w + 0, LT[0]);
+      put(2 + 6 * NT + 2 * w + 1, LT[1]);
+    };
+    stage_tile(smem + L.grp, w == 0, A.xnet.W1, A.xnet.W2, A.xnet.W4, A.xnet.b4, A.xnet.Ws, A.xnet.Wt, A.xnet.Wq, A.xnet.bs,
+               A.xnet.bt, A.xnet.bq);
+    stage_tile(smem + L.grp + ng * 256, w == (NW > 1 ? 1 : 0), A.vnet.W1, A.vnet.W2, A.vnet.W4, A.vnet.b4, A.vnet.Ws, A.vnet.Wt,
+               A.vnet.Wq, A.vnet.bs, A.vnet.bt, A.vnet.bq);
+    // time / bias tables: thread (srow = tid / 16, unit row i = tid % 16) of each net
+    const int ti = tid & 15, tui = unit_row(ti);
+    const bool tuH = tui >= 0 && tui < H;
+    const int tuc = tuH ? tui : 0;
+    const float xw3c = A.xnet.W3[tuc], xw3s = A.xnet.W3[H + tuc], xbs = (A.xnet.b1[tuc] + A.xnet.b2[tuc]) + A.xnet.b3[tuc];
+    const float vw3c = A.vnet.W3[tuc], vw3s = A.vnet.W3[H + tuc], vbs = (A.vnet.b1[tuc] + A.vnet.b2[tuc]) + A.vnet.b3[tuc];
+    for (int srow = tid >> 4; srow < T; srow += nthr >> 4) {
+      const float ct = A.trig[2 * srow], st = A.trig[2 * srow + 1];
+      const float vx = fmaf(xw3c, ct, fmaf(xw3s, st, xbs)), vv = fmaf(vw3c, ct, fmaf(vw3s, st, vbs));
+      smem[L.tb + srow * 16 + ti] = tui == H ? 1.f : (tuH ? vx : 0.f);
+      smem[L.tb + (T + srow) * 16 + ti] = tui == H ? 1.f : (tuH ? vv : 0.f);
     }
-    smem[L.grp + idx] = val;
   }
   for (int i = tid; i < 2 * T; i += nthr) smem[L.trg + i] = A.trig[i];
-  for (int idx = tid; idx < 2 * T * 16; idx += nthr) {
-    const int net = idx / (T * 16), srow = (idx / 16) % T, i = idx & 15;
-    const int ui = unit_row(i);
-    float val = 0.f;
-    if (ui == H) val = 1.f;
-    else if (ui >= 0 && ui < H) {
-      const float* W3 = net ? A.vnet.W3 : A.xnet.W3;
-      const float bsum = net ? (A.vnet.b1[ui] + A.vnet.b2[ui]) + A.vnet.b3[ui] : (A.xnet.b1[ui] + A.xnet.b2[ui]) + A.xnet.b3[ui];
-      val = fmaf(W3[ui], A.trig[2 * srow], fmaf(W3[H + ui], A.trig[2 * srow + 1], bsum));
-    }
-    smem[L.tb + idx] = val;
-  }
   for (int i = tid; i < T * DP; i += nthr) {
     const int row = i / DP, dim = i % DP;
     smem[L.msk + i] = dim < d ? A.masks[row * d + dim] : 0.f;
@@ -126,28 +140,35 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   // register-resident per-lane constants: layer-1 forward fragments of this wave's tile, exp(lam), energy parameters
   const int dim0 = 16 * w + 4 * q;
   f4 l1xa, l1xb, l1va, l1vb, esx, eqx, esv, eqv, emu = Z, epr = Z, Gf = Z;
-  {
+  {                                                 // (clamped addresses, all loads issued, selects afterwards)
     const int ui = unit_row(c);
+    const bool uok = ui >= 0 && ui < H;
+    const int uc = uok ? ui : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int dim = dim0 + r;
-      const bool ok = dim < d && ui >= 0 && ui < H;
-      l1xa[r] = ok ? A.xnet.W1[dim * H + ui] : 0.f;
-      l1xb[r] = ok ? A.xnet.W2[dim * H + ui] : 0.f;
-      l1va[r] = ok ? A.vnet.W1[dim * H + ui] : 0.f;
-      l1vb[r] = ok ? A.vnet.W2[dim * H + ui] : 0.f;
-      esx[r] = dim < d ? expf(A.xnet.lam_s[dim]) : 0.f;
-      eqx[r] = dim < d ? expf(A.xnet.lam_q[dim]) : 0.f;
-      esv[r] = dim < d ? expf(A.vnet.lam_s[dim]) : 0.f;
-      eqv[r] = dim < d ? expf(A.vnet.lam_q[dim]) : 0.f;
-      if (EK != L2HMC_ENERGY_ROUGHWELL && EK != L2HMC_ENERGY_FUNNEL) emu[r] = dim < d ? A.mu[dim] : 0.f;
-      if (EK == L2HMC_ENERGY_GAUSS_DIAG) epr[r] = dim < d ? A.prec[dim] : 0.f;
+      const bool dok = dim < d;
+      const int dc = dok ? dim : 0;
+      const float a0 = A.xnet.W1[dc * H + uc], a1 = A.xnet.W2[dc * H + uc], a2 = A.vnet.W1[dc * H + uc], a3 = A.vnet.W2[dc * H + uc];
+      const float s0 = A.xnet.lam_s[dc], s1 = A.xnet.lam_q[dc], s2 = A.vnet.lam_s[dc], s3 = A.vnet.lam_q[dc];
+      float m0 = 0.f, p0 = 0.f, ga = 0.f, gb = 0.f;
+      if (EK != L2HMC_ENERGY_ROUGHWELL && EK != L2HMC_ENERGY_FUNNEL) m0 = A.mu[dc];
+      if (EK == L2HMC_ENERGY_GAUSS_DIAG) p0 = A.prec[dc];
+      const int cc = c < d ? c : 0;
+      if (EK == L2HMC_ENERGY_GAUSS_DENSE) { ga = A.prec[cc * d + dc]; gb = A.prec[dc * d + cc]; }
+      const bool ok = dok && uok;
+      l1xa[r] = ok ? a0 : 0.f; l1xb[r] = ok ? a1 : 0.f; l1va[r] = ok ? a2 : 0.f; l1vb[r] = ok ? a3 : 0.f;
+      esx[r] = dok ? expf(s0) : 0.f; eqx[r] = dok ? expf(s1) : 0.f;
+      esv[r] = dok ? expf(s2) : 0.f; eqv[r] = dok ? expf(s3) : 0.f;
+      if (EK != L2HMC_ENERGY_ROUGHWELL && EK != L2HMC_ENERGY_FUNNEL) emu[r] = dok ? m0 : 0.f;
+      if (EK == L2HMC_ENERGY_GAUSS_DIAG) epr[r] = dok ? p0 : 0.f;
       if (EK == L2HMC_ENERGY_GAUSS_DENSE)       // NW == 1: A operand of y = G dx, rows = out dims c, k = 4 q + r
-        Gf[r] = (c < d && dim < d) ? 0.5f * (A.prec[c * d + dim] + A.prec[dim * d + c]) : 0.f;
+        Gf[r] = (c < d && dok) ? 0.5f * (ga + gb) : 0.f;
     }
   }
   const f4 live4 = f4{dim0 < d ? 1.f : 0.f, dim0 + 1 < d ? 1.f : 0.f, dim0 + 2 < d ? 1.f : 0.f, dim0 + 3 < d ? 1.f : 0.f};
   __syncthreads();
+  TS_MARK(0);      // (profiling builds only, tools/train_phase_timing.py) staging
 
   const float* grpx = smem + L.grp;
   const float* grpv = grpx + ng * 256;
@@ -386,6 +407,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     x = xo;
   }
 
+  TS_MARK(1);      // forward trajectory with checkpoints
   // ---- accept probability, loss term, adjoint seeds ----------------------------------------------------------------------
   red[2] = energy_part(x, g);                    // U1
   red[3] = 0.5f * hsum(v * v);                   // K1
@@ -483,6 +505,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     }
   };
 
+  TS_MARK(2);      // reductions, seeds
   // ---- reverse sweep ---------------------------------------------------------------------------------------------------------
   for (int it = T - 1; it >= 0; --it) {
     set_step(it);
@@ -516,6 +539,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     lx = lx + da + hessvec(cx, dg + db);
   }
 
+  TS_MARK(3);      // reverse sweep
   // ---- this workgroup's flat gradient [xnet (P) | vnet (P) | eps] -> its slot of the workspace ------------------------------------
   float* slot = A.ws + (long long)gridDim.x * T * TF_CK * (NW * 256) + (long long)blockIdx.x * (2 * P + 1);
   {
@@ -579,4 +603,6 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   };
   flush(GX, slot);
   flush(GV, slot + P);
+  TS_MARK(4);      // flush
+  TS_FLUSH();
 }

@@ -52,6 +52,8 @@ def main():
         kinds = ["stage", "forward trajectory", "reductions / seeds", "rev: net re-evaluation (+ grad U)", "rev: half-update adjoint",
                  "rev: net back-propagation (critical path)", "rev: operand transposes (LDS)", "rev: weight-gradient MFMAs",
                  "rev: step head / hessvec / hand-over", "-", "-"]
+    if case == "icg50":                  # train_fast_kernel (register-resident, 4 waves per tile): coarse phases
+        kinds = ["stage", "forward trajectory", "reductions / seeds", "reverse sweep", "flush", "-", "-", "-", "-", "-", "-"]
     for i, k in enumerate(kinds):
         print("  %-24s %10.0f  %5.1f%%" % (k, buf[i] / reps, 100.0 * buf[i] / tot))
     print("  %-24s %10.0f" % ("total", tot / reps))
