@@ -289,12 +289,15 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   auto net_fwd = [&](int net, f4 a, f4 b, f4 tbrow, Cache& C) {
     const float* gb = net ? grpv : grpx;
     f4 p = chain4(net ? l1va : l1xa, a, Z) + chain4(net ? l1vb : l1xb, b, Z);
+    // (the fragments of the layers behind the cross-wave sum are requested BEFORE its barrier: LDS loads may not be moved
+    //  across a barrier by the compiler, and their latency would otherwise sit on the chain after every exchange)
+    const f4 f2 = frag(gb, 0), fs = frag(gb, 2 + 3 * w + 0), ft = frag(gb, 2 + 3 * w + 1), fq = frag(gb, 2 + 3 * w + 2);
     p = exch(p);
     C.h1 = relu4i(p + tbrow);
-    C.h2 = relu4i(chainK(frag(gb, 0), C.h1, Z));
-    const f4 zs = chainK(frag(gb, 2 + 3 * w + 0), C.h2, Z);
-    const f4 zt = chainK(frag(gb, 2 + 3 * w + 1), C.h2, Z);
-    const f4 zq = chainK(frag(gb, 2 + 3 * w + 2), C.h2, Z);
+    C.h2 = relu4i(chainK(f2, C.h1, Z));
+    const f4 zs = chainK(fs, C.h2, Z);
+    const f4 zt = chainK(ft, C.h2, Z);
+    const f4 zq = chainK(fq, C.h2, Z);
     C.ts = tanh4(zs);
     C.Tt = zt;
     C.tq = tanh4(zq);
@@ -316,15 +319,17 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     f4 dh2 = chain4(frag(gb, 2 + 3 * NT + 3 * w + 0), dzs, Z);
     dh2 = chain4(frag(gb, 2 + 3 * NT + 3 * w + 1), dzt, dh2);
     dh2 = chain4(frag(gb, 2 + 3 * NT + 3 * w + 2), dzq, dh2);
+    const f4 f1 = frag(gb, 1), fa = frag(gb, 2 + 6 * NT + 2 * w + 0), fb = frag(gb, 2 + 6 * NT + 2 * w + 1);   // (as in net_fwd)
     dh2 = exch(dh2);
     f4 da2 = Z, da1 = Z;
 #pragma unroll
     for (int r = 0; r < KH; ++r) da2[r] = C.h2[r] > 0.f ? dh2[r] : 0.f;
-    const f4 dh1 = chainK(frag(gb, 1), da2, Z);
+    const f4 dh1 = chainK(f1, da2, Z);
 #pragma unroll
     for (int r = 0; r < KH; ++r) da1[r] = C.h1[r] > 0.f ? dh1[r] : 0.f;
-    da = chainK(frag(gb, 2 + 6 * NT + 2 * w + 0), da1, Z);
-    db = chainK(frag(gb, 2 + 6 * NT + 2 * w + 1), da1, Z);
+    da = chainK(fa, da1, Z);
+    db = chainK(fb, da1, Z);
+    TS_MARK(6);    // back-propagation: adjoints of the hidden layers and of the inputs (incl. the cross-wave sum)
     // weight gradients: contractions over the 16 chains, operands transposed through the wave's scratch
     const f4 th2 = transp(C.h2);
     G.hS = chain4(transp(dzs), th2, G.hS);
@@ -338,6 +343,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) tt[r] = c == 0 ? 1.f : (c == 1 ? scr[320 + 2 * (4 * q + r)] : (c == 2 ? scr[320 + 2 * (4 * q + r) + 1] : 0.f));
     G.tau = chain4(tt, tda1, G.tau);
+    TS_MARK(7);    // weight-gradient products (operand transposes + chain contractions)
   };
 
   // ---- per-step schedule ------------------------------------------------------------------------------------------
@@ -514,27 +520,39 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     f4 dvh = Z, dg, dzs, dzt, dzq, dA, dB, da, db, dz;
     // (1) v' = v_half(vh; g(x'), V(x', g(x')))
     f4 gq = gradU(cxo);
+    TS_MARK(3);
     net_fwd(1, cxo, gq, tbv, C);
+    TS_MARK(5);    // re-evaluation of the net (+ grad U)
     v_half_b(C, lv, cvh, gq, dvh, dg, dzs, dzt, dzq, dA, dB);
+    TS_MARK(8);    // adjoint of the half update
     net_bwd(1, C, cxo, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
     lx = lx + da + hessvec(cxo, dg + db);                         // d x'
     // (2) x' = x_half(y, k2; vh, X(vh, k2 y)),  k2 = 1 - k1
     const f4 k2 = one - k1;
+    TS_MARK(3);
     net_fwd(0, cvh, k2 * cy, tbx, C);
+    TS_MARK(5);
     x_half_b(C, lx, cy, k2, cvh, dz, dvh, dzs, dzt, dzq, dA, dB); // dz = d y (direct part)
+    TS_MARK(8);
     net_bwd(0, C, cvh, k2 * cy, dzs, dzt, dzq, dA, dB, GX, da, db);
     dvh += da;
     dz += k2 * db;
     // (3) y = x_half(x, k1; vh, X(vh, k1 x))
+    TS_MARK(3);
     net_fwd(0, cvh, k1 * cx, tbx, C);
+    TS_MARK(5);
     x_half_b(C, dz, cx, k1, cvh, lx, dvh, dzs, dzt, dzq, dA, dB); // lx = d x (direct part)
+    TS_MARK(8);
     net_bwd(0, C, cvh, k1 * cx, dzs, dzt, dzq, dA, dB, GX, da, db);
     dvh += da;
     lx += k1 * db;
     // (4) vh = v_half(v; g(x), V(x, g(x)))
     gq = gradU(cx);
+    TS_MARK(3);
     net_fwd(1, cx, gq, tbv, C);
+    TS_MARK(5);
     v_half_b(C, dvh, cv, gq, lv, dg, dzs, dzt, dzq, dA, dB);
+    TS_MARK(8);
     net_bwd(1, C, cx, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
     lx = lx + da + hessvec(cx, dg + db);
   }

@@ -53,7 +53,9 @@ def main():
                  "rev: net back-propagation (critical path)", "rev: operand transposes (LDS)", "rev: weight-gradient MFMAs",
                  "rev: step head / hessvec / hand-over", "-", "-"]
     if case == "icg50":                  # train_fast_kernel (register-resident, 4 waves per tile): coarse phases
-        kinds = ["stage", "forward trajectory", "reductions / seeds", "reverse sweep", "flush", "-", "-", "-", "-", "-", "-"]
+        kinds = ["stage", "forward trajectory", "reductions / seeds", "rev: checkpoints, grad U, hessvec, hand-over", "flush",
+                 "rev: net re-evaluation", "rev: net back-propagation (adjoints, cross-wave sum)", "rev: weight gradients (transposes + MFMAs)",
+                 "rev: half-update adjoint", "-", "-"]
     for i, k in enumerate(kinds):
         print("  %-24s %10.0f  %5.1f%%" % (k, buf[i] / reps, 100.0 * buf[i] / tot))
     print("  %-24s %10.0f" % ("total", tot / reps))
