@@ -43,7 +43,7 @@ __device__ __forceinline__ f4 ex2_4(f4 a) {
 // LDS geometry of the fast kernel (floats).  Host and device agree through these helpers.
 // NTp = NW * DT >= NT: every wave's tiles exist in the tables (zero-filled beyond NT), so the loop has no
 // "is this tile live" branches.
-__host__ __device__ inline int fast_fw_net(int NTp) { return (3 * NTp + 1) * 256; }   // staged tail fragments per net
+__host__ __device__ constexpr int fast_fw_net(int NTp) { return (3 * NTp + 1) * 256; }   // staged tail fragments per net
 __host__ __device__ inline int fast_dpp(int NTp) { return 16 * NTp + 16; }            // padded row of a constant table
 __host__ __device__ inline int fast_fc_net(int NTp) { return 4 * fast_dpp(NTp); }     // cS(fwd) cS(bwd) cQ bQ
 __host__ __device__ inline int fast_rec(int NTp) { return 32 + 16 * NTp; }            // tbx(16) tbv(16) k1 mask
@@ -135,13 +135,27 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
             RECD = fast_rec_dir(NTp, A.T);
 
   // ---- prologue: stage the tail fragments (scaled), the constant tables and the schedule records ----
-  for (int i = tid; i < 2 * (FWN / 4); i += nthr) {
-    const int net = i >= FWN / 4, j = i - net * (FWN / 4), g = j >> 6;
-    float sc = 1.f;
-    if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
-    f4 src = splat(0.f);
-    if (g < 3 * NT + 1) src = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + (2 * NT + 1) * 256)[j];
-    reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src * sc;
+  {
+    // (eight loads in flight per thread: one element per trip, each waited for before the next, made the prologue ~7 us)
+    constexpr int NCP = 2 * (fast_fw_net(NTp) / 4), NTRIP = (NCP + 64 * NW - 1) / (64 * NW);
+    for (int t0 = 0; t0 < NTRIP; t0 += 8) {
+      f4 buf[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = tid + (t0 + u) * nthr;
+        const int net = i >= FWN / 4, j = i - net * (FWN / 4), g = j >> 6;
+        buf[u] = splat(0.f);
+        if (i < NCP && g < 3 * NT + 1) buf[u] = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + (2 * NT + 1) * 256)[j];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = tid + (t0 + u) * nthr;
+        const int net = i >= FWN / 4, j = i - net * (FWN / 4), g = j >> 6;
+        float sc = 1.f;
+        if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
+        if (i < NCP) reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = buf[u] * sc;
+      }
+    }
   }
   for (int i = tid; i < 2 * 16 * NTp; i += nthr) {
     const int net = i / (16 * NTp), dim = i % (16 * NTp);
@@ -155,19 +169,17 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
     fc[2 * DPp + dim] = cq;
     fc[3 * DPp + dim] = cq + log2f(epn);
   }
-  for (int i = tid; i < 2 * A.T * R; i += nthr) {
+#pragma unroll 4
+  for (int i = tid; i < 2 * A.T * R; i += nthr) {      // (branch-free body: clamped loads, so that unrolled trips overlap)
     const int dr = i / (A.T * R), r = (i / R) % A.T, j = i % R;
-    float val;
-    if (j < 32) {
-      const int net = j >> 4, u = j & 15;
-      const float* tf = A.packed + (size_t)net * NF + (2 * NT * 64) * 4;
-      val = fmaf(tf[u * 4], A.trig[2 * r], fmaf(tf[(16 + u) * 4], A.trig[2 * r + 1], tf[(32 + u) * 4]));
-    } else {
-      const int dim = j - 32;
-      const float m = dim < A.d ? A.masks[r * A.d + dim] : 0.f;
-      val = dr ? m : 1.f - m;              // forward keeps m first, backward keeps 1 - m first
-    }
-    smem[A.o_rec + dr * RECD + (r + 1) * R + j] = val;
+    const bool tb = j < 32;
+    const int net = tb ? j >> 4 : 0, u = j & 15, dim = tb ? 0 : j - 32;
+    const float* tf = A.packed + (size_t)net * NF + (2 * NT * 64) * 4;
+    const float a0 = tf[u * 4], a1 = tf[(16 + u) * 4], a2 = tf[(32 + u) * 4], c0 = A.trig[2 * r], c1 = A.trig[2 * r + 1];
+    const float mk = A.masks[r * A.d + (dim < A.d ? dim : 0)];
+    const float m = dim < A.d ? mk : 0.f;
+    // time / bias row, or the mask row: forward keeps m first, backward keeps 1 - m first
+    smem[A.o_rec + dr * RECD + (r + 1) * R + j] = tb ? fmaf(a0, c0, fmaf(a1, c1, a2)) : (dr ? m : 1.f - m);
   }
   stage_energy<EK, false>(A, smem, tid, nthr);
 
