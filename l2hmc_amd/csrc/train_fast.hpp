@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   const float heps = 0.5f * eps;
   const float rw_den = A.easy ? A.eta : A.eta * A.eta;
   const f4 Z = splat(0.f);
+  constexpr int W_TAU = NW > 1 ? 1 : 0;          // the wave that accumulates the time-embedding gradient rows
 
   // unit carried by MFMA row i / by k index (q, r): rows 4 q' + r' with r' < KH are live, unit = q' KH + r'
   auto unit_row = [&](int i) { return ((i & 3) < KH) ? (i >> 2) * KH + (i & 3) : -1; };
@@ -338,11 +339,15 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     const f4 tda1 = transp(da1);
     G.w1 = chain4(transp(a), tda1, G.w1);
     G.w2 = chain4(transp(b), tda1, G.w2);
-    G.w4 = chain4(transp(C.h1), transp(da2), G.w4);
-    f4 tt;                                       // rows: 0 -> 1, 1 -> cos, 2 -> sin of chain 4 q + r
+    // the hidden vectors are the same in every wave: ONE wave forms the layer-2 tile, ANOTHER the time-embedding rows
+    // (every wave used to compute both and three of four threw them away -- the slowest wave sets the pace)
+    if (w == 0) G.w4 = chain4(transp(C.h1), transp(da2), G.w4);
+    if (w == W_TAU) {
+      f4 tt;                                     // rows: 0 -> 1, 1 -> cos, 2 -> sin of chain 4 q + r
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tt[r] = c == 0 ? 1.f : (c == 1 ? scr[320 + 2 * (4 * q + r)] : (c == 2 ? scr[320 + 2 * (4 * q + r) + 1] : 0.f));
-    G.tau = chain4(tt, tda1, G.tau);
+      for (int r = 0; r < 4; ++r) tt[r] = c == 0 ? 1.f : (c == 1 ? scr[320 + 2 * (4 * q + r)] : (c == 2 ? scr[320 + 2 * (4 * q + r) + 1] : 0.f));
+      G.tau = chain4(tt, tda1, G.tau);
+    }
     TS_MARK(7);    // weight-gradient products (operand transposes + chain contractions)
   };
 
@@ -600,6 +605,8 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
           else Gn[o.b4 + ui] = G.w4[r];
         }
       }
+    }
+    if (w == W_TAU) {
       if (q == 0 && ui >= 0 && ui < H) {         // rows 0, 1, 2 of the (1, cos, sin) product
         Gn[o.b1 + ui] = G.tau[0]; Gn[o.b2 + ui] = G.tau[0]; Gn[o.b3 + ui] = G.tau[0];
         Gn[o.W3 + ui] = G.tau[1];
