@@ -848,7 +848,16 @@ __global__ void train_reduce_kernel(const float* part, int n_slots, int n_grad, 
   if (i >= n_grad) return;
   const int b0 = c * chunk, b1 = (b0 + chunk < n_slots) ? b0 + chunk : n_slots;
   float s = 0.f;
-  for (int b = b0; b < b1; ++b) s += part[(long long)b * n_grad + i];
+  // (the loads of eight slots are in flight together; the additions stay in slot order)
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = part[(long long)(b + u) * n_grad + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; b < b1; ++b) s += part[(long long)b * n_grad + i];
   if (accumulate) dst[i] += s; else dst[(long long)c * n_grad + i] = s;
 }
 
