@@ -41,7 +41,11 @@ __host__ __device__ inline TFLayout tf_layout(int T, int NW) {
   L.total = p;
   return L;
 }
-constexpr int TF_CK = 5;                   // checkpointed float4 per lane and step: x, v, v_half, y, x'
+// checkpointed float4 per lane and step: x, v, v_half, y, x' and, per net evaluation e = 0..3 of the step (slots 5 + 2 e, + 1; the
+// first 64 lanes of the slot: the hidden vectors are the same in every wave, wave 0 writes them), the hidden activations h1, h2:
+// the reverse sweep reads them back one evaluation ahead and redoes only the heads -- no layer-1 products, no cross-wave sum, no
+// layer 2 in the re-evaluation (storing the head outputs too was measured: at 4096 chains its 1 GB of traffic eats the gain)
+constexpr int TF_CK = 13;
 
 template <int EK, int NW, int KH>
 __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
@@ -401,19 +405,35 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   f4* ck = reinterpret_cast<f4*>(A.ws) + ((long long)blockIdx.x * T * TF_CK) * (NW * 64) + w * 64 + lane;
   auto ckp = [&](int it, int slot) -> f4& { return ck[((long long)it * TF_CK + slot) * (NW * 64)]; };
 
+  f4* ck0 = reinterpret_cast<f4*>(A.ws) + ((long long)blockIdx.x * T * TF_CK) * (NW * 64) + lane;     // wave 0's lanes of a slot
+  auto ckh = [&](int it, int slot) -> f4& { return ck0[((long long)it * TF_CK + slot) * (NW * 64)]; };
+  auto put_cache = [&](int it, int e, const Cache& Cc) {
+    if (w == 0) { ckh(it, 5 + 2 * e) = Cc.h1; ckh(it, 6 + 2 * e) = Cc.h2; }
+  };
+  struct Hid { f4 h1, h2; };
+  auto get_cache = [&](int seq) {                 // seq = 0, 1, ...: the evaluations in the order the reverse sweep meets them
+    const int it = T - 1 - (seq >> 2), e = 3 - (seq & 3);
+    Hid h;
+    h.h1 = ckh(it, 5 + 2 * e); h.h2 = ckh(it, 6 + 2 * e);
+    return h;
+  };
   // ---- forward trajectory with checkpoints -----------------------------------------------------------------------------
   Cache C;
   for (int it = 0; it < T; ++it) {
     set_step(it);
     net_fwd(1, x, g, tbv, C);
+    put_cache(it, 0, C);
     const f4 vh = v_half_f(C, v, g);
     net_fwd(0, vh, k1 * x, tbx, C);
+    put_cache(it, 1, C);
     const f4 y = x_half_f(C, x, k1, vh);
     net_fwd(0, vh, (splat(1.f) - k1) * y, tbx, C);
+    put_cache(it, 2, C);
     const f4 xo = x_half_f(C, y, splat(1.f) - k1, vh);
     ckp(it, 0) = x; ckp(it, 1) = v; ckp(it, 2) = vh; ckp(it, 3) = y; ckp(it, 4) = xo;
     g = gradU(xo);
     net_fwd(1, xo, g, tbv, C);
+    put_cache(it, 3, C);
     v = v_half_f(C, vh, g);
     x = xo;
   }
@@ -518,6 +538,20 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
 
   TS_MARK(2);      // reductions, seeds
   // ---- reverse sweep ---------------------------------------------------------------------------------------------------------
+  int seq = 0;
+  Hid Hn = get_cache(0);                          // the next evaluation's hidden activations, requested one evaluation ahead
+  auto next_cache = [&](int net) {                // C of the evaluation the sweep is at: stored h1, h2 + the heads redone
+    const float* gb = net ? grpv : grpx;
+    C.h1 = Hn.h1; C.h2 = Hn.h2;
+    ++seq;
+    if (seq < 4 * T) Hn = get_cache(seq);
+    const f4 zs = chainK(frag(gb, 2 + 3 * w + 0), C.h2, Z);
+    const f4 zt = chainK(frag(gb, 2 + 3 * w + 1), C.h2, Z);
+    const f4 zq = chainK(frag(gb, 2 + 3 * w + 2), C.h2, Z);
+    C.ts = tanh4(zs);
+    C.Tt = zt;
+    C.tq = tanh4(zq);
+  };
   for (int it = T - 1; it >= 0; --it) {
     set_step(it);
     const f4 cx = ckp(it, 0), cv = ckp(it, 1), cvh = ckp(it, 2), cy = ckp(it, 3), cxo = ckp(it, 4);
@@ -526,8 +560,8 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     // (1) v' = v_half(vh; g(x'), V(x', g(x')))
     f4 gq = gradU(cxo);
     TS_MARK(3);
-    net_fwd(1, cxo, gq, tbv, C);
-    TS_MARK(5);    // re-evaluation of the net (+ grad U)
+    next_cache(1);
+    TS_MARK(5);    // stored hidden activations + the heads redone
     v_half_b(C, lv, cvh, gq, dvh, dg, dzs, dzt, dzq, dA, dB);
     TS_MARK(8);    // adjoint of the half update
     net_bwd(1, C, cxo, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
@@ -535,7 +569,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     // (2) x' = x_half(y, k2; vh, X(vh, k2 y)),  k2 = 1 - k1
     const f4 k2 = one - k1;
     TS_MARK(3);
-    net_fwd(0, cvh, k2 * cy, tbx, C);
+    next_cache(0);
     TS_MARK(5);
     x_half_b(C, lx, cy, k2, cvh, dz, dvh, dzs, dzt, dzq, dA, dB); // dz = d y (direct part)
     TS_MARK(8);
@@ -544,7 +578,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     dz += k2 * db;
     // (3) y = x_half(x, k1; vh, X(vh, k1 x))
     TS_MARK(3);
-    net_fwd(0, cvh, k1 * cx, tbx, C);
+    next_cache(0);
     TS_MARK(5);
     x_half_b(C, dz, cx, k1, cvh, lx, dvh, dzs, dzt, dzq, dA, dB); // lx = d x (direct part)
     TS_MARK(8);
@@ -554,7 +588,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     // (4) vh = v_half(v; g(x), V(x, g(x)))
     gq = gradU(cx);
     TS_MARK(3);
-    net_fwd(1, cx, gq, tbv, C);
+    next_cache(1);
     TS_MARK(5);
     v_half_b(C, dvh, cv, gq, lv, dg, dzs, dzt, dzq, dA, dB);
     TS_MARK(8);
