@@ -4,18 +4,20 @@
 //
 // Same mathematics as train_fast_kernel / train_kernel (hand-derived reverse mode of one direction-mixed proposal and its
 // loss term incl. the Hessian-vector path through grad U; derivation = oracle/l2hmc_train_oracle.py), in the layout of
-// traj_small.hpp: ONE wave owns 16 chains, lane l = (c = l & 15, q = l >> 4) holds chain c, DIMENSION q -- every state and
-// adjoint vector is a scalar per lane; hidden vectors stay float4 {h[unit(q, r)][chain c]}.  Per net evaluation:
+// traj_small.hpp: 16 chains per workgroup, lane l = (c = l & 15, q = l >> 4) holds chain c, DIMENSION q -- every state and
+// adjoint vector is a scalar per lane; hidden vectors stay float4 {h[unit(q, r)][chain c]}.  TWO waves: wave 0 runs the
+// trajectory and the adjoint recursion, wave 1 accumulates the weight-gradient tiles from the operands wave 0 leaves in LDS
+// (see the kernel head).  Per net evaluation:
 //   * layer 1: the d <= 4 dimensions are ONE k-step (k = q): 1 MFMA per input instead of 4;
 //   * heads: ONE 16-row block whose row 4 q' + h is (dimension q', head h = S, T, Q): KH MFMAs instead of 3 KH, and lane
 //     (c, q) finds z_S, z_T, z_Q of its own dimension in acc[0..2];
 //   * reverse: (dz_S, dz_T, dz_Q, 0) of a lane IS the B operand of the transposed head product (k-step h <-> head h);
 //     the input adjoints come back on rows 4 j (dimension j) so that lane q reads its own in acc[0];
-//   * weight gradients: the same transposes through a per-wave LDS scratch and 16 x 16 register tiles as train_fast, but
-//     ONE head tile per net (rows = (dimension, head)) instead of three.
-// 48 MFMAs per net evaluation + back-propagation instead of 69 + 20 recomputed ... per leapfrog step and wave: 192 instead
-// of 356 MFMAs, and every elementwise update is scalar instead of float4.  No barriers after staging (one wave), no atomics:
-// the workgroup's flat gradient goes to its workspace slot, train_reduce_kernel adds the slots in block order.
+//   * weight gradients: the same transposes through an LDS scratch and 16 x 16 register tiles as train_fast, but ONE head
+//     tile per net (rows = (dimension, head)) instead of three -- and on the second wave, off the step's dependency chain.
+// 48 MFMAs per net evaluation + back-propagation instead of 69 + 20 recomputed ... per leapfrog step: 192 instead of 356
+// MFMAs, and every elementwise update is scalar instead of float4.  One barrier per back-propagation (the operand hand-over),
+// no atomics: the workgroup's flat gradient goes to its workspace slot, train_reduce_kernel adds the slots in block order.
 // Targets: diagonal and dense Gaussians, Rough Well, mixtures of Gaussians (<= 8 components); the funnel stays on train_fast.
 #pragma once
 
