@@ -46,6 +46,16 @@ def test_argument_validation_without_gpu():
     with pytest.raises(RuntimeError, match="libl2hmc_hip"):
         _ffi.check(L.l2hmc_trajectory(a, None))
     assert L.l2hmc_mh_select(None, None, None, None, 4, 2, None, None) == -1
+    assert L.l2hmc_loss_terms(None, 4, 0.1, 0.25, None, None) == -1
+    # which training shapes a fused kernel holds (the host hands the others to the GEMM-engine trainer): pure host logic
+    G, D, M, R, F = (_ffi.ENERGY_GAUSS_DIAG, _ffi.ENERGY_GAUSS_DENSE, _ffi.ENERGY_GMM, _ffi.ENERGY_ROUGHWELL, _ffi.ENERGY_FUNNEL)
+    assert L.l2hmc_train_fused_lds_bytes(D, 1, 2, 10, 10) > 0            # notebook config: the d <= 4 kernel
+    assert L.l2hmc_train_fused_lds_bytes(M, 2, 2, 10, 10) > 0            # mixtures on it too
+    assert 0 < L.l2hmc_train_fused_lds_bytes(G, 1, 50, 10, 10) <= 160 * 1024      # ICG-50: register-resident, one workgroup per CU
+    assert L.l2hmc_train_fused_lds_bytes(R, 1, 128, 10, 10) == -2        # beyond the 16-chain tile's LDS plan
+    assert L.l2hmc_train_fused_lds_bytes(G, 1, 50, 40, 10) == -2         # wide nets
+    assert L.l2hmc_train_fused_lds_bytes(F, 1, 16, 10, 10) > 0 and L.l2hmc_train_fused_lds_bytes(F, 1, 20, 10, 10) == -2
+    assert L.l2hmc_train_fused_lds_bytes(99, 1, 2, 10, 10) == -2 and L.l2hmc_train_fused_lds_bytes(G, 1, 0, 10, 10) == -1
 
 
 def test_struct_layout_matches_header():
