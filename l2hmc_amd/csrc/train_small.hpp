@@ -35,7 +35,12 @@ __host__ __device__ inline TSLayout ts_layout(int T) {
   L.total = p;
   return L;
 }
-constexpr int TS_CK = 5;                      // checkpointed scalars per lane and step: x, v, v_half, y, x'
+// checkpointed scalars per lane and step: x, v, v_half, y, x' and, per net evaluation e = 0..3 of the step (slots 5 + 11 e ...),
+// everything its back-propagation needs -- h1 (4), h2 (4), tanh(zs), T, tanh(zq): the reverse sweep reads them back one evaluation
+// ahead instead of re-evaluating the net (11 KB per step and tile: the tiles of a d <= 4 problem are few).  49 x 64 floats per step
+// stay inside the TF_CK x 256 the workspace reserves per tile and step.
+constexpr int TS_CK = 49;
+static_assert(TS_CK * 64 <= TF_CK * 256, "the d <= 4 trainer's checkpoints must fit the per-tile workspace stride");
 
 template <int EK, int KH>
 __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
@@ -411,20 +416,38 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
   red[1] = 0.5f * v * v;                         // K0
   float* ck = A.ws + ((long long)blockIdx.x * T * TS_CK) * 64 + lane;
   auto ckp = [&](int it, int slot) -> float& { return ck[((long long)it * TS_CK + slot) * 64]; };
+  auto put_cache = [&](int it, int e, const Cache& Cc) {
+    const int b = 5 + 11 * e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ckp(it, b + r) = Cc.h1[r]; ckp(it, b + 4 + r) = Cc.h2[r]; }
+    ckp(it, b + 8) = Cc.ts; ckp(it, b + 9) = Cc.Tt; ckp(it, b + 10) = Cc.tq;
+  };
+  auto get_cache = [&](int seq) {                   // seq = 0, 1, ...: the evaluations in the order the reverse sweep meets them
+    const int it = T - 1 - (seq >> 2), b = 5 + 11 * (3 - (seq & 3));
+    Cache Cc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { Cc.h1[r] = ckp(it, b + r); Cc.h2[r] = ckp(it, b + 4 + r); }
+    Cc.ts = ckp(it, b + 8); Cc.Tt = ckp(it, b + 9); Cc.tq = ckp(it, b + 10);
+    return Cc;
+  };
 
   // ---- forward trajectory with checkpoints ------------------------------------------------------------------------------------------
   Cache C;
   for (int it = 0; it < T; ++it) {
     set_step(it);
     net_fwd(1, x, g, tbv, C);
+    put_cache(it, 0, C);
     const float vh = v_half_f(C, v, g);
     net_fwd(0, vh, k1 * x, tbx, C);
+    put_cache(it, 1, C);
     const float y = x_half_f(C, x, k1, vh);
     net_fwd(0, vh, (1.f - k1) * y, tbx, C);
+    put_cache(it, 2, C);
     const float xo = x_half_f(C, y, 1.f - k1, vh);
     ckp(it, 0) = x; ckp(it, 1) = v; ckp(it, 2) = vh; ckp(it, 3) = y; ckp(it, 4) = xo;
     g = gradU(xo);
     net_fwd(1, xo, g, tbv, C);
+    put_cache(it, 3, C);
     v = v_half_f(C, vh, g);
     x = xo;
   }
@@ -503,6 +526,13 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
 
   TS_MARK(2);      // reductions, accept probability, adjoint seeds
   // ---- reverse sweep ---------------------------------------------------------------------------------------------------------------
+  int seq = 0;
+  Cache Cn = get_cache(0);                          // the next evaluation's activations, requested one evaluation ahead
+  auto next_cache = [&]() {
+    C = Cn;
+    ++seq;
+    if (seq < 4 * T) Cn = get_cache(seq);
+  };
   float nx = ckp(T - 1, 0), nv = ckp(T - 1, 1), nvh = ckp(T - 1, 2), ny = ckp(T - 1, 3), nxo = ckp(T - 1, 4);
   for (int it = T - 1; it >= 0; --it) {
     set_step(it);
@@ -514,8 +544,8 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
     TS_MARK(8);    // step head: schedule record, checkpoint hand-over
     // (1) v' = v_half(vh; g(x'), V(x', g(x')))
     float gq = gradU(cxo);
-    net_fwd(1, cxo, gq, tbv, C);
-    TS_MARK(3);    // re-evaluation of the net (+ grad U)
+    next_cache();
+    TS_MARK(3);    // grad U + hand-over of the stored activations
     v_half_b(C, lv, cvh, gq, dvh, dg, dzs, dzt, dzq, dA, dB);
     TS_MARK(4);    // adjoint of the half update
     net_bwd(1, C, cxo, gq, dzs, dzt, dzq, dA, dB, GV, da, db);
@@ -523,7 +553,7 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
     // (2) x' = x_half(y, k2; vh, X(vh, k2 y)),  k2 = 1 - k1
     const float k2 = 1.f - k1;
     TS_MARK(8);
-    net_fwd(0, cvh, k2 * cy, tbx, C);
+    next_cache();
     TS_MARK(3);
     x_half_b(C, lx, cy, k2, cvh, dz, dvh, dzs, dzt, dzq, dA, dB); // dz = d y (direct part)
     TS_MARK(4);
@@ -532,7 +562,7 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
     dz += k2 * db;
     // (3) y = x_half(x, k1; vh, X(vh, k1 x))
     TS_MARK(8);
-    net_fwd(0, cvh, k1 * cx, tbx, C);
+    next_cache();
     TS_MARK(3);
     x_half_b(C, dz, cx, k1, cvh, lx, dvh, dzs, dzt, dzq, dA, dB); // lx = d x (direct part)
     TS_MARK(4);
@@ -542,7 +572,7 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
     // (4) vh = v_half(v; g(x), V(x, g(x)))
     TS_MARK(8);
     gq = gradU(cx);
-    net_fwd(1, cx, gq, tbv, C);
+    next_cache();
     TS_MARK(3);
     v_half_b(C, dvh, cv, gq, lv, dg, dzs, dzt, dzq, dA, dB);
     TS_MARK(4);
