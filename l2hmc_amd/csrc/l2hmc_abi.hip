@@ -117,24 +117,27 @@ __global__ void pack_gauss_kernel(const float* S, int d, int NT, float* out) {
   out[idx] = (a < d && b < d) ? 0.5f * (S[a * d + b] + S[b * d + a]) : 0.f;
 }
 
-// sum 1 / v and sum v in double: one workgroup, fixed order (thread t takes elements t, t + 256, ...; LDS tree)
+// sum 1 / v and sum v in double: one workgroup, fixed order (thread t takes elements t, t + 256, ...; butterfly inside each
+// wave, the four wave sums added in wave order: one barrier)
 __global__ __launch_bounds__(256) void loss_terms_kernel(const float* v1, long long n, float scale, double inv_n, double* out3) {
-  __shared__ double sa[256], sb[256];
+  __shared__ double sa[4], sb[4];
   double a = 0.0, b = 0.0;
   for (long long i = threadIdx.x; i < n; i += 256) {
-    const double v = (double)v1[i];
-    a += 1.0 / v;
-    b += v;
+    const float v = v1[i];
+    a += 1.0 / (double)v;
+    b += (double)v;
   }
-  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off);
+    b += __shfl_xor(b, off);
+  }
+  if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
-    out3[0] = sa[0]; out3[1] = sb[0];
-    out3[2] = inv_n * ((double)scale * sa[0] - sb[0] / (double)scale);
+    const double A_ = ((sa[0] + sa[1]) + sa[2]) + sa[3], B_ = ((sb[0] + sb[1]) + sb[2]) + sb[3];
+    out3[0] = A_; out3[1] = B_;
+    out3[2] = inv_n * ((double)scale * A_ - B_ / (double)scale);
   }
 }
 
