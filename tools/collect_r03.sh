@@ -60,6 +60,7 @@ rm -rf $OUT/trace $OUT/trace20 $OUT/vae $OUT/pmc_*/*.db $OUT/vae_pmc/*.db
 
 cd $R
 timeout 200 python tools/bench_train.py --no-cpu 2>&1 | grep -v amdgpu > $OUT/train_timing.txt
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trk -o t -- python $R/tools/bench_train.py --no-cpu > /dev/null 2>&1; cp $OUT/trk/t_kernel_stats.csv $OUT/train_kernel_stats.csv 2>/dev/null; rm -rf $OUT/trk)
 timeout 200 python tools/bench_vae_train.py 2>&1 | grep -v amdgpu > $OUT/vae_train_timing.txt
 timeout 100 python tools/bench_vae.py 8192 0 2>&1 | grep -v amdgpu > $OUT/vae_modes.txt
 timeout 100 python tools/bench_vae.py 8192 1 2>&1 | grep -v amdgpu >> $OUT/vae_modes.txt
