@@ -194,17 +194,17 @@ class Trainer(object):
         return int(counts.sum()), int(counts[:rank].sum())
 
     def _loss(self, v12, N, n_total, world):
-        # one fixed-order double reduction on the device (l2hmc_loss_terms) instead of a dozen elementwise framework kernels
-        if getattr(self, "_lt", None) is None or self._lt.device != v12.device:
-            self._lt = torch.empty(3, dtype=torch.float64, device=v12.device)
+        # one fixed-order double reduction on the device (l2hmc_loss_terms) instead of a dozen elementwise framework kernels;
+        # the three doubles land in a FRESH tensor (an allocation, not a launch), so the returned loss is the caller's own
+        lt = torch.empty(3, dtype=torch.float64, device=v12.device)
         _ffi.check(_ffi.lib().l2hmc_loss_terms(v12.data_ptr(), v12.numel(), self.scale, 1.0 / float(n_total),
-                                               self._lt.data_ptr(), _ffi.current_stream(v12.device)))
+                                               lt.data_ptr(), _ffi.current_stream(v12.device)))
         if world > 1:
-            terms = self._lt[:2].clone()
+            terms = lt[:2]
             dist.all_reduce(terms)
             terms = terms / n_total
             return self.scale * terms[0] - terms[1] / self.scale
-        return self._lt[2].clone()
+        return lt[2]
 
     def loss_and_grad(self, x, z=None, draws=None):
         """Loss and gradients (left in `.grad` of every parameter) for chain states `x`.
@@ -272,8 +272,10 @@ class Trainer(object):
                                     io["dir"].data_ptr(), io["u"].data_ptr(), s))
         W[0].copy_(x)
         self.flat.zero_()
+        # (the accept probabilities go to a FRESH tensor -- an allocation, not a launch -- whose first half is returned)
+        p12 = torch.empty(2 * N, dtype=torch.float32, device=dyn.device)
         self._propose_grad(W[0:2].view(2 * N, d), W[2:4].view(2 * N, d), io["dir"][1:3].view(2 * N), n_total,
-                           out=(io["Lx"], io["p"], io["v1"]))
+                           out=(io["Lx"], p12, io["v1"]))
         if world > 1:
             dist.all_reduce(self.flat)                  # the ONE collective of a training step
         loss = self._loss(io["v1"], N, n_total, world)
@@ -286,9 +288,9 @@ class Trainer(object):
         dyn._packed_key = None                          # the weights changed under the packed-fragment cache
         x_next = torch.empty_like(x)
         uu = io["u"][0] if u is None else as_device_f32(u, dyn.device)
-        _ffi.check(L.l2hmc_mh_select(x.data_ptr(), io["Lx"].data_ptr(), io["p"].data_ptr(), uu.data_ptr(), N, d,
+        _ffi.check(L.l2hmc_mh_select(x.data_ptr(), io["Lx"].data_ptr(), p12.data_ptr(), uu.data_ptr(), N, d,
                                      x_next.data_ptr(), s))
-        return loss, io["p"][:N].clone(), x_next, lr
+        return loss, p12[:N], x_next, lr
 
 
 _MLP_FIELDS = ("W1", "b1", "W2", "b2", "W3", "b3")
