@@ -163,3 +163,22 @@ def test_small_func_utils_and_losses_helpers():
     class G(object):
         mu, sigma = np.zeros(2), np.eye(2)
     assert abs(F.get_log_likelihood(np.zeros((3, 2)), G) + np.log(2 * np.pi)) < 1e-12
+
+
+def test_trainer_picks_the_engine_from_the_shape_without_a_gpu():
+    """`Trainer(dynamics)` asks the library which shapes a fused training kernel holds (`l2hmc_train_fused_lds_bytes`,
+    host logic) and hands the others -- d > 64 at H = 10, wide nets, caller-supplied energies -- to the GEMM-engine
+    trainer; construction needs no device work."""
+    from l2hmc_amd import Dynamics, layers
+    from l2hmc_amd.training import SplitTrainer, Trainer
+
+    def make(d, H=10, energy=None):
+        e = energy if energy is not None else D.RoughWell(d, 0.1, easy=True).get_energy_function()
+        return Dynamics(d, e, T=5, eps=0.1, net_factory=layers.stq_network(H), device="cpu")
+    assert type(Trainer(make(50))) is Trainer
+    assert type(Trainer(make(2))) is Trainer
+    assert isinstance(Trainer(make(128)), SplitTrainer)
+    assert isinstance(Trainer(make(50, H=32)), SplitTrainer)
+    tr = Trainer(make(3, energy=lambda x: (x * x).sum(1)))
+    assert isinstance(tr, SplitTrainer) and tr.user and not tr.image_sampler
+
