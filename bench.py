@@ -48,6 +48,7 @@ sys.path.insert(0, ROOT)
 D, H, T, CHAINS = 50, 10, 10, 4096
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector) peak
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (the pipe the bf16x3 products execute on)
 
 
 def algorithmic_flops_per_chain_step(d, h, t, grad_flops):
@@ -209,6 +210,10 @@ def config5_leg(dev, chains=8192):
     f_dec = 2 * (d * 1024 + 1024 * 1024 + 1024 * 784)
     flops_step = 4 * f_net + (1 + 1.0 / T) * 2 * f_dec                      # per chain . leapfrog step
     ach = chains * T * flops_step / (ms_prop * 1e-3) / 1e12
+    # the share of it in the 1024-wide decoder products (the ones that take the bf16x3 path; the K = 50 layer and the
+    # N = 50 latent gradient stay on the f32 MFMA)
+    f_dec_big = 2 * (1024 * 1024 + 1024 * 784)
+    ach_dec = chains * T * (1 + 1.0 / T) * 2 * f_dec_big / (ms_prop * 1e-3) / 1e12
     tr = Trainer(dyn, decay_steps=0)
     log_sigma = torch.full((chains, d), -0.5, device=dev)
     ms_train = timed(lambda: tr.sampler_step(state["x"], aux, log_sigma, MH=1), 2, 4)
@@ -218,6 +223,13 @@ def config5_leg(dev, chains=8192):
             "kernels": "gemm_nt_kernel (fused epilogues), net_eval_kernel (+ fused half-updates), gemm_tn_kernel (training)",
             "ms_per_proposal": ms_prop, "value": chains * T / (ms_prop * 1e-3), "unit": "chain\u00b7leapfrog-steps/s",
             "flops_per_chain_step": flops_step, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "frac": ach / PEAK_F32_MFMA_TFLOPS,
+            # what the matrix pipe really executes: with gemm_mode = 1 (the default) the decoder-sized products run as
+            # "bf16x3" -- six bf16 MFMAs per fp32 product, fp32-accurate -- so `frac` above is ALGORITHMIC
+            # fp32 flops over the f32-MFMA roof, not the utilisation of the pipe the products run on
+            "arithmetic": "bf16x3 (decoder GEMMs: 3-way split fp32 operands, 6 bf16 MFMAs per product, fp32 accumulate); "
+                          "f32 MFMA for the K = 50 / N = 50 / H = 200 products" if int(getattr(dyn, "gemm_mode", 1)) == 1 else "f32 MFMA",
+            "executed_tflops": (ach_dec * (6.0 if int(getattr(dyn, "gemm_mode", 1)) == 1 else 1.0) + (ach - ach_dec)),
+            "frac_of_bf16_roof": (ach_dec * 6.0 / PEAK_BF16_MFMA_TFLOPS) if int(getattr(dyn, "gemm_mode", 1)) == 1 else None,
             "mean_accept_prob": float(state["p"].mean()), "state_finite": bool(torch.isfinite(state["x"]).all()),
             "train": {"workload": "sampler update of mnist_vae.py:185-262, one differentiated proposal per step",
                       "ms_per_step": ms_train, "flops_per_chain": flops_train,
@@ -372,7 +384,7 @@ def dist_leg(dev, rank, world):
     chk = torch.stack([tr.theta.double().sum(), -tr.theta.double().sum()])
     dist.all_reduce(chk, op=dist.ReduceOp.MAX)
     same = bool(abs(float(chk[0]) + float(chk[1])) == 0.0)
-    return {"rccl_ranks": int(ones.item()),
+    return {"backend": dist.get_backend(), "ranks": int(ones.item()),
             "sharded_ess": {"workload": "SCG-2D HMC eps=0.15, %d chains (200 per rank) x %d MH steps, in-kernel "
                                         "Philox keyed by global chain; autocov partial sums + accept all-reduced" % (n * world, steps),
                             "ess_per_mh_step": ess, "mean_accept_prob": acc, "ess_per_sec": ess * steps / el * n * world,
@@ -575,6 +587,7 @@ def main():
     if est_ms > 0 and args.steps * est_ms < args.min_timed_ms:
         R = int(math.ceil(args.min_timed_ms / (args.steps * est_ms)))
     elapsed, gpu_ms, nl, nxt = timed(main_run, nxt, args.steps, R)
+    main_kernel = _ffi.last_kernel()
     mean_p = float(main_run.p_out.mean())
     finite = bool(torch.isfinite(main_run.bufs[main_run.flip]).all())
     if world > 1:
@@ -583,10 +596,6 @@ def main():
         elapsed = float(tt)
 
     flops_cs = algorithmic_flops_per_chain_step(D, H, T, 3 * D)      # diagonal precision: 3d
-
-    def kernel_for(chains):
-        """the library's dispatch for this workload (l2hmc_abi.hip): one-wave tiles once the chip is full"""
-        return "traj_tile_kernel" if chains >= 16384 else "traj_fast_kernel"
 
     def point(nc, chain_off_, seed, steps=100):
         """one extra roofline point: `nc` chains on this rank through the same sampler loop, timed like the main
@@ -600,19 +609,19 @@ def main():
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             el2 = float(t2)
         return (el2, ms2, nl2, steps * reps, float(r2.p_out.mean()),
-                bool(torch.isfinite(r2.bufs[r2.flip]).all()))
+                bool(torch.isfinite(r2.bufs[r2.flip]).all()), _ffi.last_kernel())     # (the library names what it launched)
 
     strong_out = None
     if world > 1 and not strong and not args.no_sweep:
         # the north star's operating point: ICG-50, 65 536 chains IN TOTAL over the ranks (every rank takes part)
         tot = 65536
         lo, hi = sharding.shard_range(tot, rank, world)
-        el2, ms2, nl2, k2, p2, fin2 = point(hi - lo, lo, 4321 + rank)
+        el2, ms2, nl2, k2, p2, fin2, kn2 = point(hi - lo, lo, 4321 + rank)
         a2 = flops_cs * (hi - lo) * T * (k2 / float(nl2)) / (ms2 * 1e-3 / nl2) / 1e12
         strong_out = {"workload": "ICG-50D, %d chains in total = %d per GPU, Lf=10 (north_star: >= 1e8 on 8 GPUs, "
                                   ">= 6x 1 -> 8)" % (tot, hi - lo),
                       "value": tot * T * float(k2) / el2, "unit": "chain·leapfrog-steps/s", "scaling": "strong",
-                      "chains_per_gpu": hi - lo, "kernel": kernel_for(hi - lo), "rank0_achieved": a2,
+                      "chains_per_gpu": hi - lo, "kernel": kn2, "rank0_achieved": a2,
                       "rank0_frac": a2 / PEAK_F32_MFMA_TFLOPS, "rank0_launch_us": 1e3 * ms2 / nl2,
                       "mean_accept_prob": p2, "state_finite": fin2}
         ref = os.path.join(ROOT, "profiles", "n1_sweep65536.json")
@@ -620,7 +629,8 @@ def main():
             v1 = json.load(open(ref))
             strong_out["n1_value"] = v1["value"]
             strong_out["n1_source"] = v1["source"]
-            strong_out["speedup_vs_n1"] = strong_out["value"] / v1["value"]
+            # (NOT a same-run ratio: the denominator is the committed constant above, measured on one box of the pool)
+            strong_out["speedup_vs_committed_n1_constant"] = strong_out["value"] / v1["value"]
 
     dist_out = None
     if use_dist and not args.no_ess:
@@ -651,9 +661,13 @@ def main():
                        "mean_accept_prob": mean_p, "state_finite": finite},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": kernel_for(n), "flops_per_chain_step": flops_cs,
+                         "kernel": main_kernel, "flops_per_chain_step": flops_cs,
                          "launch_us": launch_s * 1e6,
-                         "hbm_frac": algorithmic_bytes_per_chain_step(D, T) * n * T * m_avg / launch_s / 1e9 / PEAK_HBM_GBS},
+                         # bytes the persistent loop has to move per launch: x in, x_next out, p per proposal (the
+                         # counters below replace this model when the committed PMC pass matches the workload)
+                         "algorithmic_bytes": 4.0 * n * (2 * D + m_avg),
+                         "hbm_frac": 4.0 * n * (2 * D + m_avg) / launch_s / 1e9 / PEAK_HBM_GBS,
+                         "hbm_frac_source": "algorithmic bytes per launch"},
         }
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):          # HBM bytes per launch from the committed PMC passes
@@ -665,14 +679,16 @@ def main():
                 out["roofline"]["traffic"] = 1024.0 * (t["fetch_kb"] + t["write_kb"]) + (m_avg - m_ref) * 4.0 * n
                 out["roofline"]["traffic_source"] = t["source"] + (
                     "" if m_avg == m_ref else "; p_out bytes rescaled from %g to %g proposals per launch" % (m_ref, m_avg))
+                out["roofline"]["hbm_frac"] = out["roofline"]["traffic"] / launch_s / 1e9 / PEAK_HBM_GBS
+                out["roofline"]["hbm_frac_source"] = "counter traffic (FETCH_SIZE + WRITE_SIZE) / HIP-event launch time"
         if world == 1 and not args.no_sweep and not strong and n == CHAINS:
             # the same kernel at the north star's chain count: what the MFMA roof fraction becomes once the
             # chip is filled (4096 chains are ONE workgroup per CU, one wave per SIMD)
             sweep = []
             for nc in (8192, 65536):      # 8192 = one GPU's share of the north star's 65 536 chains on 8 GPUs
-                el2, ms2, nl2, k2, p2, fin2 = point(nc, 0, 99)
+                el2, ms2, nl2, k2, p2, fin2, kn2 = point(nc, 0, 99)
                 a2 = flops_cs * nc * T * (k2 / float(nl2)) / (ms2 * 1e-3 / nl2) / 1e12
-                sweep.append({"chains": nc, "kernel": kernel_for(nc),
+                sweep.append({"chains": nc, "kernel": kn2,
                               "value": nc * T * float(k2) / el2, "achieved": a2,
                               "frac": a2 / PEAK_F32_MFMA_TFLOPS, "launch_us": 1e3 * ms2 / nl2,
                               "mean_accept_prob": p2, "state_finite": fin2})

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define L2HMC_ABI_VERSION 3
+#define L2HMC_ABI_VERSION 4
 
 enum {
   L2HMC_OK = 0,
@@ -148,6 +148,10 @@ enum { L2HMC_RNG_V = 1, L2HMC_RNG_DIR = 2, L2HMC_RNG_U = 4 };
 
 int l2hmc_abi_version(void);
 const char* l2hmc_last_error(void);
+/* Name of the kernel the last l2hmc_trajectory / l2hmc_train_propose_grad / l2hmc_train_step call of THIS thread chose
+ * (e.g. "traj_fast_kernel<1, 1, 4, 3>", spelt as rocprofv3 prints the instantiation; "" before the first call): what a
+ * profile of the call has to be matched against.  Copies at most n - 1 characters, returns the full length. */
+int32_t l2hmc_last_kernel(char* buf, int32_t n);
 
 /* Number of floats of the fragment-ordered weight buffer for both nets, or a negative
  * L2HMC_ERR_* if (d, H) is outside the fused kernels' range. */
@@ -355,6 +359,39 @@ int64_t l2hmc_train_grad_floats(int32_t d, int32_t H);
 int64_t l2hmc_train_fused_lds_bytes(int32_t energy_kind, int32_t n_comp, int32_t d, int32_t H, int32_t T);
 int l2hmc_train_propose_grad(const L2hmcTrainArgs* args, void* stream);
 
+/* One optimiser step's device work in as few launches as the data flow allows (ABI 4; SCGExperiment.ipynb raw 156-181,
+ * 254-271: propose(x) and propose(z), the loss of both, Adam, the MH-selected continuation of the x chains):
+ *   launch 1  l2hmc_train_propose_grad's kernel over `args` -- with the start points of chains [0, n_head) read from
+ *             `x_head` (no staging copy of the caller's state next to z), and the Metropolis select of those chains
+ *             (sampler.py:53-55) in its epilogue when u / x_next are given;
+ *   launch 2  the fixed-order slot reduction, which OVERWRITES args->grad (no zero fill), with
+ *             - the loss terms of args->v1 (as l2hmc_loss_terms) -> `loss` and, split into float (hi, lo) pairs,
+ *               -> `terms` = {sum 1/v1, sum v1, n_head}: the tail of the ONE buffer a sharded step all-reduces;
+ *             - Adam on theta / m / v (as l2hmc_adam_step) in the same launch when `theta` is given (a single-process
+ *               step; a sharded one all-reduces first and calls l2hmc_adam_step_terms).
+ * `terms` may point right behind the gradient (args->grad + l2hmc_train_grad_floats). */
+typedef struct L2hmcTrainStep {
+  const float* x_head;      /* (n_head, d) or NULL: start points of chains [0, n_head); the others stay in args->x  */
+  int64_t n_head;
+  const float* u;           /* (n_head) uniforms and ...                                                           */
+  float* x_next;            /* ... (n_head, d) selected states; both or neither                                     */
+  float* terms;             /* 6 floats or NULL                                                                     */
+  double* loss;             /* 3 doubles {sum 1/v1, sum v1, inv_n (scale sum 1/v1 - sum v1 / scale)} or NULL        */
+  float* theta;             /* flat parameters [XNet | VNet | alpha] or NULL (no optimiser in this call)            */
+  float* m;
+  float* v;
+  float lr, beta1, beta2, epsilon;
+  int64_t step;             /* Adam's t (>= 1)                                                                      */
+  int32_t train_alpha;      /* 1: the last gradient entry is d/d eps, the parameter is log eps                      */
+} L2hmcTrainStep;
+int l2hmc_train_step(const L2hmcTrainArgs* args, const L2hmcTrainStep* step, void* stream);
+/* Adam after a sharded step's all-reduce: grad = the reduced gradient, terms6 = the reduced tail written by
+ * l2hmc_train_step; the loss of the GLOBAL batch, (scale sum 1/v1 - sum v1 / scale) / count, lands in loss_out[2]
+ * ([0], [1]: the two sums). */
+int l2hmc_adam_step_terms(float* params, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                          float beta2, float epsilon, int64_t step, int32_t last_is_log_eps, const float* terms6,
+                          float scale, double* loss_out, void* stream);
+
 /* ---- training on the GEMM engine (next-row f1 for config 5 and for wide nets) ----------------------------------
  * l2hmc_train_propose_grad's contract -- ONE proposal per chain in the chain's own direction, its accept
  * probability, the loss argument and the gradient of the loss term (accumulated into `grad`) -- for the samplers the
@@ -469,7 +506,7 @@ int l2hmc_autocov(const float* X, int64_t steps, int64_t n_chains, int32_t d, do
  * what the library was compiled with (l2hmc_amd/_ffi.py does both when it loads the library).
  * which: one of L2HMC_STRUCT_*; returns sizeof in bytes, or L2HMC_ERR_ARG. */
 enum { L2HMC_STRUCT_NET = 0, L2HMC_STRUCT_ENERGY = 1, L2HMC_STRUCT_TRAJECTORY_ARGS = 2, L2HMC_STRUCT_MLP3 = 3,
-       L2HMC_STRUCT_SPLIT_ARGS = 4, L2HMC_STRUCT_TRAIN_ARGS = 5, L2HMC_STRUCT_TRAIN_SPLIT_ARGS = 6 };
+       L2HMC_STRUCT_SPLIT_ARGS = 4, L2HMC_STRUCT_TRAIN_ARGS = 5, L2HMC_STRUCT_TRAIN_SPLIT_ARGS = 6, L2HMC_STRUCT_TRAIN_STEP = 7 };
 int64_t l2hmc_struct_bytes(int32_t which);
 
 #ifdef __cplusplus

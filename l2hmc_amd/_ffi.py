@@ -96,12 +96,20 @@ class L2hmcTrainSplitArgs(C.Structure):
                 ("energy_cb", C.c_void_p), ("hvp_cb", C.c_void_p), ("energy_cb_user", C.c_void_p)]
 
 
-STRUCTS = (L2hmcNet, L2hmcEnergy, L2hmcTrajectoryArgs, L2hmcMlp3, L2hmcSplitArgs, L2hmcTrainArgs, L2hmcTrainSplitArgs)
+class L2hmcTrainStep(C.Structure):
+    _fields_ = [("x_head", _fp), ("n_head", C.c_int64), ("u", _fp), ("x_next", _fp), ("terms", _fp), ("loss", _fp),
+                ("theta", _fp), ("m", _fp), ("v", _fp), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("epsilon", C.c_float), ("step", C.c_int64), ("train_alpha", C.c_int32)]
+
+
+STRUCTS = (L2hmcNet, L2hmcEnergy, L2hmcTrajectoryArgs, L2hmcMlp3, L2hmcSplitArgs, L2hmcTrainArgs, L2hmcTrainSplitArgs,
+           L2hmcTrainStep)
 
 # every symbol include/l2hmc.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "l2hmc_abi_version": (C.c_int, []),
     "l2hmc_last_error": (C.c_char_p, []),
+    "l2hmc_last_kernel": (C.c_int32, [C.c_char_p, C.c_int32]),
     "l2hmc_struct_bytes": (C.c_int64, [C.c_int32]),
     "l2hmc_packed_nets_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_pack_nets": (C.c_int, [C.POINTER(L2hmcNet), C.POINTER(L2hmcNet), C.c_int32, C.c_int32,
@@ -123,6 +131,9 @@ SYMBOLS = {
     "l2hmc_train_grad_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_train_fused_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "l2hmc_train_propose_grad": (C.c_int, [C.POINTER(L2hmcTrainArgs), _fp]),
+    "l2hmc_train_step": (C.c_int, [C.POINTER(L2hmcTrainArgs), C.POINTER(L2hmcTrainStep), _fp]),
+    "l2hmc_adam_step_terms": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                        C.c_int64, C.c_int32, _fp, C.c_float, _fp, _fp]),
     "l2hmc_train_split_grad_floats": (C.c_int64, [C.c_int32, C.c_int32, C.POINTER(L2hmcMlp3)]),
     "l2hmc_train_split_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                        C.POINTER(L2hmcMlp3), C.POINTER(L2hmcMlp3)]),
@@ -141,7 +152,7 @@ SYMBOLS = {
                              _fp, _fp]),
 }
 
-ABI_VERSION = 3          # L2HMC_ABI_VERSION this binding was written against
+ABI_VERSION = 4          # L2HMC_ABI_VERSION this binding was written against
 _lib = None
 
 
@@ -154,18 +165,35 @@ def lib():
                 "l2hmc_amd: %s is missing -- the HIP extension has not been built "
                 "(run `make -C l2hmc_amd/csrc`); there is no CPU/eager fallback." % LIB_PATH)
         handle = C.CDLL(LIB_PATH)
+        # the version first: a stale library lacks the newer symbols, and "undefined symbol" says less than "rebuild"
+        try:
+            handle.l2hmc_abi_version.restype, handle.l2hmc_abi_version.argtypes = SYMBOLS["l2hmc_abi_version"]
+            found = handle.l2hmc_abi_version()
+        except AttributeError:
+            found = None
+        if found != ABI_VERSION:
+            raise RuntimeError("l2hmc_amd: ABI version mismatch (library %s, binding %d): rebuild with "
+                               "`make -C l2hmc_amd/csrc`" % (found, ABI_VERSION))
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(handle, name)
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                raise RuntimeError("l2hmc_amd: %s lacks the symbol %s of ABI %d -- stale build? rebuild with "
+                                   "`make -C l2hmc_amd/csrc`" % (LIB_PATH, name, ABI_VERSION))
             fn.restype, fn.argtypes = res, args
-        if handle.l2hmc_abi_version() != ABI_VERSION:
-            raise RuntimeError("l2hmc_amd: ABI version mismatch (library %d, binding %d): rebuild with "
-                               "`make -C l2hmc_amd/csrc`" % (handle.l2hmc_abi_version(), ABI_VERSION))
         for which, mirror in enumerate(STRUCTS):        # include/l2hmc.h: L2HMC_STRUCT_* in this order
             if handle.l2hmc_struct_bytes(which) != C.sizeof(mirror):
                 raise RuntimeError("l2hmc_amd: %s is %d bytes in the library, %d in the binding -- stale build?"
                                    % (mirror.__name__, handle.l2hmc_struct_bytes(which), C.sizeof(mirror)))
         _lib = handle
     return _lib
+
+
+def last_kernel():
+    """Name of the kernel the last trajectory / training call of this thread launched (as rocprofv3 spells it)."""
+    buf = C.create_string_buffer(96)
+    lib().l2hmc_last_kernel(buf, 96)
+    return buf.value.decode()
 
 
 def check(rc):

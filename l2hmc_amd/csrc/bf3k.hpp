@@ -1,0 +1,136 @@
+// bf3k.hpp -- fp32-accurate 16 x 16 x 16 contractions on the bf16 matrix pipe of gfx950, three MFMAs each ("bf16x3, K-packed").
+//
+// On gfx950 the f32-input MFMA (v_mfma_f32_16x16x4_f32, 32 cycles) blocks every VALU instruction of its SIMD, the bf16 MFMAs
+// (16.3 cycles for K = 16 and for K = 32 alike) do not (profiles/r03_ubench_issue.txt).  An fp32 number is exactly the sum of
+// three bf16 numbers, x = h + m + l (round-to-nearest at each level), and of the nine cross products of two such sums the six
+// with weight >= 2^-16 carry fp32 accuracy (the dropped ones are <= 3 x 2^-24 |x y|, one fp32 rounding).  Round 3 issued those
+// six as six K = 16 MFMAs (96 cycles per 16 x 16 x 16 block against 128 for four f32 k-steps -- no gain, measured).  The K = 32
+// instruction costs the same 16 cycles, so TWO of the six products ride in one instruction: physical k-slot 8 q + j of lane
+// (., q) carries part one of logical k = 4 q + j for j < 4 and part two of logical k = 4 q + (j - 4) for j >= 4 -- both parts
+// are split from the lane's OWN float4 (k-step r of the f32 form is element r of the same float4), no cross-lane traffic:
+//
+//      A operand (weights, split once when they are staged)        B operand (activations, split by the consuming wave)
+//      P = [a_h | a_m]                                             hh = [b_h | b_h]    ->  a_h b_h + a_m b_h
+//      P = [a_h | a_m]                                             mm = [b_m | b_m]    ->  a_h b_m + a_m b_m
+//      Q = [a_l | a_h]                                             hl = [b_h | b_l]    ->  a_l b_h + a_h b_l
+//
+// = 3 MFMAs x 16 cycles per 16 x 16 x 16 block (f32 form: 4 x 32, or 3 x 32 for the K = 12 hidden contractions), none of them
+// blocking the VALU.  The D layout is that of the 16x16x4 form (row 4 q + r, column c), so everything downstream is unchanged.
+// The split costs ~20 VALU per float4 (6 v_cvt_pk_bf16_f32, 8 shift / and, 4 subtractions, tuple copies).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace l2hmc {
+
+typedef float bfk_f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bfk_bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned bfk_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bfk_pk(float a, float b) {          // v_cvt_pk_bf16_f32: a -> low half, b -> high half (RNE)
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 r = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, r);
+}
+struct BfkHml { unsigned h[2], m[2], l[2]; };
+__device__ __forceinline__ BfkHml bfk_split(bfk_f4 x) {
+  BfkHml o;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const unsigned ph = bfk_pk(a, b);
+    const float ra = a - __uint_as_float(ph << 16), rb = b - __uint_as_float(ph & 0xffff0000u);
+    const unsigned pm = bfk_pk(ra, rb);
+    const float sa = ra - __uint_as_float(pm << 16), sb = rb - __uint_as_float(pm & 0xffff0000u);
+    o.h[i] = ph; o.m[i] = pm; o.l[i] = bfk_pk(sa, sb);
+  }
+  return o;
+}
+struct BfkW { bfk_u4 P, Q; };            // A operand of one 16 x 16 x 16 block (32 bytes per lane)
+struct BfkA { bfk_u4 hh, mm, hl; };      // B operand
+__device__ __forceinline__ BfkW bfk_wfrag(bfk_f4 w) {
+  const BfkHml s = bfk_split(w);
+  return BfkW{bfk_u4{s.h[0], s.h[1], s.m[0], s.m[1]}, bfk_u4{s.l[0], s.l[1], s.h[0], s.h[1]}};
+}
+__device__ __forceinline__ BfkA bfk_afrag(bfk_f4 x) {
+  const BfkHml s = bfk_split(x);
+  return BfkA{bfk_u4{s.h[0], s.h[1], s.h[0], s.h[1]}, bfk_u4{s.m[0], s.m[1], s.m[0], s.m[1]}, bfk_u4{s.h[0], s.h[1], s.l[0], s.l[1]}};
+}
+__device__ __forceinline__ bfk_f4 bfk_mfma(bfk_u4 a, bfk_u4 b, bfk_f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfk_bf8, a), __builtin_bit_cast(bfk_bf8, b), c, 0, 0, 0);
+}
+// acc + W^T x over the block's 16 logical k (smallest terms first)
+__device__ __forceinline__ bfk_f4 bfk_dot(const BfkW& w, const BfkA& a, bfk_f4 acc) {
+  acc = bfk_mfma(w.Q, a.hl, acc);
+  acc = bfk_mfma(w.P, a.mm, acc);
+  return bfk_mfma(w.P, a.hh, acc);
+}
+// The split of one float4 and the nine MFMAs of three 16 x 16 x 16 blocks that share it as their B operand (the S, Q, T heads of
+// one dimension slice), written as a software pipeline for ONE wave: a bf16 MFMA occupies the matrix pipe for 16 cycles while
+// the wave goes on issuing plain VALU, so the h-products are issued as soon as the first conversion is done and the m- and
+// l-terms are formed in their shadow (three to four VALU per MFMA); scheduling fences keep the compiler from collecting the
+// split in front of the MFMAs again.  Accumulation order h h, (m m + ...), (h l + l h): largest first -- each partial sum is
+// an fp32 rounding of an fp32-representable sum either way.  Returns the split operand for further blocks (bfk_dot).
+// (A scheduling fence alone does not hold the stages apart: MFMA intrinsics and float arithmetic are pure, and instruction
+//  selection emits them where it likes -- it collected the whole split in front of the first fence.  So every stage boundary is
+//  an EMPTY asm statement that takes the values crossing it as read-write operands: a data dependence no pass can break; the
+//  fence next to it stops the machine scheduler from moving the stage's own instructions across.)
+#ifndef L2HMC_BFK_NO_PIPE
+#define BFK_STAGE2(a, b) do { asm volatile("" : "+v"(a), "+v"(b)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BFK_STAGE4(a, b, c, d) do { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define BFK_STAGE2(a, b)
+#define BFK_STAGE4(a, b, c, d)
+#endif
+__device__ __forceinline__ BfkA bfk_heads3(const BfkW& ws, const BfkW& wq, const BfkW& wt, bfk_f4 x, bfk_f4& zs, bfk_f4& zq,
+                                           bfk_f4& zt) {
+  const bfk_f4 Z = {0.f, 0.f, 0.f, 0.f};
+  typedef float f2_ __attribute__((ext_vector_type(2)));
+  f2_ xa = {x[0], x[1]}, xb = {x[2], x[3]};
+  bfk_u4 hh;
+  hh[0] = bfk_pk(xa[0], xa[1]); hh[1] = bfk_pk(xb[0], xb[1]); hh[2] = hh[0]; hh[3] = hh[1];
+  BFK_STAGE2(hh, xa);
+  // stage 1: S . hh  |  first residual pair
+  zs = bfk_mfma(ws.P, hh, Z);
+  f2_ ra = {xa[0] - __uint_as_float(hh[0] << 16), xa[1] - __uint_as_float(hh[0] & 0xffff0000u)};
+  BFK_STAGE4(hh, ra, xb, zs);
+  // stage 2: Q . hh  |  second residual pair
+  zq = bfk_mfma(wq.P, hh, Z);
+  f2_ rb = {xb[0] - __uint_as_float(hh[1] << 16), xb[1] - __uint_as_float(hh[1] & 0xffff0000u)};
+  BFK_STAGE4(hh, ra, rb, zq);
+  // stage 3: T . hh  |  the m terms
+  zt = bfk_mfma(wt.P, hh, Z);
+  bfk_u4 mm;
+  mm[0] = bfk_pk(ra[0], ra[1]); mm[1] = bfk_pk(rb[0], rb[1]); mm[2] = mm[0]; mm[3] = mm[1];
+  BFK_STAGE4(mm, ra, rb, zt);
+  // stage 4: S . mm  |  first second-level residual pair
+  zs = bfk_mfma(ws.P, mm, zs);
+  f2_ sa = {ra[0] - __uint_as_float(mm[0] << 16), ra[1] - __uint_as_float(mm[0] & 0xffff0000u)};
+  BFK_STAGE4(mm, sa, rb, zs);
+  // stage 5: Q . mm  |  second pair
+  zq = bfk_mfma(wq.P, mm, zq);
+  f2_ sb = {rb[0] - __uint_as_float(mm[1] << 16), rb[1] - __uint_as_float(mm[1] & 0xffff0000u)};
+  BFK_STAGE4(mm, sa, sb, zq);
+  // stage 6: T . mm  |  the l terms
+  zt = bfk_mfma(wt.P, mm, zt);
+  bfk_u4 hl;
+  hl[0] = hh[0]; hl[1] = hh[1]; hl[2] = bfk_pk(sa[0], sa[1]); hl[3] = bfk_pk(sb[0], sb[1]);
+  BFK_STAGE2(hl, zt);
+  // stage 7: the (h l + l h) products; S first -- its transcendental chain starts while Q and T are still in the pipe
+  zs = bfk_mfma(ws.Q, hl, zs);
+  zq = bfk_mfma(wq.Q, hl, zq);
+  zt = bfk_mfma(wt.Q, hl, zt);
+  return BfkA{hh, mm, hl};
+}
+
+// fragment storage: block b of a table of blocks = 2 x 64 x 16 bytes, P then Q, lane-major (conflict-free ds_read_b128)
+__device__ __forceinline__ void bfk_store(float* base, int block, int lane, const BfkW& w) {
+  bfk_u4* p = reinterpret_cast<bfk_u4*>(base) + (size_t)block * 128 + lane;
+  p[0] = w.P;
+  p[64] = w.Q;
+}
+__device__ __forceinline__ BfkW bfk_load(const float* base, int block, int lane) {
+  const bfk_u4* p = reinterpret_cast<const bfk_u4*>(base) + (size_t)block * 128 + lane;
+  return BfkW{p[0], p[64]};
+}
+
+}  // namespace l2hmc

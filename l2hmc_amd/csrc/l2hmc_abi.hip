@@ -8,6 +8,8 @@
 namespace l2hmc {
 
 thread_local char g_err[512] = "";
+thread_local char g_kernel[96] = "";      // the kernel the last trajectory / training call of this thread launched
+void note_kernel(const char* fmt, long long a, long long b, long long c, long long d) { snprintf(g_kernel, sizeof(g_kernel), fmt, a, b, c, d); }
 
 int fail(int code, const char* fmt, const char* a, long long b, long long c) {
   snprintf(g_err, sizeof(g_err), fmt, a, b, c);
@@ -359,7 +361,7 @@ long long plan_lds_tile(KArgs& k, int DT) {
   k.o_fw = (int)o;
   o += 2LL * fast_fw_net(DT);
   k.o_state = (int)o;
-  o += 4LL * DT * 256;
+  o += tile_l1_floats(DT);
   k.o_fc = (int)o;
   o += 2LL * fast_fc_net(DT);
   k.o_rec = (int)o;
@@ -473,6 +475,12 @@ extern "C" {
 
 int l2hmc_abi_version(void) { return L2HMC_ABI_VERSION; }
 
+int32_t l2hmc_last_kernel(char* buf, int32_t n) {
+  if (!buf || n < 1) return fail(L2HMC_ERR_ARG, "l2hmc_last_kernel: bad argument%s");
+  snprintf(buf, (size_t)n, "%s", g_kernel);
+  return (int32_t)strlen(g_kernel);
+}
+
 const char* l2hmc_last_error(void) { return g_err; }
 
 int64_t l2hmc_struct_bytes(int32_t which) {
@@ -484,6 +492,7 @@ int64_t l2hmc_struct_bytes(int32_t which) {
     case L2HMC_STRUCT_SPLIT_ARGS: return sizeof(L2hmcSplitArgs);
     case L2HMC_STRUCT_TRAIN_ARGS: return sizeof(L2hmcTrainArgs);
     case L2HMC_STRUCT_TRAIN_SPLIT_ARGS: return sizeof(L2hmcTrainSplitArgs);
+    case L2HMC_STRUCT_TRAIN_STEP: return sizeof(L2hmcTrainStep);
   }
   return fail(L2HMC_ERR_ARG, "l2hmc_struct_bytes: unknown struct id%s");
 }
@@ -600,7 +609,10 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
     const long long cus = device_cus();
     const bool lane_auto = ((a->d <= 2 && a->n_chains >= 256 * cus) || (a->d <= 4 && a->n_chains >= 512 * cus));
     if (lane_able && (a->variant == 32 || (a->variant == 0 && lane_auto)))
+    {
+      note_kernel("traj_lane_kernel");
       return launch_lane(k, s);
+    }
   }
   const bool wide_dense = k.ekind == L2HMC_ENERGY_GAUSS_DENSE || k.ekind == L2HMC_ENERGY_GMM;      // (its precision fragments stream from L2: k.prec is the packed buffer)
   const bool wide_kind = k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL || wide_dense;   // (mixtures: <= 4 tiles per wave)
@@ -610,7 +622,10 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   if (wide_able && (a->variant == 8 || (a->variant == 0 && k.NT > (wide_dense ? WIDE_DENSE_MIN_NT : 8)))) {
     KArgs kw = k;
     const long long ldsw = plan_lds_wide(kw);
-    if (ldsw <= 160 * 1024) return launch_wide(kw, KH, ldsw, s);
+    if (ldsw <= 160 * 1024) {
+      note_kernel("traj_wide_kernel");
+      return launch_wide(kw, KH, ldsw, s);
+    }
     if (a->variant == 8) return fail(L2HMC_ERR_UNSUPPORTED, "variant 8: %s%lld bytes of LDS needed (T x d too large)", "", ldsw);
   }
   int DT, NW;
@@ -627,7 +642,10 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   if (small) {
     const long long ldss = plan_lds_fast(k, 1, 1);
     // (the per-step schedule records grow with T: past 160 KiB fall through to the fast / general kernel)
-    if (ldss <= 160 * 1024) return dispatch(OP_TRAJ_SMALL, k, 1, 1, KH, ldss, s);
+    if (ldss <= 160 * 1024) {
+      note_kernel("traj_small_kernel<%lld, %lld>", k.ekind, KH <= 3 ? 3 : 4);
+      return dispatch(OP_TRAJ_SMALL, k, 1, 1, KH, ldss, s);
+    }
   }
   // many chains (>= 2 tiles per SIMD), 3-4 dimension slices, elementwise target: one wave per tile (traj_tile.hpp);
   // variant 16 forces it
@@ -639,6 +657,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 64LL * device_cus()))) {
     const long long ldst = plan_lds_tile(k, k.NT);
     if (ldst <= 160 * 1024) {
+      note_kernel("traj_tile_kernel<%lld, %lld, %lld, %lld>", k.ekind, k.NT, KH <= 3 ? 3 : 4, L2HMC_TILE_TPW);
       if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, ldst, s);
       return launch_tile_ek<L2HMC_ENERGY_ROUGHWELL>(k, k.NT, KH, ldst, s);
     }
@@ -647,9 +666,13 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   }
   if (fast) {
     const long long ldsf = plan_lds_fast(k, NW, DT);
-    if (ldsf <= 160 * 1024) return dispatch(OP_TRAJ_FAST, k, DT, NW, KH, ldsf, s);
+    if (ldsf <= 160 * 1024) {
+      note_kernel("traj_fast_kernel<%lld, %lld, %lld, %lld>", k.ekind, DT, NW, KH <= 3 ? 3 : 4);
+      return dispatch(OP_TRAJ_FAST, k, DT, NW, KH, ldsf, s);
+    }
   }
   const long long lds = plan_lds(k, a->packed_nets != nullptr, true, NW, DT);
+  note_kernel("traj_kernel<%lld, %lld, %lld, %lld>", k.ekind, DT, NW, KH <= 3 ? 3 : 4);
   return dispatch(OP_TRAJ, k, DT, NW, KH, lds, s);
 }
 

@@ -44,6 +44,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr bool weights_in_global(int DT) { return DT >= 4; }
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0);
+void note_kernel(const char* fmt, long long a = 0, long long b = 0, long long c = 0, long long d = 0);   // -> l2hmc_last_kernel
 int check_energy(const L2hmcEnergy* e, int d);
 struct KArgs;
 // traj_wide.hip: the LDS-resident-state kernel for d > 256 (elementwise energies)

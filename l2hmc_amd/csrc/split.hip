@@ -64,22 +64,28 @@ __global__ void k_vae_U(const float* rowsum, int np, const float* z, int ldz, in
 }
 // HMC mode (nets identically zero, dynamics.py:73-76): the generalised step is the plain leapfrog
 //   v_h = v - (eps/2) g(x);  x' = x + eps v_h     [k_hmc_drift]      v' = v_h - (eps/2) g(x')   [k_hmc_kick]
+// and its inverse (dynamics.py:159-201 with S = T = Q = 0: v_h = v + (eps/2) g(x'), x = x' - eps v_h, v = v_h + (eps/2) g(x))
+// is the same step with eps -> -eps, per chain by its direction bit.
+__device__ __forceinline__ float hmc_eps(const float* alpha, float eps_host, const unsigned char* dir, int dall, long long n) {
+  const float eps = alpha != nullptr ? expf(*alpha) : eps_host;
+  return (dir != nullptr ? dir[n] != 0 : dall != 0) ? eps : -eps;
+}
 __global__ void k_hmc_drift(float* x, int ldx, const float* v, const float* g, int ldg, float* vh, const float* alpha,
-                            float eps_host, long long N, int d) {
+                            float eps_host, const unsigned char* dir, int dall, long long N, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * d) return;
   const long long n = i / d;
   const int k = (int)(i % d);
-  const float eps = alpha != nullptr ? expf(*alpha) : eps_host;
+  const float eps = hmc_eps(alpha, eps_host, dir, dall, n);
   const float h = v[i] + 0.5f * eps * (-g[n * ldg + k]);
   vh[i] = h;
   x[n * ldx + k] = x[n * ldx + k] + eps * h;
 }
 __global__ void k_hmc_kick(float* v, const float* vh, const float* g, int ldg, const float* alpha, float eps_host,
-                           long long N, int d) {
+                           const unsigned char* dir, int dall, long long N, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * d) return;
-  const float eps = alpha != nullptr ? expf(*alpha) : eps_host;
+  const float eps = hmc_eps(alpha, eps_host, dir, dall, i / d);
   v[i] = vh[i] + 0.5f * eps * (-g[(i / d) * ldg + (i % d)]);
 }
 
@@ -375,8 +381,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   } else if (builtin) {
     if (a->decoder || a->aux_encoder || a->hmc)
       return fail(L2HMC_ERR_UNSUPPORTED, "a built-in energy excludes decoder / aux_encoder / hmc (HMC mode runs on l2hmc_trajectory)%s");
-    if ((rc = check_energy(a->energy, a->d))) return rc;
-    if (a->energy->temperature != 1.f) return fail(L2HMC_ERR_UNSUPPORTED, "temperature != 1 with wide nets%s");
+    if ((rc = check_energy(a->energy, a->d))) return rc;       // (a tempered target: l2hmc_energy divides U and grad U, dynamics.py:203-212)
   } else if ((rc = check_mlp(a->decoder, "decoder"))) {
     return rc;
   }
@@ -388,8 +393,6 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   const bool hmc = a->hmc != 0;
   if ((!hmc && (!a->xnet || !a->vnet || !a->masks || !a->trig)) || (!builtin && !user && !a->aux) || !a->x || !a->v || !a->workspace)
     return fail(L2HMC_ERR_ARG, "l2hmc_trajectory_split: NULL pointer%s");
-  if (hmc && (a->direction != nullptr || a->direction_all == 0))
-    return fail(L2HMC_ERR_UNSUPPORTED, "HMC mode runs forward only (sampler.py:29-31, ais.py:61)%s");
   if (!(a->bce_scale >= 0.f && a->bce_scale <= 1.f)) return fail(L2HMC_ERR_ARG, "bce_scale must be in [0, 1] (0 = off)%s");
   const float beta = a->bce_scale > 0.f ? a->bce_scale : 1.f;
   if (!builtin && !user && a->decoder->n_in != d) return fail(L2HMC_ERR_ARG, "decoder input width != d%s");
@@ -539,9 +542,9 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     const int it = a->step_begin + k;
     const bool last = k == a->n_steps - 1;
     if (hmc) {
-      hipLaunchKernelGGL(k_hmc_drift, dim3(nblk(N * d)), dim3(256), 0, s, xc, L, vc, g, L, y, a->alpha, a->eps_host, N, d);
+      hipLaunchKernelGGL(k_hmc_drift, dim3(nblk(N * d)), dim3(256), 0, s, xc, L, vc, g, L, y, a->alpha, a->eps_host, dir, dall, N, d);
       if ((rc = energy_eval(last ? U1d : nullptr))) return rc;
-      hipLaunchKernelGGL(k_hmc_kick, dim3(nblk(N * d)), dim3(256), 0, s, vc, y, g, L, a->alpha, a->eps_host, N, d);
+      hipLaunchKernelGGL(k_hmc_kick, dim3(nblk(N * d)), dim3(256), 0, s, vc, y, g, L, a->alpha, a->eps_host, dir, dall, N, d);
       continue;
     }
     net_eval(vn, 1, xc, it, v_update(vc, d, vh, L, true));            // v_h, and xin = k1 x for the next evaluation

@@ -61,7 +61,14 @@ struct TArgs {
   float eta;
   float scale, inv_n;
   float *Lx, *p, *v1, *grad, *ws;
+  // l2hmc_train_step: chains [0, n_head) start from x_head (n_head = 0: all from x) and, with u / x_next, take their
+  // Metropolis select in the kernel's epilogue (the register-resident kernels; the general one leaves it to a launch)
+  const float* x_head;
+  long long n_head;
+  const float* u;
+  float* x_next;
 };
+__device__ __forceinline__ const float* x_row0(const TArgs& A, long long n) { return n < A.n_head ? A.x_head : A.x; }
 
 constexpr int TC = 16;       // chains per workgroup
 constexpr int TNW = 4;       // waves per workgroup
@@ -639,7 +646,7 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
   // ---- load the start state -----------------------------------------------------------------------
   set_step(0);
   EW_BEGIN
-    mx[q] = alive ? A.x[n * d + k] : 0.f;
+    mx[q] = alive ? x_row0(A, n)[n * d + k] : 0.f;
     mv[q] = alive ? A.v[n * d + k] : 0.f;
     ldm[q] = 0.f;
     if (EL) mg[q] = g_elem(mx[q], k);
@@ -676,7 +683,7 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
     const bool lv_ = nn < A.N;
     float K1 = 0.f, sq = 0.f, ld = 0.f;
     for (int k = 0; k < d; ++k) {
-      const float x0 = lv_ ? A.x[nn * d + k] : 0.f;
+      const float x0 = lv_ ? x_row0(A, nn)[nn * d + k] : 0.f;
       K1 += 0.5f * mv[cc * ldd + k] * mv[cc * ldd + k];
       sq += (x0 - mx[cc * ldd + k]) * (x0 - mx[cc * ldd + k]);
       ld += ldm[cc * ldd + k];
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
     const bool okc = X.cs[CS_OK * TC + c] != 0.f;
     const float dv1p = X.cs[CS_DV1P * TC + c];
     EW_BEGIN
-      const float x0 = alive ? A.x[n * d + k] : 0.f;
+      const float x0 = alive ? x_row0(A, n)[n * d + k] : 0.f;
       if (alive) A.Lx[n * d + k] = mx[q];
       lx[q] = okc ? dv1p * (mx[q] - x0) - lam * mg[q] : 0.f;
       lv[q] = okc ? -lam * mv[q] : 0.f;
@@ -861,6 +868,83 @@ __global__ void train_reduce_kernel(const float* part, int n_slots, int n_grad, 
   if (accumulate) dst[i] += s; else dst[(long long)c * n_grad + i] = s;
 }
 
+// The LAST level of the slot reduction with the rest of an optimiser step behind it (l2hmc_train_step): thread i adds the
+// slots of parameter i in slot order, stores the sum (overwrite) and, when the optimiser's buffers are given, applies Adam to
+// that parameter at once; one extra workgroup reduces the loss terms of v1 in the fixed order of l2hmc_loss_terms.
+struct FinalArgs {
+  const float* v1; long long n_v1; float scale; double inv_n; long long n_head;
+  float* terms; double* loss;
+  float *theta, *m, *v; float lr_t, b1, b2, eps; int last_is_log_eps; int n_par;
+};
+__device__ __forceinline__ void adam_update(float* p, float gi, float* m, float* v, long long i, long long n, float lr_t,
+                                            float b1, float b2, float eps, int last_is_log_eps) {
+  if (last_is_log_eps && i == n - 1) gi *= expf(p[i]);      // d/d alpha = eps d/d eps (dynamics.py:50-58)
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+__device__ __forceinline__ void split_hi_lo(double t, float* out) {
+  const float hi = (float)t;
+  out[0] = hi;
+  out[1] = (float)(t - (double)hi);
+}
+__global__ __launch_bounds__(256) void train_final_kernel(const float* part, int n_slots, int n_grad, float* dst, FinalArgs f) {
+  const int nb = (n_grad + 255) / 256;
+  if ((int)blockIdx.x == nb) {                 // the loss block
+    __shared__ double sa[4], sb[4];
+    double a = 0.0, b = 0.0;
+    for (long long i = threadIdx.x; i < f.n_v1; i += 256) {
+      const float v = f.v1[i];
+      a += 1.0 / (double)v;
+      b += (double)v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off);
+      b += __shfl_xor(b, off);
+    }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double A_ = ((sa[0] + sa[1]) + sa[2]) + sa[3], B_ = ((sb[0] + sb[1]) + sb[2]) + sb[3];
+      if (f.loss != nullptr) {
+        f.loss[0] = A_; f.loss[1] = B_;
+        f.loss[2] = f.inv_n * ((double)f.scale * A_ - B_ / (double)f.scale);
+      }
+      if (f.terms != nullptr) {
+        split_hi_lo(A_, f.terms);
+        split_hi_lo(B_, f.terms + 2);
+        split_hi_lo((double)f.n_head, f.terms + 4);
+      }
+    }
+    return;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_grad) return;
+  float s = 0.f;
+  int b = 0;
+  for (; b + 8 <= n_slots; b += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = part[(long long)(b + u) * n_grad + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; b < n_slots; ++b) s += part[(long long)b * n_grad + i];
+  dst[i] = s;
+  if (f.theta != nullptr && i < f.n_par) adam_update(f.theta, s, f.m, f.v, i, f.n_par, f.lr_t, f.b1, f.b2, f.eps, f.last_is_log_eps);
+}
+// the Metropolis select of chains [0, n_head) behind the general kernel (the register-resident ones do it themselves)
+__global__ void train_mh_select_kernel(const float* x, const float* Lx, const float* p, const float* u, long long N, int d,
+                                       float* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * d) return;
+  const long long n = i / d;
+  out[i] = (p[n] - u[n] >= 0.f) ? Lx[i] : x[i];
+}
+
 __device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.f); }
 // Phase timers of profiling builds (-DL2HMC_TRAIN_TIMING, tools/train_phase_timing.py): accumulated in REGISTERS and written
 // once at the end (a global read-modify-write per mark would cost more than the phases it brackets).
@@ -967,8 +1051,17 @@ int64_t l2hmc_train_fused_lds_bytes(int32_t ek, int32_t n_comp, int32_t d, int32
   return lds;
 }
 
-int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
+static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
+  if (st != nullptr) {
+    if (st->n_head < 0 || st->n_head > a->n_chains || (st->n_head > 0 && !st->x_head))
+      return fail(L2HMC_ERR_ARG, "l2hmc_train_step: bad x_head / n_head%s");
+    if ((st->u != nullptr) != (st->x_next != nullptr)) return fail(L2HMC_ERR_ARG, "l2hmc_train_step: u and x_next go together%s");
+    if (st->u != nullptr && st->n_head < 1) return fail(L2HMC_ERR_ARG, "l2hmc_train_step: the Metropolis select needs n_head >= 1%s");
+    if (st->theta != nullptr && (!st->m || !st->v || st->step < 1 || !(st->lr >= 0.f) || !(st->beta1 >= 0.f && st->beta1 < 1.f) ||
+                                 !(st->beta2 >= 0.f && st->beta2 < 1.f) || !(st->epsilon > 0.f)))
+      return fail(L2HMC_ERR_ARG, "l2hmc_train_step: bad optimiser arguments%s");
+  }
   if (a->n_chains < 0 || a->d < 1 || a->T < 1 || a->H < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
   if (a->n_chains == 0) return L2HMC_OK;
   if (a->d > 4096 || a->H > 4096) return fail(L2HMC_ERR_UNSUPPORTED, "training kernel: d / H too large (got d = %s%lld, H = %lld)", "", a->d, a->H);
@@ -1000,6 +1093,9 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
   k.ncomp = ek == L2HMC_ENERGY_GMM ? a->energy.n_comp : 1; k.easy = a->energy.easy;
   k.scale = a->scale; k.inv_n = a->inv_n;
   k.Lx = a->Lx; k.p = a->p; k.v1 = a->v1; k.grad = a->grad; k.ws = a->workspace;
+  k.x_head = st ? st->x_head : nullptr; k.n_head = st ? st->n_head : 0;
+  k.u = st ? st->u : nullptr; k.x_next = st ? st->x_next : nullptr;
+  bool mh_done = false;
   const unsigned blocks = (unsigned)((a->n_chains + TC - 1) / TC);
   hipStream_t s = (hipStream_t)stream;
   const int n_grad = 2 * net_params(a->d, a->H) + 1;
@@ -1014,6 +1110,8 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
     else if (ek == L2HMC_ENERGY_GMM) launch_train_small<L2HMC_ENERGY_GMM>(k, KH, blocks, lds_small, s);
     else launch_train_small<L2HMC_ENERGY_ROUGHWELL>(k, KH, blocks, lds_small, s);
     part = a->workspace + (long long)blocks * a->T * TF_CK * 256;
+    mh_done = true;
+    note_kernel("train_small_kernel<%lld, %lld>", ek, KH <= 3 ? 3 : 4);
   } else if (fnw && lds_fast <= 160 * 1024) {    // register-resident kernel (train_fast.hpp)
     const int KH = khid_of(a->H);
     int rc;
@@ -1025,6 +1123,8 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
     else rc = launch_train_fast<L2HMC_ENERGY_GAUSS_DENSE, 1>(k, KH, blocks, lds_fast, s);
     if (rc) return rc;
     part = a->workspace + (long long)blocks * a->T * TF_CK * (fnw * 256);
+    mh_done = true;
+    note_kernel("train_fast_kernel<%lld, %lld, %lld>", ek, fnw, KH <= 3 ? 3 : 4);
   } else {
     if (ek == L2HMC_ENERGY_FUNNEL)               // the general tile kernel has no funnel Hessian-vector product
       return fail(L2HMC_ERR_UNSUPPORTED, "funnel training runs on the register-resident kernel only (d <= 16, H <= 15, "
@@ -1039,19 +1139,78 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) {
       if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(train_kernel, dim3(blocks), dim3(TTHREADS), (size_t)lds, s, k);
+    note_kernel("train_kernel");
     part = a->workspace + (long long)a->T * a->n_chains * CKPT * a->d;
   }
-  if (blocks <= (unsigned)kReduceChunk) {
-    hipLaunchKernelGGL(train_reduce_kernel, dim3((n_grad + 255) / 256, 1), dim3(256), 0, s, part, (int)blocks, n_grad,
-                       (int)blocks, a->grad, 1);
-  } else {                    // two levels, both in slot order: still deterministic
+  if (st != nullptr && st->u != nullptr && !mh_done)
+    hipLaunchKernelGGL(train_mh_select_kernel, dim3((unsigned)((st->n_head * a->d + 255) / 256)), dim3(256), 0, s, st->x_head,
+                       a->Lx, a->p, st->u, (long long)st->n_head, a->d, st->x_next);
+  const float* last = part;
+  int last_slots = (int)blocks;
+  if (blocks > (unsigned)kReduceChunk) {      // two levels, both in slot order: still deterministic
     const int chunks = (int)((blocks + kReduceChunk - 1) / kReduceChunk);
     float* part2 = part + (long long)blocks * n_grad;
     hipLaunchKernelGGL(train_reduce_kernel, dim3((n_grad + 255) / 256, chunks), dim3(256), 0, s, part, (int)blocks,
                        n_grad, kReduceChunk, part2, 0);
-    hipLaunchKernelGGL(train_reduce_kernel, dim3((n_grad + 255) / 256, 1), dim3(256), 0, s, part2, chunks, n_grad,
-                       chunks, a->grad, 1);
+    last = part2;
+    last_slots = chunks;
   }
+  if (st == nullptr) {
+    hipLaunchKernelGGL(train_reduce_kernel, dim3((n_grad + 255) / 256, 1), dim3(256), 0, s, last, last_slots, n_grad,
+                       last_slots, a->grad, 1);
+  } else {
+    FinalArgs f;
+    memset(&f, 0, sizeof(f));
+    const bool want_loss = st->terms != nullptr || st->loss != nullptr;
+    f.v1 = a->v1; f.n_v1 = a->n_chains; f.scale = a->scale; f.inv_n = (double)a->inv_n; f.n_head = st->n_head;
+    f.terms = st->terms; f.loss = st->loss;
+    if (st->theta != nullptr) {
+      // lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t)   (TF1 Adam, as l2hmc_adam_step)
+      const double t = (double)st->step;
+      f.lr_t = (float)((double)st->lr * sqrt(1.0 - pow((double)st->beta2, t)) / (1.0 - pow((double)st->beta1, t)));
+      f.theta = st->theta; f.m = st->m; f.v = st->v; f.b1 = st->beta1; f.b2 = st->beta2; f.eps = st->epsilon;
+      f.last_is_log_eps = st->train_alpha != 0;
+      f.n_par = st->train_alpha ? n_grad : n_grad - 1;
+    }
+    hipLaunchKernelGGL(train_final_kernel, dim3((n_grad + 255) / 256 + (want_loss ? 1 : 0)), dim3(256), 0, s, last, last_slots,
+                       n_grad, a->grad, f);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return L2HMC_OK;
+}
+
+int l2hmc_train_propose_grad(const L2hmcTrainArgs* a, void* stream) { return train_launch(a, nullptr, stream); }
+
+int l2hmc_train_step(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void* stream) {
+  if (!st) return fail(L2HMC_ERR_ARG, "l2hmc_train_step: step is NULL%s");
+  return train_launch(a, st, stream);
+}
+
+// Adam behind a sharded step's all-reduce, the global-batch loss from the reduced tail in the same launch
+__global__ void adam_terms_kernel(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2,
+                                  float eps, int last_is_log_eps, const float* terms6, float scale, double* loss_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && terms6 != nullptr && loss_out != nullptr) {
+    const double A_ = (double)terms6[0] + (double)terms6[1], B_ = (double)terms6[2] + (double)terms6[3];
+    const double cnt = (double)terms6[4] + (double)terms6[5];
+    loss_out[0] = A_; loss_out[1] = B_;
+    loss_out[2] = ((double)scale * A_ - B_ / (double)scale) / cnt;
+  }
+  if (i >= n) return;
+  adam_update(p, g[i], m, v, i, n, lr_t, b1, b2, eps, last_is_log_eps);
+}
+int l2hmc_adam_step_terms(float* params, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                          float beta2, float epsilon, int64_t step, int32_t last_is_log_eps, const float* terms6,
+                          float scale, double* loss_out, void* stream) {
+  if (!params || !grad || !m || !v || n < 1 || step < 1 || !(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) ||
+      !(beta2 >= 0.f && beta2 < 1.f) || !(epsilon > 0.f) || (terms6 != nullptr) != (loss_out != nullptr) ||
+      (terms6 != nullptr && !(scale > 0.f)))
+    return fail(L2HMC_ERR_ARG, "l2hmc_adam_step_terms: bad argument%s");
+  const double t = (double)step;
+  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+  hipLaunchKernelGGL(adam_terms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad, m, v,
+                     (long long)n, lr_t, beta1, beta2, epsilon, last_is_log_eps, terms6, scale, loss_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;

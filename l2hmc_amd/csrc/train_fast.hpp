@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     }
     return r;
   };
-  const f4 xs = gload(A.x);
+  const f4 xs = gload(x_row0(A, n));
   f4 x = xs, v = gload(A.v);
   f4 g = gradU(x);
   float red[6];
@@ -483,6 +483,12 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (dim0 + j < d) A.Lx[n * d + dim0 + j] = x[j];
+    if (A.x_next != nullptr && n < A.n_head) {                 // Metropolis select of the continuing chains (sampler.py:53-55)
+      const bool acc = p - A.u[n] >= 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (dim0 + j < d) A.x_next[n * d + dim0 + j] = acc ? x[j] : xs[j];
+    }
   }
   f4 lx = okc ? (x - xs) * dv1p - g * lam : Z;
   f4 lv = okc ? v * (-lam) : Z;

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
   };
 
   // ---- load the start state ---------------------------------------------------------------------------------------------------
-  const float xs = (alive && livedim) ? A.x[n * d + q] : 0.f;
+  const float xs = (alive && livedim) ? x_row0(A, n)[n * d + q] : 0.f;
   float x = xs, v = (alive && livedim) ? A.v[n * d + q] : 0.f;
   float g = gradU(x);
   float red[6];
@@ -474,6 +474,7 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
   const float dv1p = dv1 * p * 2.f;
   const bool okc = sq < 3.0e38f;
   if (alive && livedim) A.Lx[n * d + q] = x;
+  if (A.x_next != nullptr && n < A.n_head && livedim) A.x_next[n * d + q] = (p - A.u[n] >= 0.f) ? x : xs;      // sampler.py:53-55
   float lx = okc ? (x - xs) * dv1p - g * lam : 0.f;
   float lv = okc ? v * (-lam) : 0.f;
   float deps = 0.f;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
   constexpr int NTp = 1;
-  const int FWN = fast_fw_net(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
+  const int FWN = fast_fw_net_f32(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
             RECD = fast_rec_dir(NTp, A.T);
 
   // ---- prologue: the same scaled tail fragments, constant tables and schedule records as traj_fast_kernel ----

@@ -18,6 +18,16 @@ namespace l2hmc {
 
 long long plan_lds_tile(KArgs& k, int DT);
 
+// L2HMC_BFL1 = 1: the layer-1 contractions of this kernel as K-packed bf16x3 too (needs L2HMC_BFH); its fragments are split when
+// staged, every layer-1 input slice by the wave that contracts it.
+#ifndef L2HMC_BFL1
+#define L2HMC_BFL1 0
+#endif
+#ifndef L2HMC_TILE_TPW
+#define L2HMC_TILE_TPW 4
+#endif
+__host__ __device__ constexpr int tile_l1_floats(int DT) { return 4 * DT * 256 * (L2HMC_BFL1 ? 2 : 1); }
+
 template <int EK, int DT, int KH, int TPW>
 __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
   static_assert(EK == L2HMC_ENERGY_GAUSS_DIAG || EK == L2HMC_ENERGY_ROUGHWELL, "elementwise targets only");
@@ -35,13 +45,19 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
   const f4 Z = splat(0.f);
 
   // ---- prologue (whole workgroup): scaled tail fragments, layer-1 fragments, constants, schedule records ----------
-  for (int i = tid; i < 2 * (FWN / 4); i += nthr) {
-    const int net = i >= FWN / 4, j = i - net * (FWN / 4), g = j >> 6;
+  constexpr int GN = 3 * NTp + 1;                  // groups per net: W4, then (S, T, Q) per dimension slice
+  for (int i = tid; i < 2 * GN * 64; i += nthr) {
+    const int net = i >= GN * 64, j = i - net * (GN * 64), g = j >> 6;
     float sc = 1.f;
     if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
     f4 src = Z;
     if (g < 3 * NT + 1) src = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + (2 * NT + 1) * 256)[j];
+#if L2HMC_BFH
+    if (g == 0) reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src;
+    else bfk_store(smem + A.o_fw + net * FWN + 256, g - 1, j & 63, bfk_wfrag(src * sc));
+#else
     reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src * sc;
+#endif
   }
   stage_energy<EK, false>(A, smem, tid, nthr);
   __syncthreads();                                               // (the fold below reads the staged precision)
@@ -55,7 +71,11 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
         val = val + lds4(smem + A.o_prec + 16 * tg + 4 * (ln >> 4)) * wb;
       }
     }
+#if L2HMC_BFL1
+    bfk_store(smem + A.o_state, grp, ln, bfk_wfrag(val));
+#else
     reinterpret_cast<f4*>(smem + A.o_state)[i] = val;
+#endif
   }
   for (int i = tid; i < 2 * 16 * NTp; i += nthr) {
     const int net = i / (16 * NTp), dim = i % (16 * NTp);
@@ -84,12 +104,19 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     smem[A.o_rec + dr * RECD + (r + 1) * R + j] = val;
   }
   __syncthreads();
-  auto l1frag = [&](int net, int inp, int t) { return lds4(smem + A.o_state + (((net * 2 + inp) * DT + t) * 64 + lane) * 4); };
   auto chain4 = [&](f4 W, f4 in, f4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc = MFMA16(W[r], in[r], acc);
     return acc;
   };
+#if L2HMC_BFL1
+  // layer-1 contraction of dimension slice t of input inp of net: three bf16 MFMAs (dead k-slots multiply zeros)
+  auto l1dot = [&](int net, int inp, int t, f4 in, f4 acc) {
+    return bfk_dot(bfk_load(smem + A.o_state, (net * 2 + inp) * DT + t, lane), bfk_afrag(in), acc);
+  };
+#else
+  auto l1frag = [&](int net, int inp, int t) { return lds4(smem + A.o_state + (((net * 2 + inp) * DT + t) * 64 + lane) * 4); };
+#endif
   // layer-1 contraction of dimension slice t: k-step r covers the dimensions 16 t + 4 q + r, live only while 16 t + r < d --
   // the last slice of d = 50 has two live k-steps of four (wave-uniform bound: scalar branches)
   const int klast = A.d - 16 * (DT - 1);
@@ -101,6 +128,9 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     return acc;
   };
   // (+2.7 % at 65 536 chains for d = 50)
+#if !L2HMC_BFL1
+  auto l1dot = [&](int net, int inp, int t, f4 in, f4 acc) { return chain4t(t, l1frag(net, inp, t), in, acc); };
+#endif
   auto mu_of = [&](int t) { return lds4(smem + A.o_mu + 16 * t + 4 * q); };
   auto prec_of = [&](int t) { return lds4(smem + A.o_prec + 16 * t + 4 * q); };
   if (EK == L2HMC_ENERGY_GAUSS_DIAG) {           // constant -W2^T P mu of the fold -> VNet time/bias table
@@ -165,12 +195,36 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     return h;
   };
   // heads of dimension slice t: aS = log2 of the scale factor, T' = step T, EQ' = step e^{eps Q}  (traj_fast.hpp)
-  auto heads = [&](const float* fw, const float* fc, int dofs, int t, f4 h, f4& aS, f4& Tt, f4& EQ) {
-    const f4 Ws = lds4(fw + ((1 + 3 * t + 0) * 64 + lane) * 4), Wt = lds4(fw + ((1 + 3 * t + 1) * 64 + lane) * 4),
-             Wq = lds4(fw + ((1 + 3 * t + 2) * 64 + lane) * 4);
+#if L2HMC_BFH && defined(L2HMC_TILE_PIPE)
+  // the split of the hidden activation rides in the shadow of slice 0's head MFMAs (bfk_heads3); later slices reuse it
+  struct HidT { f4 h; BfkA b; };
+  auto hidden_b = [&](const float* fw, f4 hs_) { HidT r; r.h = hidden(fw, hs_); return r; };
+#elif L2HMC_BFH
+  typedef BfkA HidT;                      // the second hidden activation as the split B operand of the heads
+  auto hidden_b = [&](const float* fw, f4 hs_) { return bfk_afrag(hidden(fw, hs_)); };
+#else
+  typedef f4 HidT;
+  auto hidden_b = [&](const float* fw, f4 hs_) { return hidden(fw, hs_); };
+#endif
+  auto heads = [&](const float* fw, const float* fc, int dofs, int t, HidT& h, f4& aS, f4& Tt, f4& EQ) {
     const f4 cS = lds4(fc + dofs + 16 * t + 4 * q), cQ = lds4(fc + 2 * DPp + 16 * t + 4 * q),
              bQ = lds4(fc + 3 * DPp + 16 * t + 4 * q);
     f4 zs = Z, zt = Z, zq = Z;
+#if L2HMC_BFH && defined(L2HMC_TILE_PIPE)
+    if (t == 0) {
+      h.b = bfk_heads3(bfk_load(fw + 256, 0, lane), bfk_load(fw + 256, 2, lane), bfk_load(fw + 256, 1, lane), h.h, zs, zq, zt);
+    } else {
+      zs = bfk_dot(bfk_load(fw + 256, 3 * t + 0, lane), h.b, zs);
+      zq = bfk_dot(bfk_load(fw + 256, 3 * t + 2, lane), h.b, zq);
+      zt = bfk_dot(bfk_load(fw + 256, 3 * t + 1, lane), h.b, zt);
+    }
+#elif L2HMC_BFH
+    zs = bfk_dot(bfk_load(fw + 256, 3 * t + 0, lane), h, zs);
+    zq = bfk_dot(bfk_load(fw + 256, 3 * t + 2, lane), h, zq);
+    zt = bfk_dot(bfk_load(fw + 256, 3 * t + 1, lane), h, zt);
+#else
+    const f4 Ws = lds4(fw + ((1 + 3 * t + 0) * 64 + lane) * 4), Wt = lds4(fw + ((1 + 3 * t + 1) * 64 + lane) * 4),
+             Wq = lds4(fw + ((1 + 3 * t + 2) * 64 + lane) * 4);
 #pragma unroll
     for (int r = 0; r < KH; ++r) {
       zs = MFMA16(Ws[r], h[r], zs);
@@ -179,6 +233,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     }
     // (all nine head MFMAs before the first transcendental, as in traj_fast.hpp: +1 % at 65 536 chains)
     __builtin_amdgcn_sched_barrier(0);
+#endif
     const f4 rS = rcp4(-(ex2_4(zs) * 0.5f + 0.5f));
     aS = rS * cS + cS;
     const f4 rQ = rcp4(-(ex2_4(zq) * 0.5f + 0.5f));
@@ -193,8 +248,8 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
     g[t] = grad_t(x[t], t);
-    pv = chain4t(t, l1frag(1, 0, t), x[t], pv);
-    if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = chain4t(t, l1frag(1, 1, t), g[t], pv);
+    pv = l1dot(1, 0, t, x[t], pv);
+    if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = l1dot(1, 1, t, g[t], pv);
   }
   float U_start = energy_part(x, g);
 
@@ -244,7 +299,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       rec += drec;
       f4 aS, Tt, EQ;
       // ---- momentum half-update #1 + the XNet layer-1 sums of (v_h, k1 x)  (dynamics.py:118-131 / :162-176)
-      f4 h = hidden(fwv, pv + tbv);
+      HidT h = hidden_b(fwv, pv + tbv);
       f4 pa = Z, pq = Z;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
@@ -253,12 +308,12 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
         ldv += aS;
         const f4 tr = Tt - EQ * g[t];
         vh[t] = ES * (nf * tr + v[t]) + ff * tr;
-        pa = chain4t(t, l1frag(0, 0, t), vh[t], pa);
-        pq = chain4t(t, l1frag(0, 1, t), k1[t] * x[t], pq);
+        pa = l1dot(0, 0, t, vh[t], pa);
+        pq = l1dot(0, 1, t, k1[t] * x[t], pq);
       }
       // ---- first masked position update (:131-137 / :176-182) + the layer-1 sum of (1 - k1) y
       asm volatile("" ::: "memory");
-      h = hidden(fwx, pa + pq + tbx);
+      h = hidden_b(fwx, pa + pq + tbx);
       pq = Z;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
@@ -269,11 +324,11 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
         ldv += aSm;
         const f4 tr = up * (EQ * vh[t] + Tt);
         y[t] = ES * (nf * tr + x[t]) + ff * tr;
-        pq = chain4t(t, l1frag(0, 1, t), up * y[t], pq);
+        pq = l1dot(0, 1, t, up * y[t], pq);
       }
       // ---- second masked position update (:139-145 / :184-190), grad U and VNet's layer-1 sum at the new position
       asm volatile("" ::: "memory");
-      h = hidden(fwx, pa + pq + tbx);
+      h = hidden_b(fwx, pa + pq + tbx);
       pv = Z;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
@@ -284,12 +339,12 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
         const f4 tr = k1[t] * (EQ * vh[t] + Tt);
         x[t] = ES * (nf * tr + y[t]) + ff * tr;
         g[t] = grad_t(x[t], t);
-        pv = chain4t(t, l1frag(1, 0, t), x[t], pv);
-        if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = chain4t(t, l1frag(1, 1, t), g[t], pv);
+        pv = l1dot(1, 0, t, x[t], pv);
+        if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = l1dot(1, 1, t, g[t], pv);
       }
       // ---- momentum half-update #2  (:147-153 / :192-199)
       asm volatile("" ::: "memory");
-      h = hidden(fwv, pv + tbv);
+      h = hidden_b(fwv, pv + tbv);
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         heads(fwv, fcv, dofs, t, h, aS, Tt, EQ);

@@ -280,9 +280,7 @@ class Dynamics(object):
         if u is not None:
             u = as_device_f32(u, self.device)
         dec = mlp3_struct(self._fn.decoder) if self._vae else None
-        if self.hmc:
-            if direction is not None or not direction_all:
-                raise NotImplementedError("HMC mode runs forward only")
+        if self.hmc:                                  # (either direction: the inverse leapfrog is the step with -eps)
             xs = vs = enc = None
         else:
             xs = _ffi.L2hmcNet(*[self._xw[k].data_ptr() for k in _ffi.NET_FIELDS])
@@ -297,7 +295,9 @@ class Dynamics(object):
         a = _ffi.L2hmcSplitArgs()
         a.xnet = C.pointer(xs) if xs is not None else None
         a.vnet = C.pointer(vs) if vs is not None else None
-        a.H, a.hmc, a.bce_scale = max(self.H, 1), int(self.hmc), float(self.anneal_beta)
+        # (a caller-supplied energy anneals itself inside the callback -- evaluate(..., anneal_beta=) below; the library
+        #  refuses bce_scale next to energy_cb)
+        a.H, a.hmc, a.bce_scale = max(self.H, 1), int(self.hmc), (0.0 if self._user else float(self.anneal_beta))
         a.aux_encoder = C.pointer(enc) if enc is not None else None
         cb_error = []
         if self._vae:
@@ -327,9 +327,7 @@ class Dynamics(object):
             if self._aux_nets:
                 a.aux = aux.data_ptr()
         else:                                        # built-in target (utils/distributions.py) under wide nets
-            if self.use_temperature and float(self.temperature) != 1.0:
-                raise NotImplementedError("temperature with H > 15 nets is not implemented")
-            en = self._fn.c_struct(x.device, 1.0, self.anneal_beta)
+            en = self._fn.c_struct(x.device, float(self.temperature) if self.use_temperature else 1.0, self.anneal_beta)
             a.energy = C.pointer(en)
         a.masks, a.trig = self._mask.data_ptr(), self._trig.data_ptr()
         if self.eps_override is None:

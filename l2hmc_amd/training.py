@@ -11,11 +11,15 @@ mode incl. the Hessian-vector path through grad U).  With chains sharded over ra
 is all-reduced ONCE per step (RCCL on the GPU box / gloo in tests): the loss is a mean over chains, so
 summing per-rank gradients computed with inv_n = 1 / (global chain count) is exact.
 
-A training step is five library launches and no torch optimiser: `l2hmc_rng_fill` (z, both momenta,
-both direction vectors, the accept uniforms -- one Philox call), the gradient kernel,
-`l2hmc_adam_step` (TF1's Adam over the flat parameter vector [XNet | VNet | alpha], which the
-parameter tensors of the nets are views of), `l2hmc_mh_select`.  torch provides the buffers and the
-collective.
+A training step is THREE launches and no torch optimiser (round 4; `l2hmc_train_step`): `l2hmc_rng_fill` (z, both
+momenta, both direction vectors, the accept uniforms -- one Philox call); the gradient kernel, which reads the chains'
+state where the caller keeps it and takes their Metropolis select in its epilogue; the fixed-order slot reduction, which
+overwrites the gradient and carries the loss terms and TF1's Adam over the flat parameter vector [XNet | VNet | alpha]
+(the parameter tensors of the nets are views of it).  Sharded over ranks a step is ONE collective: the slot reduction
+leaves the rank's loss sums and chain count behind the gradient, `[gradient | loss sums | count]` is all-reduced as one
+buffer, and `l2hmc_adam_step_terms` applies Adam and forms the global loss.  The shard layout (global chain count, this
+rank's Philox offset) is exchanged ONCE, on the first step of every rank, or declared with `set_sharding`.  torch provides
+the buffers and the collective.
 """
 import ctypes as C
 
@@ -67,7 +71,7 @@ class Trainer(object):
         dev = dynamics.device
         L = _ffi.lib()
         self.n_grad = _ffi.check(L.l2hmc_train_grad_floats(d, H))
-        self.flat = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)          # gradient
+        self._alloc_flat(dev)                                                           # self.flat: the gradient
         # flat parameter vector [XNet | VNet | alpha]; every net parameter becomes a VIEW of it, so the
         # native Adam update is seen by the layers, by `Dynamics` and by its packed-weight cache
         self.theta = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)
@@ -93,6 +97,30 @@ class Trainer(object):
         self.variant = 0             # 100: force the general tile kernel (l2hmc.h)
         self._io = None              # per-N buffers of step()
         self._layout = None
+        self._auto_layout = None
+
+    N_TAIL = 8                       # floats behind the gradient in the all-reduced buffer (6 used)
+
+    def _alloc_flat(self, dev):
+        """[gradient (n_grad) | tail]: ONE buffer, so that a sharded step's gradient, loss sums and chain count travel in
+        ONE all-reduce; `self.flat` is the gradient view."""
+        self._flat_ext = torch.zeros(self.n_grad + self.N_TAIL, dtype=torch.float32, device=dev)
+        self.flat = self._flat_ext[:self.n_grad]
+
+    def _allreduce_flat(self, sums64, count):
+        """The ONE collective of a sharded step: all-reduce [gradient | (hi, lo) float pairs of the double sums | count];
+        returns (reduced sums as a float64 tensor, reduced count as a float64 scalar tensor) -- on the device, no sync."""
+        k = int(sums64.numel())
+        assert 2 * k + 2 <= self.N_TAIL
+        tail = self._flat_ext[self.n_grad:]
+        hi = sums64.to(torch.float32)
+        tail[0:2 * k:2] = hi
+        tail[1:2 * k:2] = (sums64 - hi.double()).to(torch.float32)
+        tail[2 * k] = float(count // 4096)
+        tail[2 * k + 1] = float(count % 4096)
+        dist.all_reduce(self._flat_ext[:self.n_grad + 2 * k + 2])
+        t = tail.double()
+        return t[0:2 * k:2] + t[1:2 * k:2], t[2 * k] * 4096.0 + t[2 * k + 1]
 
     # ---- checkpoint (the reference saves variables with tf.train.Saver, mnist_vae.py:290,334, and has to smuggle
     #      the masks around it, eval_sampler.py:52-59,156): everything a run needs to continue bit for bit ----
@@ -124,6 +152,12 @@ class Trainer(object):
 
     # ---- one launch: proposals + their gradient (accumulated into self.flat) ---------------------------
     def _propose_grad(self, start, v, direction, n_total, out=None):
+        a, keep, (Lx, p, v1) = self._train_args(start, v, direction, n_total, out)
+        _ffi.check(_ffi.lib().l2hmc_train_propose_grad(a, _ffi.current_stream(self.dyn.device)))
+        return Lx, p, v1
+
+    def _train_args(self, start, v, direction, n_total, out=None):
+        """L2hmcTrainArgs for the chains `start` (and what has to stay alive while the call runs)."""
         dyn = self.dyn
         N, d = start.shape
         L = _ffi.lib()
@@ -162,49 +196,61 @@ class Trainer(object):
         a.Lx, a.p, a.v1 = Lx.data_ptr(), p.data_ptr(), v1.data_ptr()
         a.grad, a.workspace = self.flat.data_ptr(), self._ws.data_ptr()
         a.variant = int(self.variant)
-        _ffi.check(L.l2hmc_train_propose_grad(a, _ffi.current_stream(dyn.device)))
-        return Lx, p, v1
+        return a, (xs, vs, buf), (Lx, p, v1)
 
     def _world(self):
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     def set_sharding(self, n_total, chain_offset):
         """Declare this rank's place in the global chain batch: `n_total` chains over all ranks, this rank's row 0 is
-        global chain `chain_offset` (e.g. from `sharding.shard_range`).  With a declared layout a step issues no
-        collective besides the flat-gradient all-reduce; `set_sharding(None, None)` returns to the discovered layout."""
+        global chain `chain_offset` (e.g. from `sharding.shard_range`).  With a declared layout no step ever exchanges
+        the layout; `set_sharding(None, None)` returns to the discovered layout (call it on EVERY rank: the next step of
+        each then takes part in the exchange)."""
         self._layout = None if n_total is None else (int(n_total), int(chain_offset))
+        self._auto_layout = None
 
     def _shard(self, N):
         """(global chain count, global index of this rank's row 0): ranks may hold different numbers of chains
         (sharding.shard_range hands out blocks whose sizes differ by up to one), so the loss normalisation and the
         Philox chain offsets come from the ranks' local counts, not from N * world.  Unless the layout was declared
-        (`set_sharding`), the counts are all-reduced on EVERY call -- unconditionally and by every rank, so the
-        collective sequence is the same on all ranks whatever happens to their local counts (a cache keyed on the
-        LOCAL count would let one rank skip the collective another rank enters)."""
+        (`set_sharding`), the counts are exchanged ONCE -- on every rank's first step, unconditionally, so all ranks
+        enter it together -- and kept.  A rank whose local count changes afterwards raises (quietly re-exchanging on
+        that rank alone would leave it in a collective no other rank enters; the review of round 2 found exactly that
+        hang): re-declare with `set_sharding`, or call `set_sharding(None, None)` on every rank."""
         world = self._world()
         if world == 1:
             return N, 0
         if getattr(self, "_layout", None) is not None:
             return self._layout
-        rank = dist.get_rank()
-        counts = torch.zeros(world, dtype=torch.float64, device=self.dyn.device)
-        counts[rank] = float(N)
-        dist.all_reduce(counts)
-        counts = counts.cpu()
-        return int(counts.sum()), int(counts[:rank].sum())
+        auto = getattr(self, "_auto_layout", None)
+        if auto is None:
+            rank = dist.get_rank()
+            counts = torch.zeros(world, dtype=torch.float64, device=self.dyn.device)
+            counts[rank] = float(N)
+            dist.all_reduce(counts)                     # once per layout, not per step
+            counts = counts.cpu()
+            auto = self._auto_layout = (int(N), int(counts.sum()), int(counts[:rank].sum()))
+        elif auto[0] != int(N):
+            raise RuntimeError("this rank's chain count changed from %d to %d under a discovered shard layout: declare the "
+                               "new layout with set_sharding(n_total, chain_offset), or call set_sharding(None, None) on "
+                               "EVERY rank so that all of them re-enter the layout exchange together" % (auto[0], N))
+        return auto[1], auto[2]
 
-    def _loss(self, v12, N, n_total, world):
-        # one fixed-order double reduction on the device (l2hmc_loss_terms) instead of a dozen elementwise framework kernels;
-        # the three doubles land in a FRESH tensor (an allocation, not a launch), so the returned loss is the caller's own
+    def _loss_terms(self, v12, n_total):
+        """[sum 1/v1, sum v1, the single-process loss] of the rank's per-chain loss arguments: one fixed-order double
+        reduction on the device (l2hmc_loss_terms), in a FRESH tensor (an allocation, not a launch)."""
         lt = torch.empty(3, dtype=torch.float64, device=v12.device)
         _ffi.check(_ffi.lib().l2hmc_loss_terms(v12.data_ptr(), v12.numel(), self.scale, 1.0 / float(n_total),
                                                lt.data_ptr(), _ffi.current_stream(v12.device)))
-        if world > 1:
-            terms = lt[:2]
-            dist.all_reduce(terms)
-            terms = terms / n_total
-            return self.scale * terms[0] - terms[1] / self.scale
-        return lt[2]
+        return lt
+
+    def _reduce_and_loss(self, v12, N, n_total, world):
+        """The step's collective (sharded: gradient + loss sums + count in ONE all-reduce) and the loss of the global batch."""
+        lt = self._loss_terms(v12, n_total)
+        if world == 1:
+            return lt[2]
+        sums, cnt = self._allreduce_flat(lt[:2], N)
+        return (self.scale * sums[0] - sums[1] / self.scale) / cnt
 
     def loss_and_grad(self, x, z=None, draws=None):
         """Loss and gradients (left in `.grad` of every parameter) for chain states `x`.
@@ -232,9 +278,7 @@ class Trainer(object):
         # the x- and the z-proposal are independent and their loss terms add: ONE launch over the 2N
         # chains [x; z] (each chain's term still weighted 1 / n_total) instead of two half-empty ones
         Lxz, pxz, v12 = self._propose_grad(torch.cat([x, z]), torch.cat([xv, zv]), torch.cat([xd, zd]), n_total)
-        if world > 1:
-            dist.all_reduce(self.flat)                  # the ONE collective of a training step
-        loss = self._loss(v12, N, n_total, world)
+        loss = self._reduce_and_loss(v12, N, n_total, world)      # (sharded: the ONE collective of a training step)
         for t, off, n in self.slots:
             t.grad = self.flat[off:off + n].view(t.shape)
         if self.train_alpha:
@@ -256,7 +300,8 @@ class Trainer(object):
 
     def step(self, x, u=None):
         """One optimiser step like nb raw 262-268: returns (loss, px, x_next, lr) where x_next is
-        the MH-selected continuation of the chains."""
+        the MH-selected continuation of the chains.  Three launches (module docstring); sharded: + ONE all-reduce and
+        the Adam launch behind it."""
         dyn = self.dyn
         x = as_device_f32(x, dyn.device)
         N, d = x.shape
@@ -270,27 +315,36 @@ class Trainer(object):
         # accept uniforms (row 0 of u): one call, stream position = (seed, 3 * global_step, global chain)
         _ffi.check(L.l2hmc_rng_fill(self.seed, 3 * self.global_step, chain_off, N, d, 3, W[1].data_ptr(),
                                     io["dir"].data_ptr(), io["u"].data_ptr(), s))
-        W[0].copy_(x)
-        self.flat.zero_()
-        # (the accept probabilities go to a FRESH tensor -- an allocation, not a launch -- whose first half is returned)
+        # (the accept probabilities, the selected states and the loss go to FRESH tensors -- allocations, not launches)
         p12 = torch.empty(2 * N, dtype=torch.float32, device=dyn.device)
-        self._propose_grad(W[0:2].view(2 * N, d), W[2:4].view(2 * N, d), io["dir"][1:3].view(2 * N), n_total,
-                           out=(io["Lx"], p12, io["v1"]))
-        if world > 1:
-            dist.all_reduce(self.flat)                  # the ONE collective of a training step
-        loss = self._loss(io["v1"], N, n_total, world)
+        x_next = torch.empty_like(x)
+        lt = torch.empty(3, dtype=torch.float64, device=dyn.device)
+        uu = io["u"][0] if u is None else as_device_f32(u, dyn.device)
+        # chains [x; z]: rows N .. 2N-1 of W[0:2] are z; the x rows are read from the caller's tensor (x_head)
+        a, keep, _ = self._train_args(W[0:2].view(2 * N, d), W[2:4].view(2 * N, d), io["dir"][1:3].view(2 * N), n_total,
+                                      out=(io["Lx"], p12, io["v1"]))
         lr = self.lr_at(self.global_step)
         self.global_step += 1
-        n_par = self.n_grad if self.train_alpha else self.n_grad - 1
-        _ffi.check(L.l2hmc_adam_step(self.theta.data_ptr(), self.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                     n_par, lr, self.beta1, self.beta2, self.epsilon, self.global_step,
-                                     int(self.train_alpha), s))
+        st = _ffi.L2hmcTrainStep()
+        st.x_head, st.n_head = x.data_ptr(), N
+        st.u, st.x_next = uu.data_ptr(), x_next.data_ptr()
+        st.loss = lt.data_ptr()
+        if world == 1:
+            st.theta, st.m, st.v = self.theta.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
+            st.lr, st.beta1, st.beta2, st.epsilon = lr, self.beta1, self.beta2, self.epsilon
+            st.step, st.train_alpha = self.global_step, int(self.train_alpha)
+        else:
+            st.terms = self._flat_ext[self.n_grad:].data_ptr()
+        _ffi.check(L.l2hmc_train_step(a, st, s))
+        if world > 1:
+            dist.all_reduce(self._flat_ext[:self.n_grad + 6])           # the ONE collective of a training step
+            n_par = self.n_grad if self.train_alpha else self.n_grad - 1
+            _ffi.check(L.l2hmc_adam_step_terms(self.theta.data_ptr(), self.flat.data_ptr(), self.m.data_ptr(),
+                                               self.v.data_ptr(), n_par, lr, self.beta1, self.beta2, self.epsilon,
+                                               self.global_step, int(self.train_alpha),
+                                               self._flat_ext[self.n_grad:].data_ptr(), self.scale, lt.data_ptr(), s))
         dyn._packed_key = None                          # the weights changed under the packed-fragment cache
-        x_next = torch.empty_like(x)
-        uu = io["u"][0] if u is None else as_device_f32(u, dyn.device)
-        _ffi.check(L.l2hmc_mh_select(x.data_ptr(), io["Lx"].data_ptr(), p12.data_ptr(), uu.data_ptr(), N, d,
-                                     x_next.data_ptr(), s))
-        return loss, p12[:N], x_next, lr
+        return lt[2], p12[:N], x_next, lr
 
 
 _MLP_FIELDS = ("W1", "b1", "W2", "b2", "W3", "b3")
@@ -334,7 +388,7 @@ class SplitTrainer(Trainer):
         self.enc = dynamics._xw["aux_encoder"]
         enc_s = mlp3_struct(self.enc) if self.enc is not None else None
         self.n_grad = _ffi.check(L.l2hmc_train_split_grad_floats(d, H, C.byref(enc_s) if enc_s is not None else None))
-        self.flat = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)
+        self._alloc_flat(dev)
         self.theta = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)
         self.slots, off = [], 0
         with torch.no_grad():
@@ -524,9 +578,7 @@ class SplitTrainer(Trainer):
         self.flat.zero_()
         self._propose_grad(W[0:2].view(2 * N, d), W[2:4].view(2 * N, d), io["dir"][1:3].view(2 * N), n_total,
                            out=(io["Lx"], io["p"], io["v1"]))
-        if world > 1:
-            dist.all_reduce(self.flat)
-        loss = self._loss(io["v1"], N, n_total, world)
+        loss = self._reduce_and_loss(io["v1"], N, n_total, world)      # (sharded: the step's ONE collective)
         lr = self.lr_at(self.global_step)
         self._adam(lr)
         x_next = torch.empty_like(x)
@@ -664,9 +716,7 @@ class SplitTrainer(Trainer):
             v1 = v1.double()
             terms = torch.stack([(1.0 / v1).sum() - v1.sum(),
                                  ((1.0 / ed.double()).sum() - ed.double().sum()) if es > 0 else torch.zeros((), dtype=torch.float64, device=dev)])
-        if world > 1:
-            dist.all_reduce(terms)
-        loss = (terms[0] + es * terms[1]) * inv
+        # (sharded: the loss sums ride behind the gradient in the ONE all-reduce at the end of this call)
         # ---- the earlier iterations, last to first: x_{t+1} = where(p_t - u_t >= 0, Lx_t, x_t) (sampler.py:53-55): the
         #      accepted rows' cotangent goes into iteration t's proposal, the rejected rows' straight on to x_t
         for t in range(MH - 2, -1, -1):
@@ -686,7 +736,10 @@ class SplitTrainer(Trainer):
                 break
             cot = through + cot * (1.0 - acc)
         if world > 1:
-            dist.all_reduce(self.flat)
+            terms, cnt = self._allreduce_flat(terms, N)               # the ONE collective: [gradient | loss sums | count]
+            loss = (terms[0] + es * terms[1]) / (cnt * MH)
+        else:
+            loss = (terms[0] + es * terms[1]) * inv
         self._publish_grads()
         return loss, x, p_last
 

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_size_queries():
     L = _ffi.lib()
-    assert L.l2hmc_abi_version() == 3 == _ffi.ABI_VERSION
+    assert L.l2hmc_abi_version() == 4 == _ffi.ABI_VERSION
     hdr = open(os.path.join(ROOT, "include", "l2hmc.h")).read()
     assert int(re.search(r"#define L2HMC_ABI_VERSION (\d+)", hdr).group(1)) == _ffi.ABI_VERSION
     # MFMA fragments (5 NT + 2 groups of 256 + 32 NT scales per net) + the lane layout (traj_lane.hpp: rows of RS = 12)

@@ -151,7 +151,7 @@ def test_bench_dist_leg_over_rccl_world_size_1():
                         "--no-cpu-baseline", "--no-sweep"], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-800:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["dist"]["rccl_ranks"] == 1 and out["dist"]["sharded_training"]["parameters_identical_across_ranks"]
+    assert out["dist"]["ranks"] == 1 and out["dist"]["backend"] == "nccl" and out["dist"]["sharded_training"]["parameters_identical_across_ranks"]
     assert 4e-3 < out["dist"]["sharded_ess"]["ess_per_mh_step"] < 8e-3         # notebook: 5.63e-3
     assert out["config"]["repeats"] > 1 and out["config"]["timed_steps"] == 20 * out["config"]["repeats"]
     assert out["value"] > 1e8 and out["config"]["state_finite"]

@@ -76,33 +76,59 @@ def test_single_process_fallthrough():
 
 
 def _layout_worker(rank, world, port, out):
-    """The host logic of `Trainer._shard` on CPU tensors: between two steps only rank 0's local chain count changes
-    (501 -> 500; rank 1 stays at 500).  Every rank must enter the same collectives in the same order -- the counts
-    exchange, then a differently-sized "flat gradient" all-reduce -- and see the new global layout."""
+    """The host logic of `Trainer._shard` / `_allreduce_flat` on CPU tensors.  The layout (global chain count, this
+    rank's offset) is exchanged ONCE -- by every rank, on its first step -- and a step then issues exactly ONE collective:
+    the all-reduce of [gradient | loss sums | count].  A rank whose local count changes afterwards raises instead of
+    re-entering an exchange no other rank takes part in; `set_sharding(None, None)` on EVERY rank re-opens the exchange."""
     import types
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(int(t.numel())), real(t, *a, **k))[1]
     try:
         from l2hmc_amd.training import Trainer
-        tr = types.SimpleNamespace(dyn=types.SimpleNamespace(device=torch.device("cpu")), _layout=None,
-                                   _world=lambda: world)
+        n_grad = 7
+        tr = types.SimpleNamespace(dyn=types.SimpleNamespace(device=torch.device("cpu")), _layout=None, _auto_layout=None,
+                                   _world=lambda: world, n_grad=n_grad, N_TAIL=Trainer.N_TAIL)
+        tr._flat_ext = torch.zeros(n_grad + Trainer.N_TAIL)
+        tr.flat = tr._flat_ext[:n_grad]
         seen = []
-        for n_local in ((501, 500), (500, 500), (500, 499)):
-            n_total, off = Trainer._shard(tr, n_local[rank])
-            flat = torch.full((7,), float(rank + 1))
-            dist.all_reduce(flat)                                   # the step's gradient all-reduce
-            seen.append((n_total, off, float(flat[0])))
-        Trainer.set_sharding(tr, 1234, 617 * rank)                  # declared layout: no collective at all
-        seen.append(Trainer._shard(tr, 617) + (0.0,))
+
+        def step(n_local):
+            n_total, off = Trainer._shard(tr, n_local)
+            tr.flat.fill_(float(rank + 1))                          # "the rank's gradient"
+            sums = torch.tensor([1e9 + 0.125 * (rank + 1), 3.0 * (rank + 1)], dtype=torch.float64)
+            red, cnt = Trainer._allreduce_flat(tr, sums, n_local)
+            return n_total, off, float(tr.flat[0]), float(red[0]), float(red[1]), float(cnt)
+
+        n0 = 501 if rank == 0 else 500                              # ragged shards
+        seen.append(step(n0))                                        # layout exchange + the step's collective
+        seen.append(step(n0))                                        # the step's collective ONLY
+        seen.append(tuple(calls))
+        raised = False
+        if rank == 0:
+            try:
+                Trainer._shard(tr, 500)                             # only this rank's count changes: no silent re-exchange
+            except RuntimeError:
+                raised = True
+        seen.append(raised)
+        Trainer.set_sharding(tr, None, None)                        # every rank re-opens the exchange ...
+        seen.append(step(500))                                      # ... and all see the new layout
+        del calls[:]
+        Trainer.set_sharding(tr, 1234, 617 * rank)                  # declared layout: no layout collective at all
+        seen.append(Trainer._shard(tr, 617))
+        seen.append(tuple(calls))
         out.put((rank, seen))
         dist.barrier()
     finally:
+        dist.all_reduce = real
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(120)
-def test_shard_layout_is_rediscovered_when_only_one_ranks_count_changes():
+def test_shard_layout_is_exchanged_once_and_a_step_is_one_collective():
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
     port = _free_port()
@@ -113,8 +139,14 @@ def test_shard_layout_is_rediscovered_when_only_one_ranks_count_changes():
         pr.join(100)
         assert pr.exitcode == 0
     res = dict(out.get() for _ in range(2))
-    assert res[0] == [(1001, 0, 3.0), (1000, 0, 3.0), (999, 0, 3.0), (1234, 0, 0.0)]
-    assert res[1] == [(1001, 501, 3.0), (1000, 500, 3.0), (999, 500, 3.0), (1234, 617, 0.0)]
+    big = 2e9 + 0.375                                               # the double sums survive the float (hi, lo) transport
+    for rank, off in ((0, 0), (1, 501)):
+        first, second, calls, raised, third, declared, calls2 = res[rank]
+        assert first == second == (1001, off, 3.0, big, 9.0, 1001.0)
+        assert calls == (2, 7 + 6, 7 + 6)                           # layout exchange once, then ONE all-reduce per step
+        assert raised == (rank == 0)
+        assert third == (1000, 500 * rank, 3.0, big, 9.0, 1000.0)
+        assert declared == (1234, 617 * rank) and calls2 == ()
 
 
 def _train_worker(rank, world, port, out):
@@ -170,6 +202,74 @@ def test_two_rank_training_step_matches_the_full_batch_gradient():
         assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (rank, loss, ref_loss)
         assert rel < 2e-4, (rank, rel)
         assert abs(ga - ref_ga) < 2e-4 * max(1.0, abs(ref_ga)), (rank, ga, ref_ga)
+
+
+def _step_worker(rank, world, port, out):
+    """Three whole optimiser steps (`Trainer.step`) with ragged shards on the SAME GPU: counts the collectives and
+    compares the sharded run with the same steps on the full batch in one process."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(int(t.numel())), real(t, *a, **k))[1]
+    try:
+        from l2hmc_amd.training import Trainer
+        from tests.helpers import hip_dynamics, load, to_dev
+        g = load("train_tilted8")
+        N = 37                                                       # 19 + 18 chains
+        x_all = np.tile(g["x"], (8, 1))[:N].copy()
+
+        def fresh():
+            dyn = hip_dynamics(g)
+            dyn.eps_override = None
+            with torch.no_grad():
+                dyn.alpha.fill_(float(np.log(g["eps"])))
+            return Trainer(dyn, seed=5)
+        tr = fresh()
+        lo, hi = sharding.shard_range(N)
+        x = to_dev(x_all[lo:hi])
+        losses = []
+        for _ in range(3):
+            loss, px, x, lr = tr.step(x)
+            losses.append(float(loss))
+        n_calls = tuple(calls)
+        ref = fresh()
+        ref._world = lambda: 1                                       # the same three steps on the full batch, one process
+        xr = to_dev(x_all)
+        ref_losses = []
+        for _ in range(3):
+            loss, px, xr, lr = ref.step(xr)
+            ref_losses.append(float(loss))
+        out.put((rank, n_calls, tr.n_grad, losses, ref_losses, float((tr.theta - ref.theta).abs().max()),
+                 float(tr.theta.double().sum()), float((x - xr[lo:hi]).abs().max())))
+        dist.barrier()
+    finally:
+        dist.all_reduce = real
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_rank_optimiser_steps_issue_one_collective_each():
+    """north_star: RCCL 'only to all-reduce the training-loss gradient': after the one-time layout exchange a sharded
+    `Trainer.step` is exactly ONE all-reduce (gradient, loss sums and chain count in one buffer), and three such steps
+    on ragged shards reproduce the single-process steps on the full batch (same Philox draws per global chain)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(280)
+        assert pr.exitcode == 0
+    res = sorted(out.get() for _ in range(2))
+    for rank, n_calls, n_grad, losses, ref_losses, dtheta, tsum, dx in res:
+        assert n_calls == (2, n_grad + 6, n_grad + 6, n_grad + 6), (rank, n_calls)
+        assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6), (losses, ref_losses)
+        assert dtheta < 2e-5 and dx < 1e-4, (rank, dtheta, dx)
+    assert res[0][6] == res[1][6]                                    # identical parameters on both ranks
 
 
 def _vae_train_worker(rank, world, port, out):
