@@ -362,9 +362,10 @@ int l2hmc_train_propose_grad(const L2hmcTrainArgs* args, void* stream);
 /* One optimiser step's device work in as few launches as the data flow allows (ABI 4; SCGExperiment.ipynb raw 156-181,
  * 254-271: propose(x) and propose(z), the loss of both, Adam, the MH-selected continuation of the x chains):
  *   launch 1  l2hmc_train_propose_grad's kernel over `args` -- with the start points of chains [0, n_head) read from
- *             `x_head` (no staging copy of the caller's state next to z), and the Metropolis select of those chains
- *             (sampler.py:53-55) in its epilogue when u / x_next are given;
+ *             `x_head` (no staging copy of the caller's state next to z);
  *   launch 2  the fixed-order slot reduction, which OVERWRITES args->grad (no zero fill), with
+ *             - the Metropolis select of chains [0, n_head) (sampler.py:53-55) in extra workgroups of the same launch
+ *               when u / x_next are given;
  *             - the loss terms of args->v1 (as l2hmc_loss_terms) -> `loss` and, split into float (hi, lo) pairs,
  *               -> `terms` = {sum 1/v1, sum v1, n_head}: the tail of the ONE buffer a sharded step all-reduces;
  *             - Adam on theta / m / v (as l2hmc_adam_step) in the same launch when `theta` is given (a single-process

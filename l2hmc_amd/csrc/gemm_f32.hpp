@@ -131,13 +131,26 @@ __device__ __forceinline__ Split3 split3(f4 x0, f4 x1) {       // 8 consecutive 
   o.l = o.h;
   return o;
 #endif
+  // The residuals are PLAIN v_sub_f32 (inline asm): left to the compiler, each pair of subtractions becomes one v_pk_add_f32,
+  // and the packed-f32 path shares the matrix pipe -- beside a wave streaming bf16 MFMAs a packed instruction issues once per
+  // ~22 cycles, a plain one every ~6.5 (profiles/r03_ubench_issue.txt, finding 3): the eight packed subtractions of a fragment
+  // cost more than its other 28 instructions together.  (L2HMC_BF3_PK_SUB restores the compiler's choice: the round-3 form.)
+  auto sub = [](float x, float y) {
+#ifdef L2HMC_BF3_PK_SUB
+    return x - y;
+#else
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#endif
+  };
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = xs[2 * i], b = xs[2 * i + 1];
     const unsigned ph = pk_bf16(a, b);
-    const float ra = a - __uint_as_float(ph << 16), rb = b - __uint_as_float(ph & 0xffff0000u);
+    const float ra = sub(a, __uint_as_float(ph << 16)), rb = sub(b, __uint_as_float(ph & 0xffff0000u));
     const unsigned pm = pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(pm << 16), sb = rb - __uint_as_float(pm & 0xffff0000u);
+    const float sa = sub(ra, __uint_as_float(pm << 16)), sb = sub(rb, __uint_as_float(pm & 0xffff0000u));
     o.h[i] = ph; o.m[i] = pm; o.l[i] = pk_bf16(sa, sb);
   }
   return o;
@@ -470,6 +483,7 @@ inline size_t net_eval_lds_bytes(int d, int H, int CB = 1) {
 template <int CB, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(const NetEvalArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  lds_poison(sm);
   constexpr int NE_MT = 16 * CB, NTHR = 64 * NWV;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;

@@ -359,7 +359,7 @@ long long plan_lds_fast(KArgs& k, int NW, int DT) {
 long long plan_lds_tile(KArgs& k, int DT) {
   long long o = 0;
   k.o_fw = (int)o;
-  o += 2LL * fast_fw_net(DT);
+  o += 2LL * tile_fw_net(DT);
   k.o_state = (int)o;
   o += tile_l1_floats(DT);
   k.o_fc = (int)o;
@@ -657,9 +657,13 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 64LL * device_cus()))) {
     const long long ldst = plan_lds_tile(k, k.NT);
     if (ldst <= 160 * 1024) {
-      note_kernel("traj_tile_kernel<%lld, %lld, %lld, %lld>", k.ekind, k.NT, KH <= 3 ? 3 : 4, L2HMC_TILE_TPW);
-      if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, ldst, s);
-      return launch_tile_ek<L2HMC_ENERGY_ROUGHWELL>(k, k.NT, KH, ldst, s);
+      // tiles (waves) per workgroup: 4, two workgroups per CU -- unless the staged tables (the split head fragments are 51 KB,
+      // the schedule records grow with T) leave room for ONE workgroup only: then 8 tiles share it, from the chain count
+      // (128 per CU) at which 8-tile workgroups still cover every CU
+      const int tpw = (2 * ldst > 160 * 1024 && a->n_chains >= 128LL * device_cus()) ? 8 : 4;
+      note_kernel("traj_tile_kernel<%lld, %lld, %lld, %lld>", k.ekind, k.NT, KH <= 3 ? 3 : 4, tpw);
+      if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, tpw, ldst, s);
+      return launch_tile_ek<L2HMC_ENERGY_ROUGHWELL>(k, k.NT, KH, tpw, ldst, s);
     }
     if (a->variant == 16)
       return fail(L2HMC_ERR_UNSUPPORTED, "variant 16: %s%lld bytes of LDS needed (T too large for the one-wave-per-tile kernel)", "", ldst);

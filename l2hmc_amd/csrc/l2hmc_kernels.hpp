@@ -45,6 +45,22 @@ __host__ __device__ constexpr bool weights_in_global(int DT) { return DT >= 4; }
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0);
 void note_kernel(const char* fmt, long long a = 0, long long b = 0, long long c = 0, long long d = 0);   // -> l2hmc_last_kernel
+
+// Debug builds with -DL2HMC_LDS_POISON (tools/build_variant_full.sh poison -DL2HMC_LDS_POISON): every kernel that works out of
+// dynamic LDS first fills ALL of it with NaN bit patterns.  LDS is not cleared between workgroups, so a kernel that reads a word
+// it never staged normally sees whatever the previous workgroup left there -- often plausible numbers, and parity tests pass by
+// luck; with the poison such a read turns into NaN and the same tests fail (profiles/r04_lds_poison.txt: the pass of round 4).
+// group_segment_size is read from the dispatch packet (hsa_kernel_dispatch_packet_t, byte offset 28).
+__device__ __forceinline__ void lds_poison(float* smem) {
+#if defined(L2HMC_LDS_POISON) && defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const unsigned* cptr_t;
+  const unsigned total = ((cptr_t)__builtin_amdgcn_dispatch_ptr())[7];
+  const unsigned words = (total - __builtin_amdgcn_groupstaticsize()) / 4;
+  const unsigned nthr = blockDim.x * blockDim.y * blockDim.z;
+  for (unsigned i = threadIdx.x; i < words; i += nthr) reinterpret_cast<unsigned*>(smem)[i] = 0xffffffffu;
+  __syncthreads();
+#endif
+}
 int check_energy(const L2hmcEnergy* e, int d);
 struct KArgs;
 // traj_wide.hip: the LDS-resident-state kernel for d > 256 (elementwise energies)
@@ -802,6 +818,7 @@ template <int EK, int DT, int NW, int KH>
 #endif
 __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void traj_kernel(const KArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * NW;
   const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
   const int c = lane & 15, q = lane >> 4;
@@ -1113,6 +1130,7 @@ __global__ __launch_bounds__(64 * NW, (DT <= 2 ? L2HMC_WAVES_PER_SIMD : 1)) void
 template <int EK, int DT, int NW>
 __global__ __launch_bounds__(64 * NW) void energy_kernel(const KArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
   const int c = lane & 15, q = lane >> 4;
@@ -1133,6 +1151,7 @@ __global__ __launch_bounds__(64 * NW) void energy_kernel(const KArgs A) {
 template <int EK, int DT, int NW>
 __global__ __launch_bounds__(64 * NW) void paccept_kernel(const KArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
   const int c = lane & 15, q = lane >> 4;
@@ -1209,7 +1228,7 @@ template <int EK>
 int launch_ek(int op, const KArgs& k, int DT, int NW, int KH, long long lds, hipStream_t s);
 // traj_tile_kernel (one wave per tile, 4 tiles per workgroup): elementwise targets only (traj_ek1.hip, traj_ek4.hip)
 template <int EK>
-int launch_tile_ek(const KArgs& k, int DT, int KH, long long lds, hipStream_t s);
+int launch_tile_ek(const KArgs& k, int DT, int KH, int tpw, long long lds, hipStream_t s);
 
 #define L2HMC_DEFINE_LAUNCH_EK(EKv)                                                              \
   template <>                                                                                    \

@@ -61,12 +61,9 @@ struct TArgs {
   float eta;
   float scale, inv_n;
   float *Lx, *p, *v1, *grad, *ws;
-  // l2hmc_train_step: chains [0, n_head) start from x_head (n_head = 0: all from x) and, with u / x_next, take their
-  // Metropolis select in the kernel's epilogue (the register-resident kernels; the general one leaves it to a launch)
+  // l2hmc_train_step: chains [0, n_head) start from x_head (n_head = 0: all from x)
   const float* x_head;
   long long n_head;
-  const float* u;
-  float* x_next;
 };
 __device__ __forceinline__ const float* x_row0(const TArgs& A, long long n) { return n < A.n_head ? A.x_head : A.x; }
 
@@ -416,6 +413,7 @@ __device__ __forceinline__ void t_net_bwd(const TCtx& X, const float* W, float* 
 
 __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   const int tid = threadIdx.x;
   const int d = A.d, H = A.H, T = A.T;
   const int ek = A.ekind;
@@ -874,6 +872,7 @@ __global__ void train_reduce_kernel(const float* part, int n_slots, int n_grad, 
 struct FinalArgs {
   const float* v1; long long n_v1; float scale; double inv_n; long long n_head;
   float* terms; double* loss;
+  const float *x0, *Lx, *p, *u; float* x_next; int d;        // the Metropolis select of chains [0, n_head) (sampler.py:53-55)
   float *theta, *m, *v; float lr_t, b1, b2, eps; int last_is_log_eps; int n_par;
 };
 __device__ __forceinline__ void adam_update(float* p, float gi, float* m, float* v, long long i, long long n, float lr_t,
@@ -892,6 +891,14 @@ __device__ __forceinline__ void split_hi_lo(double t, float* out) {
 }
 __global__ __launch_bounds__(256) void train_final_kernel(const float* part, int n_slots, int n_grad, float* dst, FinalArgs f) {
   const int nb = (n_grad + 255) / 256;
+  if ((int)blockIdx.x > nb) {                  // the Metropolis-select blocks: x_next = (p - u >= 0) ? Lx : x, thread = (chain, dim)
+    const long long i = (long long)(blockIdx.x - nb - 1) * 256 + threadIdx.x;
+    if (i < f.n_head * f.d) {
+      const long long n = i / f.d;
+      f.x_next[i] = (f.p[n] - f.u[n] >= 0.f) ? f.Lx[i] : f.x0[i];
+    }
+    return;
+  }
   if ((int)blockIdx.x == nb) {                 // the loss block
     __shared__ double sa[4], sb[4];
     double a = 0.0, b = 0.0;
@@ -936,15 +943,6 @@ __global__ __launch_bounds__(256) void train_final_kernel(const float* part, int
   dst[i] = s;
   if (f.theta != nullptr && i < f.n_par) adam_update(f.theta, s, f.m, f.v, i, f.n_par, f.lr_t, f.b1, f.b2, f.eps, f.last_is_log_eps);
 }
-// the Metropolis select of chains [0, n_head) behind the general kernel (the register-resident ones do it themselves)
-__global__ void train_mh_select_kernel(const float* x, const float* Lx, const float* p, const float* u, long long N, int d,
-                                       float* out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * d) return;
-  const long long n = i / d;
-  out[i] = (p[n] - u[n] >= 0.f) ? Lx[i] : x[i];
-}
-
 __device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.f); }
 // Phase timers of profiling builds (-DL2HMC_TRAIN_TIMING, tools/train_phase_timing.py): accumulated in REGISTERS and written
 // once at the end (a global read-modify-write per mark would cost more than the phases it brackets).
@@ -1094,8 +1092,6 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
   k.scale = a->scale; k.inv_n = a->inv_n;
   k.Lx = a->Lx; k.p = a->p; k.v1 = a->v1; k.grad = a->grad; k.ws = a->workspace;
   k.x_head = st ? st->x_head : nullptr; k.n_head = st ? st->n_head : 0;
-  k.u = st ? st->u : nullptr; k.x_next = st ? st->x_next : nullptr;
-  bool mh_done = false;
   const unsigned blocks = (unsigned)((a->n_chains + TC - 1) / TC);
   hipStream_t s = (hipStream_t)stream;
   const int n_grad = 2 * net_params(a->d, a->H) + 1;
@@ -1110,7 +1106,6 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
     else if (ek == L2HMC_ENERGY_GMM) launch_train_small<L2HMC_ENERGY_GMM>(k, KH, blocks, lds_small, s);
     else launch_train_small<L2HMC_ENERGY_ROUGHWELL>(k, KH, blocks, lds_small, s);
     part = a->workspace + (long long)blocks * a->T * TF_CK * 256;
-    mh_done = true;
     note_kernel("train_small_kernel<%lld, %lld>", ek, KH <= 3 ? 3 : 4);
   } else if (fnw && lds_fast <= 160 * 1024) {    // register-resident kernel (train_fast.hpp)
     const int KH = khid_of(a->H);
@@ -1123,7 +1118,6 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
     else rc = launch_train_fast<L2HMC_ENERGY_GAUSS_DENSE, 1>(k, KH, blocks, lds_fast, s);
     if (rc) return rc;
     part = a->workspace + (long long)blocks * a->T * TF_CK * (fnw * 256);
-    mh_done = true;
     note_kernel("train_fast_kernel<%lld, %lld, %lld>", ek, fnw, KH <= 3 ? 3 : 4);
   } else {
     if (ek == L2HMC_ENERGY_FUNNEL)               // the general tile kernel has no funnel Hessian-vector product
@@ -1142,9 +1136,6 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
     note_kernel("train_kernel");
     part = a->workspace + (long long)a->T * a->n_chains * CKPT * a->d;
   }
-  if (st != nullptr && st->u != nullptr && !mh_done)
-    hipLaunchKernelGGL(train_mh_select_kernel, dim3((unsigned)((st->n_head * a->d + 255) / 256)), dim3(256), 0, s, st->x_head,
-                       a->Lx, a->p, st->u, (long long)st->n_head, a->d, st->x_next);
   const float* last = part;
   int last_slots = (int)blocks;
   if (blocks > (unsigned)kReduceChunk) {      // two levels, both in slot order: still deterministic
@@ -1161,7 +1152,9 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
   } else {
     FinalArgs f;
     memset(&f, 0, sizeof(f));
-    const bool want_loss = st->terms != nullptr || st->loss != nullptr;
+    // (the loss block is always launched -- it idles without outputs -- so that the select blocks sit at fixed indices)
+    const long long mh_blocks = st->u != nullptr ? (st->n_head * a->d + 255) / 256 : 0;
+    f.x0 = st->x_head; f.Lx = a->Lx; f.p = a->p; f.u = st->u; f.x_next = st->x_next; f.d = a->d;
     f.v1 = a->v1; f.n_v1 = a->n_chains; f.scale = a->scale; f.inv_n = (double)a->inv_n; f.n_head = st->n_head;
     f.terms = st->terms; f.loss = st->loss;
     if (st->theta != nullptr) {
@@ -1172,7 +1165,7 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
       f.last_is_log_eps = st->train_alpha != 0;
       f.n_par = st->train_alpha ? n_grad : n_grad - 1;
     }
-    hipLaunchKernelGGL(train_final_kernel, dim3((n_grad + 255) / 256 + (want_loss ? 1 : 0)), dim3(256), 0, s, last, last_slots,
+    hipLaunchKernelGGL(train_final_kernel, dim3((unsigned)((n_grad + 255) / 256 + 1 + mh_blocks)), dim3(256), 0, s, last, last_slots,
                        n_grad, a->grad, f);
   }
   hipError_t e = hipGetLastError();

@@ -54,6 +54,7 @@ constexpr int TF_CK = 13;
 template <int EK, int NW, int KH>
 __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   TS_DECL;
   const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * NW;
   const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
@@ -483,12 +484,6 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (dim0 + j < d) A.Lx[n * d + dim0 + j] = x[j];
-    if (A.x_next != nullptr && n < A.n_head) {                 // Metropolis select of the continuing chains (sampler.py:53-55)
-      const bool acc = p - A.u[n] >= 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (dim0 + j < d) A.x_next[n * d + dim0 + j] = acc ? x[j] : xs[j];
-    }
   }
   f4 lx = okc ? (x - xs) * dv1p - g * lam : Z;
   f4 lv = okc ? v * (-lam) : Z;

@@ -45,6 +45,7 @@ static_assert(TS_CK * 64 <= TF_CK * 256, "the d <= 4 trainer's checkpoints must 
 template <int EK, int KH>
 __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   TS_DECL;
   // Two waves per 16-chain tile.  Wave 0 runs the trajectory and the adjoint recursion (the dependency chain of the step);
   // wave 1 only accumulates the weight-gradient tiles: after every back-propagation wave 0 leaves the seven operands in LDS
@@ -474,7 +475,6 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
   const float dv1p = dv1 * p * 2.f;
   const bool okc = sq < 3.0e38f;
   if (alive && livedim) A.Lx[n * d + q] = x;
-  if (A.x_next != nullptr && n < A.n_head && livedim) A.x_next[n * d + q] = (p - A.u[n] >= 0.f) ? x : xs;      // sampler.py:53-55
   float lx = okc ? (x - xs) * dv1p - g * lam : 0.f;
   float lv = okc ? v * (-lam) : 0.f;
   float deps = 0.f;

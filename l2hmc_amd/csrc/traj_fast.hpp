@@ -165,6 +165,7 @@ template <int EK, int DT, int NW, int KH>
 #endif
 __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(const KArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   static_assert(DT <= 2, "the fast kernel keeps layer-1 and tail fragments in registers");
   const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * NW;
   const int w = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
@@ -304,6 +305,12 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
     }
     __syncthreads();
   }
+#ifdef L2HMC_DEPHASE
+  // (experiment: two workgroups share a CU from 8192 chains on and run the same phases at the same time; a head start for one
+  //  of them lets its MFMA-heavy net tails fall into the other's exchange stalls)
+  if (L2HMC_DEPHASE_MODE ? (blockIdx.x & 1) : (blockIdx.x >= (gridDim.x + 1) / 2))
+    for (int i = 0; i < L2HMC_DEPHASE; ++i) __builtin_amdgcn_s_sleep(4);
+#endif
   PT_DECL;
   PT_MARK(0);      // prologue
   pv[0] = vnet_l1(x, g);

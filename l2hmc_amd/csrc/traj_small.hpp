@@ -76,6 +76,7 @@ __device__ __forceinline__ float grad_small(const KArgs& A, const float* smem, c
 template <int EK, int KH>
 __global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   const int lane = threadIdx.x;
   const int c = lane & 15, q = lane >> 4;
   const long long chain = (long long)blockIdx.x * 16 + c;

@@ -18,13 +18,19 @@ namespace l2hmc {
 
 long long plan_lds_tile(KArgs& k, int DT);
 
-// L2HMC_BFL1 = 1: the layer-1 contractions of this kernel as K-packed bf16x3 too (needs L2HMC_BFH); its fragments are split when
+// L2HMC_BFH_TILE = 1 (the default since round 4): the head contractions -- 144 of this kernel's 212 MFMAs per tile-step -- run as
+// K-packed bf16x3 (bf3k.hpp): 3 bf16 MFMAs of 16 cycles that leave the VALU to the SIMD's other wave instead of 3 f32 MFMAs of
+// 32 cycles that block it; fragments split when they are staged (32 bytes per lane and block), the second hidden activation
+// split once per net evaluation.  Measured (profiles/r04_bf16x3_heads.txt): 65 536 chains 224.8 -> 194 us per proposal
+// (0.425 -> 0.49 of the fp32 roof), 32 768 chains 115.7 -> 104, 16 384 chains 65.2 -> 64; results within the same tolerances.
+#ifndef L2HMC_BFH_TILE
+#define L2HMC_BFH_TILE 1
+#endif
+__host__ __device__ constexpr int tile_fw_net(int NTp) { return ((L2HMC_BFH_TILE ? 6 : 3) * NTp + 1) * 256; }   // staged tail fragments per net
+// L2HMC_BFL1 = 1: the layer-1 contractions of this kernel as K-packed bf16x3 too (needs L2HMC_BFH_TILE; measured slower: 205.6 vs 195 us at 65 536 chains -- the 20 extra splits per tile-step cost more VALU than the 56 f32 MFMAs they replace); its fragments are split when
 // staged, every layer-1 input slice by the wave that contracts it.
 #ifndef L2HMC_BFL1
 #define L2HMC_BFL1 0
-#endif
-#ifndef L2HMC_TILE_TPW
-#define L2HMC_TILE_TPW 4
 #endif
 __host__ __device__ constexpr int tile_l1_floats(int DT) { return 4 * DT * 256 * (L2HMC_BFL1 ? 2 : 1); }
 
@@ -32,6 +38,7 @@ template <int EK, int DT, int KH, int TPW>
 __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
   static_assert(EK == L2HMC_ENERGY_GAUSS_DIAG || EK == L2HMC_ENERGY_ROUGHWELL, "elementwise targets only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   const int tid = threadIdx.x, lane = tid & 63, nthr = 64 * TPW;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
@@ -40,7 +47,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
   constexpr int NTp = DT;
-  const int FWN = fast_fw_net(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
+  const int FWN = tile_fw_net(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
             RECD = fast_rec_dir(NTp, A.T);
   const f4 Z = splat(0.f);
 
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
     f4 src = Z;
     if (g < 3 * NT + 1) src = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + (2 * NT + 1) * 256)[j];
-#if L2HMC_BFH
+#if L2HMC_BFH_TILE
     if (g == 0) reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src;
     else bfk_store(smem + A.o_fw + net * FWN + 256, g - 1, j & 63, bfk_wfrag(src * sc));
 #else
@@ -195,11 +202,11 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     return h;
   };
   // heads of dimension slice t: aS = log2 of the scale factor, T' = step T, EQ' = step e^{eps Q}  (traj_fast.hpp)
-#if L2HMC_BFH && defined(L2HMC_TILE_PIPE)
+#if L2HMC_BFH_TILE && defined(L2HMC_TILE_PIPE)
   // the split of the hidden activation rides in the shadow of slice 0's head MFMAs (bfk_heads3); later slices reuse it
   struct HidT { f4 h; BfkA b; };
   auto hidden_b = [&](const float* fw, f4 hs_) { HidT r; r.h = hidden(fw, hs_); return r; };
-#elif L2HMC_BFH
+#elif L2HMC_BFH_TILE
   typedef BfkA HidT;                      // the second hidden activation as the split B operand of the heads
   auto hidden_b = [&](const float* fw, f4 hs_) { return bfk_afrag(hidden(fw, hs_)); };
 #else
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     const f4 cS = lds4(fc + dofs + 16 * t + 4 * q), cQ = lds4(fc + 2 * DPp + 16 * t + 4 * q),
              bQ = lds4(fc + 3 * DPp + 16 * t + 4 * q);
     f4 zs = Z, zt = Z, zq = Z;
-#if L2HMC_BFH && defined(L2HMC_TILE_PIPE)
+#if L2HMC_BFH_TILE && defined(L2HMC_TILE_PIPE)
     if (t == 0) {
       h.b = bfk_heads3(bfk_load(fw + 256, 0, lane), bfk_load(fw + 256, 2, lane), bfk_load(fw + 256, 1, lane), h.h, zs, zq, zt);
     } else {
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       zq = bfk_dot(bfk_load(fw + 256, 3 * t + 2, lane), h.b, zq);
       zt = bfk_dot(bfk_load(fw + 256, 3 * t + 1, lane), h.b, zt);
     }
-#elif L2HMC_BFH
+#elif L2HMC_BFH_TILE
     zs = bfk_dot(bfk_load(fw + 256, 3 * t + 0, lane), h, zs);
     zq = bfk_dot(bfk_load(fw + 256, 3 * t + 2, lane), h, zq);
     zt = bfk_dot(bfk_load(fw + 256, 3 * t + 1, lane), h, zt);

@@ -7,26 +7,32 @@
 namespace l2hmc {
 
 template <class K>
-static int launch_tile(K kern, const KArgs& k, long long lds, hipStream_t s) {
+static int launch_tile(K kern, int TPW, const KArgs& k, long long lds, hipStream_t s) {
   if (lds > kMaxLdsBytes) return fail(L2HMC_ERR_UNSUPPORTED, "tile kernel: %s%lld bytes of LDS needed", "", lds);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  const long long blocks = (k.N + 16 * L2HMC_TILE_TPW - 1) / (16 * L2HMC_TILE_TPW);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * L2HMC_TILE_TPW), (size_t)lds, s, k);
+  const long long blocks = (k.N + 16 * TPW - 1) / (16 * TPW);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * TPW), (size_t)lds, s, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;
 }
 template <>
-int launch_tile_ek<1>(const KArgs& k, int DT, int KH, long long lds, hipStream_t s) {
-  if (DT == 3) return KH <= 3 ? launch_tile(traj_tile_kernel<1, 3, 3, L2HMC_TILE_TPW>, k, lds, s) : launch_tile(traj_tile_kernel<1, 3, 4, L2HMC_TILE_TPW>, k, lds, s);
-  return KH <= 3 ? launch_tile(traj_tile_kernel<1, 4, 3, L2HMC_TILE_TPW>, k, lds, s) : launch_tile(traj_tile_kernel<1, 4, 4, L2HMC_TILE_TPW>, k, lds, s);
+int launch_tile_ek<1>(const KArgs& k, int DT, int KH, int tpw, long long lds, hipStream_t s) {
+#define L2HMC_TILE_GO(DTc, KHc)                                                                       \
+  return tpw == 8 ? launch_tile(traj_tile_kernel<1, DTc, KHc, 8>, 8, k, lds, s) : launch_tile(traj_tile_kernel<1, DTc, KHc, 4>, 4, k, lds, s);
+  if (DT == 3) { if (KH <= 3) { L2HMC_TILE_GO(3, 3) } else { L2HMC_TILE_GO(3, 4) } }
+  if (KH <= 3) { L2HMC_TILE_GO(4, 3) } else { L2HMC_TILE_GO(4, 4) }
+#undef L2HMC_TILE_GO
 }
 template <>
-int launch_tile_ek<4>(const KArgs& k, int DT, int KH, long long lds, hipStream_t s) {
-  if (DT == 3) return KH <= 3 ? launch_tile(traj_tile_kernel<4, 3, 3, L2HMC_TILE_TPW>, k, lds, s) : launch_tile(traj_tile_kernel<4, 3, 4, L2HMC_TILE_TPW>, k, lds, s);
-  return KH <= 3 ? launch_tile(traj_tile_kernel<4, 4, 3, L2HMC_TILE_TPW>, k, lds, s) : launch_tile(traj_tile_kernel<4, 4, 4, L2HMC_TILE_TPW>, k, lds, s);
+int launch_tile_ek<4>(const KArgs& k, int DT, int KH, int tpw, long long lds, hipStream_t s) {
+#define L2HMC_TILE_GO(DTc, KHc)                                                                       \
+  return tpw == 8 ? launch_tile(traj_tile_kernel<4, DTc, KHc, 8>, 8, k, lds, s) : launch_tile(traj_tile_kernel<4, DTc, KHc, 4>, 4, k, lds, s);
+  if (DT == 3) { if (KH <= 3) { L2HMC_TILE_GO(3, 3) } else { L2HMC_TILE_GO(3, 4) } }
+  if (KH <= 3) { L2HMC_TILE_GO(4, 3) } else { L2HMC_TILE_GO(4, 4) }
+#undef L2HMC_TILE_GO
 }
 }  // namespace l2hmc

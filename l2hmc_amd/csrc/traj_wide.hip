@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
   constexpr bool GMMK = EK == L2HMC_ENERGY_GMM;                 // (both: grad U couples all dimensions)
   constexpr bool DENSE = EK == L2HMC_ENERGY_GAUSS_DENSE || GMMK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  lds_poison(smem);
   constexpr int NTHR = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -13,9 +13,9 @@ summing per-rank gradients computed with inv_n = 1 / (global chain count) is exa
 
 A training step is THREE launches and no torch optimiser (round 4; `l2hmc_train_step`): `l2hmc_rng_fill` (z, both
 momenta, both direction vectors, the accept uniforms -- one Philox call); the gradient kernel, which reads the chains'
-state where the caller keeps it and takes their Metropolis select in its epilogue; the fixed-order slot reduction, which
-overwrites the gradient and carries the loss terms and TF1's Adam over the flat parameter vector [XNet | VNet | alpha]
-(the parameter tensors of the nets are views of it).  Sharded over ranks a step is ONE collective: the slot reduction
+state where the caller keeps it; the fixed-order slot reduction, which overwrites the gradient and carries -- in extra
+workgroups of the same launch -- the loss terms, the chains' Metropolis select and TF1's Adam over the flat parameter
+vector [XNet | VNet | alpha] (the parameter tensors of the nets are views of it).  Sharded over ranks a step is ONE collective: the slot reduction
 leaves the rank's loss sums and chain count behind the gradient, `[gradient | loss sums | count]` is all-reduced as one
 buffer, and `l2hmc_adam_step_terms` applies Adam and forms the global loss.  The shard layout (global chain count, this
 rank's Philox offset) is exchanged ONCE, on the first step of every rank, or declared with `set_sharding`.  torch provides
@@ -378,6 +378,10 @@ class SplitTrainer(Trainer):
         # over as a plain closure energy(z, aux) with the image-conditioned nets
         self.image_sampler = self.vae or (self.user and dynamics._xw["aux_encoder"] is not None)
         self.scale = float(scale) if scale is not None else (1.0 if self.image_sampler else 0.1)
+        if self.image_sampler and self.scale != 1.0:
+            # mnist_vae.py:207-226 has no scale (its loss is mean(1/v) - mean(v)); the composed-proposal branch of
+            # sampler_loss_and_grad forms its cotangents for exactly that objective
+            raise ValueError("the image-conditioned sampler objective (mnist_vae.py:207-226) has no `scale`: leave it at 1")
         self.clip_norm = clip_norm if clip_norm is not None else (5.0 if self.image_sampler else None)   # mnist_vae.py:258
         self.lr0, self.decay_steps, self.decay_rate = float(lr), int(decay_steps), float(decay_rate)
         self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)

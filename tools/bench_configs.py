@@ -6,7 +6,9 @@
 C1 SCG d=2 / 200 chains, C2 ICG d=50 / 4096 chains (the bench.py workload), C3 MoG d=2 / 65 536
 chains / Lf=25, C4 Rough Well d in {2 .. 512} / 16 384 chains, all with H=10 S/T/Q nets (random,
 head std raised so S, T, Q are exercised), direction-mixed propose + MH, M chained proposals per
-launch with the in-kernel Philox draws.  Reports useful chain.leapfrog-steps/s and the fraction of
+launch with the in-kernel Philox draws.  The step size is tuned PER CONFIGURATION on a short pilot run (x 0.6 / x 1.3
+until the mean accept probability lies in [0.2, 0.9]; printed) -- round 3 ran every configuration at eps = 0.1, where the
+wide targets accept nothing (rates of a sampler that never moves).  Reports useful chain.leapfrog-steps/s and the fraction of
 the fp32-MFMA roof with the algorithmic FLOPs of SURVEY.md 8(d).  (C5, the VAE posterior on the
 split engine, is tools/bench_vae.py.)"""
 import os
@@ -24,6 +26,22 @@ import bench
 from l2hmc_amd import Dynamics, distributions as D, layers, sample_chain
 
 
+def tune_eps(dyn, x, M, lo=0.2, hi=0.9):
+    """step size with a mean accept probability inside [lo, hi] (pilot: M proposals from x per trial)"""
+    eps = 0.1
+    for _ in range(16):
+        dyn.eps_override = eps
+        _, p, _ = sample_chain(x, dyn, M, seed=3)
+        a = float(p.mean())
+        if a < lo:
+            eps *= 0.6
+        elif a > hi:
+            eps *= 1.3
+        else:
+            break
+    return eps
+
+
 def run(name, dist, d, n, T, grad_flops, x0, M, reps):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -32,6 +50,7 @@ def run(name, dist, d, n, T, grad_flops, x0, M, reps):
                    net_factory=layers.stq_network(10, head_factor=0.03), device=dev)
     dyn.variant = int(os.environ.get("L2HMC_VARIANT", "0"))      # kernel geometry override (see l2hmc.h)
     x = torch.as_tensor(x0, dtype=torch.float32, device=dev)
+    eps = tune_eps(dyn, x, M)
     for _ in range(2):
         sample_chain(x, dyn, M, seed=1)
     torch.cuda.synchronize()
@@ -45,8 +64,10 @@ def run(name, dist, d, n, T, grad_flops, x0, M, reps):
     t = e0.elapsed_time(e1) * 1e-3 / (reps * M)
     steps = n * T / t
     fl = bench.algorithmic_flops_per_chain_step(d, 10, T, grad_flops)
-    print("%-28s chains %6d d %3d Lf %2d M %3d: %8.2f us / proposal  %.3e steps/s  mfma-frac %.3f  accept %.2f"
-          % (name, n, d, T, M, t * 1e6, steps, steps * fl / 1e12 / bench.PEAK_F32_MFMA_TFLOPS, float(p.mean())), flush=True)
+    from l2hmc_amd import _ffi as ffi_
+    print("%-30s chains %6d d %3d Lf %2d M %3d eps %.4f: %8.2f us / proposal  %.3e steps/s  mfma-frac %.3f  accept %.2f  %s"
+          % (name, n, d, T, M, eps, t * 1e6, steps, steps * fl / 1e12 / bench.PEAK_F32_MFMA_TFLOPS, float(p.mean()),
+             ffi_.last_kernel()), flush=True)
 
 
 def main():
@@ -55,6 +76,13 @@ def main():
         for d in (64, 128, 256, 512):
             run("C4 RoughWell (easy, eta=0.1)", D.RoughWell(d, 0.1, easy=True), d, 16384, 10, 4 * d,
                 rng.randn(16384, d), 10, 4)
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "one":         # one Rough-Well case (the counter passes of tools/collect_r04.sh)
+        d = int(sys.argv[2])
+        if len(sys.argv) > 3 and sys.argv[3] == "noneasy":
+            run("C4 RoughWell (eta=1e-2)", D.RoughWell(d, 1e-2, easy=False), d, 16384, 10, 4 * d, rng.randn(16384, d), 10, 4)
+        else:
+            run("C4 RoughWell (easy, eta=0.1)", D.RoughWell(d, 0.1, easy=True), d, 16384, 10, 4 * d, rng.randn(16384, d), 10, 4)
         return
     cov = np.array([[50.05, -49.95], [-49.95, 50.05]])
     g = D.Gaussian(np.zeros(2), cov)
@@ -66,6 +94,11 @@ def main():
     run("C3 MoG-2D", mog, 2, 65536, 25, 2 * (2 * 4 + 4), mog.get_samples(65536), 10, 4)
     for d in (2, 8, 32, 50, 128, 512):
         run("C4 RoughWell (easy, eta=0.1)", D.RoughWell(d, 0.1, easy=True), d, 16384, 10, 4 * d,
+            rng.randn(16384, d), 10, 4)
+    # the reference's own (non-easy) form, distributions.py:84-97 with easy=False: cos(x / eta^2), eta = 1e-2 -- arguments
+    # of 1e4 x, i.e. every sin / cos goes through the full range reduction ("run non-easy as a second series")
+    for d in (2, 8, 32, 50, 128, 512):
+        run("C4 RoughWell (eta=1e-2)", D.RoughWell(d, 1e-2, easy=False), d, 16384, 10, 4 * d,
             rng.randn(16384, d), 10, 4)
 
 

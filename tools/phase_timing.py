@@ -16,7 +16,7 @@ PHASES = ["prologue", "step head", "VNet tail #1", "XNet L1 (a,b)", "xchg", "XNe
 
 def main():
     csrc = os.path.join(ROOT, "l2hmc_amd", "csrc")
-    out = os.path.join(csrc, "variants", "libl2hmc_hip_pt.so")
+    out = os.environ.get("L2HMC_PT_LIB", os.path.join(csrc, "variants", "libl2hmc_hip_pt.so"))
     if len(sys.argv) > 1 and sys.argv[1] == "build":      # run this in the container, NOT on the GPU box
         os.makedirs(os.path.dirname(out), exist_ok=True)
         import glob
