@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libl2hmc_hip.so")
+# the in-tree build; L2HMC_LIB names another BUILD OF THE SAME LIBRARY (kernel experiments, sanitizer / LDS-poison passes:
+# tools/pytest_with_lib.py) -- never a fallback: whatever is named must exist and pass the ABI checks of lib()
+LIB_PATH = os.path.abspath(os.environ["L2HMC_LIB"]) if os.environ.get("L2HMC_LIB") else os.path.join(_HERE, "csrc", "libl2hmc_hip.so")
 
 ENERGY_GAUSS_DIAG, ENERGY_GAUSS_DENSE, ENERGY_GMM, ENERGY_ROUGHWELL, ENERGY_FUNNEL = 1, 2, 3, 4, 5
 
