@@ -237,6 +237,53 @@ def config5_leg(dev, chains=8192):
                       "frac": chains * flops_train / (ms_train * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
 
 
+def config4_leg(dev, chains=16384, dims=(2, 50, 512)):
+    """BASELINE.json config 4 inside the bench run (an extra key): Rough Well (distributions.py:84-97), 16 384 chains, Lf = 10,
+    H = 10 nets with raised head scale, one kernel family per width (d = 2 the one-dimension-per-lane tile, d = 50 one wave per
+    tile, d = 512 the LDS-resident-state kernel); both the `easy` form (eta = 0.1, cos(x / eta)) and the reference's own
+    (eta = 1e-2, cos(x / eta^2): every sin / cos through the full range reduction).  The step size is tuned per case on a pilot
+    run so that the chains move (mean accept in [0.2, 0.9]).  HIP-event time of M = 10 chained proposals per launch; the
+    counter passes of the same cases are profiles/r04_config4_pmc.txt."""
+    import torch
+    from l2hmc_amd import Dynamics, _ffi, distributions, layers, sample_chain
+    rng = np.random.RandomState(0)
+    out = []
+    for easy, eta in ((True, 0.1), (False, 1e-2)):
+        for d in dims:
+            torch.manual_seed(0)
+            np.random.seed(0)
+            dyn = Dynamics(d, distributions.RoughWell(d, eta, easy=easy).get_energy_function(), T=T, eps=0.1,
+                           net_factory=layers.stq_network(H, head_factor=0.03), device=dev)
+            x = torch.as_tensor(rng.randn(chains, d), dtype=torch.float32, device=dev)
+            eps, M = 0.1, 10
+            for _ in range(16):                         # pilot: x 0.6 / x 1.3 until the mean accept probability is in [0.2, 0.9]
+                dyn.eps_override = eps
+                acc = float(sample_chain(x, dyn, M, seed=3)[1].mean())
+                if acc < 0.2:
+                    eps *= 0.6
+                elif acc > 0.9:
+                    eps *= 1.3
+                else:
+                    break
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 4
+            e0.record()
+            for r in range(reps):
+                x, p, _ = sample_chain(x, dyn, M, seed=1, proposal0=(r + 1) * M)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            t = e0.elapsed_time(e1) * 1e-3 / (reps * M)
+            fl = algorithmic_flops_per_chain_step(d, H, T, 4 * d)
+            ach = chains * T / t * fl / 1e12
+            out.append({"d": d, "easy": easy, "eta": eta, "eps": eps, "kernel": _ffi.last_kernel(), "us_per_proposal": t * 1e6,
+                        "value": chains * T / t, "achieved": ach, "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        # the T-fused bytes SURVEY 8(d) states (x in, x_next out, p per proposal), over the 8 TB/s roof
+                        "hbm_frac": 4.0 * chains * (2 * d + M) / (t * M) / 1e9 / PEAK_HBM_GBS,
+                        "mean_accept_prob": float(p.mean()), "state_finite": bool(torch.isfinite(x).all())})
+    return {"workload": "config 4: Rough Well, %d chains, Lf=%d, H=%d, fp32 (bf16 state: measured and declined, DESIGN 5)" % (chains, T, H),
+            "unit": "chain\u00b7leapfrog-steps/s", "cases": out}
+
+
 def ess_leg(dev, train_steps=5000, seeds=5):
     """ESS/sec on the notebook's SCG-2D target (BASELINE.json configs[0] shape: 200 chains, Lf=10):
     (i) the HMC(eps=0.15) sampler whose ESS the reference publishes (nb raw 388: 5.63e-3 per MH step);
@@ -416,6 +463,7 @@ def main():
     ap.add_argument("--no-ess", action="store_true", help="skip the SCG-2D ESS/sec leg (N=1) / the dist leg (N>1)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 65 536-chain roofline point (N=1 only)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (VAE engine) extra key (N=1 only)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 (Rough-Well sweep) extra key (N=1 only)")
     ap.add_argument("--no-config5-trained", action="store_true",
                     help="skip the trained-sampler part of the config-5 key (200 sampler updates + ESS vs HMC, ~15 s)")
     ap.add_argument("--ess-train-steps", type=int, default=5000,
@@ -693,6 +741,8 @@ def main():
                               "frac": a2 / PEAK_F32_MFMA_TFLOPS, "launch_us": 1e3 * ms2 / nl2,
                               "mean_accept_prob": p2, "state_finite": fin2})
             out["sweep"] = sweep
+        if world == 1 and not args.no_config4 and not strong and n == CHAINS and not args.force_dist:
+            out["config4"] = config4_leg(dev)
         if world == 1 and not args.no_config5 and not strong and n == CHAINS and not args.force_dist:
             out["config5"] = config5_leg(dev)
             if not args.no_config5_trained:

@@ -93,3 +93,43 @@ def test_hmc_mode_goes_backwards_on_the_gemm_engine():
     assert rel_err(to_np(X), rX) < TRAJ_TOL and rel_err(to_np(V), rV) < TRAJ_TOL and abs_err(to_np(p), rp) < P_TOL
     Xf, Vf, _ = dyn.forward(X, init_v=V)
     assert rel_err(to_np(Xf), x0) < TRAJ_TOL and rel_err(to_np(Vf), v0) < TRAJ_TOL
+
+
+def test_tile_kernel_with_eight_tiles_per_workgroup_and_the_kernel_name_query():
+    """A long schedule (T = 25) makes the one-wave-per-tile kernel's staged tables -- the split bf16 head fragments are 51 KB of
+    them -- too large for two workgroups per CU; from 128 chains per CU on the dispatcher then puts EIGHT tiles into one
+    workgroup.  Same numbers as the oracle on the chains we can afford to check, bit-identical to the four-tile form on the
+    rest (a forced variant 4 -> the four-wave kernel is a different summation order, so the comparison there is the tolerance),
+    and `l2hmc_last_kernel` names what ran."""
+    import torch
+    from l2hmc_amd import _ffi, propose
+    N, T = 32768, 25
+    g = synthetic_case("gauss_diag", 50, H=10, T=T, N=256, seed=77)
+    rng = np.random.RandomState(8)
+    reps = N // 256
+    x = np.tile(g["x"], (reps, 1)) + 0.01 * rng.randn(N, 50).astype(np.float32)
+    v = rng.randn(N, 50).astype(np.float32)
+    dr, u = rng.randint(0, 2, N).astype(np.uint8), rng.rand(N).astype(np.float32)
+    dyn = hip_dynamics(g, 0)
+    Lx, _, px, outs = propose(to_dev(x), dyn, do_mh_step=True, direction=to_dev(dr), v=to_dev(v), u=to_dev(u))
+    name = _ffi.last_kernel()
+    assert name == "traj_tile_kernel<1, 4, 3, 8>", name
+    od = oracle_dynamics(g)
+    k = 192                                                   # oracle on the first chains (they span two workgroups)
+    rLx, _, rpx, _ = O.propose(x[:k], od, v[:k], v[:k], dr[:k], u[:k], both_directions=False)
+    assert rel_err(to_np(Lx)[:k], rLx) < TRAJ_TOL and abs_err(to_np(px)[:k], rpx) < P_TOL
+    check_x_next(to_np(outs[0])[:k], x[:k], rLx, rpx, u[:k], P_TOL)
+    # the same chains through the four-tile workgroups (16 384 chains at a time: below the 8-tile threshold)
+    h = N // 2
+    for lo in (0, h):
+        Lh, _, ph, _ = propose(to_dev(x[lo:lo + h]), dyn, do_mh_step=True, direction=to_dev(dr[lo:lo + h]), v=to_dev(v[lo:lo + h]),
+                               u=to_dev(u[lo:lo + h]))
+        assert _ffi.last_kernel() == "traj_tile_kernel<1, 4, 3, 4>"
+        assert torch.equal(Lh, Lx[lo:lo + h]) and torch.equal(ph, px[lo:lo + h])
+    # and the names of the other families
+    small = synthetic_case("gauss_diag", 50, H=10, T=5, N=64, seed=3)
+    propose(to_dev(small["x"]), hip_dynamics(small, 0), direction=to_dev(dr[:64]), v=to_dev(small["v"]))
+    assert _ffi.last_kernel() == "traj_fast_kernel<1, 1, 4, 3>"
+    two = synthetic_case("gauss_dense", 2, H=10, T=5, N=64, seed=3)
+    propose(to_dev(two["x"]), hip_dynamics(two, 0), direction=to_dev(dr[:64]), v=to_dev(two["v"]))
+    assert _ffi.last_kernel().startswith("traj_small_kernel<2")

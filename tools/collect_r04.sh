@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/r04
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py"
-LEAN="--no-cpu-baseline --no-ess --no-sweep --no-config5"
+LEAN="--no-cpu-baseline --no-ess --no-sweep --no-config5 --no-config4"
 PART=${PART:-bench config4 rest}
 
 summarise() {   # summarise <outfile> <title> <dirs...>: per-dispatch counter means of the traj_* kernels
@@ -44,7 +44,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 cp $OUT/trace/b_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace20 -o b -- $BENCH --steps 20 --warmup 5 $LEAN > /dev/null 2>&1
 cp $OUT/trace20/b_kernel_stats.csv $OUT/kernel_stats_steps20.csv 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sweep -o b -- $BENCH --no-cpu-baseline --no-ess --no-config5 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sweep -o b -- $BENCH --no-cpu-baseline --no-ess --no-config5 --no-config4 > /dev/null 2>&1
 cp $OUT/trace_sweep/b_kernel_stats.csv $OUT/kernel_stats_with_sweep.csv 2>/dev/null
 P25="$BENCH --steps 25 --warmup 25 $LEAN"
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE \
