@@ -416,6 +416,7 @@ def dist_leg(dev, rank, world):
     layers.set_default_device(dev)
     dyn = Dynamics(2, target.get_energy_function(), T=10, eps=0.1, net_factory=layers.stq_network(10), device=dev)
     tr = Trainer(dyn, seed=0)
+    tr.always_reduce = True               # (--force-dist at N = 1: the step's all-reduce still goes over RCCL, with one rank)
     xs = x0.clone()
     for _ in range(20):
         _, _, xs, _ = tr.step(xs)

@@ -650,8 +650,10 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   // many chains (>= 2 tiles per SIMD), 3-4 dimension slices, elementwise target: one wave per tile (traj_tile.hpp);
   // variant 16 forces it
   const bool tile_kind = k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL;
+  // (a rejected chain of this kernel resumes from the copy of its start point parked in x_next: u without x_next -- accept
+  //  decisions with nowhere to put the selected state -- stays on the four-wave kernel)
   const bool tileable = a->packed_nets != nullptr && tile_kind && k.NT >= 3 && k.NT <= 4 && k.n_steps >= 1 &&
-                        k.beta == 1.f && k.temperature == 1.f;
+                        k.beta == 1.f && k.temperature == 1.f && !(has_u && a->x_next == nullptr);
   if (a->variant == 16 && !tileable)
     return fail(L2HMC_ERR_UNSUPPORTED, "variant 16 (one wave per tile) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target and 33 <= d <= 64%s");
   if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 64LL * device_cus()))) {

@@ -27,12 +27,9 @@ long long plan_lds_tile(KArgs& k, int DT);
 #define L2HMC_BFH_TILE 1
 #endif
 __host__ __device__ constexpr int tile_fw_net(int NTp) { return ((L2HMC_BFH_TILE ? 6 : 3) * NTp + 1) * 256; }   // staged tail fragments per net
-// L2HMC_BFL1 = 1: the layer-1 contractions of this kernel as K-packed bf16x3 too (needs L2HMC_BFH_TILE; measured slower: 205.6 vs 195 us at 65 536 chains -- the 20 extra splits per tile-step cost more VALU than the 56 f32 MFMAs they replace); its fragments are split when
-// staged, every layer-1 input slice by the wave that contracts it.
-#ifndef L2HMC_BFL1
-#define L2HMC_BFL1 0
-#endif
-__host__ __device__ constexpr int tile_l1_floats(int DT) { return 4 * DT * 256 * (L2HMC_BFL1 ? 2 : 1); }
+// (The layer-1 contractions as bf16x3 too -- 20 more operand splits per tile-step -- were built and measured in round 4: 205.6 vs
+//  195 us per proposal at 65 536 chains, the splits cost more VALU than the 56 f32 MFMAs they replace; commit d230bd6 has the code.)
+__host__ __device__ constexpr int tile_l1_floats(int DT) { return 4 * DT * 256; }
 
 template <int EK, int DT, int KH, int TPW>
 __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
@@ -78,11 +75,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
         val = val + lds4(smem + A.o_prec + 16 * tg + 4 * (ln >> 4)) * wb;
       }
     }
-#if L2HMC_BFL1
-    bfk_store(smem + A.o_state, grp, ln, bfk_wfrag(val));
-#else
     reinterpret_cast<f4*>(smem + A.o_state)[i] = val;
-#endif
   }
   for (int i = tid; i < 2 * 16 * NTp; i += nthr) {
     const int net = i / (16 * NTp), dim = i % (16 * NTp);
@@ -116,14 +109,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     for (int r = 0; r < 4; ++r) acc = MFMA16(W[r], in[r], acc);
     return acc;
   };
-#if L2HMC_BFL1
-  // layer-1 contraction of dimension slice t of input inp of net: three bf16 MFMAs (dead k-slots multiply zeros)
-  auto l1dot = [&](int net, int inp, int t, f4 in, f4 acc) {
-    return bfk_dot(bfk_load(smem + A.o_state, (net * 2 + inp) * DT + t, lane), bfk_afrag(in), acc);
-  };
-#else
   auto l1frag = [&](int net, int inp, int t) { return lds4(smem + A.o_state + (((net * 2 + inp) * DT + t) * 64 + lane) * 4); };
-#endif
   // layer-1 contraction of dimension slice t: k-step r covers the dimensions 16 t + 4 q + r, live only while 16 t + r < d --
   // the last slice of d = 50 has two live k-steps of four (wave-uniform bound: scalar branches)
   const int klast = A.d - 16 * (DT - 1);
@@ -135,9 +121,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     return acc;
   };
   // (+2.7 % at 65 536 chains for d = 50)
-#if !L2HMC_BFL1
   auto l1dot = [&](int net, int inp, int t, f4 in, f4 acc) { return chain4t(t, l1frag(net, inp, t), in, acc); };
-#endif
   auto mu_of = [&](int t) { return lds4(smem + A.o_mu + 16 * t + 4 * q); };
   auto prec_of = [&](int t) { return lds4(smem + A.o_prec + 16 * t + 4 * q); };
   if (EK == L2HMC_ENERGY_GAUSS_DIAG) {           // constant -W2^T P mu of the fold -> VNet time/bias table
@@ -202,50 +186,88 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     return h;
   };
   // heads of dimension slice t: aS = log2 of the scale factor, T' = step T, EQ' = step e^{eps Q}  (traj_fast.hpp)
-#if L2HMC_BFH_TILE && defined(L2HMC_TILE_PIPE)
-  // the split of the hidden activation rides in the shadow of slice 0's head MFMAs (bfk_heads3); later slices reuse it
-  struct HidT { f4 h; BfkA b; };
-  auto hidden_b = [&](const float* fw, f4 hs_) { HidT r; r.h = hidden(fw, hs_); return r; };
-#elif L2HMC_BFH_TILE
+#if L2HMC_BFH_TILE
   typedef BfkA HidT;                      // the second hidden activation as the split B operand of the heads
   auto hidden_b = [&](const float* fw, f4 hs_) { return bfk_afrag(hidden(fw, hs_)); };
 #else
   typedef f4 HidT;
   auto hidden_b = [&](const float* fw, f4 hs_) { return hidden(fw, hs_); };
 #endif
-  auto heads = [&](const float* fw, const float* fc, int dofs, int t, HidT& h, f4& aS, f4& Tt, f4& EQ) {
-    const f4 cS = lds4(fc + dofs + 16 * t + 4 * q), cQ = lds4(fc + 2 * DPp + 16 * t + 4 * q),
-             bQ = lds4(fc + 3 * DPp + 16 * t + 4 * q);
-    f4 zs = Z, zt = Z, zq = Z;
-#if L2HMC_BFH_TILE && defined(L2HMC_TILE_PIPE)
-    if (t == 0) {
-      h.b = bfk_heads3(bfk_load(fw + 256, 0, lane), bfk_load(fw + 256, 2, lane), bfk_load(fw + 256, 1, lane), h.h, zs, zq, zt);
-    } else {
-      zs = bfk_dot(bfk_load(fw + 256, 3 * t + 0, lane), h.b, zs);
-      zq = bfk_dot(bfk_load(fw + 256, 3 * t + 2, lane), h.b, zq);
-      zt = bfk_dot(bfk_load(fw + 256, 3 * t + 1, lane), h.b, zt);
-    }
-#elif L2HMC_BFH_TILE
-    zs = bfk_dot(bfk_load(fw + 256, 3 * t + 0, lane), h, zs);
-    zq = bfk_dot(bfk_load(fw + 256, 3 * t + 2, lane), h, zq);
-    zt = bfk_dot(bfk_load(fw + 256, 3 * t + 1, lane), h, zt);
+  // The fragments and constants of a slice's heads are REQUESTED one slice ahead (heads_load) and consumed by heads_eval: fetched
+  // where they are used, every slice waited out an LDS round trip in front of its MFMAs -- 16 times per leapfrog step with only
+  // one other wave on the SIMD to cover it.  The request for slice t + 1 is issued right after slice t's MFMAs (whose operand
+  // registers it re-uses), so it flies under slice t's transcendental chain; the compiler barrier keeps it there.
+  struct HeadF {
+#if L2HMC_BFH_TILE
+    BfkW ws, wq, wt;
 #else
-    const f4 Ws = lds4(fw + ((1 + 3 * t + 0) * 64 + lane) * 4), Wt = lds4(fw + ((1 + 3 * t + 1) * 64 + lane) * 4),
-             Wq = lds4(fw + ((1 + 3 * t + 2) * 64 + lane) * 4);
+    f4 ws, wq, wt;
+#endif
+  };
+  auto heads_load = [&](const float* fw, int t) {
+    HeadF f;
+#if L2HMC_BFH_TILE
+    f.ws = bfk_load(fw + 256, 3 * t + 0, lane);
+    f.wq = bfk_load(fw + 256, 3 * t + 2, lane);
+    f.wt = bfk_load(fw + 256, 3 * t + 1, lane);
+#else
+    f.ws = lds4(fw + ((1 + 3 * t + 0) * 64 + lane) * 4);
+    f.wt = lds4(fw + ((1 + 3 * t + 1) * 64 + lane) * 4);
+    f.wq = lds4(fw + ((1 + 3 * t + 2) * 64 + lane) * 4);
+#endif
+    return f;
+  };
+  auto heads_mfma = [&](const HeadF& f, const HidT& h, f4& zs, f4& zq, f4& zt) {
+    zs = Z; zq = Z; zt = Z;
+#if L2HMC_BFH_TILE
+    zs = bfk_dot(f.ws, h, zs);
+    zq = bfk_dot(f.wq, h, zq);
+    zt = bfk_dot(f.wt, h, zt);
+#else
 #pragma unroll
     for (int r = 0; r < KH; ++r) {
-      zs = MFMA16(Ws[r], h[r], zs);
-      zq = MFMA16(Wq[r], h[r], zq);
-      zt = MFMA16(Wt[r], h[r], zt);
+      zs = MFMA16(f.ws[r], h[r], zs);
+      zq = MFMA16(f.wq[r], h[r], zq);
+      zt = MFMA16(f.wt[r], h[r], zt);
     }
     // (all nine head MFMAs before the first transcendental, as in traj_fast.hpp: +1 % at 65 536 chains)
     __builtin_amdgcn_sched_barrier(0);
 #endif
+  };
+  auto heads_chain = [&](f4 cS, f4 cQ, f4 bQ, f4 zs, f4 zq, f4 zt, f4& aS, f4& Tt, f4& EQ) {
     const f4 rS = rcp4(-(ex2_4(zs) * 0.5f + 0.5f));
     aS = rS * cS + cS;
     const f4 rQ = rcp4(-(ex2_4(zq) * 0.5f + 0.5f));
     EQ = ex2_4(rQ * cQ + bQ);
     Tt = zt;
+  };
+  // one net evaluation's heads over the DT slices: body(t, aS, T', EQ') consumes slice t (the half-update and the layer-1
+  // contribution of the next evaluation)
+  auto net_heads = [&](const float* fw, const float* fc, int dofs, const HidT& h, auto&& body) {
+#ifndef L2HMC_TILE_NO_PREFETCH
+    HeadF cur = heads_load(fw, 0);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      f4 zs, zq, zt, aS, Tt, EQ;
+      // (the slice's constants: requested in front of its MFMAs, needed behind them)
+      const f4 cS = lds4(fc + dofs + 16 * t + 4 * q), cQ = lds4(fc + 2 * DPp + 16 * t + 4 * q), bQ = lds4(fc + 3 * DPp + 16 * t + 4 * q);
+      heads_mfma(cur, h, zs, zq, zt);
+      if (t + 1 < DT) cur = heads_load(fw, t + 1);
+      asm volatile("" ::: "memory");
+      heads_chain(cS, cQ, bQ, zs, zq, zt, aS, Tt, EQ);
+      body(t, aS, Tt, EQ);
+    }
+#else
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      f4 zs, zq, zt, aS, Tt, EQ;
+      const f4 cS = lds4(fc + dofs + 16 * t + 4 * q), cQ = lds4(fc + 2 * DPp + 16 * t + 4 * q), bQ = lds4(fc + 3 * DPp + 16 * t + 4 * q);
+      const HeadF cur = heads_load(fw, t);
+      heads_mfma(cur, h, zs, zq, zt);
+      heads_chain(cS, cQ, bQ, zs, zq, zt, aS, Tt, EQ);
+      body(t, aS, Tt, EQ);
+    }
+#endif
   };
 
   f4 x[DT], v[DT], g[DT];
@@ -279,9 +301,9 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       if (rng_d) fwd = fr;
       if (rng_u) u_m = ur;
     }
-    f4 x0[DT], g0[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t) { x0[t] = x[t]; g0[t] = g[t]; }
+    // the start point, for the chains that reject (sampler.py:53-55): parked in x_next (a coalesced store per proposal) rather
+    // than in 2 DT float4 of registers per lane -- the dispatcher only takes this kernel when the caller gave x_next with u
+    if (have_u) store_state<DT, 1>(A.x_next, A, chain, live, 0, q, x);
     const f4 pv0 = pv;
     float red[5];
     red[0] = U_start;
@@ -304,27 +326,22 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
 #pragma unroll
       for (int t = 0; t < DT; ++t) k1[t] = lds4(rec + 32 + 16 * t);
       rec += drec;
-      f4 aS, Tt, EQ;
       // ---- momentum half-update #1 + the XNet layer-1 sums of (v_h, k1 x)  (dynamics.py:118-131 / :162-176)
       HidT h = hidden_b(fwv, pv + tbv);
       f4 pa = Z, pq = Z;
-#pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        heads(fwv, fcv, dofs, t, h, aS, Tt, EQ);
+      net_heads(fwv, fcv, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ) {
         const f4 ES = ex2_4(aS);
         ldv += aS;
         const f4 tr = Tt - EQ * g[t];
         vh[t] = ES * (nf * tr + v[t]) + ff * tr;
         pa = l1dot(0, 0, t, vh[t], pa);
         pq = l1dot(0, 1, t, k1[t] * x[t], pq);
-      }
+      });
       // ---- first masked position update (:131-137 / :176-182) + the layer-1 sum of (1 - k1) y
       asm volatile("" ::: "memory");
       h = hidden_b(fwx, pa + pq + tbx);
       pq = Z;
-#pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        heads(fwx, fcx, dofs, t, h, aS, Tt, EQ);
+      net_heads(fwx, fcx, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ) {
         const f4 up = 1.f - k1[t];
         const f4 aSm = up * aS;
         const f4 ES = ex2_4(aSm);
@@ -332,14 +349,12 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
         const f4 tr = up * (EQ * vh[t] + Tt);
         y[t] = ES * (nf * tr + x[t]) + ff * tr;
         pq = l1dot(0, 1, t, up * y[t], pq);
-      }
+      });
       // ---- second masked position update (:139-145 / :184-190), grad U and VNet's layer-1 sum at the new position
       asm volatile("" ::: "memory");
       h = hidden_b(fwx, pa + pq + tbx);
       pv = Z;
-#pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        heads(fwx, fcx, dofs, t, h, aS, Tt, EQ);
+      net_heads(fwx, fcx, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ) {
         const f4 aSm = k1[t] * aS;
         const f4 ES = ex2_4(aSm);
         ldv += aSm;
@@ -348,18 +363,16 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
         g[t] = grad_t(x[t], t);
         pv = l1dot(1, 0, t, x[t], pv);
         if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = l1dot(1, 1, t, g[t], pv);
-      }
+      });
       // ---- momentum half-update #2  (:147-153 / :192-199)
       asm volatile("" ::: "memory");
       h = hidden_b(fwv, pv + tbv);
-#pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        heads(fwv, fcv, dofs, t, h, aS, Tt, EQ);
+      net_heads(fwv, fcv, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ) {
         const f4 ES = ex2_4(aS);
         ldv += aS;
         const f4 tr = Tt - EQ * g[t];
         v[t] = ES * (nf * tr + vh[t]) + ff * tr;
-      }
+      });
     }
     const bool last = m == A.M - 1;
     if (last) {
@@ -384,10 +397,12 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       if (A.p_out != nullptr && writer) A.p_out[moff + chain] = p;
       if (have_u) {
         const bool acc = live && (p - u_m) >= 0.f;                                      // sampler.py:53-55
+        f4 x0[DT];
+        load_state<DT, 1>(A.x_next, A, chain, live, 0, q, x0);
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
           x[t] = sel4(acc, x[t], x0[t]);
-          g[t] = sel4(acc, g[t], g0[t]);
+          g[t] = sel4(acc, g[t], grad_t(x0[t], t));
         }
         pv = sel4(acc, pv, pv0);
         U_start = acc ? U_end : U_start;

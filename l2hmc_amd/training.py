@@ -201,6 +201,13 @@ class Trainer(object):
     def _world(self):
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
+    # a one-rank process group normally takes the single-process path (no collective); `always_reduce = True` sends it through
+    # the sharded path anyway -- the step's ONE all-reduce over RCCL with a single rank (bench.py --force-dist on a 1-GPU box)
+    always_reduce = False
+
+    def _sharded(self, world):
+        return world > 1 or (self.always_reduce and dist.is_available() and dist.is_initialized())
+
     def set_sharding(self, n_total, chain_offset):
         """Declare this rank's place in the global chain batch: `n_total` chains over all ranks, this rank's row 0 is
         global chain `chain_offset` (e.g. from `sharding.shard_range`).  With a declared layout no step ever exchanges
@@ -329,14 +336,15 @@ class Trainer(object):
         st.x_head, st.n_head = x.data_ptr(), N
         st.u, st.x_next = uu.data_ptr(), x_next.data_ptr()
         st.loss = lt.data_ptr()
-        if world == 1:
+        sharded = self._sharded(world)
+        if not sharded:
             st.theta, st.m, st.v = self.theta.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
             st.lr, st.beta1, st.beta2, st.epsilon = lr, self.beta1, self.beta2, self.epsilon
             st.step, st.train_alpha = self.global_step, int(self.train_alpha)
         else:
             st.terms = self._flat_ext[self.n_grad:].data_ptr()
         _ffi.check(L.l2hmc_train_step(a, st, s))
-        if world > 1:
+        if sharded:
             dist.all_reduce(self._flat_ext[:self.n_grad + 6])           # the ONE collective of a training step
             n_par = self.n_grad if self.train_alpha else self.n_grad - 1
             _ffi.check(L.l2hmc_adam_step_terms(self.theta.data_ptr(), self.flat.data_ptr(), self.m.data_ptr(),
