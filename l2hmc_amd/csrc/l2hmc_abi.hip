@@ -663,7 +663,8 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
       // the schedule records grow with T) leave room for ONE workgroup only: then 8 tiles share it, from the chain count
       // (128 per CU) at which 8-tile workgroups still cover every CU
       const int tpw = (2 * ldst > 160 * 1024 && a->n_chains >= 128LL * device_cus()) ? 8 : 4;
-      note_kernel("traj_tile_kernel<%lld, %lld, %lld, %lld>", k.ekind, k.NT, KH <= 3 ? 3 : 4, tpw);
+      note_kernel(a->d - 16 * (k.NT - 1) <= 2 ? "traj_tile_kernel<%lld, %lld, %lld, %lld, true>" : "traj_tile_kernel<%lld, %lld, %lld, %lld, false>",
+                  k.ekind, k.NT, KH <= 3 ? 3 : 4, tpw);
       if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, tpw, ldst, s);
       return launch_tile_ek<L2HMC_ENERGY_ROUGHWELL>(k, k.NT, KH, tpw, ldst, s);
     }

@@ -257,20 +257,30 @@ __host__ __device__ inline U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
   }
   return c;
 }
-// 4 standard normals from one Philox block (two Box-Muller pairs, 24-bit uniforms), libm logf / sqrtf / sincosf.
-// (The hardware forms -- v_log_f32 / v_sqrt_f32, v_sin_f32 / v_cos_f32 with the angle in revolutions -- were measured:
-//  normals within 1.7e-6 of these, nothing at 4096 chains, +2 % for the issue-bound many-chain kernels.  Not adopted:
-//  the draws feed the training runs of the ESS evidence, and a 2 % gain does not justify re-rolling them.)
+// 4 standard normals from one Philox block (two Box-Muller pairs, 24-bit uniforms) on the hardware transcendentals:
+// v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (which take the angle in REVOLUTIONS: the uniform itself) -- 8
+// transcendentals + 6 VALU per block against ~200 instructions for libm's logf / sqrtf / sincosf with their range reductions.
+// Normals within 2e-6 of the libm forms (tests/test_gpu_parity.py::test_in_kernel_philox_matches_oracle_stream, whose oracle uses
+// numpy's).  Round 3 measured +2 % in the many-chain regime and left it (the draws feed the training runs of the ESS evidence);
+// since round 4 the one-wave-per-tile kernel is bound by VALU issue (profiles/r04_tile_pmc.txt: the per-proposal random-number
+// work was ~20 % of its VALU instructions), which changes the sum: profiles/r04_bf16x3_heads.txt.  -DL2HMC_LIBM_NORMALS restores
+// the libm forms.
 __device__ __forceinline__ f4 philox_normal4(unsigned long long seed, long long gchain, unsigned blk,
                                              unsigned long long prop) {
   const U4 r = philox4x32_10(U4{(unsigned)gchain, blk, (unsigned)prop, (unsigned)(prop >> 32) << 1},
                              (unsigned)seed, (unsigned)(seed >> 32));
   const float k = 5.9604644775390625e-08f;   // 2^-24
   const float u1 = ((r.x >> 8) + 1) * k, u2 = (r.y >> 8) * k, u3 = ((r.z >> 8) + 1) * k, u4 = (r.w >> 8) * k;
+#ifdef L2HMC_LIBM_NORMALS
   const float ra = sqrtf(-2.f * logf(u1)), rb = sqrtf(-2.f * logf(u3));
   float sa, ca, sb, cb;
   sincosf(6.283185307179586f * u2, &sa, &ca);
   sincosf(6.283185307179586f * u4, &sb, &cb);
+#else
+  const float m2ln2 = -1.3862943611198906f;   // -2 ln 2:  -2 ln u = (-2 ln 2) log2 u
+  const float ra = __builtin_amdgcn_sqrtf(m2ln2 * __builtin_amdgcn_logf(u1)), rb = __builtin_amdgcn_sqrtf(m2ln2 * __builtin_amdgcn_logf(u3));
+  const float sa = __builtin_amdgcn_sinf(u2), ca = __builtin_amdgcn_cosf(u2), sb = __builtin_amdgcn_sinf(u4), cb = __builtin_amdgcn_cosf(u4);
+#endif
   return f4{ra * ca, ra * sa, rb * cb, rb * sb};
 }
 // direction bit and accept uniform of (chain, proposal): stream 1

@@ -31,7 +31,7 @@ __host__ __device__ constexpr int tile_fw_net(int NTp) { return ((L2HMC_BFH_TILE
 //  195 us per proposal at 65 536 chains, the splits cost more VALU than the 56 f32 MFMAs they replace; commit d230bd6 has the code.)
 __host__ __device__ constexpr int tile_l1_floats(int DT) { return 4 * DT * 256; }
 
-template <int EK, int DT, int KH, int TPW>
+template <int EK, int DT, int KH, int TPW, bool HALF>
 __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
   static_assert(EK == L2HMC_ENERGY_GAUSS_DIAG || EK == L2HMC_ENERGY_ROUGHWELL, "elementwise targets only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -234,7 +234,29 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
     __builtin_amdgcn_sched_barrier(0);
 #endif
   };
-  auto heads_chain = [&](f4 cS, f4 cQ, f4 bQ, f4 zs, f4 zq, f4 zt, f4& aS, f4& Tt, f4& EQ) {
+  // The last slice of d = 50 holds dimensions 48, 49: components 2, 3 of every lane's float4 (and the lanes q > 0 altogether) are
+  // padding whose state is identically 0 and whose weights are 0 -- z = 0, aS = 0, T = 0 there, and any finite EQ is multiplied
+  // by 0.  Transcendentals are the dearest instructions of the chain (8 cycles each, 24 per slice and evaluation: 46 % of the
+  // VALU time of a tile-step by the counters, profiles/r04_tile_pmc.txt), so that slice evaluates them on its two live components
+  // only and substitutes the padding's values (HALF: a compile-time form -- as a run-time branch both chains stay live and the
+  // kernel spills; the launcher picks it when d - 16 (DT - 1) <= 2).
+  constexpr bool half_last = HALF;
+  auto ex2_live = [&](f4 a, bool two) {           // 2^a; two: components 0, 1 only, the others read 1
+    if (two) return f4{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y), 1.f, 1.f};
+    return ex2_4(a);
+  };
+  auto heads_chain = [&](f4 cS, f4 cQ, f4 bQ, f4 zs, f4 zq, f4 zt, f4& aS, f4& Tt, f4& EQ, bool two) {
+    if (two) {
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 es = {__builtin_amdgcn_exp2f(zs.x), __builtin_amdgcn_exp2f(zs.y)}, eq = {__builtin_amdgcn_exp2f(zq.x), __builtin_amdgcn_exp2f(zq.y)};
+      const f2 ds = -(es * 0.5f + 0.5f), dq = -(eq * 0.5f + 0.5f);
+      const f2 rS = {__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y)}, rQ = {__builtin_amdgcn_rcpf(dq.x), __builtin_amdgcn_rcpf(dq.y)};
+      const f2 a2 = rS * f2{cS.x, cS.y} + f2{cS.x, cS.y}, q2 = rQ * f2{cQ.x, cQ.y} + f2{bQ.x, bQ.y};
+      aS = f4{a2.x, a2.y, 0.f, 0.f};
+      EQ = f4{__builtin_amdgcn_exp2f(q2.x), __builtin_amdgcn_exp2f(q2.y), 0.f, 0.f};
+      Tt = f4{zt.x, zt.y, 0.f, 0.f};
+      return;
+    }
     const f4 rS = rcp4(-(ex2_4(zs) * 0.5f + 0.5f));
     aS = rS * cS + cS;
     const f4 rQ = rcp4(-(ex2_4(zq) * 0.5f + 0.5f));
@@ -254,8 +276,9 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       heads_mfma(cur, h, zs, zq, zt);
       if (t + 1 < DT) cur = heads_load(fw, t + 1);
       asm volatile("" ::: "memory");
-      heads_chain(cS, cQ, bQ, zs, zq, zt, aS, Tt, EQ);
-      body(t, aS, Tt, EQ);
+      const bool two = t == DT - 1 && half_last;
+      heads_chain(cS, cQ, bQ, zs, zq, zt, aS, Tt, EQ, two);
+      body(t, aS, Tt, EQ, two);
     }
 #else
 #pragma unroll
@@ -264,8 +287,9 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       const f4 cS = lds4(fc + dofs + 16 * t + 4 * q), cQ = lds4(fc + 2 * DPp + 16 * t + 4 * q), bQ = lds4(fc + 3 * DPp + 16 * t + 4 * q);
       const HeadF cur = heads_load(fw, t);
       heads_mfma(cur, h, zs, zq, zt);
-      heads_chain(cS, cQ, bQ, zs, zq, zt, aS, Tt, EQ);
-      body(t, aS, Tt, EQ);
+      const bool two = t == DT - 1 && half_last;
+      heads_chain(cS, cQ, bQ, zs, zq, zt, aS, Tt, EQ, two);
+      body(t, aS, Tt, EQ, two);
     }
 #endif
   };
@@ -329,8 +353,8 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       // ---- momentum half-update #1 + the XNet layer-1 sums of (v_h, k1 x)  (dynamics.py:118-131 / :162-176)
       HidT h = hidden_b(fwv, pv + tbv);
       f4 pa = Z, pq = Z;
-      net_heads(fwv, fcv, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ) {
-        const f4 ES = ex2_4(aS);
+      net_heads(fwv, fcv, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ, bool two) {
+        const f4 ES = ex2_live(aS, two);
         ldv += aS;
         const f4 tr = Tt - EQ * g[t];
         vh[t] = ES * (nf * tr + v[t]) + ff * tr;
@@ -341,10 +365,10 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       asm volatile("" ::: "memory");
       h = hidden_b(fwx, pa + pq + tbx);
       pq = Z;
-      net_heads(fwx, fcx, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ) {
+      net_heads(fwx, fcx, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ, bool two) {
         const f4 up = 1.f - k1[t];
         const f4 aSm = up * aS;
-        const f4 ES = ex2_4(aSm);
+        const f4 ES = ex2_live(aSm, two);
         ldv += aSm;
         const f4 tr = up * (EQ * vh[t] + Tt);
         y[t] = ES * (nf * tr + x[t]) + ff * tr;
@@ -354,9 +378,9 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       asm volatile("" ::: "memory");
       h = hidden_b(fwx, pa + pq + tbx);
       pv = Z;
-      net_heads(fwx, fcx, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ) {
+      net_heads(fwx, fcx, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ, bool two) {
         const f4 aSm = k1[t] * aS;
-        const f4 ES = ex2_4(aSm);
+        const f4 ES = ex2_live(aSm, two);
         ldv += aSm;
         const f4 tr = k1[t] * (EQ * vh[t] + Tt);
         x[t] = ES * (nf * tr + y[t]) + ff * tr;
@@ -367,8 +391,8 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       // ---- momentum half-update #2  (:147-153 / :192-199)
       asm volatile("" ::: "memory");
       h = hidden_b(fwv, pv + tbv);
-      net_heads(fwv, fcv, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ) {
-        const f4 ES = ex2_4(aS);
+      net_heads(fwv, fcv, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ, bool two) {
+        const f4 ES = ex2_live(aS, two);
         ldv += aS;
         const f4 tr = Tt - EQ * g[t];
         v[t] = ES * (nf * tr + vh[t]) + ff * tr;

@@ -21,16 +21,20 @@ static int launch_tile(K kern, int TPW, const KArgs& k, long long lds, hipStream
 }
 template <>
 int launch_tile_ek<1>(const KArgs& k, int DT, int KH, int tpw, long long lds, hipStream_t s) {
+  const bool half = k.d - 16 * (DT - 1) <= 2;      // the last slice holds <= 2 dimensions: transcendentals on 2 of 4 components
 #define L2HMC_TILE_GO(DTc, KHc)                                                                       \
-  return tpw == 8 ? launch_tile(traj_tile_kernel<1, DTc, KHc, 8>, 8, k, lds, s) : launch_tile(traj_tile_kernel<1, DTc, KHc, 4>, 4, k, lds, s);
+  return half ? (tpw == 8 ? launch_tile(traj_tile_kernel<1, DTc, KHc, 8, true>, 8, k, lds, s) : launch_tile(traj_tile_kernel<1, DTc, KHc, 4, true>, 4, k, lds, s)) \
+              : (tpw == 8 ? launch_tile(traj_tile_kernel<1, DTc, KHc, 8, false>, 8, k, lds, s) : launch_tile(traj_tile_kernel<1, DTc, KHc, 4, false>, 4, k, lds, s));
   if (DT == 3) { if (KH <= 3) { L2HMC_TILE_GO(3, 3) } else { L2HMC_TILE_GO(3, 4) } }
   if (KH <= 3) { L2HMC_TILE_GO(4, 3) } else { L2HMC_TILE_GO(4, 4) }
 #undef L2HMC_TILE_GO
 }
 template <>
 int launch_tile_ek<4>(const KArgs& k, int DT, int KH, int tpw, long long lds, hipStream_t s) {
+  const bool half = k.d - 16 * (DT - 1) <= 2;
 #define L2HMC_TILE_GO(DTc, KHc)                                                                       \
-  return tpw == 8 ? launch_tile(traj_tile_kernel<4, DTc, KHc, 8>, 8, k, lds, s) : launch_tile(traj_tile_kernel<4, DTc, KHc, 4>, 4, k, lds, s);
+  return half ? (tpw == 8 ? launch_tile(traj_tile_kernel<4, DTc, KHc, 8, true>, 8, k, lds, s) : launch_tile(traj_tile_kernel<4, DTc, KHc, 4, true>, 4, k, lds, s)) \
+              : (tpw == 8 ? launch_tile(traj_tile_kernel<4, DTc, KHc, 8, false>, 8, k, lds, s) : launch_tile(traj_tile_kernel<4, DTc, KHc, 4, false>, 4, k, lds, s));
   if (DT == 3) { if (KH <= 3) { L2HMC_TILE_GO(3, 3) } else { L2HMC_TILE_GO(3, 4) } }
   if (KH <= 3) { L2HMC_TILE_GO(4, 3) } else { L2HMC_TILE_GO(4, 4) }
 #undef L2HMC_TILE_GO

@@ -385,7 +385,9 @@ def test_in_kernel_philox_matches_oracle_stream():
     v, dr, u = philox_draws(99, 200, 50, 4)
     rv, rd, ru = O.philox_draws(99, 200, 50, 4)
     assert np.array_equal(to_np(dr), rd) and np.array_equal(to_np(u), ru)
-    assert np.allclose(to_np(v), rv, rtol=0, atol=2e-6)
+    # (the kernel's Box-Muller runs on the hardware log2 / sqrt / sin / cos since round 4: the normals agree with numpy's to
+    #  a few float32 roundings of their ~O(1) magnitude)
+    assert np.allclose(to_np(v), rv, rtol=0, atol=4e-6)
     v2, d2, u2 = philox_draws(99, 100, 50, 2, proposal0=2, chain_offset=100)
     assert np.array_equal(to_np(v2), to_np(v)[2:, 100:]) and np.array_equal(to_np(u2), to_np(u)[2:, 100:])
 

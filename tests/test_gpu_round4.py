@@ -113,7 +113,7 @@ def test_tile_kernel_with_eight_tiles_per_workgroup_and_the_kernel_name_query():
     dyn = hip_dynamics(g, 0)
     Lx, _, px, outs = propose(to_dev(x), dyn, do_mh_step=True, direction=to_dev(dr), v=to_dev(v), u=to_dev(u))
     name = _ffi.last_kernel()
-    assert name == "traj_tile_kernel<1, 4, 3, 8>", name
+    assert name == "traj_tile_kernel<1, 4, 3, 8, true>", name      # (d = 50: the last slice holds 2 dimensions -> the HALF form)
     od = oracle_dynamics(g)
     k = 192                                                   # oracle on the first chains (they span two workgroups)
     rLx, _, rpx, _ = O.propose(x[:k], od, v[:k], v[:k], dr[:k], u[:k], both_directions=False)
@@ -124,7 +124,7 @@ def test_tile_kernel_with_eight_tiles_per_workgroup_and_the_kernel_name_query():
     for lo in (0, h):
         Lh, _, ph, _ = propose(to_dev(x[lo:lo + h]), dyn, do_mh_step=True, direction=to_dev(dr[lo:lo + h]), v=to_dev(v[lo:lo + h]),
                                u=to_dev(u[lo:lo + h]))
-        assert _ffi.last_kernel() == "traj_tile_kernel<1, 4, 3, 4>"
+        assert _ffi.last_kernel() == "traj_tile_kernel<1, 4, 3, 4, true>"
         assert torch.equal(Lh, Lx[lo:lo + h]) and torch.equal(ph, px[lo:lo + h])
     # and the names of the other families
     small = synthetic_case("gauss_diag", 50, H=10, T=5, N=64, seed=3)
