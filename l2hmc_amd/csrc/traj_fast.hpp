@@ -305,12 +305,8 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
     }
     __syncthreads();
   }
-#ifdef L2HMC_DEPHASE
-  // (experiment: two workgroups share a CU from 8192 chains on and run the same phases at the same time; a head start for one
-  //  of them lets its MFMA-heavy net tails fall into the other's exchange stalls)
-  if (L2HMC_DEPHASE_MODE ? (blockIdx.x & 1) : (blockIdx.x >= (gridDim.x + 1) / 2))
-    for (int i = 0; i < L2HMC_DEPHASE; ++i) __builtin_amdgcn_s_sleep(4);
-#endif
+  // (Measured and not kept, profiles/r04_bf16x3_heads.txt: a head start of 256-1024 cycles for every second workgroup at 8192 chains,
+  //  so that one workgroup's MFMA-heavy tails fall into the other's exchange stalls -- 38.9-39.4 us per proposal against 38.1-39.4.)
   PT_DECL;
   PT_MARK(0);      // prologue
   pv[0] = vnet_l1(x, g);
