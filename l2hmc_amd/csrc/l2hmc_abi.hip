@@ -426,7 +426,8 @@ int device_cus() {
   return cus;
 }
 
-bool pick_geometry(int d, long long N, int variant, int& DT, int& NW) {
+bool pick_geometry(int d, long long N, int variant, int& DT, int& NW, int cus = 0) {
+  if (cus <= 0) cus = device_cus();        // (l2hmc_trajectory queries once and passes it down)
   const int NT = tiles_of(d);
   if (NT <= 1) { DT = 1; NW = 1; return variant == 0 || variant == 1; }
   if (variant == 2 && NT >= 3 && NT <= 4) { DT = 2; NW = 2; return true; }   // two waves x two tiles (fast kernel only)
@@ -435,7 +436,7 @@ bool pick_geometry(int d, long long N, int variant, int& DT, int& NW) {
     // every chain count (1.7e9 vs 1.1e9 steps/s at d = 50..64); with 2 dim-tiles half of its waves idle, so it
     // only pays while there are fewer tiles than wave slots (N < 8192; 2x slower than one wave per tile above).
     // (Two waves x two tiles was tried for 3-4 dim-tiles: never faster than four waves x one tile.)
-    const bool want4 = variant == 4 || (variant == 0 && (NT >= 3 || N < 32LL * device_cus()));
+    const bool want4 = variant == 4 || (variant == 0 && (NT >= 3 || N < 32LL * cus));
     if (want4) { DT = 1; NW = 4; } else { DT = NT <= 2 ? 2 : 4; NW = 1; }
     return variant == 0 || variant == 1 || variant == 4;
   }
@@ -599,6 +600,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   // One chain per lane (traj_lane.hpp): when the chains alone fill the chip -- a wave is 64 of them -- the padding-free
   // VALU form beats the MFMA tiles (variant 32 forces it: tests).  Measured (tools/bench_lane.py): d <= 2 from 65 536
   // chains, d <= 4 from 131 072; wider states lose to the scalar-load latency of their larger nets.
+  const int cus = device_cus();                // once per call: every threshold below is a statement about tiles per CU
   {
     const bool has_u_ = a->u != nullptr || (a->rng_flags & L2HMC_RNG_U);
     const bool lane_able = a->packed_nets != nullptr && a->ais_beta == nullptr && k.beta == 1.f && k.temperature == 1.f &&
@@ -606,7 +608,6 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
                            lane_supported(k.ekind, a->d, a->H, k.ncomp) && (a->d <= 16 || a->x_next != nullptr || !has_u_);
     if (a->variant == 32 && !lane_able)
       return fail(L2HMC_ERR_UNSUPPORTED, "variant 32 (one chain per lane) needs S/T/Q nets and a Gaussian / mixture / Rough-Well target with d <= 4%s");
-    const long long cus = device_cus();
     const bool lane_auto = ((a->d <= 2 && a->n_chains >= 256 * cus) || (a->d <= 4 && a->n_chains >= 512 * cus));
     if (lane_able && (a->variant == 32 || (a->variant == 0 && lane_auto)))
     {
@@ -630,7 +631,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   }
   int DT, NW;
   const int geom_variant = a->variant >= 100 ? a->variant - 100 : ((a->variant == 16 || a->variant == 33) ? 0 : a->variant);   // 100 + v: the round-1 kernel
-  if (!pick_geometry(a->d, a->n_chains, geom_variant, DT, NW))
+  if (!pick_geometry(a->d, a->n_chains, geom_variant, DT, NW, cus))
     return fail(L2HMC_ERR_UNSUPPORTED, "d = %s%lld not supported with variant %lld", "", a->d, a->variant);
   // The instruction-lean kernel (traj_fast.hpp) covers S/T/Q nets on register-resident geometries; the
   // tempered / annealed energies (HMC-mode AIS) and zero-step calls stay on the general kernel.
@@ -656,13 +657,13 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
                         k.beta == 1.f && k.temperature == 1.f && !(has_u && a->x_next == nullptr);
   if (a->variant == 16 && !tileable)
     return fail(L2HMC_ERR_UNSUPPORTED, "variant 16 (one wave per tile) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target and 33 <= d <= 64%s");
-  if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 64LL * device_cus()))) {
+  if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 64LL * cus))) {
     const long long ldst = plan_lds_tile(k, k.NT);
     if (ldst <= 160 * 1024) {
       // tiles (waves) per workgroup: 4, two workgroups per CU -- unless the staged tables (the split head fragments are 51 KB,
       // the schedule records grow with T) leave room for ONE workgroup only: then 8 tiles share it, from the chain count
       // (128 per CU) at which 8-tile workgroups still cover every CU
-      const int tpw = (2 * ldst > 160 * 1024 && a->n_chains >= 128LL * device_cus()) ? 8 : 4;
+      const int tpw = (2 * ldst > 160 * 1024 && a->n_chains >= 128LL * cus) ? 8 : 4;
       note_kernel(a->d - 16 * (k.NT - 1) <= 2 ? "traj_tile_kernel<%lld, %lld, %lld, %lld, true>" : "traj_tile_kernel<%lld, %lld, %lld, %lld, false>",
                   k.ekind, k.NT, KH <= 3 ? 3 : 4, tpw);
       if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_tile_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, k.NT, KH, tpw, ldst, s);
