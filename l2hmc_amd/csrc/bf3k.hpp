@@ -70,6 +70,9 @@ __device__ __forceinline__ bfk_f4 bfk_dot(const BfkW& w, const BfkA& a, bfk_f4 a
 // l-terms are formed in their shadow (three to four VALU per MFMA); scheduling fences keep the compiler from collecting the
 // split in front of the MFMAs again.  Accumulation order h h, (m m + ...), (h l + l h): largest first -- each partial sum is
 // an fp32 rounding of an fp32-representable sum either way.  Returns the split operand for further blocks (bfk_dot).
+// (Used by traj_fast_kernel's -DL2HMC_BFH=1 build only: measured at 4096 / 8192 chains, no gain with one wave per SIMD -- the
+//  split is 143 cycles of VALU issue whatever runs beside it -- and not the default there; profiles/r04_bf16x3_heads.txt.  The
+//  product's user of this header is traj_tile_kernel: bfk_afrag once per net evaluation + bfk_dot per slice.)
 // (A scheduling fence alone does not hold the stages apart: MFMA intrinsics and float arithmetic are pure, and instruction
 //  selection emits them where it likes -- it collected the whole split in front of the first fence.  So every stage boundary is
 //  an EMPTY asm statement that takes the values crossing it as read-write operands: a data dependence no pass can break; the
