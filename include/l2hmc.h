@@ -111,7 +111,9 @@ typedef struct L2hmcTrajectoryArgs {
                              *   chains (d <= 4 from 131 072) ONE CHAIN PER LANE: the nets on packed VALU FMAs with
                              *   wave-uniform weights, no MFMA padding.  32 = force one chain per lane (d <= 4);
                              *   33 = the automatic choice among the MFMA kernels only.  1 / 4 = force
-                             *   that many waves per tile; 16 = one wave per tile, 4 tiles per workgroup; 8 = the
+                             *   that many waves per tile; 16 = one wave per tile, 4 or 8 tiles per workgroup (heads as
+                             *   K-packed bf16x3; it parks the rejected chains' start point in x_next, so x_next must come
+                             *   with u -- the automatic choice falls back to the 4-wave tile otherwise); 8 = the
                              *   LDS-resident-state kernel; 100 + v = geometry v on the general kernel (which also
                              *   serves HMC mode, AIS mode and tempered energies)                                   */
   /* ---- persistent sampler loop (the notebook's per-MH-step sess.run loop, nb raw 288-298) -- */

@@ -656,7 +656,7 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   const bool tileable = a->packed_nets != nullptr && tile_kind && k.NT >= 3 && k.NT <= 4 && k.n_steps >= 1 &&
                         k.beta == 1.f && k.temperature == 1.f && !(has_u && a->x_next == nullptr);
   if (a->variant == 16 && !tileable)
-    return fail(L2HMC_ERR_UNSUPPORTED, "variant 16 (one wave per tile) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target and 33 <= d <= 64%s");
+    return fail(L2HMC_ERR_UNSUPPORTED, "variant 16 (one wave per tile) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target, 33 <= d <= 64 and x_next whenever u is given%s");
   if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 64LL * cus))) {
     const long long ldst = plan_lds_tile(k, k.NT);
     if (ldst <= 160 * 1024) {

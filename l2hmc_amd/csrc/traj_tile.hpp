@@ -241,6 +241,10 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
   // only and substitutes the padding's values (HALF: a compile-time form -- as a run-time branch both chains stay live and the
   // kernel spills; the launcher picks it when d - 16 (DT - 1) <= 2).
   constexpr bool half_last = HALF;
+  typedef float f2t __attribute__((ext_vector_type(2)));
+  auto lo2 = [](f4 a) { return f2t{a.x, a.y}; };
+  auto wd2 = [](f2t a) { return f4{a.x, a.y, 0.f, 0.f}; };
+  auto add_lo = [](f4 a, f2t b) { return f4{a.x + b.x, a.y + b.y, a.z, a.w}; };
   auto ex2_live = [&](f4 a, bool two) {           // 2^a; two: components 0, 1 only, the others read 1
     if (two) return f4{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y), 1.f, 1.f};
     return ex2_4(a);
@@ -355,6 +359,14 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       f4 pa = Z, pq = Z;
       net_heads(fwv, fcv, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ, bool two) {
         const f4 ES = ex2_live(aS, two);
+        if (two) {                       // the padded slice: the arithmetic on its two live components as well (the others stay 0)
+          ldv = add_lo(ldv, lo2(aS));
+          const f2t tr = lo2(Tt) - lo2(EQ) * lo2(g[t]);
+          vh[t] = wd2(lo2(ES) * (nf * tr + lo2(v[t])) + ff * tr);
+          pa = l1dot(0, 0, t, vh[t], pa);
+          pq = l1dot(0, 1, t, wd2(lo2(k1[t]) * lo2(x[t])), pq);
+          return;
+        }
         ldv += aS;
         const f4 tr = Tt - EQ * g[t];
         vh[t] = ES * (nf * tr + v[t]) + ff * tr;
@@ -366,6 +378,16 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       h = hidden_b(fwx, pa + pq + tbx);
       pq = Z;
       net_heads(fwx, fcx, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ, bool two) {
+        if (two) {
+          const f2t up = 1.f - lo2(k1[t]), aSm = up * lo2(aS);
+          const f2t ES = {__builtin_amdgcn_exp2f(aSm.x), __builtin_amdgcn_exp2f(aSm.y)};
+          ldv = add_lo(ldv, aSm);
+          const f2t tr = up * (lo2(EQ) * lo2(vh[t]) + lo2(Tt));
+          const f2t yy = ES * (nf * tr + lo2(x[t])) + ff * tr;
+          y[t] = wd2(yy);
+          pq = l1dot(0, 1, t, wd2(up * yy), pq);
+          return;
+        }
         const f4 up = 1.f - k1[t];
         const f4 aSm = up * aS;
         const f4 ES = ex2_live(aSm, two);
@@ -379,11 +401,19 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       h = hidden_b(fwx, pa + pq + tbx);
       pv = Z;
       net_heads(fwx, fcx, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ, bool two) {
-        const f4 aSm = k1[t] * aS;
-        const f4 ES = ex2_live(aSm, two);
-        ldv += aSm;
-        const f4 tr = k1[t] * (EQ * vh[t] + Tt);
-        x[t] = ES * (nf * tr + y[t]) + ff * tr;
+        if (two) {
+          const f2t kk = lo2(k1[t]), aSm = kk * lo2(aS);
+          const f2t ES = {__builtin_amdgcn_exp2f(aSm.x), __builtin_amdgcn_exp2f(aSm.y)};
+          ldv = add_lo(ldv, aSm);
+          const f2t tr = kk * (lo2(EQ) * lo2(vh[t]) + lo2(Tt));
+          x[t] = wd2(ES * (nf * tr + lo2(y[t])) + ff * tr);
+        } else {
+          const f4 aSm = k1[t] * aS;
+          const f4 ES = ex2_live(aSm, two);
+          ldv += aSm;
+          const f4 tr = k1[t] * (EQ * vh[t] + Tt);
+          x[t] = ES * (nf * tr + y[t]) + ff * tr;
+        }
         g[t] = grad_t(x[t], t);
         pv = l1dot(1, 0, t, x[t], pv);
         if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = l1dot(1, 1, t, g[t], pv);
@@ -393,6 +423,12 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
       h = hidden_b(fwv, pv + tbv);
       net_heads(fwv, fcv, dofs, h, [&](int t, f4 aS, f4 Tt, f4 EQ, bool two) {
         const f4 ES = ex2_live(aS, two);
+        if (two) {
+          ldv = add_lo(ldv, lo2(aS));
+          const f2t tr = lo2(Tt) - lo2(EQ) * lo2(g[t]);
+          v[t] = wd2(lo2(ES) * (nf * tr + lo2(vh[t])) + ff * tr);
+          return;
+        }
         ldv += aS;
         const f4 tr = Tt - EQ * g[t];
         v[t] = ES * (nf * tr + vh[t]) + ff * tr;
