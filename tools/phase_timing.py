@@ -59,8 +59,8 @@ def main():
     print("cycles (s_memtime ticks) per phase, chains=%d variant=%d; per leapfrog step except prologue" % (chains, variant))
     for i, name in enumerate(PHASES):
         div = 1 if i == 0 else bench.T
-        print("  %-16s " % name + "  ".join("w%d %7.0f" % (w, d[w, i] / div) for w in range(4 if variant == 4 else 1)))
-    print("  %-16s " % "sum/step" + "  ".join("w%d %7.0f" % (w, d[w, 1:].sum() / bench.T) for w in range(4 if variant == 4 else 1)))
+        print("  %-16s " % name + "  ".join("w%d %7.0f" % (w, d[w, i] / div) for w in range({4: 4, 2: 2}.get(variant, 1))))
+    print("  %-16s " % "sum/step" + "  ".join("w%d %7.0f" % (w, d[w, 1:].sum() / bench.T) for w in range({4: 4, 2: 2}.get(variant, 1))))
 
 
 if __name__ == "__main__":
