@@ -133,3 +133,82 @@ def test_tile_kernel_with_eight_tiles_per_workgroup_and_the_kernel_name_query():
     two = synthetic_case("gauss_dense", 2, H=10, T=5, N=64, seed=3)
     propose(to_dev(two["x"]), hip_dynamics(two, 0), direction=to_dev(dr[:64]), v=to_dev(two["v"]))
     assert _ffi.last_kernel().startswith("traj_small_kernel<2")
+
+
+@pytest.mark.parametrize("case", ["train_scg2d", "train_icg50", "train_mog2d"])
+def test_fused_optimiser_step_equals_the_sequence_of_library_calls(case):
+    """`Trainer.step` = `l2hmc_train_step` (three launches: the slot reduction overwrites the gradient and carries the loss
+    terms, the Metropolis select and Adam) against the same step spelt as round 3 did -- Philox fill, [x; z] staged side
+    by side, `l2hmc_train_propose_grad` into a zeroed buffer, `l2hmc_loss_terms`, `l2hmc_adam_step`, `l2hmc_mh_select`:
+    parameters, Adam moments, selected states, accept probabilities and the loss are bit-identical, over three steps, on the
+    d <= 4 kernel, the register-resident one and the mixture target."""
+    import ctypes as C
+    import torch
+    from l2hmc_amd import _ffi
+    from l2hmc_amd.training import Trainer
+    g = load(case)
+
+    def fresh():
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        return Trainer(dyn, seed=3)
+    ta, tb = fresh(), fresh()
+    L, dev = _ffi.lib(), ta.dyn.device
+    s = _ffi.current_stream(dev)
+    N, d = g["x"].shape
+    xa = xb = to_dev(g["x"])
+    for it in range(3):
+        loss_a, p_a, xa, lr = ta.step(xa)
+        # ---- the unfused sequence on the second trainer --------------------------------------------------------------
+        W = torch.empty((4, N, d), dtype=torch.float32, device=dev)
+        dirs = torch.empty((3, N), dtype=torch.uint8, device=dev)
+        us = torch.empty((3, N), dtype=torch.float32, device=dev)
+        _ffi.check(L.l2hmc_rng_fill(tb.seed, 3 * tb.global_step, 0, N, d, 3, W[1].data_ptr(), dirs.data_ptr(), us.data_ptr(), s))
+        W[0].copy_(xb)
+        tb.flat.zero_()
+        Lx, p12, v1 = tb._propose_grad(W[0:2].view(2 * N, d), W[2:4].view(2 * N, d), dirs[1:3].view(2 * N), N)
+        lt = torch.empty(3, dtype=torch.float64, device=dev)
+        _ffi.check(L.l2hmc_loss_terms(v1.data_ptr(), v1.numel(), tb.scale, 1.0 / N, lt.data_ptr(), s))
+        lr_b = tb.lr_at(tb.global_step)
+        tb.global_step += 1
+        n_par = tb.n_grad if tb.train_alpha else tb.n_grad - 1
+        _ffi.check(L.l2hmc_adam_step(tb.theta.data_ptr(), tb.flat.data_ptr(), tb.m.data_ptr(), tb.v.data_ptr(), n_par, lr_b,
+                                     tb.beta1, tb.beta2, tb.epsilon, tb.global_step, int(tb.train_alpha), s))
+        tb.dyn._packed_key = None
+        x_next = torch.empty_like(xb)
+        _ffi.check(L.l2hmc_mh_select(xb.data_ptr(), Lx.data_ptr(), p12.data_ptr(), us[0].data_ptr(), N, d, x_next.data_ptr(), s))
+        xb = x_next
+        assert lr == lr_b
+        assert torch.equal(ta.flat, tb.flat), (case, it)
+        assert torch.equal(ta.theta, tb.theta) and torch.equal(ta.m, tb.m) and torch.equal(ta.v, tb.v), (case, it)
+        assert torch.equal(xa, xb) and torch.equal(p_a, p12[:N]) and float(loss_a) == float(lt[2]), (case, it)
+
+
+def test_adam_after_the_all_reduce_forms_the_global_loss():
+    """`l2hmc_adam_step_terms`: the same update as `l2hmc_adam_step`, and the loss of the global batch from the (hi, lo) float
+    pairs a sharded step all-reduces behind its gradient."""
+    import torch
+    from l2hmc_amd import _ffi
+    L = _ffi.lib()
+    dev = torch.device("cuda", 0)
+    s = _ffi.current_stream(dev)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    n = 541
+    th = torch.randn(n, device=dev, generator=gen)
+    gr = torch.randn(n, device=dev, generator=gen)
+    m = 0.1 * torch.randn(n, device=dev, generator=gen)
+    v = torch.rand(n, device=dev, generator=gen)
+    th2, m2, v2 = th.clone(), m.clone(), v.clone()
+    A, B, cnt, scale = 123456.789012345, 98.7654321, 400.0, 0.1
+    t6 = torch.tensor([np.float32(A), A - float(np.float32(A)), np.float32(B), B - float(np.float32(B)), cnt, 0.0],
+                      dtype=torch.float32, device=dev)
+    out = torch.zeros(3, dtype=torch.float64, device=dev)
+    _ffi.check(L.l2hmc_adam_step(th.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 7, 1, s))
+    _ffi.check(L.l2hmc_adam_step_terms(th2.data_ptr(), gr.data_ptr(), m2.data_ptr(), v2.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 7, 1,
+                                       t6.data_ptr(), scale, out.data_ptr(), s))
+    assert torch.equal(th, th2) and torch.equal(m, m2) and torch.equal(v, v2)
+    o = out.cpu().numpy()
+    assert abs(o[0] - A) < 1e-9 * A and abs(o[1] - B) < 1e-9 * B
+    assert abs(o[2] - (scale * A - B / scale) / cnt) < 1e-9 * abs(o[2])
