@@ -379,7 +379,8 @@ typedef struct L2hmcTrainStep {
   const float* u;           /* (n_head) uniforms and ...                                                           */
   float* x_next;            /* ... (n_head, d) selected states; both or neither                                     */
   float* terms;             /* 6 floats or NULL                                                                     */
-  double* loss;             /* 3 doubles {sum 1/v1, sum v1, inv_n (scale sum 1/v1 - sum v1 / scale)} or NULL        */
+  double* loss;             /* 3 doubles {sum 1/v1, sum v1, inv_n (scale sum 1/v1 - sum v1 / scale)} or NULL; inv_n =
+                             * 1 / k in double when args.inv_n is the float rounding of 1 / k (= l2hmc_loss_terms)   */
   float* theta;             /* flat parameters [XNet | VNet | alpha] or NULL (no optimiser in this call)            */
   float* m;
   float* v;

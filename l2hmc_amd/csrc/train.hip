@@ -1155,7 +1155,11 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
     // (the loss block is always launched -- it idles without outputs -- so that the select blocks sit at fixed indices)
     const long long mh_blocks = st->u != nullptr ? (st->n_head * a->d + 255) / 256 : 0;
     f.x0 = st->x_head; f.Lx = a->Lx; f.p = a->p; f.u = st->u; f.x_next = st->x_next; f.d = a->d;
-    f.v1 = a->v1; f.n_v1 = a->n_chains; f.scale = a->scale; f.inv_n = (double)a->inv_n; f.n_head = st->n_head;
+    f.v1 = a->v1; f.n_v1 = a->n_chains; f.scale = a->scale; f.n_head = st->n_head;
+    // the args carry inv_n as the float the kernel differentiates with; the reported loss is a double (l2hmc_loss_terms takes a
+    // double 1 / chains): when the float is the rounding of 1 / integer -- it always is from the host layer -- use that integer
+    const double inv_f = (double)a->inv_n, cnt = nearbyint(1.0 / inv_f);
+    f.inv_n = (cnt >= 1.0 && (float)(1.0 / cnt) == a->inv_n) ? 1.0 / cnt : inv_f;
     f.terms = st->terms; f.loss = st->loss;
     if (st->theta != nullptr) {
       // lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t)   (TF1 Adam, as l2hmc_adam_step)

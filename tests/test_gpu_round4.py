@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from oracle import l2hmc_oracle as O
-from tests.helpers import (abs_err, check_x_next, hip_dynamics, oracle_dynamics, rel_err, synthetic_case, to_dev, to_np)
+from tests.helpers import (abs_err, check_x_next, hip_dynamics, load, oracle_dynamics, rel_err, synthetic_case, to_dev, to_np)
 from tests.test_gpu_round3 import _banana_np, _banana_torch
 
 pytestmark = pytest.mark.gpu
@@ -142,7 +142,6 @@ def test_fused_optimiser_step_equals_the_sequence_of_library_calls(case):
     by side, `l2hmc_train_propose_grad` into a zeroed buffer, `l2hmc_loss_terms`, `l2hmc_adam_step`, `l2hmc_mh_select`:
     parameters, Adam moments, selected states, accept probabilities and the loss are bit-identical, over three steps, on the
     d <= 4 kernel, the register-resident one and the mixture target."""
-    import ctypes as C
     import torch
     from l2hmc_amd import _ffi
     from l2hmc_amd.training import Trainer
@@ -201,7 +200,7 @@ def test_adam_after_the_all_reduce_forms_the_global_loss():
     m = 0.1 * torch.randn(n, device=dev, generator=gen)
     v = torch.rand(n, device=dev, generator=gen)
     th2, m2, v2 = th.clone(), m.clone(), v.clone()
-    A, B, cnt, scale = 123456.789012345, 98.7654321, 400.0, 0.1
+    A, B, cnt, scale = 123456.789012345, 98.7654321, 400.0, float(np.float32(0.1))     # the entry point takes a float scale
     t6 = torch.tensor([np.float32(A), A - float(np.float32(A)), np.float32(B), B - float(np.float32(B)), cnt, 0.0],
                       dtype=torch.float32, device=dev)
     out = torch.zeros(3, dtype=torch.float64, device=dev)
