@@ -214,7 +214,12 @@ __global__ void k_f2d(const float* a, double* b, long long n) {
 
 // Workspace slices of one 3-layer MLP evaluation: transposed weights (forward products), activations a1 / a2
 // and their sigmoids s1 / s2 (= softplus', for the input gradient)
-struct Mlp3Ws { float *w1t, *w2t, *w3t, *a1, *s1, *a2, *s2; };
+struct Mlp3Ws {
+  float *w1t, *w2t, *w3t, *a1, *s1, *a2, *s2;
+  // pre-split bf16 planes (gemm_pl_kernel), NULL = the fp32 path: the weights of the two decoder-sized layers in both
+  // orientations, and the activations that only ever feed the next product (a1, a2, the BCE gradient, d a2)
+  unsigned short *pw2t, *pw3t, *pw2, *pw3, *pa1, *pa2, *plg, *pda2;
+};
 
 // L2hmcSplitArgs.gemm_mode / L2hmcTrainSplitArgs.gemm_mode of the call being served on this thread (set at the top of every
 // entry point, so no state survives a call): 1 = the decoder-sized products run as bf16x3 (gemm_f32.hpp)
@@ -262,6 +267,38 @@ inline int bce_tiles_max(int n_pix) { return (n_pix + 63) / 64; }
 // and rowsum (N x 2 tiles) are scratch.  The transposed decoder weights must already be in ws (mlp3_transposes).
 void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, int ldz, long long N, int d,
                 const Mlp3Ws& ws, float* lg, float* rowsum, float* U, double* Ud, float* grad, int ldg, float beta = 1.f) {
+  if (ws.pa1 != nullptr) {
+    // ---- pre-split form (gemm_mode 1 at decoder sizes): every activation that only feeds the next product is written as bf16
+    //      planes by its producer's epilogue; the four decoder-sized products read planes on both sides
+    const long long n1 = N * dec.n_h1, n2 = N * dec.n_h2, no = N * dec.n_out;
+    GemmArgs g = gemm_args(z, ldz, ws.w1t, dec.n_in, nullptr, dec.n_h1, N, dec.n_h1, dec.n_in);
+    g.bias = dec.b1; g.C2 = ws.s1; g.ldc2 = dec.n_h1; g.Cp = ws.pa1; g.cp_plane = n1; g.ldcp = dec.n_h1;
+    launch_gemm<EPI_BIAS_SOFTPLUS>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_AUTO);                 // a1 (planes), s1
+    g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_h1);
+    g.Ap = ws.pa1; g.ap_plane = n1; g.ldap = dec.n_h1; g.Bp = ws.pw2t; g.bp_plane = (long long)dec.n_h2 * dec.n_h1; g.ldbp = dec.n_h1;
+    g.bias = dec.b2; g.C2 = ws.s2; g.ldc2 = dec.n_h2; g.Cp = ws.pa2; g.cp_plane = n2; g.ldcp = dec.n_h2;
+    launch_gemm_planes<EPI_BIAS_SOFTPLUS>(g, s);                                                     // a2 (planes), s2
+    g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_out, N, dec.n_out, dec.n_h2);
+    g.Ap = ws.pa2; g.ap_plane = n2; g.ldap = dec.n_h2; g.Bp = ws.pw3t; g.bp_plane = (long long)dec.n_out * dec.n_h2; g.ldbp = dec.n_h2;
+    g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = beta;
+    g.Cp = ws.plg; g.cp_plane = no; g.ldcp = dec.n_out;
+    launch_gemm_planes<EPI_BCE>(g, s);                                                               // beta (sigmoid(logit) - aux) (planes)
+    if (U != nullptr || Ud != nullptr)
+      hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, bce_partials(N, dec.n_out), z, ldz, d, U, Ud, N);
+    if (grad == nullptr) return;
+    g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_out);
+    g.Ap = ws.plg; g.ap_plane = no; g.ldap = dec.n_out; g.Bp = ws.pw3; g.bp_plane = (long long)dec.n_h2 * dec.n_out; g.ldbp = dec.n_out;
+    g.E = ws.s2; g.lde = dec.n_h2; g.Cp = ws.pda2; g.cp_plane = n2; g.ldcp = dec.n_h2;
+    launch_gemm_planes<EPI_MUL>(g, s);                                                               // d a2 (planes)
+    g = gemm_args(nullptr, 0, nullptr, 0, ws.a1, dec.n_h1, N, dec.n_h1, dec.n_h2);
+    g.Ap = ws.pda2; g.ap_plane = n2; g.ldap = dec.n_h2; g.Bp = ws.pw2; g.bp_plane = (long long)dec.n_h1 * dec.n_h2; g.ldbp = dec.n_h2;
+    g.E = ws.s1; g.lde = dec.n_h1;
+    launch_gemm_planes<EPI_MUL>(g, s);                                                               // d a1 (fp32: the K = 1024, N = d product reads it)
+    g = gemm_args(ws.a1, dec.n_h1, dec.W1, dec.n_h1, grad, ldg, N, d, dec.n_h1);
+    g.E = z; g.lde = ldz;
+    launch_gemm<EPI_ADD>(g, s, d <= 64 ? SHAPE_SKINNY : SHAPE_MID);
+    return;
+  }
   mlp3_hidden(s, dec, z, ldz, N, ws);
   GemmArgs g = gemm_args(ws.a2, dec.n_h2, ws.w3t, dec.n_h2, lg, dec.n_out, N, dec.n_out, dec.n_h2);
   g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = beta;
@@ -288,6 +325,8 @@ struct SplitPlan {
   long long dw1t, dw2t, dw3t, a1, s1, a2, s2;                    // decoder
   long long ew1t, ew2t, ew3t, e1, e2;                            // image branch
   long long nx12t, nx4t, nxht, nv12t, nv4t, nvht;                // S/T/Q nets: [W1; W2]^T, W4^T, [Ws | Wt | Wq]^T
+  bool planes;                                                   // the decoder products can take the pre-split form at this size
+  long long pw2t, pw3t, pw2, pw3, pa1, pa2, plg, pda2;           // bf16 planes (3 x elements x 2 bytes each), in floats
 };
 
 SplitPlan plan_split(long long N, int d, int H, int T, const L2hmcMlp3* enc, const L2hmcMlp3* dec) {
@@ -312,6 +351,14 @@ SplitPlan plan_split(long long N, int d, int H, int T, const L2hmcMlp3* enc, con
   const long long n12 = (long long)ceil16(H) * ceil16(2 * d), n4 = (long long)ceil16(H) * ceil16(H), nh = (long long)ceil16(3 * d) * ceil16(H);
   p.nx12t = take(n12); p.nx4t = take(n4); p.nxht = take(nh);
   p.nv12t = take(n12); p.nv4t = take(n4); p.nvht = take(nh);
+  // bf16 planes of the decoder's two big layers and of the activations between them (gemm_pl_kernel): 3 planes x 2 bytes
+  p.planes = dec != nullptr && gemm_planes_ok(N, dec->n_h2, dec->n_h1) && gemm_planes_ok(N, dec->n_out, dec->n_h2) &&
+             gemm_planes_ok(N, dec->n_h2, dec->n_out) && gemm_planes_ok(N, dec->n_h1, dec->n_h2) && dec->n_h1 % 4 == 0;
+  auto takep = [&](long long elems) { return take(p.planes ? (elems * 3 + 1) / 2 : 0); };
+  const long long e21 = dec ? (long long)dec->n_h2 * dec->n_h1 : 0, eo2 = dec ? (long long)dec->n_out * dec->n_h2 : 0;
+  p.pw2t = takep(e21); p.pw3t = takep(eo2); p.pw2 = takep(e21); p.pw3 = takep(eo2);
+  p.pa1 = takep(dec ? N * dec->n_h1 : 0); p.pa2 = takep(dec ? N * dec->n_h2 : 0);
+  p.plg = takep(dec ? N * dec->n_out : 0); p.pda2 = takep(dec ? N * dec->n_h2 : 0);
   p.total = o;
   return p;
 }
@@ -407,7 +454,13 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   float* w = a->workspace;
   static const L2hmcMlp3 no_dec = {};
   const L2hmcMlp3& dec = (builtin || user) ? no_dec : *a->decoder;
-  const Mlp3Ws dws = {w + p.dw1t, w + p.dw2t, w + p.dw3t, w + p.a1, w + p.s1, w + p.a2, w + p.s2};
+  Mlp3Ws dws = {w + p.dw1t, w + p.dw2t, w + p.dw3t, w + p.a1, w + p.s1, w + p.a2, w + p.s2};
+  const bool use_planes = p.planes && a->gemm_mode == 1 && !builtin && !user;
+  if (use_planes) {
+    auto us = [&](long long off) { return reinterpret_cast<unsigned short*>(w + off); };
+    dws.pw2t = us(p.pw2t); dws.pw3t = us(p.pw3t); dws.pw2 = us(p.pw2); dws.pw3 = us(p.pw3);
+    dws.pa1 = us(p.pa1); dws.pa2 = us(p.pa2); dws.plg = us(p.plg); dws.pda2 = us(p.pda2);
+  }
   // [x | grad U] and [v_h | masked x] live side by side (row stride L = 2 d): they are the first-layer inputs
   const int L = 2 * d;
   float *xc = w + p.abv, *g = w + p.abv + d, *vh = w + p.abx, *xin = w + p.abx + d, *vc = w + p.vc, *y = w + p.y;
@@ -422,7 +475,15 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   (void)hipMemcpy2DAsync(xc, sizeof(float) * L, a->x, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
   (void)hipMemcpyAsync(vc, a->v, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
   const bool have_w = (a->reuse & 1) != 0, have_auxh = (a->reuse & 2) != 0;    // still in the workspace (caller vouches)
-  if (!builtin && !user && !have_w) mlp3_transposes(s, dec, dws);
+  if (!builtin && !user && !have_w) {
+    mlp3_transposes(s, dec, dws);
+    if (use_planes) {       // the two decoder-sized layers, both orientations, as bf16 planes: once per parameter update
+      to_planes(s, dws.w2t, dec.n_h1, dec.n_h2, dec.n_h1, dws.pw2t);
+      to_planes(s, dws.w3t, dec.n_h2, dec.n_out, dec.n_h2, dws.pw3t);
+      to_planes(s, dec.W2, dec.n_h2, dec.n_h1, dec.n_h2, dws.pw2);
+      to_planes(s, dec.W3, dec.n_out, dec.n_h2, dec.n_out, dws.pw3);
+    }
+  }
   if (a->aux_encoder && !hmc) {      // the image branch is step-invariant: once per trajectory, not 4T times
     const L2hmcMlp3& enc = *a->aux_encoder;
     const Mlp3Ws ews = {w + p.ew1t, w + p.ew2t, w + p.ew3t, w + p.e1, nullptr, w + p.e2, nullptr};
