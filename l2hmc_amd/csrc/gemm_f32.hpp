@@ -57,9 +57,10 @@ struct GemmArgs {
   const float* tb;               // (T, N) time/bias table of this net
   const unsigned char* dir; int dir_all, it, T;
   int bf3;                       // 1: the product runs on the bf16 MFMA with 3-way split operands (see gemm_nt_kernel)
-  // pre-split operands (gemm_pl_kernel): three bf16 planes h | m | l of an fp32 matrix, plane p at P + p * plane, row stride ld
-  // (elements; K % 8 == 0 and 16-byte aligned rows).  Cp: the epilogue ALSO (C != NULL) or ONLY (C == NULL) writes its first
-  // output as planes -- every element is split once by its producer instead of once per consumer tile.
+  // pre-split operands (gemm_xl.hpp): three bf16 planes h | m | l of an fp32 matrix, plane p at P + p * plane, row stride ld
+  // (elements).  Contract: ld >= ceil32(K) with the columns K .. ceil32(K) - 1 ZERO; Bp holds ceil128(N) rows, the rows beyond N
+  // zero (the kernel reads whole tiles without predicates).  Cp: the epilogue ALSO (C != NULL) or ONLY (C == NULL) writes its
+  // first output as planes -- every element is split once by its producer instead of once per consumer tile.
   const unsigned short* Ap; long long ap_plane; int ldap;
   const unsigned short* Bp; long long bp_plane; int ldbp;
   unsigned short* Cp; long long cp_plane; int ldcp;
@@ -461,144 +462,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
   }
 
   gemm_epilogue<EPI, WMB, WNB, WAVES_N>(g, acc, m0, n0, wm, wn, w, c, q);
-}
-
-// ---- bf16x3 on PRE-SPLIT operands (round 4) ---------------------------------------------------------------------------
-// gemm_nt_kernel<BF3 = 1> splits every operand fragment in the consuming wave: an activation element is split once per column
-// tile that reads it (8 times for a 1024-wide layer), a weight element once per row tile (64 times at 8192 chains), and the
-// main loop carries ~4.9 VALU instructions per MFMA (profiles/r04_gemm_planes.txt) -- the matrix pipe waits for the splitter.
-// Here both operands ARRIVE as three bf16 planes (h | m | l): weights are converted once per parameter update
-// (to_planes_kernel), activations are written as planes by the epilogue of the product that makes them (GemmArgs.Cp).  The
-// main loop is loads and MFMAs only: per k-tile of 32 a wave reads 8 fragments x 3 planes (one ds_read_b128 each: 8 bf16 = the
-// K = 32 MFMA operand of a lane) and issues the same six products per 16 x 16 block in the same order as the BF3 = 1 form.
-// LDS: [plane][row][32 + 8 pad] bf16 per operand = 61 KB for a 128 x 128 tile, SINGLE-buffered so that two workgroups share a
-// CU (the next k-tile waits in registers under the MFMAs; the store phase between two barriers is covered by the CU's other
-// workgroup).  K % 8 == 0; rows beyond M / N and k beyond K read as zeros.
-template <int EPI, int WMB, int WNB, int WAVES_N = 2>
-__global__ __launch_bounds__(256, 2) void gemm_pl_kernel(const GemmArgs g) {
-  constexpr int WAVES_M = 4 / WAVES_N;
-  constexpr int TM = 16 * WMB * WAVES_M, TN = 16 * WNB * WAVES_N;
-  constexpr int RS = 40;                                           // bf16 per LDS row: 32 + 8 pad (80 bytes: 16 consecutive rows
-                                                                   // start in 16 distinct bank quads, as GP = 20 floats)
-  __shared__ __attribute__((aligned(16))) unsigned short sA[3 * TM * RS];
-  __shared__ __attribute__((aligned(16))) unsigned short sB[3 * TN * RS];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int c = lane & 15, q = lane >> 4;
-  const int wm = (w / WAVES_N) * 16 * WMB, wn = (w % WAVES_N) * 16 * WNB;
-  int bx = blockIdx.x, by = blockIdx.y;
-  if ((gridDim.y & 7) == 0 && gridDim.y >= 16) {                   // XCD-aware tile order (gemm_nt_kernel)
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, k = lin >> 3;
-    by = (int)((k / gridDim.x) * 8 + xcd);
-    bx = (int)(k % gridDim.x);
-  }
-  const long long m0 = (long long)by * TM;
-  const int n0 = bx * TN;
-  // staging: 16-byte chunks (8 bf16); chunk id = (plane, row, quarter of the k-tile), thread t takes ids t, t + 256, ...
-  constexpr int CA = 12 * TM, CB = 12 * TN, NA = (CA + 255) / 256, NB = (CB + 255) / 256;
-  u4v ra[NA], rb[NB];
-  const unsigned short* pa[NA];
-  const unsigned short* pb[NB];
-  int la[NA], lb[NB];                                              // LDS offsets (bf16 units), -1: no chunk
-  bool oka[NA], okb[NB];
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int id = tid + 256 * i, pl = id / (4 * TM), rem = id % (4 * TM), row = rem >> 2, ch = rem & 3;
-    la[i] = id < CA ? (pl * TM + row) * RS + 8 * ch : -1;
-    oka[i] = id < CA && m0 + row < g.M;
-    pa[i] = g.Ap + pl * g.ap_plane + (oka[i] ? (m0 + row) : 0) * g.ldap + 8 * ch;
-  }
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int id = tid + 256 * i, pl = id / (4 * TN), rem = id % (4 * TN), row = rem >> 2, ch = rem & 3;
-    lb[i] = id < CB ? (pl * TN + row) * RS + 8 * ch : -1;
-    okb[i] = id < CB && n0 + row < g.N;
-    pb[i] = g.Bp + pl * g.bp_plane + (long long)(okb[i] ? (n0 + row) : 0) * g.ldbp + 8 * ch;
-  }
-  const u4v Zu = {0u, 0u, 0u, 0u};
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int ch8 = (la[i] % RS);                                // 8 * quarter
-      ra[i] = (oka[i] && k0 + ch8 < g.K) ? *reinterpret_cast<const u4v*>(pa[i] + k0) : Zu;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int ch8 = (lb[i] % RS);
-      rb[i] = (okb[i] && k0 + ch8 < g.K) ? *reinterpret_cast<const u4v*>(pb[i] + k0) : Zu;
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (la[i] >= 0) *reinterpret_cast<u4v*>(&sA[la[i]]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (lb[i] >= 0) *reinterpret_cast<u4v*>(&sB[lb[i]]) = rb[i];
-  };
-  f4 acc[WNB][WMB];
-#pragma unroll
-  for (int i = 0; i < WNB; ++i)
-#pragma unroll
-    for (int j = 0; j < WMB; ++j) acc[i][j] = splat(0.f);
-  const int nk = (g.K + 31) / 32;
-  gload(0);
-  sstore();
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * 32);                         // in flight under the MFMAs below
-    Split3 sa[WMB];
-#pragma unroll
-    for (int j = 0; j < WMB; ++j) {
-      const int o = (wm + 16 * j + c) * RS + 8 * q;
-      sa[j].h = *reinterpret_cast<const u4v*>(&sA[o]);
-      sa[j].m = *reinterpret_cast<const u4v*>(&sA[TM * RS + o]);
-      sa[j].l = *reinterpret_cast<const u4v*>(&sA[2 * TM * RS + o]);
-    }
-#pragma unroll
-    for (int i = 0; i < WNB; ++i) {
-      const int o = (wn + 16 * i + c) * RS + 8 * q;
-      Split3 sw;
-      sw.h = *reinterpret_cast<const u4v*>(&sB[o]);
-      sw.m = *reinterpret_cast<const u4v*>(&sB[TN * RS + o]);
-      sw.l = *reinterpret_cast<const u4v*>(&sB[2 * TN * RS + o]);
-#pragma unroll
-      for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.l, sa[j].h, acc[i][j]);
-#pragma unroll
-      for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.h, sa[j].l, acc[i][j]);
-#pragma unroll
-      for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.m, sa[j].m, acc[i][j]);
-#pragma unroll
-      for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.m, sa[j].h, acc[i][j]);
-#pragma unroll
-      for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.h, sa[j].m, acc[i][j]);
-#pragma unroll
-      for (int j = 0; j < WMB; ++j) acc[i][j] = mfma_bf16(sw.h, sa[j].h, acc[i][j]);
-    }
-    __syncthreads();                                               // every wave has read this k-tile
-    if (kt + 1 < nk) sstore();
-    __syncthreads();
-  }
-  gemm_epilogue<EPI, WMB, WNB, WAVES_N>(g, acc, m0, n0, wm, wn, w, c, q);
-}
-
-// fp32 matrix (rows x K, row stride ld) -> its three bf16 planes (row stride K): weights, once per parameter update
-__global__ void to_planes_kernel(const float* W, int ld, long long rows, int K, unsigned short* P, long long plane) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 4 consecutive k
-  const int K4 = K / 4;
-  if (i >= rows * K4) return;
-  const long long r = i / K4;
-  const int k = (int)(i % K4) * 4;
-  const float* p = W + r * ld + k;
-  const Split4 sp = split4(f4{p[0], p[1], p[2], p[3]});
-  typedef unsigned u2v __attribute__((ext_vector_type(2)));
-  unsigned short* o = P + r * K + k;
-  *reinterpret_cast<u2v*>(o) = u2v{sp.h[0], sp.h[1]};
-  *reinterpret_cast<u2v*>(o + plane) = u2v{sp.m[0], sp.m[1]};
-  *reinterpret_cast<u2v*>(o + 2 * plane) = u2v{sp.l[0], sp.l[1]};
-}
-inline void to_planes(hipStream_t s, const float* W, int ld, long long rows, int K, unsigned short* P) {
-  const long long n = rows * (K / 4);
-  hipLaunchKernelGGL(to_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ld, rows, K, P, rows * (long long)K);
 }
 
 // (A warp-specialised form -- four producer waves split every element once per workgroup into three bf16 LDS planes, four
@@ -1018,25 +881,6 @@ int launch_gemm(const GemmArgs& g, hipStream_t s, int shape = SHAPE_AUTO) {
   if (shape == SHAPE_BIG) return launch_gemm_shape<EPI, 4, 4>(g, s);
   if (shape == SHAPE_MID) return launch_gemm_shape<EPI, 2, 2>(g, s);
   return launch_gemm_shape<EPI, 1, 2>(g, s);
-}
-
-// the pre-split form: 128 x 128 tiles, or 128 x 112 for widths that are multiples of 112 but not of 128 (the 784 logits)
-template <int EPI>
-int launch_gemm_planes(const GemmArgs& g, hipStream_t s) {
-  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return L2HMC_OK;
-  if (g.N % 112 == 0 && g.N % 128 != 0) {
-    const dim3 grid((unsigned)((g.N + 111) / 112), (unsigned)((g.M + 127) / 128));
-    hipLaunchKernelGGL((gemm_pl_kernel<EPI, 2, 7, 1>), grid, dim3(256), 0, s, g);
-  } else {
-    const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + 127) / 128));
-    hipLaunchKernelGGL((gemm_pl_kernel<EPI, 4, 4, 2>), grid, dim3(256), 0, s, g);
-  }
-  return L2HMC_OK;
-}
-// can this product take the pre-split form?  (decoder-sized: the tile shapes above fill the chip; 16-byte plane rows)
-inline bool gemm_planes_ok(long long M, int N, int K) {
-  const int shape = gemm_auto_shape(M, N);
-  return (shape == SHAPE_BIG || shape == SHAPE_W112) && K % 8 == 0 && N % 4 == 0;
 }
 
 }  // namespace l2hmc

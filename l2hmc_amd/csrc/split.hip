@@ -11,6 +11,7 @@
 // a caller-provided workspace.  Same per-chain direction mixing as the fused kernel: each chain
 // runs only in its drawn direction.
 #include "gemm_f32.hpp"
+#include "gemm_xl.hpp"
 
 namespace l2hmc {
 
@@ -261,6 +262,9 @@ void mlp3_forward(hipStream_t s, const L2hmcMlp3& m, const float* x, long long N
 inline int bce_tiles(long long N, int n_pix) { return (n_pix + gemm_tile_n(gemm_auto_shape(N, n_pix)) - 1) / gemm_tile_n(gemm_auto_shape(N, n_pix)); }
 inline int bce_partials(long long N, int n_pix) { return gemm_waves_n(gemm_auto_shape(N, n_pix)) * bce_tiles(N, n_pix); }   // per chain
 inline int bce_tiles_max(int n_pix) { return (n_pix + 63) / 64; }
+// bf16 planes (gemm_xl.hpp): row stride of a K-extent, rows of a weight matrix with N outputs
+inline int pld(int K) { return ceil_to(K, 32); }
+inline long long prows(int N) { return ceil_to(N, XLP_TN); }
 
 // U (N) and grad (N x d, row stride ldg) of the VAE latent posterior at z (row stride ldz) (mnist_vae.py:122-126):
 // six GEMMs, every bias / softplus / sigmoid / BCE / chain-rule product fused into their epilogues; lg (N x n_pix)
@@ -268,30 +272,32 @@ inline int bce_tiles_max(int n_pix) { return (n_pix + 63) / 64; }
 void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, int ldz, long long N, int d,
                 const Mlp3Ws& ws, float* lg, float* rowsum, float* U, double* Ud, float* grad, int ldg, float beta = 1.f) {
   if (ws.pa1 != nullptr) {
-    // ---- pre-split form (gemm_mode 1 at decoder sizes): every activation that only feeds the next product is written as bf16
-    //      planes by its producer's epilogue; the four decoder-sized products read planes on both sides
-    const long long n1 = N * dec.n_h1, n2 = N * dec.n_h2, no = N * dec.n_out;
+    // ---- pre-split form (gemm_mode 1 at decoder sizes, gemm_xl.hpp): every activation that only feeds the next product is
+    //      written as bf16 planes by its producer's epilogue; the four decoder-sized products read planes on both sides.
+    //      Plane row strides are whole k-tiles (pld) and the weight planes whole tiles of rows (prows), zero-padded.
+    const int l1 = pld(dec.n_h1), l2 = pld(dec.n_h2), lo = pld(dec.n_out);
+    const long long n1 = N * l1, n2 = N * l2, no = N * lo;
     GemmArgs g = gemm_args(z, ldz, ws.w1t, dec.n_in, nullptr, dec.n_h1, N, dec.n_h1, dec.n_in);
-    g.bias = dec.b1; g.C2 = ws.s1; g.ldc2 = dec.n_h1; g.Cp = ws.pa1; g.cp_plane = n1; g.ldcp = dec.n_h1;
+    g.bias = dec.b1; g.C2 = ws.s1; g.ldc2 = dec.n_h1; g.Cp = ws.pa1; g.cp_plane = n1; g.ldcp = l1;
     launch_gemm<EPI_BIAS_SOFTPLUS>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_AUTO);                 // a1 (planes), s1
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_h1);
-    g.Ap = ws.pa1; g.ap_plane = n1; g.ldap = dec.n_h1; g.Bp = ws.pw2t; g.bp_plane = (long long)dec.n_h2 * dec.n_h1; g.ldbp = dec.n_h1;
-    g.bias = dec.b2; g.C2 = ws.s2; g.ldc2 = dec.n_h2; g.Cp = ws.pa2; g.cp_plane = n2; g.ldcp = dec.n_h2;
+    g.Ap = ws.pa1; g.ap_plane = n1; g.ldap = l1; g.Bp = ws.pw2t; g.bp_plane = prows(dec.n_h2) * l1; g.ldbp = l1;
+    g.bias = dec.b2; g.C2 = ws.s2; g.ldc2 = dec.n_h2; g.Cp = ws.pa2; g.cp_plane = n2; g.ldcp = l2;
     launch_gemm_planes<EPI_BIAS_SOFTPLUS>(g, s);                                                     // a2 (planes), s2
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_out, N, dec.n_out, dec.n_h2);
-    g.Ap = ws.pa2; g.ap_plane = n2; g.ldap = dec.n_h2; g.Bp = ws.pw3t; g.bp_plane = (long long)dec.n_out * dec.n_h2; g.ldbp = dec.n_h2;
-    g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = beta;
-    g.Cp = ws.plg; g.cp_plane = no; g.ldcp = dec.n_out;
+    g.Ap = ws.pa2; g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw3t; g.bp_plane = prows(dec.n_out) * l2; g.ldbp = l2;
+    g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles_planes(dec.n_out); g.beta = beta;
+    g.Cp = ws.plg; g.cp_plane = no; g.ldcp = lo;
     launch_gemm_planes<EPI_BCE>(g, s);                                                               // beta (sigmoid(logit) - aux) (planes)
     if (U != nullptr || Ud != nullptr)
-      hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, bce_partials(N, dec.n_out), z, ldz, d, U, Ud, N);
+      hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles_planes(dec.n_out), z, ldz, d, U, Ud, N);
     if (grad == nullptr) return;
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_out);
-    g.Ap = ws.plg; g.ap_plane = no; g.ldap = dec.n_out; g.Bp = ws.pw3; g.bp_plane = (long long)dec.n_h2 * dec.n_out; g.ldbp = dec.n_out;
-    g.E = ws.s2; g.lde = dec.n_h2; g.Cp = ws.pda2; g.cp_plane = n2; g.ldcp = dec.n_h2;
+    g.Ap = ws.plg; g.ap_plane = no; g.ldap = lo; g.Bp = ws.pw3; g.bp_plane = prows(dec.n_h2) * lo; g.ldbp = lo;
+    g.E = ws.s2; g.lde = dec.n_h2; g.Cp = ws.pda2; g.cp_plane = n2; g.ldcp = l2;
     launch_gemm_planes<EPI_MUL>(g, s);                                                               // d a2 (planes)
     g = gemm_args(nullptr, 0, nullptr, 0, ws.a1, dec.n_h1, N, dec.n_h1, dec.n_h2);
-    g.Ap = ws.pda2; g.ap_plane = n2; g.ldap = dec.n_h2; g.Bp = ws.pw2; g.bp_plane = (long long)dec.n_h1 * dec.n_h2; g.ldbp = dec.n_h2;
+    g.Ap = ws.pda2; g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw2; g.bp_plane = prows(dec.n_h1) * l2; g.ldbp = l2;
     g.E = ws.s1; g.lde = dec.n_h1;
     launch_gemm_planes<EPI_MUL>(g, s);                                                               // d a1 (fp32: the K = 1024, N = d product reads it)
     g = gemm_args(ws.a1, dec.n_h1, dec.W1, dec.n_h1, grad, ldg, N, d, dec.n_h1);
@@ -351,14 +357,18 @@ SplitPlan plan_split(long long N, int d, int H, int T, const L2hmcMlp3* enc, con
   const long long n12 = (long long)ceil16(H) * ceil16(2 * d), n4 = (long long)ceil16(H) * ceil16(H), nh = (long long)ceil16(3 * d) * ceil16(H);
   p.nx12t = take(n12); p.nx4t = take(n4); p.nxht = take(nh);
   p.nv12t = take(n12); p.nv4t = take(n4); p.nvht = take(nh);
-  // bf16 planes of the decoder's two big layers and of the activations between them (gemm_pl_kernel): 3 planes x 2 bytes
+  // bf16 planes of the decoder's two big layers and of the activations between them (gemm_xl.hpp): 3 planes x 2 bytes
   p.planes = dec != nullptr && gemm_planes_ok(N, dec->n_h2, dec->n_h1) && gemm_planes_ok(N, dec->n_out, dec->n_h2) &&
              gemm_planes_ok(N, dec->n_h2, dec->n_out) && gemm_planes_ok(N, dec->n_h1, dec->n_h2) && dec->n_h1 % 4 == 0;
   auto takep = [&](long long elems) { return take(p.planes ? (elems * 3 + 1) / 2 : 0); };
-  const long long e21 = dec ? (long long)dec->n_h2 * dec->n_h1 : 0, eo2 = dec ? (long long)dec->n_out * dec->n_h2 : 0;
-  p.pw2t = takep(e21); p.pw3t = takep(eo2); p.pw2 = takep(e21); p.pw3 = takep(eo2);
-  p.pa1 = takep(dec ? N * dec->n_h1 : 0); p.pa2 = takep(dec ? N * dec->n_h2 : 0);
-  p.plg = takep(dec ? N * dec->n_out : 0); p.pda2 = takep(dec ? N * dec->n_h2 : 0);
+  if (dec != nullptr) {
+    p.pw2t = takep(prows(dec->n_h2) * pld(dec->n_h1)); p.pw3t = takep(prows(dec->n_out) * pld(dec->n_h2));
+    p.pw2 = takep(prows(dec->n_h1) * pld(dec->n_h2)); p.pw3 = takep(prows(dec->n_h2) * pld(dec->n_out));
+    p.pa1 = takep(N * pld(dec->n_h1)); p.pa2 = takep(N * pld(dec->n_h2));
+    p.plg = takep(N * pld(dec->n_out)); p.pda2 = takep(N * pld(dec->n_h2));
+  } else {
+    p.pw2t = p.pw3t = p.pw2 = p.pw3 = p.pa1 = p.pa2 = p.plg = p.pda2 = o;
+  }
   p.total = o;
   return p;
 }
@@ -456,6 +466,8 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   const L2hmcMlp3& dec = (builtin || user) ? no_dec : *a->decoder;
   Mlp3Ws dws = {w + p.dw1t, w + p.dw2t, w + p.dw3t, w + p.a1, w + p.s1, w + p.a2, w + p.s2};
   const bool use_planes = p.planes && a->gemm_mode == 1 && !builtin && !user;
+  // (what l2hmc_last_kernel reports for this engine: the kernel of the decoder-sized products, or the net evaluation)
+  note_kernel(builtin || user ? "net_eval_kernel" : use_planes ? "gemm_xlp_kernel" : "gemm_nt_kernel");
   if (use_planes) {
     auto us = [&](long long off) { return reinterpret_cast<unsigned short*>(w + off); };
     dws.pw2t = us(p.pw2t); dws.pw3t = us(p.pw3t); dws.pw2 = us(p.pw2); dws.pw3 = us(p.pw3);
@@ -478,10 +490,15 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (!builtin && !user && !have_w) {
     mlp3_transposes(s, dec, dws);
     if (use_planes) {       // the two decoder-sized layers, both orientations, as bf16 planes: once per parameter update
-      to_planes(s, dws.w2t, dec.n_h1, dec.n_h2, dec.n_h1, dws.pw2t);
-      to_planes(s, dws.w3t, dec.n_h2, dec.n_out, dec.n_h2, dws.pw3t);
-      to_planes(s, dec.W2, dec.n_h2, dec.n_h1, dec.n_h2, dws.pw2);
-      to_planes(s, dec.W3, dec.n_out, dec.n_h2, dec.n_out, dws.pw3);
+      to_planes(s, dws.w2t, dec.n_h1, dec.n_h2, dec.n_h1, dws.pw2t, prows(dec.n_h2), pld(dec.n_h1));
+      to_planes(s, dws.w3t, dec.n_h2, dec.n_out, dec.n_h2, dws.pw3t, prows(dec.n_out), pld(dec.n_h2));
+      to_planes(s, dec.W2, dec.n_h2, dec.n_h1, dec.n_h2, dws.pw2, prows(dec.n_h1), pld(dec.n_h2));
+      to_planes(s, dec.W3, dec.n_out, dec.n_h2, dec.n_out, dws.pw3, prows(dec.n_h2), pld(dec.n_out));
+      // the epilogues write the columns of an activation only: its padding up to a whole k-tile is zeroed here
+      planes_zero_pad(s, dws.pa1, N, dec.n_h1, pld(dec.n_h1));
+      planes_zero_pad(s, dws.pa2, N, dec.n_h2, pld(dec.n_h2));
+      planes_zero_pad(s, dws.plg, N, dec.n_out, pld(dec.n_out));
+      planes_zero_pad(s, dws.pda2, N, dec.n_h2, pld(dec.n_h2));
     }
   }
   if (a->aux_encoder && !hmc) {      // the image branch is step-invariant: once per trajectory, not 4T times

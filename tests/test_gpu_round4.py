@@ -211,3 +211,37 @@ def test_adam_after_the_all_reduce_forms_the_global_loss():
     o = out.cpu().numpy()
     assert abs(o[0] - A) < 1e-9 * A and abs(o[1] - B) < 1e-9 * B
     assert abs(o[2] - (scale * A - B / scale) / cnt) < 1e-9 * abs(o[2])
+
+
+@pytest.mark.parametrize("N", [6144, 6200])
+def test_config5_on_presplit_planes(N):
+    """Config 5's widths at a chain count where the decoder-sized products run on pre-split bf16 planes (csrc/gemm_xl.hpp:
+    256 x 128 tiles, weights split once per call, activations by the epilogue that produces them -- same six bf16 products per
+    block as the in-loop split, so the same fp32-level accuracy): positions 2e-4 relative, accept probability 1e-4 absolute
+    against the float64 evaluation of the same map (the tolerances of the 3072-chain test of the in-loop form).  6200 chains:
+    the last row tile is partial (56 rows), its loads clamp to the last chain."""
+    from l2hmc_amd import _ffi, propose
+    from tests.helpers import aux_of, synthetic_vae_case
+    g = synthetic_vae_case(N=N, seed=6)
+    dyn = hip_dynamics(g)
+    assert dyn.gemm_mode == 1
+    rng = np.random.RandomState(3)
+    direction = rng.randint(0, 2, size=N).astype(np.uint8)
+    u = rng.rand(N).astype(np.float32)
+    aux = aux_of(g)
+    Lx, _, px, outs = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(g["v"]),
+                              u=to_dev(u), aux=aux)
+    assert _ffi.last_kernel() == "gemm_xlp_kernel"
+    od64 = oracle_dynamics(g, np.float64)
+    with np.errstate(all="ignore"):
+        tLx, _, tpx, _ = O.propose(g["x"].astype(np.float64), od64, g["v"].astype(np.float64), g["v"].astype(np.float64),
+                                   direction, u.astype(np.float64), both_directions=False)
+    ex, ep = rel_err(to_np(Lx), tLx), abs_err(to_np(px), tpx)
+    print("config 5 @ %d chains on planes: mean p %.3f  max rel err x %.2e  |p - p64| max %.2e" % (N, float(tpx.mean()), ex, ep))
+    assert ex < 2e-4 and ep < 1e-4, (ex, ep)
+    check_x_next(to_np(outs[0]), g["x"], tLx, tpx, u, 5e-4)
+    # the in-loop form of the same products (gemm_mode 0 = f32-input MFMA) agrees to the same tolerances
+    dyn.gemm_mode = 0
+    Lx0, _, px0, _ = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(g["v"]), u=to_dev(u), aux=aux)
+    assert _ffi.last_kernel() == "gemm_nt_kernel"
+    assert rel_err(to_np(Lx), to_np(Lx0)) < 2e-4 and abs_err(to_np(px), to_np(px0)) < 1e-4

@@ -1,4 +1,5 @@
-// ubench_gemm_bf3.hip -- the split engine's NT GEMM on the f32-input MFMA vs the bf16x3 form (csrc/gemm_f32.hpp, BF3 = 1):
+// ubench_gemm_bf3.hip -- the split engine's NT GEMM on the f32-input MFMA vs the bf16x3 form (csrc/gemm_f32.hpp, BF3 = 1) vs the
+// bf16x3 form on pre-split planes (csrc/gemm_xl.hpp; -DL2HMC_XL_TIMING adds the shader cycles of its k loop):
 // time and accuracy on the decoder-sized products of config 5 (M = 8192 chains, 1024 x 1024 and 1024 x 784 weights).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I l2hmc_amd/csrc -I include -o tools/bin/ubench_gemm_bf3 tools/ubench_gemm_bf3.hip
 #include <hip/hip_runtime.h>
@@ -9,9 +10,6 @@
 
 #include "gemm_f32.hpp"
 #include "gemm_xl.hpp"
-#ifndef XLP_CFG
-#define XLP_CFG 8, 4, 2, 2
-#endif
 namespace l2hmc {   // the two symbols of l2hmc_abi.hip the header refers to
 thread_local char g_err[512];
 int fail(int code, const char* fmt, const char* s, long long a, long long b) { (void)fmt; (void)s; (void)a; (void)b; return code; }
@@ -37,37 +35,19 @@ static double run(int epi_softplus, int M, int N, int K, int bf3, const float* A
   return ms * 1e3 / reps;
 }
 
-static double run_xl(int epi_softplus, int M, int N, int K, const float* A, const float* B, const float* bias, float* C, float* C2,
-                     int reps) {
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));
-  g.A = A; g.lda = K; g.B = B; g.ldb = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.beta = 1.f; g.bias = bias;
-  g.C2 = C2; g.ldc2 = N; g.bf3 = 1;
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) { if (epi_softplus) launch_gemm_xl<EPI_BIAS_SOFTPLUS>(g, 0); else launch_gemm_xl<EPI_BIAS>(g, 0); }
-  if (hipDeviceSynchronize() != hipSuccess) { printf("xl launch failed: %s\n", hipGetErrorString(hipGetLastError())); return -1; }
-  hipEventRecord(e0);
-  for (int i = 0; i < reps; ++i) { if (epi_softplus) launch_gemm_xl<EPI_BIAS_SOFTPLUS>(g, 0); else launch_gemm_xl<EPI_BIAS>(g, 0); }
-  hipEventRecord(e1);
-  hipDeviceSynchronize();
-  float ms;
-  hipEventElapsedTime(&ms, e0, e1);
-  return ms * 1e3 / reps;
-}
-
 static double run_xlp(int epi_softplus, int M, int N, int K, const unsigned short* Ap, const unsigned short* Bp, const float* bias, float* C,
                       float* C2, int reps) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
-  g.Ap = Ap; g.ap_plane = (long long)M * K; g.ldap = K; g.Bp = Bp; g.bp_plane = (long long)N * K; g.ldbp = K;
+  const int ldp = ceil_to(K, 32);
+  g.Ap = Ap; g.ap_plane = (long long)M * ldp; g.ldap = ldp; g.Bp = Bp; g.bp_plane = (long long)ceil_to(N, XLP_TN) * ldp; g.ldbp = ldp;
   g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.beta = 1.f; g.bias = bias; g.C2 = C2; g.ldc2 = N; g.bf3 = 1;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) { if (epi_softplus) launch_gemm_xlp<EPI_BIAS_SOFTPLUS, XLP_CFG>(g, 0); else launch_gemm_xlp<EPI_BIAS, XLP_CFG>(g, 0); }
+  for (int i = 0; i < 3; ++i) { if (epi_softplus) launch_gemm_planes<EPI_BIAS_SOFTPLUS>(g, 0); else launch_gemm_planes<EPI_BIAS>(g, 0); }
   if (hipDeviceSynchronize() != hipSuccess) { printf("xlp launch failed: %s\n", hipGetErrorString(hipGetLastError())); return -1; }
   hipEventRecord(e0);
-  for (int i = 0; i < reps; ++i) { if (epi_softplus) launch_gemm_xlp<EPI_BIAS_SOFTPLUS, XLP_CFG>(g, 0); else launch_gemm_xlp<EPI_BIAS, XLP_CFG>(g, 0); }
+  for (int i = 0; i < reps; ++i) { if (epi_softplus) launch_gemm_planes<EPI_BIAS_SOFTPLUS>(g, 0); else launch_gemm_planes<EPI_BIAS>(g, 0); }
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms;
@@ -111,36 +91,12 @@ int main() {
     printf("M=%d N=%d K=%d: f32 MFMA %.1f us = %.1f TFLOP/s | bf16x3 %.1f us = %.1f TFLOP/s (algorithmic; x%.2f) | "
            "softplus epilogue: f32 %.1f us, bf16x3 %.1f us | max |err| vs fp64: f32 %.2e  bf16x3 %.2e  (|C| <= %.2f)\n",
            M, N, K, us[0], fl / us[0] * 1e-6, us[1], fl / us[1] * 1e-6, us[0] / us[1], us_sp0, us_sp, e[0], e[1], scale);
-    {   // the 256 x 128 one-wave-per-SIMD form: time, and its output against the 128 x 128 bf16x3 kernel's (bit for bit)
-      run(0, M, N, K, 1, A, B, b, C, nullptr, 1);
-      std::vector<float> ref((size_t)M * N), got((size_t)M * N);
-      hipMemcpy(ref.data(), C, ref.size() * 4, hipMemcpyDeviceToHost);
-      hipMemset(C, 0, ref.size() * 4);
-      const double us_xl = run_xl(0, M, N, K, A, B, b, C, nullptr, 20);
-      hipMemcpy(got.data(), C, got.size() * 4, hipMemcpyDeviceToHost);
-      size_t diff = 0;
-      double worst = 0;
-      for (size_t i = 0; i < ref.size(); ++i) { if (ref[i] != got[i]) ++diff; worst = fmax(worst, fabs((double)ref[i] - got[i])); }
-#ifdef L2HMC_XL_TIMING
-      {
-        unsigned long long z[4] = {0, 0, 0, 0}, t[4];
-        hipMemcpyToSymbol(HIP_SYMBOL(l2hmc::xl_ticks), z, sizeof(z));
-        const double us1 = run_xl(0, M, N, K, A, B, b, C, nullptr, 5);      // 3 + 5 launches
-        hipMemcpyFromSymbol(t, HIP_SYMBOL(l2hmc::xl_ticks), sizeof(t));
-        const double cyc = (double)t[0] / (double)t[1], wall_us = (double)t[2] / (double)t[1] / 100.0;   // wall clock: 100 MHz
-        printf("   k loop of a workgroup: %.0f shader cycles = %.0f per k-tile of 32, %.1f us by the constant clock -> %.2f GHz; launch %.1f us\n",
-               cyc, cyc / ((K + 31) / 32), wall_us, cyc / wall_us * 1e-3, us1);
-      }
-#endif
-      const double us_xl_sp = run_xl(1, M, N, K, A, B, b, C, C2, 20);
-      printf("   256 x 128 tiles, one wave per SIMD: %.1f us = %.1f TFLOP/s (x%.2f vs 128 x 128 bf16x3), softplus epilogue %.1f us | "
-             "elements that differ from the 128 x 128 kernel: %zu (max %.2e)\n", us_xl, fl / us_xl * 1e-6, us[1] / us_xl, us_xl_sp, diff, worst);
-    }
     if (K % 8 == 0) {   // the same tile on pre-split bf16 planes (gemm_xlp_kernel): time, and bit-equality with the 128 x 128 bf16x3 kernel
       unsigned short *Ap, *Bp;
-      hipMalloc(&Ap, (size_t)M * K * 6); hipMalloc(&Bp, (size_t)N * K * 6);
-      to_planes(0, A, K, M, K, Ap);
-      to_planes(0, B, K, N, K, Bp);
+      const int ldp = ceil_to(K, 32), Np = ceil_to(N, XLP_TN);
+      hipMalloc(&Ap, (size_t)M * ldp * 6); hipMalloc(&Bp, (size_t)Np * ldp * 6);
+      to_planes(0, A, K, M, K, Ap, M, ldp);
+      to_planes(0, B, K, N, K, Bp, Np, ldp);
       run(0, M, N, K, 1, A, B, b, C, nullptr, 1);
       std::vector<float> ref((size_t)M * N), got((size_t)M * N);
       hipMemcpy(ref.data(), C, ref.size() * 4, hipMemcpyDeviceToHost);
@@ -161,7 +117,7 @@ int main() {
       double worst = 0;
       for (size_t i = 0; i < ref.size(); ++i) { if (ref[i] != got[i]) ++diff; worst = fmax(worst, fabs((double)ref[i] - got[i])); }
       const double us_p_sp = run_xlp(1, M, N, K, Ap, Bp, b, C, C2, 20);
-      printf("   256 x 128 tiles on pre-split planes: %.1f us = %.1f TFLOP/s (x%.2f vs 128 x 128 bf16x3), softplus epilogue %.1f us | "
+      printf("   256 x 128 tiles, 8 waves, on pre-split planes (gemm_xlp_kernel): %.1f us = %.1f TFLOP/s (x%.2f vs 128 x 128 bf16x3), softplus epilogue %.1f us | "
              "elements that differ from the 128 x 128 kernel: %zu (max %.2e)\n", us_p, fl / us_p * 1e-6, us[1] / us_p, us_p_sp, diff, worst);
       hipFree(Ap); hipFree(Bp);
     }
