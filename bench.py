@@ -206,6 +206,8 @@ def config5_leg(dev, chains=8192):
         _, _, px, out = propose(state["x"], dyn, do_mh_step=True, aux=aux)
         state["x"], state["p"] = out[0], px
     ms_prop = timed(one_proposal, 3, 12)
+    from l2hmc_amd import _ffi
+    k_dec = _ffi.last_kernel()                 # the kernel of the decoder-sized products, as the library names it
     f_net = 2 * (2 * d * H + H * H + 3 * d * H)
     f_dec = 2 * (d * 1024 + 1024 * 1024 + 1024 * 784)
     flops_step = 4 * f_net + (1 + 1.0 / T) * 2 * f_dec                      # per chain . leapfrog step
@@ -220,13 +222,15 @@ def config5_leg(dev, chains=8192):
     flops_train = 3 * 4 * T * f_net + (T + 1) * 4 * f_dec                      # forward + input & weight gradients + HVPs
     return {"workload": "config 5: VAE latent posterior d=50, decoder 1024/1024/784, H=200 nets + image branch, "
                         "%d chains, Lf=5, random weights, synthetic images" % chains,
-            "kernels": "gemm_nt_kernel (fused epilogues), net_eval_kernel (+ fused half-updates), gemm_tn_kernel (training)",
+            "kernels": "%s (decoder products), gemm_nt_kernel (fused epilogues), net_eval_kernel (+ fused half-updates), "
+                       "gemm_tn_kernel (training)" % k_dec,
             "ms_per_proposal": ms_prop, "value": chains * T / (ms_prop * 1e-3), "unit": "chain\u00b7leapfrog-steps/s",
             "flops_per_chain_step": flops_step, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "frac": ach / PEAK_F32_MFMA_TFLOPS,
             # what the matrix pipe really executes: with gemm_mode = 1 (the default) the decoder-sized products run as
             # "bf16x3" -- six bf16 MFMAs per fp32 product, fp32-accurate -- so `frac` above is ALGORITHMIC
             # fp32 flops over the f32-MFMA roof, not the utilisation of the pipe the products run on
-            "arithmetic": "bf16x3 (decoder GEMMs: 3-way split fp32 operands, 6 bf16 MFMAs per product, fp32 accumulate); "
+            "arithmetic": "bf16x3 (decoder GEMMs: 3-way split fp32 operands -- on pre-split bf16 planes from 6144 chains, "
+                          "gemm_xlp_kernel -- 6 bf16 MFMAs per product, fp32 accumulate); "
                           "f32 MFMA for the K = 50 / N = 50 / H = 200 products" if int(getattr(dyn, "gemm_mode", 1)) == 1 else "f32 MFMA",
             "executed_tflops": (ach_dec * (6.0 if int(getattr(dyn, "gemm_mode", 1)) == 1 else 1.0) + (ach - ach_dec)),
             "frac_of_bf16_roof": (ach_dec * 6.0 / PEAK_BF16_MFMA_TFLOPS) if int(getattr(dyn, "gemm_mode", 1)) == 1 else None,

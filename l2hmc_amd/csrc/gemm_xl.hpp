@@ -13,7 +13,7 @@
 //
 //   * 256 x 128 tile, 4 x 2 waves of 64 x 64 blocks: two waves per SIMD, so one wave's LDS / global instructions issue while the
 //     other's MFMAs run (a lone wave pays them in full: 22 cycles per ds_read_b128, 42 per ds_write_b128 of matrix-pipe idle time;
-//     4 waves of 128 x 64 blocks: 5430 cycles per k-tile, 8 waves: 4870; the matrix pipe alone: 3280);
+//     4 waves of 128 x 64 blocks: 5430 cycles per k-tile, 8 waves: 4650; the matrix pipe alone: 3280);
 //   * LDS: [buffer][plane][row: TM activation rows, TN weight rows][4 chunks of 16 bytes = 8 bf16], UNPADDED (2 x 72 KB; padded
 //     rows would not fit twice) with the chunk index XOR-swizzled by bits 2-3 of the row: the 16 lanes (row c, chunk q) of a
 //     fragment read hit 16 distinct 16-byte bank groups, and so do the staging writes;
@@ -22,7 +22,8 @@
 //     over the stages: in one burst the waves of the CU queue behind one another at the texture addresser and the LDS pipe);
 //   * the k-tile is a sequence of STAGES (one fragment requested from LDS per stage, AHEAD of the MFMAs that need it), fenced so
 //     that the compiler keeps the memory instructions between the MFMAs instead of collecting them.
-// 8192 x 1024 x 1024: 103 us against 123-127 us for the in-loop split in the same cold-clock run (x1.19-1.23).
+// 8192 x 1024 x 1024 standalone: 93 us against 121 us for the in-loop split in the same cold-clock run (x1.29); inside config 5's
+// chain of launches (where every epilogue also writes 6 bytes of planes per element): 3.79 -> 3.6 ms per proposal.
 #pragma once
 #include <type_traits>
 
@@ -120,10 +121,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
 
   using Ord = XlSched<WMB, WNB>;
   const int nk = (g.K + 31) / 32;
-  constexpr int AHEAD = 4;
-  // staging chunks per stage, stages 0 .. 5 only: the compiler waits for EVERY outstanding load before the first ds_write of the
-  // next k-tile (its counter bookkeeping across the loop edge is conservative), so the youngest load must be old by then
-  constexpr int CPS = (NCH + 5) / 6;
+  constexpr int AHEAD = 4;                 // fragments requested from LDS ahead of the stage that multiplies them
+  // staging chunks per stage, in the first STG stages only: the compiler waits for EVERY outstanding load before the first ds_write
+  // of the next k-tile (its counter bookkeeping across the loop edge is conservative), so the youngest load must be old by then.
+  // Measured (profiles/r04_gemm_xl.txt, cycles per k-tile): 3 stages 4647, 6 stages 4817, 9 stages 4677; AHEAD 2 / 4 / 8 within 1 %;
+  // giving the second wave of every SIMD its staging in the LAST stages instead (so that the two do not stage at the same time):
+  // 5430 -- the wave-uniform branches cost more than the overlap gains.
+  constexpr int STG = 3, CPS = (NCH + STG - 1) / STG;
   const int f_lds = c * 4 + (q ^ ((c >> 2) & 3));                     // this lane's chunk inside a 16-row fragment
   // (the loop exists twice: whole row tiles load without the row clamp)
   auto main_loop = [&](auto fast_c) {
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
       XL_FENCE();
       xl_static_for<0, CPS>([&](auto uc) {
         constexpr int ci = CPS * t + decltype(uc)::value;
-        if constexpr (t < 6 && ci < NCH) {
+        if constexpr (t < STG && ci < NCH) {
           sstore1(std::integral_constant<int, ci>{}, buf ^ 1);
           gload1(std::integral_constant<int, ci>{}, k_next, fast_c);
         }
