@@ -229,7 +229,7 @@ def config5_leg(dev, chains=8192):
             # what the matrix pipe really executes: with gemm_mode = 1 (the default) the decoder-sized products run as
             # "bf16x3" -- six bf16 MFMAs per fp32 product, fp32-accurate -- so `frac` above is ALGORITHMIC
             # fp32 flops over the f32-MFMA roof, not the utilisation of the pipe the products run on
-            "arithmetic": "bf16x3 (decoder GEMMs: 3-way split fp32 operands -- on pre-split bf16 planes from 6144 chains, "
+            "arithmetic": "bf16x3 (decoder GEMMs: 3-way split fp32 operands -- on pre-split bf16 planes from 3072 chains, "
                           "gemm_xlp_kernel -- 6 bf16 MFMAs per product, fp32 accumulate); "
                           "f32 MFMA for the K = 50 / N = 50 / H = 200 products" if int(getattr(dyn, "gemm_mode", 1)) == 1 else "f32 MFMA",
             "executed_tflops": (ach_dec * (6.0 if int(getattr(dyn, "gemm_mode", 1)) == 1 else 1.0) + (ach - ach_dec)),

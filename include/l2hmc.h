@@ -153,7 +153,7 @@ const char* l2hmc_last_error(void);
 /* Name of the kernel the last l2hmc_trajectory / l2hmc_train_propose_grad / l2hmc_train_step call of THIS thread chose
  * (e.g. "traj_fast_kernel<1, 1, 4, 3>", spelt as rocprofv3 prints the instantiation; "" before the first call): what a
  * profile of the call has to be matched against.  l2hmc_trajectory_split reports the template of its dominant kernel
- * without arguments: "gemm_xlp_kernel" (decoder products on pre-split bf16 planes, from 6144 chains at config 5's widths
+ * without arguments: "gemm_xlp_kernel" (decoder products on pre-split bf16 planes, from 3072 chains at config 5's widths
  * in gemm_mode 1), "gemm_nt_kernel", or "net_eval_kernel" for a built-in / caller-supplied energy.  Copies at most n - 1 characters, returns the full length. */
 int32_t l2hmc_last_kernel(char* buf, int32_t n);
 

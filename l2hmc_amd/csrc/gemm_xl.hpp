@@ -206,6 +206,9 @@ template <int WMB, int WNB, int WAVES_M, int WAVES_N>
 constexpr size_t gemm_xlp_lds_bytes() { return (size_t)2 * 3 * (16 * WMB * WAVES_M + 16 * WNB * WAVES_N) * 64; }
 
 constexpr int XLP_TM = 256, XLP_TN = 128;
+#ifndef XLP_MIN_TILES
+#define XLP_MIN_TILES 84             // measured (profiles/r04_gemm_xl.txt): the planes form wins from 3072 chains (12 x 7 tiles) up
+#endif
 inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // C = epilogue(A B^T) on planes; GemmArgs as for launch_gemm with Ap / Bp instead of A / B (contract at GemmArgs)
@@ -228,12 +231,13 @@ int launch_gemm_planes(const GemmArgs& g, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, g);
   return L2HMC_OK;
 }
-// can this product take the pre-split form?  (decoder-sized: two thirds of the CUs get a 256 x 128 tile: from 6144 chains at the widths of config 5)
+// can this product take the pre-split form?  (decoder-sized: from 3072 chains at the widths of config 5 -- a third of the CUs get a
+// 256 x 128 tile, and the k loop is as long whether 84 or 256 tiles run it)
 inline bool gemm_planes_ok(long long M, int N, int K) {
 #ifdef L2HMC_NO_PLANES            // A/B builds (tools/build_variant_full.sh): every product keeps the in-loop split
   return false;
 #endif
-  return ((M + XLP_TM - 1) / XLP_TM) * ((N + XLP_TN - 1) / XLP_TN) >= 168 && K >= 256 && K % 8 == 0 && N % 4 == 0;
+  return ((M + XLP_TM - 1) / XLP_TM) * ((N + XLP_TN - 1) / XLP_TN) >= XLP_MIN_TILES && K >= 256 && K % 8 == 0 && N % 4 == 0;
 }
 // EPI_BCE on planes: row partials per chain = 2 per 128-wide column tile
 inline int bce_tiles_planes(int n_pix) { return (n_pix + XLP_TN - 1) / XLP_TN; }

@@ -215,11 +215,12 @@ def test_adam_after_the_all_reduce_forms_the_global_loss():
 
 @pytest.mark.parametrize("N", [6144, 6200])
 def test_config5_on_presplit_planes(N):
-    """Config 5's widths at a chain count where the decoder-sized products run on pre-split bf16 planes (csrc/gemm_xl.hpp:
-    256 x 128 tiles, weights split once per call, activations by the epilogue that produces them -- same six bf16 products per
-    block as the in-loop split, so the same fp32-level accuracy): positions 2e-4 relative, accept probability 1e-4 absolute
-    against the float64 evaluation of the same map (the tolerances of the 3072-chain test of the in-loop form).  6200 chains:
-    the last row tile is partial (56 rows), its loads clamp to the last chain."""
+    """Config 5's widths with the decoder-sized products on pre-split bf16 planes (csrc/gemm_xl.hpp: 256 x 128 tiles, weights
+    split once per call, activations by the epilogue that produces them -- same six bf16 products per block as the in-loop
+    split, so the same fp32-level accuracy) at MORE than one tile per XCD slot: 6144 chains = 24 row tiles (the XCD-aware tile
+    order engages from 16), and 6200: the last row tile is partial (56 rows), its loads clamp to the last chain.  Positions
+    2e-4 relative, accept probability 1e-4 absolute against the float64 evaluation of the same map (the tolerances of the
+    3072-chain test, tests/test_gpu_round3.py)."""
     from l2hmc_amd import _ffi, propose
     from tests.helpers import aux_of, synthetic_vae_case
     g = synthetic_vae_case(N=N, seed=6)
