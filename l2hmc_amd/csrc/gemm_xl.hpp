@@ -211,24 +211,33 @@ constexpr int XLP_TM = 256, XLP_TN = 128;
 #endif
 inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 
+// The kernel's 144 KB of dynamic LDS have to be asked for once per instantiation: an entry point that is going to use the
+// planes form calls this FIRST and returns its error (the launches below cannot report one to their void callers)
+constexpr int XLP_WMB = 4, XLP_WNB = 4, XLP_WAVES_M = 4, XLP_WAVES_N = 2;
+template <int EPI>
+int gemm_planes_prepare() {
+  constexpr size_t lds = gemm_xlp_lds_bytes<XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>();
+  static_assert(lds <= 160 * 1024, "two plane buffers must fit the CU's LDS");
+  static bool done = false;
+  if (done) return L2HMC_OK;
+  auto kern = gemm_xlp_kernel<EPI, XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(L2HMC_ERR_HIP, "gemm planes: %s", "the device refuses the LDS size of the 256-row plane tiles");
+  done = true;
+  return L2HMC_OK;
+}
 // C = epilogue(A B^T) on planes; GemmArgs as for launch_gemm with Ap / Bp instead of A / B (contract at GemmArgs)
 template <int EPI>
 int launch_gemm_planes(const GemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return L2HMC_OK;
-  constexpr int WMB = 4, WNB = 4, WAVES_M = 4, WAVES_N = 2;
-  constexpr size_t lds = gemm_xlp_lds_bytes<WMB, WNB, WAVES_M, WAVES_N>();
-  static_assert(lds <= 160 * 1024, "two plane buffers must fit the CU's LDS");
   if (g.ldap < ceil_to(g.K, 32) || g.ldbp < ceil_to(g.K, 32) || (g.ldap & 7) || (g.ldbp & 7))
     return fail(L2HMC_ERR_ARG, "gemm planes: row strides must cover ceil32(K) (zero-padded) in multiples of 8%s");
-  static bool once = false;                                           // (> 64 KB of dynamic LDS has to be asked for)
-  auto kern = gemm_xlp_kernel<EPI, WMB, WNB, WAVES_M, WAVES_N>;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(L2HMC_ERR_HIP, "gemm planes: %s", "the device refuses the LDS size of the 256-row plane tiles");
-    once = true;
-  }
+  const int rc = gemm_planes_prepare<EPI>();
+  if (rc != L2HMC_OK) return rc;
   const dim3 grid((unsigned)((g.N + XLP_TN - 1) / XLP_TN), (unsigned)((g.M + XLP_TM - 1) / XLP_TM));
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, g);
+  constexpr size_t lds = gemm_xlp_lds_bytes<XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>();
+  auto kern = gemm_xlp_kernel<EPI, XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>;
+  hipLaunchKernelGGL(kern, grid, dim3(64 * XLP_WAVES_M * XLP_WAVES_N), lds, s, g);
   return L2HMC_OK;
 }
 // can this product take the pre-split form?  (decoder-sized: from 3072 chains at the widths of config 5 -- a third of the CUs get a

@@ -468,6 +468,11 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   const bool use_planes = p.planes && a->gemm_mode == 1 && !builtin && !user;
   // (what l2hmc_last_kernel reports for this engine: the kernel of the decoder-sized products, or the net evaluation)
   note_kernel(builtin || user ? "net_eval_kernel" : use_planes ? "gemm_xlp_kernel" : "gemm_nt_kernel");
+  if (use_planes) {     // the three epilogues vae_energy launches on planes
+    if ((rc = gemm_planes_prepare<EPI_BIAS_SOFTPLUS>()) != L2HMC_OK || (rc = gemm_planes_prepare<EPI_BCE>()) != L2HMC_OK ||
+        (rc = gemm_planes_prepare<EPI_MUL>()) != L2HMC_OK)
+      return rc;
+  }
   if (use_planes) {
     auto us = [&](long long off) { return reinterpret_cast<unsigned short*>(w + off); };
     dws.pw2t = us(p.pw2t); dws.pw3t = us(p.pw3t); dws.pw2 = us(p.pw2); dws.pw3 = us(p.pw3);
