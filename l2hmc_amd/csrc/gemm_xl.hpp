@@ -52,6 +52,11 @@ struct XlSched {
   }
   static constexpr int n = WMB + WNB;
 };
+// (the schedule of the product's 4 x 4 blocks: eight distinct positions, sixteen pairs, none before both its fragments)
+static_assert(XlSched<4, 4>::pairs(0) == 0 && XlSched<4, 4>::pairs(1) + XlSched<4, 4>::pairs(2) + XlSched<4, 4>::pairs(3) + XlSched<4, 4>::pairs(4) +
+                      XlSched<4, 4>::pairs(5) + XlSched<4, 4>::pairs(6) + XlSched<4, 4>::pairs(7) == 16, "every (W, A) pair exactly once");
+static_assert(XlSched<4, 4>::posW(0) == 0 && XlSched<4, 4>::posA(0) == 1 && XlSched<4, 4>::posA(1) == 2 && XlSched<4, 4>::posW(1) == 3 &&
+              XlSched<4, 4>::posA(2) == 4 && XlSched<4, 4>::posA(3) == 5 && XlSched<4, 4>::posW(2) == 6 && XlSched<4, 4>::posW(3) == 7, "W0 A0 A1 W1 A2 A3 W2 W3");
 template <int I, int N, class F>
 __device__ __forceinline__ void xl_static_for(F&& f) {
   if constexpr (I < N) {
