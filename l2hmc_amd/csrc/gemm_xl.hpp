@@ -13,17 +13,25 @@
 //
 //   * 256 x 128 tile, 4 x 2 waves of 64 x 64 blocks: two waves per SIMD, so one wave's LDS / global instructions issue while the
 //     other's MFMAs run (a lone wave pays them in full: 22 cycles per ds_read_b128, 42 per ds_write_b128 of matrix-pipe idle time;
-//     4 waves of 128 x 64 blocks: 5430 cycles per k-tile, 8 waves: 4650; the matrix pipe alone: 3280);
+//     4 waves of 128 x 64 blocks: 5430 cycles per k-tile, 8 waves: 4650);
 //   * LDS: [buffer][plane][row: TM activation rows, TN weight rows][4 chunks of 16 bytes = 8 bf16], UNPADDED (2 x 72 KB; padded
 //     rows would not fit twice) with the chunk index XOR-swizzled by bits 2-3 of the row: the 16 lanes (row c, chunk q) of a
 //     fragment read hit 16 distinct 16-byte bank groups, and so do the staging writes;
 //   * staging: chunk (plane, row, quarter of the k-tile) = one dwordx4; the registers hold tile kt + 1 while tile kt is
 //     multiplied; the first stages of a k-tile store them to the other buffer and re-issue their loads for tile kt + 2 (spread
 //     over the stages: in one burst the waves of the CU queue behind one another at the texture addresser and the LDS pipe);
-//   * the k-tile is a sequence of STAGES (one fragment requested from LDS per stage, AHEAD of the MFMAs that need it), fenced so
-//     that the compiler keeps the memory instructions between the MFMAs instead of collecting them.
-// 8192 x 1024 x 1024 standalone: 93 us against 121 us for the in-loop split in the same cold-clock run (x1.29); inside config 5's
-// chain of launches (where every epilogue also writes 6 bytes of planes per element): 3.79 -> 3.6 ms per proposal.
+//   * the k-tile is six fenced STAGES (the compiler keeps the memory instructions between the MFMAs instead of collecting them)
+//     with ONE workgroup barrier, in the MIDDLE: stages 0-2 store tile kt + 1 and request the rest of tile kt's fragments, after
+//     stage 3 every wave has finished reading tile kt and storing tile kt + 1 -- barrier (LDS counter only: the global loads in
+//     flight are not waited for) -- and stages 4-5 already request the first three fragments of tile kt + 1 while they multiply.
+//     The tile boundary has no barrier and no LDS latency in front of its first MFMA: 3990 cycles per k-tile against 4650 with
+//     the barrier at the end (the matrix pipe alone: 3280).  Hazards: tile t + 2 is stored into tile t's buffer only behind
+//     the barrier of k-tile t, which every wave reaches with its reads of tile t complete; tile t + 1 is read only behind the
+//     barrier that follows its stores.
+// 8192 x 1024 x 1024 standalone: 91 us against 121-125 us for the in-loop split in the same cold-clock run (x1.33-1.37; the chip
+// clocks DOWN as the matrix pipe fills -- 1.74 GHz against 1.90 -- so cycles improve more than microseconds); inside config 5's
+// chain of launches (where every epilogue also writes 6 bytes of planes per element): 3.79 -> 3.57 ms per proposal in an A/B on one
+// box with the barrier at the end of the k-tile, 3.54-3.55 with it in the middle (another box).
 #pragma once
 #include <type_traits>
 
@@ -31,32 +39,6 @@
 
 namespace l2hmc {
 
-// position of a fragment in the order the k-tile requests them from LDS: the operand with more blocks ("major") takes slots 1, 2
-// of every three, the other one slot 0; leftovers of either kind follow in index order.  4 x 4 blocks: W0 A0 A1 W1 A2 A3 W2 W3 --
-// the fragments complete 0 1 1 2 2 2 4 4 (W, A) pairs, whose MFMAs are issued one stage later.
-template <int WMB, int WNB>
-struct XlSched {
-  static constexpr bool A_MAJOR = WMB >= WNB;
-  static constexpr int NMAJ = A_MAJOR ? WMB : WNB, NMIN = A_MAJOR ? WNB : WMB;
-  static constexpr int triples = (NMAJ / 2 < NMIN) ? NMAJ / 2 : NMIN;           // complete (minor, major, major) groups
-  static constexpr int pos_min(int i) { return i < triples ? 3 * i : 3 * triples + (NMAJ - 2 * triples) + (i - triples); }
-  static constexpr int pos_maj(int j) { return j < 2 * triples ? 3 * (j / 2) + 1 + (j % 2) : 3 * triples + (j - 2 * triples); }
-  static constexpr int posA(int j) { return A_MAJOR ? pos_maj(j) : pos_min(j); }
-  static constexpr int posW(int i) { return A_MAJOR ? pos_min(i) : pos_maj(i); }
-  static constexpr int ready(int i, int j) { return posW(i) > posA(j) ? posW(i) : posA(j); }
-  static constexpr int pairs(int t) {                                           // pairs completed by the split of stage t
-    int n = 0;
-    for (int i = 0; i < WNB; ++i)
-      for (int j = 0; j < WMB; ++j) n += ready(i, j) == t;
-    return n;
-  }
-  static constexpr int n = WMB + WNB;
-};
-// (the schedule of the product's 4 x 4 blocks: eight distinct positions, sixteen pairs, none before both its fragments)
-static_assert(XlSched<4, 4>::pairs(0) == 0 && XlSched<4, 4>::pairs(1) + XlSched<4, 4>::pairs(2) + XlSched<4, 4>::pairs(3) + XlSched<4, 4>::pairs(4) +
-                      XlSched<4, 4>::pairs(5) + XlSched<4, 4>::pairs(6) + XlSched<4, 4>::pairs(7) == 16, "every (W, A) pair exactly once");
-static_assert(XlSched<4, 4>::posW(0) == 0 && XlSched<4, 4>::posA(0) == 1 && XlSched<4, 4>::posA(1) == 2 && XlSched<4, 4>::posW(1) == 3 &&
-              XlSched<4, 4>::posA(2) == 4 && XlSched<4, 4>::posA(3) == 5 && XlSched<4, 4>::posW(2) == 6 && XlSched<4, 4>::posW(3) == 7, "W0 A0 A1 W1 A2 A3 W2 W3");
 template <int I, int N, class F>
 __device__ __forceinline__ void xl_static_for(F&& f) {
   if constexpr (I < N) {
@@ -124,72 +106,81 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
 #pragma unroll
     for (int j = 0; j < WMB; ++j) acc[i][j] = splat(0.f);
 
-  using Ord = XlSched<WMB, WNB>;
   const int nk = (g.K + 31) / 32;
-  constexpr int AHEAD = 4;                 // fragments requested from LDS ahead of the stage that multiplies them
-  // staging chunks per stage, in the first STG stages only: the compiler waits for EVERY outstanding load before the first ds_write
-  // of the next k-tile (its counter bookkeeping across the loop edge is conservative), so the youngest load must be old by then.
-  // Measured (profiles/r04_gemm_xl.txt, cycles per k-tile): 3 stages 4647, 6 stages 4817, 9 stages 4677; AHEAD 2 / 4 / 8 within 1 %;
-  // giving the second wave of every SIMD its staging in the LAST stages instead (so that the two do not stage at the same time):
-  // 5430 -- the wave-uniform branches cost more than the overlap gains.
-  constexpr int STG = 3, CPS = (NCH + STG - 1) / STG;
+  // staging chunks per stage, in the first three stages of the k-tile: the compiler waits for EVERY outstanding load before the
+  // first ds_write of the next k-tile (its counter bookkeeping across the loop edge is conservative), so the youngest load must
+  // be old by then (3 stages 4647 cycles per k-tile, 6 stages 4817, 9 stages 4677 -- measured on the end-of-tile-barrier form)
+  constexpr int CPS = (NCH + 2) / 3;
   const int f_lds = c * 4 + (q ^ ((c >> 2) & 3));                     // this lane's chunk inside a 16-row fragment
-  // (the loop exists twice: whole row tiles load without the row clamp)
+  // The k-tile (header): fragment order W0 A0 A1 W1 W2 W3 A2 A3 -- A0 / A1 are dead after the fourth stage and take the next tile's
+  // behind the barrier; its W0 waits in 12 extra registers (sw0n).  The loop exists twice: whole row tiles load without the row clamp.
+  static_assert(WMB == 4 && WNB == 4, "the mid-barrier schedule is written for 4 x 4 blocks");
   auto main_loop = [&](auto fast_c) {
+  Split3 sa[4], sw[4], sw0n;
+  auto rdA = [&](Split3& dst, const u4v* base, int j) { const u4v* pa = base + (wm + 16 * j) * 4; dst.h = pa[0]; dst.m = pa[TR * 4]; dst.l = pa[2 * TR * 4]; };
+  auto rdW = [&](Split3& dst, const u4v* base, int i) { const u4v* pw = base + (TM + wn + 16 * i) * 4; dst.h = pw[0]; dst.m = pw[TR * 4]; dst.l = pw[2 * TR * 4]; };
+  auto mm = [&](const Split3& w_, const Split3& a0, const Split3& a1, f4& c0, f4& c1) {       // two accumulators, product-major
+    c0 = mfma_bf16(w_.l, a0.h, c0); c1 = mfma_bf16(w_.l, a1.h, c1);
+    c0 = mfma_bf16(w_.h, a0.l, c0); c1 = mfma_bf16(w_.h, a1.l, c1);
+    c0 = mfma_bf16(w_.m, a0.m, c0); c1 = mfma_bf16(w_.m, a1.m, c1);
+    c0 = mfma_bf16(w_.m, a0.h, c0); c1 = mfma_bf16(w_.m, a1.h, c1);
+    c0 = mfma_bf16(w_.h, a0.m, c0); c1 = mfma_bf16(w_.h, a1.m, c1);
+    c0 = mfma_bf16(w_.h, a0.h, c0); c1 = mfma_bf16(w_.h, a1.h, c1);
+  };
+  auto mm4 = [&](const Split3& a_, int j) {                                                     // four accumulators (all W, one A)
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (p == 0) acc[i][j] = mfma_bf16(sw[i].l, a_.h, acc[i][j]);
+        if (p == 1) acc[i][j] = mfma_bf16(sw[i].h, a_.l, acc[i][j]);
+        if (p == 2) acc[i][j] = mfma_bf16(sw[i].m, a_.m, acc[i][j]);
+        if (p == 3) acc[i][j] = mfma_bf16(sw[i].m, a_.h, acc[i][j]);
+        if (p == 4) acc[i][j] = mfma_bf16(sw[i].h, a_.m, acc[i][j]);
+        if (p == 5) acc[i][j] = mfma_bf16(sw[i].h, a_.h, acc[i][j]);
+      }
+  };
+  auto stage_chunks = [&](auto tc, int buf, int k_next) {
+    constexpr int t = decltype(tc)::value;
+    xl_static_for<0, CPS>([&](auto uc) {
+      constexpr int ci = CPS * t + decltype(uc)::value;
+      if constexpr (ci < NCH) {
+        sstore1(std::integral_constant<int, ci>{}, buf ^ 1);
+        gload1(std::integral_constant<int, ci>{}, k_next, fast_c);
+      }
+    });
+  };
   xl_static_for<0, NCH>([&](auto ci) { gload1(ci, 0, fast_c); });
   xl_static_for<0, NCH>([&](auto ci) { sstore1(ci, 0); });
   __syncthreads();
   xl_static_for<0, NCH>([&](auto ci) { gload1(ci, (nk > 1 ? 1 : 0) * 32, fast_c); });
+  rdW(sw0n, xlp_smem + f_lds, 0); rdA(sa[0], xlp_smem + f_lds, 0); rdA(sa[1], xlp_smem + f_lds, 1);
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    const int k_next = (kt + 2 < nk ? kt + 2 : nk - 1) * 32;          // (past the end: the last tile again, no branch)
+    const int k_next = (kt + 2 < nk ? kt + 2 : nk - 1) * 32;
     const u4v* sb = xlp_smem + buf * BUFC + f_lds;
-    Split3 sa[WMB], sw[WNB];
-    auto lds_read = [&](int t) {
-#pragma unroll
-      for (int j = 0; j < WMB; ++j)
-        if (Ord::posA(j) == t) {
-          const u4v* pa = sb + (wm + 16 * j) * 4;
-          sa[j].h = pa[0]; sa[j].m = pa[TR * 4]; sa[j].l = pa[2 * TR * 4];
-        }
-#pragma unroll
-      for (int i = 0; i < WNB; ++i)
-        if (Ord::posW(i) == t) {
-          const u4v* pw = sb + (TM + wn + 16 * i) * 4;
-          sw[i].h = pw[0]; sw[i].m = pw[TR * 4]; sw[i].l = pw[2 * TR * 4];
-        }
-    };
-#pragma unroll
-    for (int t = 0; t < AHEAD; ++t) lds_read(t);
-    xl_static_for<0, Ord::n + 1>([&](auto tc) {
-      constexpr int t = decltype(tc)::value;
-      XL_FENCE();
-      xl_static_for<0, CPS>([&](auto uc) {
-        constexpr int ci = CPS * t + decltype(uc)::value;
-        if constexpr (t < STG && ci < NCH) {
-          sstore1(std::integral_constant<int, ci>{}, buf ^ 1);
-          gload1(std::integral_constant<int, ci>{}, k_next, fast_c);
-        }
-      });
-      if constexpr (t + AHEAD < Ord::n) lds_read(t + AHEAD);
-      // the pairs fragment t - 1 completed; product-major, smallest terms first per accumulator (as gemm_nt_kernel)
-#pragma unroll
-      for (int p = 0; p < 6; ++p)
-#pragma unroll
-        for (int i = 0; i < WNB; ++i)
-#pragma unroll
-          for (int j = 0; j < WMB; ++j) {
-            if (Ord::ready(i, j) != t - 1) continue;
-            if (p == 0) acc[i][j] = mfma_bf16(sw[i].l, sa[j].h, acc[i][j]);
-            if (p == 1) acc[i][j] = mfma_bf16(sw[i].h, sa[j].l, acc[i][j]);
-            if (p == 2) acc[i][j] = mfma_bf16(sw[i].m, sa[j].m, acc[i][j]);
-            if (p == 3) acc[i][j] = mfma_bf16(sw[i].m, sa[j].h, acc[i][j]);
-            if (p == 4) acc[i][j] = mfma_bf16(sw[i].h, sa[j].m, acc[i][j]);
-            if (p == 5) acc[i][j] = mfma_bf16(sw[i].h, sa[j].h, acc[i][j]);
-          }
-    });
+    const u4v* sbn = xlp_smem + (buf ^ 1) * BUFC + f_lds;
+    sw[0] = sw0n;
+    rdW(sw[1], sb, 1); rdW(sw[2], sb, 2);
     XL_FENCE();
-    __syncthreads();
+    stage_chunks(std::integral_constant<int, 0>{}, buf, k_next); rdW(sw[3], sb, 3);
+    mm(sw[0], sa[0], sa[1], acc[0][0], acc[0][1]);
+    XL_FENCE();
+    stage_chunks(std::integral_constant<int, 1>{}, buf, k_next); rdA(sa[2], sb, 2);
+    mm(sw[1], sa[0], sa[1], acc[1][0], acc[1][1]);
+    XL_FENCE();
+    stage_chunks(std::integral_constant<int, 2>{}, buf, k_next); rdA(sa[3], sb, 3);
+    mm(sw[2], sa[0], sa[1], acc[2][0], acc[2][1]);
+    XL_FENCE();
+    mm(sw[3], sa[0], sa[1], acc[3][0], acc[3][1]);
+    XL_FENCE();
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
+    XL_FENCE();
+    rdA(sa[0], sbn, 0); rdA(sa[1], sbn, 1); rdW(sw0n, sbn, 0);
+    mm4(sa[2], 2);
+    XL_FENCE();
+    mm4(sa[3], 3);
+    XL_FENCE();
   }
   };
 #ifdef L2HMC_XL_TIMING
