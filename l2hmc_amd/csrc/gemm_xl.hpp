@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
   constexpr int PA = (TM + RPS - 1) / RPS, PB = (TN + RPS - 1) / RPS, NA = 3 * PA, NB = 3 * PB, NCH = NA + NB;
   u4v rch[NCH];
   const int srow = tid >> 2, sch = tid & 3;
-  const int s_lds = srow * 4 + (sch ^ ((srow >> 2) & 3));             // this thread's chunk inside a 64-row pass
+  const int s_lds = srow * 4 + (sch ^ ((srow >> 2) & 3));             // this thread's chunk inside a pass of RPS rows
   const bool fast = m0 + TM <= g.M;          // (the weight planes hold whole tiles of rows and both row strides whole k-tiles)
   auto gload1 = [&](auto ci_c, int k0, auto fast_c) {
     constexpr int ci = decltype(ci_c)::value;
