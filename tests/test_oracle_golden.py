@@ -330,3 +330,51 @@ def test_torch_cpu_baseline_matches_goldens(case, nxn):
     assert rel_err(Lx.numpy(), g["prop.Lx"]) < TRAJ_TOL
     assert abs_err(px.numpy(), g["prop.px"]) < P_TOL
     check_x_next(x_next.numpy(), g["x"], g["prop.Lx"], g["prop.px"], g["prop.u"], P_TOL)
+
+
+# ---- the bf16x3 arithmetic of the GEMM engine (oracle/bf16x3_oracle.py): claims checked without a GPU ------------------------
+def test_bf16x3_split_is_exact():
+    """x = h + m + l exactly, every term a bf16 number, for fp32 values of every magnitude the decoder sees and well beyond
+    (the split needs 16 more exponent steps below x: true for |x| >= 2^-110)."""
+    from oracle import bf16x3_oracle as B
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.randn(20000), rng.randn(2000) * 1e-20, rng.randn(2000) * 1e20, rng.rand(2000) * 2.0 ** -100,
+                        [0.0, -0.0, 1.0, -1.0, 3.0, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 255.0 + 255.0 / 256, 2.0 ** 100 * (2 - 2.0 ** -23)]]).astype(np.float32)
+    h, m, l = B.split3(x)
+    for t in (h, m, l):
+        assert np.all(t.view(np.uint32) & 0xFFFF == 0)
+    s = (h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64))
+    assert np.array_equal(s, x.astype(np.float64))
+    assert np.array_equal(((h + m).astype(np.float32) + l).astype(np.float32), x)       # ... and in fp32, in the kernels' order
+    # each level is a round-to-nearest: |x - h| <= ulp_bf16(x) / 2 = 2^-8 |x| (2^-9 relative to the next power of two above)
+    nz = x != 0
+    assert np.all(np.abs(x[nz] - h[nz]) <= 2.0 ** -8 * np.abs(x[nz]))
+    assert np.all(np.abs((x - h - m)[nz]) <= 2.0 ** -16 * np.abs(x[nz]))
+
+
+def test_bf16x3_planes_layout_round_trips():
+    """The plane layout the kernels agree on: (3, rows_pad, ld) bf16 bit patterns h | m | l, zero beyond the matrix; h + m + l
+    gives the matrix back bit for bit (784 columns: ld = 800; 784 weight rows: 896)."""
+    from oracle import bf16x3_oracle as B
+    rng = np.random.RandomState(1)
+    W = (rng.randn(784, 1000) * 0.05).astype(np.float32)
+    P = B.to_planes(W, rows_pad=896)
+    assert P.shape == (3, 896, 1024) and P.dtype == np.uint16
+    assert not P[:, 784:, :].any() and not P[:, :, 1000:].any()
+    assert np.array_equal(B.from_planes(P, 784, 1000), W)
+
+
+def test_bf16x3_six_products_are_fp32_accurate_three_are_not():
+    """A decoder-sized contraction (K = 1024, softplus-like activations, 0.05-scale weights) against float64: the six products
+    of weight >= 2^-16 land where an fp32 GEMM lands (a few 1e-6 at |C| ~ 3), the three largest alone are an order of
+    magnitude worse -- why the kernels issue six MFMAs per block and not three."""
+    from oracle import bf16x3_oracle as B
+    rng = np.random.RandomState(2)
+    A = (rng.rand(96, 1024) * 2.0 - 0.5).astype(np.float32)
+    W = ((rng.rand(80, 1024) - 0.5) * 0.1).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    e6 = np.abs(B.gemm_nt(A, W, B.SIX) - ref).max()
+    e3 = np.abs(B.gemm_nt(A, W, B.THREE) - ref).max()
+    e32 = np.abs((A @ W.T).astype(np.float64) - ref).max()
+    print("K = 1024: max |err| vs float64: six products %.2e, three %.2e, fp32 GEMM %.2e (|C| <= %.2f)" % (e6, e3, e32, np.abs(ref).max()))
+    assert e6 < 4e-6 and e6 < 3 * e32 + 1e-6 and e3 > 5 * e6
