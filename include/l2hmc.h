@@ -308,6 +308,14 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* args, void* stream);
 int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x, int64_t n_chains,
                      int32_t d, float* U_out, float* grad_out, float* workspace, float bce_scale, void* stream);
 
+/* The operand form of gemm_mode 1 at decoder sizes, exposed for inspection and tests: the exact three-way bf16 split
+ * x = h + m + l (round-to-nearest-even at each level) of the fp32 matrix W (rows x K, row stride ld) as three planes of
+ * rows_pad x ld_planes bf16 bit patterns (uint16), plane p at planes + p * rows_pad * ld_planes, zero beyond the matrix
+ * (rows_pad >= rows; ld_planes >= K, a multiple of 4).  This is what l2hmc_trajectory_split converts the decoder weights
+ * to once per call (csrc/gemm_xl.hpp); oracle/bf16x3_oracle.py restates it in numpy. */
+int l2hmc_bf16_planes(const float* W, int32_t ld, int64_t rows, int32_t K, uint16_t* planes, int64_t rows_pad,
+                      int32_t ld_planes, void* stream);
+
 /* Dynamics.p_accept (dynamics.py:302-309) for energies evaluated separately (l2hmc_vae_energy):
  * p = exp(min(U0 + |v0|^2/2 - U1 - |v1|^2/2 + log_jac, 0)), non-finite -> 0. */
 int l2hmc_p_accept_energies(const float* U0, const float* v0, const float* U1, const float* v1, const float* log_jac,

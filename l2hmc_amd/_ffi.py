@@ -112,6 +112,7 @@ SYMBOLS = {
     "l2hmc_abi_version": (C.c_int, []),
     "l2hmc_last_error": (C.c_char_p, []),
     "l2hmc_last_kernel": (C.c_int32, [C.c_char_p, C.c_int32]),
+    "l2hmc_bf16_planes": (C.c_int, [_fp, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "l2hmc_struct_bytes": (C.c_int64, [C.c_int32]),
     "l2hmc_packed_nets_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "l2hmc_pack_nets": (C.c_int, [C.POINTER(L2hmcNet), C.POINTER(L2hmcNet), C.c_int32, C.c_int32,

@@ -392,6 +392,14 @@ int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int
   return plan_split(n_chains, d, H, T, aux_encoder, decoder).total;
 }
 
+int l2hmc_bf16_planes(const float* W, int32_t ld, int64_t rows, int32_t K, uint16_t* planes, int64_t rows_pad, int32_t ld_planes,
+                      void* stream) {
+  if (!W || !planes || rows < 1 || K < 1 || ld < K || rows_pad < rows || ld_planes < K || (ld_planes & 3))
+    return fail(L2HMC_ERR_ARG, "l2hmc_bf16_planes: bad argument%s");
+  to_planes((hipStream_t)stream, W, ld, rows, K, planes, rows_pad, ld_planes);
+  return L2HMC_OK;
+}
+
 int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x, int64_t n_chains, int32_t d,
                      float* U_out, float* grad_out, float* workspace, float bce_scale, void* stream) {
   t_gemm_bf3 = 0;

@@ -246,3 +246,24 @@ def test_config5_on_presplit_planes(N):
     Lx0, _, px0, _ = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(g["v"]), u=to_dev(u), aux=aux)
     assert _ffi.last_kernel() == "gemm_nt_kernel"
     assert rel_err(to_np(Lx), to_np(Lx0)) < 2e-4 and abs_err(to_np(px), to_np(px0)) < 1e-4
+
+
+def test_device_bf16_planes_equal_the_numpy_restatement():
+    """`l2hmc_bf16_planes` (= `to_planes` of csrc/gemm_xl.hpp, what the GEMM engine turns the decoder weights into) against
+    oracle/bf16x3_oracle.py bit for bit: the round-to-nearest-even three-way split, the plane order h | m | l, the zero padding
+    of rows and columns -- incl. magnitudes from 1e-30 to 1e30, zeros and a ragged K (1000 -> row stride 1024)."""
+    import torch
+    from l2hmc_amd import _ffi
+    from oracle import bf16x3_oracle as B
+    rng = np.random.RandomState(7)
+    rows, K, rows_pad, ldp = 300, 1000, 384, 1024
+    W = (rng.randn(rows, K) * np.exp(rng.uniform(-69, 69, size=(rows, 1)))).astype(np.float32)
+    W[5, :7] = 0.0
+    W[6, 3] = -0.0
+    dW = to_dev(W)
+    P = torch.full((3, rows_pad, ldp), 0x7FFF, dtype=torch.int16, device=dW.device)          # poison: the padding must be WRITTEN
+    _ffi.check(_ffi.lib().l2hmc_bf16_planes(dW.data_ptr(), K, rows, K, P.data_ptr(), rows_pad, ldp, _ffi.current_stream(dW.device)))
+    got = P.cpu().numpy().view(np.uint16)
+    ref = B.to_planes(W, rows_pad=rows_pad, ld=ldp)
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    assert np.array_equal(B.from_planes(got, rows, K), W)
