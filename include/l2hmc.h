@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define L2HMC_ABI_VERSION 4
+#define L2HMC_ABI_VERSION 5
 
 enum {
   L2HMC_OK = 0,
@@ -61,7 +61,11 @@ typedef struct L2hmcNet {
  *   GAUSS_DENSE: mu (d), prec = buffer written by l2hmc_pack_gaussian (n_comp = 1)
  *   GMM        : mu (n_comp, d), prec = n_comp packed precisions back to back
  *                (stride l2hmc_packed_gaussian_floats(d)), logc (n_comp) = log(pi_i / sqrt((2 pi)^d det Sigma_i))
- *   ROUGHWELL  : eta, easy (distributions.py:84-97: U = |x|^2/2 + eta sum cos(x / eta^2), or x / eta if easy)
+ *   ROUGHWELL  : eta, easy (distributions.py:84-97: U = |x|^2/2 + eta sum cos(x / eta^2), or x / eta if easy);
+ *                den = the divisor of the cosine argument as the reference rounds it: the Python-DOUBLE product
+ *                eps * eps (or eps if easy) converted to float32 ONCE (`x / (self.eps * self.eps)`, :93).  A binding
+ *                that holds the caller's double passes float(eps * eps); 0 = derive from the float `eta`
+ *                (identical whenever eps is exactly a float; last-bit different for e.g. eps = 0.1)
  *   FUNNEL     : eta = sigma (distributions.py:155-180; clip = 4 sigma)
  * temperature divides U and grad U (dynamics.py:204-212); 1.0 when unused.
  * anneal_beta in (0, 1): the AIS bridge of utils/ais.py:46-47 with the standard-normal initial
@@ -76,6 +80,8 @@ typedef struct L2hmcEnergy {
   int32_t easy;
   float temperature;
   float anneal_beta;
+  float den;               /* ROUGHWELL only (ABI 5); 0 = derive from eta */
+  int32_t reserved_;       /* keeps the struct a multiple of 8 bytes; must be 0 */
 } L2hmcEnergy;
 
 /* Arguments of l2hmc_trajectory (passed by pointer; a HOST struct of device pointers). */

@@ -27,7 +27,8 @@ class L2hmcNet(C.Structure):
 class L2hmcEnergy(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_comp", C.c_int32), ("mu", _fp), ("prec", _fp),
                 ("logc", _fp), ("eta", C.c_float), ("easy", C.c_int32),
-                ("temperature", C.c_float), ("anneal_beta", C.c_float)]
+                ("temperature", C.c_float), ("anneal_beta", C.c_float),
+                ("den", C.c_float), ("reserved_", C.c_int32)]
 
 
 class L2hmcTrajectoryArgs(C.Structure):
@@ -155,7 +156,7 @@ SYMBOLS = {
                              _fp, _fp]),
 }
 
-ABI_VERSION = 4          # L2HMC_ABI_VERSION this binding was written against
+ABI_VERSION = 5          # L2HMC_ABI_VERSION this binding was written against
 _lib = None
 
 

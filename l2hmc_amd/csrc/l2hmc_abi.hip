@@ -407,6 +407,7 @@ void fill_energy(KArgs& k, const L2hmcEnergy* e) {
   k.prec = e->prec;
   k.logc = e->logc;
   k.eta = e->eta;
+  k.den = roughwell_den(e);
   k.temperature = e->temperature;
   k.beta = e->anneal_beta > 0.f ? e->anneal_beta : 1.f;
 }

@@ -44,6 +44,13 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr bool weights_in_global(int DT) { return DT >= 4; }
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0);
+// Rough Well (distributions.py:93): the divisor of the cosine argument.  The reference forms the Python-DOUBLE product
+// eps * eps and TF rounds it to float32 once; a binding that holds the double passes that float in L2hmcEnergy.den.  den = 0:
+// derived here from the float eta (the exact product of two floats rounded once -- the same value whenever eta is a float).
+inline float roughwell_den(const L2hmcEnergy* e) {
+  if (e->den > 0.f) return e->den;
+  return e->easy ? e->eta : (float)((double)e->eta * (double)e->eta);
+}
 void note_kernel(const char* fmt, long long a = 0, long long b = 0, long long c = 0, long long d = 0);   // -> l2hmc_last_kernel
 
 // Debug builds with -DL2HMC_LDS_POISON (tools/build_variant_full.sh poison -DL2HMC_LDS_POISON): every kernel that works out of
@@ -107,6 +114,7 @@ struct KArgs {
   int ekind, ncomp, easy;
   const float *mu, *prec, *logc;
   float eta, temperature;
+  float den;                 // Rough Well: the divisor of the cosine argument (L2hmcEnergy.den, or derived from eta in float32)
   float beta;                // AIS bridge (utils/ais.py:46-47): U := (1 - beta) |x|^2 / 2 + beta U;  1 = off
   // p_accept-only kernel inputs
   const float *x1, *v1, *logjac_in;
@@ -484,7 +492,7 @@ __device__ __forceinline__ void grad_energy(const KArgs& A, float* smem, int w, 
   } else if constexpr (EK == L2HMC_ENERGY_ROUGHWELL) {
     {
       const float eta = A.eta;
-      const float den = A.easy ? eta : eta * eta;
+      const float den = A.den;
       const float scale = eta / den;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {

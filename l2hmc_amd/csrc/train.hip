@@ -58,7 +58,7 @@ struct TArgs {
   int ekind;                 // GAUSS_DIAG: prec = (d) | GAUSS_DENSE: raw (d, d) | GMM: raw (k, d, d)
   int ncomp, easy;
   const float *mu, *prec, *logc;
-  float eta;
+  float eta, den;            // den: Rough-Well divisor (L2hmcEnergy.den, or derived from eta in float32)
   float scale, inv_n;
   float *Lx, *p, *v1, *grad, *ws;
   // l2hmc_train_step: chains [0, n_head) start from x_head (n_head = 0: all from x)
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(TTHREADS) void train_kernel(const TArgs A) {
 
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
-  const float rw_den = A.easy ? A.eta : A.eta * A.eta;
+  const float rw_den = A.den;
   const bool EL = ek == L2HMC_ENERGY_GAUSS_DIAG || ek == L2HMC_ENERGY_ROUGHWELL;   // elementwise grad / Hessian
   float deps = 0.f;           // this thread's share of d loss / d eps
   int s_me = 0;               // step index of this thread's chain at iteration X.it
@@ -1089,6 +1089,7 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
   k.dir = a->direction; k.dir_all = a->direction_all; k.ekind = a->energy.kind;
   k.mu = a->energy.mu; k.prec = a->energy.prec; k.logc = a->energy.logc; k.eta = a->energy.eta;
   k.ncomp = ek == L2HMC_ENERGY_GMM ? a->energy.n_comp : 1; k.easy = a->energy.easy;
+  k.den = roughwell_den(&a->energy);
   k.scale = a->scale; k.inv_n = a->inv_n;
   k.Lx = a->Lx; k.p = a->p; k.v1 = a->v1; k.grad = a->grad; k.ws = a->workspace;
   k.x_head = st ? st->x_head : nullptr; k.n_head = st ? st->n_head : 0;

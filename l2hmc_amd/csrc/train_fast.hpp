@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   const float sg = isf ? 1.f : -1.f;
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
-  const float rw_den = A.easy ? A.eta : A.eta * A.eta;
+  const float rw_den = A.den;
   const f4 Z = splat(0.f);
   constexpr int W_TAU = NW > 1 ? 1 : 0;          // the wave that accumulates the time-embedding gradient rows
 

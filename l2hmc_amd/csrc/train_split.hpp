@@ -163,7 +163,7 @@ __global__ void k_comb_v2(float* lx, const float* dAB, const float* hv, long lon
 // Hessian-vector products of the built-in targets (oracle/l2hmc_train_oracle.py *Target.hessvec): diagonal Gaussian
 // P u; Rough Well (1 - (eta / den^2) cos(x / den)) u; dense Gaussian G u with G = (S + S^T) / 2 of the RAW precision
 __global__ void k_hvp_builtin(int kind, const float* x, int ldx, const float* u, float* hv, const float* prec,
-                              const float* hess, float eta, int easy, long long N, int d) {
+                              const float* hess, float eta, float den, long long N, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * d) return;
   const long long n = i / d;
@@ -172,7 +172,6 @@ __global__ void k_hvp_builtin(int kind, const float* x, int ldx, const float* u,
   if (kind == L2HMC_ENERGY_GAUSS_DIAG) {
     o = prec[k] * u[i];
   } else if (kind == L2HMC_ENERGY_ROUGHWELL) {
-    const float den = easy ? eta : eta * eta;
     o = (1.f - (eta / (den * den)) * cosf(x[n * ldx + k] / den)) * u[i];
   } else {
     o = 0.f;
@@ -846,7 +845,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
                          a->energy->logc, a->energy->n_comp, a->energy->eta, N, d);      // (dg is free: its sum went into uu)
     } else {
       hipLaunchKernelGGL(k_hvp_builtin, dim3(nblk(Nd)), dim3(256), 0, s, a->energy->kind, ab, L, uu, hv, a->energy->prec,
-                         a->hess, a->energy->eta, a->energy->easy, N, d);
+                         a->hess, a->energy->eta, a->energy->kind == L2HMC_ENERGY_ROUGHWELL ? roughwell_den(a->energy) : 1.f, N, d);
     }
     hipLaunchKernelGGL(k_comb_v2, dim3(nblk(Nd)), dim3(256), 0, s, lx, dAB, hv, N, d);
     return L2HMC_OK;

@@ -103,7 +103,7 @@ __device__ __forceinline__ float lane_grad(const KArgs& A, const float* __restri
       U = fmaf(0.5f * dx, pk * dx, U);
     }
   } else if constexpr (EK == L2HMC_ENERGY_ROUGHWELL) {
-    const float eta = A.eta, den = A.easy ? eta : eta * eta, scale = eta / den;
+    const float eta = A.eta, den = A.den, scale = eta / den;
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
       const float arg = x[k] / den, lv = k < d ? 1.f : 0.f;

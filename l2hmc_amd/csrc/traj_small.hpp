@@ -64,7 +64,7 @@ __device__ __forceinline__ float grad_small(const KArgs& A, const float* smem, c
     g = gacc / ssum;
     if (lane < 16) U = -(m + logf(ssum));
   } else if constexpr (EK == L2HMC_ENERGY_ROUGHWELL) {
-    const float den = A.easy ? A.eta : A.eta * A.eta;
+    const float den = A.den;
     const float arg = x / den;
     g = x - (A.eta / den) * rw_sin1(arg);
     if (wantU) U = livedim ? 0.5f * x * x + A.eta * rw_cos1(arg) : 0.f;

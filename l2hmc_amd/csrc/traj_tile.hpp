@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
   const float* fwv = fwx + FWN;
   const float* fcx = smem + A.o_fc;
   const float* fcv = fcx + FCN;
-  const float rw_den = A.easy ? A.eta : A.eta * A.eta;
+  const float rw_den = A.den;
 
   auto grad_t = [&](f4 xx, int t) {
     if (EK == L2HMC_ENERGY_GAUSS_DIAG) return prec_of(t) * (xx - mu_of(t));

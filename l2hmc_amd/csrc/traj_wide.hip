@@ -46,7 +46,7 @@ __device__ __forceinline__ f4 wide_grad(const KArgs& A, const float* smem, int t
     g = s * dx;
     if (wantU) u = 0.5f * hsum(dx * g);
   } else {
-    const float eta = A.eta, den = A.easy ? eta : eta * eta, scale = eta / den;
+    const float eta = A.eta, den = A.den, scale = eta / den;
     const f4 arg = x / den;
     g = x - scale * rw_sin4(arg);
     if (wantU) {                           // (wave-uniform: only the end points of a trajectory need U)

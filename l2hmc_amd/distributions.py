@@ -21,6 +21,8 @@ class EnergyFunction(object):
                  easy=False):
         self.kind, self.x_dim, self.n_comp = kind, x_dim, n_comp
         self.eta, self.easy = float(eta), bool(easy)
+        # Rough Well: the reference divides by the Python-double product eps * eps, rounded to float32 once (distributions.py:93)
+        self.den = float(np.float32(self.eta if self.easy else self.eta * self.eta)) if kind == _ffi.ENERGY_ROUGHWELL else 0.0
         self._host = {'mu': mu, 'prec': prec, 'logc': logc}
         self._dev = {}
 
@@ -57,7 +59,7 @@ class EnergyFunction(object):
         b = self._buffers(device)
         return _ffi.L2hmcEnergy(self.kind, self.n_comp, _ffi.ptr(b['mu']), _ffi.ptr(b['prec']),
                                 _ffi.ptr(b['logc']), self.eta, int(self.easy), float(temperature),
-                                float(anneal_beta))
+                                float(anneal_beta), self.den, 0)
 
     def evaluate(self, x, temperature=1.0, want_U=True, want_grad=False, anneal_beta=0.0):
         x = as_device_f32(x)

@@ -183,7 +183,7 @@ class Trainer(object):
         a = _ffi.L2hmcTrainArgs()
         a.xnet, a.vnet = C.pointer(xs), C.pointer(vs)
         a.energy = _ffi.L2hmcEnergy(fn.kind, fn.n_comp, _ffi.ptr(buf["mu"]), _ffi.ptr(prec), _ffi.ptr(buf["logc"]),
-                                    fn.eta, int(fn.easy), 1.0)
+                                    fn.eta, int(fn.easy), 1.0, 0.0, fn.den, 0)
         a.masks, a.trig = dyn._mask.data_ptr(), dyn._trig.data_ptr()
         if dyn.eps_override is None:
             a.alpha, a.eps_host = dyn.alpha.data_ptr(), 0.0

@@ -155,24 +155,23 @@ class GMM:
 
 
 class RoughWell:
-    """distributions.py:84-97.  U = 0.5|x|^2 + eta sum cos(x/eta^2)   (or x/eta if easy)."""
+    """distributions.py:84-97.  U = 0.5|x|^2 + eta sum cos(x/eta^2)   (or x/eta if easy).
+    `eta` is the Python double the caller hands the reference; the divisor is formed like there: the DOUBLE product
+    eta * eta rounded to the working precision once (`x / (self.eps * self.eps)`, :93 -- TF converts the Python scalar to
+    a float32 constant), not float32(eta) squared in float32 (the two differ in the last bit for e.g. eta = 0.1)."""
 
     def __init__(self, eta, easy=False, dtype=np.float32):
         self.eta = dtype(eta)
+        self.den = dtype(float(eta)) if easy else dtype(float(eta) * float(eta))
         self.easy = easy
         self.dtype = dtype
 
     def __call__(self, x):
-        eta = self.eta
+        eta, den = self.eta, self.den
         n = np.sum(np.square(x), axis=1)
-        if not self.easy:
-            arg = x / (eta * eta)
-            scale = eta / (eta * eta)
-        else:
-            arg = x / eta
-            scale = eta / eta
+        arg = x / den
         U = 0.5 * n + eta * np.sum(np.cos(arg), axis=1)
-        g = x - scale * np.sin(arg)
+        g = x - (eta * np.sin(arg)) / den          # the graph's gradient: (-sin(arg) * eta) / den, TF's RealDiv gradient
         return U.astype(self.dtype), g.astype(self.dtype)
 
 

@@ -157,7 +157,7 @@ class RoughWellTarget:
 
     def __init__(self, eta, easy, dtype):
         self.eta = dtype(eta)
-        self.den = self.eta if easy else self.eta * self.eta
+        self.den = dtype(float(eta)) if easy else dtype(float(eta) * float(eta))     # the double product rounded once (distributions.py:93)
 
     def energy(self, x):
         return 0.5 * np.sum(x * x, axis=1) + self.eta * np.sum(np.cos(x / self.den), axis=1)
@@ -216,7 +216,7 @@ def target_of(g, dtype=np.float64):
     if kind == 'gmm':
         return GMMTarget(g['energy.mus'], g['energy.i_sigmas'], g['energy.constants'], dtype)
     if kind == 'roughwell':
-        return RoughWellTarget(float(g['energy.eta']), bool(g['energy.easy']), dtype)
+        return RoughWellTarget(float(g['energy.eta64']) if 'energy.eta64' in g else float(g['energy.eta']), bool(g['energy.easy']), dtype)
     if kind == 'funnel':
         return FunnelTarget(float(g['energy.sigma']), dtype)
     raise ValueError(kind)

@@ -3,8 +3,8 @@
 TEST INFRASTRUCTURE.  Run here (never on the GPU box -- /root/reference does not exist
 there):
 
-    python oracle/make_goldens.py            # writes ALL of tests/golden/*.npz (36 files; bit-reproducible)
-    python oracle/make_goldens.py ais|wide|train_funnel|train_vae|train_vae_extra|train_wide|ess   # only that group
+    python oracle/make_goldens.py            # writes ALL of tests/golden/*.npz (44 files; bit-reproducible)
+    python oracle/make_goldens.py ais|wide|train_funnel|train_vae|train_vae_extra|train_wide|ess|rough_ne   # only that group
     L2HMC_GOLDEN_OUT=/tmp/gold python oracle/make_goldens.py                  # elsewhere, to diff against the committed set
 
 How: ``oracle/tf1_stub.py`` is registered as ``tensorflow``; ``/root/reference/utils`` is
@@ -696,9 +696,48 @@ def ess_case():
     print('ess_funcutils      Tm=%d N=%d d=%d  ESS %.5f' % (Tm, N, d, out['ess']))
 
 
+def rough_ne_cases():
+    """The reference's DEFAULT Rough Well (distributions.py:84-97, `easy=False`: cos(x / eps^2)) at the scale BASELINE config 4's
+    second series is benchmarked on: eta = 1e-2, arguments ~ 1e4 x.  Step sizes are the ones bench.py's pilot tunes for these
+    widths (profiles/r04_bench_steps20.json: 7.8e-3 / 1.7e-3 / 3.6e-4): the curvature of this target is eta^-3 = 1e6, so a
+    leapfrog step is only stable -- and two float32 evaluations of it only comparable -- for eps < 2e-3 sqrt(...) of that order.
+    The first 16 chains start inside |x| < 1.29 (every argument below the 8192 pi/2 switch of the kernels' range reduction),
+    the others on both sides of it.  `energy.den` = the divisor as the reference forms it: the Python-double product
+    eps * eps rounded to float32 ONCE (`x / (self.eps * self.eps)`, :93); `energy.eta64` = the double the caller passed.
+    rough8_eta01: eta = 0.1, where float32(0.1)^2 in float32 and float32(0.1 * 0.1) differ in the last bit."""
+    for nm, d, eta, eps, N, seed in (('rough2_ne', 2, 1e-2, 3e-4, 64, 71), ('rough50_ne', 50, 1e-2, 3e-4, 64, 72),
+                                     ('rough512_ne', 512, 1e-2, 3.63e-4, 32, 73), ('rough8_eta01', 8, 0.1, 0.02, 64, 74)):
+        rw = ref_distributions.RoughWell(d, eta, easy=False)
+        params = {'energy.kind': 'roughwell', 'energy.eta': np.float32(eta), 'energy.easy': np.int32(0),
+                  'energy.den': np.float32(eta * eta), 'energy.eta64': np.float64(eta)}
+        rng = np.random.RandomState(seed)
+        x0 = rng.randn(N, d)
+        x0[:16] = np.clip(0.3 * x0[:16], -1.25, 1.25)
+        run_case(nm, d, H=10, T=10, eps=eps, N=N, energy_fn=rw.get_energy_function(), energy_params=params, seed=seed,
+                 head_std=0.5, x0=x0.astype(np.float32))
+
+
+def train_rough_ne_cases():
+    """training gradients through the non-easy Rough Well's Hessian (1 - eta^-3 cos(x / eta^2)): eta = 0.05, arguments 400 x,
+    curvature 8000 => eps = 0.01.  One case per trainer: d = 2 (one dimension per lane), d = 6 (register-resident, one wave;
+    also the general kernel), d = 50 (register-resident, four waves), d = 6 with 20-wide nets (GEMM engine)."""
+    for nm, d, H, N, seed in (('train_rough2_ne', 2, 10, 32, 81), ('train_rough6_ne', 6, 10, 32, 82),
+                              ('train_rough50_ne', 50, 10, 16, 83), ('train_rough6_ne_h20', 6, 20, 32, 84)):
+        eta = 0.05
+        with contextlib.redirect_stdout(io.StringIO()):
+            rw_t = ref_distributions.RoughWell(d, eta, easy=False)
+        train_case(nm, np.zeros(d), None, H=H, T=5, eps=0.01, N=N, seed=seed, head_std=0.3, dist=rw_t,
+                   params={'energy.kind': 'roughwell', 'energy.eta': np.float32(eta), 'energy.easy': np.int32(0),
+                           'energy.den': np.float32(eta * eta), 'energy.eta64': np.float64(eta)},
+                   x_start=lambda rng, N=N, d=d: rng.randn(N, d))
+
+
 def main():
     if sys.argv[1:] == ['ess']:
         return ess_case()
+    if sys.argv[1:] == ['rough_ne']:             # only the non-easy Rough-Well fixtures
+        rough_ne_cases()
+        return train_rough_ne_cases()
     if sys.argv[1:] == ['train_funnel']:         # only this fixture
         return train_funnel_case()
     if sys.argv[1:] == ['ais']:                  # only the AIS fixtures (leaves the other files untouched)
@@ -824,6 +863,8 @@ def main():
     train_vae_case('train_vae_small', latent=10, H=24, dec_h=48, n_pix=40, enc_h=32, T=4, eps=0.1, N=32, seed=43)
     train_vae_extra_cases()
     train_wide_cases()
+    rough_ne_cases()
+    train_rough_ne_cases()
 
 
 if __name__ == '__main__':

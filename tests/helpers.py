@@ -27,12 +27,72 @@ def oracle_energy(g, dtype=np.float32):
     if kind == "gmm":
         return O.GMM(g["energy.mus"], g["energy.i_sigmas"], g["energy.constants"], dtype)
     if kind == "roughwell":
-        return O.RoughWell(float(g["energy.eta"]), bool(g["energy.easy"]), dtype)
+        return O.RoughWell(rough_eta(g), bool(g["energy.easy"]), dtype)
     if kind == "funnel":
         return O.GaussianFunnel(float(g["energy.sigma"]), dtype)
     if kind == "vae":
         return O.VAEPosterior(mlp_weights(g, "dec."), g["aux"], dtype)
     raise ValueError(kind)
+
+
+def rough_eta(g):
+    """the Python double the reference's caller passed (newer fixtures keep it; the older ones' etas are float32-exact in effect)"""
+    return float(g["energy.eta64"]) if "energy.eta64" in g else float(g["energy.eta"])
+
+
+def stiffness(g):
+    """Curvature amplitude of the Rough Well's cosine term, eta / den^2 (= eta^-3 for the reference's default form): the
+    factor by which an error in x comes back through grad U.  >= 1e3 marks the STIFF fixtures (rough*_ne, rough8_eta01,
+    train_rough*_ne): two float32 evaluations of the same T-step map then differ by (ulps of x) * curvature * eps per step,
+    amplified by ~exp(eps sqrt(curvature)) per step -- far above the 3e-5 / 1e-4 gates of the well-conditioned cases, for
+    the reference's own arithmetic as much as for any restatement of it."""
+    if str(g["energy.kind"]) != "roughwell":
+        return 0.0
+    eta = rough_eta(g)
+    den = eta if bool(g["energy.easy"]) else eta * eta
+    return eta / (den * den)
+
+
+def is_stiff(g):
+    return stiffness(g) >= 1e3
+
+
+_ORACLE_DISTANCE = {}
+
+
+def oracle_distance(case):
+    """How far the float32 numpy oracle lands from a STIFF fixture (the reference's own float32 run), per stored output:
+    the yardstick of the GPU gates for these cases -- `stiff_tol`.  Both are float32 evaluations of the same op sequence,
+    so this distance IS the conditioning of the map at float32, measured rather than bounded."""
+    if case not in _ORACLE_DISTANCE:
+        g = load(case)
+        d = oracle_dynamics(g)
+        x, v = g["x"], g["v"]
+        out = {}
+        with np.errstate(all="ignore"):
+            for s in g["steps"]:
+                f = d.forward_step(x, v, np.float32(s))
+                b = d.backward_step(x, v, np.float32(s))
+                for pre, r in (("fstep%d" % s, f), ("bstep%d" % s, b)):
+                    for key, val in zip((".x", ".v", ".logdet"), r):
+                        out[pre + key] = rel_err(val, g[pre + key])
+            for nm, fn in (("fwd", d.forward), ("bwd", d.backward)):
+                X, V, lj = fn(x, v, log_jac=True)
+                p = fn(x, v)[2]
+                out[nm + ".x"], out[nm + ".v"] = rel_err(X, g[nm + ".x"]), rel_err(V, g[nm + ".v"])
+                out[nm + ".logjac"], out[nm + ".p"] = rel_err(lj, g[nm + ".logjac"]), abs_err(p, g[nm + ".p"])
+            Lx, _, px, _ = O.propose(x, d, g["prop.v_fwd"], g["prop.v_bwd"], g["prop.dir"], g["prop.u"])
+            out["prop.Lx"], out["prop.px"] = rel_err(Lx, g["prop.Lx"]), abs_err(px, g["prop.px"])
+        _ORACLE_DISTANCE[case] = out
+    return _ORACLE_DISTANCE[case]
+
+
+def stiff_tol(case, g, key, base):
+    """Gate of a GPU-vs-fixture comparison: `base` (the suite's 3e-5 / 1e-4 / 1e-4) for the well-conditioned fixtures; for a
+    STIFF one, 4x the float32 oracle's own distance to the same fixture value, never below `base`."""
+    if not is_stiff(g):
+        return base
+    return max(base, 4.0 * oracle_distance(case)[key])
 
 
 def mlp_weights(g, prefix):
@@ -99,7 +159,7 @@ def hip_energy(g):
         obj.nb_mixtures, obj.k = len(obj.mus), obj.mus[0].shape[0]
         return obj.get_energy_function()
     if kind == "roughwell":
-        return D.RoughWell(int(g["x_dim"]), float(g["energy.eta"]), bool(g["energy.easy"])).get_energy_function()
+        return D.RoughWell(int(g["x_dim"]), rough_eta(g), bool(g["energy.easy"])).get_energy_function()
     if kind == "funnel":
         return D.GaussianFunnel(int(g["x_dim"])).get_energy_function()
     if kind == "vae":
@@ -194,6 +254,9 @@ def synthetic_case(kind, d, H=10, T=10, N=64, seed=0, eps=0.1, head_std=0.3):
                   "energy.i_sigma": prec.astype(np.float32)})
     elif kind == "roughwell_easy":
         g.update({"energy.kind": "roughwell", "energy.eta": np.float32(0.1), "energy.easy": np.int32(1)})
+    elif kind == "roughwell_ne":                     # the reference's default form at BASELINE config 4's second series
+        g.update({"energy.kind": "roughwell", "energy.eta": np.float32(1e-2), "energy.easy": np.int32(0),
+                  "energy.eta64": np.float64(1e-2)})
     elif kind.startswith("gmm"):                     # "gmm<K>": K components, slightly non-symmetric raw precisions
         K = int(kind[3:] or 2)
         mus, i_sigmas, consts = [], [], []

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_size_queries():
     L = _ffi.lib()
-    assert L.l2hmc_abi_version() == 4 == _ffi.ABI_VERSION
+    assert L.l2hmc_abi_version() == 5 == _ffi.ABI_VERSION
     hdr = open(os.path.join(ROOT, "include", "l2hmc.h")).read()
     assert int(re.search(r"#define L2HMC_ABI_VERSION (\d+)", hdr).group(1)) == _ffi.ABI_VERSION
     # MFMA fragments (5 NT + 2 groups of 256 + 32 NT scales per net) + the lane layout (traj_lane.hpp: rows of RS = 12)
@@ -61,9 +61,9 @@ def test_argument_validation_without_gpu():
 def test_struct_layout_matches_header():
     # field order / sizes of the ctypes mirrors (x86-64: pointers 8, ints 4, natural alignment)
     assert ctypes.sizeof(_ffi.L2hmcNet) == 16 * 8
-    assert ctypes.sizeof(_ffi.L2hmcEnergy) == 48
+    assert ctypes.sizeof(_ffi.L2hmcEnergy) == 56
     assert _ffi.L2hmcTrajectoryArgs.energy.offset == 8
-    assert _ffi.L2hmcTrajectoryArgs.n_chains.offset == 8 + 48 + 3 * 8 + 8
+    assert _ffi.L2hmcTrajectoryArgs.n_chains.offset == 8 + 56 + 3 * 8 + 8
     assert _ffi.L2hmcTrajectoryArgs.ais_alpha.offset == ctypes.sizeof(_ffi.L2hmcTrajectoryArgs) - 8
     assert _ffi.L2hmcTrajectoryArgs.ais_beta.offset == _ffi.L2hmcTrajectoryArgs.chain_offset.offset + 8
     assert _ffi.L2hmcTrajectoryArgs.rng_seed.offset == _ffi.L2hmcTrajectoryArgs.x_hist.offset + 16

@@ -4,13 +4,15 @@ own modules produced, and against the CPU oracle on the same seeded inputs.
 Tolerances (fp32, stated per north_star): positions / momenta / log-det within 1e-4 of
 max(1,|ref|) after a full T-step trajectory (single steps: 3e-5); accept probability within
 1e-4 absolute.  Both sides are fp32 evaluations of the same real-valued map whose mutual
-distance is a few ulp per step amplified by the dynamics (measured: see DESIGN.md)."""
+distance is a few ulp per step amplified by the dynamics (measured: see DESIGN.md).
+The STIFF fixtures (the reference's default Rough Well at eta = 1e-2: curvature 1e6, tests/helpers.py `stiffness`) are
+gated at max(those, 4x the float32 numpy oracle's own distance to the same reference-run value): `stiff_tol`."""
 import numpy as np
 import pytest
 
 from oracle import l2hmc_oracle as O
 from tests.helpers import (CASES, abs_err, aux_of, check_x_next, hip_dynamics, load, oracle_dynamics, rel_err,
-                           to_dev, to_np)
+                           stiff_tol, to_dev, to_np)
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +29,8 @@ def variants(g):
     lane = not int(g["hmc"]) and int(g["H"]) <= 15 and kind in ("gaussian", "gmm", "roughwell") and d <= 4
     if d <= 16:
         return [0, 100] + ([32] if lane else [])
+    if d > 128:          # 0: the LDS-resident-state kernel; 4 / 104: eight dim-tiles per wave on the register-resident kernels
+        return [0, 4, 104]
     # 16: one wave per tile (many-chains form; elementwise targets with S/T/Q nets, 33 <= d <= 64)
     tile = 33 <= d <= 64 and not int(g["hmc"]) and int(g["H"]) <= 15 and (
         str(g["energy.kind"]) == "roughwell" or (str(g["energy.kind"]) == "gaussian" and
@@ -54,7 +58,7 @@ def test_single_steps(case):
             xb, vb, ljb = dyn._backward_step(x, v, int(s), aux=aux_of(g))
             for got, key in ((xo, "fstep%d.x"), (vo, "fstep%d.v"), (lj, "fstep%d.logdet"),
                              (xb, "bstep%d.x"), (vb, "bstep%d.v"), (ljb, "bstep%d.logdet")):
-                assert rel_err(to_np(got), g[key % s]) < STEP_TOL, (case, var, key % s)
+                assert rel_err(to_np(got), g[key % s]) < stiff_tol(case, g, key % s, STEP_TOL), (case, var, key % s)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -67,12 +71,12 @@ def test_trajectories_and_accept_prob(case):
             X, V, lj = fn(x, init_v=v, log_jac=True, aux=aux_of(g))
             X2, V2, p = fn(x, init_v=v, aux=aux_of(g))
             assert np.array_equal(to_np(X), to_np(X2), equal_nan=True)
-            assert rel_err(to_np(X), g[nm + ".x"]) < TRAJ_TOL, (case, var, nm)
-            assert rel_err(to_np(V), g[nm + ".v"]) < TRAJ_TOL, (case, var, nm)
-            assert rel_err(to_np(lj), g[nm + ".logjac"]) < TRAJ_TOL, (case, var, nm)
+            assert rel_err(to_np(X), g[nm + ".x"]) < stiff_tol(case, g, nm + ".x", TRAJ_TOL), (case, var, nm)
+            assert rel_err(to_np(V), g[nm + ".v"]) < stiff_tol(case, g, nm + ".v", TRAJ_TOL), (case, var, nm)
+            assert rel_err(to_np(lj), g[nm + ".logjac"]) < stiff_tol(case, g, nm + ".logjac", TRAJ_TOL), (case, var, nm)
             p = to_np(p)
             assert np.all(np.isfinite(p))
-            assert abs_err(p, g[nm + ".p"]) < P_TOL, (case, var, nm)
+            assert abs_err(p, g[nm + ".p"]) < stiff_tol(case, g, nm + ".p", P_TOL), (case, var, nm)
             bad = ~np.all(np.isfinite(g[nm + ".x"]), axis=1)       # diverged chains are rejected
             assert np.all(p[bad] == 0)
 
@@ -93,9 +97,9 @@ def test_propose_matches_reference(case):
                                        v=(to_dev(g["prop.v_fwd"]), to_dev(g["prop.v_bwd"])),
                                        u=to_dev(g["prop.u"]), aux=aux_of(g))
             assert Lv is None                       # sampler.py:40-42: no init_v -> no Lv
-        assert rel_err(to_np(Lx), g["prop.Lx"]) < TRAJ_TOL
-        assert abs_err(to_np(px), g["prop.px"]) < P_TOL
-        check_x_next(to_np(outs[0]), g["x"], g["prop.Lx"], g["prop.px"], g["prop.u"], P_TOL)
+        assert rel_err(to_np(Lx), g["prop.Lx"]) < stiff_tol(case, g, "prop.Lx", TRAJ_TOL)
+        assert abs_err(to_np(px), g["prop.px"]) < stiff_tol(case, g, "prop.px", P_TOL)
+        check_x_next(to_np(outs[0]), g["x"], g["prop.Lx"], g["prop.px"], g["prop.u"], stiff_tol(case, g, "prop.px", P_TOL))
 
 
 def test_p_accept_edge_cases():
@@ -415,7 +419,8 @@ def test_sample_chain_with_in_kernel_rng(case):
 
 
 @pytest.mark.parametrize("variant", [0, 100])
-@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6", "train_funnel3"])
+@pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6", "train_funnel3",
+                                  "train_rough2_ne", "train_rough6_ne", "train_rough50_ne"])
 def test_training_gradient_matches_reference_graph(case, variant):
     """l2hmc_train_propose_grad (HIP, hand-derived reverse mode) vs tf.gradients of the notebook
     loss from the reference's own graph: loss, proposals, every parameter gradient and alpha.
@@ -435,19 +440,25 @@ def test_training_gradient_matches_reference_graph(case, variant):
              "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
              "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
     loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
-    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
-    assert rel_err(to_np(Lx), g["Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["px"]) < P_TOL
+    # train_rough*_ne: the reference's default Rough Well at eta = 0.05 (arguments 400 x, curvature 8000; one fixture per
+    # trainer: d = 2 one dimension per lane, d = 6 register-resident on one wave, d = 50 on four).  An ulp of the float32
+    # quotient x / eta^2 moves the cosines by 2e-5: the float64 AND float32 numpy restatements sit 6e-5 (loss), 4e-4 (px),
+    # 6e-4 of the scale (gradients) from these fixtures (tests/test_oracle_golden.py); gates 2e-4 / 1e-3 / 2e-3
+    stiff = "_ne" in case
+    assert abs(float(loss) - float(g["loss"])) < (2e-4 if stiff else 1e-4) * max(1.0, abs(float(g["loss"])))
+    assert rel_err(to_np(Lx), g["Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["px"]) < (1e-3 if stiff else P_TOL)
     scale = max(float(np.abs(g["grad." + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
+    gtol = 2e-3 if stiff else 2e-4
     worst = 0.0
     for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
         for k in O.NET_KEYS:
             ref = g["grad.%s.%s" % (n, k)]
             got = to_np(w[k].grad).reshape(ref.shape)
             worst = max(worst, float(np.abs(got - ref).max()))
-            assert np.abs(got - ref).max() < 2e-4 * scale, (case, n, k)
+            assert np.abs(got - ref).max() < gtol * scale, (case, n, k)
     ga = float(dyn.alpha.grad)
     print("%s: loss %.6e  max |dgrad| %.2e (scale %.2e)  alpha %.5e vs %.5e" % (case, float(loss), worst, scale, ga, float(g["grad.alpha"])))
-    assert abs(ga - float(g["grad.alpha"])) < 2e-4 * max(scale, abs(float(g["grad.alpha"])))
+    assert abs(ga - float(g["grad.alpha"])) < gtol * max(scale, abs(float(g["grad.alpha"])))
 
 
 def test_sharded_training_gradient_sums_to_full_batch():

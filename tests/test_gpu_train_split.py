@@ -41,7 +41,8 @@ def _check_net_grads(g, dyn, pre="grad.", tol=2e-4):
                                         ("train_mog3d_h20", False), ("train_funnel4_h20", False), ("train_mog2d", True),
                                         ("train_funnel3", True),
                                         ("train_scg2d", True), ("train_tilted8", True), ("train_icg50", True),
-                                        ("train_rough6", True)])
+                                        ("train_rough6", True), ("train_rough6_ne_h20", False), ("train_rough6_ne", True),
+                                        ("train_rough50_ne", True), ("train_rough2_ne", True)])
 def test_gemm_engine_training_gradient_matches_reference_graph(case, force):
     """tf.gradients of the notebook loss from the reference's own graph (SCGExperiment.ipynb raw 156-169) vs the
     GEMM-engine trainer: the wide-net fixtures (H > 15: `Trainer` picks the engine itself) and, forced onto the engine,
@@ -52,9 +53,10 @@ def test_gemm_engine_training_gradient_matches_reference_graph(case, force):
              "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
              "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
     loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
-    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
-    assert rel_err(to_np(Lx), g["Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["px"]) < P_TOL
-    worst, scale = _check_net_grads(g, dyn)
+    stiff = "_ne" in case      # the default Rough Well at eta = 0.05: gates as in tests/test_gpu_parity.py's training test
+    assert abs(float(loss) - float(g["loss"])) < (2e-4 if stiff else 1e-4) * max(1.0, abs(float(g["loss"])))
+    assert rel_err(to_np(Lx), g["Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["px"]) < (1e-3 if stiff else P_TOL)
+    worst, scale = _check_net_grads(g, dyn, tol=2e-3 if stiff else 2e-4)
     print("%s: loss %.6e  max |dgrad| %.2e (scale %.2e)" % (case, float(loss), worst, scale))
 
 

@@ -15,6 +15,25 @@ STEP_TOL = 3e-5     # one generalised leapfrog step (funnel's |grad| ~ 5e3 ampli
 TRAJ_TOL = 1e-4     # T steps
 P_TOL = 5e-5        # accept probability (north_star asks 1e-4)
 
+# The STIFF fixtures: the reference's default Rough Well cos(x / eta^2) (distributions.py:84-97) at eta = 1e-2 (curvature
+# eta^-3 = 1e6) and eta = 0.1 (1e3).  Energy, gradient and the POSITION after one step still agree to float32 rounding (the
+# same float32 quotient x / den goes into cos / sin on both sides), but the step's last momentum half-update reads grad U at
+# the new position: an ulp of x' (1e-7) comes back as curvature * eps / 2 * 1e-7 in v', and every further step multiplies it
+# by ~exp(eps sqrt(curvature)) (eps = 3e-4: 1.35).  numpy and torch-CPU float32 differ by exactly such ulps (libm vs
+# SLEEF cos / sin, fma contraction).  Gates = 4x the distance measured between the two (columns: one step x, v, logdet;
+# T steps x, v, logjac, p).  Measured (max over the stored steps / both directions): rough2_ne 2.1e-7 6.5e-5 4.0e-5 | 8.8e-7
+# 1.0e-3 3.2e-5 4.6e-4; rough50_ne 2.3e-7 7.9e-5 1.8e-5 | 1.8e-6 1.7e-3 2.0e-4 1.8e-3; rough512_ne 2.4e-7 1.2e-4 2.8e-5 |
+# 2.4e-6 2.5e-3 4.0e-4 2.2e-3; rough8_eta01 2.3e-7 4.6e-6 2.6e-6 | 6.1e-6 3.8e-4 4.1e-5 6.7e-5.
+STIFF_TOL = {"rough2_ne": (3e-5, 3e-4, 1.6e-4, 1e-4, 4e-3, 2e-4, 2e-3),
+             "rough50_ne": (3e-5, 3.2e-4, 8e-5, 1e-4, 7e-3, 8e-4, 8e-3),
+             "rough512_ne": (3e-5, 5e-4, 1.2e-4, 1e-4, 1e-2, 1.6e-3, 9e-3),
+             "rough8_eta01": (3e-5, 3e-5, 3e-5, 1e-4, 1.6e-3, 2e-4, 3e-4)}
+
+
+def tols(case):
+    """(step x, step v, step logdet, traj x, traj v, traj logjac, p)"""
+    return STIFF_TOL.get(case, (STEP_TOL, STEP_TOL, STEP_TOL, TRAJ_TOL, TRAJ_TOL, TRAJ_TOL, P_TOL))
+
 
 @pytest.mark.parametrize("case", CASES)
 def test_energy_and_grad(case):
@@ -33,9 +52,10 @@ def test_single_steps(case):
         with np.errstate(all="ignore"):
             xo, vo, lj = d.forward_step(x, v, np.float32(s))
             xb, vb, ljb = d.backward_step(x, v, np.float32(s))
-        for got, key in ((xo, "fstep%d.x"), (vo, "fstep%d.v"), (lj, "fstep%d.logdet"),
-                         (xb, "bstep%d.x"), (vb, "bstep%d.v"), (ljb, "bstep%d.logdet")):
-            assert rel_err(got, g[key % s]) < STEP_TOL, (case, key % s)
+        sx, sv, sl = tols(case)[:3]
+        for got, key, tol in ((xo, "fstep%d.x", sx), (vo, "fstep%d.v", sv), (lj, "fstep%d.logdet", sl),
+                              (xb, "bstep%d.x", sx), (vb, "bstep%d.v", sv), (ljb, "bstep%d.logdet", sl)):
+            assert rel_err(got, g[key % s]) < tol, (case, key % s)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -47,10 +67,11 @@ def test_trajectories_and_accept_prob(case):
         for nm, fn in (("fwd", d.forward), ("bwd", d.backward)):
             X, V, lj = fn(x, v, log_jac=True)
             _, _, p = fn(x, v)
-            assert rel_err(X, g[nm + ".x"]) < TRAJ_TOL
-            assert rel_err(V, g[nm + ".v"]) < TRAJ_TOL
-            assert rel_err(lj, g[nm + ".logjac"]) < TRAJ_TOL
-            assert abs_err(p, g[nm + ".p"]) < P_TOL
+            tx, tv, tl, tp = tols(case)[3:]
+            assert rel_err(X, g[nm + ".x"]) < tx
+            assert rel_err(V, g[nm + ".v"]) < tv
+            assert rel_err(lj, g[nm + ".logjac"]) < tl
+            assert abs_err(p, g[nm + ".p"]) < tp
             # NaN trajectories of the reference must be rejected (dynamics.py:309)
             bad = ~np.all(np.isfinite(g[nm + ".x"]), axis=1)
             assert np.all(p[bad] == 0)
@@ -68,9 +89,10 @@ def test_propose(case, both):
         else:
             Lx, Lv, px, xn = O.propose(x, d, g["prop.v_fwd"], g["prop.v_bwd"], g["prop.dir"],
                                        g["prop.u"], both_directions=both)
-    assert rel_err(Lx, g["prop.Lx"]) < TRAJ_TOL
-    assert abs_err(px, g["prop.px"]) < P_TOL
-    check_x_next(xn, x, g["prop.Lx"], g["prop.px"], g["prop.u"], 1e-4)
+    tx, _, _, tp = tols(case)[3:]
+    assert rel_err(Lx, g["prop.Lx"]) < tx
+    assert abs_err(px, g["prop.px"]) < tp
+    check_x_next(xn, x, g["prop.Lx"], g["prop.px"], g["prop.u"], max(1e-4, tp))
     check_x_next(g["prop.x_next"], x, g["prop.Lx"], g["prop.px"], g["prop.u"], 1e-4)
 
 
@@ -217,19 +239,24 @@ def test_philox_draws_are_sharding_invariant_and_standard():
 
 @pytest.mark.parametrize("case", ["train_scg2d", "train_tilted8", "train_icg50", "train_mog2d", "train_rough6", "train_funnel3",
                                   "train_icg50_h32", "train_tilted8_h24", "train_rough6_h20", "train_mog3d_h20",
-                                  "train_funnel4_h20"])
+                                  "train_funnel4_h20", "train_rough2_ne", "train_rough6_ne", "train_rough50_ne",
+                                  "train_rough6_ne_h20"])
 def test_training_gradient_oracle_matches_reference_graph(case):
     """oracle/l2hmc_train_oracle.py (hand-derived reverse mode incl. the Hessian-vector path)
     vs tf.gradients of the notebook loss evaluated by the reference's own graph (stub)."""
     from oracle import l2hmc_train_oracle as TO
     g = load(case)
     loss, out = TO.training_loss_and_grad(g, np.float64)
-    assert abs(loss - float(g["loss"])) < 2e-5 * max(1.0, abs(float(g["loss"])))
-    assert rel_err(out["Lx"], g["Lx"]) < TRAJ_TOL and abs_err(out["px"], g["px"]) < P_TOL
+    # the non-easy Rough Well at eta = 0.05 (arguments 400 x, curvature 8000): the reference graph divides in float32, this
+    # restatement in float64, so the cosine arguments differ by an ulp of 400 x = 2e-5 -- measured against the four fixtures:
+    # loss 6e-5, px 1.5e-4, gradients 4e-4 of their scale (float32 restatement: 6e-4).  Gates: 2e-4 / 1e-3 / 2e-3.
+    stiff = case.startswith("train_rough") and "_ne" in case
+    assert abs(loss - float(g["loss"])) < (2e-4 if stiff else 2e-5) * max(1.0, abs(float(g["loss"])))
+    assert rel_err(out["Lx"], g["Lx"]) < TRAJ_TOL and abs_err(out["px"], g["px"]) < (1e-3 if stiff else P_TOL)
     scale = max(float(np.abs(g["grad." + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
     # (the fixtures are float32 outputs; on the ill-conditioned d = 50 target with 32-wide nets the reference graph's own
     #  rounding is 8e-5 of the gradient scale against this float64 restatement)
-    tol = 2e-4 if case == "train_icg50_h32" else 2e-5
+    tol = 2e-3 if stiff else (2e-4 if case == "train_icg50_h32" else 2e-5)
     for n in ("xnet", "vnet"):
         for k in O.NET_KEYS:
             ref = g["grad.%s.%s" % (n, k)]
