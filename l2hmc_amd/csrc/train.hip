@@ -64,6 +64,10 @@ struct TArgs {
   // l2hmc_train_step: chains [0, n_head) start from x_head (n_head = 0: all from x)
   const float* x_head;
   long long n_head;
+#ifdef L2HMC_DBG_EPILOGUE_SELECT     // round-4 experiment: the Metropolis select in the gradient kernel's epilogue
+  const float* u;
+  float* x_next;
+#endif
 };
 __device__ __forceinline__ const float* x_row0(const TArgs& A, long long n) { return n < A.n_head ? A.x_head : A.x; }
 
@@ -1093,6 +1097,9 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
   k.scale = a->scale; k.inv_n = a->inv_n;
   k.Lx = a->Lx; k.p = a->p; k.v1 = a->v1; k.grad = a->grad; k.ws = a->workspace;
   k.x_head = st ? st->x_head : nullptr; k.n_head = st ? st->n_head : 0;
+#ifdef L2HMC_DBG_EPILOGUE_SELECT
+  k.u = nullptr; k.x_next = nullptr;
+#endif
   const unsigned blocks = (unsigned)((a->n_chains + TC - 1) / TC);
   hipStream_t s = (hipStream_t)stream;
   const int n_grad = 2 * net_params(a->d, a->H) + 1;

@@ -484,6 +484,16 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (dim0 + j < d) A.Lx[n * d + dim0 + j] = x[j];
+#ifdef L2HMC_DBG_EPILOGUE_SELECT   // NOT a feature: the six lines whose presence made roc-7.2.0's register allocator place a copy before an
+                                  // exec restore in train_fast_kernel<2,1,3> (tools/check_exec_prologue.py
+                                  // finds it in `hipcc -S -DL2HMC_DBG_EPILOGUE_SELECT train.hip`).  Kept as the reproducer.
+    if (A.x_next != nullptr && n < A.n_head) {                 // Metropolis select of the continuing chains (sampler.py:53-55)
+      const bool acc = p - A.u[n] >= 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (dim0 + j < d) A.x_next[n * d + dim0 + j] = acc ? x[j] : xs[j];
+    }
+#endif
   }
   f4 lx = okc ? (x - xs) * dv1p - g * lam : Z;
   f4 lv = okc ? v * (-lam) : Z;

@@ -54,7 +54,7 @@ def stiffness(g):
 
 
 def is_stiff(g):
-    return stiffness(g) >= 1e3
+    return stiffness(g) >= 500.0     # (eta = 0.1: 1000 up to rounding)
 
 
 _ORACLE_DISTANCE = {}

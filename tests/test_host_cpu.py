@@ -182,3 +182,29 @@ def test_trainer_picks_the_engine_from_the_shape_without_a_gpu():
     tr = Trainer(make(3, energy=lambda x: (x * x).sum(1)))
     assert isinstance(tr, SplitTrainer) and tr.user and not tr.image_sampler
 
+
+
+def test_exec_prologue_check_finds_the_defect_it_was_written_for():
+    """tools/check_exec_prologue.py on two 40-line excerpts of this tree's own compiler output (tests/golden/asm/): the
+    train_fast_kernel<2,1,3> build in which the register allocator's copy of the hidden-unit index ran before the exec restore of
+    its reconvergence block (16 lanes kept garbage: gradient rows stored to wrong addresses), and the hand-corrected listing
+    that was verified bit-equal on the GPU.  `make -C l2hmc_amd/csrc lint` (run by __graft_entry__.build()) applies the same
+    check to every translation unit of the shipped library."""
+    import importlib.util
+    from tests.helpers import ROOT
+    spec = importlib.util.spec_from_file_location("check_exec_prologue", os.path.join(ROOT, "tools", "check_exec_prologue.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.check(os.path.join(ROOT, "tests", "golden", "asm", "exec_prologue_bad.s"))
+    assert len(bad) == 1 and "v_accvgpr_write_b32 a76, v51" in bad[0][3] and "s[16:17]" in bad[0][5]
+    assert mod.check(os.path.join(ROOT, "tests", "golden", "asm", "exec_prologue_good.s")) == []
+    # an `if` body with its exec restore at its own end, and SGPR-spill lane traffic ahead of a restore, are not findings
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write("_Zk:\n\ts_and_saveexec_b64 s[0:1], vcc\n; %bb.1:\n\tv_add_f32_e32 v0, v1, v2\n\ts_or_b64 exec, exec, s[0:1]\n"
+                "\ts_and_saveexec_b64 s[0:1], vcc\n\ts_cbranch_execz .LBB0_3\n; %bb.2:\n\tv_mov_b32_e32 v0, 0\n.LBB0_3:\n"
+                "\tv_readlane_b32 s4, v255, 0\n\ts_or_b64 exec, exec, s[0:1]\n\tv_mov_b32_e32 v1, v0\n\ts_endpgm\n")
+    try:
+        assert mod.check(f.name) == []
+    finally:
+        os.unlink(f.name)
