@@ -33,6 +33,7 @@
 // chain of launches (where every epilogue also writes 6 bytes of planes per element): 3.79 -> 3.57 ms per proposal in an A/B on one
 // box with the barrier at the end of the k-tile, 3.54-3.55 with it in the middle (another box).
 #pragma once
+#include <atomic>
 #include <type_traits>
 
 #include "gemm_f32.hpp"
@@ -214,12 +215,18 @@ template <int EPI>
 int gemm_planes_prepare() {
   constexpr size_t lds = gemm_xlp_lds_bytes<XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>();
   static_assert(lds <= 160 * 1024, "two plane buffers must fit the CU's LDS");
-  static bool done = false;
-  if (done) return L2HMC_OK;
+  // The attribute is per DEVICE: remembered per device id (one bit each, atomically -- the only process-wide word the library
+  // keeps, and it only ever says "already asked"); ids beyond 63 simply ask every time.  (Round 4 kept ONE flag: a second GPU of
+  // the same process would have launched without the attribute.)
+  static std::atomic<unsigned long long> asked{0ull};
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(L2HMC_ERR_HIP, "gemm planes: %s", "hipGetDevice failed");
+  const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+  if (bit && (asked.load(std::memory_order_acquire) & bit)) return L2HMC_OK;
   auto kern = gemm_xlp_kernel<EPI, XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(L2HMC_ERR_HIP, "gemm planes: %s", "the device refuses the LDS size of the 256-row plane tiles");
-  done = true;
+  asked.fetch_or(bit, std::memory_order_release);
   return L2HMC_OK;
 }
 // C = epilogue(A B^T) on planes; GemmArgs as for launch_gemm with Ap / Bp instead of A / B (contract at GemmArgs)

@@ -269,9 +269,11 @@ inline long long prows(int N) { return ceil_to(N, XLP_TN); }
 // U (N) and grad (N x d, row stride ldg) of the VAE latent posterior at z (row stride ldz) (mnist_vae.py:122-126):
 // six GEMMs, every bias / softplus / sigmoid / BCE / chain-rule product fused into their epilogues; lg (N x n_pix)
 // and rowsum (N x 2 tiles) are scratch.  The transposed decoder weights must already be in ws (mlp3_transposes).
-void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, int ldz, long long N, int d,
-                const Mlp3Ws& ws, float* lg, float* rowsum, float* U, double* Ud, float* grad, int ldg, float beta = 1.f) {
+// Returns the first error of the pre-split launches (their LDS-size request can be refused by a device), L2HMC_OK otherwise.
+int vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const float* z, int ldz, long long N, int d,
+               const Mlp3Ws& ws, float* lg, float* rowsum, float* U, double* Ud, float* grad, int ldg, float beta = 1.f) {
   if (ws.pa1 != nullptr) {
+    int rc = L2HMC_OK, r1;
     // ---- pre-split form (gemm_mode 1 at decoder sizes, gemm_xl.hpp): every activation that only feeds the next product is
     //      written as bf16 planes by its producer's epilogue; the four decoder-sized products read planes on both sides.
     //      Plane row strides are whole k-tiles (pld) and the weight planes whole tiles of rows (prows), zero-padded.
@@ -283,27 +285,27 @@ void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const flo
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_h1);
     g.Ap = ws.pa1; g.ap_plane = n1; g.ldap = l1; g.Bp = ws.pw2t; g.bp_plane = prows(dec.n_h2) * l1; g.ldbp = l1;
     g.bias = dec.b2; g.C2 = ws.s2; g.ldc2 = dec.n_h2; g.Cp = ws.pa2; g.cp_plane = n2; g.ldcp = l2;
-    launch_gemm_planes<EPI_BIAS_SOFTPLUS>(g, s);                                                     // a2 (planes), s2
+    if ((r1 = launch_gemm_planes<EPI_BIAS_SOFTPLUS>(g, s)) != L2HMC_OK) rc = rc ? rc : r1;                                                     // a2 (planes), s2
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_out, N, dec.n_out, dec.n_h2);
     g.Ap = ws.pa2; g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw3t; g.bp_plane = prows(dec.n_out) * l2; g.ldbp = l2;
     g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles_planes(dec.n_out); g.beta = beta;
     g.Cp = ws.plg; g.cp_plane = no; g.ldcp = lo;
-    launch_gemm_planes<EPI_BCE>(g, s);                                                               // beta (sigmoid(logit) - aux) (planes)
+    if ((r1 = launch_gemm_planes<EPI_BCE>(g, s)) != L2HMC_OK) rc = rc ? rc : r1;                                                               // beta (sigmoid(logit) - aux) (planes)
     if (U != nullptr || Ud != nullptr)
       hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles_planes(dec.n_out), z, ldz, d, U, Ud, N);
-    if (grad == nullptr) return;
+    if (grad == nullptr) return rc;
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_out);
     g.Ap = ws.plg; g.ap_plane = no; g.ldap = lo; g.Bp = ws.pw3; g.bp_plane = prows(dec.n_h2) * lo; g.ldbp = lo;
     g.E = ws.s2; g.lde = dec.n_h2; g.Cp = ws.pda2; g.cp_plane = n2; g.ldcp = l2;
-    launch_gemm_planes<EPI_MUL>(g, s);                                                               // d a2 (planes)
+    if ((r1 = launch_gemm_planes<EPI_MUL>(g, s)) != L2HMC_OK) rc = rc ? rc : r1;                                                               // d a2 (planes)
     g = gemm_args(nullptr, 0, nullptr, 0, ws.a1, dec.n_h1, N, dec.n_h1, dec.n_h2);
     g.Ap = ws.pda2; g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw2; g.bp_plane = prows(dec.n_h1) * l2; g.ldbp = l2;
     g.E = ws.s1; g.lde = dec.n_h1;
-    launch_gemm_planes<EPI_MUL>(g, s);                                                               // d a1 (fp32: the K = 1024, N = d product reads it)
+    if ((r1 = launch_gemm_planes<EPI_MUL>(g, s)) != L2HMC_OK) rc = rc ? rc : r1;                                                               // d a1 (fp32: the K = 1024, N = d product reads it)
     g = gemm_args(ws.a1, dec.n_h1, dec.W1, dec.n_h1, grad, ldg, N, d, dec.n_h1);
     g.E = z; g.lde = ldz;
     launch_gemm<EPI_ADD>(g, s, d <= 64 ? SHAPE_SKINNY : SHAPE_MID);
-    return;
+    return rc;
   }
   mlp3_hidden(s, dec, z, ldz, N, ws);
   GemmArgs g = gemm_args(ws.a2, dec.n_h2, ws.w3t, dec.n_h2, lg, dec.n_out, N, dec.n_out, dec.n_h2);
@@ -311,7 +313,7 @@ void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const flo
   launch_gemm<EPI_BCE>(g, s);                                     // lg := beta (sigmoid(logit) - aux)
   if (U != nullptr || Ud != nullptr)
     hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, bce_partials(N, dec.n_out), z, ldz, d, U, Ud, N);
-  if (grad == nullptr) return;
+  if (grad == nullptr) return L2HMC_OK;
   // d a2 = dl W3^T (.) sigmoid(p2);  d a1 = d a2 W2^T (.) sigmoid(p1);  d z = d a1 W1^T + z
   g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);
   g.E = ws.s2; g.lde = dec.n_h2;
@@ -322,6 +324,7 @@ void vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const flo
   g = gemm_args(ws.a1, dec.n_h1, dec.W1, dec.n_h1, grad, ldg, N, d, dec.n_h1);
   g.E = z; g.lde = ldz;
   launch_gemm<EPI_ADD>(g, s, d <= 64 ? SHAPE_SKINNY : SHAPE_MID);
+  return L2HMC_OK;
 }
 
 struct SplitPlan {
@@ -414,7 +417,8 @@ int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x,
   float* w = workspace;
   const Mlp3Ws ws = {w + p.dw1t, w + p.dw2t, w + p.dw3t, w + p.a1, w + p.s1, w + p.a2, w + p.s2};
   mlp3_transposes(s, *decoder, ws);
-  vae_energy(s, *decoder, aux, x, d, n_chains, d, ws, w + p.lg, w + p.rowsum, U_out, nullptr, grad_out, d, beta);
+  rc = vae_energy(s, *decoder, aux, x, d, n_chains, d, ws, w + p.lg, w + p.rowsum, U_out, nullptr, grad_out, d, beta);
+  if (rc) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return L2HMC_OK;
@@ -548,8 +552,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
       return r ? fail(L2HMC_ERR_ARG, "the energy callback failed (returned %s%lld)", "", (long long)r) : L2HMC_OK;
     }
     if (!builtin) {
-      vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, Ud, g, L, beta);
-      return L2HMC_OK;
+      return vae_energy(s, dec, a->aux, xc, L, N, d, dws, w + p.lg, w + p.rowsum, nullptr, Ud, g, L, beta);
     }
     (void)hipMemcpy2DAsync(w + p.xp, sizeof(float) * d, xc, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
     const int r = l2hmc_energy(a->energy, w + p.xp, N, d, Ud ? w + p.uf : nullptr, w + p.gp, stream);

@@ -1065,7 +1065,23 @@ static int train_launch(const L2hmcTrainArgs* a, const L2hmcTrainStep* st, void*
       return fail(L2HMC_ERR_ARG, "l2hmc_train_step: bad optimiser arguments%s");
   }
   if (a->n_chains < 0 || a->d < 1 || a->T < 1 || a->H < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
-  if (a->n_chains == 0) return L2HMC_OK;
+  if (a->n_chains == 0) {
+    if (st == nullptr) return L2HMC_OK;
+    // An EMPTY shard of a sharded optimiser step (fewer chains than ranks): its slice of the one all-reduce must still be a
+    // zero gradient and zero loss terms -- the reduction overwrites its destination, nothing zeroes it beforehand (round 4's
+    // early return left the previous step's already-reduced gradient there, which every rank then added again).
+    if (st->theta != nullptr) return fail(L2HMC_ERR_ARG, "l2hmc_train_step: an optimiser update needs at least one chain%s");
+    if (!a->grad || !(a->scale > 0.f) || !(a->inv_n > 0.f)) return fail(L2HMC_ERR_ARG, "l2hmc_train_step: NULL grad / bad scale, inv_n%s");
+    const int n_grad0 = 2 * net_params(a->d, a->H) + 1;
+    FinalArgs f;
+    memset(&f, 0, sizeof(f));
+    f.scale = a->scale; f.inv_n = (double)a->inv_n; f.terms = st->terms; f.loss = st->loss;
+    hipLaunchKernelGGL(train_final_kernel, dim3((unsigned)((n_grad0 + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, a->grad, 0,
+                       n_grad0, a->grad, f);
+    hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e0));
+    return L2HMC_OK;
+  }
   if (a->d > 4096 || a->H > 4096) return fail(L2HMC_ERR_UNSUPPORTED, "training kernel: d / H too large (got d = %s%lld, H = %lld)", "", a->d, a->H);
   if (!a->xnet || !a->vnet || !a->masks || !a->trig || !a->x || !a->v || !a->Lx || !a->p || !a->v1 ||
       !a->grad || !a->workspace)

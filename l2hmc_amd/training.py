@@ -40,6 +40,9 @@ def _numel(code, d, H):
     return {"dH": d * H, "H": H, "2H": 2 * H, "HH": H * H, "Hd": H * d, "d": d}[code]
 
 
+RNG_STREAM = "philox4x32-10/hw-boxmuller"       # (l2hmc_kernels.hpp philox_normal4; "…/libm-normals" up to ABI 3)
+
+
 class Trainer(object):
     def __new__(cls, dynamics, *args, **kwargs):
         if getattr(dynamics, "_user", False) and cls is not SplitTrainer and cls is not Trainer:
@@ -109,7 +112,11 @@ class Trainer(object):
 
     def _allreduce_flat(self, sums64, count):
         """The ONE collective of a sharded step: all-reduce [gradient | (hi, lo) float pairs of the double sums | count];
-        returns (reduced sums as a float64 tensor, reduced count as a float64 scalar tensor) -- on the device, no sync."""
+        returns (reduced sums as a float64 tensor, reduced count as a float64 scalar tensor) -- on the device, no sync.
+        Accuracy: each rank's double sum travels as float32 hi + lo (exact to ~2^-48 of the value), but the collective ADDS
+        in float32, so the reduced loss sums are float32-accurate: relative 2^-24 of the sum per addition (the gradient next
+        to them is float32 anyway; the single-process loss stays a double).  The chain count (two 12-bit-scaled halves) is
+        exact up to 2^36 chains."""
         k = int(sums64.numel())
         assert 2 * k + 2 <= self.N_TAIL
         tail = self._flat_ext[self.n_grad:]
@@ -128,12 +135,21 @@ class Trainer(object):
         return {"dynamics": self.dyn.state_dict(), "theta": self.theta.detach().cpu().clone(),
                 "m": self.m.cpu().clone(), "v": self.v.cpu().clone(), "global_step": int(self.global_step),
                 "seed": int(self.seed),
+                # which random stream the continuation will draw from: ABI 4 switched the in-kernel normals from libm to the
+                # hardware log / sqrt / sin / cos forms (last-bit different draws); a checkpoint resumed on another stream
+                # still trains, but not "bit for bit" -- load_state_dict warns
+                "rng_stream": RNG_STREAM, "abi": int(_ffi.ABI_VERSION),
                 "hyper": {"lr": self.lr0, "decay_steps": self.decay_steps, "decay_rate": self.decay_rate,
                           "scale": self.scale, "beta1": self.beta1, "beta2": self.beta2, "epsilon": self.epsilon}}
 
     def load_state_dict(self, sd):
         if sd["theta"].numel() != self.theta.numel():
             raise ValueError("checkpoint has %d parameters, this sampler %d" % (sd["theta"].numel(), self.theta.numel()))
+        if sd.get("rng_stream", "philox4x32-10/libm-normals") != RNG_STREAM:
+            import warnings
+            warnings.warn("checkpoint was written on random stream %r, this library draws %r: the run continues, but not bit "
+                          "for bit (rebuild with -DL2HMC_LIBM_NORMALS for the old normals)"
+                          % (sd.get("rng_stream", "philox4x32-10/libm-normals"), RNG_STREAM))
         self.dyn.mask = sd["dynamics"]["mask"]
         with torch.no_grad():
             self.theta.copy_(sd["theta"].to(self.theta.device))       # the net tensors and alpha are views of theta
@@ -215,18 +231,25 @@ class Trainer(object):
         each then takes part in the exchange)."""
         self._layout = None if n_total is None else (int(n_total), int(chain_offset))
         self._auto_layout = None
+        self._stale = self._reduced = None
 
     def _shard(self, N):
         """(global chain count, global index of this rank's row 0): ranks may hold different numbers of chains
         (sharding.shard_range hands out blocks whose sizes differ by up to one), so the loss normalisation and the
         Philox chain offsets come from the ranks' local counts, not from N * world.  Unless the layout was declared
         (`set_sharding`), the counts are exchanged ONCE -- on every rank's first step, unconditionally, so all ranks
-        enter it together -- and kept.  A rank whose local count changes afterwards raises (quietly re-exchanging on
-        that rank alone would leave it in a collective no other rank enters; the review of round 2 found exactly that
-        hang): re-declare with `set_sharding`, or call `set_sharding(None, None)` on every rank."""
+        enter it together -- and kept.  A rank whose local count changes afterwards must not quietly re-exchange (it would
+        sit in a collective no other rank enters: the hang the review of round 2 found) and must not raise BEFORE the
+        step's all-reduce either (the other ranks would then wait for it until the backend times out -- review of round
+        4): it takes this one step on the cached layout, so every rank passes the collective, and raises at the END of
+        the step; every other rank learns of it from the reduced chain count of that same all-reduce, which no longer
+        matches its cached total, and raises at the start of ITS next step (`_check_reduced_count`: an asynchronous
+        two-float copy to pinned memory, read one step late -- no host synchronisation in a healthy run).  Recover with
+        `set_sharding(n_total, chain_offset)`, or `set_sharding(None, None)` on every rank."""
         world = self._world()
         if world == 1:
             return N, 0
+        self._check_reduced_count()
         if getattr(self, "_layout", None) is not None:
             return self._layout
         auto = getattr(self, "_auto_layout", None)
@@ -238,10 +261,44 @@ class Trainer(object):
             counts = counts.cpu()
             auto = self._auto_layout = (int(N), int(counts.sum()), int(counts[:rank].sum()))
         elif auto[0] != int(N):
-            raise RuntimeError("this rank's chain count changed from %d to %d under a discovered shard layout: declare the "
-                               "new layout with set_sharding(n_total, chain_offset), or call set_sharding(None, None) on "
-                               "EVERY rank so that all of them re-enter the layout exchange together" % (auto[0], N))
+            self._stale = (auto[0], int(N))             # raised by `_raise_if_stale` once this step's collective is behind us
         return auto[1], auto[2]
+
+    _STALE_MSG = ("this rank's chain count changed from %d to %d under a discovered shard layout: declare the new layout with "
+                  "set_sharding(n_total, chain_offset), or call set_sharding(None, None) on EVERY rank so that all of them "
+                  "re-enter the layout exchange together")
+
+    def _raise_if_stale(self):
+        st = getattr(self, "_stale", None)
+        if st is not None:
+            self._stale = None
+            raise RuntimeError(self._STALE_MSG % st)
+
+    def _note_reduced_count(self, cnt2, n_total, hi_scale=1.0):
+        """Keep the chain count the step's all-reduce produced (a 2-float device view: hi_scale * hi + lo) for
+        `_check_reduced_count`."""
+        if cnt2.is_cuda:
+            host = torch.empty(2, dtype=cnt2.dtype, pin_memory=True)
+            host.copy_(cnt2, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = cnt2.detach().clone(), None
+        self._reduced = (host, ev, int(n_total), float(hi_scale))
+
+    def _check_reduced_count(self):
+        red = getattr(self, "_reduced", None)
+        if red is None:
+            return
+        host, ev, expect, hi_scale = red
+        self._reduced = None
+        if ev is not None:
+            ev.synchronize()                            # (recorded a whole step ago: returns at once)
+        got = int(round(float(host[0]) * hi_scale + float(host[1])))
+        if got != expect:
+            raise RuntimeError("the last step's all-reduce counted %d chains over all ranks, this rank's shard layout says %d: "
+                               "some rank's chain count changed -- call set_sharding(None, None) on EVERY rank (or declare "
+                               "the new layout) before the next step" % (got, expect))
 
     def _loss_terms(self, v12, n_total):
         """[sum 1/v1, sum v1, the single-process loss] of the rank's per-chain loss arguments: one fixed-order double
@@ -257,6 +314,7 @@ class Trainer(object):
         if world == 1:
             return lt[2]
         sums, cnt = self._allreduce_flat(lt[:2], N)
+        self._note_reduced_count(self._flat_ext[self.n_grad + 4:self.n_grad + 6], n_total, hi_scale=4096.0)
         return (self.scale * sums[0] - sums[1] / self.scale) / cnt
 
     def loss_and_grad(self, x, z=None, draws=None):
@@ -290,6 +348,7 @@ class Trainer(object):
             t.grad = self.flat[off:off + n].view(t.shape)
         if self.train_alpha:
             self.dyn.alpha.grad = (self.flat[-1] * torch.exp(dyn.alpha.detach())).reshape(dyn.alpha.shape)
+        self._raise_if_stale()
         return loss, Lxz[:N], pxz[:N]
 
     def _buffers(self, N, d):
@@ -346,12 +405,14 @@ class Trainer(object):
         _ffi.check(L.l2hmc_train_step(a, st, s))
         if sharded:
             dist.all_reduce(self._flat_ext[:self.n_grad + 6])           # the ONE collective of a training step
+            self._note_reduced_count(self._flat_ext[self.n_grad + 4:self.n_grad + 6], n_total)
             n_par = self.n_grad if self.train_alpha else self.n_grad - 1
             _ffi.check(L.l2hmc_adam_step_terms(self.theta.data_ptr(), self.flat.data_ptr(), self.m.data_ptr(),
                                                self.v.data_ptr(), n_par, lr, self.beta1, self.beta2, self.epsilon,
                                                self.global_step, int(self.train_alpha),
                                                self._flat_ext[self.n_grad:].data_ptr(), self.scale, lt.data_ptr(), s))
         dyn._packed_key = None                          # the weights changed under the packed-fragment cache
+        self._raise_if_stale()
         return lt[2], p12[:N], x_next, lr
 
 

@@ -91,7 +91,9 @@ def _layout_worker(rank, world, port, out):
         from l2hmc_amd.training import Trainer
         n_grad = 7
         tr = types.SimpleNamespace(dyn=types.SimpleNamespace(device=torch.device("cpu")), _layout=None, _auto_layout=None,
-                                   _world=lambda: world, n_grad=n_grad, N_TAIL=Trainer.N_TAIL)
+                                   _world=lambda: world, n_grad=n_grad, N_TAIL=Trainer.N_TAIL, _stale=None, _reduced=None,
+                                   _STALE_MSG=Trainer._STALE_MSG)
+        tr._check_reduced_count = lambda: Trainer._check_reduced_count(tr)
         tr._flat_ext = torch.zeros(n_grad + Trainer.N_TAIL)
         tr.flat = tr._flat_ext[:n_grad]
         seen = []
@@ -99,21 +101,31 @@ def _layout_worker(rank, world, port, out):
         def step(n_local):
             n_total, off = Trainer._shard(tr, n_local)
             tr.flat.fill_(float(rank + 1))                          # "the rank's gradient"
-            sums = torch.tensor([1e9 + 0.125 * (rank + 1), 3.0 * (rank + 1)], dtype=torch.float64)
+            # (hi parts 1e9 + 64 and 1e9 + 128: their float32 sum is NOT exact -- the reduced sums are float32-accurate)
+            sums = torch.tensor([1e9 + 64.0 * (rank + 1) + 0.125 * (rank + 1), 3.0 * (rank + 1)], dtype=torch.float64)
             red, cnt = Trainer._allreduce_flat(tr, sums, n_local)
+            Trainer._note_reduced_count(tr, tr._flat_ext[n_grad + 4:n_grad + 6], n_total, hi_scale=4096.0)
             return n_total, off, float(tr.flat[0]), float(red[0]), float(red[1]), float(cnt)
 
         n0 = 501 if rank == 0 else 500                              # ragged shards
         seen.append(step(n0))                                        # layout exchange + the step's collective
         seen.append(step(n0))                                        # the step's collective ONLY
         seen.append(tuple(calls))
-        raised = False
-        if rank == 0:
-            try:
-                Trainer._shard(tr, 500)                             # only this rank's count changes: no silent re-exchange
-            except RuntimeError:
-                raised = True
-        seen.append(raised)
+        # only rank 0's count changes: it must NOT re-exchange on its own and must NOT raise before the step's collective (the
+        # other rank would wait in it); it raises once the collective is behind it, rank 1 at its next `_shard` from the count
+        raised = []
+        step(500 if rank == 0 else n0)
+        try:
+            Trainer._raise_if_stale(tr)
+            raised.append(False)
+        except RuntimeError:
+            raised.append(True)
+        try:
+            Trainer._shard(tr, 500 if rank == 0 else n0)
+            raised.append(False)
+        except RuntimeError:
+            raised.append(True)
+        seen.append(tuple(raised))
         Trainer.set_sharding(tr, None, None)                        # every rank re-opens the exchange ...
         seen.append(step(500))                                      # ... and all see the new layout
         del calls[:]
@@ -139,13 +151,17 @@ def test_shard_layout_is_exchanged_once_and_a_step_is_one_collective():
         pr.join(100)
         assert pr.exitcode == 0
     res = dict(out.get() for _ in range(2))
-    big = 2e9 + 0.375                                               # the double sums survive the float (hi, lo) transport
+    big = 2e9 + 192.375          # the double sums travel as float (hi, lo) pairs and are ADDED in float32: 2^-23 of the sum
     for rank, off in ((0, 0), (1, 501)):
         first, second, calls, raised, third, declared, calls2 = res[rank]
-        assert first == second == (1001, off, 3.0, big, 9.0, 1001.0)
+        for got in (first, second):
+            assert got[:3] == (1001, off, 3.0) and got[4:] == (9.0, 1001.0)
+            assert abs(got[3] - big) <= 2.0 ** -23 * big and got[3] != big
         assert calls == (2, 7 + 6, 7 + 6)                           # layout exchange once, then ONE all-reduce per step
-        assert raised == (rank == 0)
-        assert third == (1000, 500 * rank, 3.0, big, 9.0, 1000.0)
+        # rank 0 (whose count changed) raises after the collective; BOTH ranks at their next step, from the reduced count
+        # (1000 != the cached 1001) -- nobody is left waiting in a collective
+        assert raised == ((True, True) if rank == 0 else (False, True))
+        assert third[:3] == (1000, 500 * rank, 3.0) and third[4:] == (9.0, 1000.0)
         assert declared == (1234, 617 * rank) and calls2 == ()
 
 
