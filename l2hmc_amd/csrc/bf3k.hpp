@@ -64,66 +64,10 @@ __device__ __forceinline__ bfk_f4 bfk_dot(const BfkW& w, const BfkA& a, bfk_f4 a
   acc = bfk_mfma(w.P, a.mm, acc);
   return bfk_mfma(w.P, a.hh, acc);
 }
-// The split of one float4 and the nine MFMAs of three 16 x 16 x 16 blocks that share it as their B operand (the S, Q, T heads of
-// one dimension slice), written as a software pipeline for ONE wave: a bf16 MFMA occupies the matrix pipe for 16 cycles while
-// the wave goes on issuing plain VALU, so the h-products are issued as soon as the first conversion is done and the m- and
-// l-terms are formed in their shadow (three to four VALU per MFMA); scheduling fences keep the compiler from collecting the
-// split in front of the MFMAs again.  Accumulation order h h, (m m + ...), (h l + l h): largest first -- each partial sum is
-// an fp32 rounding of an fp32-representable sum either way.  Returns the split operand for further blocks (bfk_dot).
-// (Used by traj_fast_kernel's -DL2HMC_BFH=1 build only: measured at 4096 / 8192 chains, no gain with one wave per SIMD -- the
-//  split is 143 cycles of VALU issue whatever runs beside it -- and not the default there; profiles/r04_bf16x3_heads.txt.  The
-//  product's user of this header is traj_tile_kernel: bfk_afrag once per net evaluation + bfk_dot per slice.)
-// (A scheduling fence alone does not hold the stages apart: MFMA intrinsics and float arithmetic are pure, and instruction
-//  selection emits them where it likes -- it collected the whole split in front of the first fence.  So every stage boundary is
-//  an EMPTY asm statement that takes the values crossing it as read-write operands: a data dependence no pass can break; the
-//  fence next to it stops the machine scheduler from moving the stage's own instructions across.)
-#ifndef L2HMC_BFK_NO_PIPE
-#define BFK_STAGE2(a, b) do { asm volatile("" : "+v"(a), "+v"(b)); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define BFK_STAGE4(a, b, c, d) do { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define BFK_STAGE2(a, b)
-#define BFK_STAGE4(a, b, c, d)
-#endif
-__device__ __forceinline__ BfkA bfk_heads3(const BfkW& ws, const BfkW& wq, const BfkW& wt, bfk_f4 x, bfk_f4& zs, bfk_f4& zq,
-                                           bfk_f4& zt) {
-  const bfk_f4 Z = {0.f, 0.f, 0.f, 0.f};
-  typedef float f2_ __attribute__((ext_vector_type(2)));
-  f2_ xa = {x[0], x[1]}, xb = {x[2], x[3]};
-  bfk_u4 hh;
-  hh[0] = bfk_pk(xa[0], xa[1]); hh[1] = bfk_pk(xb[0], xb[1]); hh[2] = hh[0]; hh[3] = hh[1];
-  BFK_STAGE2(hh, xa);
-  // stage 1: S . hh  |  first residual pair
-  zs = bfk_mfma(ws.P, hh, Z);
-  f2_ ra = {xa[0] - __uint_as_float(hh[0] << 16), xa[1] - __uint_as_float(hh[0] & 0xffff0000u)};
-  BFK_STAGE4(hh, ra, xb, zs);
-  // stage 2: Q . hh  |  second residual pair
-  zq = bfk_mfma(wq.P, hh, Z);
-  f2_ rb = {xb[0] - __uint_as_float(hh[1] << 16), xb[1] - __uint_as_float(hh[1] & 0xffff0000u)};
-  BFK_STAGE4(hh, ra, rb, zq);
-  // stage 3: T . hh  |  the m terms
-  zt = bfk_mfma(wt.P, hh, Z);
-  bfk_u4 mm;
-  mm[0] = bfk_pk(ra[0], ra[1]); mm[1] = bfk_pk(rb[0], rb[1]); mm[2] = mm[0]; mm[3] = mm[1];
-  BFK_STAGE4(mm, ra, rb, zt);
-  // stage 4: S . mm  |  first second-level residual pair
-  zs = bfk_mfma(ws.P, mm, zs);
-  f2_ sa = {ra[0] - __uint_as_float(mm[0] << 16), ra[1] - __uint_as_float(mm[0] & 0xffff0000u)};
-  BFK_STAGE4(mm, sa, rb, zs);
-  // stage 5: Q . mm  |  second pair
-  zq = bfk_mfma(wq.P, mm, zq);
-  f2_ sb = {rb[0] - __uint_as_float(mm[1] << 16), rb[1] - __uint_as_float(mm[1] & 0xffff0000u)};
-  BFK_STAGE4(mm, sa, sb, zq);
-  // stage 6: T . mm  |  the l terms
-  zt = bfk_mfma(wt.P, mm, zt);
-  bfk_u4 hl;
-  hl[0] = hh[0]; hl[1] = hh[1]; hl[2] = bfk_pk(sa[0], sa[1]); hl[3] = bfk_pk(sb[0], sb[1]);
-  BFK_STAGE2(hl, zt);
-  // stage 7: the (h l + l h) products; S first -- its transcendental chain starts while Q and T are still in the pipe
-  zs = bfk_mfma(ws.Q, hl, zs);
-  zq = bfk_mfma(wq.Q, hl, zq);
-  zt = bfk_mfma(wt.Q, hl, zt);
-  return BfkA{hh, mm, hl};
-}
+// (Round 4 also had `bfk_heads3` here: the split of one float4 software-pipelined under the nine MFMAs of the three head blocks
+//  that share it, for ONE wave per SIMD -- traj_fast_kernel's experiment.  Measured no gain (the split is 143 cycles of VALU issue
+//  whatever runs beside it: profiles/r04_bf16x3_heads.txt); removed with its only caller in round 5.  The product's user of this
+//  header is traj_tile_kernel: bfk_afrag once per net evaluation + bfk_dot per dimension slice.)
 
 // fragment storage: block b of a table of blocks = 2 x 64 x 16 bytes, P then Q, lane-major (conflict-free ds_read_b128)
 __device__ __forceinline__ void bfk_store(float* base, int block, int lane, const BfkW& w) {

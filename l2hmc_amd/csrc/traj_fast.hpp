@@ -25,12 +25,9 @@
 #include "l2hmc_kernels.hpp"
 #include "bf3k.hpp"
 
-// L2HMC_BFH = 1: the head contractions (S, T, Q: 9 of a net tail's 12 f32 MFMAs) run as K-packed bf16x3 (bf3k.hpp): their
-// fragments are split when they are staged (P | Q, 32 bytes per lane and block instead of 16), the second hidden activation is
-// split once per net evaluation.
-#ifndef L2HMC_BFH
-#define L2HMC_BFH 0
-#endif
+// (Round 4 measured the head contractions as K-packed bf16x3 -- bf3k.hpp, the form traj_tile.hpp uses -- in this kernel too: no
+//  gain with one wave per SIMD, profiles/r04_bf16x3_heads.txt; the switch and its code were removed in round 5, commit history
+//  has them.)
 
 namespace l2hmc {
 
@@ -52,7 +49,7 @@ __device__ __forceinline__ f4 ex2_4(f4 a) {
 // NTp = NW * DT >= NT: every wave's tiles exist in the tables (zero-filled beyond NT), so the loop has no
 // "is this tile live" branches.
 __host__ __device__ constexpr int fast_fw_net_f32(int NTp) { return (3 * NTp + 1) * 256; }                   // f32 tail fragments per net
-__host__ __device__ constexpr int fast_fw_net(int NTp) { return ((L2HMC_BFH ? 6 : 3) * NTp + 1) * 256; }   // staged tail fragments per net
+__host__ __device__ constexpr int fast_fw_net(int NTp) { return (3 * NTp + 1) * 256; }                       // staged tail fragments per net
 __host__ __device__ inline int fast_dpp(int NTp) { return 16 * NTp + 16; }            // padded row of a constant table
 __host__ __device__ inline int fast_fc_net(int NTp) { return 4 * fast_dpp(NTp); }     // cS(fwd) cS(bwd) cQ bQ
 __host__ __device__ inline int fast_rec(int NTp) { return 32 + 16 * NTp; }            // tbx(16) tbv(16) k1 mask
@@ -64,16 +61,7 @@ long long plan_lds_fast(KArgs& k, int NW, int DT);
 template <int DT>
 struct TailK {
   f4 w2;
-#if L2HMC_BFH
-  // one tile per wave: the split head fragments are fetched ahead of the exchange barrier; two tiles per wave: 48 registers of
-  // fragments do not fit beside the state, they are read from LDS where they are used
-  static constexpr bool PRE = DT == 1;
-  BfkW hs[PRE ? DT : 1], ht[PRE ? DT : 1], hq[PRE ? DT : 1];
-  const float* fwh;
-  int tg0, lane;
-#else
   f4 hs[DT], ht[DT], hq[DT];
-#endif
   f4 cS[DT], cQ[DT], bQ[DT];
 };
 
@@ -86,18 +74,9 @@ __device__ __forceinline__ void load_tailk(TailK<DT>& tk, const float* fw, const
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
     const int tg = w * DT + t;
-#if L2HMC_BFH
-    tk.fwh = fw + 256; tk.tg0 = w * DT; tk.lane = lane;
-    if constexpr (TailK<DT>::PRE) {
-      tk.hs[t] = bfk_load(fw + 256, 3 * tg + 0, lane);
-      tk.ht[t] = bfk_load(fw + 256, 3 * tg + 1, lane);
-      tk.hq[t] = bfk_load(fw + 256, 3 * tg + 2, lane);
-    }
-#else
     tk.hs[t] = lds4(fw + ((1 + 3 * tg + 0) * 64 + lane) * 4);
     tk.ht[t] = lds4(fw + ((1 + 3 * tg + 1) * 64 + lane) * 4);
     tk.hq[t] = lds4(fw + ((1 + 3 * tg + 2) * 64 + lane) * 4);
-#endif
     tk.cS[t] = lds4(fc + dofs + 16 * tg + 4 * q);
     tk.cQ[t] = lds4(fc + 2 * DPp + 16 * tg + 4 * q);
     tk.bQ[t] = lds4(fc + 3 * DPp + 16 * tg + 4 * q);
@@ -118,33 +97,16 @@ __device__ __forceinline__ void tail_fast(const TailK<DT>& tk, f4 hs_, F&& apply
 #pragma unroll
     for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
   }
-#if L2HMC_BFH
-  BfkA hb;
-  if constexpr (!TailK<DT>::PRE) hb = bfk_afrag(h);
-#endif
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
     f4 zs = splat(0.f), zt = splat(0.f), zq = splat(0.f);
-#if L2HMC_BFH
-    if constexpr (TailK<DT>::PRE) {       // (DT = 1) the split of h rides in the shadow of the first head MFMAs
-      hb = bfk_heads3(tk.hs[t], tk.hq[t], tk.ht[t], h, zs, zq, zt);
-    } else {
-      // (compiler barrier: without an exchange barrier in the loop -- NW = 1 -- these loop-invariant LDS loads would be
-      //  hoisted out of the step loop into registers that do not exist)
-      asm volatile("" ::: "memory");
-      zs = bfk_dot(bfk_load(tk.fwh, 3 * (tk.tg0 + t) + 0, tk.lane), hb, zs);
-      zq = bfk_dot(bfk_load(tk.fwh, 3 * (tk.tg0 + t) + 2, tk.lane), hb, zq);
-      zt = bfk_dot(bfk_load(tk.fwh, 3 * (tk.tg0 + t) + 1, tk.lane), hb, zt);
-    }
-#else
 #pragma unroll
     for (int r = 0; r < KH; ++r) {
       zs = MFMA16(tk.hs[t][r], h[r], zs);
       zq = MFMA16(tk.hq[t][r], h[r], zq);
       zt = MFMA16(tk.ht[t][r], h[r], zt);
     }
-#endif
-#if !defined(L2HMC_NO_HEAD_FENCE) && !L2HMC_BFH
+#if !defined(L2HMC_NO_HEAD_FENCE)
     // all nine head MFMAs first: by the time they have issued, zs (whose chain ended two MFMAs ago) is readable
     // without hazard nops, then zq; zt is used last (the compiler otherwise starts the exps after two chains and pays
     // the MFMA -> VALU wait states in front of them)
@@ -200,14 +162,7 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
         const int net = i >= GN * 64, j = i - net * (GN * 64), g = j >> 6;
         float sc = 1.f;
         if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
-#if L2HMC_BFH
-        if (i < NCP) {
-          if (g == 0) reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = buf[u];
-          else bfk_store(smem + A.o_fw + net * FWN + 256, g - 1, j & 63, bfk_wfrag(buf[u] * sc));
-        }
-#else
         if (i < NCP) reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = buf[u] * sc;
-#endif
       }
     }
   }

@@ -210,3 +210,37 @@ def test_training_gradients_do_not_depend_on_the_instruction_schedule(case):
         assert np.array_equal(a["flat"].view(np.uint32), b["flat"].view(np.uint32)) and np.all(np.isfinite(a["flat"]))
         written = np.isfinite(a["slots"])
         assert written.mean() > 0.5           # (the dump really holds gradients: most slot entries are written)
+
+
+def test_empty_shard_of_a_training_step_contributes_a_zero_gradient():
+    """A rank that holds no chains (fewer chains than ranks) still takes part in the step's ONE all-reduce: its
+    `l2hmc_train_step` must overwrite its gradient slice and loss terms with zeros (the reduction launch overwrites, nothing
+    zeroes beforehand -- round 4 returned early and the rank re-sent the previous step's already-reduced gradient)."""
+    import torch
+    from l2hmc_amd import _ffi
+    from l2hmc_amd.training import Trainer
+    g = load("train_icg50")
+    dyn = hip_dynamics(g)
+    dyn.eps_override = None
+    with torch.no_grad():
+        dyn.alpha.fill_(float(np.log(g["eps"])))
+    tr = Trainer(dyn)
+    d = int(g["x_dim"])
+    tr._flat_ext.fill_(123.0)                                   # "last step's reduced gradient and tail"
+    e2 = torch.empty((0, d), device="cuda")
+    a, keep, _ = tr._train_args(e2, e2, torch.empty(0, dtype=torch.uint8, device="cuda"), 64)
+    st = _ffi.L2hmcTrainStep()
+    st.x_head, st.n_head = None, 0
+    lt = torch.full((3,), 7.0, dtype=torch.float64, device="cuda")
+    st.loss = lt.data_ptr()
+    st.terms = tr._flat_ext[tr.n_grad:].data_ptr()
+    _ffi.check(_ffi.lib().l2hmc_train_step(a, st, _ffi.current_stream(dyn.device)))
+    torch.cuda.synchronize()
+    assert float(tr.flat.abs().max()) == 0.0
+    assert float(tr._flat_ext[tr.n_grad:tr.n_grad + 6].abs().max()) == 0.0
+    assert lt.cpu().tolist() == [0.0, 0.0, 0.0]
+    # ... and an optimiser update on zero chains is refused
+    st.theta, st.m, st.v = tr.theta.data_ptr(), tr.m.data_ptr(), tr.v.data_ptr()
+    st.lr, st.beta1, st.beta2, st.epsilon, st.step = 1e-3, 0.9, 0.999, 1e-8, 1
+    with pytest.raises(RuntimeError, match="at least one chain"):
+        _ffi.check(_ffi.lib().l2hmc_train_step(a, st, _ffi.current_stream(dyn.device)))
