@@ -223,14 +223,16 @@ def target_of(g, dtype=np.float64):
 
 
 def propose_loss_and_grad(x0, v0, direction, target, xnet, vnet, eps, mask, T, scale=0.1,
-                          dtype=np.float64):
+                          dtype=np.float64, float32_weights=True):
     """One direction-mixed proposal from x0 with momenta v0 (each chain in its own direction) and
     its loss term  scale * mean(1/v1) - mean(v1)/scale,  v1 = |x0 - Lx|^2 p + 1e-4  (nb 164-169).
     Returns (loss, Lx, p, grads) with grads = {'xnet': {...}, 'vnet': {...}, 'eps': d loss/d eps}."""
     x0, v0 = np.asarray(x0, dtype), np.asarray(v0, dtype)
     N, d = x0.shape
-    xn = {k: np.asarray(xnet[k], np.float32).astype(dtype) for k in NET_KEYS}
-    vn = {k: np.asarray(vnet[k], np.float32).astype(dtype) for k in NET_KEYS}
+    # (the fixtures' weights ARE float32; a training replay in `dtype` -- tools/ess_seed_study.py -- keeps its own precision)
+    wt = np.float32 if float32_weights else dtype
+    xn = {k: np.asarray(xnet[k], wt).astype(dtype) for k in NET_KEYS}
+    vn = {k: np.asarray(vnet[k], wt).astype(dtype) for k in NET_KEYS}
     eps = dtype(eps)
     mask = np.asarray(mask, dtype)
     fwd = (np.asarray(direction) != 0)[:, None]
