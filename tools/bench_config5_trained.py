@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(dev, updates=300, chains=8192, mh_steps=300, burn=100, train_batch=512, seed=0, hmc_eps=(0.05, 0.075, 0.1, 0.125, 0.15, 0.175)):
+def run(dev, updates=300, chains=8192, mh_steps=300, burn=100, train_batch=512, seed=0, hmc_eps=(0.05, 0.075, 0.1, 0.125, 0.15, 0.175),
+        checkpoints=()):
     from l2hmc_amd import Dynamics, chain_operator, func_utils, propose, vae
     from l2hmc_amd.training import Trainer
     d, H, T = 50, 200, 5
@@ -51,17 +52,22 @@ def run(dev, updates=300, chains=8192, mh_steps=300, burn=100, train_batch=512, 
         ls = torch.full((n, d), log_sigma_v, device=dev)
         return inp, torch.randn((n, d), device=dev, generator=gen) * torch.exp(ls), ls
 
-    # ---- (i) train ------------------------------------------------------------------------------------------------
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
+    # ---- (i) train (in stages when `checkpoints` asks for the ESS along the way) -----------------------------------------
     trace = []
-    for t in range(updates):
-        inp, zq, ls = batch(train_batch)
-        loss, _, px, _ = trainer.sampler_step(zq, inp, ls, MH=5)
-        if t % max(1, updates // 6) == 0 or t == updates - 1:
-            trace.append({"update": t, "loss": float(loss), "accept": float(px.mean()), "eps": float(torch.exp(dyn.alpha.detach()))})
-    torch.cuda.synchronize(dev)
-    t_train = time.perf_counter() - t0
+    state = {"t": 0, "seconds": 0.0}
+
+    def train_to(target):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        while state["t"] < target:
+            t = state["t"]
+            inp, zq, ls = batch(train_batch)
+            loss, _, px, _ = trainer.sampler_step(zq, inp, ls, MH=5)
+            if t % max(1, updates // 6) == 0 or t == updates - 1:
+                trace.append({"update": t, "loss": float(loss), "accept": float(px.mean()), "eps": float(torch.exp(dyn.alpha.detach()))})
+            state["t"] = t + 1
+        torch.cuda.synchronize(dev)
+        state["seconds"] += time.perf_counter() - t0
 
     # ---- (ii) measure on 64 images x (chains / 64) chains ----------------------------------------------------------------
     n_img = 64
@@ -105,6 +111,14 @@ def run(dev, updates=300, chains=8192, mh_steps=300, burn=100, train_batch=512, 
     def l2hmc_cs_step(z):                                       # eval_sampler.py:161-162
         _, _, p, out = chain_operator(z, dyn, int(host_rng.randint(1, 4)), aux=aux, do_mh_step=True)
         return out[0], p
+    along = []
+    for cp in sorted(set(int(c) for c in checkpoints if 0 < int(c) < updates)):
+        train_to(cp)
+        r = measure(l2hmc_step, "L2HMC after %d updates, propose" % cp)
+        r.update({"updates": cp, "train_seconds_so_far": state["seconds"]})
+        along.append(r)
+    train_to(updates)
+    t_train = state["seconds"]
     res = [measure(l2hmc_step, "L2HMC trained, propose"), measure(l2hmc_cs_step, "L2HMC trained, chain_operator nb_steps~U{1..3}")]
     for eps in hmc_eps:
         hd = Dynamics(d, energy, T=T, eps=float(eps), hmc=True, device=dev)
@@ -123,6 +137,7 @@ def run(dev, updates=300, chains=8192, mh_steps=300, burn=100, train_batch=512, 
                         "%d MH steps (%d burn-in)" % (updates, train_batch, chains, n_img, per, mh_steps, burn),
             "train": {"updates": updates, "seconds": t_train, "ms_per_update": 1e3 * t_train / max(1, updates), "trace": trace},
             "samplers": res,
+            "along_the_way": along,
             "l2hmc_chain_leapfrog_steps_per_sec": chains * T * 1e3 / res[0]["ms_per_mh_step"],
             "l2hmc_frac_of_fp32_roof": chains * T * flops_step * 1e3 / res[0]["ms_per_mh_step"] / 1e12 / 157.3,
             "best_hmc": best_hmc["sampler"],
@@ -134,5 +149,7 @@ if __name__ == "__main__":
     ap.add_argument("--updates", type=int, default=300)
     ap.add_argument("--chains", type=int, default=8192)
     ap.add_argument("--mh-steps", type=int, default=300)
+    ap.add_argument("--checkpoints", type=str, default="", help="comma-separated update counts at which the L2HMC ESS is measured too")
     a = ap.parse_args()
-    print(json.dumps(run(torch.device("cuda", 0), updates=a.updates, chains=a.chains, mh_steps=a.mh_steps), indent=1))
+    cps = [int(c) for c in a.checkpoints.split(",") if c]
+    print(json.dumps(run(torch.device("cuda", 0), updates=a.updates, chains=a.chains, mh_steps=a.mh_steps, checkpoints=cps), indent=1))
