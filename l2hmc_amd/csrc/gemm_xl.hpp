@@ -28,14 +28,10 @@
 //     the barrier at the end (the matrix pipe alone: 3280).  Hazards: tile t + 2 is stored into tile t's buffer only behind
 //     the barrier of k-tile t, which every wave reaches with its reads of tile t complete; tile t + 1 is read only behind the
 //     barrier that follows its stores.
-//   * round 5, L2HMC_XL_DMA = 1 (the default): staging by `global_load_lds_dwordx4` -- gfx950's 16-byte LDS DMA.  A wave-level
-//     instruction writes 64 consecutive 16-byte chunks at M0 + 16 lane, which IS this layout's block of 16 rows x 4 chunks; the
-//     XOR swizzle moves into the global address (lane (row, slot) fetches k-chunk slot ^ ((row >> 2) & 3)).  No staging
-//     registers (36 VGPRs), no ds_write_b128 (9 per thread and k-tile: 42 cycles of matrix-pipe idle time each for a lone wave).
-//     Tile kt + 2 is requested behind the barrier of k-tile kt -- into the buffer tile kt was just read from -- and has until the
-//     barrier of k-tile kt + 1 to land (`s_waitcnt vmcnt(0)` in front of it): the same one-k-tile latency budget as the register
-//     form.  Written as inline assembly (M0 + the DMA): the compiler's own wait-count pass makes EVERY later ds_read wait for an
-//     outstanding LDS DMA it cannot prove disjoint, which would serialise the two buffers.
+//   * (round 5, measured and not kept -- profiles/r05_gemm_dma.txt, the code is one commit in the history: staging by gfx950's 16-byte
+//     LDS DMA, `global_load_lds_dwordx4`, the swizzle moved into the global address.  Bit-identical, 36 registers and every
+//     ds_write_b128 gone, and 4140 cycles per k-tile against 3990: nine wave-level DMAs cost more issue time than nine loads + nine
+//     stores.  Config 5: a tie at 8192 chains, 2.6 % slower at 4096.  Without ANY staging the k-tile takes 3412 cycles.)
 // 8192 x 1024 x 1024 standalone: 91 us against 121-125 us for the in-loop split in the same cold-clock run (x1.33-1.37; the chip
 // clocks DOWN as the matrix pipe fills -- 1.74 GHz against 1.90 -- so cycles improve more than microseconds); inside config 5's
 // chain of launches (where every epilogue also writes 6 bytes of planes per element): 3.79 -> 3.57 ms per proposal in an A/B on one
@@ -59,13 +55,6 @@ __device__ __forceinline__ void xl_static_for(F&& f) {
 #ifdef L2HMC_XL_TIMING      // tools/ubench_gemm_bf3.hip: shader cycles of the k loop of wave 0, summed over the workgroups
 __device__ unsigned long long xl_ticks[4];
 #endif
-#ifndef L2HMC_XL_DMA
-#define L2HMC_XL_DMA 1
-#endif
-// one wave-level LDS DMA: lane L's 16 bytes at `gptr` land at LDS byte offset `lds_off` (wave-uniform) + 16 L
-__device__ __forceinline__ void xl_dma16(const void* gptr, unsigned lds_off) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_off) : "memory");
-}
 #ifndef L2HMC_XL_NO_FENCE
 #define XL_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -90,13 +79,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
   const int n0 = bx * TN;
 
   constexpr int PA = (TM + RPS - 1) / RPS, PB = (TN + RPS - 1) / RPS, NA = 3 * PA, NB = 3 * PB, NCH = NA + NB;
-  const int srow = tid >> 2, sch = tid & 3;
-#if !L2HMC_XL_DMA
   u4v rch[NCH];
+  const int srow = tid >> 2, sch = tid & 3;
   const int s_lds = srow * 4 + (sch ^ ((srow >> 2) & 3));             // this thread's chunk inside a pass of RPS rows
-#endif
   const bool fast = m0 + TM <= g.M;          // (the weight planes hold whole tiles of rows and both row strides whole k-tiles)
-#if !L2HMC_XL_DMA
   auto gload1 = [&](auto ci_c, int k0, auto fast_c) {
     constexpr int ci = decltype(ci_c)::value;
     constexpr bool isA = ci < NA;
@@ -118,26 +104,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
     constexpr int T = isA ? TM : TN, rbase = isA ? 0 : TM;
     if (T % RPS == 0 || srow + RPS * pass < T) xlp_smem[buf * BUFC + (pl * TR + rbase + RPS * pass) * 4 + s_lds] = rch[ci];
   };
-#endif
-
-#if L2HMC_XL_DMA
-  const int wu = __builtin_amdgcn_readfirstlane(w);
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)xlp_smem;
-  const int kq8 = 8 * (sch ^ ((srow >> 2) & 3));                      // the k-chunk that belongs at this lane's LDS position
-  auto dma1 = [&](auto ci_c, int k0, int buf, auto fast_c) {
-    constexpr int ci = decltype(ci_c)::value;
-    constexpr bool isA = ci < NA;
-    constexpr int pl = isA ? ci / PA : (ci - NA) / PB, pass = isA ? ci % PA : (ci - NA) % PB;
-    constexpr int rbase = isA ? 0 : TM;
-    const unsigned short* base = isA ? g.Ap + pl * g.ap_plane : g.Bp + pl * g.bp_plane;
-    const long long ld = isA ? g.ldap : g.ldbp;
-    long long r = (isA ? m0 : (long long)n0) + srow + RPS * pass;
-    if constexpr (isA && !decltype(fast_c)::value) r = r < g.M - 1 ? r : (long long)g.M - 1;
-#if !defined(L2HMC_XL_ABL_NODMA)     // (timing ablation, wrong results: no staging at all)
-    xl_dma16(base + r * ld + k0 + kq8, lds0 + 16u * (unsigned)(buf * BUFC + (pl * TR + rbase + RPS * pass + 16 * wu) * 4));
-#endif
-  };
-#endif
 
   f4 acc[WNB][WMB];
 #pragma unroll
@@ -149,9 +115,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
   // staging chunks per stage, in the first three stages of the k-tile: the compiler waits for EVERY outstanding load before the
   // first ds_write of the next k-tile (its counter bookkeeping across the loop edge is conservative), so the youngest load must
   // be old by then (3 stages 4647 cycles per k-tile, 6 stages 4817, 9 stages 4677 -- measured on the end-of-tile-barrier form)
-#if !L2HMC_XL_DMA
   constexpr int CPS = (NCH + 2) / 3;
-#endif
   const int f_lds = c * 4 + (q ^ ((c >> 2) & 3));                     // this lane's chunk inside a 16-row fragment
   // The k-tile (header): fragment order W0 A0 A1 W1 W2 W3 A2 A3 -- A0 / A1 are dead after the fourth stage and take the next tile's
   // behind the barrier; its W0 waits in 12 extra registers (sw0n).  The loop exists twice: whole row tiles load without the row clamp.
@@ -181,7 +145,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
         if (p == 5) acc[i][j] = mfma_bf16(sw[i].h, a_.h, acc[i][j]);
       }
   };
-#if !L2HMC_XL_DMA
   auto stage_chunks = [&](auto tc, int buf, int k_next) {
     constexpr int t = decltype(tc)::value;
     xl_static_for<0, CPS>([&](auto uc) {
@@ -192,57 +155,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
       }
     });
   };
-#endif
-#if L2HMC_XL_DMA
-  static_assert(TM % RPS == 0 && TN % RPS == 0, "every staging pass is a whole block of rows");
-  auto dma_chunks = [&](auto hc, int buf, int k0) {                   // half h of a tile's NCH wave-level DMAs
-    constexpr int h = decltype(hc)::value, HALF = (NCH + 1) / 2;
-    xl_static_for<0, HALF>([&](auto uc) {
-      constexpr int ci = HALF * h + decltype(uc)::value;
-      if constexpr (ci < NCH) dma1(std::integral_constant<int, ci>{}, k0, buf, fast_c);
-    });
-  };
-  dma_chunks(std::integral_constant<int, 0>{}, 0, 0); dma_chunks(std::integral_constant<int, 1>{}, 0, 0);
-  if (nk > 1) { dma_chunks(std::integral_constant<int, 0>{}, 1, 32); dma_chunks(std::integral_constant<int, 1>{}, 1, 32); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  rdW(sw0n, xlp_smem + f_lds, 0); rdA(sa[0], xlp_smem + f_lds, 0); rdA(sa[1], xlp_smem + f_lds, 1);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 2 < nk;                                   // (wave-uniform)
-    const u4v* sb = xlp_smem + buf * BUFC + f_lds;
-    const u4v* sbn = xlp_smem + (buf ^ 1) * BUFC + f_lds;
-    sw[0] = sw0n;
-    rdW(sw[1], sb, 1); rdW(sw[2], sb, 2);
-    XL_FENCE();
-    rdW(sw[3], sb, 3);
-    mm(sw[0], sa[0], sa[1], acc[0][0], acc[0][1]);
-    XL_FENCE();
-    rdA(sa[2], sb, 2);
-    mm(sw[1], sa[0], sa[1], acc[1][0], acc[1][1]);
-    XL_FENCE();
-    rdA(sa[3], sb, 3);
-    mm(sw[2], sa[0], sa[1], acc[2][0], acc[2][1]);
-    XL_FENCE();
-    mm(sw[3], sa[0], sa[1], acc[3][0], acc[3][1]);
-    XL_FENCE();
-    // every wave: its reads of tile kt are complete (lgkmcnt) and its share of tile kt + 1 -- requested one k-tile ago -- has
-    // landed in the other buffer (vmcnt); behind the barrier that holds for all of them
-#if defined(L2HMC_XL_ABL_NOWAIT)      // timing ablation (wrong results): the barrier without the DMA wait
-    asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier" ::: "memory");
-#endif
-    XL_FENCE();
-    rdA(sa[0], sbn, 0); rdA(sa[1], sbn, 1); rdW(sw0n, sbn, 0);
-    if (more) dma_chunks(std::integral_constant<int, 0>{}, buf, (kt + 2) * 32);     // tile kt + 2 into the buffer just released
-    mm4(sa[2], 2);
-    XL_FENCE();
-    if (more) dma_chunks(std::integral_constant<int, 1>{}, buf, (kt + 2) * 32);
-    mm4(sa[3], 3);
-    XL_FENCE();
-  }
-#else
   xl_static_for<0, NCH>([&](auto ci) { gload1(ci, 0, fast_c); });
   xl_static_for<0, NCH>([&](auto ci) { sstore1(ci, 0); });
   __syncthreads();
@@ -275,7 +187,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
     mm4(sa[3], 3);
     XL_FENCE();
   }
-#endif
   };
 #ifdef L2HMC_XL_TIMING
   const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
