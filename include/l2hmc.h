@@ -259,6 +259,17 @@ typedef int (*L2hmcEnergyCallback)(void* user, const float* x, int64_t ldx, int6
 typedef int (*L2hmcHvpCallback)(void* user, const float* x, int64_t ldx, const float* u, int64_t ldu, int64_t n_chains,
                                 int32_t d, float* hv_out, int64_t ldhv, void* stream);
 
+/* A caller-supplied S/T/Q net (the reference's `net_factory` may return ANY callable [a, b, tau, aux] -> [S, T, Q],
+ * utils/dynamics.py:69-79; only the notebook's architecture is fused into kernels).  Called on the host between launches, like
+ * the energy callback: `ab` is the (n_chains, 2 d) block [a | b] of first-layer inputs on the device (row stride ldab floats):
+ * a = ab[:, :d], b = ab[:, d:]; net = 0 (XNet: a = v_h, b = kept * x) or 1 (VNet: a = x, b = grad U); chain n sits at schedule
+ * row `it` if it runs forward (direction[n] != 0, or direction == NULL and direction_all != 0), else T - 1 - it: its time input
+ * is tau = (cos, sin)(2 pi row / T) (dynamics.py:99-105).  The callback enqueues, on `stream`, the FINAL S, T, Q (dynamics.py's
+ * `scale, translation, transformed`) as the three (n_chains, d) column blocks of stq_out (row stride 3 d).  Nonzero return
+ * aborts the trajectory.  Sampling only: the trainers differentiate the fused architecture. */
+typedef int (*L2hmcNetCallback)(void* user, int32_t net, const float* ab, int64_t ldab, int64_t n_chains, int32_t d, int32_t it,
+                                const uint8_t* direction, int32_t direction_all, float* stq_out, void* stream);
+
 typedef struct L2hmcSplitArgs {
   const L2hmcNet* xnet;
   const L2hmcNet* vnet;
@@ -304,6 +315,9 @@ typedef struct L2hmcSplitArgs {
                                   *       significant cross products on the bf16 MFMA (16x the f32 MFMA rate), fp32
                                   *       accumulation: dropped terms <= 3 x 2^-24 |x y| per product, i.e. fp32-level
                                   *       accuracy (measured against float64 in profiles/ and the config-5 parity tests) */
+  L2hmcNetCallback net_cb;       /* (ABI 5) non-NULL: the caller's nets (see L2hmcNetCallback); xnet = vnet = aux_encoder = NULL,
+                                  *    H is ignored, hmc = 0.  Goes with energy_cb or a built-in energy.                 */
+  void* net_cb_user;             /* passed back as the callback's first argument                                         */
 } L2hmcSplitArgs;
 
 int64_t l2hmc_split_workspace_floats(int64_t n_chains, int32_t d, int32_t H, int32_t T,

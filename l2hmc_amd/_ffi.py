@@ -64,12 +64,16 @@ class L2hmcSplitArgs(C.Structure):
                 ("x_out", _fp), ("v_out", _fp), ("logjac_out", _fp), ("p_out", _fp), ("x_next", _fp),
                 ("workspace", _fp), ("workspace_floats", C.c_int64), ("hmc", C.c_int32),
                 ("bce_scale", C.c_float), ("energy", C.POINTER(L2hmcEnergy)), ("reuse", C.c_int32),
-                ("energy_cb", _fp), ("energy_cb_user", _fp), ("gemm_mode", C.c_int32)]
+                ("energy_cb", _fp), ("energy_cb_user", _fp), ("gemm_mode", C.c_int32),
+                ("net_cb", _fp), ("net_cb_user", _fp)]
 
 
 # include/l2hmc.h L2hmcEnergyCallback: (user, x, ldx, n_chains, d, U_out, grad_out, ldg, stream) -> int
 ENERGY_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_int64, C.c_void_p)
+# L2hmcNetCallback(user, net, ab, ldab, n_chains, d, it, direction, direction_all, stq_out, stream)
+NET_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                           C.c_int32, C.c_void_p, C.c_void_p)
 # L2hmcHvpCallback(user, x, ldx, u, ldu, n_chains, d, hv_out, ldhv, stream)
 HVP_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                            C.c_void_p, C.c_int64, C.c_void_p)

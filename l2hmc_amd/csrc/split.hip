@@ -112,9 +112,11 @@ __global__ __launch_bounds__(256) void k_v_half(const float* out3, L2hmcNet w, c
   const float eps = alpha != nullptr ? expf(*alpha) : eps_host, heps = 0.5f * eps, sgn = fwd ? 1.f : -1.f;
   float acc = 0.f;
   for (int k = lane; k < d; k += 64) {
-    const float S = expf(w.lam_s[k]) * tanhf(out3[n * 3 * d + k] + w.bs[k]);
-    const float T = out3[n * 3 * d + d + k] + w.bt[k];
-    const float Q = expf(w.lam_q[k]) * tanhf(out3[n * 3 * d + 2 * d + k] + w.bq[k]);
+    // (w.lam_s == NULL: out3 already holds the final S | T | Q of a caller-supplied net, L2hmcNetCallback)
+    const bool raw = w.lam_s == nullptr;
+    const float S = raw ? out3[n * 3 * d + k] : expf(w.lam_s[k]) * tanhf(out3[n * 3 * d + k] + w.bs[k]);
+    const float T = raw ? out3[n * 3 * d + d + k] : out3[n * 3 * d + d + k] + w.bt[k];
+    const float Q = raw ? out3[n * 3 * d + 2 * d + k] : expf(w.lam_q[k]) * tanhf(out3[n * 3 * d + 2 * d + k] + w.bq[k]);
     const float sv = sgn * heps * S, ES = expf(sv), EQ = expf(eps * Q);
     const float cc = heps * (T - EQ * g[n * ldg + k]);
     const float vi = vin[n * ldvi + k];
@@ -143,9 +145,10 @@ __global__ __launch_bounds__(256) void k_x_half(const float* out3, L2hmcNet w, c
     const float m = masks[s * d + k];
     const float k1 = fwd ? m : 1.f - m;
     const float kp = second ? 1.f - k1 : k1, up = 1.f - kp;
-    const float S = expf(w.lam_s[k]) * tanhf(out3[n * 3 * d + k] + w.bs[k]);
-    const float T_ = out3[n * 3 * d + d + k] + w.bt[k];
-    const float Q = expf(w.lam_q[k]) * tanhf(out3[n * 3 * d + 2 * d + k] + w.bq[k]);
+    const bool raw = w.lam_s == nullptr;
+    const float S = raw ? out3[n * 3 * d + k] : expf(w.lam_s[k]) * tanhf(out3[n * 3 * d + k] + w.bs[k]);
+    const float T_ = raw ? out3[n * 3 * d + d + k] : out3[n * 3 * d + d + k] + w.bt[k];
+    const float Q = raw ? out3[n * 3 * d + 2 * d + k] : expf(w.lam_q[k]) * tanhf(out3[n * 3 * d + 2 * d + k] + w.bq[k]);
     const float sx = sgn * eps * S, ES = expf(sx), EQ = expf(eps * Q);
     const float tr = eps * (EQ * vh[n * ldvh + k] + T_);
     const float zi = zin[n * ldzi + k];
@@ -442,7 +445,10 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   t_gemm_bf3 = a->gemm_mode;
   const bool user = a->energy_cb != nullptr;        // the caller's own energy, evaluated on the host between launches
   const bool builtin = a->energy != nullptr;        // a target of utils/distributions.py instead of the decoder posterior
+  const bool unets = a->net_cb != nullptr;          // the caller's own S/T/Q nets (any callable, dynamics.py:69-79)
   int rc;
+  if (unets && (a->xnet || a->vnet || a->aux_encoder || a->hmc || !(user || builtin)))
+    return fail(L2HMC_ERR_ARG, "net_cb excludes xnet / vnet / aux_encoder / hmc and goes with energy_cb or a built-in energy%s");
   if (user) {
     if (a->decoder || a->energy) return fail(L2HMC_ERR_ARG, "energy_cb excludes decoder and energy%s");
     if (a->bce_scale != 0.f) return fail(L2HMC_ERR_UNSUPPORTED, "bce_scale with a caller-supplied energy (anneal it in the callback)%s");
@@ -456,11 +462,11 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   }
   if (a->aux_encoder && (rc = check_mlp(a->aux_encoder, "aux_encoder"))) return rc;
   const long long N = a->n_chains;
-  const int d = a->d, H = a->H, T = a->T;
+  const int d = a->d, H = unets ? 4 : a->H, T = a->T;      // (caller-supplied nets: no hidden activations are planned for)
   if (N < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
   if (N == 0) return L2HMC_OK;
   const bool hmc = a->hmc != 0;
-  if ((!hmc && (!a->xnet || !a->vnet || !a->masks || !a->trig)) || (!builtin && !user && !a->aux) || !a->x || !a->v || !a->workspace)
+  if ((!hmc && ((!unets && (!a->xnet || !a->vnet)) || !a->masks || !a->trig)) || (!builtin && !user && !a->aux) || !a->x || !a->v || !a->workspace)
     return fail(L2HMC_ERR_ARG, "l2hmc_trajectory_split: NULL pointer%s");
   if (!(a->bce_scale >= 0.f && a->bce_scale <= 1.f)) return fail(L2HMC_ERR_ARG, "bce_scale must be in [0, 1] (0 = off)%s");
   const float beta = a->bce_scale > 0.f ? a->bce_scale : 1.f;
@@ -496,7 +502,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   float *h1 = w + p.h1, *h2 = w + p.h2, *out3 = w + p.out3, *tb = w + p.tb, *ld = w + p.ld;
   float* aux_h = a->aux_encoder ? w + p.aux_h : nullptr;
   static const L2hmcNet no_net = {};
-  const L2hmcNet &xn = hmc ? no_net : *a->xnet, &vn = hmc ? no_net : *a->vnet;
+  const L2hmcNet &xn = (hmc || unets) ? no_net : *a->xnet, &vn = (hmc || unets) ? no_net : *a->vnet;
   const unsigned char* dir = a->direction;
   const int dall = a->direction_all;
   const unsigned nw4 = (unsigned)((N + 3) / 4);                  // one wave per chain, 4 per workgroup
@@ -524,7 +530,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     if (!have_w) mlp3_transposes(s, enc, ews);
     if (!have_auxh) mlp3_forward(s, enc, a->aux, N, ews, aux_h);
   }
-  if (!hmc && !have_w) {
+  if (!hmc && !unets && !have_w) {
     hipLaunchKernelGGL(k_time_table, dim3(nblk(2LL * T * H)), dim3(256), 0, s, xn, vn, a->trig, T, H, tb);
     // per net: [W1; W2]^T (H x 2d), W4^T (H x H), [Ws | Wt | Wq]^T (3d x H)
     const L2hmcNet* nets[2] = {&xn, &vn};
@@ -578,7 +584,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     ne_cus = 256;
   const int ne_cb = N >= 32LL * ne_cus ? 2 : 1;            // (32 chains per CU = one 8-wave workgroup each; 8192 on 256 CUs)
   const size_t ne_lds = net_eval_lds_bytes(d, H, ne_cb);
-  const bool ne_ok = (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(2 * d) <= 16 * NE_MAXKT && ne_lds <= 160 * 1024;
+  const bool ne_ok = !unets && (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(2 * d) <= 16 * NE_MAXKT && ne_lds <= 160 * 1024;
   if (ne_ok && !hmc && ne_lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_eval_kernel<2, 8>) : reinterpret_cast<const void*>(net_eval_kernel<1, 4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
@@ -586,7 +592,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   }
   // `upd`: the half-update that consumes the evaluation; fused into net_eval_kernel when that kernel runs, else the
   // stand-alone update kernel(s) follow the three GEMMs
-  auto net_eval = [&](const L2hmcNet& nw, int net, const float* ab, int it, NetEvalArgs::Update upd) {
+  auto net_eval = [&](const L2hmcNet& nw, int net, const float* ab, int it, NetEvalArgs::Update upd) -> int {
     upd.bs = nw.bs; upd.bt = nw.bt; upd.bq = nw.bq; upd.lam_s = nw.lam_s; upd.lam_q = nw.lam_q;
     upd.alpha = a->alpha; upd.eps_host = a->eps_host; upd.ld = ld; upd.masks = a->masks;
     if (ne_ok) {
@@ -598,8 +604,12 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
       const unsigned blocks = (unsigned)((N + 16 * ne_cb - 1) / (16 * ne_cb));
       if (ne_cb == 2) hipLaunchKernelGGL((net_eval_kernel<2, 8>), dim3(blocks), dim3(512), ne_lds, s, na);
       else hipLaunchKernelGGL((net_eval_kernel<1, 4>), dim3(blocks), dim3(256), ne_lds, s, na);
-      return;
+      return L2HMC_OK;
     }
+    if (unets) {     // the caller's net writes the final S | T | Q into out3 (nw = no_net: the update kernels take them as they are)
+      const int r = a->net_cb(a->net_cb_user, net, ab, L, N, d, it, dir, dall, out3, stream);
+      if (r) return fail(L2HMC_ERR_ARG, "the net callback failed (returned %s%lld)", "", (long long)r);
+    } else {
     GemmArgs ga = gemm_args(ab, L, w + (net == 0 ? p.nx12t : p.nv12t), ceil16(L), h1, H, N, H, L);
     ga.E = aux_h; ga.lde = H; ga.tb = tb + (long long)net * T * H; ga.dir = dir; ga.dir_all = dall; ga.it = it; ga.T = T;
     launch_gemm<EPI_NET1>(ga, s, SHAPE_MID);
@@ -608,6 +618,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     launch_gemm<EPI_BIAS_RELU>(ga, s, SHAPE_MID);
     ga = gemm_args(h2, H, w + (net == 0 ? p.nxht : p.nvht), ceil16(H), out3, 3 * d, N, 3 * d, H);
     launch_gemm<EPI_BIAS>(ga, s, SHAPE_MID);
+    }
     if (upd.mode == 1) {
       hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, out3, nw, upd.vin, upd.ldvi, upd.g, upd.ldg, upd.vout, upd.ldvo, ld,
                          dir, dall, a->alpha, a->eps_host, N, d);
@@ -618,6 +629,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
       hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, out3, nw, upd.zin, upd.ldzi, upd.vh, upd.ldvh, upd.zout, upd.ldzo,
                          upd.xin_next, upd.ldxn, ld, a->masks, dir, dall, it, T, upd.second, a->alpha, a->eps_host, N, d);
     }
+    return L2HMC_OK;
   };
   auto v_update = [&](const float* vin, int ldvi, float* vout, int ldvo, bool with_mask) {
     NetEvalArgs::Update u = {};
@@ -641,11 +653,11 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
       hipLaunchKernelGGL(k_hmc_kick, dim3(nblk(N * d)), dim3(256), 0, s, vc, y, g, L, a->alpha, a->eps_host, dir, dall, N, d);
       continue;
     }
-    net_eval(vn, 1, xc, it, v_update(vc, d, vh, L, true));            // v_h, and xin = k1 x for the next evaluation
-    net_eval(xn, 0, vh, it, x_update(xc, L, y, d, xin, 0));            // y, xin = (1 - k1) y
-    net_eval(xn, 0, vh, it, x_update(y, d, xc, L, nullptr, 1));        // x'
+    if ((rc = net_eval(vn, 1, xc, it, v_update(vc, d, vh, L, true)))) return rc;      // v_h, and xin = k1 x for the next evaluation
+    if ((rc = net_eval(xn, 0, vh, it, x_update(xc, L, y, d, xin, 0)))) return rc;      // y, xin = (1 - k1) y
+    if ((rc = net_eval(xn, 0, vh, it, x_update(y, d, xc, L, nullptr, 1)))) return rc;  // x'
     if ((rc = energy_eval(last ? U1d : nullptr))) return rc;
-    net_eval(vn, 1, xc, it, v_update(vh, L, vc, d, false));            // v'
+    if ((rc = net_eval(vn, 1, xc, it, v_update(vh, L, vc, d, false)))) return rc;      // v'
   }
   hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, vc, w + p.K1, (float*)nullptr, N, d);
   if (a->x_out) (void)hipMemcpy2DAsync(a->x_out, sizeof(float) * d, xc, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);

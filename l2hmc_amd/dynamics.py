@@ -60,6 +60,7 @@ class Dynamics(object):
         self.variant = 0                # kernel geometry override (0 = auto), see l2hmc.h
         self.eps_override = None        # float: bypass exp(alpha) (exact step size for parity tests)
         self.anneal_beta = 0.0          # AIS bridge (utils/ais.py:46-47): U := (1-b) |x|^2/2 + b U; 0 = off
+        self._user_nets = False         # nets outside the fused architecture: evaluated by the caller's torch code (net_cb)
         self.gemm_mode = 1              # GEMM engine, decoder-sized products: 1 = bf16x3 (exact 3-way bf16 split of every
         #                                 fp32 operand on the bf16 MFMA, fp32-level accuracy), 0 = f32-input MFMA
 
@@ -95,23 +96,30 @@ class Dynamics(object):
             self._xw = extract_stq(self.XNet, self.x_dim)
             self._vw = extract_stq(self.VNet, self.x_dim)
             if self._xw is None or self._vw is None or self._xw['H'] != self._vw['H']:
-                raise NotImplementedError(
-                    "net_factory must build the S/T/Q architecture of l2hmc_amd.layers.stq_network "
-                    "(SCGExperiment.ipynb `network`); other structures are not fused")
-            self.H = self._xw['H']
-            # mnist_vae.py:134-150 builds ONE `encoder_sampler` and hands it to both nets; the split engine
-            # evaluates that shared image branch once per trajectory.  Two different branches (or one net
-            # with a branch and one without) would silently run VNet on XNet's encoder: refuse.
-            ax, av = self._xw['aux_encoder'], self._vw['aux_encoder']
-            if (ax is None) != (av is None) or (ax is not None and any(
-                    ax[k].data_ptr() != av[k].data_ptr() for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'))):
-                raise NotImplementedError(
-                    "XNet and VNet must share ONE aux branch (the same encoder_sampler parameters, as in "
-                    "mnist_vae.py:134-150) or have none; separate image branches per net are not implemented")
-            for w in (self._xw, self._vw):
-                for k in _ffi.NET_FIELDS:
-                    if w[k].device != self.device:
-                        raise ValueError("net parameters live on %s, Dynamics on %s" % (w[k].device, self.device))
+                # dynamics.py:69-79: `net_factory` may return ANY callable [a, b, tau, aux] -> [S, T, Q].  Only the notebook's
+                # architecture is fused into kernels; anything else is evaluated by the caller's own torch code between the
+                # library's launches (L2hmcSplitArgs.net_cb) -- the slow path, sampling only (the trainers differentiate the
+                # fused architecture).
+                if not (callable(self.XNet) and callable(self.VNet)):
+                    raise TypeError("net_factory must return callables net([a, b, tau, aux]) -> [S, T, Q]")
+                self._xw = self._vw = None
+                self._user_nets = True
+                self.H = 0
+            else:
+                self.H = self._xw['H']
+                # mnist_vae.py:134-150 builds ONE `encoder_sampler` and hands it to both nets; the split engine
+                # evaluates that shared image branch once per trajectory.  Two different branches (or one net
+                # with a branch and one without) would silently run VNet on XNet's encoder: refuse.
+                ax, av = self._xw['aux_encoder'], self._vw['aux_encoder']
+                if (ax is None) != (av is None) or (ax is not None and any(
+                        ax[k].data_ptr() != av[k].data_ptr() for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'))):
+                    raise NotImplementedError(
+                        "XNet and VNet must share ONE aux branch (the same encoder_sampler parameters, as in "
+                        "mnist_vae.py:134-150) or have none; separate image branches per net are not implemented")
+                for w in (self._xw, self._vw):
+                    for k in _ffi.NET_FIELDS:
+                        if w[k].device != self.device:
+                            raise ValueError("net parameters live on %s, Dynamics on %s" % (w[k].device, self.device))
         self._packed = None
         self._packed_key = None
         # Engine choice: the single fused kernel covers the built-in targets with H <= 15 and no
@@ -123,8 +131,11 @@ class Dynamics(object):
         # the fused kernel's H <= 15 (nb:51-78 with H != 10; mnist_vae.py:142-167 uses 200)
         self._vae = energy_function.kind == ENERGY_VAE
         self._user = energy_function.kind == ENERGY_USER          # caller's torch code supplies U, grad U (slow path)
-        self._split = self._vae or self._user or (not self.hmc and self.H > 15)
-        self._aux_nets = (not self.hmc) and self._xw['aux_encoder'] is not None
+        self._split = self._vae or self._user or self._user_nets or (not self.hmc and self.H > 15)
+        if self._user_nets and self._vae:
+            raise NotImplementedError("caller-supplied nets go with a built-in energy of l2hmc_amd.distributions or a "
+                                      "caller-supplied energy callable (pass the VAE posterior as a plain closure)")
+        self._aux_nets = (not self.hmc) and not self._user_nets and self._xw['aux_encoder'] is not None
         if not (self._vae or self._user) and self._aux_nets:
             raise NotImplementedError("an aux (image) branch is only implemented together with the VAE posterior energy "
                                       "or a caller-supplied energy")
@@ -200,6 +211,9 @@ class Dynamics(object):
         """[(name, tensor)] with the reference's variable names."""
         if self.hmc:
             return []
+        if self._user_nets:          # arbitrary callables: whatever of them exposes the layer kit's `parameters()`
+            return [('alpha', self.alpha)] + [kv for net in (self.XNet, self.VNet)
+                                              for kv in (net.parameters() if hasattr(net, 'parameters') else [])]
         return [('alpha', self.alpha)] + self.XNet.parameters() + self.VNet.parameters()
 
     def state_dict(self):
@@ -244,8 +258,8 @@ class Dynamics(object):
         if self._vae or (self._user and self._aux_nets):
             if aux is None:
                 raise ValueError("this Dynamics is image-conditioned (mnist_vae.py): pass aux=")
-        elif self._user:
-            pass                   # forwarded to the caller's energy function when given
+        elif self._user or self._user_nets:
+            pass                   # forwarded to the caller's energy function / nets when given
         elif aux is not None:
             raise ValueError("aux= is only meaningful for an aux-conditioned model (mnist_vae.py)")
 
@@ -280,14 +294,15 @@ class Dynamics(object):
         if u is not None:
             u = as_device_f32(u, self.device)
         dec = mlp3_struct(self._fn.decoder) if self._vae else None
-        if self.hmc:                                  # (either direction: the inverse leapfrog is the step with -eps)
+        if self.hmc or self._user_nets:               # (HMC, either direction: the inverse leapfrog is the step with -eps)
             xs = vs = enc = None
         else:
             xs = _ffi.L2hmcNet(*[self._xw[k].data_ptr() for k in _ffi.NET_FIELDS])
             vs = _ffi.L2hmcNet(*[self._vw[k].data_ptr() for k in _ffi.NET_FIELDS])
             enc = mlp3_struct(self._xw['aux_encoder']) if self._xw['aux_encoder'] is not None else None
         L = _ffi.lib()
-        need = _ffi.check(L.l2hmc_split_workspace_floats(N, d, max(self.H, 1), self.T,
+        H_ws = 4 if self._user_nets else max(self.H, 1)    # (caller-supplied nets: the library plans no hidden activations)
+        need = _ffi.check(L.l2hmc_split_workspace_floats(N, d, H_ws, self.T,
                                                          C.byref(enc) if enc is not None else None,
                                                          C.byref(dec) if dec is not None else None))
         if self._split_ws is None or self._split_ws.numel() < need:
@@ -297,7 +312,7 @@ class Dynamics(object):
         a.vnet = C.pointer(vs) if vs is not None else None
         # (a caller-supplied energy anneals itself inside the callback -- evaluate(..., anneal_beta=) below; the library
         #  refuses bce_scale next to energy_cb)
-        a.H, a.hmc, a.bce_scale = max(self.H, 1), int(self.hmc), (0.0 if self._user else float(self.anneal_beta))
+        a.H, a.hmc, a.bce_scale = H_ws, int(self.hmc), (0.0 if self._user else float(self.anneal_beta))
         a.aux_encoder = C.pointer(enc) if enc is not None else None
         cb_error = []
         if self._vae:
@@ -329,6 +344,36 @@ class Dynamics(object):
         else:                                        # built-in target (utils/distributions.py) under wide nets
             en = self._fn.c_struct(x.device, float(self.temperature) if self.use_temperature else 1.0, self.anneal_beta)
             a.energy = C.pointer(en)
+        if self._user_nets:
+            # the caller's nets (dynamics.py:69-79: any callable [a, b, tau, aux] -> [S, T, Q]): evaluated here, on views of the
+            # workspace, between the library's launches; chain n's time input is row `it` of the schedule if it runs forward,
+            # row T - 1 - it otherwise (dynamics.py:99-105, :285)
+            wsn, basen, Tn = self._split_ws, self._split_ws.data_ptr(), self.T
+            fwd_mask = (direction != 0) if direction is not None else None
+
+            def net_cb(_user, net, abp, ldab, n, dd, it, _dirp, dall, outp, _stream):
+                try:
+                    ab = wsn.as_strided((n, 2 * dd), (ldab, 1), (abp - basen) // 4)
+                    if fwd_mask is not None:
+                        rows = torch.where(fwd_mask, it, Tn - 1 - it)
+                        tau = self._trig[rows]
+                    else:
+                        tau = self._trig[it if dall else Tn - 1 - it].expand(n, 2)
+                    stq = (self.XNet if net == 0 else self.VNet)([ab[:, :dd], ab[:, dd:], tau, aux])
+                    if len(stq) != 3:
+                        raise ValueError("a net must return [S, T, Q], got %d outputs" % len(stq))
+                    out = wsn.as_strided((n, 3 * dd), (3 * dd, 1), (outp - basen) // 4)
+                    for i, t in enumerate(stq):          # (HMC-style nets return plain zeros, dynamics.py:73-76)
+                        t = torch.as_tensor(t, dtype=torch.float32, device=wsn.device)
+                        if t.dim() != 0 and tuple(t.shape) != (n, dd):
+                            raise ValueError("net output %d must be (N, d) = (%d, %d), got %s" % (i, n, dd, tuple(t.shape)))
+                        out[:, i * dd:(i + 1) * dd] = t
+                    return 0
+                except Exception as e:                   # never let an exception cross the C frame
+                    cb_error.append(e)
+                    return 1
+            ncb = _ffi.NET_CALLBACK(net_cb)              # (kept alive by this frame for the duration of the call)
+            a.net_cb = C.cast(ncb, C.c_void_p)
         a.masks, a.trig = self._mask.data_ptr(), self._trig.data_ptr()
         if self.eps_override is None:
             a.alpha, a.eps_host = self.alpha.data_ptr(), 0.0
@@ -347,7 +392,7 @@ class Dynamics(object):
         # reference to it is kept, so its address cannot be recycled for other data).
         wkey = None
         img = self._vae or (self._user and self._aux_nets)          # an image branch whose result can be reused
-        if not self.hmc:
+        if not self.hmc and not self._user_nets:
             ws_ = [self._xw[k] for k in _ffi.NET_FIELDS] + [self._vw[k] for k in _ffi.NET_FIELDS]
             for m3 in (self._xw['aux_encoder'], self._fn.decoder if self._vae else None):
                 if m3 is not None:

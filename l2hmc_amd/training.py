@@ -45,6 +45,9 @@ RNG_STREAM = "philox4x32-10/hw-boxmuller"       # (l2hmc_kernels.hpp philox_norm
 
 class Trainer(object):
     def __new__(cls, dynamics, *args, **kwargs):
+        if getattr(dynamics, "_user_nets", False):
+            raise NotImplementedError("training differentiates the fused S/T/Q architecture (l2hmc_amd.layers.stq_network); a "
+                                      "Dynamics whose nets are arbitrary callables samples only")
         if getattr(dynamics, "_user", False) and cls is not SplitTrainer and cls is not Trainer:
             raise NotImplementedError("a caller-supplied energy trains on the GEMM engine: use Trainer(dynamics)")
         # samplers that run on the GEMM engine (nets wider than H = 15, the image-conditioned VAE sampler) train there

@@ -235,7 +235,8 @@ def format_time(step, T, dtype=np.float32):
 class Dynamics:
     """Functional restatement of utils/dynamics.py:34-309.
 
-    energy(x) -> (U, gradU); xnet / vnet: dicts of NET_KEYS arrays, or None for HMC mode.
+    energy(x) -> (U, gradU); xnet / vnet: dicts of NET_KEYS arrays, None for HMC mode, or -- the reference's own generality,
+    dynamics.py:69-79 -- ANY callables net(a, b, tau) -> (S, T, Q) on (N, d) / (N, d) / (N, 2) arrays.
     """
 
     def __init__(self, x_dim, energy, T, eps, mask, xnet=None, vnet=None,
@@ -248,6 +249,8 @@ class Dynamics:
         self.hmc = xnet is None
         if self.hmc:
             self.XNet = self.VNet = zero_net
+        elif callable(xnet) and callable(vnet):
+            self.XNet, self.VNet = xnet, vnet
         else:
             xn, vn = net_cast(xnet, dtype), net_cast(vnet, dtype)
             ah = None if aux_h is None else np.asarray(aux_h, dtype=dtype)

@@ -244,3 +244,111 @@ def test_empty_shard_of_a_training_step_contributes_a_zero_gradient():
     st.lr, st.beta1, st.beta2, st.epsilon, st.step = 1e-3, 0.9, 0.999, 1e-8, 1
     with pytest.raises(RuntimeError, match="at least one chain"):
         _ffi.check(_ffi.lib().l2hmc_train_step(a, st, _ffi.current_stream(dyn.device)))
+
+
+# ---- net_factory in the reference's full generality (dynamics.py:69-79): ANY callable [a, b, tau, aux] -> [S, T, Q] ------------------
+def _opaque(net):
+    """the same function as `net`, with nothing for l2hmc_amd.layers.extract_stq to recognise"""
+    return lambda inp: net(inp)
+
+
+@pytest.mark.parametrize("case", ["tilted8", "icg50", "mog2d", "rough8"])
+def test_arbitrary_net_callables_match_the_reference_fixtures(case):
+    """The reference's `net_factory` returns any callable; here the fixture's OWN S/T/Q nets are handed over as opaque lambdas, so the
+    Dynamics cannot fuse them and takes the general path (the caller's torch code between the library's launches,
+    L2hmcSplitArgs.net_cb) -- which must then reproduce the reference-run fixture like the fused kernels do: single steps 3e-5,
+    trajectories 1e-4 (2e-4 for the 25-step mixture, whose fused-path gate in test_gpu_train_split is the same), accept 1e-4,
+    propose on the recorded draws incl. the MH select."""
+    import torch
+    from l2hmc_amd import Dynamics, layers, propose
+    from tests.helpers import hip_energy
+    g = load(case)
+    d, H, T = int(g["x_dim"]), int(g["H"]), int(g["T"])
+    fused = hip_dynamics(g)                               # builds the recognised nets with the fixture's weights ...
+    nets = {"XNet": fused.XNet, "VNet": fused.VNet}
+    dyn = Dynamics(d, hip_energy(g), T=T, eps=float(g["eps"]), net_factory=lambda x_dim, scope, factor: _opaque(nets[scope]))
+    assert dyn._user_nets and dyn._split
+    dyn.mask = g["mask"]
+    dyn.eps_override = float(g["eps"])
+    x, v = to_dev(g["x"]), to_dev(g["v"])
+    traj = 2e-4 if T > 10 else 1e-4
+    for s in g["steps"]:
+        xo, vo, lj = dyn._forward_step(x, v, int(s))
+        xb, vb, ljb = dyn._backward_step(x, v, int(s))
+        for got, key in ((xo, "fstep%d.x"), (vo, "fstep%d.v"), (lj, "fstep%d.logdet"), (xb, "bstep%d.x"), (vb, "bstep%d.v"),
+                         (ljb, "bstep%d.logdet")):
+            assert rel_err(to_np(got), g[key % s]) < STEP_TOL, (case, key % s)
+    for nm, fn in (("fwd", dyn.forward), ("bwd", dyn.backward)):
+        X, V, lj = fn(x, init_v=v, log_jac=True)
+        _, _, p = fn(x, init_v=v)
+        assert rel_err(to_np(X), g[nm + ".x"]) < traj and rel_err(to_np(V), g[nm + ".v"]) < traj
+        assert rel_err(to_np(lj), g[nm + ".logjac"]) < traj and abs_err(to_np(p), g[nm + ".p"]) < P_TOL
+    Lx, Lv, px, outs = propose(x, dyn, do_mh_step=True, direction=to_dev(g["prop.dir"]),
+                               v=(to_dev(g["prop.v_fwd"]), to_dev(g["prop.v_bwd"])), u=to_dev(g["prop.u"]))
+    assert Lv is None
+    assert rel_err(to_np(Lx), g["prop.Lx"]) < traj and abs_err(to_np(px), g["prop.px"]) < P_TOL
+    from tests.helpers import check_x_next
+    check_x_next(to_np(outs[0]), g["x"], g["prop.Lx"], g["prop.px"], g["prop.u"], P_TOL)
+    # ... and the trainers say what they differentiate instead of crashing
+    from l2hmc_amd.training import Trainer
+    with pytest.raises(NotImplementedError, match="arbitrary callables"):
+        Trainer(dyn)
+
+
+def test_a_net_outside_the_notebook_architecture_matches_the_oracle():
+    """A structure the fused kernels do not have -- one tanh layer, S bounded by a sigmoid, Q identically zero (a Python float,
+    like the reference's HMC lambdas, dynamics.py:73-76), the time input entering multiplicatively -- written twice, in torch for
+    the product and in numpy for oracle/l2hmc_oracle.py's Dynamics (which takes callables), on a built-in Gaussian AND on the same
+    target as a caller-supplied torch closure: direction-mixed propose + MH against the float32 oracle."""
+    import torch
+    from l2hmc_amd import Dynamics, distributions as D, propose
+    d, N, T, eps = 6, 96, 7, 0.07
+    rng = np.random.RandomState(5)
+    W = {k: (0.4 * rng.randn(*shp)).astype(np.float32) for k, shp in
+         (("A", (d, 12)), ("B", (d, 12)), ("C", (2, 12)), ("S", (12, d)), ("T", (12, d)))}
+    Wt = {k: to_dev(v) for k, v in W.items()}
+
+    def make_torch(scale):
+        def net(inp):
+            a, b, tau, aux = inp
+            h = torch.tanh(a @ Wt["A"] + b @ Wt["B"]) * (1.0 + tau @ Wt["C"])
+            return [scale * torch.sigmoid(h @ Wt["S"]) - 0.5 * scale, h @ Wt["T"], 0.0]
+        return net
+
+    def make_numpy(scale):
+        def net(a, b, tau):
+            h = np.tanh(a @ W["A"] + b @ W["B"]) * (np.float32(1.0) + tau @ W["C"])
+            return (np.float32(scale) / (1 + np.exp(-(h @ W["S"]))) - np.float32(0.5 * scale), h @ W["T"], np.zeros_like(a))
+        return net
+    prec = np.diag(np.exp(np.linspace(-1, 1, d))).astype(np.float32)
+    mu = (0.2 * rng.randn(d)).astype(np.float32)
+    mask = O.init_mask(T, d, np.random.RandomState(2))
+    x0 = rng.randn(N, d).astype(np.float32)
+    v0 = rng.randn(N, d).astype(np.float32)
+    direction = rng.randint(0, 2, size=N).astype(np.uint8)
+    u = rng.rand(N).astype(np.float32)
+    gauss = D.Gaussian.__new__(D.Gaussian)
+    gauss.mu, gauss.sigma, gauss.i_sigma = mu, None, prec
+    mu_t, prec_t = to_dev(mu), to_dev(prec)
+
+    def closure(x):                  # the same target as a plain torch callable: the caller's energy AND the caller's nets
+        dx = x - mu_t
+        return 0.5 * ((dx @ prec_t) * dx).sum(1)
+    for energy, oracle_energy in ((gauss.get_energy_function(), O.Gaussian(mu, prec, np.float32)),
+                                  (closure, O.Gaussian(mu, prec, np.float32))):
+        dyn = Dynamics(d, energy, T=T, eps=eps, net_factory=lambda x_dim, scope, factor: make_torch(0.6 if scope == "XNet" else 0.3))
+        assert dyn._user_nets
+        dyn.mask = mask
+        dyn.eps_override = eps
+        od = O.Dynamics(d, oracle_energy, T, eps, mask, make_numpy(0.6), make_numpy(0.3))
+        Lx, _, px, outs = propose(to_dev(x0), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(v0), u=to_dev(u))
+        rLx, _, rpx, rxn = O.propose(x0, od, v0, v0, direction, u, both_directions=False)
+        assert rel_err(to_np(Lx), rLx) < 1e-4 and abs_err(to_np(px), rpx) < P_TOL
+        from tests.helpers import check_x_next
+        check_x_next(to_np(outs[0]), x0, rLx, rpx, u, P_TOL)
+        assert 0.05 < float(px.mean()) < 0.999
+    # a net that returns the wrong shape surfaces as a Python exception, not as a crash inside the library
+    bad = Dynamics(d, gauss.get_energy_function(), T=T, eps=eps,
+                   net_factory=lambda x_dim, scope, factor: (lambda inp: [inp[0][:, :2], inp[0], 0.0]))
+    with pytest.raises(ValueError, match="must be"):
+        bad.forward(to_dev(x0), init_v=to_dev(v0))
