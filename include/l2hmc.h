@@ -314,7 +314,10 @@ typedef struct L2hmcSplitArgs {
                                   *    1: "bf16x3" -- every fp32 operand split EXACTLY into three bf16 terms, the six
                                   *       significant cross products on the bf16 MFMA (16x the f32 MFMA rate), fp32
                                   *       accumulation: dropped terms <= 3 x 2^-24 |x y| per product, i.e. fp32-level
-                                  *       accuracy (measured against float64 in profiles/ and the config-5 parity tests) */
+                                  *       accuracy (measured against float64 in profiles/ and the config-5 parity tests);
+                                  *       from 3072 chains at config 5's widths on operands PRE-SPLIT into bf16 planes
+                                  *    2: the same six products with the split inside the k loop at every size -- bit-identical
+                                  *       results to mode 1 (the planes only move where the split happens); kept for tests and A/B */
   L2hmcNetCallback net_cb;       /* (ABI 5) non-NULL: the caller's nets (see L2hmcNetCallback); xnet = vnet = aux_encoder = NULL,
                                   *    H is ignored, hmc = 0.  Goes with energy_cb or a built-in energy.                 */
   void* net_cb_user;             /* passed back as the callback's first argument                                         */

@@ -441,8 +441,8 @@ int l2hmc_p_accept_energies(const float* U0, const float* v0, const float* U1, c
 
 int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
-  if (a->gemm_mode != 0 && a->gemm_mode != 1) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA) or 1 (bf16x3)%s");
-  t_gemm_bf3 = a->gemm_mode;
+  if (a->gemm_mode < 0 || a->gemm_mode > 2) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA), 1 (bf16x3) or 2 (bf16x3, split in the loop)%s");
+  t_gemm_bf3 = a->gemm_mode != 0;
   const bool user = a->energy_cb != nullptr;        // the caller's own energy, evaluated on the host between launches
   const bool builtin = a->energy != nullptr;        // a target of utils/distributions.py instead of the decoder posterior
   const bool unets = a->net_cb != nullptr;          // the caller's own S/T/Q nets (any callable, dynamics.py:69-79)

@@ -503,6 +503,7 @@ struct TrainSplitPlan {
   long long part;                                   // chunk partials of the TN products and column sums
   long long part_cap;
   long long HD1, HD2, M1, M2, RD;                   // decoder Hessian-vector product: tangents
+  long long pHD1, pHD2, pRD, pM2;                   // ... and the ones that only feed the next decoder-sized product, as bf16 planes
   long long PS1, PS2, PRD, PB2, PB1;                // ... and, per trajectory point (T + 1 of them), the decoder's
                                                     // sigmoids, sigma' of the logits and the raw reverse products
   long long carry;                                  // Hessian-vector input carried to the same point's other use
@@ -543,8 +544,12 @@ inline TrainSplitPlan plan_train_split(long long N, int d, int H, int T, const L
     const long long P = T + 1;
     p.PS1 = take(P * N * dec->n_h1); p.PS2 = take(P * N * dec->n_h2); p.PRD = take(P * N * dec->n_out);
     p.PB2 = take(P * N * dec->n_h2); p.PB1 = take(P * N * dec->n_h1);
+    auto takep = [&](long long elems) { return take(p.fwd.planes ? (elems * 3 + 1) / 2 : 0); };
+    p.pHD1 = takep(N * pld(dec->n_h1)); p.pHD2 = takep(N * pld(dec->n_h2));
+    p.pRD = takep(N * pld(dec->n_out)); p.pM2 = takep(N * pld(dec->n_h2));
     p.xq = 0;
   } else {
+    p.pHD1 = p.pHD2 = p.pRD = p.pM2 = 0;
     p.HD1 = p.HD2 = p.M1 = p.M2 = p.RD = p.PS1 = p.PS2 = p.PRD = p.PB2 = p.PB1 = 0;
     p.xq = take(N * d);
   }
@@ -567,6 +572,41 @@ void vae_energy_keep(hipStream_t s, const L2hmcMlp3& dec, const float* aux, cons
                      const Mlp3Ws& ws0, float* lg, float* rowsum, double* Ud, float* grad, int ldg, const DecPoint& pt) {
   Mlp3Ws ws = ws0;
   ws.s1 = pt.s1; ws.s2 = pt.s2;
+  if (ws.pa1 != nullptr) {
+    // ---- pre-split form (round 5; vae_energy's chain of split.hip with the point's DecPoint kept): activations that only feed the
+    //      next product are written as bf16 planes by their producer's epilogue, the four decoder-sized products read planes on both
+    //      sides (gemm_xlp_kernel: bit-identical per product to the in-loop split, x1.37)
+    const int l1 = pld(dec.n_h1), l2 = pld(dec.n_h2), lo = pld(dec.n_out);
+    const long long n1 = N * l1, n2 = N * l2, no = N * lo;
+    GemmArgs g = gemm_args(z, ldz, ws.w1t, dec.n_in, nullptr, dec.n_h1, N, dec.n_h1, dec.n_in);
+    g.bias = dec.b1; g.C2 = pt.s1; g.ldc2 = dec.n_h1; g.Cp = ws.pa1; g.cp_plane = n1; g.ldcp = l1;
+    launch_gemm<EPI_BIAS_SOFTPLUS>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_AUTO);                 // a1 (planes), s1
+    g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_h1);
+    g.Ap = ws.pa1; g.ap_plane = n1; g.ldap = l1; g.Bp = ws.pw2t; g.bp_plane = prows(dec.n_h2) * l1; g.ldbp = l1;
+    g.bias = dec.b2; g.C2 = pt.s2; g.ldc2 = dec.n_h2; g.Cp = ws.pa2; g.cp_plane = n2; g.ldcp = l2;
+    launch_gemm_planes<EPI_BIAS_SOFTPLUS>(g, s);                                                     // a2 (planes), s2
+    g = gemm_args(nullptr, 0, nullptr, 0, lg, dec.n_out, N, dec.n_out, dec.n_h2);                    // (lg in fp32 too: k_sigd reads it)
+    g.Ap = ws.pa2; g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw3t; g.bp_plane = prows(dec.n_out) * l2; g.ldbp = l2;
+    g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles_planes(dec.n_out); g.beta = 1.f;
+    g.Cp = ws.plg; g.cp_plane = no; g.ldcp = lo;
+    launch_gemm_planes<EPI_BCE>(g, s);
+    if (Ud != nullptr)
+      hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles_planes(dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
+    const long long npix_ = N * dec.n_out;
+    hipLaunchKernelGGL(k_sigd, dim3(nblk(npix_)), dim3(256), 0, s, lg, aux, pt.rd, npix_);
+    g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_out);
+    g.Ap = ws.plg; g.ap_plane = no; g.ldap = lo; g.Bp = ws.pw3; g.bp_plane = prows(dec.n_h2) * lo; g.ldbp = lo;
+    g.E = pt.s2; g.lde = dec.n_h2; g.C2 = pt.b2; g.ldc2 = dec.n_h2; g.Cp = ws.pda2; g.cp_plane = n2; g.ldcp = l2;
+    launch_gemm_planes<EPI_MUL>(g, s);                                                               // c2 = s2 b2 (planes), b2
+    g = gemm_args(nullptr, 0, nullptr, 0, ws.a1, dec.n_h1, N, dec.n_h1, dec.n_h2);
+    g.Ap = ws.pda2; g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw2; g.bp_plane = prows(dec.n_h1) * l2; g.ldbp = l2;
+    g.E = pt.s1; g.lde = dec.n_h1; g.C2 = pt.b1; g.ldc2 = dec.n_h1;
+    launch_gemm_planes<EPI_MUL>(g, s);                                                               // c1 = s1 b1 (fp32), b1
+    g = gemm_args(ws.a1, dec.n_h1, dec.W1, dec.n_h1, grad, ldg, N, d, dec.n_h1);
+    g.E = z; g.lde = ldz;
+    launch_gemm<EPI_ADD>(g, s, d <= 64 ? SHAPE_SKINNY : SHAPE_MID);
+    return;
+  }
   mlp3_hidden(s, dec, z, ldz, N, ws);
   GemmArgs g = gemm_args(ws.a2, dec.n_h2, ws.w3t, dec.n_h2, lg, dec.n_out, N, dec.n_out, dec.n_h2);
   g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = 1.f;
@@ -594,6 +634,36 @@ void vae_energy_keep(hipStream_t s, const L2hmcMlp3& dec, const float* aux, cons
 // three tangent GEMMs and three reverse-tangent GEMMs, the softplus'' terms in their epilogues.
 void vae_hvp(hipStream_t s, const L2hmcMlp3& dec, long long N, int d, const Mlp3Ws& ws, const DecPoint& pt,
              const TrainSplitPlan& p, float* w, const float* u, float* hv) {
+  if (ws.pa1 != nullptr) {       // pre-split form: the tangents between the decoder-sized products travel as planes
+    auto us = [&](long long off) { return reinterpret_cast<unsigned short*>(w + off); };
+    const int l1 = pld(dec.n_h1), l2 = pld(dec.n_h2), lo = pld(dec.n_out);
+    const long long n1 = N * l1, n2 = N * l2, no = N * lo;
+    GemmArgs g = gemm_args(u, d, ws.w1t, dec.n_in, nullptr, dec.n_h1, N, dec.n_h1, dec.n_in);
+    g.E = pt.s1; g.lde = dec.n_h1; g.E2 = pt.b1; g.lde2 = dec.n_h1; g.C2 = w + p.M1; g.ldc2 = dec.n_h1;
+    g.Cp = us(p.pHD1); g.cp_plane = n1; g.ldcp = l1;
+    launch_gemm<EPI_TAN>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_AUTO);                             // h1. (planes), M1
+    g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_h1);
+    g.Ap = us(p.pHD1); g.ap_plane = n1; g.ldap = l1; g.Bp = ws.pw2t; g.bp_plane = prows(dec.n_h2) * l1; g.ldbp = l1;
+    g.E = pt.s2; g.lde = dec.n_h2; g.E2 = pt.b2; g.lde2 = dec.n_h2; g.C2 = w + p.M2; g.ldc2 = dec.n_h2;
+    g.Cp = us(p.pHD2); g.cp_plane = n2; g.ldcp = l2;
+    launch_gemm_planes<EPI_TAN>(g, s);                                                               // h2. (planes), M2
+    g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_out, N, dec.n_out, dec.n_h2);
+    g.Ap = us(p.pHD2); g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw3t; g.bp_plane = prows(dec.n_out) * l2; g.ldbp = l2;
+    g.E = pt.rd; g.lde = dec.n_out; g.Cp = us(p.pRD); g.cp_plane = no; g.ldcp = lo;
+    launch_gemm_planes<EPI_MUL>(g, s);                                                               // r. (planes)
+    g = gemm_args(nullptr, 0, nullptr, 0, w + p.M2, dec.n_h2, N, dec.n_h2, dec.n_out);
+    g.Ap = us(p.pRD); g.ap_plane = no; g.ldap = lo; g.Bp = ws.pw3; g.bp_plane = prows(dec.n_h2) * lo; g.ldbp = lo;
+    g.E = pt.s2; g.lde = dec.n_h2; g.accum = 1; g.Cp = us(p.pM2); g.cp_plane = n2; g.ldcp = l2;
+    launch_gemm_planes<EPI_MUL>(g, s);                                                               // c2. (fp32 + planes)
+    g = gemm_args(nullptr, 0, nullptr, 0, w + p.M1, dec.n_h1, N, dec.n_h1, dec.n_h2);
+    g.Ap = us(p.pM2); g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw2; g.bp_plane = prows(dec.n_h1) * l2; g.ldbp = l2;
+    g.E = pt.s1; g.lde = dec.n_h1; g.accum = 1;
+    launch_gemm_planes<EPI_MUL>(g, s);                                                               // c1. (fp32)
+    g = gemm_args(w + p.M1, dec.n_h1, dec.W1, dec.n_h1, hv, d, N, d, dec.n_h1);
+    g.E = u; g.lde = d;
+    launch_gemm<EPI_ADD>(g, s, d <= 64 ? SHAPE_SKINNY : SHAPE_MID);
+    return;
+  }
   GemmArgs g = gemm_args(u, d, ws.w1t, dec.n_in, w + p.HD1, dec.n_h1, N, dec.n_h1, dec.n_in);
   g.E = pt.s1; g.lde = dec.n_h1; g.E2 = pt.b1; g.lde2 = dec.n_h1; g.C2 = w + p.M1; g.ldc2 = dec.n_h1;
   launch_gemm<EPI_TAN>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_AUTO);
@@ -632,8 +702,8 @@ int64_t l2hmc_train_split_workspace_floats(int64_t n_chains, int32_t d, int32_t 
 }
 
 int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
-  if (a && a->gemm_mode != 0 && a->gemm_mode != 1) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA) or 1 (bf16x3)%s");
-  t_gemm_bf3 = a ? a->gemm_mode : 0;
+  if (a && (a->gemm_mode < 0 || a->gemm_mode > 2)) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA), 1 (bf16x3) or 2 (bf16x3, split in the loop)%s");
+  t_gemm_bf3 = a ? a->gemm_mode != 0 : 0;
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
   const bool builtin = a->energy != nullptr;
   const bool user = a->energy_cb != nullptr;       // the caller's energy: U / grad U and Hessian-vector products by callback
@@ -683,7 +753,18 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   const SplitPlan& f = p.fwd;
   static const L2hmcMlp3 no_dec = {};
   const L2hmcMlp3& dec = vae ? *a->decoder : no_dec;
-  const Mlp3Ws dws = {w + f.dw1t, w + f.dw2t, w + f.dw3t, w + f.a1, w + f.s1, w + f.a2, w + f.s2};
+  Mlp3Ws dws = {w + f.dw1t, w + f.dw2t, w + f.dw3t, w + f.a1, w + f.s1, w + f.a2, w + f.s2};
+  // the decoder-sized products of the forward pass and of the Hessian-vector products on pre-split planes (round 5), when the
+  // sampler's own planes rule says so (gemm_mode 1, >= 84 tiles: 3072 chains at config 5's widths)
+  const bool use_planes = vae && f.planes && a->gemm_mode == 1;
+  if (use_planes) {
+    if ((rc = gemm_planes_prepare<EPI_BIAS_SOFTPLUS>()) != L2HMC_OK || (rc = gemm_planes_prepare<EPI_BCE>()) != L2HMC_OK ||
+        (rc = gemm_planes_prepare<EPI_MUL>()) != L2HMC_OK || (rc = gemm_planes_prepare<EPI_TAN>()) != L2HMC_OK)
+      return rc;
+    auto us = [&](long long off) { return reinterpret_cast<unsigned short*>(w + off); };
+    dws.pw2t = us(f.pw2t); dws.pw3t = us(f.pw3t); dws.pw2 = us(f.pw2); dws.pw3 = us(f.pw3);
+    dws.pa1 = us(f.pa1); dws.pa2 = us(f.pa2); dws.plg = us(f.plg); dws.pda2 = us(f.pda2);
+  }
   const int L = 2 * d;
   const L2hmcNet &xn = *a->xnet, &vn = *a->vnet;
   const L2hmcNet* nets[2] = {&xn, &vn};
@@ -707,6 +788,21 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
 
   // ---- weights: transposed copies for the forward products, stacked copies for the input-gradient products ------
   if (vae) mlp3_transposes(s, dec, dws);
+  if (use_planes) {           // weights split once per call; the activations' padding up to whole k-tiles zeroed once
+    auto us = [&](long long off) { return reinterpret_cast<unsigned short*>(w + off); };
+    to_planes(s, dws.w2t, dec.n_h1, dec.n_h2, dec.n_h1, dws.pw2t, prows(dec.n_h2), pld(dec.n_h1));
+    to_planes(s, dws.w3t, dec.n_h2, dec.n_out, dec.n_h2, dws.pw3t, prows(dec.n_out), pld(dec.n_h2));
+    to_planes(s, dec.W2, dec.n_h2, dec.n_h1, dec.n_h2, dws.pw2, prows(dec.n_h1), pld(dec.n_h2));
+    to_planes(s, dec.W3, dec.n_out, dec.n_h2, dec.n_out, dws.pw3, prows(dec.n_h2), pld(dec.n_out));
+    planes_zero_pad(s, dws.pa1, N, dec.n_h1, pld(dec.n_h1));
+    planes_zero_pad(s, dws.pa2, N, dec.n_h2, pld(dec.n_h2));
+    planes_zero_pad(s, dws.plg, N, dec.n_out, pld(dec.n_out));
+    planes_zero_pad(s, dws.pda2, N, dec.n_h2, pld(dec.n_h2));
+    planes_zero_pad(s, us(p.pHD1), N, dec.n_h1, pld(dec.n_h1));
+    planes_zero_pad(s, us(p.pHD2), N, dec.n_h2, pld(dec.n_h2));
+    planes_zero_pad(s, us(p.pRD), N, dec.n_out, pld(dec.n_out));
+    planes_zero_pad(s, us(p.pM2), N, dec.n_h2, pld(dec.n_h2));
+  }
   Mlp3Ws ews = {};
   if (a->aux_encoder) {
     const L2hmcMlp3& enc = *a->aux_encoder;

@@ -352,3 +352,44 @@ def test_a_net_outside_the_notebook_architecture_matches_the_oracle():
                    net_factory=lambda x_dim, scope, factor: (lambda inp: [inp[0][:, :2], inp[0], 0.0]))
     with pytest.raises(ValueError, match="must be"):
         bad.forward(to_dev(x0), init_v=to_dev(v0))
+
+
+def test_training_on_presplit_planes_agrees_with_the_split_in_the_loop():
+    """The GEMM-engine trainer at config 5's widths and 3072 chains (the chain count from which the decoder-sized products take the
+    pre-split form, csrc/gemm_xl.hpp): round 5 puts the forward pass's and the Hessian-vector products' 1024-wide products on bf16
+    planes (`vae_energy_keep`, `vae_hvp` of csrc/train_split.hpp; activations split by the producing epilogue, weights once per
+    call).  gemm_mode 2 keeps the split inside the k loop of every product: the same six bf16 products per block in the same order
+    -- every product is bit-identical (tools/ubench_gemm_bf3.hip) -- but the BCE row sums of the energy are formed per 128-wide
+    column tile instead of per 64-wide one: float32 partial sums of ~45 each (ulp 4e-6), 13 or 7 of them per chain, so U ~ 540
+    differs by ~2e-5 and the accept probability with it (measured 2.8e-5; the suite's gate on p is 1e-4).  The proposals agree to
+    2e-6, the loss to 1e-6, the gradient to 1.6e-7 of its scale (gate 1e-4: a tenth of the round-3 gate of gemm_mode 1 against
+    the f32-MFMA form, which both modes also meet)."""
+    import torch
+    from l2hmc_amd import _ffi
+    from l2hmc_amd.training import Trainer
+    from tests.helpers import synthetic_vae_case
+    N = 3072
+    g = synthetic_vae_case(N=N, seed=7)
+    rng = np.random.RandomState(4)
+    dr = {"v": rng.randn(N, 50).astype(np.float32), "dir": rng.randint(0, 2, N).astype(np.uint8), "u": rng.rand(N).astype(np.float32)}
+    ls = np.full((N, 50), -0.5, np.float32)
+    res = {}
+    for mode in (1, 2, 0):
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        dyn.gemm_mode = mode
+        tr = Trainer(dyn, decay_steps=0)
+        loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(ls), MH=1, draws=[dr])
+        res[mode] = (float(loss), to_np(px).copy(), to_np(tr.flat).copy(), to_np(x_T).copy())
+    a, b, c = res[1], res[2], res[0]
+    scale = float(np.abs(c[2]).max())
+    print("planes vs in-loop: loss %.9e / %.9e  |dp| %.1e  |dx| %.1e  |dgrad| / scale %.1e" % (
+        a[0], b[0], np.abs(a[1] - b[1]).max(), np.abs(a[3] - b[3]).max(), np.abs(a[2] - b[2]).max() / scale))
+    assert abs(a[0] - b[0]) < 1e-6 * max(1.0, abs(b[0])), (a[0], b[0])
+    assert np.abs(a[1] - b[1]).max() < P_TOL, float(np.abs(a[1] - b[1]).max())
+    assert rel_err(a[3], b[3]) < 2e-6, rel_err(a[3], b[3])
+    assert np.abs(a[2] - b[2]).max() < 1e-4 * scale, float(np.abs(a[2] - b[2]).max() / scale)
+    assert abs(a[0] - c[0]) < 1e-4 * max(1.0, abs(c[0])) and np.abs(a[1] - c[1]).max() < 5e-5
+    assert np.abs(a[2] - c[2]).max() < 1e-3 * scale
