@@ -32,7 +32,12 @@ __host__ __device__ constexpr int tile_fw_net(int NTp) { return ((L2HMC_BFH_TILE
 __host__ __device__ constexpr int tile_l1_floats(int DT) { return 4 * DT * 256; }
 
 template <int EK, int DT, int KH, int TPW, bool HALF>
-__global__ __launch_bounds__(64 * TPW, 2) void traj_tile_kernel(const KArgs A) {
+#ifndef L2HMC_TILE_WPE
+// waves per SIMD the register budget is set for (HIP's second launch-bounds argument).  3 was compiled in round 5: 168
+// VGPRs with 78 of them spilled, and no third wave fits beside 80 KB of staged tables anyway.
+#define L2HMC_TILE_WPE 2
+#endif
+__global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(const KArgs A) {
   static_assert(EK == L2HMC_ENERGY_GAUSS_DIAG || EK == L2HMC_ENERGY_ROUGHWELL, "elementwise targets only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   lds_poison(smem);
