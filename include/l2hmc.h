@@ -486,6 +486,9 @@ typedef struct L2hmcTrainSplitArgs {
   float* Lv_out;                 /* (N, d) or NULL                                                              */
   float* logjac_out;             /* (N) or NULL                                                                 */
   int32_t gemm_mode;             /* as L2hmcSplitArgs.gemm_mode                                                 */
+  int32_t net_mode;              /* 0: one launch per S/T/Q net evaluation and one per its reverse wherever the
+                                  *    shapes allow (H % 4 == 0, d even, widths <= 256); 1: three GEMM launches each
+                                  *    (the form every other shape takes; here for A/B measurements and tests)     */
   /* ---- training on a caller-supplied energy (energy = decoder = NULL; aux only feeds aux_encoder, if any) ------- */
   L2hmcEnergyCallback energy_cb; /* U / grad U at a trajectory point (as in L2hmcSplitArgs), or NULL              */
   L2hmcHvpCallback hvp_cb;       /* its Hessian-vector product; required with energy_cb                          */

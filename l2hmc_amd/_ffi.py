@@ -99,7 +99,7 @@ class L2hmcTrainSplitArgs(C.Structure):
                 ("Lx", _fp), ("p", _fp), ("v1", _fp), ("dx0_out", _fp), ("grad", _fp),
                 ("workspace", _fp), ("workspace_floats", C.c_int64),
                 ("energy_scale", C.c_float), ("ediff_out", _fp), ("no_accept", C.c_int32), ("dLv_in", _fp),
-                ("dlogjac_in", _fp), ("Lv_out", _fp), ("logjac_out", _fp), ("gemm_mode", C.c_int32),
+                ("dlogjac_in", _fp), ("Lv_out", _fp), ("logjac_out", _fp), ("gemm_mode", C.c_int32), ("net_mode", C.c_int32),
                 ("energy_cb", C.c_void_p), ("hvp_cb", C.c_void_p), ("energy_cb_user", C.c_void_p)]
 
 

@@ -490,6 +490,7 @@ struct NetEvalArgs {
   const unsigned char* dir; int dir_all, it, T;
   float* out3;                      // (M, 3 d)  (upd.mode == 0)
   int M, d, H;
+  float *keep_h1, *keep_h2;         // (M, H) or NULL: both hidden activations also go to HBM (the trainer's reverse sweep needs them)
   // The leapfrog half-update that consumes this evaluation, fused behind the heads (upd.mode != 0: the head products stay in
   // LDS and out3 is not written).  Same formulas as the stand-alone update kernels of split.hip.
   struct Update {
@@ -605,13 +606,17 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
       t = *reinterpret_cast<const f4*>(g.tb + (long long)trow[cb] * H + n);
       if (g.auxh != nullptr) e = *reinterpret_cast<const f4*>(g.auxh + (m0 + 16 * cb + c) * H + n);
     }
-    *reinterpret_cast<f4*>(sH1 + (16 * cb + c) * ldh + n) = relu4f(v + t + e);
+    const f4 h = relu4f(v + t + e);
+    *reinterpret_cast<f4*>(sH1 + (16 * cb + c) * ldh + n) = h;
+    if (g.keep_h1 != nullptr && mok[cb]) *reinterpret_cast<f4*>(g.keep_h1 + (m0 + 16 * cb + c) * H + n) = h;
   });
   __syncthreads();
   layer(sH1, ldh, Hp, g.W4t, Hp, [&](int nb, int cb, f4 v) {
     const int n = nb * 16 + 4 * q;
     if (n >= H) return;
-    *reinterpret_cast<f4*>(sH2 + (16 * cb + c) * ldh + n) = relu4f(v + *reinterpret_cast<const f4*>(g.b4 + n));
+    const f4 h = relu4f(v + *reinterpret_cast<const f4*>(g.b4 + n));
+    *reinterpret_cast<f4*>(sH2 + (16 * cb + c) * ldh + n) = h;
+    if (g.keep_h2 != nullptr && mok[cb]) *reinterpret_cast<f4*>(g.keep_h2 + (m0 + 16 * cb + c) * H + n) = h;
   });
   __syncthreads();
   const int N3 = 3 * g.d;
@@ -686,6 +691,114 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
 #pragma unroll
   for (int off = TPC / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if (ok && j == 0) U.ld[n] += acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The reverse of one S/T/Q net evaluation in ONE launch (the trainer's data path, train_split.hpp `net_bwd`):
+//   d a2 = (d out3 [Ws | Wt | Wq]^T) [h2 > 0],   d a1 = (d a2 W4^T) [h1 > 0],   d [a | b] = d a1 [W1; W2]^T
+// -- net_eval_kernel run backwards: the same 16 (x CB) chains per workgroup, the cotangent tile and both hidden
+// cotangents resident in LDS, the weights (as stored = K-contiguous for these products; zero-padded copies, rows and K to
+// multiples of 16) streamed from L2 as the MFMA A operand.  d a2 and d a1 also go to HBM: they are the B operands of the
+// weight-gradient contractions over all (evaluation, chain) rows that follow the sweep.
+struct NetBwdArgs {
+  const float* dO3; int ldo;        // (M, 3 d) cotangents of the raw head products (d zs | d zt | d zq)
+  const float* Whc;                 // (Hp, K3p)   [Ws | Wt | Wq] side by side, K3p = ceil16(3 d)
+  const float* W4;                  // (Hp, Hp)    W4 as stored (in, out)
+  const float* W12;                 // (K1p, Hp)   [W1; W2] stacked, K1p = ceil16(2 d)
+  const float *h2, *h1;             // (M, H) the forward activations (relu masks)
+  float *da2, *da1;                 // (M, H)
+  float* dAB; int ldab;             // (M, 2 d)
+  int M, d, H;
+};
+inline size_t net_bwd_lds_bytes(int d, int H, int CB = 1) {
+  return sizeof(float) * 16 * CB * (size_t)(odd_quarter_stride(ceil16(3 * d)) + 2 * odd_quarter_stride(ceil16(H)));
+}
+
+template <int CB, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_bwd_kernel(const NetBwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  lds_poison(sm);
+  constexpr int NE_MT = 16 * CB, NTHR = 64 * NWV;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int N3 = 3 * g.d, K1 = 2 * g.d, H = g.H, K3p = ceil16(N3), K1p = ceil16(K1), Hp = ceil16(H);
+  const int ld3 = odd_quarter_stride(K3p), ldh = odd_quarter_stride(Hp);
+  float* sIn = sm;
+  float* sD2 = sIn + NE_MT * ld3;
+  float* sD1 = sD2 + NE_MT * ldh;
+  const long long m0 = (long long)blockIdx.x * NE_MT;
+
+  for (int i = tid; i < NE_MT * K3p; i += NTHR) {            // cotangent tile, zero padded to K3p (3 d need not be a multiple of 4)
+    const int r = i / K3p, k = i % K3p;
+    sIn[r * ld3 + k] = (m0 + r < g.M && k < N3) ? g.dO3[(m0 + r) * g.ldo + k] : 0.f;
+  }
+  for (int i = tid; i < NE_MT * (ldh - H); i += NTHR) {      // pad columns of the hidden cotangents
+    const int r = i / (ldh - H), k = H + i % (ldh - H);
+    sD2[r * ldh + k] = 0.f;
+    sD1[r * ldh + k] = 0.f;
+  }
+  __syncthreads();
+
+  auto layer = [&](const float* As, int ldA, int Kp, const float* Wt, int Np, auto&& epi) {      // as in net_eval_kernel
+    const int nk = Kp >> 4;
+    for (int nb = w; nb * 16 < Np; nb += NWV) {
+      const float* wrow = Wt + (long long)(nb * 16 + c) * Kp + 4 * q;
+      f4 wf[NE_MAXKT];
+#pragma unroll
+      for (int j = 0; j < NE_MAXKT; ++j)
+        if (j < nk) wf[j] = *reinterpret_cast<const f4*>(wrow + j * 16);
+      f4 acc[CB];
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[cb] = splat(0.f);
+#pragma unroll
+      for (int j = 0; j < NE_MAXKT; ++j) {
+        if (j < nk) {
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) {
+            const f4 af = *reinterpret_cast<const f4*>(As + (16 * cb + c) * ldA + j * 16 + 4 * q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[cb] = MFMA16(wf[j][s], af[s], acc[cb]);
+          }
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) epi(nb, cb, acc[cb]);
+    }
+  };
+  auto masked = [](f4 v, f4 h) { return f4{h.x > 0.f ? v.x : 0.f, h.y > 0.f ? v.y : 0.f, h.z > 0.f ? v.z : 0.f, h.w > 0.f ? v.w : 0.f}; };
+  bool mok[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) mok[cb] = m0 + 16 * cb + c < g.M;
+
+  layer(sIn, ld3, K3p, g.Whc, Hp, [&](int nb, int cb, f4 v) {
+    const int n = nb * 16 + 4 * q;
+    if (n >= H) return;                                        // (H % 4 == 0)
+    f4 o = splat(0.f);
+    if (mok[cb]) {
+      const long long at = (m0 + 16 * cb + c) * H + n;
+      o = masked(v, *reinterpret_cast<const f4*>(g.h2 + at));
+      *reinterpret_cast<f4*>(g.da2 + at) = o;
+    }
+    *reinterpret_cast<f4*>(sD2 + (16 * cb + c) * ldh + n) = o;
+  });
+  __syncthreads();
+  layer(sD2, ldh, Hp, g.W4, Hp, [&](int nb, int cb, f4 v) {
+    const int n = nb * 16 + 4 * q;
+    if (n >= H) return;
+    f4 o = splat(0.f);
+    if (mok[cb]) {
+      const long long at = (m0 + 16 * cb + c) * H + n;
+      o = masked(v, *reinterpret_cast<const f4*>(g.h1 + at));
+      *reinterpret_cast<f4*>(g.da1 + at) = o;
+    }
+    *reinterpret_cast<f4*>(sD1 + (16 * cb + c) * ldh + n) = o;
+  });
+  __syncthreads();
+  layer(sD1, ldh, Hp, g.W12, K1p, [&](int nb, int cb, f4 v) {
+    const int n = nb * 16 + 4 * q;
+    if (!mok[cb] || n >= K1) return;                           // (2 d % 4 == 0)
+    *reinterpret_cast<f4*>(g.dAB + (m0 + 16 * cb + c) * g.ldab + n) = v;
+  });
 }
 
 

@@ -596,7 +596,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     upd.bs = nw.bs; upd.bt = nw.bt; upd.bq = nw.bq; upd.lam_s = nw.lam_s; upd.lam_q = nw.lam_q;
     upd.alpha = a->alpha; upd.eps_host = a->eps_host; upd.ld = ld; upd.masks = a->masks;
     if (ne_ok) {
-      NetEvalArgs na;
+      NetEvalArgs na = {};
       na.AB = ab; na.ldab = L; na.W12t = w + (net == 0 ? p.nx12t : p.nv12t); na.W4t = w + (net == 0 ? p.nx4t : p.nv4t);
       na.Wht = w + (net == 0 ? p.nxht : p.nvht); na.b4 = nw.b4; na.tb = tb + (long long)net * T * H; na.auxh = aux_h;
       na.dir = dir; na.dir_all = dall; na.it = it; na.T = T; na.out3 = out3; na.M = (int)N; na.d = d; na.H = H;

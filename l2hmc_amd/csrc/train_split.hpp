@@ -500,6 +500,7 @@ struct TrainSplitPlan {
   long long lx, lv, dvh, dz, dg, u, hv, dAB;        // running cotangents
   long long lam, lamU, dv1p, deps;
   long long w12c[2], whc[2];                        // stacked / side-by-side weight copies per net
+  long long w12p[2], w4p[2], whp[2];                // ... and zero-padded to multiples of 16 both ways (net_bwd_kernel)
   long long part;                                   // chunk partials of the TN products and column sums
   long long part_cap;
   long long HD1, HD2, M1, M2, RD;                   // decoder Hessian-vector product: tangents
@@ -522,6 +523,8 @@ inline TrainSplitPlan plan_train_split(long long N, int d, int H, int T, const L
     p.AB[i] = take(R * 2 * d); p.H1[i] = take(R * H); p.H2[i] = take(R * H); p.O3[i] = take(R * 3 * d);
     p.DA2[i] = take(R * H); p.DA1[i] = take(R * H); p.DL[i] = take(R * 2 * d);
     p.w12c[i] = take(2LL * d * H); p.whc[i] = take(3LL * d * H);
+    p.w12p[i] = take((long long)ceil16(2 * d) * ceil16(H)); p.w4p[i] = take((long long)ceil16(H) * ceil16(H));
+    p.whp[i] = take((long long)ceil16(H) * ceil16(3 * d));
   }
   p.VS = take((T + 1) * N * d); p.YS = take((long long)T * N * d);
   p.lx = take(N * d); p.lv = take(N * d); p.dvh = take(N * d); p.dz = take(N * d); p.dg = take(N * d);
@@ -703,6 +706,7 @@ int64_t l2hmc_train_split_workspace_floats(int64_t n_chains, int32_t d, int32_t 
 
 int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   if (a && (a->gemm_mode < 0 || a->gemm_mode > 2)) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA), 1 (bf16x3) or 2 (bf16x3, split in the loop)%s");
+  if (a && (a->net_mode < 0 || a->net_mode > 1)) return fail(L2HMC_ERR_ARG, "net_mode must be 0 (fused) or 1 (three products)%s");
   t_gemm_bf3 = a ? a->gemm_mode != 0 : 0;
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
   const bool builtin = a->energy != nullptr;
@@ -786,6 +790,28 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   auto VS = [&](int it) { return w + p.VS + it * Nd; };
   auto YS = [&](int it) { return w + p.YS + it * Nd; };
 
+  // One net evaluation -- and its reverse -- in ONE launch each (net_eval_kernel with both hidden activations kept,
+  // net_bwd_kernel) under the sampler's own rule for the fused form: H % 4 == 0, d even, K <= 256, the tiles fit the LDS.
+  // (Round 5: at config 5's shapes the 120 launches of 64 x 64-tile products these replace were 2.5 ms of a 10.5 ms step.)
+  int ne_dev = 0, ne_cus = 256;
+  if (hipGetDevice(&ne_dev) != hipSuccess || hipDeviceGetAttribute(&ne_cus, hipDeviceAttributeMultiprocessorCount, ne_dev) != hipSuccess ||
+      ne_cus <= 0)
+    ne_cus = 256;
+  const int ne_cb = N >= 32LL * ne_cus ? 2 : 1;
+  const size_t ne_lds = net_eval_lds_bytes(d, H, ne_cb), nb_lds = net_bwd_lds_bytes(d, H, ne_cb);
+  const bool fused_nets = (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(3 * d) <= 16 * NE_MAXKT &&
+                          ne_lds <= 160 * 1024 && nb_lds <= 160 * 1024 && a->net_mode == 0;
+  if (fused_nets) {
+    hipError_t e = hipSuccess;
+    if (ne_lds > 48 * 1024)
+      e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_eval_kernel<2, 8>) : reinterpret_cast<const void*>(net_eval_kernel<1, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
+    if (e == hipSuccess && nb_lds > 48 * 1024)
+      e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_bwd_kernel<2, 8>) : reinterpret_cast<const void*>(net_bwd_kernel<1, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_lds);
+    if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const unsigned ne_blocks = (unsigned)((N + 16 * ne_cb - 1) / (16 * ne_cb));
   // ---- weights: transposed copies for the forward products, stacked copies for the input-gradient products ------
   if (vae) mlp3_transposes(s, dec, dws);
   if (use_planes) {           // weights split once per call; the activations' padding up to whole k-tiles zeroed once
@@ -827,6 +853,16 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
                        (long long)d * H, w + p.w12c[i]);
     hipLaunchKernelGGL(k_heads_side, dim3(nblk(3LL * d * H)), dim3(256), 0, s, nets[i]->Ws, nets[i]->Wt, nets[i]->Wq, H, d,
                        w + p.whc[i]);
+    if (fused_nets) {          // the same three matrices, rows and K zero-padded to multiples of 16 (net_bwd_kernel has no guards)
+      const int K3p = ceil16(3 * d);
+      (void)hipMemsetAsync(w + p.w12p[i], 0, sizeof(float) * (size_t)(p.whp[i] + (long long)Hp * K3p - p.w12p[i]), s);
+      (void)hipMemcpy2DAsync(w + p.w12p[i], sizeof(float) * Hp, w + p.w12c[i], sizeof(float) * H, sizeof(float) * H, (size_t)L,
+                             hipMemcpyDeviceToDevice, s);
+      (void)hipMemcpy2DAsync(w + p.w4p[i], sizeof(float) * Hp, nets[i]->W4, sizeof(float) * H, sizeof(float) * H, (size_t)H,
+                             hipMemcpyDeviceToDevice, s);
+      (void)hipMemcpy2DAsync(w + p.whp[i], sizeof(float) * K3p, w + p.whc[i], sizeof(float) * 3 * d, sizeof(float) * 3 * d, (size_t)H,
+                             hipMemcpyDeviceToDevice, s);
+    }
   }
 
   // trajectory point j = 0 .. T (the start point and the position after each leapfrog step)
@@ -858,6 +894,15 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   };
   // one net evaluation with everything kept: h1, h2 and the head products of evaluation (net, ne)
   auto net_fwd = [&](int net, int ne, int it) {
+    if (fused_nets) {
+      NetEvalArgs na = {};
+      na.AB = AB(net, ne); na.ldab = L; na.W12t = w12t[net]; na.W4t = w4t[net]; na.Wht = wht[net]; na.b4 = nets[net]->b4;
+      na.tb = tb + (long long)net * T * H; na.auxh = aux_h; na.dir = dir; na.dir_all = dall; na.it = it; na.T = T;
+      na.out3 = O3(net, ne); na.M = (int)N; na.d = d; na.H = H; na.keep_h1 = H1(net, ne); na.keep_h2 = H2(net, ne);
+      if (ne_cb == 2) hipLaunchKernelGGL((net_eval_kernel<2, 8>), dim3(ne_blocks), dim3(512), ne_lds, s, na);
+      else hipLaunchKernelGGL((net_eval_kernel<1, 4>), dim3(ne_blocks), dim3(256), ne_lds, s, na);
+      return;
+    }
     GemmArgs ga = gemm_args(AB(net, ne), L, w12t[net], K1p, H1(net, ne), H, N, H, L);
     ga.E = aux_h; ga.lde = H; ga.tb = tb + (long long)net * T * H; ga.dir = dir; ga.dir_all = dall; ga.it = it; ga.T = T;
     launch_gemm<EPI_NET1>(ga, s, SHAPE_MID);
@@ -869,6 +914,15 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   };
   // reverse of net_fwd for the data path: O3 holds (d zs | d zt | d zq) -> DA2, DA1 (kept for the weight gradients), dAB
   auto net_bwd = [&](int net, int ne) {
+    if (fused_nets) {
+      NetBwdArgs nb = {};
+      nb.dO3 = O3(net, ne); nb.ldo = 3 * d; nb.Whc = w + p.whp[net]; nb.W4 = w + p.w4p[net]; nb.W12 = w + p.w12p[net];
+      nb.h2 = H2(net, ne); nb.h1 = H1(net, ne); nb.da2 = DA2(net, ne); nb.da1 = DA1(net, ne); nb.dAB = w + p.dAB; nb.ldab = L;
+      nb.M = (int)N; nb.d = d; nb.H = H;
+      if (ne_cb == 2) hipLaunchKernelGGL((net_bwd_kernel<2, 8>), dim3(ne_blocks), dim3(512), nb_lds, s, nb);
+      else hipLaunchKernelGGL((net_bwd_kernel<1, 4>), dim3(ne_blocks), dim3(256), nb_lds, s, nb);
+      return;
+    }
     GemmArgs ga = gemm_args(O3(net, ne), 3 * d, w + p.whc[net], 3 * d, DA2(net, ne), H, N, H, 3 * d);
     ga.E = H2(net, ne); ga.lde = H;
     launch_gemm<EPI_MASK>(ga, s, SHAPE_MID);

@@ -63,6 +63,7 @@ class Dynamics(object):
         self._user_nets = False         # nets outside the fused architecture: evaluated by the caller's torch code (net_cb)
         self.gemm_mode = 1              # GEMM engine, decoder-sized products: 1 = bf16x3 (exact 3-way bf16 split of every
         #                                 fp32 operand on the bf16 MFMA, fp32-level accuracy), 0 = f32-input MFMA
+        self.net_mode = 0               # GEMM-engine trainer: 0 = one launch per net evaluation / per its reverse; 1 = three products each (A/B)
 
         if not isinstance(energy_function, EnergyFunction):
             if not callable(energy_function):

@@ -596,6 +596,7 @@ class SplitTrainer(Trainer):
         a.dLv_in, a.dlogjac_in = _ffi.ptr(dLv_in), _ffi.ptr(dlogjac_in)
         a.Lv_out, a.logjac_out = _ffi.ptr(Lv_out), _ffi.ptr(logjac_out)
         a.gemm_mode = int(getattr(dyn, "gemm_mode", 0))
+        a.net_mode = int(getattr(dyn, "net_mode", 0))          # 1: three products per net evaluation (A/B, tests)
         rc = L.l2hmc_train_split_grad(a, _ffi.current_stream(dyn.device))
         if cb_error:
             raise cb_error[0]

@@ -393,3 +393,64 @@ def test_training_on_presplit_planes_agrees_with_the_split_in_the_loop():
     assert np.abs(a[2] - b[2]).max() < 1e-4 * scale, float(np.abs(a[2] - b[2]).max() / scale)
     assert abs(a[0] - c[0]) < 1e-4 * max(1.0, abs(c[0])) and np.abs(a[1] - c[1]).max() < 5e-5
     assert np.abs(a[2] - c[2]).max() < 1e-3 * scale
+
+
+@pytest.mark.parametrize("N", [3072, 8192])
+def test_fused_net_launches_of_the_trainer_agree_with_the_three_products(N):
+    """Round 5: the GEMM-engine trainer evaluates an S/T/Q net -- and its reverse -- in ONE launch each (`net_eval_kernel` with both
+    hidden activations kept, `net_bwd_kernel`; csrc/gemm_f32.hpp) instead of three 64 x 64-tile products each.  Same contraction
+    order (k ascending, four k per MFMA), same epilogues: the two forms are expected to agree to rounding, and are held to a
+    hundredth of the gates of the suite.  3072 chains = 16 chains per workgroup, 8192 = 32 (the form config 5's bench runs)."""
+    import torch
+    from l2hmc_amd.training import Trainer
+    from tests.helpers import synthetic_vae_case
+    g = synthetic_vae_case(N=N, seed=11)
+    rng = np.random.RandomState(5)
+    dr = {"v": rng.randn(N, 50).astype(np.float32), "dir": rng.randint(0, 2, N).astype(np.uint8), "u": rng.rand(N).astype(np.float32)}
+    ls = np.full((N, 50), -0.5, np.float32)
+    res = {}
+    for mode in (0, 1):
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        dyn.net_mode = mode
+        tr = Trainer(dyn, decay_steps=0)
+        loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(ls), MH=1, draws=[dr])
+        res[mode] = (float(loss), to_np(px).copy(), to_np(tr.flat).copy(), to_np(x_T).copy())
+    a, b = res[0], res[1]
+    scale = float(np.abs(b[2]).max())
+    print("fused vs three products, %d chains: loss %.9e / %.9e  |dp| %.1e  |dx| %.1e  |dgrad| / scale %.1e  bitwise %s" % (
+        N, a[0], b[0], np.abs(a[1] - b[1]).max(), np.abs(a[3] - b[3]).max(), np.abs(a[2] - b[2]).max() / scale,
+        np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])))
+    assert abs(a[0] - b[0]) < 1e-6 * max(1.0, abs(b[0])), (a[0], b[0])
+    assert np.abs(a[1] - b[1]).max() < 1e-6 and rel_err(a[3], b[3]) < 2e-6
+    assert np.abs(a[2] - b[2]).max() < 2e-6 * scale, float(np.abs(a[2] - b[2]).max() / scale)
+
+
+@pytest.mark.parametrize("case", ["train_icg50_h32", "train_rough6_h20", "train_tilted8_h24"])
+def test_fused_net_launches_on_ragged_widths(case):
+    """The same A/B on the reference-graph fixtures of the wide-net trainer: 3 d = 18 / 24 / 150 and H = 20 / 24 / 32 are not
+    multiples of 16 -- the zero padding of the weight copies and of the LDS tiles is what these exercise."""
+    import torch
+    from l2hmc_amd.training import SplitTrainer
+    g = load(case)
+    draws = {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
+             "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
+             "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
+    res = {}
+    for mode in (0, 1):
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        dyn.net_mode = mode
+        tr = SplitTrainer(dyn)
+        loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=draws)
+        res[mode] = (float(loss), to_np(px).copy(), to_np(tr.flat).copy(), to_np(Lx).copy())
+    a, b = res[0], res[1]
+    scale = float(np.abs(b[2]).max())
+    print("%s: |dgrad| / scale %.1e  |dp| %.1e" % (case, np.abs(a[2] - b[2]).max() / scale, np.abs(a[1] - b[1]).max()))
+    assert abs(a[0] - b[0]) < 1e-6 * max(1.0, abs(b[0]))
+    assert np.abs(a[1] - b[1]).max() < 1e-6 and rel_err(a[3], b[3]) < 2e-6
+    assert np.abs(a[2] - b[2]).max() < 2e-6 * scale

@@ -3,7 +3,7 @@
 image branch, decoder 50 -> 1024 -> 1024 -> 784, Lf = 5; mnist_vae.py:185-262's sampler objective (MH chained proposals,
 clipped Adam) on the GEMM engine (`l2hmc_train_split_grad`).  Random weights (no checkpoint / MNIST offline).
 
-  python tools/bench_vae_train.py [chains=8192] [MH=1]
+  python tools/bench_vae_train.py [chains=8192] [MH=1] [net_mode=0]     (net_mode 1: three products per net evaluation, the round-4 form)
 """
 import os
 import sys
@@ -21,6 +21,7 @@ MH = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 g = synthetic_vae_case(N=N, seed=0)
 dyn = hip_dynamics(g)
 dyn.eps_override = None
+dyn.net_mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dyn.generator = torch.Generator(device="cuda").manual_seed(0)
 tr = Trainer(dyn, decay_steps=0)
 x, aux = to_dev(g["x"]), to_dev(g["aux"])
@@ -45,6 +46,6 @@ flops = 4 * T * f_net + (T + 1) * 2 * f_dec + 4 * T * 2 * f_net + (T + 1) * 2 * 
 n_diff = 1 if MH == 1 else MH                 # proposals differentiated (stop_gradient off)
 fwd_only = 0 if MH == 1 else (MH - 1) * (4 * T * f_net + (T + 1) * 2 * f_dec)
 tot = N * (n_diff * flops + fwd_only)
-print("config 5 sampler training, %d chains, MH = %d: %.2f ms per step = %.1f TFLOP/s algorithmic (%.3g flop per chain); "
+print("config 5 sampler training, %d chains, MH = %d, net_mode %d: %.2f ms per step = %.1f TFLOP/s algorithmic (%.3g flop per chain); "
       "loss %.4e, mean accept %.3f, workspace %.2f GB"
-      % (N, MH, 1e3 * el, tot / el / 1e12, tot / N, float(loss), float(px.mean()), tr._ws.numel() * 4 / 2 ** 30))
+      % (N, MH, dyn.net_mode, 1e3 * el, tot / el / 1e12, tot / N, float(loss), float(px.mean()), tr._ws.numel() * 4 / 2 ** 30))
