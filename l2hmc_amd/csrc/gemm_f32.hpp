@@ -973,6 +973,77 @@ int launch_gemm_shape(const GemmArgs& g, hipStream_t s) {
 
 // 128 x 128, 64 x 64, 32 x 64 workgroup tiles; SHAPE_W112: 128 x 112 (4 x 1 waves of 2 x 7 MFMA tiles) for widths that
 // are multiples of 112 but not of 128 -- the decoder's 784 = 7 x 112 logits, where 128-wide tiles waste 1/8 of the work
+// ------------------------------------------------------------------------------------------------------------
+// The N = d <= 64 products with a long K (the latent gradient d z = d a1 W1^T + z of the decoder posterior, K = 1024, and the
+// same shape inside its Hessian-vector product):  C = A B^T + E.  On the 32 x 64 tiles of gemm_nt_kernel this is 256 workgroups
+// of four waves walking 64 k-tiles with ONE tile of loads in flight each: 38.7 us for 33.5 MB of A at 8192 chains (0.87 TB/s)
+// -- latency, not bandwidth or the matrix pipe.  Here a workgroup owns 16 rows of A and its four waves a QUARTER of K each
+// (all NBLK column blocks): a wave requests its whole A fragment of a chunk of 16 k-tiles up front (16 dwordx4 per lane in
+// flight, 8 waves per CU), streams the weight fragments from L2 one k-tile ahead, and the four partial sums meet in LDS in
+// wave order (fixed order: reproducible).  No staging of A in LDS -- every element is used by exactly one wave.
+// Contract: K % 16 == 0, lda / ldb % 4 == 0, 16-byte aligned A and B, N <= 16 NBLK.
+template <int NBLK>
+__global__ __launch_bounds__(256) void gemm_skinny_add_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) f4 red[4][NBLK][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * 16;
+  const long long m = m0 + c;
+  const bool mok = m < g.M;
+  const int nk = g.K >> 4, nkq = (nk + 3) >> 2;                 // k-tiles of 16; per wave
+  const int jb = w * nkq, je = min(nk, jb + nkq);
+  const float* arow = g.A + (mok ? m : 0) * g.lda + 4 * q;
+  const float* wrow[NBLK];
+  bool nok[NBLK];
+#pragma unroll
+  for (int i = 0; i < NBLK; ++i) {
+    nok[i] = 16 * i + c < g.N;
+    wrow[i] = g.B + (long long)(nok[i] ? 16 * i + c : 0) * g.ldb + 4 * q;
+  }
+  f4 acc[NBLK];
+#pragma unroll
+  for (int i = 0; i < NBLK; ++i) acc[i] = splat(0.f);
+  constexpr int CH = 16;
+  for (int j0 = jb; j0 < je; j0 += CH) {
+    f4 af[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) af[u] = (mok && j0 + u < je) ? *reinterpret_cast<const f4*>(arow + 16 * (j0 + u)) : splat(0.f);
+    f4 wf[2][NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) wf[0][i] = nok[i] ? *reinterpret_cast<const f4*>(wrow[i] + 16 * j0) : splat(0.f);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      if (u + 1 < CH) {
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i)
+          wf[(u + 1) & 1][i] = (nok[i] && j0 + u + 1 < je) ? *reinterpret_cast<const f4*>(wrow[i] + 16 * (j0 + u + 1)) : splat(0.f);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) acc[i] = MFMA16(wf[u & 1][i][s], af[u][s], acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NBLK; ++i) red[w][i][lane] = acc[i];
+  __syncthreads();
+  // thread (i = w, lane): the four partial sums of block i in wave order, then the epilogue: lane holds C[m][16 i + 4 q + (0..3)]
+  if (w < NBLK && mok) {
+    f4 v = red[0][w][lane];
+    v = v + red[1][w][lane];
+    v = v + red[2][w][lane];
+    v = v + red[3][w][lane];
+    const int n = 16 * w + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < g.N) g.C[m * g.ldc + n + r] = v[r] + (g.E != nullptr ? g.E[m * g.lde + n + r] : 0.f);
+  }
+}
+inline bool gemm_skinny_ok(const GemmArgs& g) {
+  return g.N <= 64 && g.K % 16 == 0 && g.K >= 256 && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.bias == nullptr && g.C != nullptr &&
+         g.Cp == nullptr && ((reinterpret_cast<size_t>(g.A) | reinterpret_cast<size_t>(g.B)) & 15) == 0;
+}
+
 enum { SHAPE_BIG = 0, SHAPE_MID = 1, SHAPE_SKINNY = 2, SHAPE_AUTO = 3, SHAPE_W112 = 4 };
 inline int gemm_tile_n(int shape) { return shape == SHAPE_BIG ? 128 : (shape == SHAPE_W112 ? 112 : 64); }
 inline int gemm_waves_n(int shape) { return shape == SHAPE_W112 ? 1 : 2; }
@@ -993,6 +1064,16 @@ int launch_gemm(const GemmArgs& g, hipStream_t s, int shape = SHAPE_AUTO) {
   }
   if (shape == SHAPE_BIG) return launch_gemm_shape<EPI, 4, 4>(g, s);
   if (shape == SHAPE_MID) return launch_gemm_shape<EPI, 2, 2>(g, s);
+  if constexpr (EPI == EPI_ADD) {
+#ifndef L2HMC_NO_SKINNY_SPLITK
+    if (gemm_skinny_ok(g)) {
+      const dim3 grid((unsigned)((g.M + 15) / 16));
+      if (g.N <= 32) hipLaunchKernelGGL((gemm_skinny_add_kernel<2>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gemm_skinny_add_kernel<4>), grid, dim3(256), 0, s, g);
+      return L2HMC_OK;
+    }
+#endif
+  }
   return launch_gemm_shape<EPI, 1, 2>(g, s);
 }
 
