@@ -981,66 +981,99 @@ int launch_gemm_shape(const GemmArgs& g, hipStream_t s) {
 // (all NBLK column blocks): a wave requests its whole A fragment of a chunk of 16 k-tiles up front (16 dwordx4 per lane in
 // flight, 8 waves per CU), streams the weight fragments from L2 one k-tile ahead, and the four partial sums meet in LDS in
 // wave order (fixed order: reproducible).  No staging of A in LDS -- every element is used by exactly one wave.
-// Contract: K % 16 == 0, lda / ldb % 4 == 0, 16-byte aligned A and B, N <= 16 NBLK.
-template <int NBLK>
-__global__ __launch_bounds__(256) void gemm_skinny_add_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) f4 red[4][NBLK][64];
+// Contract: K % 256 == 0 (chunks of 4 k-tiles per wave; of 16 when K % 1024 == 0), lda / ldb % 4 == 0, 16-byte aligned A and B,
+// N <= 16 NBLK.
+template <int NBLK, int MB, int NW, int CH>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_add_kernel(const GemmArgs g) {
+  static_assert(NW == 4 || NW == 8, "K is split over 4 or 8 waves");
+  static_assert(MB * NBLK <= NW, "one wave per output block in the epilogue");
+  __shared__ __attribute__((aligned(16))) f4 red[4][MB * NBLK][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const long long m0 = (long long)blockIdx.x * 16;
-  const long long m = m0 + c;
-  const bool mok = m < g.M;
-  const int nk = g.K >> 4, nkq = (nk + 3) >> 2;                 // k-tiles of 16; per wave
-  const int jb = w * nkq, je = min(nk, jb + nkq);
-  const float* arow = g.A + (mok ? m : 0) * g.lda + 4 * q;
+  const long long m0 = (long long)blockIdx.x * (16 * MB);
+  const int nkq = (g.K >> 4) / NW;                               // k-tiles of 16 per wave (K % (16 NW CH) == 0)
+  const int jb = w * nkq, je = jb + nkq;
+  // No predicates in the loop: rows beyond M and weight rows beyond N are CLAMPED to row 0 -- an output element depends on its
+  // own row of A and its own row of B only, and the elements of those rows / columns are never stored.  (With a guard per load
+  // the compiler branches around every one of them and waits for vmcnt(0) at each join.)
+  const float* arow[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) arow[b] = g.A + (m0 + 16 * b + c < g.M ? m0 + 16 * b + c : 0) * g.lda + 4 * q;
   const float* wrow[NBLK];
-  bool nok[NBLK];
 #pragma unroll
-  for (int i = 0; i < NBLK; ++i) {
-    nok[i] = 16 * i + c < g.N;
-    wrow[i] = g.B + (long long)(nok[i] ? 16 * i + c : 0) * g.ldb + 4 * q;
-  }
-  f4 acc[NBLK];
+  for (int i = 0; i < NBLK; ++i) wrow[i] = g.B + (long long)(16 * i + c < g.N ? 16 * i + c : 0) * g.ldb + 4 * q;
+  f4 acc[MB][NBLK];
 #pragma unroll
-  for (int i = 0; i < NBLK; ++i) acc[i] = splat(0.f);
-  constexpr int CH = 16;
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) acc[b][i] = splat(0.f);
+  constexpr int WD = CH < 4 ? CH : 4;                            // ring of weight fragments, WD - 1 k-tiles ahead of the MFMAs
   for (int j0 = jb; j0 < je; j0 += CH) {
-    f4 af[CH];
+    f4 af[MB][CH];
 #pragma unroll
-    for (int u = 0; u < CH; ++u) af[u] = (mok && j0 + u < je) ? *reinterpret_cast<const f4*>(arow + 16 * (j0 + u)) : splat(0.f);
-    f4 wf[2][NBLK];
+    for (int u = 0; u < CH; ++u)
 #pragma unroll
-    for (int i = 0; i < NBLK; ++i) wf[0][i] = nok[i] ? *reinterpret_cast<const f4*>(wrow[i] + 16 * j0) : splat(0.f);
+      for (int b = 0; b < MB; ++b) af[b][u] = *reinterpret_cast<const f4*>(arow[b] + 16 * (j0 + u));
+    f4 wf[WD][NBLK];
+#pragma unroll
+    for (int t = 0; t < WD - 1; ++t)
+#pragma unroll
+      for (int i = 0; i < NBLK; ++i) wf[t][i] = *reinterpret_cast<const f4*>(wrow[i] + 16 * (j0 + t));
+    __builtin_amdgcn_sched_barrier(0);     // (the scheduler otherwise sinks every load to its first use: one round trip per k-tile)
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
-      if (u + 1 < CH) {
+      if (u + WD - 1 < CH) {
 #pragma unroll
-        for (int i = 0; i < NBLK; ++i)
-          wf[(u + 1) & 1][i] = (nok[i] && j0 + u + 1 < je) ? *reinterpret_cast<const f4*>(wrow[i] + 16 * (j0 + u + 1)) : splat(0.f);
+        for (int i = 0; i < NBLK; ++i) wf[(u + WD - 1) % WD][i] = *reinterpret_cast<const f4*>(wrow[i] + 16 * (j0 + u + WD - 1));
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int i = 0; i < NBLK; ++i) acc[i] = MFMA16(wf[u & 1][i][s], af[u][s], acc[i]);
+        for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+          for (int b = 0; b < MB; ++b) acc[b][i] = MFMA16(wf[u % WD][i][s], af[b][u][s], acc[b][i]);
     }
   }
+  // the NW partial sums in a fixed order: (w + 4) onto w first (eight waves), then 0 + 1 + 2 + 3 by the epilogue threads
+  if (NW == 8) {
+    if (w >= 4) {
 #pragma unroll
-  for (int i = 0; i < NBLK; ++i) red[w][i][lane] = acc[i];
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) red[w - 4][b * NBLK + i][lane] = acc[b][i];
+    }
+    __syncthreads();
+    if (w < 4) {
+#pragma unroll
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) acc[b][i] = acc[b][i] + red[w][b * NBLK + i][lane];
+    }
+    __syncthreads();
+  }
+  if (w < 4) {
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int i = 0; i < NBLK; ++i) red[w][b * NBLK + i][lane] = acc[b][i];
+  }
   __syncthreads();
-  // thread (i = w, lane): the four partial sums of block i in wave order, then the epilogue: lane holds C[m][16 i + 4 q + (0..3)]
-  if (w < NBLK && mok) {
+  // thread (block = w, lane): lane holds C[m0 + 16 b + c][16 i + 4 q + (0..3)] of block (b, i) = (w / NBLK, w % NBLK)
+  const long long m = m0 + 16 * (w / NBLK) + c;
+  if (w < MB * NBLK && m < g.M) {
     f4 v = red[0][w][lane];
     v = v + red[1][w][lane];
     v = v + red[2][w][lane];
     v = v + red[3][w][lane];
-    const int n = 16 * w + 4 * q;
+    const int n = 16 * (w % NBLK) + 4 * q;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (n + r < g.N) g.C[m * g.ldc + n + r] = v[r] + (g.E != nullptr ? g.E[m * g.lde + n + r] : 0.f);
   }
 }
 inline bool gemm_skinny_ok(const GemmArgs& g) {
-  return g.N <= 64 && g.K % 16 == 0 && g.K >= 256 && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.bias == nullptr && g.C != nullptr &&
+  return g.N <= 64 && g.K % 256 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.bias == nullptr && g.C != nullptr &&
          g.Cp == nullptr && ((reinterpret_cast<size_t>(g.A) | reinterpret_cast<size_t>(g.B)) & 15) == 0;
 }
 
@@ -1067,9 +1100,16 @@ int launch_gemm(const GemmArgs& g, hipStream_t s, int shape = SHAPE_AUTO) {
   if constexpr (EPI == EPI_ADD) {
 #ifndef L2HMC_NO_SKINNY_SPLITK
     if (gemm_skinny_ok(g)) {
-      const dim3 grid((unsigned)((g.M + 15) / 16));
-      if (g.N <= 32) hipLaunchKernelGGL((gemm_skinny_add_kernel<2>), grid, dim3(256), 0, s, g);
-      else hipLaunchKernelGGL((gemm_skinny_add_kernel<4>), grid, dim3(256), 0, s, g);
+      // 32 rows on eight waves (every weight fragment from L2 feeds two MFMAs) once that still gives every CU a workgroup
+      if (g.K % 1024 == 0 && g.M >= 32LL * 200) {
+        const dim3 grid((unsigned)((g.M + 31) / 32));
+        if (g.N <= 32) hipLaunchKernelGGL((gemm_skinny_add_kernel<2, 2, 8, 8>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_skinny_add_kernel<4, 2, 8, 8>), grid, dim3(512), 0, s, g);
+      } else {
+        const dim3 grid((unsigned)((g.M + 15) / 16));
+        if (g.N <= 32) hipLaunchKernelGGL((gemm_skinny_add_kernel<2, 1, 4, 4>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_skinny_add_kernel<4, 1, 4, 4>), grid, dim3(256), 0, s, g);
+      }
       return L2HMC_OK;
     }
 #endif

@@ -141,7 +141,7 @@ class Dynamics(object):
             raise NotImplementedError("an aux (image) branch is only implemented together with the VAE posterior energy "
                                       "or a caller-supplied energy")
         self._split_ws = None
-        self._split_key, self._split_aux = None, (None, -1)
+        self._split_key, self._split_aux, self._last_reuse = None, (None, -1), 0
 
     # ---- masks / time encoding -----------------------------------------------------------------
     def _init_mask(self):
@@ -255,6 +255,14 @@ class Dynamics(object):
         return self._packed
 
     # ---- the fused trajectory ----------------------------------------------------------------------
+    @staticmethod
+    def _aux_key(aux):
+        """What identifies the CONTENT of the conditioning images between two launches: the storage address, the version
+        counter torch bumps on every in-place write (shared by all views of the storage -- `as_device_f32` hands a fresh
+        `detach()` view to every launch, so object identity would never match) and the shape.  `_split_aux` keeps a
+        reference to the tensor, so the address cannot be recycled for other data in between."""
+        return (aux.data_ptr(), aux._version, tuple(aux.shape))
+
     def _check_aux(self, aux):
         if self._vae or (self._user and self._aux_nets):
             if aux is None:
@@ -389,8 +397,7 @@ class Dynamics(object):
         a.workspace, a.workspace_floats = self._split_ws.data_ptr(), self._split_ws.numel()
         # What the workspace still holds from the previous launch (L2hmcSplitArgs.reuse): the prepared weights while no
         # parameter changed (same storage and torch version counters; the native optimiser resets `_packed_key`, which
-        # clears this too), the image branch while the very same `aux` tensor object is passed again unmodified (a
-        # reference to it is kept, so its address cannot be recycled for other data).
+        # clears this too), the image branch while the same `aux` storage is passed again unmodified (`_aux_key`).
         wkey = None
         img = self._vae or (self._user and self._aux_nets)          # an image branch whose result can be reused
         if not self.hmc and not self._user_nets:
@@ -402,16 +409,16 @@ class Dynamics(object):
         reuse = 0
         if wkey is not None and wkey == self._split_key:
             reuse |= 1
-            if img and aux is self._split_aux[0] and aux._version == self._split_aux[1]:
+            if img and self._split_aux[0] is not None and self._aux_key(aux) == self._split_aux[1]:
                 reuse |= 2
-        a.reuse = reuse
+        a.reuse = self._last_reuse = reuse
         a.gemm_mode = int(self.gemm_mode)
         rc = L.l2hmc_trajectory_split(a, _ffi.current_stream(x.device))
         if cb_error:
             raise cb_error[0]
         _ffi.check(rc)
         self._split_key = wkey
-        self._split_aux = (aux, aux._version) if (img and aux is not None) else (None, -1)
+        self._split_aux = (aux, self._aux_key(aux)) if (img and aux is not None) else (None, -1)
         return out
 
     def _run_split_chain(self, x, v, step_begin, n_steps, direction, direction_all, u, want, M, rng, aux):

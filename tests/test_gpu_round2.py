@@ -267,6 +267,7 @@ def test_split_engine_workspace_reuse_is_invisible():
     first = run(dyn, aux)
     assert dyn._split_key is not None
     assert same(run(dyn, aux), first) and same(run(dyn, aux), first)          # reuse = 3 on these
+    assert dyn._last_reuse == 3      # (round 5: it was 1 -- every launch gets a fresh detach() view of aux, identity never matched)
     with torch.no_grad():
         dyn._xw["W1"].mul_(1.25)                                               # a parameter changes (version counter)
         dyn._xw["aux_encoder"]["W3"].mul_(0.5)
@@ -276,11 +277,11 @@ def test_split_engine_workspace_reuse_is_invisible():
         fresh._xw["aux_encoder"]["W3"].mul_(0.5)
     want = run(fresh, aux)
     assert not same(want, first)
-    assert same(run(dyn, aux), want)
+    assert same(run(dyn, aux), want) and dyn._last_reuse == 0
     aux2 = aux.clone()
     aux2[:, ::3] = 1.0 - aux2[:, ::3]                                          # other images, another tensor
     want2 = run(fresh, aux2)
-    assert not same(want2, want) and same(run(dyn, aux2), want2)
+    assert not same(want2, want) and same(run(dyn, aux2), want2) and dyn._last_reuse == 1
     aux2[:, 1::3] = 1.0 - aux2[:, 1::3]                                        # ... and the same tensor modified in place
     assert same(run(dyn, aux2), run(hip_dynamics_like(fresh, g), aux2))
 
