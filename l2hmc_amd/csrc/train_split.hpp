@@ -460,8 +460,7 @@ __global__ void colsum_reduce_kernel(const float* part, int n_chunks, int cols, 
                                      int jblock, long long jstride) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
-  float s = 0.f;
-  for (int z = 0; z < n_chunks; ++z) s += part[(long long)z * cols + j];
+  const float s = sum_chunks(part + j, n_chunks, cols);
   if (jblock > 0) {
     dst0[(long long)(j / jblock) * jstride + (j % jblock)] += s;
   } else {
