@@ -491,6 +491,7 @@ struct NetEvalArgs {
   float* out3;                      // (M, 3 d)  (upd.mode == 0)
   int M, d, H;
   float *keep_h1, *keep_h2;         // (M, H) or NULL: both hidden activations also go to HBM (the trainer's reverse sweep needs them)
+  float* keep_out3;                 // (M, 3 d) or NULL: with a fused update (upd.mode != 0), the raw head products ALSO go to HBM
   // The leapfrog half-update that consumes this evaluation, fused behind the heads (upd.mode != 0: the head products stay in
   // LDS and out3 is not written).  Same formulas as the stand-alone update kernels of split.hip.
   struct Update {
@@ -625,6 +626,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
     const int n = nb * 16 + 4 * q;
     if (mode != 0) {                                         // (n + 3 < ceil16(3 d) = ldo always)
       *reinterpret_cast<f4*>(sOut + (16 * cb + c) * ldo + n) = v;
+      if (g.keep_out3 != nullptr && mok[cb]) {
+        float* o = g.keep_out3 + (m0 + 16 * cb + c) * N3 + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N3) o[r] = v[r];
+      }
       return;
     }
     if (!mok[cb]) return;

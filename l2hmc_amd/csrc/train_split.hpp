@@ -347,6 +347,13 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* A, int lda, lo
     if (V4 && col + 3 < cols) {
 #pragma unroll 4
       for (long long r = r0 + ry; r < r1; r += 16) s = s + *reinterpret_cast<const f4*>(A + r * lda + col);
+    } else if (!V4 && col + 3 < cols && lda % 2 == 0 && (col & 1) == 0 && (reinterpret_cast<size_t>(A) & 7) == 0) {
+      typedef float f2 __attribute__((ext_vector_type(2)));        // 8-byte rows (the 3 d = 150 head cotangents): two dwordx2
+#pragma unroll 4
+      for (long long r = r0 + ry; r < r1; r += 16) {
+        const f2 a = *reinterpret_cast<const f2*>(A + r * lda + col), b = *reinterpret_cast<const f2*>(A + r * lda + col + 2);
+        s = s + f4{a.x, a.y, b.x, b.y};
+      }
     } else {
       for (long long r = r0 + ry; r < r1; r += 16) {
         const float* p = A + r * lda + col;
@@ -385,7 +392,15 @@ __global__ __launch_bounds__(256) void k_w3_part(const float* A, int H, long lon
   if (n1 > N) n1 = N;
   const float cf = trig[2 * it], sf = trig[2 * it + 1], cb = trig[2 * (T - 1 - it)], sb = trig[2 * (T - 1 - it) + 1];
   f4 sc = splat(0.f), ss = splat(0.f);
-  if (col < H)
+  if (col < H && H % 4 == 0 && (reinterpret_cast<size_t>(A) & 15) == 0) {       // whole quads, 16-byte rows: dwordx4, four rows in flight
+#pragma unroll 4
+    for (long long n = n0 + ry; n < n1; n += 16) {
+      const bool fwd = dir != nullptr ? dir[n] != 0 : (dir_all != 0);
+      const f4 a = *reinterpret_cast<const f4*>(A + ((long long)e * N + n) * H + col);
+      sc = sc + (fwd ? cf : cb) * a;
+      ss = ss + (fwd ? sf : sb) * a;
+    }
+  } else if (col < H)
     for (long long n = n0 + ry; n < n1; n += 16) {
       const bool fwd = dir != nullptr ? dir[n] != 0 : (dir_all != 0);
       const float* p = A + ((long long)e * N + n) * H + col;
@@ -892,15 +907,22 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     return L2HMC_OK;
   };
   // one net evaluation with everything kept: h1, h2 and the head products of evaluation (net, ne)
-  auto net_fwd = [&](int net, int ne, int it) {
+  // `upd`: the half-update that consumes the evaluation (fused behind the heads when the fused kernel runs: the raw head
+  // products still go to O3 for the reverse sweep); returns false when the caller has to launch the stand-alone update kernel
+  auto net_fwd = [&](int net, int ne, int it, NetEvalArgs::Update upd = NetEvalArgs::Update{}) -> bool {
     if (fused_nets) {
       NetEvalArgs na = {};
+      const L2hmcNet& nw = *nets[net];
+      upd.bs = nw.bs; upd.bt = nw.bt; upd.bq = nw.bq; upd.lam_s = nw.lam_s; upd.lam_q = nw.lam_q;
+      upd.alpha = a->alpha; upd.eps_host = a->eps_host; upd.ld = ld; upd.masks = a->masks;
+      na.upd = upd;
+      na.keep_out3 = O3(net, ne);
       na.AB = AB(net, ne); na.ldab = L; na.W12t = w12t[net]; na.W4t = w4t[net]; na.Wht = wht[net]; na.b4 = nets[net]->b4;
       na.tb = tb + (long long)net * T * H; na.auxh = aux_h; na.dir = dir; na.dir_all = dall; na.it = it; na.T = T;
       na.out3 = O3(net, ne); na.M = (int)N; na.d = d; na.H = H; na.keep_h1 = H1(net, ne); na.keep_h2 = H2(net, ne);
       if (ne_cb == 2) hipLaunchKernelGGL((net_eval_kernel<2, 8>), dim3(ne_blocks), dim3(512), ne_lds, s, na);
       else hipLaunchKernelGGL((net_eval_kernel<1, 4>), dim3(ne_blocks), dim3(256), ne_lds, s, na);
-      return;
+      return upd.mode != 0;
     }
     GemmArgs ga = gemm_args(AB(net, ne), L, w12t[net], K1p, H1(net, ne), H, N, H, L);
     ga.E = aux_h; ga.lde = H; ga.tb = tb + (long long)net * T * H; ga.dir = dir; ga.dir_all = dall; ga.it = it; ga.T = T;
@@ -910,6 +932,19 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     launch_gemm<EPI_BIAS_RELU>(ga, s, SHAPE_MID);
     ga = gemm_args(H2(net, ne), H, wht[net], Hp, O3(net, ne), 3 * d, N, 3 * d, H);
     launch_gemm<EPI_BIAS>(ga, s, SHAPE_MID);
+    return false;
+  };
+  auto v_upd = [&](const float* vin, int ldvi, const float* g, float* vout, int ldvo, const float* x, float* xin) {
+    NetEvalArgs::Update u = {};
+    u.mode = 1; u.vin = vin; u.ldvi = ldvi; u.g = g; u.ldg = L; u.vout = vout; u.ldvo = ldvo;
+    if (xin != nullptr) { u.x = x; u.ldx = L; u.xin = xin; u.ldxi = L; }
+    return u;
+  };
+  auto x_upd = [&](const float* zin, int ldzi, const float* vh, float* zout, int ldzo, float* xin_next, int second) {
+    NetEvalArgs::Update u = {};
+    u.mode = 2; u.zin = zin; u.ldzi = ldzi; u.vh = vh; u.ldvh = L; u.zout = zout; u.ldzo = ldzo;
+    u.xin_next = xin_next; u.ldxn = L; u.second = second;
+    return u;
   };
   // reverse of net_fwd for the data path: O3 holds (d zs | d zt | d zq) -> DA2, DA1 (kept for the weight gradients), dAB
   auto net_bwd = [&](int net, int ne) {
@@ -940,21 +975,22 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   for (int it = 0; it < T; ++it) {
     const bool last = it == T - 1;
     float *abv0 = AB(1, 2 * it), *abv1 = AB(1, 2 * it + 1), *abx0 = AB(0, 2 * it), *abx1 = AB(0, 2 * it + 1);
-    net_fwd(1, 2 * it, it);
-    hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it), vn, VS(it), d, abv0 + d, L, abx0, L, ld, dir, dall,
-                       a->alpha, a->eps_host, N, d);
-    hipLaunchKernelGGL(k_mask_first, dim3(nblk(Nd)), dim3(256), 0, s, abv0, L, abx0 + d, L, a->masks, dir, dall, it, T, N, d);
-    net_fwd(0, 2 * it, it);
-    hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it), xn, abv0, L, abx0, L, YS(it), d, abx1 + d, L, ld,
-                       a->masks, dir, dall, it, T, 0, a->alpha, a->eps_host, N, d);
+    if (!net_fwd(1, 2 * it, it, v_upd(VS(it), d, abv0 + d, abx0, L, abv0, abx0 + d))) {
+      hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it), vn, VS(it), d, abv0 + d, L, abx0, L, ld, dir, dall,
+                         a->alpha, a->eps_host, N, d);
+      hipLaunchKernelGGL(k_mask_first, dim3(nblk(Nd)), dim3(256), 0, s, abv0, L, abx0 + d, L, a->masks, dir, dall, it, T, N, d);
+    }
+    if (!net_fwd(0, 2 * it, it, x_upd(abv0, L, abx0, YS(it), d, abx1 + d, 0)))
+      hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it), xn, abv0, L, abx0, L, YS(it), d, abx1 + d, L, ld,
+                         a->masks, dir, dall, it, T, 0, a->alpha, a->eps_host, N, d);
     (void)hipMemcpy2DAsync(abx1, sizeof(float) * L, abx0, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
-    net_fwd(0, 2 * it + 1, it);
-    hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it + 1), xn, YS(it), d, abx0, L, abv1, L, (float*)nullptr, 0,
-                       ld, a->masks, dir, dall, it, T, 1, a->alpha, a->eps_host, N, d);
+    if (!net_fwd(0, 2 * it + 1, it, x_upd(YS(it), d, abx0, abv1, L, nullptr, 1)))
+      hipLaunchKernelGGL(k_x_half, dim3(nw4), dim3(256), 0, s, O3(0, 2 * it + 1), xn, YS(it), d, abx0, L, abv1, L, (float*)nullptr, 0,
+                         ld, a->masks, dir, dall, it, T, 1, a->alpha, a->eps_host, N, d);
     if ((rc = energy_eval(abv1, it + 1, last ? U1d : nullptr))) return rc;
-    net_fwd(1, 2 * it + 1, it);
-    hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it + 1), vn, abx0, L, abv1 + d, L, VS(it + 1), d, ld, dir,
-                       dall, a->alpha, a->eps_host, N, d);
+    if (!net_fwd(1, 2 * it + 1, it, v_upd(abx0, L, abv1 + d, VS(it + 1), d, nullptr, nullptr)))
+      hipLaunchKernelGGL(k_v_half, dim3(nw4), dim3(256), 0, s, O3(1, 2 * it + 1), vn, abx0, L, abv1 + d, L, VS(it + 1), d, ld, dir,
+                         dall, a->alpha, a->eps_host, N, d);
     if (!last) (void)hipMemcpyAsync(AB(1, 2 * it + 2), abv1, sizeof(float) * NL, hipMemcpyDeviceToDevice, s);
   }
 
