@@ -32,6 +32,7 @@
 //   EPI_NET1            C = relu(acc + tb[row(m)][n] + auxh[m][n])      (first hidden layer of an S/T/Q net:
 //                       time/bias table row of the chain's schedule row, image-branch term)
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "l2hmc_kernels.hpp"
@@ -526,13 +527,63 @@ inline size_t net_eval_lds_bytes(int d, int H, int CB = 1) {
 // NWV = waves per workgroup (the waves share out the 16-wide output blocks of every layer): <1, 4> = 16 chains on 4 waves,
 // two workgroups per CU; <2, 8> = 32 chains on 8 waves, one workgroup per CU -- the same 8 waves per CU, but every weight
 // fragment streamed from L2 now feeds two MFMAs (half the L2 traffic of a net evaluation).
-template <int CB, int NWV = 4>
+//
+// NK1 / NKH > 0 (round 5): the k-tile counts of the first layer and of the hidden layers are COMPILE-TIME (config 5: K1p = 112,
+// Hp = 208 -> <7, 13>), a wave owns at most two output blocks per layer (NWV >= half the block count), and the weight
+// fragments of the NEXT block -- of the next LAYER across the barrier: they depend on no activation -- are requested before
+// the MFMAs of the current one (two register sets, `sched_barrier` pins the order: left alone, the scheduler sinks every load
+// to its first use).  With runtime k-tile counts (the generic form, NK1 = 0) every fragment load sits behind a uniform branch
+// and the compiler waits for vmcnt(0) at each join: one L2 round trip per block with nothing to run beside it.
+template <int CB, int NWV = 4, int NK1 = 0, int NKH = 0>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(const NetEvalArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   lds_poison(sm);
   constexpr int NE_MT = 16 * CB, NTHR = 64 * NWV;
+  constexpr bool PIPE = NK1 > 0;
+  constexpr int NKMAX = PIPE ? (NKH > NK1 ? NKH : NK1) : 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
+  f4 wset[2][NKMAX];                                         // (PIPE) the two fragment sets
+  auto wload = [&](auto nkc, const float* Wt, int nb, f4* wf) {
+    constexpr int NK = decltype(nkc)::value;
+    const float* wrow = Wt + (long long)(nb * 16 + c) * (16 * NK) + 4 * q;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) wf[j] = *reinterpret_cast<const f4*>(wrow + 16 * j);
+  };
+  // NCB = CB: the whole block; NCB = 1: its chain block `cb0` only (a block shared out between two waves, see the stage plan)
+  auto wcomp = [&](auto nkc, auto ncbc, int cb0, const float* As, int ldA, const f4* wf, int nb, auto&& epi) {
+    constexpr int NK = decltype(nkc)::value, NCB = decltype(ncbc)::value;
+    f4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = splat(0.f);
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const f4 af = *reinterpret_cast<const f4*>(As + (16 * (cb0 + cb) + c) * ldA + j * 16 + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[cb] = MFMA16(wf[j][s], af[s], acc[cb]);
+      }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) epi(nb, cb0 + cb, acc[cb]);
+  };
+  typedef std::integral_constant<int, CB> ICB;
+  typedef std::integral_constant<int, 1> IC1;
+  // second slot of wave w in a layer of NBL output blocks (the first is block w): with rem = NBL - NWV blocks left, an odd
+  // rem (or rem == 2) leaves the SIMD that holds waves 0 and NWV / 2 a whole block more than the others (13 blocks on 8 waves:
+  // 4 / 3 / 3 / 3) -- so the last block (both, for rem == 2) is shared out by chain block between two waves of different
+  // SIMDs: 3.5 / 3.5 / 3 / 3.  Returns the block (or -1) and which chain blocks (-1: all).
+  auto slot1 = [&](int NBL, int& cbh) {
+    const int rem = NBL - NWV, S = (rem & 1) ? 1 : (rem == 2 ? 2 : 0), F = rem - S;
+    cbh = -1;
+    if (CB != 2 || F + 2 * S > NWV) return w < rem ? NWV + w : -1;
+    if (w < F) return NWV + w;
+    if (w < F + 2 * S) { cbh = (w - F) & 1; return NWV + F + ((w - F) >> 1); }
+    return -1;
+  };
+  typedef std::integral_constant<int, NK1> IK1;
+  typedef std::integral_constant<int, NKH> IKH;
+  if constexpr (PIPE) wload(IK1{}, g.W12t, w, wset[0]);      // stage 0 travels under the input tile's own round trip
   const int K1 = 2 * g.d, H = g.H, K1p = ceil16(K1), Hp = ceil16(H);
   const int ld1 = odd_quarter_stride(K1p), ldh = odd_quarter_stride(Hp);
   float* sIn = sm;
@@ -599,7 +650,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
     }
   }
 
-  layer(sIn, ld1, K1p, g.W12t, Hp, [&](int nb, int cb, f4 v) {
+  const int N3 = 3 * g.d;
+  const int mode = g.upd.mode;
+  auto epi1 = [&](int nb, int cb, f4 v) {
     const int n = nb * 16 + 4 * q;
     if (n >= H) return;                                        // (H % 4 == 0)
     f4 t = splat(0.f), e = splat(0.f);
@@ -610,19 +663,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
     const f4 h = relu4f(v + t + e);
     *reinterpret_cast<f4*>(sH1 + (16 * cb + c) * ldh + n) = h;
     if (g.keep_h1 != nullptr && mok[cb]) *reinterpret_cast<f4*>(g.keep_h1 + (m0 + 16 * cb + c) * H + n) = h;
-  });
-  __syncthreads();
-  layer(sH1, ldh, Hp, g.W4t, Hp, [&](int nb, int cb, f4 v) {
+  };
+  auto epi2 = [&](int nb, int cb, f4 v) {
     const int n = nb * 16 + 4 * q;
     if (n >= H) return;
     const f4 h = relu4f(v + *reinterpret_cast<const f4*>(g.b4 + n));
     *reinterpret_cast<f4*>(sH2 + (16 * cb + c) * ldh + n) = h;
     if (g.keep_h2 != nullptr && mok[cb]) *reinterpret_cast<f4*>(g.keep_h2 + (m0 + 16 * cb + c) * H + n) = h;
-  });
-  __syncthreads();
-  const int N3 = 3 * g.d;
-  const int mode = g.upd.mode;
-  layer(sH2, ldh, Hp, g.Wht, ceil16(N3), [&](int nb, int cb, f4 v) {
+  };
+  auto epi3 = [&](int nb, int cb, f4 v) {
     const int n = nb * 16 + 4 * q;
     if (mode != 0) {                                         // (n + 3 < ceil16(3 d) = ldo always)
       *reinterpret_cast<f4*>(sOut + (16 * cb + c) * ldo + n) = v;
@@ -639,7 +688,46 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (n + r < N3) o[r] = v[r];
-  });
+  };
+  if constexpr (PIPE) {
+    // stages (layer, slot): a wave's blocks are w and `slot1` of each layer; stage k's fragments live in set k % 2 and are
+    // requested one stage ahead.  (K1p == 16 NK1, Hp == 16 NKH: the host picks the instantiation.)
+    const int nb0 = w, NB3 = ceil16(N3) >> 4;
+    int hH, h3;
+    const int nbH = slot1(NKH, hH), nb3 = slot1(NB3, h3);      // second blocks in the hidden layers / the head layer
+    const bool one3 = nb0 < NB3;
+    auto second = [&](auto nkc, const float* As, int ldA, const f4* wf, int nb, int cbh, auto&& epi) {
+      if (nb < 0) return;
+      if (cbh < 0) wcomp(nkc, ICB{}, 0, As, ldA, wf, nb, epi);
+      else wcomp(nkc, IC1{}, cbh, As, ldA, wf, nb, epi);
+    };
+    if (nbH >= 0) wload(IK1{}, g.W12t, nbH, wset[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    wcomp(IK1{}, ICB{}, 0, sIn, ld1, wset[0], nb0, epi1);
+    __builtin_amdgcn_sched_barrier(0);
+    wload(IKH{}, g.W4t, nb0, wset[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    second(IK1{}, sIn, ld1, wset[1], nbH, hH, epi1);
+    __syncthreads();
+    if (nbH >= 0) wload(IKH{}, g.W4t, nbH, wset[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    wcomp(IKH{}, ICB{}, 0, sH1, ldh, wset[0], nb0, epi2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (one3) wload(IKH{}, g.Wht, nb0, wset[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    second(IKH{}, sH1, ldh, wset[1], nbH, hH, epi2);
+    __syncthreads();
+    if (nb3 >= 0) wload(IKH{}, g.Wht, nb3, wset[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (one3) wcomp(IKH{}, ICB{}, 0, sH2, ldh, wset[0], nb0, epi3);
+    second(IKH{}, sH2, ldh, wset[1], nb3, h3, epi3);
+  } else {
+    layer(sIn, ld1, K1p, g.W12t, Hp, epi1);
+    __syncthreads();
+    layer(sH1, ldh, Hp, g.W4t, Hp, epi2);
+    __syncthreads();
+    layer(sH2, ldh, Hp, g.Wht, ceil16(N3), epi3);
+  }
   if (mode == 0) return;
   __syncthreads();
   // ---- fused half-update: TPC = 16 / CB threads per chain, dimensions strided by TPC; the chain's log-det share is
@@ -698,6 +786,18 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
 #pragma unroll
   for (int off = TPC / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if (ok && j == 0) U.ld[n] += acc;
+}
+
+// which instantiation runs: 32 chains on 8 waves from `cb` == 2; the software-pipelined form for the shapes it is compiled for
+inline bool net_eval_piped(int cb, int d, int H) { return cb == 2 && ceil16(2 * d) == 16 * 7 && ceil16(H) == 16 * 13; }
+inline const void* net_eval_fn(int cb, int d, int H) {
+  if (net_eval_piped(cb, d, H)) return reinterpret_cast<const void*>(net_eval_kernel<2, 8, 7, 13>);
+  return cb == 2 ? reinterpret_cast<const void*>(net_eval_kernel<2, 8>) : reinterpret_cast<const void*>(net_eval_kernel<1, 4>);
+}
+inline void launch_net_eval(int cb, unsigned blocks, size_t lds, hipStream_t s, const NetEvalArgs& na) {
+  if (net_eval_piped(cb, na.d, na.H)) hipLaunchKernelGGL((net_eval_kernel<2, 8, 7, 13>), dim3(blocks), dim3(512), lds, s, na);
+  else if (cb == 2) hipLaunchKernelGGL((net_eval_kernel<2, 8>), dim3(blocks), dim3(512), lds, s, na);
+  else hipLaunchKernelGGL((net_eval_kernel<1, 4>), dim3(blocks), dim3(256), lds, s, na);
 }
 
 // ------------------------------------------------------------------------------------------------------------

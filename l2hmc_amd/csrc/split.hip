@@ -586,8 +586,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   const size_t ne_lds = net_eval_lds_bytes(d, H, ne_cb);
   const bool ne_ok = !unets && (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(2 * d) <= 16 * NE_MAXKT && ne_lds <= 160 * 1024;
   if (ne_ok && !hmc && ne_lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_eval_kernel<2, 8>) : reinterpret_cast<const void*>(net_eval_kernel<1, 4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
+    hipError_t e = hipFuncSetAttribute(net_eval_fn(ne_cb, d, H), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
     if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   // `upd`: the half-update that consumes the evaluation; fused into net_eval_kernel when that kernel runs, else the
@@ -602,8 +601,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
       na.dir = dir; na.dir_all = dall; na.it = it; na.T = T; na.out3 = out3; na.M = (int)N; na.d = d; na.H = H;
       na.upd = upd;
       const unsigned blocks = (unsigned)((N + 16 * ne_cb - 1) / (16 * ne_cb));
-      if (ne_cb == 2) hipLaunchKernelGGL((net_eval_kernel<2, 8>), dim3(blocks), dim3(512), ne_lds, s, na);
-      else hipLaunchKernelGGL((net_eval_kernel<1, 4>), dim3(blocks), dim3(256), ne_lds, s, na);
+      launch_net_eval(ne_cb, blocks, ne_lds, s, na);
       return L2HMC_OK;
     }
     if (unets) {     // the caller's net writes the final S | T | Q into out3 (nw = no_net: the update kernels take them as they are)

@@ -818,8 +818,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   if (fused_nets) {
     hipError_t e = hipSuccess;
     if (ne_lds > 48 * 1024)
-      e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_eval_kernel<2, 8>) : reinterpret_cast<const void*>(net_eval_kernel<1, 4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
+      e = hipFuncSetAttribute(net_eval_fn(ne_cb, d, H), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
     if (e == hipSuccess && nb_lds > 48 * 1024)
       e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_bwd_kernel<2, 8>) : reinterpret_cast<const void*>(net_bwd_kernel<1, 4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_lds);
@@ -920,8 +919,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
       na.AB = AB(net, ne); na.ldab = L; na.W12t = w12t[net]; na.W4t = w4t[net]; na.Wht = wht[net]; na.b4 = nets[net]->b4;
       na.tb = tb + (long long)net * T * H; na.auxh = aux_h; na.dir = dir; na.dir_all = dall; na.it = it; na.T = T;
       na.out3 = O3(net, ne); na.M = (int)N; na.d = d; na.H = H; na.keep_h1 = H1(net, ne); na.keep_h2 = H2(net, ne);
-      if (ne_cb == 2) hipLaunchKernelGGL((net_eval_kernel<2, 8>), dim3(ne_blocks), dim3(512), ne_lds, s, na);
-      else hipLaunchKernelGGL((net_eval_kernel<1, 4>), dim3(ne_blocks), dim3(256), ne_lds, s, na);
+      launch_net_eval(ne_cb, ne_blocks, ne_lds, s, na);
       return upd.mode != 0;
     }
     GemmArgs ga = gemm_args(AB(net, ne), L, w12t[net], K1p, H1(net, ne), H, N, H, L);
