@@ -557,13 +557,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) acc[cb] = splat(0.f);
 #pragma unroll
-    for (int j = 0; j < NK; ++j)
+    for (int j = 0; j < NK; ++j) {
+      f4 af[NCB];
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const f4 af = *reinterpret_cast<const f4*>(As + (16 * (cb0 + cb) + c) * ldA + j * 16 + 4 * q);
+      for (int cb = 0; cb < NCB; ++cb) af[cb] = *reinterpret_cast<const f4*>(As + (16 * (cb0 + cb) + c) * ldA + j * 16 + 4 * q);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[cb] = MFMA16(wf[j][s], af[s], acc[cb]);
-      }
+      for (int s = 0; s < 4; ++s)                              // the chain blocks' accumulators alternate: no MFMA waits on its predecessor
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = MFMA16(wf[j][s], af[cb][s], acc[cb]);
+    }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) epi(nb, cb0 + cb, acc[cb]);
   };
@@ -576,6 +578,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
   auto slot1 = [&](int NBL, int& cbh) {
     const int rem = NBL - NWV, S = (rem & 1) ? 1 : (rem == 2 ? 2 : 0), F = rem - S;
     cbh = -1;
+    if (rem <= 0) return -1;
     if (CB != 2 || F + 2 * S > NWV) return w < rem ? NWV + w : -1;
     if (w < F) return NWV + w;
     if (w < F + 2 * S) { cbh = (w - F) & 1; return NWV + F + ((w - F) >> 1); }
@@ -583,7 +586,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
   };
   typedef std::integral_constant<int, NK1> IK1;
   typedef std::integral_constant<int, NKH> IKH;
-  if constexpr (PIPE) wload(IK1{}, g.W12t, w, wset[0]);      // stage 0 travels under the input tile's own round trip
+#ifdef L2HMC_NE_TIMERS          // phase stamps of two workgroups, printed by lane 0 of every wave (tools/experiments: variant build only)
+  unsigned long long ne_t[8];
+  int ne_n = 0;
+#define NE_STAMP() do { if (ne_n < 8) ne_t[ne_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NE_STAMP() do {} while (0)
+#endif
+  NE_STAMP();
   const int K1 = 2 * g.d, H = g.H, K1p = ceil16(K1), Hp = ceil16(H);
   const int ld1 = odd_quarter_stride(K1p), ldh = odd_quarter_stride(Hp);
   float* sIn = sm;
@@ -593,11 +603,71 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
   float* sOut = ldo <= ldh ? sH1 : sH2 + NE_MT * ldh;    // (NE_MT, ceil16(3 d)) head products of the fused update
   const long long m0 = (long long)blockIdx.x * NE_MT;
 
-  for (int i = tid; i < NE_MT * (K1p / 4); i += NTHR) {        // input tile, zero padded to K1p (K1 % 4 == 0)
-    const int r = i / (K1p / 4), kq4 = (i % (K1p / 4)) * 4;
-    f4 v = splat(0.f);
-    if (m0 + r < g.M && kq4 < K1) v = *reinterpret_cast<const f4*>(g.AB + (m0 + r) * g.ldab + kq4);
-    *reinterpret_cast<f4*>(sIn + r * ld1 + kq4) = v;
+  // (PIPE) the input tile's loads go out FIRST -- loads return in order, whatever is requested ahead of them delays the first
+  // barrier -- and are parked in registers while everything else this wave will need is requested behind them
+  constexpr int IN_Q = PIPE ? 4 * NK1 : 1, IN_U = PIPE ? (NE_MT * IN_Q + NTHR - 1) / NTHR : 1;       // quads per row; per thread
+  f4 vin_[IN_U];
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int u = 0; u < IN_U; ++u) {
+      const int i = tid + u * NTHR, r = i / IN_Q, kq4 = (i % IN_Q) * 4;
+      const bool valid = i < NE_MT * IN_Q && m0 + r < g.M && kq4 < K1;
+      vin_[u] = *reinterpret_cast<const f4*>(g.AB + (valid ? (m0 + r) * g.ldab + kq4 : 0));      // (clamped: no branch around the load)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wload(IK1{}, g.W12t, w, wset[0]);                          // stage 0
+  }
+  // schedule rows of this lane's chains: requested early -- the epilogue of layer 1 hangs on them
+  bool mok[CB], fwdc[CB];
+  int trow[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const long long m = m0 + 16 * cb + c;
+    mok[cb] = m < g.M;
+    trow[cb] = 0;
+    fwdc[cb] = true;
+    if (mok[cb]) {
+      fwdc[cb] = g.dir != nullptr ? g.dir[m] != 0 : (g.dir_all != 0);
+      trow[cb] = fwdc[cb] ? g.it : (g.T - 1 - g.it);
+    }
+  }
+  // (PIPE) the epilogue operands of this wave's two blocks of layers 1 and 2 -- the image-branch term (an HBM round trip per
+  // block when it is requested where it is used: the phase stamps of round 5 showed layer 1 at twice its matrix-pipe time),
+  // BOTH candidate rows of the time/bias table (which one depends on the chain's direction, itself still in flight), b4 --
+  // are requested here, under the input tile's round trip
+  f4 pe[2][CB], ptF[2], ptB[2], pb[2];
+  int hH = -1, nbH = -1;
+  if constexpr (PIPE) {
+    nbH = slot1(NKH, hH);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int nb = sl == 0 ? w : nbH;
+      const int n = nb * 16 + 4 * q;
+      const bool nin = nb >= 0 && n < g.H;
+      ptF[sl] = nin ? *reinterpret_cast<const f4*>(g.tb + (long long)g.it * g.H + n) : splat(0.f);
+      ptB[sl] = nin ? *reinterpret_cast<const f4*>(g.tb + (long long)(g.T - 1 - g.it) * g.H + n) : splat(0.f);
+      pb[sl] = nin ? *reinterpret_cast<const f4*>(g.b4 + n) : splat(0.f);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        pe[sl][cb] = (nin && mok[cb] && g.auxh != nullptr) ? *reinterpret_cast<const f4*>(g.auxh + (m0 + 16 * cb + c) * g.H + n) : splat(0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int N3 = 3 * g.d;
+  const int mode = g.upd.mode;
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int u = 0; u < IN_U; ++u) {
+      const int i = tid + u * NTHR, r = i / IN_Q, kq4 = (i % IN_Q) * 4;
+      if (i < NE_MT * IN_Q) *reinterpret_cast<f4*>(sIn + r * ld1 + kq4) = (m0 + r < g.M && kq4 < K1) ? vin_[u] : splat(0.f);
+    }
+  } else {
+    for (int i = tid; i < NE_MT * (K1p / 4); i += NTHR) {        // input tile, zero padded to K1p (K1 % 4 == 0)
+      const int r = i / (K1p / 4), kq4 = (i % (K1p / 4)) * 4;
+      f4 v = splat(0.f);
+      if (m0 + r < g.M && kq4 < K1) v = *reinterpret_cast<const f4*>(g.AB + (m0 + r) * g.ldab + kq4);
+      *reinterpret_cast<f4*>(sIn + r * ld1 + kq4) = v;
+    }
   }
   for (int i = tid; i < NE_MT * (ldh - H) ; i += NTHR) {       // pad columns of the hidden activations
     const int r = i / (ldh - H), k = H + i % (ldh - H);
@@ -605,6 +675,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
     sH2[r * ldh + k] = 0.f;
   }
   __syncthreads();
+  NE_STAMP();
 
   // one layer: C[m][n] = sum_k As[m][k] Wt[n][k] over the padded Kp; epi(nb, cb, acc): lane holds
   // C[m = 16 cb + c][n = 16 nb + 4 q + r]
@@ -637,26 +708,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
     }
   };
   auto relu4f = [](f4 p) { return f4{fmaxf(p.x, 0.f), fmaxf(p.y, 0.f), fmaxf(p.z, 0.f), fmaxf(p.w, 0.f)}; };
-  bool mok[CB];
-  int trow[CB];
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) {
-    const long long m = m0 + 16 * cb + c;
-    mok[cb] = m < g.M;
-    trow[cb] = 0;
-    if (mok[cb]) {
-      const bool fwd = g.dir != nullptr ? g.dir[m] != 0 : (g.dir_all != 0);
-      trow[cb] = fwd ? g.it : (g.T - 1 - g.it);
-    }
-  }
-
-  const int N3 = 3 * g.d;
-  const int mode = g.upd.mode;
-  auto epi1 = [&](int nb, int cb, f4 v) {
+  auto epi1p = [&](auto sc, int nb, int cb, f4 v) {           // sc: the slot (PIPE: which preloaded operands)
+    constexpr int SL = decltype(sc)::value;
     const int n = nb * 16 + 4 * q;
     if (n >= H) return;                                        // (H % 4 == 0)
     f4 t = splat(0.f), e = splat(0.f);
-    if (mok[cb]) {
+    if constexpr (PIPE) {
+      if (mok[cb]) t = fwdc[cb] ? ptF[SL] : ptB[SL];
+      e = pe[SL][cb];
+    } else if (mok[cb]) {
       t = *reinterpret_cast<const f4*>(g.tb + (long long)trow[cb] * H + n);
       if (g.auxh != nullptr) e = *reinterpret_cast<const f4*>(g.auxh + (m0 + 16 * cb + c) * H + n);
     }
@@ -664,13 +724,22 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
     *reinterpret_cast<f4*>(sH1 + (16 * cb + c) * ldh + n) = h;
     if (g.keep_h1 != nullptr && mok[cb]) *reinterpret_cast<f4*>(g.keep_h1 + (m0 + 16 * cb + c) * H + n) = h;
   };
-  auto epi2 = [&](int nb, int cb, f4 v) {
+  auto epi2p = [&](auto sc, int nb, int cb, f4 v) {
+    constexpr int SL = decltype(sc)::value;
     const int n = nb * 16 + 4 * q;
     if (n >= H) return;
-    const f4 h = relu4f(v + *reinterpret_cast<const f4*>(g.b4 + n));
+    f4 b;
+    if constexpr (PIPE) b = pb[SL];
+    else b = *reinterpret_cast<const f4*>(g.b4 + n);
+    const f4 h = relu4f(v + b);
     *reinterpret_cast<f4*>(sH2 + (16 * cb + c) * ldh + n) = h;
     if (g.keep_h2 != nullptr && mok[cb]) *reinterpret_cast<f4*>(g.keep_h2 + (m0 + 16 * cb + c) * H + n) = h;
   };
+  typedef std::integral_constant<int, 0> IS0;
+  auto epi1 = [&](int nb, int cb, f4 v) { epi1p(IS0{}, nb, cb, v); };
+  auto epi1b = [&](int nb, int cb, f4 v) { epi1p(IC1{}, nb, cb, v); };
+  auto epi2 = [&](int nb, int cb, f4 v) { epi2p(IS0{}, nb, cb, v); };
+  auto epi2b = [&](int nb, int cb, f4 v) { epi2p(IC1{}, nb, cb, v); };
   auto epi3 = [&](int nb, int cb, f4 v) {
     const int n = nb * 16 + 4 * q;
     if (mode != 0) {                                         // (n + 3 < ceil16(3 d) = ldo always)
@@ -693,8 +762,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
     // stages (layer, slot): a wave's blocks are w and `slot1` of each layer; stage k's fragments live in set k % 2 and are
     // requested one stage ahead.  (K1p == 16 NK1, Hp == 16 NKH: the host picks the instantiation.)
     const int nb0 = w, NB3 = ceil16(N3) >> 4;
-    int hH, h3;
-    const int nbH = slot1(NKH, hH), nb3 = slot1(NB3, h3);      // second blocks in the hidden layers / the head layer
+    int h3;
+    const int nb3 = slot1(NB3, h3);                            // second block in the head layer (hidden layers: nbH, hH above)
     const bool one3 = nb0 < NB3;
     auto second = [&](auto nkc, const float* As, int ldA, const f4* wf, int nb, int cbh, auto&& epi) {
       if (nb < 0) return;
@@ -707,16 +776,20 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
     __builtin_amdgcn_sched_barrier(0);
     wload(IKH{}, g.W4t, nb0, wset[0]);
     __builtin_amdgcn_sched_barrier(0);
-    second(IK1{}, sIn, ld1, wset[1], nbH, hH, epi1);
+    second(IK1{}, sIn, ld1, wset[1], nbH, hH, epi1b);
+    NE_STAMP();
     __syncthreads();
+    NE_STAMP();
     if (nbH >= 0) wload(IKH{}, g.W4t, nbH, wset[1]);
     __builtin_amdgcn_sched_barrier(0);
     wcomp(IKH{}, ICB{}, 0, sH1, ldh, wset[0], nb0, epi2);
     __builtin_amdgcn_sched_barrier(0);
     if (one3) wload(IKH{}, g.Wht, nb0, wset[0]);
     __builtin_amdgcn_sched_barrier(0);
-    second(IKH{}, sH1, ldh, wset[1], nbH, hH, epi2);
+    second(IKH{}, sH1, ldh, wset[1], nbH, hH, epi2b);
+    NE_STAMP();
     __syncthreads();
+    NE_STAMP();
     if (nb3 >= 0) wload(IKH{}, g.Wht, nb3, wset[1]);
     __builtin_amdgcn_sched_barrier(0);
     if (one3) wcomp(IKH{}, ICB{}, 0, sH2, ldh, wset[0], nb0, epi3);
@@ -729,7 +802,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
     layer(sH2, ldh, Hp, g.Wht, ceil16(N3), epi3);
   }
   if (mode == 0) return;
+  NE_STAMP();
   __syncthreads();
+  NE_STAMP();
   // ---- fused half-update: TPC = 16 / CB threads per chain, dimensions strided by TPC; the chain's log-det share is
   // reduced over its TPC lanes in a fixed order
   const NetEvalArgs::Update& U = g.upd;
@@ -747,45 +822,56 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
   const float eps = U.alpha != nullptr ? expf(*U.alpha) : U.eps_host, sgn = fwd ? 1.f : -1.f;
   const float* o3 = sOut + r * ldo;
   float acc = 0.f;
+  const float heps = 0.5f * eps;
+  auto upd_v = [&](int k, float vi, float gk, float xk) {      // momentum half-update of dimension k (k_v_half of split.hip)
+    const float S = expf(U.lam_s[k]) * tanhf(o3[k] + U.bs[k]);
+    const float T_ = o3[d + k] + U.bt[k];
+    const float Q = expf(U.lam_q[k]) * tanhf(o3[2 * d + k] + U.bq[k]);
+    const float sv = sgn * heps * S, ES = expf(sv), EQ = expf(eps * Q);
+    const float cc = heps * (T_ - EQ * gk);
+    U.vout[n * U.ldvo + k] = fwd ? vi * ES + cc : (vi - cc) * ES;
+    acc += sv;
+    if (U.xin != nullptr) {
+      const float mk = U.masks[srow * d + k];
+      U.xin[n * U.ldxi + k] = (fwd ? mk : 1.f - mk) * xk;
+    }
+  };
+  auto upd_x = [&](int k, float zi, float vhk) {               // masked position update of dimension k (k_x_half)
+    const float mk = U.masks[srow * d + k];
+    const float k1 = fwd ? mk : 1.f - mk;
+    const float kp = U.second ? 1.f - k1 : k1, up = 1.f - kp;
+    const float S = expf(U.lam_s[k]) * tanhf(o3[k] + U.bs[k]);
+    const float T_ = o3[d + k] + U.bt[k];
+    const float Q = expf(U.lam_q[k]) * tanhf(o3[2 * d + k] + U.bq[k]);
+    const float sx = sgn * eps * S, ES = expf(sx), EQ = expf(eps * Q);
+    const float tr = eps * (EQ * vhk + T_);
+    const float nw = fwd ? zi * ES + tr : ES * (zi - tr);
+    const float zo = kp * zi + up * nw;
+    U.zout[n * U.ldzo + k] = zo;
+    if (U.xin_next != nullptr) U.xin_next[n * U.ldxn + k] = up * zo;
+    acc += up * sx;
+  };
+  // (Requesting these operands at the top of the kernel, or right behind its first barrier, was measured in round 5: the update
+  //  phase shrinks by 1200 cycles and the phase that issues the twelve extra loads per thread grows by as much.)
   if (ok) {
     if (mode == 1) {
-      const float heps = 0.5f * eps;
-      for (int k = j; k < d; k += TPC) {
-        const float S = expf(U.lam_s[k]) * tanhf(o3[k] + U.bs[k]);
-        const float T_ = o3[d + k] + U.bt[k];
-        const float Q = expf(U.lam_q[k]) * tanhf(o3[2 * d + k] + U.bq[k]);
-        const float sv = sgn * heps * S, ES = expf(sv), EQ = expf(eps * Q);
-        const float cc = heps * (T_ - EQ * U.g[n * U.ldg + k]);
-        const float vi = U.vin[n * U.ldvi + k];
-        U.vout[n * U.ldvo + k] = fwd ? vi * ES + cc : (vi - cc) * ES;
-        acc += sv;
-        if (U.xin != nullptr) {
-          const float mk = U.masks[srow * d + k];
-          U.xin[n * U.ldxi + k] = (fwd ? mk : 1.f - mk) * U.x[n * U.ldx + k];
-        }
-      }
+      for (int k = j; k < d; k += TPC) upd_v(k, U.vin[n * U.ldvi + k], U.g[n * U.ldg + k], U.xin != nullptr ? U.x[n * U.ldx + k] : 0.f);
     } else {
-      for (int k = j; k < d; k += TPC) {
-        const float mk = U.masks[srow * d + k];
-        const float k1 = fwd ? mk : 1.f - mk;
-        const float kp = U.second ? 1.f - k1 : k1, up = 1.f - kp;
-        const float S = expf(U.lam_s[k]) * tanhf(o3[k] + U.bs[k]);
-        const float T_ = o3[d + k] + U.bt[k];
-        const float Q = expf(U.lam_q[k]) * tanhf(o3[2 * d + k] + U.bq[k]);
-        const float sx = sgn * eps * S, ES = expf(sx), EQ = expf(eps * Q);
-        const float tr = eps * (EQ * U.vh[n * U.ldvh + k] + T_);
-        const float zi = U.zin[n * U.ldzi + k];
-        const float nw = fwd ? zi * ES + tr : ES * (zi - tr);
-        const float zo = kp * zi + up * nw;
-        U.zout[n * U.ldzo + k] = zo;
-        if (U.xin_next != nullptr) U.xin_next[n * U.ldxn + k] = up * zo;
-        acc += up * sx;
-      }
+      for (int k = j; k < d; k += TPC) upd_x(k, U.zin[n * U.ldzi + k], U.vh[n * U.ldvh + k]);
     }
   }
 #pragma unroll
   for (int off = TPC / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if (ok && j == 0) U.ld[n] += acc;
+#ifdef L2HMC_NE_TIMERS
+  {
+    const unsigned long long te = __builtin_amdgcn_s_memtime();
+    if (PIPE && lane == 0 && (blockIdx.x == 3 || blockIdx.x == 131) && g.it == 2)
+      printf("NE wg %d w %d mode %d : in %llu  L1 %llu bar %llu  L2 %llu bar %llu  L3 %llu bar %llu  upd %llu  total %llu\n", (int)blockIdx.x, w, mode,
+             ne_t[1] - ne_t[0], ne_t[2] - ne_t[1], ne_t[3] - ne_t[2], ne_t[4] - ne_t[3], ne_t[5] - ne_t[4], ne_t[6] - ne_t[5],
+             ne_t[7] - ne_t[6], te - ne_t[7], te - ne_t[0]);
+  }
+#endif
 }
 
 // which instantiation runs: 32 chains on 8 waves from `cb` == 2; the software-pipelined form for the shapes it is compiled for
@@ -821,11 +907,16 @@ inline size_t net_bwd_lds_bytes(int d, int H, int CB = 1) {
   return sizeof(float) * 16 * CB * (size_t)(odd_quarter_stride(ceil16(3 * d)) + 2 * odd_quarter_stride(ceil16(H)));
 }
 
-template <int CB, int NWV = 4>
+// NK3 / NKH > 0: the software-pipelined form of net_eval_kernel<CB, NWV, NK1, NKH> (compile-time k-tile counts, fragments a stage
+// ahead, the odd block shared out between two SIMDs, the relu masks of both blocks requested ahead of the first barrier) for
+// ceil16(3 d) == 16 NK3 and ceil16(H) == 16 NKH.
+template <int CB, int NWV = 4, int NK3 = 0, int NKH = 0>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_bwd_kernel(const NetBwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   lds_poison(sm);
   constexpr int NE_MT = 16 * CB, NTHR = 64 * NWV;
+  constexpr bool PIPE = NK3 > 0;
+  constexpr int NKMAX = PIPE ? (NKH > NK3 ? NKH : NK3) : 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int N3 = 3 * g.d, K1 = 2 * g.d, H = g.H, K3p = ceil16(N3), K1p = ceil16(K1), Hp = ceil16(H);
@@ -834,6 +925,151 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_bwd_kernel(con
   float* sD2 = sIn + NE_MT * ld3;
   float* sD1 = sD2 + NE_MT * ldh;
   const long long m0 = (long long)blockIdx.x * NE_MT;
+  bool mok[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) mok[cb] = m0 + 16 * cb + c < g.M;
+  auto masked = [](f4 v, f4 h) { return f4{h.x > 0.f ? v.x : 0.f, h.y > 0.f ? v.y : 0.f, h.z > 0.f ? v.z : 0.f, h.w > 0.f ? v.w : 0.f}; };
+
+  if constexpr (PIPE) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef std::integral_constant<int, NK3> IK3;
+    typedef std::integral_constant<int, NKH> IKH;
+    typedef std::integral_constant<int, CB> ICB;
+    typedef std::integral_constant<int, 1> IC1;
+    typedef std::integral_constant<int, 0> IS0;
+    f4 wset[2][NKMAX];
+    auto wload = [&](auto nkc, const float* Wt, int nb, f4* wf) {
+      constexpr int NK = decltype(nkc)::value;
+      const float* wrow = Wt + (long long)(nb * 16 + c) * (16 * NK) + 4 * q;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) wf[j] = *reinterpret_cast<const f4*>(wrow + 16 * j);
+    };
+    auto wcomp = [&](auto nkc, auto ncbc, int cb0, const float* As, int ldA, const f4* wf, int nb, auto&& epi) {
+      constexpr int NK = decltype(nkc)::value, NCB = decltype(ncbc)::value;
+      f4 acc[NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[cb] = splat(0.f);
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        f4 af[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) af[cb] = *reinterpret_cast<const f4*>(As + (16 * (cb0 + cb) + c) * ldA + j * 16 + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) acc[cb] = MFMA16(wf[j][s], af[cb][s], acc[cb]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) epi(nb, cb0 + cb, acc[cb]);
+    };
+    auto slot1 = [&](int NBL, int& cbh) {                      // as in net_eval_kernel
+      const int rem = NBL - NWV, S = (rem & 1) ? 1 : (rem == 2 ? 2 : 0), F = rem - S;
+      cbh = -1;
+      if (rem <= 0) return -1;
+      if (CB != 2 || F + 2 * S > NWV) return w < rem ? NWV + w : -1;
+      if (w < F) return NWV + w;
+      if (w < F + 2 * S) { cbh = (w - F) & 1; return NWV + F + ((w - F) >> 1); }
+      return -1;
+    };
+    auto second = [&](auto nkc, const float* As, int ldA, const f4* wf, int nb, int cbh, auto&& epi) {
+      if (nb < 0) return;
+      if (cbh < 0) wcomp(nkc, ICB{}, 0, As, ldA, wf, nb, epi);
+      else wcomp(nkc, IC1{}, cbh, As, ldA, wf, nb, epi);
+    };
+    // the cotangent tile's loads first (3 d even: 8-byte row segments), parked in registers; then stage 0 and the masks
+    constexpr int IN_P = 8 * NK3, IN_U = (NE_MT * IN_P + NTHR - 1) / NTHR;       // pairs per row; per thread
+    f2 vin_[IN_U];
+#pragma unroll
+    for (int u = 0; u < IN_U; ++u) {
+      const int i = tid + u * NTHR, r = i / IN_P, k2 = (i % IN_P) * 2;
+      const bool valid = i < NE_MT * IN_P && m0 + r < g.M && k2 < N3;
+      vin_[u] = *reinterpret_cast<const f2*>(g.dO3 + (valid ? (m0 + r) * g.ldo + k2 : 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int nb0 = w;
+    int hH, hC;
+    const int nbH = slot1(NKH, hH), NBC = K1p >> 4, nbC = slot1(NBC, hC);
+    wload(IK3{}, g.Whc, nb0, wset[0]);
+    f4 pm2[2][CB], pm1[2][CB];                                 // relu masks (the forward activations) of this wave's two blocks
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int nb = sl == 0 ? nb0 : nbH;
+      const int n = nb * 16 + 4 * q;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const bool v = nb >= 0 && n < H && mok[cb];
+        const long long at = v ? (m0 + 16 * cb + c) * H + n : 0;
+        pm2[sl][cb] = *reinterpret_cast<const f4*>(g.h2 + at);
+        pm1[sl][cb] = *reinterpret_cast<const f4*>(g.h1 + at);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < IN_U; ++u) {
+      const int i = tid + u * NTHR, r = i / IN_P, k2 = (i % IN_P) * 2;
+      if (i < NE_MT * IN_P)
+        *reinterpret_cast<f2*>(sIn + r * ld3 + k2) = (m0 + r < g.M && k2 < N3) ? vin_[u] : f2{0.f, 0.f};
+    }
+    for (int i = tid; i < NE_MT * (ldh - H); i += NTHR) {      // pad columns of the hidden cotangents
+      const int r = i / (ldh - H), k = H + i % (ldh - H);
+      sD2[r * ldh + k] = 0.f;
+      sD1[r * ldh + k] = 0.f;
+    }
+    __syncthreads();
+    auto epiA = [&](auto sc, int nb, int cb, f4 v) {
+      constexpr int SL = decltype(sc)::value;
+      const int n = nb * 16 + 4 * q;
+      if (n >= H) return;
+      f4 o = splat(0.f);
+      if (mok[cb]) {
+        o = masked(v, pm2[SL][cb]);
+        *reinterpret_cast<f4*>(g.da2 + (m0 + 16 * cb + c) * H + n) = o;
+      }
+      *reinterpret_cast<f4*>(sD2 + (16 * cb + c) * ldh + n) = o;
+    };
+    auto epiB = [&](auto sc, int nb, int cb, f4 v) {
+      constexpr int SL = decltype(sc)::value;
+      const int n = nb * 16 + 4 * q;
+      if (n >= H) return;
+      f4 o = splat(0.f);
+      if (mok[cb]) {
+        o = masked(v, pm1[SL][cb]);
+        *reinterpret_cast<f4*>(g.da1 + (m0 + 16 * cb + c) * H + n) = o;
+      }
+      *reinterpret_cast<f4*>(sD1 + (16 * cb + c) * ldh + n) = o;
+    };
+    auto epiC = [&](int nb, int cb, f4 v) {
+      const int n = nb * 16 + 4 * q;
+      if (!mok[cb] || n >= K1) return;
+      *reinterpret_cast<f4*>(g.dAB + (m0 + 16 * cb + c) * g.ldab + n) = v;
+    };
+    auto epiA0 = [&](int nb, int cb, f4 v) { epiA(IS0{}, nb, cb, v); };
+    auto epiA1 = [&](int nb, int cb, f4 v) { epiA(IC1{}, nb, cb, v); };
+    auto epiB0 = [&](int nb, int cb, f4 v) { epiB(IS0{}, nb, cb, v); };
+    auto epiB1 = [&](int nb, int cb, f4 v) { epiB(IC1{}, nb, cb, v); };
+    const bool oneC = nb0 < NBC;
+    if (nbH >= 0) wload(IK3{}, g.Whc, nbH, wset[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    wcomp(IK3{}, ICB{}, 0, sIn, ld3, wset[0], nb0, epiA0);
+    __builtin_amdgcn_sched_barrier(0);
+    wload(IKH{}, g.W4, nb0, wset[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    second(IK3{}, sIn, ld3, wset[1], nbH, hH, epiA1);
+    __syncthreads();
+    if (nbH >= 0) wload(IKH{}, g.W4, nbH, wset[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    wcomp(IKH{}, ICB{}, 0, sD2, ldh, wset[0], nb0, epiB0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (oneC) wload(IKH{}, g.W12, nb0, wset[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    second(IKH{}, sD2, ldh, wset[1], nbH, hH, epiB1);
+    __syncthreads();
+    if (nbC >= 0) wload(IKH{}, g.W12, nbC, wset[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (oneC) wcomp(IKH{}, ICB{}, 0, sD1, ldh, wset[0], nb0, epiC);
+    second(IKH{}, sD1, ldh, wset[1], nbC, hC, epiC);
+    return;
+  }
 
   for (int i = tid; i < NE_MT * K3p; i += NTHR) {            // cotangent tile, zero padded to K3p (3 d need not be a multiple of 4)
     const int r = i / K3p, k = i % K3p;
@@ -872,10 +1108,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_bwd_kernel(con
       for (int cb = 0; cb < CB; ++cb) epi(nb, cb, acc[cb]);
     }
   };
-  auto masked = [](f4 v, f4 h) { return f4{h.x > 0.f ? v.x : 0.f, h.y > 0.f ? v.y : 0.f, h.z > 0.f ? v.z : 0.f, h.w > 0.f ? v.w : 0.f}; };
-  bool mok[CB];
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) mok[cb] = m0 + 16 * cb + c < g.M;
 
   layer(sIn, ld3, K3p, g.Whc, Hp, [&](int nb, int cb, f4 v) {
     const int n = nb * 16 + 4 * q;
@@ -906,6 +1138,16 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_bwd_kernel(con
     if (!mok[cb] || n >= K1) return;                           // (2 d % 4 == 0)
     *reinterpret_cast<f4*>(g.dAB + (m0 + 16 * cb + c) * g.ldab + n) = v;
   });
+}
+inline bool net_bwd_piped(int cb, int d, int H) { return cb == 2 && d % 2 == 0 && ceil16(3 * d) == 16 * 10 && ceil16(H) == 16 * 13; }
+inline const void* net_bwd_fn(int cb, int d, int H) {
+  if (net_bwd_piped(cb, d, H)) return reinterpret_cast<const void*>(net_bwd_kernel<2, 8, 10, 13>);
+  return cb == 2 ? reinterpret_cast<const void*>(net_bwd_kernel<2, 8>) : reinterpret_cast<const void*>(net_bwd_kernel<1, 4>);
+}
+inline void launch_net_bwd(int cb, unsigned blocks, size_t lds, hipStream_t s, const NetBwdArgs& nb) {
+  if (net_bwd_piped(cb, nb.d, nb.H)) hipLaunchKernelGGL((net_bwd_kernel<2, 8, 10, 13>), dim3(blocks), dim3(512), lds, s, nb);
+  else if (cb == 2) hipLaunchKernelGGL((net_bwd_kernel<2, 8>), dim3(blocks), dim3(512), lds, s, nb);
+  else hipLaunchKernelGGL((net_bwd_kernel<1, 4>), dim3(blocks), dim3(256), lds, s, nb);
 }
 
 

@@ -820,8 +820,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     if (ne_lds > 48 * 1024)
       e = hipFuncSetAttribute(net_eval_fn(ne_cb, d, H), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ne_lds);
     if (e == hipSuccess && nb_lds > 48 * 1024)
-      e = hipFuncSetAttribute(ne_cb == 2 ? reinterpret_cast<const void*>(net_bwd_kernel<2, 8>) : reinterpret_cast<const void*>(net_bwd_kernel<1, 4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_lds);
+      e = hipFuncSetAttribute(net_bwd_fn(ne_cb, d, H), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_lds);
     if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const unsigned ne_blocks = (unsigned)((N + 16 * ne_cb - 1) / (16 * ne_cb));
@@ -951,8 +950,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
       nb.dO3 = O3(net, ne); nb.ldo = 3 * d; nb.Whc = w + p.whp[net]; nb.W4 = w + p.w4p[net]; nb.W12 = w + p.w12p[net];
       nb.h2 = H2(net, ne); nb.h1 = H1(net, ne); nb.da2 = DA2(net, ne); nb.da1 = DA1(net, ne); nb.dAB = w + p.dAB; nb.ldab = L;
       nb.M = (int)N; nb.d = d; nb.H = H;
-      if (ne_cb == 2) hipLaunchKernelGGL((net_bwd_kernel<2, 8>), dim3(ne_blocks), dim3(512), nb_lds, s, nb);
-      else hipLaunchKernelGGL((net_bwd_kernel<1, 4>), dim3(ne_blocks), dim3(256), nb_lds, s, nb);
+      launch_net_bwd(ne_cb, ne_blocks, nb_lds, s, nb);
       return;
     }
     GemmArgs ga = gemm_args(O3(net, ne), 3 * d, w + p.whc[net], 3 * d, DA2(net, ne), H, N, H, 3 * d);
