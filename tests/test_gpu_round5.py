@@ -454,3 +454,28 @@ def test_fused_net_launches_on_ragged_widths(case):
     assert abs(a[0] - b[0]) < 1e-6 * max(1.0, abs(b[0]))
     assert np.abs(a[1] - b[1]).max() < 1e-6 and rel_err(a[3], b[3]) < 2e-6
     assert np.abs(a[2] - b[2]).max() < 2e-6 * scale
+
+
+@pytest.mark.parametrize("latent,dec_h,N", [(20, 256, 384), (50, 256, 384), (20, 1024, 6400)])
+def test_split_k_latent_gradient_on_other_shapes(latent, dec_h, N):
+    """`gemm_skinny_add_kernel` (the N = d <= 64, K = decoder width products: latent gradient of the decoder posterior) beyond
+    config 5's own shape: d = 20 takes the two-column-block instantiation, a 256-wide decoder the 4-k-tile chunks, 6400 chains
+    of a 1024-wide one the 32-row / eight-wave form with N <= 32.  Proposal against the float64 evaluation of the same map at
+    the suite's gates."""
+    from l2hmc_amd import propose
+    from tests.helpers import check_x_next, synthetic_vae_case
+    g = synthetic_vae_case(latent=latent, H=40, dec_h=dec_h, n_pix=96, enc_h=64, N=N, seed=3)
+    dyn = hip_dynamics(g)
+    rng = np.random.RandomState(6)
+    direction = rng.randint(0, 2, size=N).astype(np.uint8)
+    u = rng.rand(N).astype(np.float32)
+    Lx, _, px, outs = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(g["v"]), u=to_dev(u),
+                              aux=to_dev(g["aux"]))
+    od64 = oracle_dynamics(g, np.float64)
+    with np.errstate(all="ignore"):
+        tLx, _, tpx, _ = O.propose(g["x"].astype(np.float64), od64, g["v"].astype(np.float64), g["v"].astype(np.float64),
+                                   direction, u.astype(np.float64), both_directions=False)
+    ex, ep = rel_err(to_np(Lx), tLx), abs_err(to_np(px), tpx)
+    print("d %d, decoder %d, %d chains: mean p %.3f  max rel err x %.2e  |p - p64| %.2e" % (latent, dec_h, N, float(tpx.mean()), ex, ep))
+    assert ex < 2e-4 and ep < 1e-4, (ex, ep)
+    check_x_next(to_np(outs[0]), g["x"], tLx, tpx, u, 5e-4)
