@@ -562,7 +562,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) af[cb] = *reinterpret_cast<const f4*>(As + (16 * (cb0 + cb) + c) * ldA + j * 16 + 4 * q);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)                              // the chain blocks' accumulators alternate: no MFMA waits on its predecessor
+      for (int s = 0; s < 4; ++s)                              // (the chain blocks' accumulators alternate; measured equal to block-major)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) acc[cb] = MFMA16(wf[j][s], af[cb][s], acc[cb]);
     }
@@ -681,8 +681,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void net_eval_kernel(co
   // C[m = 16 cb + c][n = 16 nb + 4 q + r]
   auto layer = [&](const float* As, int ldA, int Kp, const float* Wt, int Np, auto&& epi) {
     const int nk = Kp >> 4;
-    // (requesting block nb + NWV's weight fragments before block nb's MFMAs -- two register stages -- was measured: 3.84 vs
-    //  3.79 ms per config-5 proposal; the eight waves of a CU already cover the L2 latency)
+    // (requesting block nb + NWV's weight fragments before block nb's MFMAs IN THIS FORM -- two register stages behind the
+    //  uniform `j < nk` branches -- was measured in round 3: 3.84 vs 3.79 ms per config-5 proposal.  With compile-time k-tile
+    //  counts and pinned load order it is what the PIPE form above gains from.)
     for (int nb = w; nb * 16 < Np; nb += NWV) {
       const float* wrow = Wt + (long long)(nb * 16 + c) * Kp + 4 * q;
       f4 wf[NE_MAXKT];
