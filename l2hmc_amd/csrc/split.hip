@@ -63,6 +63,42 @@ __global__ void k_vae_U(const float* rowsum, int np, const float* z, int ldz, in
   if (U != nullptr) U[n] = (float)acc;
   if (Ud != nullptr) Ud[n] = acc;
 }
+// The per-chain reductions of the engine (energy from its row partials, kinetic energy) as one thread per chain walk 50-odd
+// strided words each: 8192 chains = 32 workgroups of pure latency (17 / 10 us, the proposal's MH select 29 us -- round 5 trace).
+// Staged forms: a workgroup's ROW_CPB chains are read coalesced into LDS, then thread = chain sums ITS row in the same order as
+// before (bit-identical results).  Taken while the rows fit 48 KB.
+constexpr int ROW_CPB = 64;
+__device__ __forceinline__ void stage_rows(float* sm, const float* src, long long ld, int cols, long long n0, long long N) {
+  for (int i = threadIdx.x; i < ROW_CPB * cols; i += blockDim.x) {
+    const int r = i / cols, k = i % cols;
+    sm[i] = n0 + r < N ? src[(n0 + r) * ld + k] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void k_vae_U_staged(const float* rowsum, int np, const float* z, int ldz, int d, float* U,
+                                                      double* Ud, long long N) {
+  extern __shared__ float rsm[];
+  float *sr = rsm, *sz = rsm + ROW_CPB * np;
+  const long long n0 = (long long)blockIdx.x * ROW_CPB;
+  stage_rows(sr, rowsum, np, np, n0, N);
+  stage_rows(sz, z, ldz, d, n0, N);
+  __syncthreads();
+  const long long n = n0 + threadIdx.x;
+  if (threadIdx.x >= ROW_CPB || n >= N) return;
+  double acc = 0.0;
+  for (int k = 0; k < np; ++k) acc += (double)sr[threadIdx.x * np + k];
+  double qd = 0.0;
+  for (int k = 0; k < d; ++k) qd += (double)sz[threadIdx.x * d + k] * (double)sz[threadIdx.x * d + k];
+  acc += 0.5 * qd;
+  if (U != nullptr) U[n] = (float)acc;
+  if (Ud != nullptr) Ud[n] = acc;
+}
+inline void launch_vae_U(hipStream_t s, const float* rowsum, int np, const float* z, int ldz, int d, float* U, double* Ud, long long N) {
+  const size_t lds = sizeof(float) * ROW_CPB * (size_t)(np + d);
+  if (lds <= 48 * 1024)
+    hipLaunchKernelGGL(k_vae_U_staged, dim3((unsigned)((N + ROW_CPB - 1) / ROW_CPB)), dim3(256), lds, s, rowsum, np, z, ldz, d, U, Ud, N);
+  else
+    hipLaunchKernelGGL(k_vae_U, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rowsum, np, z, ldz, d, U, Ud, N);
+}
 // HMC mode (nets identically zero, dynamics.py:73-76): the generalised step is the plain leapfrog
 //   v_h = v - (eps/2) g(x);  x' = x + eps v_h     [k_hmc_drift]      v' = v_h - (eps/2) g(x')   [k_hmc_kick]
 // and its inverse (dynamics.py:159-201 with S = T = Q = 0: v_h = v + (eps/2) g(x'), x = x' - eps v_h, v = v_h + (eps/2) g(x))
@@ -181,18 +217,40 @@ __global__ void k_kinetic(const float* v, float* K, float* ld, long long N, int 
   K[n] = acc;
   if (ld != nullptr) ld[n] = 0.f;
 }
-// accept probability (dynamics.py:302-309) + MH select (sampler.py:53-55)
+__global__ __launch_bounds__(256) void k_kinetic_staged(const float* v, float* K, float* ld, long long N, int d) {
+  extern __shared__ float rsm[];
+  const long long n0 = (long long)blockIdx.x * ROW_CPB;
+  stage_rows(rsm, v, d, d, n0, N);
+  __syncthreads();
+  const long long n = n0 + threadIdx.x;
+  if (threadIdx.x >= ROW_CPB || n >= N) return;
+  float acc = 0.f;
+  for (int k = 0; k < d; ++k) acc += 0.5f * rsm[threadIdx.x * d + k] * rsm[threadIdx.x * d + k];
+  K[n] = acc;
+  if (ld != nullptr) ld[n] = 0.f;
+}
+inline void launch_kinetic(hipStream_t s, const float* v, float* K, float* ld, long long N, int d) {
+  const size_t lds = sizeof(float) * ROW_CPB * (size_t)d;
+  if (lds <= 48 * 1024) hipLaunchKernelGGL(k_kinetic_staged, dim3((unsigned)((N + ROW_CPB - 1) / ROW_CPB)), dim3(256), lds, s, v, K, ld, N, d);
+  else hipLaunchKernelGGL(k_kinetic, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, v, K, ld, N, d);
+}
+// accept probability (dynamics.py:302-309) + MH select (sampler.py:53-55): one thread per ELEMENT of the state (every thread of a
+// chain forms the same p from the same five words; the select is a coalesced copy), dimension 0 writes the chain's outputs
 __global__ void k_finish(const double* U0, const float* K0, const double* U1, const float* K1, const float* ld,
                          const float* u, const float* x0, const float* x1, int ldx1, float* p_out, float* logjac_out,
                          float* x_next, long long N, int d) {
-  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * d) return;
+  const long long n = i / d;
+  const int k = (int)(i % d);
   const float p = accept_prob((float)((U0[n] - U1[n]) + ((double)K0[n] - (double)K1[n]) + (double)ld[n]));
-  if (p_out != nullptr) p_out[n] = p;
-  if (logjac_out != nullptr) logjac_out[n] = ld[n];
+  if (k == 0) {
+    if (p_out != nullptr) p_out[n] = p;
+    if (logjac_out != nullptr) logjac_out[n] = ld[n];
+  }
   if (x_next != nullptr) {
     const bool acc = (p - u[n]) >= 0.f;
-    for (int k = 0; k < d; ++k) x_next[n * d + k] = acc ? x1[n * ldx1 + k] : x0[n * d + k];
+    x_next[i] = acc ? x1[n * ldx1 + k] : x0[i];
   }
 }
 
@@ -295,7 +353,7 @@ int vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const floa
     g.Cp = ws.plg; g.cp_plane = no; g.ldcp = lo;
     if ((r1 = launch_gemm_planes<EPI_BCE>(g, s)) != L2HMC_OK) rc = rc ? rc : r1;                                                               // beta (sigmoid(logit) - aux) (planes)
     if (U != nullptr || Ud != nullptr)
-      hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles_planes(dec.n_out), z, ldz, d, U, Ud, N);
+      launch_vae_U(s, rowsum, 2 * bce_tiles_planes(dec.n_out), z, ldz, d, U, Ud, N);
     if (grad == nullptr) return rc;
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_out);
     g.Ap = ws.plg; g.ap_plane = no; g.ldap = lo; g.Bp = ws.pw3; g.bp_plane = prows(dec.n_h2) * lo; g.ldbp = lo;
@@ -315,7 +373,7 @@ int vae_energy(hipStream_t s, const L2hmcMlp3& dec, const float* aux, const floa
   g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = beta;
   launch_gemm<EPI_BCE>(g, s);                                     // lg := beta (sigmoid(logit) - aux)
   if (U != nullptr || Ud != nullptr)
-    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, bce_partials(N, dec.n_out), z, ldz, d, U, Ud, N);
+    launch_vae_U(s, rowsum, bce_partials(N, dec.n_out), z, ldz, d, U, Ud, N);
   if (grad == nullptr) return L2HMC_OK;
   // d a2 = dl W3^T (.) sigmoid(p2);  d a1 = d a2 W2^T (.) sigmoid(p1);  d z = d a1 W1^T + z
   g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);
@@ -548,7 +606,7 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
       transpose_into(s, nets[i]->Wq, H, d, wht[i] + 2LL * d * Hp, Hp, 0);
     }
   }
-  hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, vc, w + p.K0, ld, N, d);
+  launch_kinetic(s, vc, w + p.K0, ld, N, d);
   double *U0d = reinterpret_cast<double*>(w + p.U0), *U1d = reinterpret_cast<double*>(w + p.U1);
   // U (double, optional) and grad U at the current x: the decoder posterior (six GEMMs) or one of the built-in
   // targets (the fused kernels' own energy kernel on a contiguous copy of x)
@@ -657,10 +715,10 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
     if ((rc = energy_eval(last ? U1d : nullptr))) return rc;
     if ((rc = net_eval(vn, 1, xc, it, v_update(vh, L, vc, d, false)))) return rc;      // v'
   }
-  hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, vc, w + p.K1, (float*)nullptr, N, d);
+  launch_kinetic(s, vc, w + p.K1, (float*)nullptr, N, d);
   if (a->x_out) (void)hipMemcpy2DAsync(a->x_out, sizeof(float) * d, xc, sizeof(float) * L, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
   if (a->v_out) (void)hipMemcpyAsync(a->v_out, vc, sizeof(float) * N * d, hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(k_finish, dim3(nblk(N)), dim3(256), 0, s, U0d, w + p.K0, U1d, w + p.K1, ld, a->u, a->x,
+  hipLaunchKernelGGL(k_finish, dim3(nblk(N * d)), dim3(256), 0, s, U0d, w + p.K0, U1d, w + p.K1, ld, a->u, a->x,
                      xc, L, a->p_out, a->logjac_out, a->x_next, N, d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));

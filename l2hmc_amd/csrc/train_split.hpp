@@ -610,7 +610,7 @@ void vae_energy_keep(hipStream_t s, const L2hmcMlp3& dec, const float* aux, cons
     g.Cp = ws.plg; g.cp_plane = no; g.ldcp = lo;
     launch_gemm_planes<EPI_BCE>(g, s);
     if (Ud != nullptr)
-      hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, 2 * bce_tiles_planes(dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
+      launch_vae_U(s, rowsum, 2 * bce_tiles_planes(dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
     const long long npix_ = N * dec.n_out;
     hipLaunchKernelGGL(k_sigd, dim3(nblk(npix_)), dim3(256), 0, s, lg, aux, pt.rd, npix_);
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_out);
@@ -631,7 +631,7 @@ void vae_energy_keep(hipStream_t s, const L2hmcMlp3& dec, const float* aux, cons
   g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles(N, dec.n_out); g.beta = 1.f;
   launch_gemm<EPI_BCE>(g, s);
   if (Ud != nullptr)
-    hipLaunchKernelGGL(k_vae_U, dim3(nblk(N)), dim3(256), 0, s, rowsum, bce_partials(N, dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
+    launch_vae_U(s, rowsum, bce_partials(N, dec.n_out), z, ldz, d, (float*)nullptr, Ud, N);
   const long long npix = N * dec.n_out;
   hipLaunchKernelGGL(k_sigd, dim3(nblk(npix)), dim3(256), 0, s, lg, aux, pt.rd, npix);
   g = gemm_args(lg, dec.n_out, dec.W3, dec.n_out, ws.a2, dec.n_h2, N, dec.n_h2, dec.n_out);
@@ -968,7 +968,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   // ---- forward trajectory, everything kept ------------------------------------------------------------------------
   (void)hipMemcpy2DAsync(AB(1, 0), sizeof(float) * L, a->x, sizeof(float) * d, sizeof(float) * d, (size_t)N, hipMemcpyDeviceToDevice, s);
   (void)hipMemcpyAsync(VS(0), a->v, sizeof(float) * Nd, hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(k_kinetic, dim3(nblk(N)), dim3(256), 0, s, VS(0), w + f.K0, ld, N, d);
+  launch_kinetic(s, VS(0), w + f.K0, ld, N, d);
   if ((rc = energy_eval(AB(1, 0), 0, U0d))) return rc;
   for (int it = 0; it < T; ++it) {
     const bool last = it == T - 1;
