@@ -1169,8 +1169,12 @@ struct GemmTnArgs {
 };
 constexpr int TN_P = 68;
 
-template <bool V4>
+// VA / VB: what a row quad of A / B loads as -- 4: one dwordx4 (16-byte rows, column count a multiple of 4), 2: two dwordx2
+// (8-byte rows, even column count: the 3 d = 150 head cotangents), 1: guarded scalars.  Both >= 2: the branchless two-deep form.
+template <int VA, int VB>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
+  constexpr bool V4 = VA == 4 && VB == 4;                      // (the guarded loop's dwordx4 fast path)
+  constexpr bool DEEP = VA >= 2 && VB >= 2;
   __shared__ __attribute__((aligned(16))) float sA[2][16 * TN_P];
   __shared__ __attribute__((aligned(16))) float sB[2][16 * TN_P];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1210,14 +1214,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = splat(0.f);
   const long long nt = (r_end - r_begin + 15) / 16;
-  if (nt > 0) {
-    gload(r_begin);
-    sstore(0);
-  }
-  __syncthreads();
-  for (long long t = 0; t < nt; ++t) {
-    const int buf = (int)(t & 1);
-    if (t + 1 < nt) gload(r_begin + (t + 1) * 16);
+  // 16 x 16 blocks of this wave that lie wholly beyond the matrix (I, J = 200 on 64-wide tiles: 87 of 256 blocks) are skipped:
+  // wave-uniform, decided once
+  bool live[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) live[a][b] = i0 + wi + 16 * a < g.I && j0 + wj + 16 * b < g.J;
+  auto compute = [&](int buf) {
     float fa[2][4], fb[2][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -1231,9 +1235,73 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(fa[a][s], fb[b][s], acc[a][b]);
-    if (t + 1 < nt) sstore(buf ^ 1);
+        for (int b = 0; b < 2; ++b)
+          if (live[a][b]) acc[a][b] = MFMA16(fa[a][s], fb[b][s], acc[a][b]);
+  };
+  if constexpr (DEEP) {
+    // (round 5) no branch around a load -- rows / quads (pairs) beyond the matrix are clamped to element 0 and zeroed when they
+    // are stored -- and TWO row tiles in flight in registers (tile k in slot k & 1): with one, a 16-row tile's MFMAs (512 cycles
+    // per wave) are a fraction of the round trip that feeds the next.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f4 pa[2], pb[2];
+    bool oka[2][2], okb[2][2];                                 // [slot][low / high pair of the quad]
+    auto ld1 = [&](auto vc, const float* base, long long ld, long long r, int col, int ncol, f4& v, bool (&ok)[2]) {
+      constexpr int V = decltype(vc)::value;
+      ok[0] = r < r_end && col < ncol;
+      ok[1] = r < r_end && col + 2 < ncol;
+      if constexpr (V == 4) {
+        v = *reinterpret_cast<const f4*>(base + (ok[0] ? r * ld + col : 0));
+      } else {
+        const f2 lo = *reinterpret_cast<const f2*>(base + (ok[0] ? r * ld + col : 0));
+        const f2 hi = *reinterpret_cast<const f2*>(base + (ok[1] ? r * ld + col + 2 : 0));
+        v = f4{lo.x, lo.y, hi.x, hi.y};
+      }
+    };
+    auto gl = [&](auto sc, long long r0) {
+      constexpr int S = decltype(sc)::value;
+      ld1(std::integral_constant<int, VA>{}, g.A, g.lda, r0 + lr, i0 + lc, g.I, pa[S], oka[S]);
+      ld1(std::integral_constant<int, VB>{}, g.B, g.ldb, r0 + lr, j0 + lc, g.J, pb[S], okb[S]);
+    };
+    auto st = [&](auto sc, int buf) {
+      constexpr int S = decltype(sc)::value;
+      const f4 a = pa[S], b = pb[S];
+      *reinterpret_cast<f4*>(&sA[buf][lr * TN_P + lc]) = f4{oka[S][0] ? a.x : 0.f, oka[S][0] ? a.y : 0.f, oka[S][1] ? a.z : 0.f, oka[S][1] ? a.w : 0.f};
+      *reinterpret_cast<f4*>(&sB[buf][lr * TN_P + lc]) = f4{okb[S][0] ? b.x : 0.f, okb[S][0] ? b.y : 0.f, okb[S][1] ? b.z : 0.f, okb[S][1] ? b.w : 0.f};
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    if (nt > 0) {
+      gl(S0{}, r_begin);
+      st(S0{}, 0);
+      if (nt > 1) gl(S1{}, r_begin + 16);
+      if (nt > 2) gl(S0{}, r_begin + 32);
+    }
     __syncthreads();
+    for (long long t = 0; t < nt; t += 2) {
+      compute(0);                                              // tile t (even) from buffer 0
+      if (t + 1 < nt) st(S1{}, 1);                             // tile t + 1 waits in slot 1
+      if (t + 3 < nt) gl(S1{}, r_begin + (t + 3) * 16);
+      __syncthreads();
+      if (t + 1 < nt) {
+        compute(1);
+        if (t + 2 < nt) st(S0{}, 0);
+        if (t + 4 < nt) gl(S0{}, r_begin + (t + 4) * 16);
+        __syncthreads();
+      }
+    }
+  } else {
+    if (nt > 0) {
+      gload(r_begin);
+      sstore(0);
+    }
+    __syncthreads();
+    for (long long t = 0; t < nt; ++t) {
+      const int buf = (int)(t & 1);
+      if (t + 1 < nt) gload(r_begin + (t + 1) * 16);
+      compute(buf);
+      if (t + 1 < nt) sstore(buf ^ 1);
+      __syncthreads();
+    }
   }
   // lane holds D[i = i0 + wi + 16 a + 4 q + r][j = j0 + wj + 16 b + c]
   float* out = g.part + (long long)blockIdx.z * g.I * g.J;
@@ -1314,9 +1382,16 @@ inline void launch_gemm_tn(hipStream_t s, const float* A, int lda, const float* 
   int nc;
   tn_chunks(R, (long long)I * J, part_cap, nc, g.rows_per_chunk);
   const dim3 grid((unsigned)((J + 63) / 64), (unsigned)((I + 63) / 64), (unsigned)nc);
-  const bool v4 = lda % 4 == 0 && ldb % 4 == 0 && ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(B)) & 15) == 0;
-  if (v4) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, s, g);
+  auto width = [](const float* p, int ld, int cols) {          // widest load a row quad of this operand can take
+    if (ld % 4 == 0 && cols % 4 == 0 && (reinterpret_cast<size_t>(p) & 15) == 0) return 4;
+    if (ld % 2 == 0 && cols % 2 == 0 && (reinterpret_cast<size_t>(p) & 7) == 0) return 2;
+    return 1;
+  };
+  const int va = width(A, lda, I), vb = width(B, ldb, J);
+  if (va == 4 && vb == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, dim3(256), 0, s, g);
+  else if (va == 4 && vb == 2) hipLaunchKernelGGL((gemm_tn_kernel<4, 2>), grid, dim3(256), 0, s, g);
+  else if (va >= 2 && vb >= 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_tn_kernel<1, 1>), grid, dim3(256), 0, s, g);
   const long long n = (long long)I * J;
   hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nc, I, J, dst, ldd, accumulate, sc);
 }
