@@ -208,3 +208,22 @@ def test_exec_prologue_check_finds_the_defect_it_was_written_for():
         assert mod.check(f.name) == []
     finally:
         os.unlink(f.name)
+
+
+def test_aux_key_follows_the_storage_not_the_tensor_object():
+    """`Dynamics._aux_key` (what `L2hmcSplitArgs.reuse` bit 1 is decided by): every launch sees a fresh `detach()` view of the
+    caller's images -- object identity never matches (the round-2 key; the image branch was recomputed on every launch until
+    round 5) -- while (storage address, version counter, shape) identifies unchanged content and notices in-place writes,
+    through any view, and other storages."""
+    from l2hmc_amd.dynamics import Dynamics
+    a = torch.rand(8, 12)
+    v1, v2 = a.detach(), a.detach()
+    assert v1 is not v2 and Dynamics._aux_key(v1) == Dynamics._aux_key(v2)
+    k0 = Dynamics._aux_key(v1)
+    a[:, ::3] = 0.5                                   # in place, through the base tensor
+    assert Dynamics._aux_key(a.detach()) != k0
+    k1 = Dynamics._aux_key(a.detach())
+    v1.mul_(2.0)                                      # in place, through an old view
+    assert Dynamics._aux_key(a.detach()) != k1
+    assert Dynamics._aux_key(a.clone()) != Dynamics._aux_key(a.detach())          # same content, another storage
+    assert Dynamics._aux_key(a[:4].detach()) != Dynamics._aux_key(a.detach())     # same address, another shape
