@@ -1430,6 +1430,8 @@ int launch_gemm_shape(const GemmArgs& g, hipStream_t s) {
 // (all NBLK column blocks): a wave requests its whole A fragment of a chunk of 16 k-tiles up front (16 dwordx4 per lane in
 // flight, 8 waves per CU), streams the weight fragments from L2 one k-tile ahead, and the four partial sums meet in LDS in
 // wave order (fixed order: reproducible).  No staging of A in LDS -- every element is used by exactly one wave.
+// (Measured at 19.6 us per 8192 x 50 x 1024 product against a matrix-pipe floor of 8-9: weight fragments 1 / 3 / 7 k-tiles ahead,
+// 16 rows on four waves or 32 on eight, the weight rows at a stride that is not a power of two -- all within 2 us of each other.)
 // Contract: K % 256 == 0 (chunks of 4 k-tiles per wave; of 16 when K % 1024 == 0), lda / ldb % 4 == 0, 16-byte aligned A and B,
 // N <= 16 NBLK.
 template <int NBLK, int MB, int NW, int CH>
