@@ -1431,7 +1431,10 @@ int launch_gemm_shape(const GemmArgs& g, hipStream_t s) {
 // flight, 8 waves per CU), streams the weight fragments from L2 one k-tile ahead, and the four partial sums meet in LDS in
 // wave order (fixed order: reproducible).  No staging of A in LDS -- every element is used by exactly one wave.
 // (Measured at 19.6 us per 8192 x 50 x 1024 product against a matrix-pipe floor of 8-9: weight fragments 1 / 3 / 7 k-tiles ahead,
-// 16 rows on four waves or 32 on eight, the weight rows at a stride that is not a power of two -- all within 2 us of each other.)
+// 16 rows on four waves or 32 on eight, the weight rows at a stride that is not a power of two, chunks of 2 k-tiles requested one
+// chunk ahead instead of a wave's whole share up front -- all within 2 us of each other.  Phase stamps: a wave's k loop takes
+// 7400-10 000 cycles, its FIRST k-tile arrives after 10 000-12 000 (waves 0-3) or 24 000-25 000 (waves 4-7, which issue second on
+// their SIMD): 33.5 MB in 64-byte pieces, 16 rows x 4 KB apart per load, at 1.7 TB/s -- the access pattern, not the schedule.)
 // Contract: K % 256 == 0 (chunks of 4 k-tiles per wave; of 16 when K % 1024 == 0), lda / ldb % 4 == 0, 16-byte aligned A and B,
 // N <= 16 NBLK.
 template <int NBLK, int MB, int NW, int CH>
