@@ -213,13 +213,14 @@ def test_adam_after_the_all_reduce_forms_the_global_loss():
     assert abs(o[2] - (scale * A - B / scale) / cnt) < 1e-9 * abs(o[2])
 
 
-@pytest.mark.parametrize("N", [6144, 6200, 8192])
+@pytest.mark.parametrize("N", [6144, 6200, 8192, 8205])
 def test_config5_on_presplit_planes(N):
     """Config 5's widths with the decoder-sized products on pre-split bf16 planes (csrc/gemm_xl.hpp: 256 x 128 tiles, weights
     split once per call, activations by the epilogue that produces them -- same six bf16 products per block as the in-loop
     split, so the same fp32-level accuracy) at MORE than one tile per XCD slot: 6144 chains = 24 row tiles (the XCD-aware tile
     order engages from 16), 6200: the last row tile is partial (56 rows), its loads clamp to the last chain, and 8192: BASELINE
-    config 5's own chain count (32 row tiles, the shape bench.py times).  Positions
+    config 5's own chain count (32 row tiles, the shape bench.py times), 8205 (round 5): the 32-chain forms of the net kernels
+    and of the split-K product with a last workgroup of 13 chains.  Positions
     2e-4 relative, accept probability 1e-4 absolute against the float64 evaluation of the same map (the tolerances of the
     3072-chain test, tests/test_gpu_round3.py)."""
     from l2hmc_amd import _ffi, propose

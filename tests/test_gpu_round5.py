@@ -395,12 +395,13 @@ def test_training_on_presplit_planes_agrees_with_the_split_in_the_loop():
     assert np.abs(a[2] - c[2]).max() < 1e-3 * scale
 
 
-@pytest.mark.parametrize("N", [3072, 8192])
+@pytest.mark.parametrize("N", [3072, 8192, 8205])
 def test_fused_net_launches_of_the_trainer_agree_with_the_three_products(N):
     """Round 5: the GEMM-engine trainer evaluates an S/T/Q net -- and its reverse -- in ONE launch each (`net_eval_kernel` with both
     hidden activations kept, `net_bwd_kernel`; csrc/gemm_f32.hpp) instead of three 64 x 64-tile products each.  Same contraction
     order (k ascending, four k per MFMA), same epilogues: the two forms are expected to agree to rounding, and are held to a
-    hundredth of the gates of the suite.  3072 chains = 16 chains per workgroup, 8192 = 32 (the form config 5's bench runs)."""
+    hundredth of the gates of the suite.  3072 chains = 16 chains per workgroup, 8192 = 32 (the form config 5's bench runs), 8205 = the same with a last workgroup of 13
+    chains (rows beyond the batch: clamped loads, no stores)."""
     import torch
     from l2hmc_amd.training import Trainer
     from tests.helpers import synthetic_vae_case
