@@ -67,6 +67,10 @@ def test_struct_layout_matches_header():
     assert _ffi.L2hmcTrajectoryArgs.ais_alpha.offset == ctypes.sizeof(_ffi.L2hmcTrajectoryArgs) - 8
     assert _ffi.L2hmcTrajectoryArgs.ais_beta.offset == _ffi.L2hmcTrajectoryArgs.chain_offset.offset + 8
     assert _ffi.L2hmcTrajectoryArgs.rng_seed.offset == _ffi.L2hmcTrajectoryArgs.x_hist.offset + 16
+    # `net_mode` (round 5) took the padding behind `gemm_mode`: the callbacks that follow keep their offsets
+    T = _ffi.L2hmcTrainSplitArgs
+    assert T.net_mode.offset == T.gemm_mode.offset + 4 and T.energy_cb.offset == T.gemm_mode.offset + 8
+    assert ctypes.sizeof(T) == 312
 
 
 def test_struct_sizes_are_checked_against_the_library():
