@@ -480,3 +480,49 @@ def test_split_k_latent_gradient_on_other_shapes(latent, dec_h, N):
     print("d %d, decoder %d, %d chains: mean p %.3f  max rel err x %.2e  |p - p64| %.2e" % (latent, dec_h, N, float(tpx.mean()), ex, ep))
     assert ex < 2e-4 and ep < 1e-4, (ex, ep)
     check_x_next(to_np(outs[0]), g["x"], tLx, tpx, u, 5e-4)
+
+
+def test_pipelined_net_kernels_on_a_neighbouring_shape():
+    """The software-pipelined instantiations `net_eval_kernel<2, 8, 7, 13>` / `net_bwd_kernel<2, 8, 10, 13>` are picked by the PADDED
+    widths (ceil16(2 d) = 112, ceil16(H) = 208, ceil16(3 d) = 160), not by config 5's own d = 50, H = 200: d = 52, H = 204 lands on
+    the same kernels with other pad columns (3 d = 156, four live columns in the last hidden block).  8192 chains (32 per
+    workgroup); the sampler against the float64 evaluation of the same map at the suite's gates, the trainer's fused launches
+    against its three-product form."""
+    import torch
+    from l2hmc_amd import propose
+    from l2hmc_amd.training import Trainer
+    from tests.helpers import check_x_next, synthetic_vae_case
+    N, d = 8192, 52
+    g = synthetic_vae_case(latent=d, H=204, dec_h=256, n_pix=96, enc_h=64, N=N, seed=8)
+    dyn = hip_dynamics(g)
+    rng = np.random.RandomState(9)
+    direction = rng.randint(0, 2, size=N).astype(np.uint8)
+    u = rng.rand(N).astype(np.float32)
+    Lx, _, px, outs = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(g["v"]), u=to_dev(u),
+                              aux=to_dev(g["aux"]))
+    od64 = oracle_dynamics(g, np.float64)
+    with np.errstate(all="ignore"):
+        tLx, _, tpx, _ = O.propose(g["x"].astype(np.float64), od64, g["v"].astype(np.float64), g["v"].astype(np.float64),
+                                   direction, u.astype(np.float64), both_directions=False)
+    ex, ep = rel_err(to_np(Lx), tLx), abs_err(to_np(px), tpx)
+    print("d 52, H 204, 8192 chains: mean p %.3f  max rel err x %.2e  |p - p64| %.2e" % (float(tpx.mean()), ex, ep))
+    assert ex < 2e-4 and ep < 1e-4, (ex, ep)
+    check_x_next(to_np(outs[0]), g["x"], tLx, tpx, u, 5e-4)
+    dr = {"v": rng.randn(N, d).astype(np.float32), "dir": direction, "u": u}
+    ls = np.full((N, d), -0.5, np.float32)
+    res = {}
+    for mode in (0, 1):
+        dyn = hip_dynamics(g)
+        dyn.eps_override = None
+        with torch.no_grad():
+            dyn.alpha.fill_(float(np.log(g["eps"])))
+        dyn.net_mode = mode
+        tr = Trainer(dyn, decay_steps=0)
+        loss, x_T, pxt = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(ls), MH=1, draws=[dr])
+        res[mode] = (float(loss), to_np(pxt).copy(), to_np(tr.flat).copy(), to_np(x_T).copy())
+    a, b = res[0], res[1]
+    scale = float(np.abs(b[2]).max())
+    print("trainer, fused vs three products: |dp| %.1e  |dgrad| / scale %.1e" % (np.abs(a[1] - b[1]).max(), np.abs(a[2] - b[2]).max() / scale))
+    assert abs(a[0] - b[0]) < 1e-6 * max(1.0, abs(b[0]))
+    assert np.abs(a[1] - b[1]).max() < 1e-6 and rel_err(a[3], b[3]) < 2e-6
+    assert np.abs(a[2] - b[2]).max() < 2e-6 * scale
