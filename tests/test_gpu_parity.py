@@ -11,8 +11,9 @@ import numpy as np
 import pytest
 
 from oracle import l2hmc_oracle as O
-from tests.helpers import (CASES, abs_err, aux_of, check_x_next, hip_dynamics, load, oracle_dynamics, rel_err,
-                           stiff_tol, to_dev, to_np)
+from tests.helpers import (CASES, CONDITIONED_TRAIN_CASES, abs_err, aux_of, check_grads_per_tensor, check_x_next,
+                           fixture_grads, hip_dynamics, load, net_grads, oracle_dynamics, rel_err, stiff_tol, to_dev, to_np,
+                           train_yardstick)
 
 pytestmark = pytest.mark.gpu
 
@@ -447,18 +448,13 @@ def test_training_gradient_matches_reference_graph(case, variant):
     stiff = "_ne" in case
     assert abs(float(loss) - float(g["loss"])) < (2e-4 if stiff else 1e-4) * max(1.0, abs(float(g["loss"])))
     assert rel_err(to_np(Lx), g["Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["px"]) < (1e-3 if stiff else P_TOL)
-    scale = max(float(np.abs(g["grad." + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
-    gtol = 2e-3 if stiff else 2e-4
-    worst = 0.0
-    for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
-        for k in O.NET_KEYS:
-            ref = g["grad.%s.%s" % (n, k)]
-            got = to_np(w[k].grad).reshape(ref.shape)
-            worst = max(worst, float(np.abs(got - ref).max()))
-            assert np.abs(got - ref).max() < gtol * scale, (case, n, k)
-    ga = float(dyn.alpha.grad)
-    print("%s: loss %.6e  max |dgrad| %.2e (scale %.2e)  alpha %.5e vs %.5e" % (case, float(loss), worst, scale, ga, float(g["grad.alpha"])))
-    assert abs(ga - float(g["grad.alpha"])) < gtol * max(scale, abs(float(g["grad.alpha"])))
+    # every tensor against its own size (round 6; before: against the largest entry of ANY tensor, which left vnet.b1/b2/b3/W3 --
+    # 3e-4 of that scale in train_icg50 -- unchecked): 2e-4 of the tensor's max + 1e-6 of the scale; the ill-conditioned
+    # fixtures at 4x the float32 oracle's own per-tensor distance (tests/helpers.py `train_yardstick`)
+    yard = train_yardstick(case) if case in CONDITIONED_TRAIN_CASES else None
+    worst = check_grads_per_tensor("%s v%d" % (case, variant), net_grads(dyn), fixture_grads(g), yard=yard)
+    print("%s: loss %.6e  worst tensor %s at %.2f of its gate  alpha %.5e vs %.5e"
+          % (case, float(loss), worst[1], worst[0], float(dyn.alpha.grad), float(g["grad.alpha"])))
 
 
 def test_sharded_training_gradient_sums_to_full_batch():

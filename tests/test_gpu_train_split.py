@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 from oracle import l2hmc_oracle as O
-from tests.helpers import abs_err, hip_dynamics, load, rel_err, to_dev, to_np
+from tests.helpers import (CONDITIONED_TRAIN_CASES, abs_err, check_grads_per_tensor, fixture_grads, hip_dynamics, load, net_grads,
+                           rel_err, to_dev, to_np, train_yardstick)
 
 pytestmark = pytest.mark.gpu
 TRAJ_TOL = 2e-4     # T steps, fp32 on the GPU vs the float32 reference graph
@@ -23,18 +24,15 @@ def _trainer(g, force_split=False):
     return dyn, tr
 
 
-def _check_net_grads(g, dyn, pre="grad.", tol=2e-4):
-    scale = max(float(np.abs(g[pre + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
-    worst = 0.0
-    for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
-        for k in O.NET_KEYS:
-            ref = g[pre + "%s.%s" % (n, k)]
-            got = to_np(w[k].grad).reshape(ref.shape)
-            worst = max(worst, float(np.abs(got - ref).max()))
-            assert np.abs(got - ref).max() < tol * scale, (n, k, float(np.abs(got - ref).max()), scale)
-    ga = float(dyn.alpha.grad)
-    assert abs(ga - float(g[pre + "alpha"])) < tol * max(scale, abs(float(g[pre + "alpha"]))), (ga, float(g[pre + "alpha"]))
-    return worst, scale
+def _check_net_grads(g, dyn, pre="grad.", tol=2e-4, yard=None, label=""):
+    """every sampler variable -- XNet, VNet, the shared image branch where the fixture has it, alpha -- against ITS OWN size
+    (tests/helpers.py `check_grads_per_tensor`: tol of the tensor's max + 1e-6 of the scale)"""
+    ref = fixture_grads(g, pre)
+    extra = None
+    if any(k.startswith("enc.") for k in ref):
+        enc = dyn._xw["aux_encoder"]
+        extra = {"enc." + k: enc[k] for k in ("W1", "b1", "W2", "b2", "W3", "b3")}
+    return check_grads_per_tensor(label, net_grads(dyn, extra), ref, rel=tol, yard=yard)
 
 
 @pytest.mark.parametrize("case,force", [("train_icg50_h32", False), ("train_tilted8_h24", False), ("train_rough6_h20", False),
@@ -56,8 +54,8 @@ def test_gemm_engine_training_gradient_matches_reference_graph(case, force):
     stiff = "_ne" in case      # the default Rough Well at eta = 0.05: gates as in tests/test_gpu_parity.py's training test
     assert abs(float(loss) - float(g["loss"])) < (2e-4 if stiff else 1e-4) * max(1.0, abs(float(g["loss"])))
     assert rel_err(to_np(Lx), g["Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["px"]) < (1e-3 if stiff else P_TOL)
-    worst, scale = _check_net_grads(g, dyn, tol=2e-3 if stiff else 2e-4)
-    print("%s: loss %.6e  max |dgrad| %.2e (scale %.2e)" % (case, float(loss), worst, scale))
+    worst = _check_net_grads(g, dyn, yard=train_yardstick(case) if case in CONDITIONED_TRAIN_CASES else None, label=case)
+    print("%s: loss %.6e  worst tensor %s at %.2f of its gate" % (case, float(loss), worst[1], worst[0]))
 
 
 def _vae_draws(g):
@@ -73,13 +71,8 @@ def test_vae_sampler_gradient_matches_reference_graph():
     loss, x_T, px = tr.sampler_loss_and_grad(to_dev(g["x"]), to_dev(g["aux"]), to_dev(g["log_sigma"]), MH=1, draws=[_vae_draws(g)])
     assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
     assert abs_err(to_np(px), g["px"]) < P_TOL and rel_err(to_np(x_T), g["x_next"]) < TRAJ_TOL
-    worst, scale = _check_net_grads(g, dyn)
-    enc = dyn._xw["aux_encoder"]
-    for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
-        ref = g["grad.enc." + k]
-        got = to_np(enc[k].grad).reshape(ref.shape)
-        assert np.abs(got - ref).max() < 2e-4 * max(float(np.abs(ref).max()), 1e-2 * scale), ("enc", k)
-    print("train_vae_small: loss %.6e  max |dgrad| %.2e (scale %.2e)" % (float(loss), worst, scale))
+    worst = _check_net_grads(g, dyn, label="train_vae_small")
+    print("train_vae_small: loss %.6e  worst tensor %s at %.2f of its gate" % (float(loss), worst[1], worst[0]))
 
 
 def test_vae_sampler_cotangent_in_and_start_point_gradient_out():
@@ -150,20 +143,8 @@ def test_vae_sampler_optional_terms_match_reference_graph(case):
                                              energy_scale=float(g["energy_scale"]), random_lf_composition=R)
     assert abs(float(loss) - float(g["loss"])) < 5e-4 * max(1.0, abs(float(g["loss"]))), (float(loss), float(g["loss"]))
     assert abs_err(to_np(px), g["px"]) < P_TOL and rel_err(to_np(x_T), g["x_next"]) < 3 * TRAJ_TOL
-    keys = [k[5:] for k in g if k.startswith("grad.") and k not in ("grad.alpha", "grad.x0")]
-    scale = max(float(np.abs(g["grad." + k]).max()) for k in keys)
-    worst = 0.0
-    enc = dyn._xw["aux_encoder"]
-    for k in keys:
-        net, leaf = k.split(".")
-        t = (dyn._xw if net == "xnet" else dyn._vw if net == "vnet" else enc)[leaf]
-        ref = g["grad." + k]
-        err = float(np.abs(to_np(t.grad).reshape(ref.shape) - ref).max())
-        worst = max(worst, err)
-        assert err < 5e-4 * scale, (k, err, scale)
-    ga = float(dyn.alpha.grad)
-    assert abs(ga - float(g["grad.alpha"])) < 5e-4 * max(scale, abs(float(g["grad.alpha"])))
-    print("%s: loss %.6e (ref %.6e)  max |dgrad| %.2e (scale %.2e)" % (case, float(loss), float(g["loss"]), worst, scale))
+    worst = _check_net_grads(g, dyn, tol=5e-4, label=case)
+    print("%s: loss %.6e (ref %.6e)  worst tensor %s at %.2f of its gate" % (case, float(loss), float(g["loss"]), worst[1], worst[0]))
 
 
 @pytest.mark.parametrize("stop", [False, True])
@@ -231,13 +212,8 @@ def test_vae_sampler_gradient_at_config5_widths_matches_the_autograd_oracle():
     assert abs(float(loss) - o["loss"]) < 2e-4 * max(1.0, abs(o["loss"]))
     assert abs_err(to_np(px), o["px"]) < P_TOL
     gg = {k: v for k, v in o.items() if k.startswith("grad.")}
-    worst, scale = _check_net_grads(gg, dyn, tol=5e-4)
-    enc = dyn._xw["aux_encoder"]
-    for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
-        ref = o["grad.enc." + k]
-        got = to_np(enc[k].grad).reshape(ref.shape)
-        assert np.abs(got - ref).max() < 5e-4 * max(float(np.abs(ref).max()), 1e-2 * scale), ("enc", k)
-    print("config-5 widths: loss %.6e  max |dgrad| %.2e (scale %.2e), mean p %.3f" % (float(loss), worst, scale, float(px.mean())))
+    worst = _check_net_grads(gg, dyn, tol=5e-4, label="config-5 widths")
+    print("config-5 widths: loss %.6e  worst tensor %s at %.2f of its gate, mean p %.3f" % (float(loss), worst[1], worst[0], float(px.mean())))
 
 
 def test_short_vae_sampler_training_run_improves_the_objective():

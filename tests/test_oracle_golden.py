@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import l2hmc_oracle as O
-from tests.helpers import CASES, CHAINOP_CASES, abs_err, check_x_next, load, oracle_dynamics, rel_err
+from tests.helpers import CASES, CHAINOP_CASES, abs_err, check_x_next, is_stiff, load, oracle_dynamics, rel_err, stiff_bracket
 
 STEP_TOL = 3e-5     # one generalised leapfrog step (funnel's |grad| ~ 5e3 amplifies: 1.3e-5 seen)
 TRAJ_TOL = 1e-4     # T steps
@@ -405,3 +405,19 @@ def test_bf16x3_six_products_are_fp32_accurate_three_are_not():
     e32 = np.abs((A @ W.T).astype(np.float64) - ref).max()
     print("K = 1024: max |err| vs float64: six products %.2e, three %.2e, fp32 GEMM %.2e (|C| <= %.2f)" % (e6, e3, e32, np.abs(ref).max()))
     assert e6 < 4e-6 and e6 < 3 * e32 + 1e-6 and e3 > 5 * e6
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if is_stiff(load(c))])
+def test_stiff_fixtures_sit_in_the_float64_bracket(case):
+    """The yardstick of tests/test_gpu_round6.py's bracket, checked on the reference's own float32 run: every stored output of a
+    STIFF fixture lies within 3x the float32 numpy oracle's distance from the same map evaluated in float64 with the
+    reference's float32 constants (`truth_dynamics`), + the suite's base tolerance.  Measured ratios 0.2 ... 2.2: the float64
+    evaluation is the truth both float32 runs scatter around, and a pure-float64 Rough Well (divisor 1e-4 instead of
+    float32(1e-4)) is not -- with that divisor the reference's own run would sit 10 ... 100x outside."""
+    g = load(case)
+    truth, e32 = stiff_bracket(case)
+    for key in truth:
+        prob = key.endswith((".p", ".px"))
+        base = P_TOL if prob else (STEP_TOL if "step" in key else TRAJ_TOL)
+        e = (abs_err if prob else rel_err)(g[key], truth[key])
+        assert e <= 3.0 * e32[key] + base, (case, key, e, e32[key])
