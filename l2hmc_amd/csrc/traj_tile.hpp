@@ -12,6 +12,7 @@
 // and every fragment is fetched from LDS where it is used.  Same algorithm and sampler loop as traj_kernel
 // (utils/dynamics.py:115-309, utils/sampler.py:28-55).
 #pragma once
+#include <type_traits>
 #include "traj_fast.hpp"
 
 namespace l2hmc {
@@ -274,16 +275,24 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
   };
   // one net evaluation's heads over the DT slices: body(t, aS, T', EQ') consumes slice t (the half-update and the layer-1
   // contribution of the next evaluation)
-  auto net_heads = [&](const float* fw, const float* fc, int dofs, const HidT& h, auto&& body) {
+  // L2HMC_TILE_XNET_SLICES = n < DT (TIMING-ONLY experiment of round 6, profiles/r06_masked_heads.txt; results are wrong): the two
+  // XNet evaluations of a step run their heads, transcendental chains, half-updates and layer-1 contributions on the first n
+  // dimension slices only -- what a form that packs the dimensions a sub-update really moves (dynamics.py:127-145: update 1 the
+  // 1 - m ones, update 2 the m ones) into n slices could save AT MOST, with the gather / scatter it needs priced at zero.
+#ifndef L2HMC_TILE_XNET_SLICES
+#define L2HMC_TILE_XNET_SLICES DT
+#endif
+  auto net_heads = [&](const float* fw, const float* fc, int dofs, const HidT& h, auto&& body, auto ns_tag) {
+    constexpr int NS = decltype(ns_tag)::value;
 #ifndef L2HMC_TILE_NO_PREFETCH
     HeadF cur = heads_load(fw, 0);
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
+    for (int t = 0; t < NS; ++t) {
       f4 zs, zq, zt, aS, Tt, EQ;
       // (the slice's constants: requested in front of its MFMAs, needed behind them)
       const f4 cS = lds4(fc + dofs + 16 * t + 4 * q), cQ = lds4(fc + 2 * DPp + 16 * t + 4 * q), bQ = lds4(fc + 3 * DPp + 16 * t + 4 * q);
       heads_mfma(cur, h, zs, zq, zt);
-      if (t + 1 < DT) cur = heads_load(fw, t + 1);
+      if (t + 1 < NS) cur = heads_load(fw, t + 1);
       asm volatile("" ::: "memory");
       const bool two = t == DT - 1 && half_last;
       heads_chain(cS, cQ, bQ, zs, zq, zt, aS, Tt, EQ, two);
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
     }
 #else
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
+    for (int t = 0; t < NS; ++t) {
       f4 zs, zq, zt, aS, Tt, EQ;
       const f4 cS = lds4(fc + dofs + 16 * t + 4 * q), cQ = lds4(fc + 2 * DPp + 16 * t + 4 * q), bQ = lds4(fc + 3 * DPp + 16 * t + 4 * q);
       const HeadF cur = heads_load(fw, t);
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
 #endif
   };
 
+  constexpr int XS = (L2HMC_TILE_XNET_SLICES) < DT ? (L2HMC_TILE_XNET_SLICES) : DT;
   f4 x[DT], v[DT], g[DT];
   load_state<DT, 1>(A.x, A, chain, live, 0, q, x);
   const bool need_p = A.p_out != nullptr || A.x_next != nullptr || A.u != nullptr || (A.rng_flags & L2HMC_RNG_U) != 0;
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
         vh[t] = ES * (nf * tr + v[t]) + ff * tr;
         pa = l1dot(0, 0, t, vh[t], pa);
         pq = l1dot(0, 1, t, k1[t] * x[t], pq);
-      });
+      }, std::integral_constant<int, DT>());
       // ---- first masked position update (:131-137 / :176-182) + the layer-1 sum of (1 - k1) y
       asm volatile("" ::: "memory");
       h = hidden_b(fwx, pa + pq + tbx);
@@ -400,7 +410,9 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
         const f4 tr = up * (EQ * vh[t] + Tt);
         y[t] = ES * (nf * tr + x[t]) + ff * tr;
         pq = l1dot(0, 1, t, up * y[t], pq);
-      });
+      }, std::integral_constant<int, XS>());
+#pragma unroll
+      for (int t = XS; t < DT; ++t) y[t] = x[t];          // (timing experiment only: XS == DT in the product)
       // ---- second masked position update (:139-145 / :184-190), grad U and VNet's layer-1 sum at the new position
       asm volatile("" ::: "memory");
       h = hidden_b(fwx, pa + pq + tbx);
@@ -422,7 +434,14 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
         g[t] = grad_t(x[t], t);
         pv = l1dot(1, 0, t, x[t], pv);
         if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = l1dot(1, 1, t, g[t], pv);
-      });
+      }, std::integral_constant<int, XS>());
+#pragma unroll
+      for (int t = XS; t < DT; ++t) {                      // (timing experiment only)
+        x[t] = y[t];
+        g[t] = grad_t(x[t], t);
+        pv = l1dot(1, 0, t, x[t], pv);
+        if (EK != L2HMC_ENERGY_GAUSS_DIAG) pv = l1dot(1, 1, t, g[t], pv);
+      }
       // ---- momentum half-update #2  (:147-153 / :192-199)
       asm volatile("" ::: "memory");
       h = hidden_b(fwv, pv + tbv);
@@ -437,7 +456,7 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
         ldv += aS;
         const f4 tr = Tt - EQ * g[t];
         v[t] = ES * (nf * tr + vh[t]) + ff * tr;
-      });
+      }, std::integral_constant<int, DT>());
     }
     const bool last = m == A.M - 1;
     if (last) {

@@ -212,9 +212,15 @@ class Dynamics(object):
         """[(name, tensor)] with the reference's variable names."""
         if self.hmc:
             return []
-        if self._user_nets:          # arbitrary callables: whatever of them exposes the layer kit's `parameters()`
-            return [('alpha', self.alpha)] + [kv for net in (self.XNet, self.VNet)
-                                              for kv in (net.parameters() if hasattr(net, 'parameters') else [])]
+        if self._user_nets:          # arbitrary callables: the layer kit's `parameters()` ([(name, tensor)]), or a torch
+            out = [('alpha', self.alpha)]          # Module's named_parameters() under the net's scope; anything else: nothing
+            for scope, net in (('XNet', self.XNet), ('VNet', self.VNet)):
+                if isinstance(net, torch.nn.Module):
+                    out += [('%s/%s' % (scope, k), v) for k, v in net.named_parameters()]
+                elif hasattr(net, 'parameters'):
+                    out += [kv for kv in net.parameters()
+                            if isinstance(kv, tuple) and len(kv) == 2 and isinstance(kv[0], str) and torch.is_tensor(kv[1])]
+            return out
         return [('alpha', self.alpha)] + self.XNet.parameters() + self.VNet.parameters()
 
     def state_dict(self):
@@ -360,6 +366,7 @@ class Dynamics(object):
             wsn, basen, Tn = self._split_ws, self._split_ws.data_ptr(), self.T
             fwd_mask = (direction != 0) if direction is not None else None
 
+            @torch.no_grad()      # (a net whose parameters require grad must not hang a CopySlices graph on the persistent workspace)
             def net_cb(_user, net, abp, ldab, n, dd, it, _dirp, dall, outp, _stream):
                 try:
                     ab = wsn.as_strided((n, 2 * dd), (ldab, 1), (abp - basen) // 4)

@@ -148,11 +148,15 @@ class Trainer(object):
     def load_state_dict(self, sd):
         if sd["theta"].numel() != self.theta.numel():
             raise ValueError("checkpoint has %d parameters, this sampler %d" % (sd["theta"].numel(), self.theta.numel()))
-        if sd.get("rng_stream", "philox4x32-10/libm-normals") != RNG_STREAM:
+        # a checkpoint that STATES its stream (round 5 on) or an ABI <= 3 (libm normals) is compared; one with neither key
+        # (rounds 1-4: ABI 4 already drew the hardware normals without saying so) is of unknown stream -- no warning
+        stream = sd.get("rng_stream")
+        if stream is None and "abi" in sd and int(sd["abi"]) <= 3:
+            stream = "philox4x32-10/libm-normals"
+        if stream is not None and stream != RNG_STREAM:
             import warnings
             warnings.warn("checkpoint was written on random stream %r, this library draws %r: the run continues, but not bit "
-                          "for bit (rebuild with -DL2HMC_LIBM_NORMALS for the old normals)"
-                          % (sd.get("rng_stream", "philox4x32-10/libm-normals"), RNG_STREAM))
+                          "for bit (rebuild with -DL2HMC_LIBM_NORMALS for the old normals)" % (stream, RNG_STREAM))
         self.dyn.mask = sd["dynamics"]["mask"]
         with torch.no_grad():
             self.theta.copy_(sd["theta"].to(self.theta.device))       # the net tensors and alpha are views of theta
@@ -662,6 +666,7 @@ class SplitTrainer(Trainer):
         uu = io["u"][0] if u is None else as_device_f32(u, dyn.device)
         _ffi.check(L.l2hmc_mh_select(x.data_ptr(), io["Lx"].data_ptr(), io["p"].data_ptr(), uu.data_ptr(), N, d,
                                      x_next.data_ptr(), s))
+        self._raise_if_stale()
         return loss, io["p"][:N].clone(), x_next, lr
 
     # ---- the VAE experiment's sampler objective (mnist_vae.py:185-226) ---------------------------------------------------
@@ -814,10 +819,13 @@ class SplitTrainer(Trainer):
             cot = through + cot * (1.0 - acc)
         if world > 1:
             terms, cnt = self._allreduce_flat(terms, N)               # the ONE collective: [gradient | loss sums | count]
+            # (the other ranks learn of a changed chain count from this reduced count, one step late: `_check_reduced_count`)
+            self._note_reduced_count(self._flat_ext[self.n_grad + 4:self.n_grad + 6], n_total, hi_scale=4096.0)
             loss = (terms[0] + es * terms[1]) / (cnt * MH)
         else:
             loss = (terms[0] + es * terms[1]) * inv
         self._publish_grads()
+        self._raise_if_stale()                                        # this rank's own count changed: raise now that the collective is behind us
         return loss, x, p_last
 
     def sampler_step(self, latent_q, aux, log_sigma, MH=5, stop_gradient=False, energy_scale=0.0, random_lf_composition=0):

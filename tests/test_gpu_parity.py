@@ -13,7 +13,7 @@ import pytest
 from oracle import l2hmc_oracle as O
 from tests.helpers import (CASES, CONDITIONED_TRAIN_CASES, abs_err, aux_of, check_grads_per_tensor, check_x_next,
                            fixture_grads, hip_dynamics, load, net_grads, oracle_dynamics, rel_err, stiff_tol, to_dev, to_np,
-                           train_yardstick)
+                           train_bracket, train_yardstick)
 
 pytestmark = pytest.mark.gpu
 
@@ -453,6 +453,10 @@ def test_training_gradient_matches_reference_graph(case, variant):
     # fixtures at 4x the float32 oracle's own per-tensor distance (tests/helpers.py `train_yardstick`)
     yard = train_yardstick(case) if case in CONDITIONED_TRAIN_CASES else None
     worst = check_grads_per_tensor("%s v%d" % (case, variant), net_grads(dyn), fixture_grads(g), yard=yard)
+    if yard is not None:       # ... and bracketed by the float64 evaluation: at most 3x as far from it as the float32 CPU runs
+        truth, e = train_bracket(case)
+        wb = check_grads_per_tensor("%s v%d vs float64" % (case, variant), net_grads(dyn), truth, yard=e, yard_factor=3.0)
+        print("%s: float64 bracket, worst tensor %s at %.2f of its gate" % (case, wb[1], wb[0]))
     print("%s: loss %.6e  worst tensor %s at %.2f of its gate  alpha %.5e vs %.5e"
           % (case, float(loss), worst[1], worst[0], float(dyn.alpha.grad), float(g["grad.alpha"])))
 

@@ -5,7 +5,7 @@ import pytest
 
 from oracle import l2hmc_oracle as O
 from tests.helpers import (CONDITIONED_TRAIN_CASES, abs_err, check_grads_per_tensor, fixture_grads, hip_dynamics, load, net_grads,
-                           rel_err, to_dev, to_np, train_yardstick)
+                           rel_err, to_dev, to_np, train_bracket, train_yardstick)
 
 pytestmark = pytest.mark.gpu
 TRAJ_TOL = 2e-4     # T steps, fp32 on the GPU vs the float32 reference graph
@@ -55,6 +55,9 @@ def test_gemm_engine_training_gradient_matches_reference_graph(case, force):
     assert abs(float(loss) - float(g["loss"])) < (2e-4 if stiff else 1e-4) * max(1.0, abs(float(g["loss"])))
     assert rel_err(to_np(Lx), g["Lx"]) < TRAJ_TOL and abs_err(to_np(px), g["px"]) < (1e-3 if stiff else P_TOL)
     worst = _check_net_grads(g, dyn, yard=train_yardstick(case) if case in CONDITIONED_TRAIN_CASES else None, label=case)
+    if case in CONDITIONED_TRAIN_CASES:        # bracketed by the float64 evaluation (tests/helpers.py `train_bracket`)
+        truth, e = train_bracket(case)
+        check_grads_per_tensor(case + " vs float64", net_grads(dyn), truth, yard=e, yard_factor=3.0)
     print("%s: loss %.6e  worst tensor %s at %.2f of its gate" % (case, float(loss), worst[1], worst[0]))
 
 

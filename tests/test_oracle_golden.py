@@ -253,16 +253,18 @@ def test_training_gradient_oracle_matches_reference_graph(case):
     stiff = case.startswith("train_rough") and "_ne" in case
     assert abs(loss - float(g["loss"])) < (2e-4 if stiff else 2e-5) * max(1.0, abs(float(g["loss"])))
     assert rel_err(out["Lx"], g["Lx"]) < TRAJ_TOL and abs_err(out["px"], g["px"]) < (1e-3 if stiff else P_TOL)
-    scale = max(float(np.abs(g["grad." + n + "." + k]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
-    # (the fixtures are float32 outputs; on the ill-conditioned d = 50 target with 32-wide nets the reference graph's own
-    #  rounding is 8e-5 of the gradient scale against this float64 restatement)
-    tol = 2e-3 if stiff else (2e-4 if case == "train_icg50_h32" else 2e-5)
-    for n in ("xnet", "vnet"):
-        for k in O.NET_KEYS:
-            ref = g["grad.%s.%s" % (n, k)]
-            got = np.asarray(out[n + "." + k]).reshape(ref.shape)
-            assert np.abs(got - ref).max() < tol * scale, (case, n, k)
-    assert abs(out["alpha"] - float(g["grad.alpha"])) < tol * max(scale, abs(float(g["grad.alpha"])))
+    # per tensor (round 6: before, every tensor was gated against the largest entry of ANY tensor): 2e-4 of the tensor's own max
+    # + 1e-6 of the scale -- measured <= 3.3e-5 (float64) / 5.7e-5 (float32 restatement) on the well-conditioned fixtures; the
+    # ill-conditioned ones (the default Rough Well at eta = 0.05; the d = 50 Gaussian under 32-wide nets, where the reference
+    # graph's own float32 rounding is 1e-4 of a tensor) at 4x `train_yardstick`
+    from tests.helpers import CONDITIONED_TRAIN_CASES, check_grads_per_tensor, fixture_grads, train_yardstick
+    yard = train_yardstick(case) if case in CONDITIONED_TRAIN_CASES else None
+    got = {k: out[k] for k in out if k.startswith(("xnet.", "vnet.")) or k == "alpha"}
+    check_grads_per_tensor(case + " float64 oracle", got, fixture_grads(g), yard=yard)
+    with np.errstate(all="ignore"):
+        _, out32 = TO.training_loss_and_grad(g, np.float32)
+    got = {k: out32[k] for k in out32 if k.startswith(("xnet.", "vnet.")) or k == "alpha"}
+    check_grads_per_tensor(case + " float32 oracle", got, fixture_grads(g), yard=yard)
 
 
 def test_vae_sampler_objective_oracle_matches_reference_graph():

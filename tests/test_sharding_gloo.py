@@ -187,12 +187,9 @@ def _train_worker(rank, world, port, out):
         draws = {"z": g["z"][lo:hi], "x_dir": g["x.dir"][lo:hi], "z_dir": g["z.dir"][lo:hi],
                  "x_v": pick(g["x.dir"], g["x.v_fwd"], g["x.v_bwd"]), "z_v": pick(g["z.dir"], g["z.v_fwd"], g["z.v_bwd"])}
         loss, _, _ = tr.loss_and_grad(to_dev(g["x"][lo:hi]), draws=draws)
-        scale = max(float(np.abs(g["grad.%s.%s" % (n, k)]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
-        worst = 0.0
-        for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
-            for k in O.NET_KEYS:
-                ref = g["grad.%s.%s" % (n, k)]
-                worst = max(worst, float(np.abs(to_np(w[k].grad).reshape(ref.shape) - ref).max()))
+        from tests.helpers import check_grads_per_tensor, fixture_grads, net_grads
+        worst = check_grads_per_tensor("rank %d" % rank, net_grads(dyn), fixture_grads(g))[0] * 2e-4      # per tensor (round 6)
+        scale = 1.0
         out.put((rank, float(loss), float(g["loss"]), worst / scale, float(dyn.alpha.grad), float(g["grad.alpha"])))
         dist.barrier()
     finally:
@@ -311,16 +308,11 @@ def _vae_train_worker(rank, world, port, out):
               "dir": g["prop.dir"][lo:hi], "u": g["prop.u"][lo:hi]}
         loss, xT, px = tr.sampler_loss_and_grad(to_dev(g["x"][lo:hi]), to_dev(g["aux"][lo:hi]), to_dev(g["log_sigma"][lo:hi]),
                                                 MH=1, draws=[dr])
-        scale = max(float(np.abs(g["grad.%s.%s" % (n, k)]).max()) for n in ("xnet", "vnet") for k in O.NET_KEYS)
-        worst = 0.0
-        for n, w in (("xnet", dyn._xw), ("vnet", dyn._vw)):
-            for k in O.NET_KEYS:
-                ref = g["grad.%s.%s" % (n, k)]
-                worst = max(worst, float(np.abs(to_np(w[k].grad).reshape(ref.shape) - ref).max()))
+        from tests.helpers import check_grads_per_tensor, fixture_grads, net_grads
         enc = dyn._xw["aux_encoder"]
-        for k in ("W1", "b1", "W2", "b2", "W3", "b3"):
-            ref = g["grad.enc." + k]
-            worst = max(worst, float(np.abs(to_np(enc[k].grad).reshape(ref.shape) - ref).max()))
+        got = net_grads(dyn, extra={"enc." + k: enc[k] for k in ("W1", "b1", "W2", "b2", "W3", "b3")})
+        worst = check_grads_per_tensor("rank %d" % rank, got, fixture_grads(g))[0] * 2e-4                 # per tensor (round 6)
+        scale = 1.0
         tr._adam(tr.lr_at(0))                       # every rank applies the same update to its replica
         out.put((rank, float(loss), float(g["loss"]), worst / scale, float(dyn.alpha.grad), float(g["grad.alpha"]),
                  float(tr.theta.double().sum()), float(tr.theta.double().abs().sum())))
@@ -349,3 +341,71 @@ def test_two_rank_vae_sampler_update_matches_the_full_batch_gradient():
         assert rel < 2e-4, (rank, rel)
         assert abs(ga - ref_ga) < 2e-4 * max(1.0, abs(ref_ga)), (rank, ga, ref_ga)
     assert res[0][6] == res[1][6] and res[0][7] == res[1][7]
+
+
+def _ragged_split_worker(rank, world, port, out):
+    """SplitTrainer's two sharded entry points (`sampler_step`, `step`) when ONE rank's chain count changes under a
+    discovered layout (a ragged last mini-batch): that rank must pass the step's collective and raise at the END of its
+    call; the other rank learns of it from the reduced chain count and raises at the START of its next call, before any
+    collective -- nobody waits in an all-reduce the other never enters (training.py)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from l2hmc_amd.training import SplitTrainer, Trainer
+        from tests.helpers import hip_dynamics, load, to_dev
+        seen = {}
+        for name, case in (("sampler", "train_vae_small"), ("step", "train_tilted8_h24")):
+            g = load(case)
+            dyn = hip_dynamics(g)
+            dyn.eps_override = None
+            with torch.no_grad():
+                dyn.alpha.fill_(float(np.log(g["eps"])))
+            tr = Trainer(dyn, decay_steps=0)
+            assert isinstance(tr, SplitTrainer)
+            N = g["x"].shape[0]
+            lo, hi = sharding.shard_range(N)
+
+            def call(hi_):
+                if name == "sampler":
+                    return tr.sampler_step(to_dev(g["x"][lo:hi_]), to_dev(g["aux"][lo:hi_]), to_dev(g["log_sigma"][lo:hi_]), MH=1)
+                return tr.step(to_dev(g["x"][lo:hi_]))
+            call(hi)                                   # layout exchange + a healthy step
+            call(hi)
+            events = []
+            try:                                       # rank 0 arrives one chain short; rank 1 as before
+                call(hi - 1 if rank == 0 else hi)
+                events.append("passed")
+            except RuntimeError as e:
+                events.append("stale" if "chain count changed" in str(e) else "other: %s" % e)
+            try:                                       # the next call: both ranks raise before any collective (the reduced count)
+                call(hi - 1 if rank == 0 else hi)
+                events.append("passed")
+            except RuntimeError as e:
+                events.append("count" if "counted" in str(e) else ("stale" if "chain count changed" in str(e) else "other: %s" % e))
+            tr.set_sharding(None, None)                # every rank re-opens the exchange: healthy again on the new layout
+            call(hi - 1 if rank == 0 else hi)
+            events.append("recovered")
+            seen[name] = tuple(events)
+        out.put((rank, seen))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_rank_gemm_engine_trainer_survives_a_ragged_shard():
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_split_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(280)
+        assert pr.exitcode == 0
+    res = dict(out.get() for _ in range(2))
+    for name in ("sampler", "step"):
+        assert res[0][name] == ("stale", "count", "recovered"), (name, res[0][name])
+        assert res[1][name] == ("passed", "count", "recovered"), (name, res[1][name])
