@@ -361,7 +361,7 @@ def _ragged_split_worker(rank, world, port, out):
             dyn.eps_override = None
             with torch.no_grad():
                 dyn.alpha.fill_(float(np.log(g["eps"])))
-            tr = Trainer(dyn, decay_steps=0)
+            tr = Trainer(dyn, decay_steps=0) if name == "sampler" else Trainer(dyn)
             assert isinstance(tr, SplitTrainer)
             N = g["x"].shape[0]
             lo, hi = sharding.shard_range(N)
