@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define L2HMC_ABI_VERSION 5
+#define L2HMC_ABI_VERSION 6
 
 enum {
   L2HMC_OK = 0,
@@ -266,9 +266,21 @@ typedef int (*L2hmcHvpCallback)(void* user, const float* x, int64_t ldx, const f
  * row `it` if it runs forward (direction[n] != 0, or direction == NULL and direction_all != 0), else T - 1 - it: its time input
  * is tau = (cos, sin)(2 pi row / T) (dynamics.py:99-105).  The callback enqueues, on `stream`, the FINAL S, T, Q (dynamics.py's
  * `scale, translation, transformed`) as the three (n_chains, d) column blocks of stq_out (row stride 3 d).  Nonzero return
- * aborts the trajectory.  Sampling only: the trainers differentiate the fused architecture. */
+ * aborts the trajectory.  Training such nets: L2hmcNetVjpCallback below (ABI 6). */
 typedef int (*L2hmcNetCallback)(void* user, int32_t net, const float* ab, int64_t ldab, int64_t n_chains, int32_t d, int32_t it,
                                 const uint8_t* direction, int32_t direction_all, float* stq_out, void* stream);
+/* (ABI 6) The reverse of ONE evaluation of a caller-supplied net, for l2hmc_train_split_grad: the reference minimises its loss
+ * over whatever variables `net_factory` created (utils/dynamics.py:78-79; SCGExperiment.ipynb raw 178-181 `minimize(loss)`;
+ * mnist_vae.py:254-262), so the adjoint of an opaque net is the caller's to form.  `ab`, `it`, `direction` identify the
+ * evaluation exactly as in L2hmcNetCallback (the library hands back the SAME inputs it kept from the forward pass);
+ * d_stq (n_chains, 3 d, row stride 3 d) holds the cotangents of the net's outputs (d S | d T | d Q) -- already weighted by
+ * inv_n and the loss.  The callback enqueues on `stream`: (i) the cotangents of the inputs, (d a | d b), into d_ab
+ * (n_chains, 2 d, row stride ld_dab); (ii) the accumulation of its OWN parameters' gradients wherever it keeps them (with
+ * torch: one `torch.autograd.backward` of the re-evaluated net) -- the library never sees those parameters.  Nonzero return
+ * aborts the call. */
+typedef int (*L2hmcNetVjpCallback)(void* user, int32_t net, const float* ab, int64_t ldab, int64_t n_chains, int32_t d, int32_t it,
+                                   const uint8_t* direction, int32_t direction_all, const float* d_stq, float* d_ab,
+                                   int64_t ld_dab, void* stream);
 
 typedef struct L2hmcSplitArgs {
   const L2hmcNet* xnet;
@@ -493,6 +505,13 @@ typedef struct L2hmcTrainSplitArgs {
   L2hmcEnergyCallback energy_cb; /* U / grad U at a trajectory point (as in L2hmcSplitArgs), or NULL              */
   L2hmcHvpCallback hvp_cb;       /* its Hessian-vector product; required with energy_cb                          */
   void* energy_cb_user;          /* first argument of both callbacks                                              */
+  /* ---- (ABI 6) training caller-supplied nets: xnet = vnet = aux_encoder = NULL, H ignored; goes with a built-in `energy` or
+   *      with energy_cb + hvp_cb.  Every net evaluation of the forward pass is net_cb (final S | T | Q into the library's
+   *      stash), every one of the reverse sweep net_vjp_cb; `grad` then holds ONE float, d loss / d eps (accumulated) --
+   *      the nets' parameter gradients are accumulated by the callback on the caller's side ---------------------------- */
+  L2hmcNetCallback net_cb;
+  L2hmcNetVjpCallback net_vjp_cb;
+  void* net_cb_user;             /* first argument of both                                                        */
 } L2hmcTrainSplitArgs;
 
 int64_t l2hmc_train_split_grad_floats(int32_t d, int32_t H, const L2hmcMlp3* aux_encoder);

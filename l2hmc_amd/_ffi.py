@@ -74,6 +74,9 @@ ENERGY_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_in
 # L2hmcNetCallback(user, net, ab, ldab, n_chains, d, it, direction, direction_all, stq_out, stream)
 NET_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                            C.c_int32, C.c_void_p, C.c_void_p)
+# L2hmcNetVjpCallback(user, net, ab, ldab, n_chains, d, it, direction, direction_all, d_stq, d_ab, ld_dab, stream)   (ABI 6)
+NET_VJP_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                               C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 # L2hmcHvpCallback(user, x, ldx, u, ldu, n_chains, d, hv_out, ldhv, stream)
 HVP_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                            C.c_void_p, C.c_int64, C.c_void_p)
@@ -100,7 +103,8 @@ class L2hmcTrainSplitArgs(C.Structure):
                 ("workspace", _fp), ("workspace_floats", C.c_int64),
                 ("energy_scale", C.c_float), ("ediff_out", _fp), ("no_accept", C.c_int32), ("dLv_in", _fp),
                 ("dlogjac_in", _fp), ("Lv_out", _fp), ("logjac_out", _fp), ("gemm_mode", C.c_int32), ("net_mode", C.c_int32),
-                ("energy_cb", C.c_void_p), ("hvp_cb", C.c_void_p), ("energy_cb_user", C.c_void_p)]
+                ("energy_cb", C.c_void_p), ("hvp_cb", C.c_void_p), ("energy_cb_user", C.c_void_p),
+                ("net_cb", C.c_void_p), ("net_vjp_cb", C.c_void_p), ("net_cb_user", C.c_void_p)]          # (ABI 6)
 
 
 class L2hmcTrainStep(C.Structure):
@@ -160,7 +164,7 @@ SYMBOLS = {
                              _fp, _fp]),
 }
 
-ABI_VERSION = 5          # L2HMC_ABI_VERSION this binding was written against
+ABI_VERSION = 6          # L2HMC_ABI_VERSION this binding was written against
 _lib = None
 
 

@@ -57,8 +57,12 @@ __global__ __launch_bounds__(256) void k_tv_half_bwd(float* out3, L2hmcNet w, co
   float acc = 0.f;
   for (int k = lane; k < d; k += 64) {
     float* o = out3 + n * 3 * d;
-    const float els = expf(w.lam_s[k]), elq = expf(w.lam_q[k]);
-    const float ts = tanhf(o[k] + w.bs[k]), Tt = o[d + k] + w.bt[k], tq = tanhf(o[2 * d + k] + w.bq[k]);
+    // (w.lam_s == NULL: out3 holds the FINAL S | T | Q of a caller-supplied net on entry and their cotangents on exit,
+    //  L2hmcNetVjpCallback; DL is not written)
+    const bool raw = w.lam_s == nullptr;
+    const float els = raw ? 1.f : expf(w.lam_s[k]), elq = raw ? 1.f : expf(w.lam_q[k]);
+    const float ts = raw ? o[k] : tanhf(o[k] + w.bs[k]), Tt = raw ? o[d + k] : o[d + k] + w.bt[k],
+                tq = raw ? o[2 * d + k] : tanhf(o[2 * d + k] + w.bq[k]);
     const float S = els * ts, Q = elq * tq;
     const float ES = expf(sg * heps * S), EQ = expf(eps * Q);
     const float gq = g[n * ldg + k], vi = vin[n * ldvi + k];
@@ -72,11 +76,13 @@ __global__ __launch_bounds__(256) void k_tv_half_bwd(float* out3, L2hmcNet w, co
     const float dQr = dq * eps;
     dvin[n * d + k] = dO * ES;
     dg[n * d + k] = -dcc * heps * EQ;
-    DL[n * 2 * d + k] = dSr * S;
-    DL[n * 2 * d + d + k] = dQr * Q;
-    o[k] = dSr * els * (1.f - ts * ts);
+    if (!raw) {
+      DL[n * 2 * d + k] = dSr * S;
+      DL[n * 2 * d + d + k] = dQr * Q;
+    }
+    o[k] = raw ? dSr : dSr * els * (1.f - ts * ts);
     o[d + k] = dcc * heps;
-    o[2 * d + k] = dQr * elq * (1.f - tq * tq);
+    o[2 * d + k] = raw ? dQr : dQr * elq * (1.f - tq * tq);
     acc += ds * sg * 0.5f * S + dcc * 0.5f * (Tt - EQ * gq) + dq * Q;
   }
   acc = wave_sum(acc);
@@ -102,8 +108,10 @@ __global__ __launch_bounds__(256) void k_tx_half_bwd(float* out3, L2hmcNet w, co
     const float m = masks[s * d + k];
     const float k1 = fwd ? m : 1.f - m;
     const float kp = second ? 1.f - k1 : k1, up = 1.f - kp;
-    const float els = expf(w.lam_s[k]), elq = expf(w.lam_q[k]);
-    const float ts = tanhf(o[k] + w.bs[k]), Tt = o[d + k] + w.bt[k], tq = tanhf(o[2 * d + k] + w.bq[k]);
+    const bool raw = w.lam_s == nullptr;           // (a caller-supplied net's final S | T | Q: see k_tv_half_bwd)
+    const float els = raw ? 1.f : expf(w.lam_s[k]), elq = raw ? 1.f : expf(w.lam_q[k]);
+    const float ts = raw ? o[k] : tanhf(o[k] + w.bs[k]), Tt = raw ? o[d + k] : o[d + k] + w.bt[k],
+                tq = raw ? o[2 * d + k] : tanhf(o[2 * d + k] + w.bq[k]);
     const float S = els * ts, Q = elq * tq;
     const float ES = expf(sg * eps * S), EQ = expf(eps * Q);
     const float vhq = vh[n * ldvh + k], zi = zin[n * ldzi + k];
@@ -118,11 +126,13 @@ __global__ __launch_bounds__(256) void k_tx_half_bwd(float* out3, L2hmcNet w, co
     const float dQr = dq * eps;
     dzin_out[n * d + k] = kp * dO + dnw * ES;
     dvh[n * d + k] += dtr * eps * EQ;
-    DL[n * 2 * d + k] = dSr * S;
-    DL[n * 2 * d + d + k] = dQr * Q;
-    o[k] = dSr * els * (1.f - ts * ts);
+    if (!raw) {
+      DL[n * 2 * d + k] = dSr * S;
+      DL[n * 2 * d + d + k] = dQr * Q;
+    }
+    o[k] = raw ? dSr : dSr * els * (1.f - ts * ts);
     o[d + k] = dtr * eps;
-    o[2 * d + k] = dQr * elq * (1.f - tq * tq);
+    o[2 * d + k] = raw ? dQr : dQr * elq * (1.f - tq * tq);
     acc += dsx * sg * S + dtr * (EQ * vhq + Tt) + dq * Q;
   }
   acc = wave_sum(acc);
@@ -728,9 +738,16 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   const bool builtin = a->energy != nullptr;
   const bool user = a->energy_cb != nullptr;       // the caller's energy: U / grad U and Hessian-vector products by callback
   const bool vae = !builtin && !user;              // the decoder posterior
+  // (ABI 6) the caller's own S/T/Q nets (any callable, dynamics.py:69-79): forward by net_cb, reverse by net_vjp_cb
+  const bool unets = a->net_cb != nullptr || a->net_vjp_cb != nullptr;
   int rc;
+  if (unets) {
+    if (!a->net_cb || !a->net_vjp_cb) return fail(L2HMC_ERR_ARG, "training caller-supplied nets needs BOTH net_cb and net_vjp_cb%s");
+    if (a->xnet || a->vnet || a->aux_encoder || vae)
+      return fail(L2HMC_ERR_ARG, "net_cb excludes xnet / vnet / aux_encoder and goes with a built-in energy or energy_cb + hvp_cb%s");
+  }
   const long long N = a->n_chains;
-  const int d = a->d, H = a->H, T = a->T;
+  const int d = a->d, H = unets ? 4 : a->H, T = a->T;     // (caller-supplied nets: no hidden activations are planned for)
   if (N < 0 || d < 1 || H < 1 || T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / H / T%s");
   if (N == 0) return L2HMC_OK;
   if (user) {
@@ -758,7 +775,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     if (a->aux_encoder->n_out != H || (vae && a->aux_encoder->n_in != a->decoder->n_out))
       return fail(L2HMC_ERR_ARG, "aux_encoder must map (N, n_pix) -> (N, H)%s");
   }
-  if (!a->xnet || !a->vnet || !a->masks || !a->trig || !a->x || !a->v || !a->Lx || (!a->no_accept && (!a->p || !a->v1)) ||
+  if ((!unets && (!a->xnet || !a->vnet)) || !a->masks || !a->trig || !a->x || !a->v || !a->Lx || (!a->no_accept && (!a->p || !a->v1)) ||
       !a->grad || !a->workspace)
     return fail(L2HMC_ERR_ARG, "l2hmc_train_split_grad: NULL pointer%s");
   if (!a->alpha && !(a->eps_host > 0.f)) return fail(L2HMC_ERR_ARG, "eps must be > 0%s");
@@ -786,7 +803,8 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     dws.pa1 = us(f.pa1); dws.pa2 = us(f.pa2); dws.plg = us(f.plg); dws.pda2 = us(f.pda2);
   }
   const int L = 2 * d;
-  const L2hmcNet &xn = *a->xnet, &vn = *a->vnet;
+  static const L2hmcNet no_net = {};              // lam_s == NULL: the update kernels and their adjoints take S | T | Q as they are
+  const L2hmcNet &xn = unets ? no_net : *a->xnet, &vn = unets ? no_net : *a->vnet;
   const L2hmcNet* nets[2] = {&xn, &vn};
   const unsigned char* dir = a->direction;
   const int dall = a->direction_all;
@@ -815,7 +833,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     ne_cus = 256;
   const int ne_cb = N >= 32LL * ne_cus ? 2 : 1;
   const size_t ne_lds = net_eval_lds_bytes(d, H, ne_cb), nb_lds = net_bwd_lds_bytes(d, H, ne_cb);
-  const bool fused_nets = (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(3 * d) <= 16 * NE_MAXKT &&
+  const bool fused_nets = !unets && (H % 4 == 0) && (d % 2 == 0) && ceil16(H) <= 16 * NE_MAXKT && ceil16(3 * d) <= 16 * NE_MAXKT &&
                           ne_lds <= 160 * 1024 && nb_lds <= 160 * 1024 && a->net_mode == 0;
   if (fused_nets) {
     hipError_t e = hipSuccess;
@@ -850,13 +868,13 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     mlp3_transposes(s, enc, ews);
     mlp3_forward(s, enc, a->aux, N, ews, aux_h);
   }
-  hipLaunchKernelGGL(k_time_table, dim3(nblk(2LL * T * H)), dim3(256), 0, s, xn, vn, a->trig, T, H, tb);
+  if (!unets) hipLaunchKernelGGL(k_time_table, dim3(nblk(2LL * T * H)), dim3(256), 0, s, xn, vn, a->trig, T, H, tb);
   float* w12t[2] = {w + f.nx12t, w + f.nv12t};
   float* w4t[2] = {w + f.nx4t, w + f.nv4t};
   float* wht[2] = {w + f.nxht, w + f.nvht};
   const int K1p = ceil16(L), Hp = ceil16(H);
-  (void)hipMemsetAsync(w + f.nx12t, 0, sizeof(float) * (size_t)(f.nvht + (long long)ceil16(3 * d) * Hp - f.nx12t), s);
-  for (int i = 0; i < 2; ++i) {
+  if (!unets) (void)hipMemsetAsync(w + f.nx12t, 0, sizeof(float) * (size_t)(f.nvht + (long long)ceil16(3 * d) * Hp - f.nx12t), s);
+  for (int i = 0; i < 2 && !unets; ++i) {
     transpose_into(s, nets[i]->W1, d, H, w12t[i], K1p, 0);
     transpose_into(s, nets[i]->W2, d, H, w12t[i], K1p, d);
     transpose_into(s, nets[i]->W4, H, H, w4t[i], Hp, 0);
@@ -909,7 +927,12 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   // one net evaluation with everything kept: h1, h2 and the head products of evaluation (net, ne)
   // `upd`: the half-update that consumes the evaluation (fused behind the heads when the fused kernel runs: the raw head
   // products still go to O3 for the reverse sweep); returns false when the caller has to launch the stand-alone update kernel
+  int cb_rc = 0;                                   // first nonzero return of a net callback (checked after each phase)
   auto net_fwd = [&](int net, int ne, int it, NetEvalArgs::Update upd = NetEvalArgs::Update{}) -> bool {
+    if (unets) {       // the caller's net writes the final S | T | Q of evaluation (net, ne) into the stash
+      if (!cb_rc) cb_rc = a->net_cb(a->net_cb_user, net, AB(net, ne), L, N, d, it, dir, dall, O3(net, ne), stream);
+      return false;
+    }
     if (fused_nets) {
       NetEvalArgs na = {};
       const L2hmcNet& nw = *nets[net];
@@ -947,6 +970,10 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   };
   // reverse of net_fwd for the data path: O3 holds (d zs | d zt | d zq) -> DA2, DA1 (kept for the weight gradients), dAB
   auto net_bwd = [&](int net, int ne) {
+    if (unets) {       // (d S | d T | d Q) of evaluation (net, ne) -> (d a | d b); the caller accumulates its parameters' gradients
+      if (!cb_rc) cb_rc = a->net_vjp_cb(a->net_cb_user, net, AB(net, ne), L, N, d, ne / 2, dir, dall, O3(net, ne), w + p.dAB, L, stream);
+      return;
+    }
     if (fused_nets) {
       NetBwdArgs nb = {};
       nb.dO3 = O3(net, ne); nb.ldo = 3 * d; nb.Whc = w + p.whp[net]; nb.W4 = w + p.w4p[net]; nb.W12 = w + p.w12p[net];
@@ -992,6 +1019,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     if (!last) (void)hipMemcpyAsync(AB(1, 2 * it + 2), abv1, sizeof(float) * NL, hipMemcpyDeviceToDevice, s);
   }
 
+  if (cb_rc) return fail(L2HMC_ERR_ARG, "the net callback failed (returned %s%lld)", "", (long long)cb_rc);
   // ---- accept probability, loss argument, adjoint seeds -----------------------------------------------------------
   float *lx = w + p.lx, *lv = w + p.lv, *dvh = w + p.dvh, *dz = w + p.dz, *dg = w + p.dg, *uu = w + p.u, *hv = w + p.hv;
   float *lam = w + p.lam, *lamU = w + p.lamU, *dv1p = w + p.dv1p, *deps = w + p.deps, *dAB = w + p.dAB;
@@ -1064,6 +1092,13 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
                        lamU, dv1p, a->dx0_out, N, d);
   }
 
+  if (cb_rc) return fail(L2HMC_ERR_ARG, "the net reverse callback failed (returned %s%lld)", "", (long long)cb_rc);
+  if (unets) {         // the nets' parameter gradients were accumulated by the callbacks; what is the library's is d loss / d eps
+    hipLaunchKernelGGL(k_sum_chain, dim3(1), dim3(256), 0, s, deps, N, a->grad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return L2HMC_OK;
+  }
   // ---- parameter gradients: one contraction over all (evaluation, chain) rows per weight matrix ---------------------
   const SNetOff o = snet_off(d, H);
   const long long R = 2LL * T * N;

@@ -239,6 +239,72 @@ class Dynamics(object):
         self.mask = sd['mask']
         self._packed_key = None
 
+    def _net_callbacks(self, ws, direction, aux, cb_error):
+        """(net_cb, net_vjp_cb): the Python bodies of include/l2hmc.h's L2hmcNetCallback / L2hmcNetVjpCallback for this
+        Dynamics' caller-supplied nets (dynamics.py:69-79: any callable [a, b, tau, aux] -> [S, T, Q]), working on views of the
+        workspace tensor `ws` the library points into.  Chain n's time input is row `it` of the schedule if it runs forward, row
+        T - 1 - it otherwise (dynamics.py:99-105, :285).  net_cb evaluates under no_grad (a net whose parameters require
+        grad must not hang a graph on the persistent workspace); net_vjp_cb RE-evaluates the net on the kept inputs with
+        autograd on and runs ONE backward: the inputs' cotangents go to the library, the parameters' gradients accumulate
+        in their `.grad` (which the trainer aliases to its flat gradient vector)."""
+        base, T = ws.data_ptr(), self.T
+        fwd_mask = (direction != 0) if direction is not None else None
+
+        def inputs(net, abp, ldab, n, dd, it, dall):
+            ab = ws.as_strided((n, 2 * dd), (ldab, 1), (abp - base) // 4)
+            if fwd_mask is not None:
+                tau = self._trig[torch.where(fwd_mask, it, T - 1 - it)]
+            else:
+                tau = self._trig[it if dall else T - 1 - it].expand(n, 2)
+            return (self.XNet if net == 0 else self.VNet), ab[:, :dd], ab[:, dd:], tau
+
+        def outputs(stq, n, dd):
+            if len(stq) != 3:
+                raise ValueError("a net must return [S, T, Q], got %d outputs" % len(stq))
+            res = []
+            for i, t in enumerate(stq):                # (HMC-style nets return plain zeros, dynamics.py:73-76)
+                t = torch.as_tensor(t, dtype=torch.float32, device=ws.device)
+                if t.dim() != 0 and tuple(t.shape) != (n, dd):
+                    raise ValueError("net output %d must be (N, d) = (%d, %d), got %s" % (i, n, dd, tuple(t.shape)))
+                res.append(t)
+            return res
+
+        @torch.no_grad()
+        def net_cb(_user, net, abp, ldab, n, dd, it, _dirp, dall, outp, _stream):
+            try:
+                fn, a, b, tau = inputs(net, abp, ldab, n, dd, it, dall)
+                out = ws.as_strided((n, 3 * dd), (3 * dd, 1), (outp - base) // 4)
+                for i, t in enumerate(outputs(fn([a, b, tau, aux]), n, dd)):
+                    out[:, i * dd:(i + 1) * dd] = t
+                return 0
+            except Exception as e:                     # never let an exception cross the C frame
+                cb_error.append(e)
+                return 1
+
+        def net_vjp_cb(_user, net, abp, ldab, n, dd, it, _dirp, dall, dstqp, dabp, ld_dab, _stream):
+            try:
+                with torch.no_grad():
+                    fn, a, b, tau = inputs(net, abp, ldab, n, dd, it, dall)
+                    a, b = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+                    dstq = ws.as_strided((n, 3 * dd), (3 * dd, 1), (dstqp - base) // 4)
+                    dab = ws.as_strided((n, 2 * dd), (ld_dab, 1), (dabp - base) // 4)
+                with torch.enable_grad():
+                    stq = outputs(fn([a, b, tau, aux]), n, dd)
+                    live = [(t, dstq[:, i * dd:(i + 1) * dd]) for i, t in enumerate(stq) if t.requires_grad]
+                    if live:
+                        torch.autograd.backward([t for t, _ in live], [g.clone() for _, g in live])
+                with torch.no_grad():
+                    for j, t in enumerate((a, b)):
+                        if t.grad is None:
+                            dab[:, j * dd:(j + 1) * dd] = 0.0
+                        else:
+                            dab[:, j * dd:(j + 1) * dd] = t.grad
+                return 0
+            except Exception as e:
+                cb_error.append(e)
+                return 1
+        return net_cb, net_vjp_cb
+
     def _packed_nets(self):
         """Fragment-ordered weights for the kernels; re-packed when any parameter changed."""
         if self.hmc:
@@ -363,31 +429,7 @@ class Dynamics(object):
             # the caller's nets (dynamics.py:69-79: any callable [a, b, tau, aux] -> [S, T, Q]): evaluated here, on views of the
             # workspace, between the library's launches; chain n's time input is row `it` of the schedule if it runs forward,
             # row T - 1 - it otherwise (dynamics.py:99-105, :285)
-            wsn, basen, Tn = self._split_ws, self._split_ws.data_ptr(), self.T
-            fwd_mask = (direction != 0) if direction is not None else None
-
-            @torch.no_grad()      # (a net whose parameters require grad must not hang a CopySlices graph on the persistent workspace)
-            def net_cb(_user, net, abp, ldab, n, dd, it, _dirp, dall, outp, _stream):
-                try:
-                    ab = wsn.as_strided((n, 2 * dd), (ldab, 1), (abp - basen) // 4)
-                    if fwd_mask is not None:
-                        rows = torch.where(fwd_mask, it, Tn - 1 - it)
-                        tau = self._trig[rows]
-                    else:
-                        tau = self._trig[it if dall else Tn - 1 - it].expand(n, 2)
-                    stq = (self.XNet if net == 0 else self.VNet)([ab[:, :dd], ab[:, dd:], tau, aux])
-                    if len(stq) != 3:
-                        raise ValueError("a net must return [S, T, Q], got %d outputs" % len(stq))
-                    out = wsn.as_strided((n, 3 * dd), (3 * dd, 1), (outp - basen) // 4)
-                    for i, t in enumerate(stq):          # (HMC-style nets return plain zeros, dynamics.py:73-76)
-                        t = torch.as_tensor(t, dtype=torch.float32, device=wsn.device)
-                        if t.dim() != 0 and tuple(t.shape) != (n, dd):
-                            raise ValueError("net output %d must be (N, d) = (%d, %d), got %s" % (i, n, dd, tuple(t.shape)))
-                        out[:, i * dd:(i + 1) * dd] = t
-                    return 0
-                except Exception as e:                   # never let an exception cross the C frame
-                    cb_error.append(e)
-                    return 1
+            net_cb = self._net_callbacks(self._split_ws, direction, aux, cb_error)[0]
             ncb = _ffi.NET_CALLBACK(net_cb)              # (kept alive by this frame for the duration of the call)
             a.net_cb = C.cast(ncb, C.c_void_p)
         a.masks, a.trig = self._mask.data_ptr(), self._trig.data_ptr()

@@ -46,8 +46,11 @@ RNG_STREAM = "philox4x32-10/hw-boxmuller"       # (l2hmc_kernels.hpp philox_norm
 class Trainer(object):
     def __new__(cls, dynamics, *args, **kwargs):
         if getattr(dynamics, "_user_nets", False):
-            raise NotImplementedError("training differentiates the fused S/T/Q architecture (l2hmc_amd.layers.stq_network); a "
-                                      "Dynamics whose nets are arbitrary callables samples only")
+            # dynamics.py:78-79 + SCGExperiment.ipynb raw 178-181: the reference minimises over whatever variables net_factory
+            # created.  Arbitrary callables train on the GEMM-engine trainer, their adjoints by callback (ABI 6 net_vjp_cb).
+            if cls is not Trainer and cls is not SplitTrainer:
+                raise NotImplementedError("caller-supplied nets train on the GEMM engine: use Trainer(dynamics)")
+            return object.__new__(SplitTrainer)
         if getattr(dynamics, "_user", False) and cls is not SplitTrainer and cls is not Trainer:
             raise NotImplementedError("a caller-supplied energy trains on the GEMM engine: use Trainer(dynamics)")
         # samplers that run on the GEMM engine (nets wider than H = 15, the image-conditioned VAE sampler) train there
@@ -452,7 +455,7 @@ class SplitTrainer(Trainer):
         self.user = bool(getattr(dynamics, "_user", False))     # U, grad U and Hessian-vector products by callback (slow path)
         # the VAE experiment's sampler (mnist_vae.py:185-262): the built-in decoder posterior, or the same model handed
         # over as a plain closure energy(z, aux) with the image-conditioned nets
-        self.image_sampler = self.vae or (self.user and dynamics._xw["aux_encoder"] is not None)
+        self.image_sampler = self.vae or (self.user and dynamics._xw is not None and dynamics._xw["aux_encoder"] is not None)
         self.scale = float(scale) if scale is not None else (1.0 if self.image_sampler else 0.1)
         if self.image_sampler and self.scale != 1.0:
             # mnist_vae.py:207-226 has no scale (its loss is mean(1/v) - mean(v)); the composed-proposal branch of
@@ -465,14 +468,43 @@ class SplitTrainer(Trainer):
         d, H = dynamics.x_dim, dynamics.H
         dev = dynamics.device
         L = _ffi.lib()
-        self.enc = dynamics._xw["aux_encoder"]
+        self.unets = bool(getattr(dynamics, "_user_nets", False))
+        self.enc = None if self.unets else dynamics._xw["aux_encoder"]
         enc_s = mlp3_struct(self.enc) if self.enc is not None else None
-        self.n_grad = _ffi.check(L.l2hmc_train_split_grad_floats(d, H, C.byref(enc_s) if enc_s is not None else None))
+        if self.unets:
+            # Arbitrary callables (dynamics.py:69-79): the variables are whatever the nets expose -- the layer kit's
+            # `parameters()` or a torch Module's named_parameters() (`Dynamics.parameters`).  Flat vector [those, in order |
+            # alpha]; every one of them becomes a view of theta (the native Adam update is seen by the caller's nets) and its
+            # `.grad` a view of the flat gradient (the caller's autograd accumulates straight into what is all-reduced).
+            plist = [(k, t) for k, t in dynamics.parameters() if k != "alpha"]
+            seen, uniq = set(), []
+            for k, t in plist:                       # (one tensor shared by both nets is one variable)
+                if t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    uniq.append((k, t))
+            if not uniq:
+                raise ValueError("the caller-supplied nets expose no parameters (layer-kit parameters() or torch Module "
+                                 "named_parameters()): nothing to train")
+            for k, t in uniq:
+                if t.dtype != torch.float32 or t.device != dev:
+                    raise ValueError("net parameter %s must be float32 on %s" % (k, dev))
+            self._uparams = uniq
+            self.n_grad = sum(int(t.numel()) for _, t in uniq) + 1
+        else:
+            self.n_grad = _ffi.check(L.l2hmc_train_split_grad_floats(d, H, C.byref(enc_s) if enc_s is not None else None))
         self._alloc_flat(dev)
         self.theta = torch.zeros(self.n_grad, dtype=torch.float32, device=dev)
         self.slots, off = [], 0
         with torch.no_grad():
-            for w in (dynamics._xw, dynamics._vw):
+            if self.unets:
+                for k, t in self._uparams:
+                    n = int(t.numel())
+                    view = self.theta[off:off + n].view(t.shape)
+                    view.copy_(t)
+                    t.data = view
+                    self.slots.append((t, off, n))
+                    off += n
+            for w in (() if self.unets else (dynamics._xw, dynamics._vw)):
                 for name, code in _SHAPES:
                     n = _numel(code, d, H)
                     t = w[name]
@@ -518,7 +550,7 @@ class SplitTrainer(Trainer):
         L = _ffi.lib()
         enc_s = self._mlp3_struct(self.enc) if self.enc is not None else None
         dec_s = self._mlp3_struct(dyn._fn.decoder) if self.vae else None
-        need = _ffi.check(L.l2hmc_train_split_workspace_floats(N, d, dyn.H, dyn.T,
+        need = _ffi.check(L.l2hmc_train_split_workspace_floats(N, d, 4 if self.unets else dyn.H, dyn.T,
                                                                C.byref(enc_s) if enc_s is not None else None,
                                                                C.byref(dec_s) if dec_s is not None else None))
         if self._ws is None or self._ws.numel() < need:
@@ -528,13 +560,24 @@ class SplitTrainer(Trainer):
             out = (torch.empty_like(start), torch.empty(N, dtype=torch.float32, device=dyn.device),
                    torch.empty(N, dtype=torch.float32, device=dyn.device))
         Lx, p, v1 = out
-        xs = _ffi.L2hmcNet(*[dyn._xw[k].data_ptr() for k in _ffi.NET_FIELDS])
-        vs = _ffi.L2hmcNet(*[dyn._vw[k].data_ptr() for k in _ffi.NET_FIELDS])
         a = _ffi.L2hmcTrainSplitArgs()
-        a.xnet, a.vnet, a.H = C.pointer(xs), C.pointer(vs), dyn.H
+        cb_error = []
+        keep_nets = None
+        if self.unets:
+            # forward by net_cb, reverse by net_vjp_cb (include/l2hmc.h, ABI 6): the parameters' `.grad` are views of self.flat
+            # (set here, before the caller's autograd accumulates into them in place)
+            for t, off, n in self.slots:
+                t.grad = self.flat[off:off + n].view(t.shape)
+            ncb, vcb = dyn._net_callbacks(self._ws, direction, aux, cb_error)
+            keep_nets = (_ffi.NET_CALLBACK(ncb), _ffi.NET_VJP_CALLBACK(vcb))           # alive for the duration of the call
+            a.net_cb, a.net_vjp_cb = C.cast(keep_nets[0], C.c_void_p), C.cast(keep_nets[1], C.c_void_p)
+            a.H = 0
+        else:
+            xs = _ffi.L2hmcNet(*[dyn._xw[k].data_ptr() for k in _ffi.NET_FIELDS])
+            vs = _ffi.L2hmcNet(*[dyn._vw[k].data_ptr() for k in _ffi.NET_FIELDS])
+            a.xnet, a.vnet, a.H = C.pointer(xs), C.pointer(vs), dyn.H
         a.aux_encoder = C.pointer(enc_s) if enc_s is not None else None
         keep = None
-        cb_error = []
         if self.user:
             fn, ws = dyn._fn, self._ws
             base = ws.data_ptr()
@@ -595,7 +638,9 @@ class SplitTrainer(Trainer):
         a.scale, a.inv_n = self.scale, 1.0 / float(n_total)
         a.dLx_in, a.dx0_out = _ffi.ptr(dLx_in), _ffi.ptr(dx0_out)
         a.Lx, a.p, a.v1 = Lx.data_ptr(), p.data_ptr(), v1.data_ptr()
-        a.grad, a.workspace, a.workspace_floats = self.flat.data_ptr(), self._ws.data_ptr(), self._ws.numel()
+        # (caller-supplied nets: the library's share of the gradient is the ONE float d loss / d eps, at alpha's slot)
+        a.grad = self.flat[self.alpha_index:].data_ptr() if self.unets else self.flat.data_ptr()
+        a.workspace, a.workspace_floats = self._ws.data_ptr(), self._ws.numel()
         a.energy_scale, a.ediff_out, a.no_accept = float(energy_scale), _ffi.ptr(ediff_out), int(bool(no_accept))
         a.dLv_in, a.dlogjac_in = _ffi.ptr(dLv_in), _ffi.ptr(dlogjac_in)
         a.Lv_out, a.logjac_out = _ffi.ptr(Lv_out), _ffi.ptr(logjac_out)

@@ -50,6 +50,54 @@ def _net_bwd(net, c, dS, dT, dQ, grad):
     return da1 @ net['W1'].T, da1 @ net['W2'].T
 
 
+# A net OUTSIDE the notebook's architecture (the reference's `net_factory` may return any callable, dynamics.py:69-79): an
+# object with  fwd(a, b, tau) -> ((S, T, Q), cache)  and  bwd(cache, dS, dT, dQ) -> (da, db)  that accumulates its own
+# parameter gradients in `.grads` (a dict).  `TanhSigmoidNet` below is the one the tests use; dict nets are the notebook's.
+def _fwd(net, a, b, tau):
+    return net.fwd(a, b, tau) if hasattr(net, 'fwd') else _net_fwd(net, a, b, tau)
+
+
+def _bwd(net, c, dS, dT, dQ, grad):
+    return net.bwd(c, dS, dT, dQ) if hasattr(net, 'bwd') else _net_bwd(net, c, dS, dT, dQ, grad)
+
+
+class TanhSigmoidNet:
+    """h = tanh(a A + b B + c) * (1 + tau C);  S = s (sigmoid(h Ws) - 1/2);  T = h Wt + bt;  Q = q tanh(h Wq)  -- one hidden
+    layer, the time input entering multiplicatively, S bounded by a sigmoid: nothing the fused kernels have.  Hand-derived
+    reverse mode, pinned by finite differences (tests/test_oracle_golden.py)."""
+    KEYS = ('A', 'B', 'c', 'C', 'Ws', 'Wt', 'bt', 'Wq')
+
+    def __init__(self, w, s, q, dtype=np.float64):
+        self.w = {k: np.asarray(w[k], dtype) for k in self.KEYS}
+        self.s, self.q = dtype(s), dtype(q)
+        self.grads = {k: np.zeros_like(self.w[k]) for k in self.KEYS}
+
+    def fwd(self, a, b, tau):
+        w = self.w
+        t = np.tanh(a @ w['A'] + b @ w['B'] + w['c'])
+        m = 1.0 + tau @ w['C']
+        h = t * m
+        sg = 1.0 / (1.0 + np.exp(-(h @ w['Ws'])))
+        tq = np.tanh(h @ w['Wq'])
+        return (self.s * (sg - 0.5), h @ w['Wt'] + w['bt'], self.q * tq), dict(a=a, b=b, tau=tau, t=t, m=m, h=h, sg=sg, tq=tq)
+
+    def bwd(self, c, dS, dT, dQ):
+        w, g = self.w, self.grads
+        dzs = dS * self.s * c['sg'] * (1.0 - c['sg'])
+        dzq = dQ * self.q * (1.0 - c['tq'] ** 2)
+        g['Ws'] += c['h'].T @ dzs
+        g['Wt'] += c['h'].T @ dT
+        g['bt'] += dT.sum(0)
+        g['Wq'] += c['h'].T @ dzq
+        dh = dzs @ w['Ws'].T + dT @ w['Wt'].T + dzq @ w['Wq'].T
+        g['C'] += c['tau'].T @ (dh * c['t'])
+        dpre = dh * c['m'] * (1.0 - c['t'] ** 2)
+        g['A'] += c['a'].T @ dpre
+        g['B'] += c['b'].T @ dpre
+        g['c'] += dpre.sum(0)
+        return dpre @ w['A'].T, dpre @ w['B'].T
+
+
 def _v_half(vin, g, S, T, Q, eps, sgn, fwd):
     ES, EQ = np.exp(sgn * 0.5 * eps * S), np.exp(eps * Q)
     cc = 0.5 * eps * (T - EQ * g)
@@ -231,8 +279,8 @@ def propose_loss_and_grad(x0, v0, direction, target, xnet, vnet, eps, mask, T, s
     N, d = x0.shape
     # (the fixtures' weights ARE float32; a training replay in `dtype` -- tools/ess_seed_study.py -- keeps its own precision)
     wt = np.float32 if float32_weights else dtype
-    xn = {k: np.asarray(xnet[k], wt).astype(dtype) for k in NET_KEYS}
-    vn = {k: np.asarray(vnet[k], wt).astype(dtype) for k in NET_KEYS}
+    xn = xnet if hasattr(xnet, 'fwd') else {k: np.asarray(xnet[k], wt).astype(dtype) for k in NET_KEYS}
+    vn = vnet if hasattr(vnet, 'fwd') else {k: np.asarray(vnet[k], wt).astype(dtype) for k in NET_KEYS}
     eps = dtype(eps)
     mask = np.asarray(mask, dtype)
     fwd = (np.asarray(direction) != 0)[:, None]
@@ -251,14 +299,14 @@ def propose_loss_and_grad(x0, v0, direction, target, xnet, vnet, eps, mask, T, s
         k1 = np.where(fwd, m, 1 - m)
         k2 = 1 - k1
         g1 = gradU(x)
-        (S1, T1, Q1), c1 = _net_fwd(vn, x, g1, tau)
+        (S1, T1, Q1), c1 = _fwd(vn, x, g1, tau)
         vh, a1 = _v_half(v, g1, S1, T1, Q1, eps, sgn, fwd)
-        (Sa, Ta, Qa), ca = _net_fwd(xn, vh, k1 * x, tau)
+        (Sa, Ta, Qa), ca = _fwd(xn, vh, k1 * x, tau)
         y, aa = _x_half(x, k1, vh, Sa, Ta, Qa, eps, sgn, fwd)
-        (Sb, Tb, Qb), cb = _net_fwd(xn, vh, k2 * y, tau)
+        (Sb, Tb, Qb), cb = _fwd(xn, vh, k2 * y, tau)
         xo, ab = _x_half(y, k2, vh, Sb, Tb, Qb, eps, sgn, fwd)
         g2 = gradU(xo)
-        (S2, T2, Q2), c2 = _net_fwd(vn, xo, g2, tau)
+        (S2, T2, Q2), c2 = _fwd(vn, xo, g2, tau)
         vo, a2 = _v_half(vh, g2, S2, T2, Q2, eps, sgn, fwd)
         ld = ld + np.sum(sgn * 0.5 * eps * (S1 + S2) + k2 * sgn * eps * Sa + k1 * sgn * eps * Sb, axis=1)
         tape.append(dict(x=x, v=v, k1=k1, k2=k2, g1=g1, c1=c1, a1=a1, vh=vh, ca=ca, aa=aa, y=y,
@@ -281,8 +329,8 @@ def propose_loss_and_grad(x0, v0, direction, target, xnet, vnet, eps, mask, T, s
     lx = (dv1 * p)[:, None] * 2 * (x - x0) - dval[:, None] * gradU(x)
     lv = -dval[:, None] * v
     lam_ld = dval[:, None]
-    gx = {k: np.zeros_like(xn[k]) for k in NET_KEYS}
-    gv = {k: np.zeros_like(vn[k]) for k in NET_KEYS}
+    gx = xn.grads if hasattr(xn, 'fwd') else {k: np.zeros_like(xn[k]) for k in NET_KEYS}
+    gv = vn.grads if hasattr(vn, 'fwd') else {k: np.zeros_like(vn[k]) for k in NET_KEYS}
     deps = np.zeros(N, dtype)
     for it in reversed(range(T)):
         t = tape[it]
@@ -290,24 +338,24 @@ def propose_loss_and_grad(x0, v0, direction, target, xnet, vnet, eps, mask, T, s
         # v' = v_half(vh, g2, V(x', g2))
         dvh, dg2, dS, dT, dQ, de = _v_half_bwd(lv, lam_ld, t['vh'], t['g2'], S2, T2, Q2, eps, sgn, fwd, t['a2'])
         deps += de
-        da, db = _net_bwd(vn, t['c2'], dS, dT, dQ, gv)
+        da, db = _bwd(vn, t['c2'], dS, dT, dQ, gv)
         dxo = lx + da + target.hessvec(t['xo'], dg2 + db)
         # x' = x_half(y, k2, vh, X(vh, k2 y))
         dy, dvh2, dS, dT, dQ, de = _x_half_bwd(dxo, lam_ld, t['y'], t['k2'], t['vh'], Sb, Tb, Qb, eps, sgn, fwd, t['ab'])
         deps += de
-        da, db = _net_bwd(xn, t['cb'], dS, dT, dQ, gx)
+        da, db = _bwd(xn, t['cb'], dS, dT, dQ, gx)
         dvh = dvh + dvh2 + da
         dy = dy + t['k2'] * db
         # y = x_half(x, k1, vh, X(vh, k1 x))
         dx, dvh2, dS, dT, dQ, de = _x_half_bwd(dy, lam_ld, t['x'], t['k1'], t['vh'], Sa, Ta, Qa, eps, sgn, fwd, t['aa'])
         deps += de
-        da, db = _net_bwd(xn, t['ca'], dS, dT, dQ, gx)
+        da, db = _bwd(xn, t['ca'], dS, dT, dQ, gx)
         dvh = dvh + dvh2 + da
         dx = dx + t['k1'] * db
         # vh = v_half(v, g1, V(x, g1))
         dv, dg1, dS, dT, dQ, de = _v_half_bwd(dvh, lam_ld, t['v'], t['g1'], S1, T1, Q1, eps, sgn, fwd, t['a1'])
         deps += de
-        da, db = _net_bwd(vn, t['c1'], dS, dT, dQ, gv)
+        da, db = _bwd(vn, t['c1'], dS, dT, dQ, gv)
         lx = dx + da + target.hessvec(t['x'], dg1 + db)
         lv = dv
     return loss, x, p, {'xnet': gx, 'vnet': gv, 'eps': float(np.sum(deps))}

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_size_queries():
     L = _ffi.lib()
-    assert L.l2hmc_abi_version() == 5 == _ffi.ABI_VERSION
+    assert L.l2hmc_abi_version() == 6 == _ffi.ABI_VERSION
     hdr = open(os.path.join(ROOT, "include", "l2hmc.h")).read()
     assert int(re.search(r"#define L2HMC_ABI_VERSION (\d+)", hdr).group(1)) == _ffi.ABI_VERSION
     # MFMA fragments (5 NT + 2 groups of 256 + 32 NT scales per net) + the lane layout (traj_lane.hpp: rows of RS = 12)
@@ -70,7 +70,8 @@ def test_struct_layout_matches_header():
     # `net_mode` (round 5) took the padding behind `gemm_mode`: the callbacks that follow keep their offsets
     T = _ffi.L2hmcTrainSplitArgs
     assert T.net_mode.offset == T.gemm_mode.offset + 4 and T.energy_cb.offset == T.gemm_mode.offset + 8
-    assert ctypes.sizeof(T) == 312
+    # ABI 6: three trailing pointers (net_cb, net_vjp_cb, net_cb_user) -- every earlier offset is unchanged
+    assert T.net_cb.offset == 312 and T.net_cb_user.offset == 328 and ctypes.sizeof(T) == 336
 
 
 def test_struct_sizes_are_checked_against_the_library():

@@ -289,9 +289,10 @@ def test_arbitrary_net_callables_match_the_reference_fixtures(case):
     assert rel_err(to_np(Lx), g["prop.Lx"]) < traj and abs_err(to_np(px), g["prop.px"]) < P_TOL
     from tests.helpers import check_x_next
     check_x_next(to_np(outs[0]), g["x"], g["prop.Lx"], g["prop.px"], g["prop.u"], P_TOL)
-    # ... and the trainers say what they differentiate instead of crashing
+    # ... and the trainer says what it needs instead of crashing: these lambdas expose no variables (round 6 trains caller-supplied
+    # nets that do -- tests/test_gpu_round6.py)
     from l2hmc_amd.training import Trainer
-    with pytest.raises(NotImplementedError, match="arbitrary callables"):
+    with pytest.raises(ValueError, match="expose no parameters"):
         Trainer(dyn)
 
 

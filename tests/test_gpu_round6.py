@@ -54,3 +54,148 @@ def test_stiff_fixtures_sit_in_the_float64_bracket_on_every_kernel_family(case):
         chk("prop.px", px, P_TOL)
         report[var] = worst
     print("%s: worst (|hip - fp64| / gate) per variant: %s" % (case, {k: round(v, 2) for k, v in report.items()}))
+
+
+# ---- training an arbitrary net_factory (include/l2hmc.h ABI 6: L2hmcTrainSplitArgs.net_cb / net_vjp_cb) ---------------------------
+class _Opaque(object):
+    """the same function and the same variables as `net`, with nothing for l2hmc_amd.layers.extract_stq to recognise"""
+
+    def __init__(self, net):
+        self._net = net
+
+    def __call__(self, inp):
+        return self._net(inp)
+
+    def parameters(self):
+        return self._net.parameters()
+
+
+def _draws(g):
+    return {"z": g["z"], "x_dir": g["x.dir"], "z_dir": g["z.dir"],
+            "x_v": np.where(g["x.dir"][:, None] != 0, g["x.v_fwd"], g["x.v_bwd"]),
+            "z_v": np.where(g["z.dir"][:, None] != 0, g["z.v_fwd"], g["z.v_bwd"])}
+
+
+@pytest.mark.parametrize("case", ["train_tilted8_h24", "train_icg50", "train_mog2d", "train_rough6"])
+def test_training_an_opaque_copy_of_the_fixture_nets_reproduces_the_reference_graph_gradient(case):
+    """/root/reference/utils/dynamics.py:78-79 takes any callable from `net_factory` and SCGExperiment.ipynb raw 178-181 minimises the
+    loss over whatever variables it created.  Here the fixture's OWN nets are handed over as opaque objects: the Dynamics
+    cannot fuse them, `Trainer` takes the GEMM-engine trainer with the nets' forward AND reverse evaluated by the caller's
+    torch code between the library's launches (net_cb / net_vjp_cb) -- and must reproduce tf.gradients of the reference's own
+    graph per tensor at the suite's gates (2e-4 of each tensor's max), loss 1e-4, proposals 2e-4, accept 1e-4."""
+    import torch
+    from l2hmc_amd import Dynamics
+    from l2hmc_amd.training import SplitTrainer, Trainer
+    from tests.helpers import check_grads_per_tensor, fixture_grads, hip_energy
+    g = load(case)
+    d, T = int(g["x_dim"]), int(g["T"])
+    fused = hip_dynamics(g)                               # builds the recognised nets with the fixture's weights ...
+    nets = {"XNet": _Opaque(fused.XNet), "VNet": _Opaque(fused.VNet)}
+    dyn = Dynamics(d, hip_energy(g), T=T, eps=float(g["eps"]), net_factory=lambda x_dim, scope, factor: nets[scope])
+    assert dyn._user_nets and dyn._split
+    dyn.mask = g["mask"]
+    with torch.no_grad():
+        dyn.alpha.fill_(float(np.log(g["eps"])))
+    tr = Trainer(dyn)
+    assert isinstance(tr, SplitTrainer) and tr.unets
+    loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=_draws(g))
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    assert rel_err(to_np(Lx), g["Lx"]) < 2e-4 and abs_err(to_np(px), g["px"]) < P_TOL
+    got = {"alpha": float(dyn.alpha.grad)}
+    for n, w in (("xnet", fused._xw), ("vnet", fused._vw)):      # (the SAME Parameter objects the opaque nets hold)
+        for k in O.NET_KEYS:
+            got[n + "." + k] = to_np(w[k].grad)
+    worst = check_grads_per_tensor(case + " (opaque nets)", got, fixture_grads(g))
+    print("%s, nets by callback: loss %.6e (ref %.6e)  worst tensor %s at %.2f of its gate" % (case, float(loss), float(g["loss"]), worst[1], worst[0]))
+    # ... bitwise reproducible, and a few optimiser steps run and move the variables
+    flat1 = tr.flat.clone()
+    tr.loss_and_grad(to_dev(g["x"]), draws=_draws(g))
+    assert torch.equal(flat1, tr.flat)
+    theta0 = tr.theta.clone()
+    x = to_dev(g["x"])
+    for _ in range(3):
+        x = tr.step(x)[2]
+    assert torch.isfinite(x).all() and torch.isfinite(tr.theta).all() and not torch.equal(theta0, tr.theta)
+    assert float((fused._xw["W1"].detach() - tr.theta[:fused._xw["W1"].numel()].view_as(fused._xw["W1"])).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("energy_by", ["builtin", "closure"])
+def test_training_a_net_outside_the_notebook_architecture_matches_the_float64_oracle(energy_by):
+    """A structure the fused kernels do not have (one tanh layer whose output is multiplied by a function of the time input, S
+    bounded by a sigmoid, Q through a tanh; oracle/l2hmc_train_oracle.py `TanhSigmoidNet`, hand-derived reverse mode pinned by
+    finite differences on the CPU) written as torch Modules for the product: the notebook loss and its gradient w.r.t. every
+    Module parameter and alpha against the float64 oracle, on a built-in Gaussian and on the same target as a caller-supplied
+    torch closure (energy_cb + hvp_cb + net_cb + net_vjp_cb: everything but the leapfrog arithmetic is the caller's)."""
+    import torch
+    from oracle import l2hmc_train_oracle as TO
+    from l2hmc_amd import Dynamics, distributions as D
+    from l2hmc_amd.training import SplitTrainer, Trainer
+    from tests.helpers import check_grads_per_tensor
+    d, N, T, eps, Hh = 6, 80, 5, 0.12, 12
+    rng = np.random.RandomState(11)
+    shapes = (("A", (d, Hh)), ("B", (d, Hh)), ("c", (Hh,)), ("C", (2, Hh)), ("Ws", (Hh, d)), ("Wt", (Hh, d)), ("bt", (d,)), ("Wq", (Hh, d)))
+    W = {net: {k: (0.35 * rng.randn(*shp)).astype(np.float32) for k, shp in shapes} for net in ("XNet", "VNet")}
+    scal = {"XNet": (0.8, 0.5), "VNet": (0.4, 0.3)}
+
+    class Net(torch.nn.Module):
+        def __init__(self, w, s, q):
+            super().__init__()
+            for k, v in w.items():
+                setattr(self, k, torch.nn.Parameter(to_dev(v)))
+            self.s, self.q = s, q
+
+        def forward(self, inp):
+            a, b, tau, aux = inp
+            h = torch.tanh(a @ self.A + b @ self.B + self.c) * (1.0 + tau @ self.C)
+            return [self.s * (torch.sigmoid(h @ self.Ws) - 0.5), h @ self.Wt + self.bt, self.q * torch.tanh(h @ self.Wq)]
+    mods = {k: Net(W[k], *scal[k]) for k in W}
+    prec = np.diag(np.exp(np.linspace(-1, 1, d))).astype(np.float32)
+    mu = (0.2 * rng.randn(d)).astype(np.float32)
+    mask = O.init_mask(T, d, np.random.RandomState(2))
+    g = {"x": rng.randn(N, d).astype(np.float32), "z": rng.randn(N, d).astype(np.float32), "eps": np.float32(eps), "mask": mask, "T": T}
+    for pre in ("x.", "z."):
+        g[pre + "dir"] = rng.randint(0, 2, N).astype(np.uint8)
+        g[pre + "v_fwd"] = rng.randn(N, d).astype(np.float32)
+        g[pre + "v_bwd"] = rng.randn(N, d).astype(np.float32)
+    # float64 oracle: the two proposals' loss terms and gradients add (nb raw 156-169)
+    on = {k: TO.TanhSigmoidNet(W[k], *scal[k]) for k in W}
+    target = TO.GaussianTarget(mu, prec, np.float64)
+    ref_loss, ref_alpha, rLx, rpx = 0.0, 0.0, None, None
+    for tag in ("x", "z"):
+        dr = g[tag + ".dir"]
+        v0 = np.where(dr[:, None] != 0, g[tag + ".v_fwd"], g[tag + ".v_bwd"])
+        ls, Lx_, p_, gr = TO.propose_loss_and_grad(g[tag], v0, dr, target, on["XNet"], on["VNet"], g["eps"], mask, T)
+        ref_loss += ls
+        ref_alpha += gr["eps"] * float(g["eps"])
+        if tag == "x":
+            rLx, rpx = Lx_, p_
+    ref = {"%s.%s" % (n, k): on[n].grads[k] for n in on for k in TO.TanhSigmoidNet.KEYS}
+    ref["alpha"] = ref_alpha
+    if energy_by == "builtin":
+        gauss = D.Gaussian.__new__(D.Gaussian)
+        gauss.mu, gauss.sigma, gauss.i_sigma = mu, None, prec
+        energy = gauss.get_energy_function()
+    else:
+        mu_t, prec_t = to_dev(mu), to_dev(prec)
+
+        def energy(x):
+            dx = x - mu_t
+            return 0.5 * ((dx @ prec_t) * dx).sum(1)
+    dyn = Dynamics(d, energy, T=T, eps=eps, net_factory=lambda x_dim, scope, factor: mods[scope])
+    assert dyn._user_nets
+    dyn.mask = mask
+    tr = Trainer(dyn)
+    assert isinstance(tr, SplitTrainer) and tr.unets and tr.user == (energy_by == "closure")
+    loss, Lx, px = tr.loss_and_grad(to_dev(g["x"]), draws=_draws(g))
+    assert abs(float(loss) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (float(loss), ref_loss)
+    assert rel_err(to_np(Lx), rLx) < 2e-4 and abs_err(to_np(px), rpx) < P_TOL
+    got = {"%s.%s" % (n, k): to_np(getattr(mods[n], k).grad) for n in mods for k in TO.TanhSigmoidNet.KEYS}
+    got["alpha"] = float(dyn.alpha.grad)
+    worst = check_grads_per_tensor("TanhSigmoidNet / " + energy_by, got, ref)
+    print("non-notebook nets, energy %s: loss %.6e (ref %.6e)  worst tensor %s at %.2f of its gate" % (energy_by, float(loss), ref_loss, worst[1], worst[0]))
+    # state_dict names the Module parameters under their scope; an optimiser step updates the Modules' own tensors
+    sd = dyn.state_dict()
+    assert "XNet/A" in sd and "VNet/Wq" in sd and "alpha" in sd
+    before = mods["XNet"].A.detach().clone()
+    tr.step(to_dev(g["x"]))
+    assert not torch.equal(before, mods["XNet"].A.detach())

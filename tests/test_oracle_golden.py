@@ -423,3 +423,40 @@ def test_stiff_fixtures_sit_in_the_float64_bracket(case):
         base = P_TOL if prob else (STEP_TOL if "step" in key else TRAJ_TOL)
         e = (abs_err if prob else rel_err)(g[key], truth[key])
         assert e <= 3.0 * e32[key] + base, (case, key, e, e32[key])
+
+
+def test_generic_net_protocol_of_the_training_oracle_by_finite_differences():
+    """oracle/l2hmc_train_oracle.py takes nets outside the notebook's architecture as objects with fwd / bwd (`TanhSigmoidNet`: the
+    yardstick of tests/test_gpu_round6.py's arbitrary-net training test).  Its hand-derived reverse mode -- and the generic path
+    through `propose_loss_and_grad` -- against central differences of the float64 loss: every parameter tensor's largest entry and
+    three random ones, eps too."""
+    from oracle import l2hmc_train_oracle as TO
+    d, N, T, eps, Hh = 4, 24, 3, 0.15, 7
+    rng = np.random.RandomState(3)
+    shapes = (("A", (d, Hh)), ("B", (d, Hh)), ("c", (Hh,)), ("C", (2, Hh)), ("Ws", (Hh, d)), ("Wt", (Hh, d)), ("bt", (d,)), ("Wq", (Hh, d)))
+    W = {net: {k: 0.4 * rng.randn(*shp) for k, shp in shapes} for net in ("X", "V")}
+    prec = np.diag(np.exp(np.linspace(-0.5, 0.5, d)))
+    target = TO.GaussianTarget(0.1 * rng.randn(d), prec, np.float64)
+    mask = O.init_mask(T, d, np.random.RandomState(1))
+    x0, v0 = rng.randn(N, d), rng.randn(N, d)
+    dr = rng.randint(0, 2, N)
+
+    def loss_of(Wd, e):
+        xn, vn = TO.TanhSigmoidNet(Wd["X"], 0.7, 0.4), TO.TanhSigmoidNet(Wd["V"], 0.5, 0.3)
+        ls, _, p, gr = TO.propose_loss_and_grad(x0, v0, dr, target, xn, vn, e, mask, T)
+        return ls, xn.grads, vn.grads, gr["eps"], p
+    ls, gx, gv, ge, p = loss_of(W, eps)
+    assert 0.05 < p.mean() < 0.999
+    h = 1e-6
+    for net, gr in (("X", gx), ("V", gv)):
+        for k, shp in shapes:
+            idx = [np.unravel_index(np.abs(gr[k]).argmax(), gr[k].shape)] + [tuple(rng.randint(0, s) for s in shp) for _ in range(3)]
+            for i in idx:
+                Wp = {n: {kk: v.copy() for kk, v in W[n].items()} for n in W}
+                Wm = {n: {kk: v.copy() for kk, v in W[n].items()} for n in W}
+                Wp[net][k][i] += h
+                Wm[net][k][i] -= h
+                fd = (loss_of(Wp, eps)[0] - loss_of(Wm, eps)[0]) / (2 * h)
+                assert abs(fd - gr[k][i]) < 1e-5 * max(1.0, np.abs(gr[k]).max()), (net, k, i, fd, gr[k][i])
+    fd = (loss_of(W, eps + h)[0] - loss_of(W, eps - h)[0]) / (2 * h)
+    assert abs(fd - ge) < 1e-5 * max(1.0, abs(ge)), (fd, ge)
