@@ -142,6 +142,9 @@ class Dynamics(object):
                                       "or a caller-supplied energy")
         self._split_ws = None
         self._split_key, self._split_aux, self._last_reuse = None, (None, -1), 0
+        self._slot1 = [None, None, (None, -1), 0]      # the same four for the second half-batch (`split_streams`)
+        self._side_stream = None
+        self.split_streams = 2          # GEMM engine, decoder posterior: 2 = two half-batches on two HIP streams from 6144 chains; 1 = off
 
     # ---- masks / time encoding -----------------------------------------------------------------
     def _init_mask(self):
@@ -165,6 +168,8 @@ class Dynamics(object):
         self.__dict__['_pk'] = value
         if value is None:
             self.__dict__['_split_key'] = None
+            if '_slot1' in self.__dict__:
+                self._slot1[1] = None
 
     def invalidate_caches(self):
         """Forget every prepared copy of the parameters (the packed MFMA fragments of the fused kernels, the transposed
@@ -176,6 +181,7 @@ class Dynamics(object):
         need nothing.)"""
         self._packed_key = None
         self._split_aux = (None, -1)
+        self._slot1[2] = (None, -1)
 
     @property
     def mask(self):
@@ -374,6 +380,46 @@ class Dynamics(object):
             direction = direction.to(device=x.device, dtype=torch.uint8).contiguous()
         if u is not None:
             u = as_device_f32(u, self.device)
+        # Two half-batches on two HIP streams (round 6; DESIGN section 3b "two streams"): chains never interact, so rows [0, h)
+        # and [h, N) are two independent trajectories.  Alone, every decoder-sized product is 256 tiles on 256 CUs marching in
+        # phase -- 70 us of matrix pipe, then 20 us in which all of them write their epilogues at HBM speed with the pipe idle.
+        # Side by side (128 tiles each) one half's HBM-bound phases -- epilogues, the K = 50 / N = 50 products, the update
+        # kernels -- fall under the other half's MFMA-bound ones.  Only for the built-in decoder posterior (no host callbacks
+        # between the launches) and from 2 x 3072 chains, so that each half still takes the pre-split-planes form.
+        h = (N // 2 + 255) // 256 * 256
+        if int(self.split_streams) >= 2 and self._vae and not self.hmc and h >= 3072 and N - h >= 3072:
+            cur = torch.cuda.current_stream(x.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=x.device)
+            side = self._side_stream
+            side.wait_stream(cur)                       # (the inputs were produced on the caller's stream)
+
+            def rows(t, lo, hi):
+                return None if t is None else t[lo:hi]
+            self._launch_split(x[:h], v[:h], step_begin, n_steps, rows(direction, 0, h), direction_all, rows(u, 0, h),
+                               aux[:h], {k: t[:h] for k, t in out.items()})
+            with torch.cuda.stream(side):
+                self._swap_slot()
+                try:
+                    self._launch_split(x[h:], v[h:], step_begin, n_steps, rows(direction, h, N), direction_all, rows(u, h, N),
+                                       aux[h:], {k: t[h:] for k, t in out.items()})
+                finally:
+                    self._swap_slot()
+            cur.wait_stream(side)                       # (the results are consumed on the caller's stream)
+            return out
+        self._launch_split(x, v, step_begin, n_steps, direction, direction_all, u, aux, out)
+        return out
+
+    def _swap_slot(self):
+        """exchange the GEMM engine's workspace + its reuse keys with those of the second half-batch"""
+        cur = [self._split_ws, self.__dict__.get('_split_key'), self._split_aux, self._last_reuse]
+        (self._split_ws, self.__dict__['_split_key'], self._split_aux, self._last_reuse), self._slot1 = self._slot1, cur
+
+    def _launch_split(self, x, v, step_begin, n_steps, direction, direction_all, u, aux, out):
+        """ONE `l2hmc_trajectory_split` call on torch's current stream: (N, d) row blocks in, `out`'s tensors filled"""
+        import ctypes as C
+        from .vae import mlp3_struct
+        N, d = x.shape
         dec = mlp3_struct(self._fn.decoder) if self._vae else None
         if self.hmc or self._user_nets:               # (HMC, either direction: the inverse leapfrog is the step with -eps)
             xs = vs = enc = None
@@ -468,7 +514,6 @@ class Dynamics(object):
         _ffi.check(rc)
         self._split_key = wkey
         self._split_aux = (aux, self._aux_key(aux)) if (img and aux is not None) else (None, -1)
-        return out
 
     def _run_split_chain(self, x, v, step_begin, n_steps, direction, direction_all, u, want, M, rng, aux):
         """M chained proposals on the split engine (the sampler loop of mnist_vae.py:185-224 / eval_sampler.py): a

@@ -199,3 +199,43 @@ def test_training_a_net_outside_the_notebook_architecture_matches_the_float64_or
     before = mods["XNet"].A.detach().clone()
     tr.step(to_dev(g["x"]))
     assert not torch.equal(before, mods["XNet"].A.detach())
+
+
+# ---- config 5: two half-batches on two HIP streams (Dynamics.split_streams) ------------------------------------------------------------
+def test_config5_two_stream_halves_equal_the_single_stream_batch():
+    """BASELINE config 5's shapes at 8192 chains: `Dynamics.split_streams = 2` runs rows [0, 4096) and [4096, 8192) as two
+    independent trajectories on two HIP streams (chains never interact; one half's HBM-bound epilogues fall under the other's
+    MFMA-bound main loops).  Same draws -> the same proposal, accept probability and MH-selected state as the single-stream
+    launch: every chain's arithmetic is its own row of every product (gates: float32 rounding of a different tile shape of the
+    net kernels at 4096 vs 8192 chains, 2e-6 / 2e-6; bit-equal in practice is reported), twice in a row (workspace reuse keys of
+    both halves), and the side stream's work is ordered before the caller's next use of the results."""
+    import torch
+    from l2hmc_amd import propose
+    from tests.helpers import synthetic_vae_case
+    N = 8192
+    g = synthetic_vae_case(N=N, seed=7)
+    rng = np.random.RandomState(3)
+    direction = to_dev(rng.randint(0, 2, size=N).astype(np.uint8))
+    v, u = to_dev(rng.randn(N, 50).astype(np.float32)), to_dev(rng.rand(N).astype(np.float32))
+    x, aux = to_dev(g["x"]), to_dev(g["aux"])
+    res = {}
+    for streams in (1, 2):
+        dyn = hip_dynamics(g)
+        dyn.split_streams = streams
+        outs = []
+        xx = x
+        for rep in range(2):
+            Lx, _, px, o = propose(xx, dyn, do_mh_step=True, direction=direction, v=v, u=u, aux=aux)
+            outs.append((to_np(Lx), to_np(px), to_np(o[0])))     # (read on the caller's stream right away: the join must hold)
+            xx = o[0]
+        res[streams] = outs
+        assert (dyn._slot1[0] is not None) == (streams == 2)
+        if streams == 2:
+            assert dyn._last_reuse == 3 and dyn._slot1[3] == 3           # second proposal: weights and image branch kept, both halves
+    for rep in range(2):
+        a, b = res[1][rep], res[2][rep]
+        fin = np.all(np.isfinite(a[0]), axis=1)
+        print("rep %d: |dLx| %.1e  |dp| %.1e  bit-equal %s" % (rep, np.abs(a[0][fin] - b[0][fin]).max(), np.abs(a[1] - b[1]).max(),
+                                                            np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])))
+        assert rel_err(b[0][fin], a[0][fin]) < (2e-6 if rep == 0 else 2e-4) and abs_err(b[1], a[1]) < (2e-6 if rep == 0 else 2e-4)
+    assert 0.05 < res[2][0][1].mean() < 0.999

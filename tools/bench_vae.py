@@ -18,6 +18,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 g = synthetic_vae_case(N=N, seed=0)
 dyn = hip_dynamics(g)
 dyn.gemm_mode = int(sys.argv[2]) if len(sys.argv) > 2 else dyn.gemm_mode      # 0 = f32-input MFMA, 1 = bf16x3
+dyn.split_streams = int(os.environ.get("L2HMC_SPLIT_STREAMS", dyn.split_streams))   # 2 = two half-batches on two streams (round 6), 1 = off
 x, aux = to_dev(g["x"]), to_dev(g["aux"])
 gen = torch.Generator(device="cuda").manual_seed(0)
 dyn.generator = gen
@@ -34,6 +35,6 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 T = int(g["T"])
 flops = 4 * 2 * (50 * 200 * 2 + 200 * 200 + 200 * 150) + (1 + 1.0 / T) * 2 * 2 * (50 * 1024 + 1024 * 1024 + 1024 * 784)
-print("gemm_mode %d | " % dyn.gemm_mode, end="")
+print("gemm_mode %d streams %d | " % (dyn.gemm_mode, dyn.split_streams), end="")
 print("config 5, %d chains: %.2f ms per proposal (Lf=%d) = %.3e chain-leapfrog-steps/s; ~%.1f TFLOP/s of %.2e flop/chain-step; mean accept %.3f"
       % (N, 1e3 * el / K, T, N * T * K / el, N * T * K / el * flops / 1e12, flops, float(px.mean())))
