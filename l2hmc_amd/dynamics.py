@@ -144,7 +144,12 @@ class Dynamics(object):
         self._split_key, self._split_aux, self._last_reuse = None, (None, -1), 0
         self._slot1 = [None, None, (None, -1), 0]      # the same four for the second half-batch (`split_streams`)
         self._side_stream = None
-        self.split_streams = 2          # GEMM engine, decoder posterior: 2 = two half-batches on two HIP streams from 6144 chains; 1 = off
+        # GEMM engine, decoder posterior: 2 = two half-batches on two HIP streams from 6144 chains.  OFF (1) by default: measured
+        # 3.38 ms against 3.09 ms per proposal at config 5 (profiles/r06_config5_two_streams.txt) -- a half-size plane product
+        # takes 75 us alone against 90 us for the full one, two of them side by side 91 + 103 us: the main loop is not bound by
+        # the CU it runs on (the chip clocks down as the matrix pipes fill), so there is no idle pipe for the other half's
+        # HBM-bound phases to hide under.
+        self.split_streams = 1
 
     # ---- masks / time encoding -----------------------------------------------------------------
     def _init_mask(self):
@@ -380,12 +385,12 @@ class Dynamics(object):
             direction = direction.to(device=x.device, dtype=torch.uint8).contiguous()
         if u is not None:
             u = as_device_f32(u, self.device)
-        # Two half-batches on two HIP streams (round 6; DESIGN section 3b "two streams"): chains never interact, so rows [0, h)
-        # and [h, N) are two independent trajectories.  Alone, every decoder-sized product is 256 tiles on 256 CUs marching in
-        # phase -- 70 us of matrix pipe, then 20 us in which all of them write their epilogues at HBM speed with the pipe idle.
-        # Side by side (128 tiles each) one half's HBM-bound phases -- epilogues, the K = 50 / N = 50 products, the update
-        # kernels -- fall under the other half's MFMA-bound ones.  Only for the built-in decoder posterior (no host callbacks
-        # between the launches) and from 2 x 3072 chains, so that each half still takes the pre-split-planes form.
+        # Two half-batches on two HIP streams (round 6 experiment, `split_streams = 2`; off by default -- see __init__): chains
+        # never interact, so rows [0, h) and [h, N) are two independent trajectories.  Alone, every decoder-sized product is 256
+        # tiles on 256 CUs marching in phase -- 70 us of matrix pipe, then 20 us in which all of them write their epilogues at
+        # HBM speed with the pipe idle; the idea was that side by side (128 tiles each) one half's HBM-bound phases fall under
+        # the other half's MFMA-bound ones.  Only for the built-in decoder posterior (no host callbacks between the launches)
+        # and from 2 x 3072 chains, so that each half still takes the pre-split-planes form.
         h = (N // 2 + 255) // 256 * 256
         if int(self.split_streams) >= 2 and self._vae and not self.hmc and h >= 3072 and N - h >= 3072:
             cur = torch.cuda.current_stream(x.device)
