@@ -331,7 +331,8 @@ typedef struct L2hmcSplitArgs {
                                   *    2: the same six products with the split inside the k loop at every size -- bit-identical
                                   *       results to mode 1 (the planes only move where the split happens); kept for tests and A/B */
   L2hmcNetCallback net_cb;       /* (ABI 5) non-NULL: the caller's nets (see L2hmcNetCallback); xnet = vnet = aux_encoder = NULL,
-                                  *    H is ignored, hmc = 0.  Goes with energy_cb or a built-in energy.                 */
+                                  *    H is ignored, hmc = 0.  With any target: energy_cb, a built-in energy, or (round 6) the
+                                  *    decoder posterior -- the callback's nets then read the images on their own           */
   void* net_cb_user;             /* passed back as the callback's first argument                                         */
 } L2hmcSplitArgs;
 
@@ -505,8 +506,8 @@ typedef struct L2hmcTrainSplitArgs {
   L2hmcEnergyCallback energy_cb; /* U / grad U at a trajectory point (as in L2hmcSplitArgs), or NULL              */
   L2hmcHvpCallback hvp_cb;       /* its Hessian-vector product; required with energy_cb                          */
   void* energy_cb_user;          /* first argument of both callbacks                                              */
-  /* ---- (ABI 6) training caller-supplied nets: xnet = vnet = aux_encoder = NULL, H ignored; goes with a built-in `energy` or
-   *      with energy_cb + hvp_cb.  Every net evaluation of the forward pass is net_cb (final S | T | Q into the library's
+  /* ---- (ABI 6) training caller-supplied nets: xnet = vnet = aux_encoder = NULL, H ignored; with any target (a built-in
+   *      `energy`, energy_cb + hvp_cb, or the decoder posterior).  Every net evaluation of the forward pass is net_cb (final S | T | Q into the library's
    *      stash), every one of the reverse sweep net_vjp_cb; `grad` then holds ONE float, d loss / d eps (accumulated) --
    *      the nets' parameter gradients are accumulated by the callback on the caller's side ---------------------------- */
   L2hmcNetCallback net_cb;

@@ -505,8 +505,10 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   const bool builtin = a->energy != nullptr;        // a target of utils/distributions.py instead of the decoder posterior
   const bool unets = a->net_cb != nullptr;          // the caller's own S/T/Q nets (any callable, dynamics.py:69-79)
   int rc;
-  if (unets && (a->xnet || a->vnet || a->aux_encoder || a->hmc || !(user || builtin)))
-    return fail(L2HMC_ERR_ARG, "net_cb excludes xnet / vnet / aux_encoder / hmc and goes with energy_cb or a built-in energy%s");
+  // (round 6: also with the decoder posterior -- the caller's nets then receive the images themselves, e.g. two nets with
+  //  SEPARATE image branches, which the fused form does not have)
+  if (unets && (a->xnet || a->vnet || a->aux_encoder || a->hmc))
+    return fail(L2HMC_ERR_ARG, "net_cb excludes xnet / vnet / aux_encoder / hmc%s");
   if (user) {
     if (a->decoder || a->energy) return fail(L2HMC_ERR_ARG, "energy_cb excludes decoder and energy%s");
     if (a->bce_scale != 0.f) return fail(L2HMC_ERR_UNSUPPORTED, "bce_scale with a caller-supplied energy (anneal it in the callback)%s");

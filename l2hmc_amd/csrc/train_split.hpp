@@ -743,8 +743,8 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   int rc;
   if (unets) {
     if (!a->net_cb || !a->net_vjp_cb) return fail(L2HMC_ERR_ARG, "training caller-supplied nets needs BOTH net_cb and net_vjp_cb%s");
-    if (a->xnet || a->vnet || a->aux_encoder || vae)
-      return fail(L2HMC_ERR_ARG, "net_cb excludes xnet / vnet / aux_encoder and goes with a built-in energy or energy_cb + hvp_cb%s");
+    if (a->xnet || a->vnet || a->aux_encoder)
+      return fail(L2HMC_ERR_ARG, "net_cb excludes xnet / vnet / aux_encoder (an image branch is the caller's net's own business)%s");
   }
   const long long N = a->n_chains;
   const int d = a->d, H = unets ? 4 : a->H, T = a->T;     // (caller-supplied nets: no hidden activations are planned for)

@@ -99,8 +99,7 @@ class Dynamics(object):
             if self._xw is None or self._vw is None or self._xw['H'] != self._vw['H']:
                 # dynamics.py:69-79: `net_factory` may return ANY callable [a, b, tau, aux] -> [S, T, Q].  Only the notebook's
                 # architecture is fused into kernels; anything else is evaluated by the caller's own torch code between the
-                # library's launches (L2hmcSplitArgs.net_cb) -- the slow path, sampling only (the trainers differentiate the
-                # fused architecture).
+                # library's launches (L2hmcSplitArgs.net_cb; training: L2hmcTrainSplitArgs.net_vjp_cb) -- the slow path.
                 if not (callable(self.XNet) and callable(self.VNet)):
                     raise TypeError("net_factory must return callables net([a, b, tau, aux]) -> [S, T, Q]")
                 self._xw = self._vw = None
@@ -109,18 +108,21 @@ class Dynamics(object):
             else:
                 self.H = self._xw['H']
                 # mnist_vae.py:134-150 builds ONE `encoder_sampler` and hands it to both nets; the split engine
-                # evaluates that shared image branch once per trajectory.  Two different branches (or one net
-                # with a branch and one without) would silently run VNet on XNet's encoder: refuse.
+                # evaluates that shared image branch once per trajectory.
                 ax, av = self._xw['aux_encoder'], self._vw['aux_encoder']
-                if (ax is None) != (av is None) or (ax is not None and any(
-                        ax[k].data_ptr() != av[k].data_ptr() for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'))):
-                    raise NotImplementedError(
-                        "XNet and VNet must share ONE aux branch (the same encoder_sampler parameters, as in "
-                        "mnist_vae.py:134-150) or have none; separate image branches per net are not implemented")
                 for w in (self._xw, self._vw):
                     for k in _ffi.NET_FIELDS:
                         if w[k].device != self.device:
                             raise ValueError("net parameters live on %s, Dynamics on %s" % (w[k].device, self.device))
+                if (ax is None) != (av is None) or (ax is not None and any(
+                        ax[k].data_ptr() != av[k].data_ptr() for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'))):
+                    # Two DIFFERENT image branches (or one net with a branch and one without): the fused form evaluates ONE
+                    # shared branch per trajectory (mnist_vae.py:134-150 builds one `encoder_sampler` for both nets).  Round 6:
+                    # such nets are what they are -- callables -- and take the general path (evaluated by their own torch code
+                    # between the launches, each reading the images itself) instead of being refused.
+                    self._xw = self._vw = None
+                    self._user_nets = True
+                    self.H = 0
         self._packed = None
         self._packed_key = None
         # Engine choice: the single fused kernel covers the built-in targets with H <= 15 and no
@@ -133,9 +135,6 @@ class Dynamics(object):
         self._vae = energy_function.kind == ENERGY_VAE
         self._user = energy_function.kind == ENERGY_USER          # caller's torch code supplies U, grad U (slow path)
         self._split = self._vae or self._user or self._user_nets or (not self.hmc and self.H > 15)
-        if self._user_nets and self._vae:
-            raise NotImplementedError("caller-supplied nets go with a built-in energy of l2hmc_amd.distributions or a "
-                                      "caller-supplied energy callable (pass the VAE posterior as a plain closure)")
         self._aux_nets = (not self.hmc) and not self._user_nets and self._xw['aux_encoder'] is not None
         if not (self._vae or self._user) and self._aux_nets:
             raise NotImplementedError("an aux (image) branch is only implemented together with the VAE posterior energy "

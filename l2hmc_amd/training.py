@@ -568,7 +568,7 @@ class SplitTrainer(Trainer):
             # (set here, before the caller's autograd accumulates into them in place)
             for t, off, n in self.slots:
                 t.grad = self.flat[off:off + n].view(t.shape)
-            ncb, vcb = dyn._net_callbacks(self._ws, direction, aux, cb_error)
+            ncb, vcb = dyn._net_callbacks(self._ws, direction, None if aux is None else as_device_f32(aux, dyn.device), cb_error)
             keep_nets = (_ffi.NET_CALLBACK(ncb), _ffi.NET_VJP_CALLBACK(vcb))           # alive for the duration of the call
             a.net_cb, a.net_vjp_cb = C.cast(keep_nets[0], C.c_void_p), C.cast(keep_nets[1], C.c_void_p)
             a.H = 0

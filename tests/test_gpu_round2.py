@@ -126,9 +126,11 @@ def test_gmm_zero_weight_component_matches_logsumexp():
     assert rel_err(Ua, Ub) < 1e-6 and rel_err(ga, gb) < 1e-6
 
 
-def test_separate_aux_branches_are_refused():
-    """mnist_vae.py:134-150 shares ONE encoder_sampler between XNet and VNet; a factory that builds one per net
-    would silently run VNet on XNet's encoder: it must raise instead."""
+def test_separate_aux_branches_take_the_general_path():
+    """mnist_vae.py:134-150 shares ONE encoder_sampler between XNet and VNet, and that is what the fused form evaluates (once per
+    trajectory).  A factory that builds one image branch per net must not silently run VNet on XNet's encoder:
+    rounds 1-5 refused it, round 6 runs such nets as what they are -- callables, each evaluating its own branch -- on the
+    general path (tests/test_gpu_round6.py holds that path against the oracle)."""
     from l2hmc_amd import Dynamics, vae
     d, H = 6, 16
     dec = vae.make_decoder(d, 32, 20)
@@ -136,10 +138,10 @@ def test_separate_aux_branches_are_refused():
 
     def per_net_factory(x_dim, scope, factor):
         return vae.sampler_net_factory(d, vae.make_encoder_sampler(20, 24, H), H, H)(x_dim, scope=scope, factor=factor)
-    with pytest.raises(NotImplementedError, match="share ONE aux branch"):
-        Dynamics(d, energy, T=3, eps=0.1, net_factory=per_net_factory)
+    sep = Dynamics(d, energy, T=3, eps=0.1, net_factory=per_net_factory)
+    assert sep._user_nets and sep._split and sep._vae
     shared = vae.sampler_net_factory(d, vae.make_encoder_sampler(20, 24, H), H, H)
-    Dynamics(d, energy, T=3, eps=0.1, net_factory=shared)
+    assert not Dynamics(d, energy, T=3, eps=0.1, net_factory=shared)._user_nets
 
 
 def test_bench_dist_leg_over_rccl_world_size_1():
