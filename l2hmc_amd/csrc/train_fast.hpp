@@ -296,21 +296,31 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
 
   // ---- one net evaluation (forward): caches h1, h2, ts = tanh(zs), T, tq = tanh(zq) ------------------------------
   struct Cache { f4 h1, h2, ts, Tt, tq; };
-  auto net_fwd = [&](int net, f4 a, f4 b, f4 tbrow, Cache& C) {
+  // Layer 1 (this wave's K-split partial, then the cross-wave sum) and the rest of the evaluation are separate (round 6): the
+  // forward trajectory re-uses what the inference kernel re-uses (traj_fast.hpp) -- VNet's layer-1 sum at (x', grad U(x')) is
+  // the same at the end of step t and at the start of step t + 1 (only the time row differs), and both XNet evaluations of a
+  // step see the same v_h -- so a step costs 3 exchanges and 20 layer-1 MFMAs instead of 4 and 32.  The re-used values are
+  // the SAME MFMA chains on the same operands: results are bit-identical to evaluating them again.
+  struct TailF { f4 f2, fs, ft, fq; };
+  auto tail_frags = [&](int net) {
     const float* gb = net ? grpv : grpx;
-    f4 p = chain4(net ? l1va : l1xa, a, Z) + chain4(net ? l1vb : l1xb, b, Z);
     // (the fragments of the layers behind the cross-wave sum are requested BEFORE its barrier: LDS loads may not be moved
     //  across a barrier by the compiler, and their latency would otherwise sit on the chain after every exchange)
-    const f4 f2 = frag(gb, 0), fs = frag(gb, 2 + 3 * w + 0), ft = frag(gb, 2 + 3 * w + 1), fq = frag(gb, 2 + 3 * w + 2);
-    p = exch(p);
-    C.h1 = relu4i(p + tbrow);
-    C.h2 = relu4i(chainK(f2, C.h1, Z));
-    const f4 zs = chainK(fs, C.h2, Z);
-    const f4 zt = chainK(ft, C.h2, Z);
-    const f4 zq = chainK(fq, C.h2, Z);
+    return TailF{frag(gb, 0), frag(gb, 2 + 3 * w + 0), frag(gb, 2 + 3 * w + 1), frag(gb, 2 + 3 * w + 2)};
+  };
+  auto net_tail = [&](const TailF& F, f4 psum, f4 tbrow, Cache& C) {
+    C.h1 = relu4i(psum + tbrow);
+    C.h2 = relu4i(chainK(F.f2, C.h1, Z));
+    const f4 zs = chainK(F.fs, C.h2, Z);
+    const f4 zt = chainK(F.ft, C.h2, Z);
+    const f4 zq = chainK(F.fq, C.h2, Z);
     C.ts = tanh4(zs);
     C.Tt = zt;
     C.tq = tanh4(zq);
+  };
+  auto net_fwd_sum = [&](int net, f4 pa_part, f4 pb_part, f4 tbrow, Cache& C) {      // partials -> exchange -> tail
+    const TailF F = tail_frags(net);
+    net_tail(F, exch(pa_part + pb_part), tbrow, C);
   };
 
   // gradient tiles of one net (registers, whole reverse sweep)
@@ -424,20 +434,26 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   };
   // ---- forward trajectory with checkpoints -----------------------------------------------------------------------------
   Cache C;
+  f4 pvs = exch(chain4(l1va, x, Z) + chain4(l1vb, g, Z));         // VNet layer-1 sum at the start point
   for (int it = 0; it < T; ++it) {
     set_step(it);
-    net_fwd(1, x, g, tbv, C);
+    net_tail(tail_frags(1), pvs, tbv, C);                         // VNet at (x, grad U(x)): the sum the previous step ended on
     put_cache(it, 0, C);
     const f4 vh = v_half_f(C, v, g);
-    net_fwd(0, vh, k1 * x, tbx, C);
+    const f4 pa = chain4(l1xa, vh, Z);                            // shared by the step's two XNet evaluations
+    net_fwd_sum(0, pa, chain4(l1xb, k1 * x, Z), tbx, C);
     put_cache(it, 1, C);
     const f4 y = x_half_f(C, x, k1, vh);
-    net_fwd(0, vh, (splat(1.f) - k1) * y, tbx, C);
+    net_fwd_sum(0, pa, chain4(l1xb, (splat(1.f) - k1) * y, Z), tbx, C);
     put_cache(it, 2, C);
     const f4 xo = x_half_f(C, y, splat(1.f) - k1, vh);
     ckp(it, 0) = x; ckp(it, 1) = v; ckp(it, 2) = vh; ckp(it, 3) = y; ckp(it, 4) = xo;
     g = gradU(xo);
-    net_fwd(1, xo, g, tbv, C);
+    {
+      const TailF F = tail_frags(1);
+      pvs = exch(chain4(l1va, xo, Z) + chain4(l1vb, g, Z));
+      net_tail(F, pvs, tbv, C);
+    }
     put_cache(it, 3, C);
     v = v_half_f(C, vh, g);
     x = xo;

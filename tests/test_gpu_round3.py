@@ -613,8 +613,8 @@ def test_config4_rough_well_sweep_at_full_chain_count(d):
     ep_hip, ep_o32 = np.abs(to_np(px) - tpx)[fin], np.abs(rpx - tpx)[fin]
     print("rough well d=%d N=%d: x err vs fp64 hip 99%% %.1e max %.1e | oracle32 max %.1e ; p err hip max %.1e | oracle32 %.1e ; mean p %.3f"
           % (d, N, np.quantile(e_hip[fin], 0.99), e_hip[fin].max(), e_o32[fin].max(), ep_hip.max(), ep_o32.max(), float(tpx.mean())))
-    assert np.quantile(e_hip[fin], 0.99) < TRAJ_TOL and e_hip[fin].max() < 10 * e_o32[fin].max() + TRAJ_TOL
-    assert np.quantile(ep_hip, 0.99) < P_TOL and ep_hip.max() < 10 * ep_o32.max() + P_TOL
+    assert np.quantile(e_hip[fin], 0.99) < TRAJ_TOL and e_hip[fin].max() < 3 * e_o32[fin].max() + TRAJ_TOL
+    assert np.quantile(ep_hip, 0.99) < P_TOL and ep_hip.max() < 3 * ep_o32.max() + P_TOL
     check_x_next(to_np(outs[0])[fin], g["x"][fin], tLx[fin], tpx[fin], u[fin], 5 * P_TOL)
     # half batches: d <= 4 switches kernels at chain-count thresholds, so pin the variant the full batch took only where
     # both halves take the same automatic choice (8192 chains: 4-wave tile for d >= 33, same small / wide kernels otherwise)
