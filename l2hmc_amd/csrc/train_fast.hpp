@@ -362,9 +362,16 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     // (every wave used to compute both and three of four threw them away -- the slowest wave sets the pace)
     if (w == 0) G.w4 = chain4(transp(C.h1), transp(da2), G.w4);
     if (w == W_TAU) {
-      f4 tt;                                     // rows: 0 -> 1, 1 -> cos, 2 -> sin of chain 4 q + r
+      // rows: 0 -> 1, 1 -> cos, 2 -> sin of chain 4 q + r.  Branch-free (round 6): the (cos, sin) pairs of the lane's four chains
+      // are two unconditional ds_read_b128 and two fmas per component -- as `c == 1 ? scr[..] : ...` the compiler built
+      // twelve exec-masked blocks with a ds_read_b32 each, on the ONE wave that forms these rows (the slowest wave sets the pace)
+      const f4 cs01 = lds4(scr + 320 + 8 * q), cs23 = lds4(scr + 320 + 8 * q + 4);
+      const float cosv[4] = {cs01.x, cs01.z, cs23.x, cs23.z}, sinv[4] = {cs01.y, cs01.w, cs23.y, cs23.w};
+      // (0/1 lane weights instead of selects on c: the compiler lowers the ternary chain to a switch with exec-masked blocks)
+      const float l0 = c == 0 ? 1.f : 0.f, l1 = c == 1 ? 1.f : 0.f, l2 = c == 2 ? 1.f : 0.f;
+      f4 tt;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tt[r] = c == 0 ? 1.f : (c == 1 ? scr[320 + 2 * (4 * q + r)] : (c == 2 ? scr[320 + 2 * (4 * q + r) + 1] : 0.f));
+      for (int r = 0; r < 4; ++r) tt[r] = fmaf(l2, sinv[r], fmaf(l1, cosv[r], l0));
       G.tau = chain4(tt, tda1, G.tau);
     }
     TS_MARK(7);    // weight-gradient products (operand transposes + chain contractions)
