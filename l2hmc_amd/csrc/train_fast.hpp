@@ -323,7 +323,6 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     net_tail(F, exch(pa_part + pb_part), tbrow, C);
   };
 
-  const float lw0 = c == 0 ? 1.f : 0.f, lw1 = c == 1 ? 1.f : 0.f, lw2 = c == 2 ? 1.f : 0.f;
   // gradient tiles of one net (registers, whole reverse sweep)
   struct Acc { f4 hS, hT, hQ, w1, w2, w4, tau, lamS, lamQ; };
   Acc GX, GV;
@@ -357,34 +356,23 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     G.hT = chain4(transp(dzt), th2, G.hT);
     G.hQ = chain4(transp(dzq), th2, G.hQ);
     const f4 tda1 = transp(da1);
-    const float tda1w = NW == 4 ? scr[(4 * q + w) * 20 + c] : 0.f;    // component w of it again (the scratch still holds da1)
     G.w1 = chain4(transp(a), tda1, G.w1);
     G.w2 = chain4(transp(b), tda1, G.w2);
-    // The hidden vectors are the same in every wave, so the layer-2 tile and the time-embedding rows are needed ONCE per workgroup.
-    // Round 3 gave them to one wave each (every wave used to compute both and three of four threw them away); the waves are
-    // barrier-coupled, so those two waves set the pace.  Round 6: the contraction over the tile's 16 chains is four k-steps --
-    // wave w takes k-step w (chains 4 q + w) of BOTH tiles: one MFMA each and single-component transposes, the four partial
-    // tiles are summed once per proposal at the flush (cross-wave sum in wave order).
-    if constexpr (NW == 4) {
-      *reinterpret_cast<f4*>(scr + c * 20 + 4 * q) = C.h1;
-      const float th1 = scr[(4 * q + w) * 20 + c];
-      *reinterpret_cast<f4*>(scr + c * 20 + 4 * q) = da2;
-      const float tda2 = scr[(4 * q + w) * 20 + c];
-      G.w4 = MFMA16(th1, tda2, G.w4);
-      // row 0 -> 1, 1 -> cos, 2 -> sin of chain 4 q + w (0/1 lane weights instead of selects on c: the compiler lowers a ternary
-      // chain on c to a switch with exec-masked blocks -- twelve of them sat on the one wave that formed these rows)
-      const float cw = scr[320 + 2 * (4 * q + w)], sw = scr[320 + 2 * (4 * q + w) + 1];
-      G.tau = MFMA16(fmaf(lw2, sw, fmaf(lw1, cw, lw0)), tda1w, G.tau);
-    } else {
-      if (w == 0) G.w4 = chain4(transp(C.h1), transp(da2), G.w4);
-      if (w == W_TAU) {
-        const f4 cs01 = lds4(scr + 320 + 8 * q), cs23 = lds4(scr + 320 + 8 * q + 4);
-        const float cosv[4] = {cs01.x, cs01.z, cs23.x, cs23.z}, sinv[4] = {cs01.y, cs01.w, cs23.y, cs23.w};
-        f4 tt;
+    // the hidden vectors are the same in every wave: ONE wave forms the layer-2 tile, ANOTHER the time-embedding rows
+    // (every wave used to compute both and three of four threw them away -- the slowest wave sets the pace)
+    if (w == 0) G.w4 = chain4(transp(C.h1), transp(da2), G.w4);
+    if (w == W_TAU) {
+      // rows: 0 -> 1, 1 -> cos, 2 -> sin of chain 4 q + r.  Branch-free (round 6): the (cos, sin) pairs of the lane's four chains
+      // are two unconditional ds_read_b128 and two fmas per component -- as `c == 1 ? scr[..] : ...` the compiler built
+      // twelve exec-masked blocks with a ds_read_b32 each, on the ONE wave that forms these rows (the slowest wave sets the pace)
+      const f4 cs01 = lds4(scr + 320 + 8 * q), cs23 = lds4(scr + 320 + 8 * q + 4);
+      const float cosv[4] = {cs01.x, cs01.z, cs23.x, cs23.z}, sinv[4] = {cs01.y, cs01.w, cs23.y, cs23.w};
+      // (0/1 lane weights instead of selects on c: the compiler lowers the ternary chain to a switch with exec-masked blocks)
+      const float l0 = c == 0 ? 1.f : 0.f, l1 = c == 1 ? 1.f : 0.f, l2 = c == 2 ? 1.f : 0.f;
+      f4 tt;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tt[r] = fmaf(lw2, sinv[r], fmaf(lw1, cosv[r], lw0));
-        G.tau = chain4(tt, tda1, G.tau);
-      }
+      for (int r = 0; r < 4; ++r) tt[r] = fmaf(l2, sinv[r], fmaf(l1, cosv[r], l0));
+      G.tau = chain4(tt, tda1, G.tau);
     }
     TS_MARK(7);    // weight-gradient products (operand transposes + chain contractions)
   };
@@ -710,10 +698,6 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
         if (dim0 + r < d) { Gn[o.ls + dim0 + r] = ls[r]; Gn[o.lq + dim0 + r] = lq[r]; }
     }
   };
-  if constexpr (NW == 4) {                       // the per-wave k-step partials of the layer-2 tile and the time rows (net_bwd)
-    GX.w4 = exch(GX.w4); GX.tau = exch(GX.tau);
-    GV.w4 = exch(GV.w4); GV.tau = exch(GV.tau);
-  }
   flush(GX, slot);
   flush(GV, slot + P);
   TS_MARK(4);      // flush
