@@ -207,12 +207,14 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   };
   // in: lane (c, q) holds val[row 4 q + r][chain c];  out: lane (i, kq) holds val[row i][chain 4 kq + r]
   float* scr = smem + L.tr + w * (320 + 32);
+  // (round 6: four scalar writes + ONE ds_read_b128 -- before: one ds_write_b128 + four ds_read_b32, i.e. four data returns on the
+  //  critical path of every MFMA that consumes a transposed operand, nine times per net evaluation: 259.5 -> 252.5 us per
+  //  gradient call at ICG-50 / 4096 chains, profiles/r06_train_timing.txt.  Banks: the writes of a wave hit (16 q + c + 20 r) mod 64,
+  //  all distinct; results are the same bits.)
   auto transp = [&](f4 val) {
-    *reinterpret_cast<f4*>(scr + c * 20 + 4 * q) = val;
-    f4 ov;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ov[r] = scr[(4 * q + r) * 20 + c];
-    return ov;
+    for (int r = 0; r < 4; ++r) scr[(4 * q + r) * 20 + c] = val[r];
+    return *reinterpret_cast<const f4*>(scr + c * 20 + 4 * q);
   };
   auto relu4i = [&](f4 a) {
     f4 o = Z;
