@@ -320,6 +320,13 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
     const int drec = fwd ? R : -R;
     f4 tbv = lds4(rec + 16);
 
+#ifdef L2HMC_FAST_RESIDENT_TAILS     // experiment (round 6): both nets' tail fragments + constants stay in registers for the whole proposal
+    TailK<DT> tkx;
+    load_tailk<DT>(tkx, fwx, fcx, dofs, NTp, w, lane);
+#define TKX tkx
+#else
+#define TKX tk
+#endif
     load_tailk<DT>(tk, fwv, fcv, dofs, NTp, w, lane);
     for (int it = 0; it < A.n_steps; ++it) {
       f4 k1[DT], vh[DT], y[DT], xin[DT];
@@ -340,7 +347,9 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
       PT_MARK(2);  // VNet tail #1
 
       // ---- two masked position updates: XNet([v_h, kept * x, t])  (:127-145 / :172-190)
+#ifndef L2HMC_FAST_RESIDENT_TAILS
       load_tailk<DT>(tk, fwx, fcx, dofs, NTp, w, lane);
+#endif
 #pragma unroll
       for (int t = 0; t < DT; ++t) xin[t] = k1[t] * x[t];
       const f4 pa = l1_part<DT, NW>(nullptr, 0, A, w, lane, vh, Z, l1w.xa);
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
       PT_MARK(3);  // XNet layer-1 partials (a, b)
       xchg<NW, 1>(px, A, smem, w, lane, pb);
       PT_MARK(4);  // exchange
-      tail_fast<DT, KH>(tk, px[0] + tbx, [&](int t, f4 aS, f4 T, f4 EQ) {
+      tail_fast<DT, KH>(TKX, px[0] + tbx, [&](int t, f4 aS, f4 T, f4 EQ) {
         const f4 up = 1.f - k1[t];
         const f4 aSm = up * aS;
         const f4 ES = ex2_4(aSm);
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
       PT_MARK(6);  // XNet layer-1 partial (b only)
       xchg<NW, 1>(py, A, smem, w, lane, pb);
       PT_MARK(7);  // exchange
-      tail_fast<DT, KH>(tk, py[0] + tbx, [&](int t, f4 aS, f4 T, f4 EQ) {
+      tail_fast<DT, KH>(TKX, py[0] + tbx, [&](int t, f4 aS, f4 T, f4 EQ) {
         const f4 aSm = k1[t] * aS;
         const f4 ES = ex2_4(aSm);
         ldv += aSm;
@@ -374,7 +383,9 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
       PT_MARK(8);  // XNet tail #2
 
       // ---- momentum half-update #2 at the new position  (:147-153 / :192-199)
+#ifndef L2HMC_FAST_RESIDENT_TAILS
       load_tailk<DT>(tk, fwv, fcv, dofs, NTp, w, lane);
+#endif
       grad(x, g, red[2], need_p && it == A.n_steps - 1);
       pv[0] = vnet_l1(x, g);
       PT_MARK(9);  // grad U + VNet layer-1 partials
