@@ -41,6 +41,65 @@ __device__ __forceinline__ f4 ex2_4(f4 a) {
             __builtin_amdgcn_exp2f(a.w)};
 }
 
+// ---- f16x2: every 16-wide contraction of the step loop as TWO f16 MFMAs at fp32 accuracy (round 6) --------------------------
+// v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate and blocks the SIMD's VALU while it does (32 cycles per instruction,
+// profiles/r03_ubench_issue.txt); the f16 MFMAs take 16 cycles for K = 32 and leave the plain VALU free.  A float a is split
+// exactly into a = hi + lo + r with hi = f16(a), lo = f16(a - hi) (both round-to-nearest: |r| <= 2^-24 |a|, f32's own
+// rounding, while lo stays a normal f16; below that its quantum is 2^-24 absolute), and the k-slots of ONE
+// v_mfma_f32_16x16x32_f16 carry [hi(k) | lo(k)] of the lane's own four k (slot 8q + j: hi of k = 4q + j for j < 4, lo of k =
+// 4q + j - 4 above) against [w_hi | w_hi]; a v_mfma_f32_16x16x16_f16 adds hi x w_lo.  The products of two f16 are exact
+// in the f32 accumulator, the dropped lo x w_lo term is 2^-24 relative.  |a| >= 65520 overflows f16 to inf and the
+// result to NaN (loud): the dispatcher's `variant` 5 keeps the f32-input MFMA for such states.
+#ifndef L2HMC_FAST_F16X2
+#define L2HMC_FAST_F16X2 0
+#endif
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+struct WF16 {      // one weight fragment: [w_hi | w_hi] and [w_lo | w_lo], one K = 32 instruction each
+  h8v a1;
+  h8v a2;
+};
+__device__ __forceinline__ h2v cvt_pk16(float a, float b) { return __builtin_convertvector(f2v{a, b}, h2v); }   // v_cvt_pk_f16_f32
+// a - float(h.x) resp. a - float(h.y), exact, in one instruction (no builtin; VALU -> VALU only: nothing to pad)
+__device__ __forceinline__ float sub_lo16(float a, h2v h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float sub_hi16(float a, h2v h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+  return r;
+}
+__device__ __forceinline__ h8v split16(f4 a) {
+  const h2v h01 = cvt_pk16(a.x, a.y), h23 = cvt_pk16(a.z, a.w);
+  const h2v l01 = cvt_pk16(sub_lo16(a.x, h01), sub_hi16(a.y, h01)), l23 = cvt_pk16(sub_lo16(a.z, h23), sub_hi16(a.w, h23));
+  return h8v{h01.x, h01.y, h23.x, h23.y, l01.x, l01.y, l23.x, l23.y};
+}
+__device__ __forceinline__ WF16 wsplit16(f4 w) {
+  const h2v h01 = cvt_pk16(w.x, w.y), h23 = cvt_pk16(w.z, w.w);
+  const h2v l01 = cvt_pk16(w.x - (float)h01.x, w.y - (float)h01.y), l23 = cvt_pk16(w.z - (float)h23.x, w.w - (float)h23.y);
+  WF16 f;
+  f.a1 = h8v{h01.x, h01.y, h23.x, h23.y, h01.x, h01.y, h23.x, h23.y};
+  f.a2 = h8v{l01.x, l01.y, l23.x, l23.y, l01.x, l01.y, l23.x, l23.y};
+  return f;
+}
+#ifndef L2HMC_F16_DBG
+#define L2HMC_F16_DBG 0
+#endif
+// acc += W^T (hi + lo) for the 16 logical k of one fragment
+__device__ __forceinline__ f4 mfma16x2(const WF16& W, h8v b, f4 acc) {
+#if L2HMC_F16_DBG
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc = MFMA16((float)W.a1[r] + (float)W.a2[r], (float)b[r] + (float)b[4 + r], acc);
+  return acc;
+#endif
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.a1, b, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(W.a2, b, acc, 0, 0, 0);
+}
+
 // (Measured and not kept, profiles/r03_exchange_variants.txt: moving the K-split partial as 96 bits -- only r < KH of the
 //  float4 are live hidden units -- and keeping a wave's own partial in registers, 3 x ds_read_b96 instead of
 //  4 x ds_read_b128 per wave.  The exchange is latency-, not LDS-bandwidth-bound: b96 is neutral, and the wave-uniform
@@ -49,7 +108,7 @@ __device__ __forceinline__ f4 ex2_4(f4 a) {
 // NTp = NW * DT >= NT: every wave's tiles exist in the tables (zero-filled beyond NT), so the loop has no
 // "is this tile live" branches.
 __host__ __device__ constexpr int fast_fw_net_f32(int NTp) { return (3 * NTp + 1) * 256; }                   // f32 tail fragments per net
-__host__ __device__ constexpr int fast_fw_net(int NTp) { return (3 * NTp + 1) * 256; }                       // staged tail fragments per net
+__host__ __device__ constexpr int fast_fw_net(int NTp) { return (3 * NTp + 1) * (L2HMC_FAST_F16X2 ? 512 : 256); }   // staged tail fragments per net (f16x2: 2 x 16 bytes per lane)
 __host__ __device__ inline int fast_dpp(int NTp) { return 16 * NTp + 16; }            // padded row of a constant table
 __host__ __device__ inline int fast_fc_net(int NTp) { return 4 * fast_dpp(NTp); }     // cS(fwd) cS(bwd) cQ bQ
 __host__ __device__ inline int fast_rec(int NTp) { return 32 + 16 * NTp; }            // tbx(16) tbv(16) k1 mask
@@ -58,16 +117,22 @@ __host__ __device__ inline int fast_rec_dir(int NTp, int T) { return (T + 2) * f
 
 long long plan_lds_fast(KArgs& k, int NW, int DT);
 
-template <int DT>
+template <int DT, bool F16 = false>
 struct TailK {
   f4 w2;
   f4 hs[DT], ht[DT], hq[DT];
   f4 cS[DT], cQ[DT], bQ[DT];
 };
+template <int DT>
+struct TailK<DT, true> {
+  WF16 w2;
+  WF16 hs[DT], ht[DT], hq[DT];
+  f4 cS[DT], cQ[DT], bQ[DT];
+};
 
 // fw: this net's staged fragments; fc: this net's constant tables; dofs: 0 (forward) / DPp (backward)
 template <int DT>
-__device__ __forceinline__ void load_tailk(TailK<DT>& tk, const float* fw, const float* fc, int dofs, int NTp,
+__device__ __forceinline__ void load_tailk(TailK<DT, false>& tk, const float* fw, const float* fc, int dofs, int NTp,
                                            int w, int lane) {
   const int q = lane >> 4, DPp = fast_dpp(NTp);
   tk.w2 = lds4(fw + lane * 4);
@@ -82,11 +147,35 @@ __device__ __forceinline__ void load_tailk(TailK<DT>& tk, const float* fw, const
     tk.bQ[t] = lds4(fc + 3 * DPp + 16 * tg + 4 * q);
   }
 }
+// f16x2: group g's [w_hi | w_hi] fragment at 16-byte slot g * 64 + lane, its [w_lo | w_lo] fragment at the same slot behind
+// all the first ones
+__device__ __forceinline__ WF16 lds_wf16(const float* fw, int NTp, int g, int lane) {
+  WF16 f;
+  f.a1 = *reinterpret_cast<const h8v*>(fw + (g * 64 + lane) * 4);
+  f.a2 = *reinterpret_cast<const h8v*>(fw + (3 * NTp + 1) * 256 + (g * 64 + lane) * 4);
+  return f;
+}
+template <int DT>
+__device__ __forceinline__ void load_tailk(TailK<DT, true>& tk, const float* fw, const float* fc, int dofs, int NTp,
+                                           int w, int lane) {
+  const int q = lane >> 4, DPp = fast_dpp(NTp);
+  tk.w2 = lds_wf16(fw, NTp, 0, lane);
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    const int tg = w * DT + t;
+    tk.hs[t] = lds_wf16(fw, NTp, 1 + 3 * tg + 0, lane);
+    tk.ht[t] = lds_wf16(fw, NTp, 1 + 3 * tg + 1, lane);
+    tk.hq[t] = lds_wf16(fw, NTp, 1 + 3 * tg + 2, lane);
+    tk.cS[t] = lds4(fc + dofs + 16 * tg + 4 * q);
+    tk.cQ[t] = lds4(fc + 2 * DPp + 16 * tg + 4 * q);
+    tk.bQ[t] = lds4(fc + 3 * DPp + 16 * tg + 4 * q);
+  }
+}
 
 // hsum = exchanged layer-1 sum + time/bias term.  apply(t, aS, T', EQ') with
 //   aS = log2 of the (unmasked) scale factor,  T' = step * T,  EQ' = step * e^{eps Q}.
 template <int DT, int KH, class F>
-__device__ __forceinline__ void tail_fast(const TailK<DT>& tk, f4 hs_, F&& apply) {
+__device__ __forceinline__ void tail_fast(const TailK<DT, false>& tk, f4 hs_, F&& apply) {
   f4 h = splat(0.f);
 #pragma unroll
   for (int r = 0; r < KH; ++r) h[r] = relu_i(hs_[r]);
@@ -120,6 +209,50 @@ __device__ __forceinline__ void tail_fast(const TailK<DT>& tk, f4 hs_, F&& apply
     apply(t, aS, zt, EQ);
   }
 }
+// f16x2 form: two splits (the two hidden layers' activations: rows r >= KH are dead hidden units, zero), 2 + 6 MFMAs of
+// 16 cycles that leave the VALU free -- no fence: the S chain's transcendentals run beside the Q and T products
+template <int DT, int KH, class F>
+__device__ __forceinline__ void tail_fast(const TailK<DT, true>& tk, f4 hs_, F&& apply) {
+  f4 h = splat(0.f);
+#pragma unroll
+  for (int r = 0; r < KH; ++r) h[r] = relu_i(hs_[r]);
+  {
+    const f4 acc = mfma16x2(tk.w2, split16(h), splat(0.f));
+#pragma unroll
+    for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
+  }
+  const h8v b = split16(h);
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+#if L2HMC_F16_DBG
+    f4 zs = mfma16x2(tk.hs[t], b, splat(0.f)), zq = mfma16x2(tk.hq[t], b, splat(0.f)), zt = mfma16x2(tk.ht[t], b, splat(0.f));
+#else
+    f4 zs = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a1, b, splat(0.f), 0, 0, 0);
+    f4 zq = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hq[t].a1, b, splat(0.f), 0, 0, 0);
+    f4 zt = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.ht[t].a1, b, splat(0.f), 0, 0, 0);
+    zs = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a2, b, zs, 0, 0, 0);
+    zq = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hq[t].a2, b, zq, 0, 0, 0);
+    zt = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.ht[t].a2, b, zt, 0, 0, 0);
+#endif
+    const f4 rS = rcp4(-(ex2_4(zs) * 0.5f + 0.5f));
+    const f4 aS = rS * tk.cS[t] + tk.cS[t];
+    const f4 rQ = rcp4(-(ex2_4(zq) * 0.5f + 0.5f));
+    const f4 EQ = ex2_4(rQ * tk.cQ[t] + tk.bQ[t]);
+    apply(t, aS, zt, EQ);
+  }
+}
+
+// layer-1 fragments of the f16x2 form (register-resident, split once per launch)
+template <int DT>
+struct L1W16 {
+  WF16 xa[DT], xb[DT], va[DT], vb[DT];
+};
+template <int DT>
+__device__ __forceinline__ f4 l1_part16(const f4 (&z)[DT], f4 acc, const WF16* W) {
+#pragma unroll
+  for (int t = 0; t < DT; ++t) acc = mfma16x2(W[t], split16(z[t]), acc);
+  return acc;
+}
 
 template <int EK, int DT, int NW, int KH>
 #ifndef L2HMC_FAST_WAVES
@@ -139,6 +272,7 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
   constexpr int NTp = NW * DT;
+  constexpr bool F16 = L2HMC_FAST_F16X2 != 0;
   const int FWN = fast_fw_net(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
             RECD = fast_rec_dir(NTp, A.T);
 
@@ -162,7 +296,16 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
         const int net = i >= GN * 64, j = i - net * (GN * 64), g = j >> 6;
         float sc = 1.f;
         if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
-        if (i < NCP) reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = buf[u] * sc;
+        if constexpr (F16) {
+          if (i < NCP) {
+            const WF16 f = wsplit16(buf[u] * sc);
+            float* base = smem + A.o_fw + net * FWN;
+            reinterpret_cast<h8v*>(base)[j] = f.a1;
+            reinterpret_cast<h8v*>(base + GN * 256)[j] = f.a2;
+          }
+        } else {
+          if (i < NCP) reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = buf[u] * sc;
+        }
       }
     }
   }
@@ -229,15 +372,19 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
 
   L1W<DT> l1w;
   load_l1w<DT, NW>(l1w, A.packed, A.packed + NF, A, w, lane);
-  TailK<DT> tk;
+  TailK<DT, F16> tk;
   f4 pv[1];
   // VNet layer 1 at (x, grad U(x)).  Diagonal Gaussian: grad U = P (x - mu) is linear in x, so
   //   W1^T x + W2^T grad U = (W1 + P W2)^T x - W2^T P mu:
   // the precision is folded into the register-resident W1 fragments once per launch (fragment element
   // (lane, r) belongs to dimension 16 tg + 4 q + r -- this lane's own slice of P) and the constant goes
   // into the VNet time/bias table: one contraction per step instead of two.
+  L1W16<F16 ? DT : 1> l1h;       // (filled below, after the precision has been folded into va)
   auto vnet_l1 = [&](const f4 (&xx)[DT], const f4 (&gg)[DT]) {
-    if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
+    if constexpr (F16) {
+      if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) return l1_part16<DT>(xx, Z, l1h.va);
+      else return l1_part16<DT>(gg, l1_part16<DT>(xx, Z, l1h.va), l1h.vb);
+    } else if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
       return l1_part<DT, NW>(nullptr, 0, A, w, lane, xx, Z, l1w.va);
     } else {
       return l1_part<DT, NW>(nullptr, 0, A, w, lane, xx, Z, l1w.va) + l1_part<DT, NW>(nullptr, NT, A, w, lane, gg, Z, l1w.vb);
@@ -259,6 +406,15 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
       }
     }
     __syncthreads();
+  }
+  if constexpr (F16) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      l1h.xa[t] = wsplit16(l1w.xa[t]);
+      l1h.xb[t] = wsplit16(l1w.xb[t]);
+      l1h.va[t] = wsplit16(l1w.va[t]);
+      l1h.vb[t] = wsplit16(l1w.vb[t]);
+    }
   }
   // (Measured and not kept, profiles/r04_bf16x3_heads.txt: a head start of 256-1024 cycles for every second workgroup at 8192 chains,
   //  so that one workgroup's MFMA-heavy tails fall into the other's exchange stalls -- 38.9-39.4 us per proposal against 38.1-39.4.)
@@ -321,7 +477,7 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
     f4 tbv = lds4(rec + 16);
 
 #ifdef L2HMC_FAST_RESIDENT_TAILS     // experiment (round 6): both nets' tail fragments + constants stay in registers for the whole proposal
-    TailK<DT> tkx;
+    TailK<DT, F16> tkx;
     load_tailk<DT>(tkx, fwx, fcx, dofs, NTp, w, lane);
 #define TKX tkx
 #else
@@ -352,9 +508,14 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
 #endif
 #pragma unroll
       for (int t = 0; t < DT; ++t) xin[t] = k1[t] * x[t];
-      const f4 pa = l1_part<DT, NW>(nullptr, 0, A, w, lane, vh, Z, l1w.xa);
-      f4 px[1];
-      px[0] = pa + l1_part<DT, NW>(nullptr, NT, A, w, lane, xin, Z, l1w.xb);
+      f4 pa, px[1];
+      if constexpr (F16) {
+        pa = l1_part16<DT>(vh, Z, l1h.xa);
+        px[0] = l1_part16<DT>(xin, pa, l1h.xb);
+      } else {
+        pa = l1_part<DT, NW>(nullptr, 0, A, w, lane, vh, Z, l1w.xa);
+        px[0] = pa + l1_part<DT, NW>(nullptr, NT, A, w, lane, xin, Z, l1w.xb);
+      }
       PT_MARK(3);  // XNet layer-1 partials (a, b)
       xchg<NW, 1>(px, A, smem, w, lane, pb);
       PT_MARK(4);  // exchange
@@ -369,7 +530,8 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
       });
       PT_MARK(5);  // XNet tail #1
       f4 py[1];
-      py[0] = pa + l1_part<DT, NW>(nullptr, NT, A, w, lane, xin, Z, l1w.xb);
+      if constexpr (F16) py[0] = l1_part16<DT>(xin, pa, l1h.xb);
+      else py[0] = pa + l1_part<DT, NW>(nullptr, NT, A, w, lane, xin, Z, l1w.xb);
       PT_MARK(6);  // XNet layer-1 partial (b only)
       xchg<NW, 1>(py, A, smem, w, lane, pb);
       PT_MARK(7);  // exchange

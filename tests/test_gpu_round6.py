@@ -206,9 +206,12 @@ def test_config5_two_stream_halves_equal_the_single_stream_batch():
     """BASELINE config 5's shapes at 8192 chains: `Dynamics.split_streams = 2` runs rows [0, 4096) and [4096, 8192) as two
     independent trajectories on two HIP streams (chains never interact; one half's HBM-bound epilogues fall under the other's
     MFMA-bound main loops).  Same draws -> the same proposal, accept probability and MH-selected state as the single-stream
-    launch: every chain's arithmetic is its own row of every product (gates: float32 rounding of a different tile shape of the
-    net kernels at 4096 vs 8192 chains, 2e-6 / 2e-6; bit-equal in practice is reported), twice in a row (workspace reuse keys of
-    both halves), and the side stream's work is ordered before the caller's next use of the results."""
+    launch: every chain's arithmetic is its own row of every product.  Gates: the proposal to 2e-6 relative; the accept
+    probability to north_star's 1e-4 absolute -- it is exp of a difference of float32 energies of several hundred (the decoder's
+    784-term log-likelihood), and the net kernels sum in another tile shape at 4096 than at 8192 chains: measured 2.4e-5.  Twice in
+    a row (workspace reuse keys of both halves; the second proposal of both runs starts from the single-stream run's selected
+    state, so that an accept decision flipped by that 2.4e-5 cannot enter the comparison), and the side stream's work is ordered
+    before the caller's next use of the results."""
     import torch
     from l2hmc_amd import propose
     from tests.helpers import synthetic_vae_case
@@ -227,7 +230,7 @@ def test_config5_two_stream_halves_equal_the_single_stream_batch():
         for rep in range(2):
             Lx, _, px, o = propose(xx, dyn, do_mh_step=True, direction=direction, v=v, u=u, aux=aux)
             outs.append((to_np(Lx), to_np(px), to_np(o[0])))     # (read on the caller's stream right away: the join must hold)
-            xx = o[0]
+            xx = o[0] if streams == 1 else to_dev(res[1][0][2])
         res[streams] = outs
         assert (dyn._slot1[0] is not None) == (streams == 2)
         if streams == 2:
@@ -237,7 +240,8 @@ def test_config5_two_stream_halves_equal_the_single_stream_batch():
         fin = np.all(np.isfinite(a[0]), axis=1)
         print("rep %d: |dLx| %.1e  |dp| %.1e  bit-equal %s" % (rep, np.abs(a[0][fin] - b[0][fin]).max(), np.abs(a[1] - b[1]).max(),
                                                             np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])))
-        assert rel_err(b[0][fin], a[0][fin]) < (2e-6 if rep == 0 else 2e-4) and abs_err(b[1], a[1]) < (2e-6 if rep == 0 else 2e-4)
+        assert rel_err(b[0][fin], a[0][fin]) < 2e-6 and abs_err(b[1], a[1]) < 1e-4
+        assert np.array_equal(fin, np.all(np.isfinite(b[0]), axis=1))
     assert 0.05 < res[2][0][1].mean() < 0.999
 
 
