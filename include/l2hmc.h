@@ -117,11 +117,16 @@ typedef struct L2hmcTrajectoryArgs {
                              *   chains (d <= 4 from 131 072) ONE CHAIN PER LANE: the nets on packed VALU FMAs with
                              *   wave-uniform weights, no MFMA padding.  32 = force one chain per lane (d <= 4);
                              *   33 = the automatic choice among the MFMA kernels only.  1 / 4 = force
-                             *   that many waves per tile; 16 = one wave per tile, 4 or 8 tiles per workgroup (heads as
-                             *   K-packed bf16x3; it parks the rejected chains' start point in x_next, so x_next must come
+                             *   that many waves per tile; 16 = one wave per tile, 4 or 8 tiles per workgroup (every
+                             *   contraction as f16x2; it parks the rejected chains' start point in x_next, so x_next must come
                              *   with u -- the automatic choice falls back to the 4-wave tile otherwise); 8 = the
                              *   LDS-resident-state kernel; 100 + v = geometry v on the general kernel (which also
-                             *   serves HMC mode, AIS mode and tempered energies)                                   */
+                             *   serves HMC mode, AIS mode and tempered energies); 200 + v = choice v with the
+                             *   f32-input MFMA forced: the tile kernels of the elementwise targets (diagonal Gaussian,
+                             *   Rough Well) otherwise run their contractions as f16x2 -- two f16 MFMAs on an exact
+                             *   split of both operands, fp32-accurate for |state|, |grad U|, |activation| < 4.2e6 and
+                             *   |weight| < 1023 (csrc/traj_fast.hpp; L2HMC_F32_MFMA=1 in the environment = 200 + v
+                             *   for every call)                                                                    */
   /* ---- persistent sampler loop (the notebook's per-MH-step sess.run loop, nb raw 288-298) -- */
   int32_t n_proposals;      /* M >= 1 proposals per launch (0 = 1).  With M > 1: v is (M,N,d),  */
                             /* direction (M,N), u (M,N) [required], p_out / logjac_out (M,N);   */

@@ -328,11 +328,11 @@ long long plan_lds(KArgs& k, bool with_nets, bool with_schedule, int NW, int DT)
 
 // LDS plan of traj_fast_kernel (DT <= 2): scaled tail fragments, constant tables, schedule records, then
 // the exchange / reduction / energy areas as in plan_lds.
-long long plan_lds_fast(KArgs& k, int NW, int DT) {
+long long plan_lds_fast(KArgs& k, int NW, int DT, bool f16) {
   const int NT = k.NT, DP = 16 * NT, NTp = NW * DT;
   long long o = 0;
   k.o_fw = (int)o;
-  o += 2LL * fast_fw_net(NTp);
+  o += 2LL * fast_fw_net(NTp, f16);
   k.o_fc = (int)o;
   o += 2LL * fast_fc_net(NTp);
   k.o_rec = (int)o;
@@ -549,8 +549,19 @@ int l2hmc_pack_gaussian(const float* i_sigma, int32_t d, float* packed, void* st
 #define WIDE_DENSE_MIN_NT 8
 #endif
 
-int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
-  if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
+// L2HMC_F32_MFMA=1 in the environment: every trajectory on the f32-input MFMA (as variant 200 + v does per call)
+static bool env_f32_mfma() {
+  static const int v = [] { const char* e = getenv("L2HMC_F32_MFMA"); return (e && e[0] && e[0] != '0') ? 1 : 0; }();
+  return v != 0;
+}
+
+int l2hmc_trajectory(const L2hmcTrajectoryArgs* a_in, void* stream) {
+  if (!a_in) return fail(L2HMC_ERR_ARG, "args is NULL%s");
+  // variant 200 + v: geometry choice v with the f32-input MFMA forced (no f16x2 contraction anywhere)
+  L2hmcTrajectoryArgs a_loc = *a_in;
+  const bool force_f32 = a_loc.variant >= 200 || env_f32_mfma();
+  if (a_loc.variant >= 200) a_loc.variant -= 200;
+  const L2hmcTrajectoryArgs* a = &a_loc;
   if (a->n_chains < 0 || a->d < 1 || a->T < 1) return fail(L2HMC_ERR_ARG, "bad n_chains / d / T%s");
   if (a->n_chains == 0) return L2HMC_OK;
   if (!a->x || !a->masks || !a->trig) return fail(L2HMC_ERR_ARG, "x, masks, trig are required%s");
@@ -655,7 +666,8 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
   // (a rejected chain of this kernel resumes from the copy of its start point parked in x_next: u without x_next -- accept
   //  decisions with nowhere to put the selected state -- stays on the four-wave kernel)
   const bool tileable = a->packed_nets != nullptr && tile_kind && k.NT >= 3 && k.NT <= 4 && k.n_steps >= 1 &&
-                        k.beta == 1.f && k.temperature == 1.f && !(has_u && a->x_next == nullptr);
+                        k.beta == 1.f && k.temperature == 1.f && !(has_u && a->x_next == nullptr) &&
+                        !force_f32;        // (its contractions are f16x2 throughout: traj_tile.hpp)
   if (a->variant == 16 && !tileable)
     return fail(L2HMC_ERR_UNSUPPORTED, "variant 16 (one wave per tile) needs S/T/Q nets, a diagonal-Gaussian or Rough-Well target, 33 <= d <= 64 and x_next whenever u is given%s");
   if (tileable && (a->variant == 16 || (a->variant == 0 && a->n_chains >= 64LL * cus))) {
@@ -674,6 +686,19 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a, void* stream) {
       return fail(L2HMC_ERR_UNSUPPORTED, "variant 16: %s%lld bytes of LDS needed (T too large for the one-wave-per-tile kernel)", "", ldst);
   }
   if (fast) {
+    // f16x2 (traj_fast.hpp): every contraction of the step loop as two f16 MFMAs on an exact hi / lo split of both operands --
+    // fp32-accurate while |states|, |activations|, |grad U| < 65504 (beyond: inf - inf = NaN, which the accept rule treats as a
+    // rejection).  The elementwise targets take it unless the caller asks for the f32-input MFMA (variant 200 + v, or
+    // L2HMC_F32_MFMA=1 in the environment); the funnel (grad U ~ e^{-x_0}), the mixtures and dense Gaussians stay on f32.
+    const bool f16 = !force_f32 && (k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL);
+    if (f16) {
+      const long long lds16 = plan_lds_fast(k, NW, DT, true);
+      if (lds16 <= 160 * 1024) {
+        note_kernel("traj_fast_kernel<%lld, %lld, %lld, %lld, 1>", k.ekind, DT, NW, KH <= 3 ? 3 : 4);
+        if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) return launch_fast16_ek<L2HMC_ENERGY_GAUSS_DIAG>(k, DT, NW, KH, lds16, s);
+        return launch_fast16_ek<L2HMC_ENERGY_ROUGHWELL>(k, DT, NW, KH, lds16, s);
+      }
+    }
     const long long ldsf = plan_lds_fast(k, NW, DT);
     if (ldsf <= 160 * 1024) {
       note_kernel("traj_fast_kernel<%lld, %lld, %lld, %lld>", k.ekind, DT, NW, KH <= 3 ? 3 : 4);

@@ -1244,6 +1244,9 @@ enum { OP_TRAJ = 0, OP_ENERGY = 1, OP_PACCEPT = 2, OP_TRAJ_FAST = 3, OP_TRAJ_SMA
 // Declared here, defined (explicitly instantiated) once per energy kind.
 template <int EK>
 int launch_ek(int op, const KArgs& k, int DT, int NW, int KH, long long lds, hipStream_t s);
+// traj_fast_kernel<EK, DT, NW, KH, 1>: the f16x2 form of the instruction-lean kernel (traj_f16_ek1.hip, traj_f16_ek4.hip)
+template <int EK>
+int launch_fast16_ek(const KArgs& k, int DT, int NW, int KH, long long lds, hipStream_t s);
 // traj_tile_kernel (one wave per tile, 4 tiles per workgroup): elementwise targets only (traj_ek1.hip, traj_ek4.hip)
 template <int EK>
 int launch_tile_ek(const KArgs& k, int DT, int KH, int tpw, long long lds, hipStream_t s);

@@ -43,59 +43,77 @@ __device__ __forceinline__ f4 ex2_4(f4 a) {
 
 // ---- f16x2: every 16-wide contraction of the step loop as TWO f16 MFMAs at fp32 accuracy (round 6) --------------------------
 // v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate and blocks the SIMD's VALU while it does (32 cycles per instruction,
-// profiles/r03_ubench_issue.txt); the f16 MFMAs take 16 cycles for K = 32 and leave the plain VALU free.  A float a is split
-// exactly into a = hi + lo + r with hi = f16(a), lo = f16(a - hi) (both round-to-nearest: |r| <= 2^-24 |a|, f32's own
-// rounding, while lo stays a normal f16; below that its quantum is 2^-24 absolute), and the k-slots of ONE
-// v_mfma_f32_16x16x32_f16 carry [hi(k) | lo(k)] of the lane's own four k (slot 8q + j: hi of k = 4q + j for j < 4, lo of k =
-// 4q + j - 4 above) against [w_hi | w_hi]; a v_mfma_f32_16x16x16_f16 adds hi x w_lo.  The products of two f16 are exact
-// in the f32 accumulator, the dropped lo x w_lo term is 2^-24 relative.  |a| >= 65520 overflows f16 to inf and the
-// result to NaN (loud): the dispatcher's `variant` 5 keeps the f32-input MFMA for such states.
-#ifndef L2HMC_FAST_F16X2
-#define L2HMC_FAST_F16X2 0
-#endif
+// profiles/r03_ubench_issue.txt); v_mfma_f32_16x16x32_f16 takes 16 cycles for K = 32 and leaves the plain VALU free.
+//   * w a = (64 w) (a / 64).  An activation a is split as  hd = f16(a / 64),  lo = f16(a - 64 hd)  (both round-to-nearest; the
+//     fma in front of the second rounding is exact):  |a - 64 hd - lo| <= 2^-24 |a| -- f32's own rounding -- while lo is a
+//     normal f16, |a| >= 0.25; below that lo's quantum is 2^-25 ABSOLUTE.  Eight VALU instructions per float4: 2 v_pk_mul_f32,
+//     2 v_cvt_pk_f16_f32, 4 v_fma_mixlo/hi_f16 (or ten: split16<true>).  hd overflows at |a| = 64 x 65504 = 4.2e6 (then inf - inf = NaN, loud: the
+//     accept rule takes a NaN as a rejection; variant 200 + v keeps the f32-input MFMA for such states).
+//   * A weight w is split as  w_hi = f16(w),  w_lo = f16(64 (w - w_hi)) / 64  -- exact to 2^-24 |w| down to |w| ~ 4e-3, whatever
+//     the size of the activation it multiplies -- and staged as two fragments  [64 w_hi | w_hi]  and  [64 w_lo | w_lo]
+//     (|w| < 1023).
+//   * The k-slots of one MFMA carry [hd(k) | lo(k)] of the lane's own four k (slot 8q + j: hd of k = 4q + j for j < 4, lo of k =
+//     4q + j - 4 above): the first MFMA adds w_hi (64 hd + lo), the second one w_lo (64 hd + lo), ONE accumulate chain, no
+//     rescaling anywhere.  Products of two f16 are exact in the f32 accumulator.
+//   * Error of a K-term contraction: 2^-24 sum |w_k a_k| (as f32) + 2^-25 sum over {k: |a_k| < 1/4} of |w_k|.
+//   * The two MFMAs of a chain MUST be the same instruction: a v_mfma_f32_16x16x16_f16 issued right behind the
+//     v_mfma_f32_16x16x32_f16 whose result it accumulates onto loses that result (roc-7.2.0 places no wait states between the
+//     two pass counts; tools/ubench_f16x2.hip).
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef float f2v __attribute__((ext_vector_type(2)));
-struct WF16 {      // one weight fragment: [w_hi | w_hi] and [w_lo | w_lo], one K = 32 instruction each
+#define L2HMC_F16_SCALE 64.0f
+struct WF16 {      // one weight fragment: [64 w_hi | w_hi] and [64 w_lo | w_lo], one K = 32 instruction each
   h8v a1;
   h8v a2;
 };
 __device__ __forceinline__ h2v cvt_pk16(float a, float b) { return __builtin_convertvector(f2v{a, b}, h2v); }   // v_cvt_pk_f16_f32
-// a - float(h.x) resp. a - float(h.y), exact, in one instruction (no builtin; VALU -> VALU only: nothing to pad)
-__device__ __forceinline__ float sub_lo16(float a, h2v h) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+// { f16(a0 - 64 h.x), f16(a1 - 64 h.y) }: the fma is exact, one rounding each (no builtin; VALU -> VALU only: nothing to pad)
+__device__ __forceinline__ h2v lo_pair16(h2v h, float a0, float a1) {
+  h2v r;
+  const float ns = -L2HMC_F16_SCALE;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(ns), "v"(a0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h), "s"(ns), "v"(a1));
   return r;
 }
-__device__ __forceinline__ float sub_hi16(float a, h2v h) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
-  return r;
-}
+// LAT = true: the two residuals of a pair through independent v_fma_mix_f32 and one v_cvt_pk_f16_f32 -- ten instructions per
+// float4 instead of eight, but no instruction waits for its neighbour's half of a register: measured faster where one wave owns
+// its SIMD (traj_fast_kernel: 20.4 against 20.7 us per proposal at 4096 chains, 31.5 against 32.3 at 8192;
+// profiles/r06_f16x2.txt).  LAT = false: v_fma_mixlo_f16 + v_fma_mixhi_f16 write the two halves of the pair in place.
+template <bool LAT>
 __device__ __forceinline__ h8v split16(f4 a) {
-  const h2v h01 = cvt_pk16(a.x, a.y), h23 = cvt_pk16(a.z, a.w);
-  const h2v l01 = cvt_pk16(sub_lo16(a.x, h01), sub_hi16(a.y, h01)), l23 = cvt_pk16(sub_lo16(a.z, h23), sub_hi16(a.w, h23));
+  const f4 ad = a * (1.f / L2HMC_F16_SCALE);
+  const h2v h01 = cvt_pk16(ad.x, ad.y), h23 = cvt_pk16(ad.z, ad.w);
+  h2v l01, l23;
+  if constexpr (LAT) {
+    float r0, r1, r2, r3;
+    const float ns = -L2HMC_F16_SCALE;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "s"(ns), "v"(a.x));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "s"(ns), "v"(a.y));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "s"(ns), "v"(a.z));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "s"(ns), "v"(a.w));
+    l01 = cvt_pk16(r0, r1);
+    l23 = cvt_pk16(r2, r3);
+  } else {
+    l01 = lo_pair16(h01, a.x, a.y);
+    l23 = lo_pair16(h23, a.z, a.w);
+  }
   return h8v{h01.x, h01.y, h23.x, h23.y, l01.x, l01.y, l23.x, l23.y};
 }
 __device__ __forceinline__ WF16 wsplit16(f4 w) {
-  const h2v h01 = cvt_pk16(w.x, w.y), h23 = cvt_pk16(w.z, w.w);
-  const h2v l01 = cvt_pk16(w.x - (float)h01.x, w.y - (float)h01.y), l23 = cvt_pk16(w.z - (float)h23.x, w.w - (float)h23.y);
+  const float sc = L2HMC_F16_SCALE;
+  const h2v h01 = cvt_pk16(w.x, w.y), h23 = cvt_pk16(w.z, w.w);                       // w_hi
+  const f4 r = f4{w.x - (float)h01.x, w.y - (float)h01.y, w.z - (float)h23.x, w.w - (float)h23.y} * sc;
+  const h2v L01 = cvt_pk16(r.x, r.y), L23 = cvt_pk16(r.z, r.w);                       // 64 w_lo
+  const h2v H01 = cvt_pk16((float)h01.x * sc, (float)h01.y * sc), H23 = cvt_pk16((float)h23.x * sc, (float)h23.y * sc);   // 64 w_hi
+  const h2v l01 = cvt_pk16((float)L01.x / sc, (float)L01.y / sc), l23 = cvt_pk16((float)L23.x / sc, (float)L23.y / sc);   // w_lo
   WF16 f;
-  f.a1 = h8v{h01.x, h01.y, h23.x, h23.y, h01.x, h01.y, h23.x, h23.y};
-  f.a2 = h8v{l01.x, l01.y, l23.x, l23.y, l01.x, l01.y, l23.x, l23.y};
+  f.a1 = h8v{H01.x, H01.y, H23.x, H23.y, h01.x, h01.y, h23.x, h23.y};
+  f.a2 = h8v{L01.x, L01.y, L23.x, L23.y, l01.x, l01.y, l23.x, l23.y};
   return f;
 }
-#ifndef L2HMC_F16_DBG
-#define L2HMC_F16_DBG 0
-#endif
-// acc += W^T (hi + lo) for the 16 logical k of one fragment
+// acc += W^T a for the 16 logical k of one fragment
 __device__ __forceinline__ f4 mfma16x2(const WF16& W, h8v b, f4 acc) {
-#if L2HMC_F16_DBG
-#pragma unroll
-  for (int r = 0; r < 4; ++r) acc = MFMA16((float)W.a1[r] + (float)W.a2[r], (float)b[r] + (float)b[4 + r], acc);
-  return acc;
-#endif
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.a1, b, acc, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(W.a2, b, acc, 0, 0, 0);
 }
@@ -108,14 +126,14 @@ __device__ __forceinline__ f4 mfma16x2(const WF16& W, h8v b, f4 acc) {
 // NTp = NW * DT >= NT: every wave's tiles exist in the tables (zero-filled beyond NT), so the loop has no
 // "is this tile live" branches.
 __host__ __device__ constexpr int fast_fw_net_f32(int NTp) { return (3 * NTp + 1) * 256; }                   // f32 tail fragments per net
-__host__ __device__ constexpr int fast_fw_net(int NTp) { return (3 * NTp + 1) * (L2HMC_FAST_F16X2 ? 512 : 256); }   // staged tail fragments per net (f16x2: 2 x 16 bytes per lane)
+__host__ __device__ constexpr int fast_fw_net(int NTp, bool f16 = false) { return (3 * NTp + 1) * (f16 ? 512 : 256); }   // staged tail fragments per net (f16x2: 2 x 16 bytes per lane)
 __host__ __device__ inline int fast_dpp(int NTp) { return 16 * NTp + 16; }            // padded row of a constant table
 __host__ __device__ inline int fast_fc_net(int NTp) { return 4 * fast_dpp(NTp); }     // cS(fwd) cS(bwd) cQ bQ
 __host__ __device__ inline int fast_rec(int NTp) { return 32 + 16 * NTp; }            // tbx(16) tbv(16) k1 mask
 // T rows plus one never-used row on either side (the next-row prefetch of the last step lands there)
 __host__ __device__ inline int fast_rec_dir(int NTp, int T) { return (T + 2) * fast_rec(NTp) + 16; }
 
-long long plan_lds_fast(KArgs& k, int NW, int DT);
+long long plan_lds_fast(KArgs& k, int NW, int DT, bool f16 = false);
 
 template <int DT, bool F16 = false>
 struct TailK {
@@ -217,23 +235,19 @@ __device__ __forceinline__ void tail_fast(const TailK<DT, true>& tk, f4 hs_, F&&
 #pragma unroll
   for (int r = 0; r < KH; ++r) h[r] = relu_i(hs_[r]);
   {
-    const f4 acc = mfma16x2(tk.w2, split16(h), splat(0.f));
+    const f4 acc = mfma16x2(tk.w2, split16<true>(h), splat(0.f));
 #pragma unroll
     for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
   }
-  const h8v b = split16(h);
+  const h8v b = split16<true>(h);
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
-#if L2HMC_F16_DBG
-    f4 zs = mfma16x2(tk.hs[t], b, splat(0.f)), zq = mfma16x2(tk.hq[t], b, splat(0.f)), zt = mfma16x2(tk.ht[t], b, splat(0.f));
-#else
     f4 zs = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a1, b, splat(0.f), 0, 0, 0);
     f4 zq = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hq[t].a1, b, splat(0.f), 0, 0, 0);
     f4 zt = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.ht[t].a1, b, splat(0.f), 0, 0, 0);
     zs = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a2, b, zs, 0, 0, 0);
     zq = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hq[t].a2, b, zq, 0, 0, 0);
     zt = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.ht[t].a2, b, zt, 0, 0, 0);
-#endif
     const f4 rS = rcp4(-(ex2_4(zs) * 0.5f + 0.5f));
     const f4 aS = rS * tk.cS[t] + tk.cS[t];
     const f4 rQ = rcp4(-(ex2_4(zq) * 0.5f + 0.5f));
@@ -250,11 +264,12 @@ struct L1W16 {
 template <int DT>
 __device__ __forceinline__ f4 l1_part16(const f4 (&z)[DT], f4 acc, const WF16* W) {
 #pragma unroll
-  for (int t = 0; t < DT; ++t) acc = mfma16x2(W[t], split16(z[t]), acc);
+  for (int t = 0; t < DT; ++t) acc = mfma16x2(W[t], split16<true>(z[t]), acc);
   return acc;
 }
 
-template <int EK, int DT, int NW, int KH>
+// PK: 0 = f32-input MFMA (v_mfma_f32_16x16x4_f32), 1 = f16x2 (above)
+template <int EK, int DT, int NW, int KH, int PK = 0>
 #ifndef L2HMC_FAST_WAVES
 #define L2HMC_FAST_WAVES 2
 #endif
@@ -272,8 +287,8 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
   constexpr int NTp = NW * DT;
-  constexpr bool F16 = L2HMC_FAST_F16X2 != 0;
-  const int FWN = fast_fw_net(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
+  constexpr bool F16 = PK == 1;
+  const int FWN = fast_fw_net(NTp, F16), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
             RECD = fast_rec_dir(NTp, A.T);
 
   // ---- prologue: stage the tail fragments (scaled), the constant tables and the schedule records ----

@@ -19,19 +19,43 @@ namespace l2hmc {
 
 long long plan_lds_tile(KArgs& k, int DT);
 
-// L2HMC_BFH_TILE = 1 (the default since round 4): the head contractions -- 144 of this kernel's 212 MFMAs per tile-step -- run as
-// K-packed bf16x3 (bf3k.hpp): 3 bf16 MFMAs of 16 cycles that leave the VALU to the SIMD's other wave instead of 3 f32 MFMAs of
-// 32 cycles that block it; fragments split when they are staged (32 bytes per lane and block), the second hidden activation
-// split once per net evaluation.  Measured (profiles/r04_bf16x3_heads.txt): 65 536 chains 224.8 -> 194 us per proposal
-// (0.425 -> 0.49 of the fp32 roof), 32 768 chains 115.7 -> 104, 16 384 chains 65.2 -> 64; results within the same tolerances.
+// L2HMC_BFH_TILE: how the contractions run.
+//   0  every contraction on the f32-input MFMA (round 3).
+//   1  the head contractions -- 144 of the kernel's 212 MFMAs per tile-step -- as K-packed bf16x3 (bf3k.hpp, round 4): 3 bf16
+//      MFMAs of 16 cycles that leave the VALU to the SIMD's other wave instead of 3 f32 MFMAs of 32 cycles that block it
+//      (profiles/r04_bf16x3_heads.txt: 65 536 chains 224.8 -> 194 us per proposal); layer 1 and the hidden layer stay f32.
+//   2  (the default since round 6) EVERY contraction as f16x2 (traj_fast.hpp): two v_mfma_f32_16x16x32_f16 per 16-k block on an
+//      exact hd / lo split of the activation (8 VALU per float4 against bf16x3's 26, one 4-register operand against three) and
+//      [64 w_hi | w_hi], [64 w_lo | w_lo] fragments split when they are staged (32 bytes per lane and block, as bf16x3's).
+//      No f32-input MFMA is left in the step loop: 136 MFMAs of 16 cycles per tile-step (layer 1: 32, hidden: 8, heads: 96)
+//      instead of 68 x 32 blocking + 144 x 16 (profiles/r06_f16x2.txt).
 #ifndef L2HMC_BFH_TILE
-#define L2HMC_BFH_TILE 1
+#define L2HMC_BFH_TILE 2
 #endif
-__host__ __device__ constexpr int tile_fw_net(int NTp) { return ((L2HMC_BFH_TILE ? 6 : 3) * NTp + 1) * 256; }   // staged tail fragments per net
+// staged tail fragments per net: mode 0: W4 + 3 per slice, 16 bytes per lane; mode 1: W4 as f32 + 3 split blocks per slice;
+// mode 2: (1 + 3 per slice) split blocks
+__host__ __device__ constexpr int tile_fw_net(int NTp) {
+  return L2HMC_BFH_TILE == 2 ? (6 * NTp + 2) * 256 : ((L2HMC_BFH_TILE ? 6 : 3) * NTp + 1) * 256;
+}
 // (The layer-1 contractions as bf16x3 too -- 20 more operand splits per tile-step -- were built and measured in round 4: 205.6 vs
-//  195 us per proposal at 65 536 chains, the splits cost more VALU than the 56 f32 MFMAs they replace; commit d230bd6 has the code.)
-__host__ __device__ constexpr int tile_l1_floats(int DT) { return 4 * DT * 256; }
+//  195 us per proposal at 65 536 chains, the splits cost more VALU than the 56 f32 MFMAs they replace; commit d230bd6 has the code.
+//  With f16x2's 8-instruction split they pay: mode 2.)
+__host__ __device__ constexpr int tile_l1_floats(int DT) { return (L2HMC_BFH_TILE == 2 ? 8 : 4) * DT * 256; }
+// mode 2: block b of a table = 2 x 64 x 16 bytes, a1 then a2, lane-major (the layout of bf3k.hpp's blocks)
+__device__ __forceinline__ void wf16_store(float* base, int block, int lane, const WF16& w) {
+  h8v* p = reinterpret_cast<h8v*>(base) + (size_t)block * 128 + lane;
+  p[0] = w.a1;
+  p[64] = w.a2;
+}
+__device__ __forceinline__ WF16 wf16_load(const float* base, int block, int lane) {
+  const h8v* p = reinterpret_cast<const h8v*>(base) + (size_t)block * 128 + lane;
+  return WF16{p[0], p[64]};
+}
 
+// the activation split of mode 2: 8 instructions with in-place halves (false) or 10 with independent ones (true, traj_fast.hpp)
+#ifndef L2HMC_TILE_SPLIT_LAT
+#define L2HMC_TILE_SPLIT_LAT false
+#endif
 template <int EK, int DT, int KH, int TPW, bool HALF>
 #ifndef L2HMC_TILE_WPE
 // waves per SIMD the register budget is set for (HIP's second launch-bounds argument).  3 was compiled in round 5: 168
@@ -62,7 +86,9 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
     if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
     f4 src = Z;
     if (g < 3 * NT + 1) src = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + (2 * NT + 1) * 256)[j];
-#if L2HMC_BFH_TILE
+#if L2HMC_BFH_TILE == 2
+    wf16_store(smem + A.o_fw + net * FWN, g, j & 63, wsplit16(src * sc));
+#elif L2HMC_BFH_TILE
     if (g == 0) reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src;
     else bfk_store(smem + A.o_fw + net * FWN + 256, g - 1, j & 63, bfk_wfrag(src * sc));
 #else
@@ -81,7 +107,11 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
         val = val + lds4(smem + A.o_prec + 16 * tg + 4 * (ln >> 4)) * wb;
       }
     }
+#if L2HMC_BFH_TILE == 2
+    wf16_store(smem + A.o_state, grp, ln, wsplit16(val));
+#else
     reinterpret_cast<f4*>(smem + A.o_state)[i] = val;
+#endif
   }
   for (int i = tid; i < 2 * 16 * NTp; i += nthr) {
     const int net = i / (16 * NTp), dim = i % (16 * NTp);
@@ -115,11 +145,11 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
     for (int r = 0; r < 4; ++r) acc = MFMA16(W[r], in[r], acc);
     return acc;
   };
-  auto l1frag = [&](int net, int inp, int t) { return lds4(smem + A.o_state + (((net * 2 + inp) * DT + t) * 64 + lane) * 4); };
+  [[maybe_unused]] auto l1frag = [&](int net, int inp, int t) { return lds4(smem + A.o_state + (((net * 2 + inp) * DT + t) * 64 + lane) * 4); };
   // layer-1 contraction of dimension slice t: k-step r covers the dimensions 16 t + 4 q + r, live only while 16 t + r < d --
   // the last slice of d = 50 has two live k-steps of four (wave-uniform bound: scalar branches)
   const int klast = A.d - 16 * (DT - 1);
-  auto chain4t = [&](int t, f4 W, f4 in, f4 acc) {
+  [[maybe_unused]] auto chain4t = [&](int t, f4 W, f4 in, f4 acc) {
     if (t < DT - 1 || klast >= 4) return chain4(W, in, acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -127,7 +157,13 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
     return acc;
   };
   // (+2.7 % at 65 536 chains for d = 50)
+#if L2HMC_BFH_TILE == 2
+  auto l1dot = [&](int net, int inp, int t, f4 in, f4 acc) {
+    return mfma16x2(wf16_load(smem + A.o_state, (net * 2 + inp) * DT + t, lane), split16<L2HMC_TILE_SPLIT_LAT>(in), acc);
+  };
+#else
   auto l1dot = [&](int net, int inp, int t, f4 in, f4 acc) { return chain4t(t, l1frag(net, inp, t), in, acc); };
+#endif
   auto mu_of = [&](int t) { return lds4(smem + A.o_mu + 16 * t + 4 * q); };
   auto prec_of = [&](int t) { return lds4(smem + A.o_prec + 16 * t + 4 * q); };
   if (EK == L2HMC_ENERGY_GAUSS_DIAG) {           // constant -W2^T P mu of the fold -> VNet time/bias table
@@ -179,6 +215,18 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
     return U;
   };
   // hidden layers of one net: h2 (unit rows) from the layer-1 sum + time/bias row
+#if L2HMC_BFH_TILE == 2
+  auto hidden = [&](const float* fw, f4 hs_) {
+    const WF16 w2 = wf16_load(fw, 0, lane);
+    f4 h = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) h[r] = relu_i(hs_[r]);
+    const f4 acc = mfma16x2(w2, split16<L2HMC_TILE_SPLIT_LAT>(h), Z);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
+    return h;
+  };
+#else
   auto hidden = [&](const float* fw, f4 hs_) {
     const f4 w2 = lds4(fw + lane * 4);
     f4 h = Z;
@@ -191,8 +239,12 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
     for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
     return h;
   };
+#endif
   // heads of dimension slice t: aS = log2 of the scale factor, T' = step T, EQ' = step e^{eps Q}  (traj_fast.hpp)
-#if L2HMC_BFH_TILE
+#if L2HMC_BFH_TILE == 2
+  typedef h8v HidT;                       // the second hidden activation as the split B operand of the heads
+  auto hidden_b = [&](const float* fw, f4 hs_) { return split16<L2HMC_TILE_SPLIT_LAT>(hidden(fw, hs_)); };
+#elif L2HMC_BFH_TILE
   typedef BfkA HidT;                      // the second hidden activation as the split B operand of the heads
   auto hidden_b = [&](const float* fw, f4 hs_) { return bfk_afrag(hidden(fw, hs_)); };
 #else
@@ -204,7 +256,9 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
   // one other wave on the SIMD to cover it.  The request for slice t + 1 is issued right after slice t's MFMAs (whose operand
   // registers it re-uses), so it flies under slice t's transcendental chain; the compiler barrier keeps it there.
   struct HeadF {
-#if L2HMC_BFH_TILE
+#if L2HMC_BFH_TILE == 2
+    WF16 ws, wq, wt;
+#elif L2HMC_BFH_TILE
     BfkW ws, wq, wt;
 #else
     f4 ws, wq, wt;
@@ -212,7 +266,11 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
   };
   auto heads_load = [&](const float* fw, int t) {
     HeadF f;
-#if L2HMC_BFH_TILE
+#if L2HMC_BFH_TILE == 2
+    f.ws = wf16_load(fw, 1 + 3 * t + 0, lane);
+    f.wq = wf16_load(fw, 1 + 3 * t + 2, lane);
+    f.wt = wf16_load(fw, 1 + 3 * t + 1, lane);
+#elif L2HMC_BFH_TILE
     f.ws = bfk_load(fw + 256, 3 * t + 0, lane);
     f.wq = bfk_load(fw + 256, 3 * t + 2, lane);
     f.wt = bfk_load(fw + 256, 3 * t + 1, lane);
@@ -225,7 +283,14 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
   };
   auto heads_mfma = [&](const HeadF& f, const HidT& h, f4& zs, f4& zq, f4& zt) {
     zs = Z; zq = Z; zt = Z;
-#if L2HMC_BFH_TILE
+#if L2HMC_BFH_TILE == 2
+    zs = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ws.a1, h, zs, 0, 0, 0);
+    zq = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.wq.a1, h, zq, 0, 0, 0);
+    zt = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.wt.a1, h, zt, 0, 0, 0);
+    zs = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ws.a2, h, zs, 0, 0, 0);
+    zq = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.wq.a2, h, zq, 0, 0, 0);
+    zt = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.wt.a2, h, zt, 0, 0, 0);
+#elif L2HMC_BFH_TILE
     zs = bfk_dot(f.ws, h, zs);
     zq = bfk_dot(f.wq, h, zq);
     zt = bfk_dot(f.wt, h, zt);

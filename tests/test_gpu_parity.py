@@ -21,7 +21,8 @@ STEP_TOL, TRAJ_TOL, P_TOL = 3e-5, 1e-4, 1e-4
 
 
 def variants(g):
-    # 0 / 1 / 4: automatic / one / four waves per 16-chain tile (the instruction-lean kernel where it applies);
+    # 0 / 1 / 4: automatic / one / four waves per 16-chain tile (the instruction-lean kernel where it applies; f16x2
+    # contractions for the elementwise targets, traj_fast.hpp);
     # 100 + v: the same geometry on the general kernel
     d = int(g["x_dim"])
     # 32: one chain per lane (traj_lane.hpp: the many-chain VALU form; forced here on the fixtures' few chains)
@@ -36,7 +37,8 @@ def variants(g):
     tile = 33 <= d <= 64 and not int(g["hmc"]) and int(g["H"]) <= 15 and (
         str(g["energy.kind"]) == "roughwell" or (str(g["energy.kind"]) == "gaussian" and
                                                   np.count_nonzero(g["energy.i_sigma"] - np.diag(np.diagonal(g["energy.i_sigma"]))) == 0))
-    return [1, 4, 104] + ([16] if tile else []) + ([32] if lane else [])
+    # 204: the four-wave tile with the f32-input MFMA forced (4 takes the f16x2 contractions where the dispatcher offers them)
+    return [1, 4, 104, 204] + ([16] if tile else []) + ([32] if lane else [])
 
 
 @pytest.mark.parametrize("case", CASES)

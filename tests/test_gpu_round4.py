@@ -129,7 +129,7 @@ def test_tile_kernel_with_eight_tiles_per_workgroup_and_the_kernel_name_query():
     # and the names of the other families
     small = synthetic_case("gauss_diag", 50, H=10, T=5, N=64, seed=3)
     propose(to_dev(small["x"]), hip_dynamics(small, 0), direction=to_dev(dr[:64]), v=to_dev(small["v"]))
-    assert _ffi.last_kernel() == "traj_fast_kernel<1, 1, 4, 3>"
+    assert _ffi.last_kernel() == "traj_fast_kernel<1, 1, 4, 3, 1>"          # (f16x2 contractions: traj_fast.hpp)
     two = synthetic_case("gauss_dense", 2, H=10, T=5, N=64, seed=3)
     propose(to_dev(two["x"]), hip_dynamics(two, 0), direction=to_dev(dr[:64]), v=to_dev(two["v"]))
     assert _ffi.last_kernel().startswith("traj_small_kernel<2")
