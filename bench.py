@@ -229,11 +229,16 @@ def config5_leg(dev, chains=8192):
             # what the matrix pipe really executes: with gemm_mode = 1 (the default) the decoder-sized products run as
             # "bf16x3" -- six bf16 MFMAs per fp32 product, fp32-accurate -- so `frac` above is ALGORITHMIC
             # fp32 flops over the f32-MFMA roof, not the utilisation of the pipe the products run on
-            "arithmetic": "bf16x3 (decoder GEMMs: 3-way split fp32 operands -- on pre-split bf16 planes from 3072 chains, "
-                          "gemm_xlp_kernel -- 6 bf16 MFMAs per product, fp32 accumulate); "
-                          "f32 MFMA for the K = 50 / N = 50 / H = 200 products" if int(getattr(dyn, "gemm_mode", 1)) == 1 else "f32 MFMA",
-            "executed_tflops": (ach_dec * (6.0 if int(getattr(dyn, "gemm_mode", 1)) == 1 else 1.0) + (ach - ach_dec)),
-            "frac_of_bf16_roof": (ach_dec * 6.0 / PEAK_BF16_MFMA_TFLOPS) if int(getattr(dyn, "gemm_mode", 1)) == 1 else None,
+            "arithmetic": {3: "f16x2 planes (decoder GEMMs of the sampler: exact 2-way f16 split of both operands on pre-split planes, "
+                              "gemm_xlp_kernel<..., 1> -- 3 f16 MFMAs per product, fp32 accumulate; the trainer's adjoint products "
+                              "stay bf16x3); f32 MFMA for the K = 50 / N = 50 / H = 200 products",
+                           1: "bf16x3 (decoder GEMMs: 3-way split fp32 operands -- on pre-split bf16 planes from 3072 chains, "
+                              "gemm_xlp_kernel -- 6 bf16 MFMAs per product, fp32 accumulate); "
+                              "f32 MFMA for the K = 50 / N = 50 / H = 200 products"}.get(int(getattr(dyn, "gemm_mode", 1)), "f32 MFMA"),
+            "gemm_mode": int(getattr(dyn, "gemm_mode", 1)),
+            "executed_tflops": (ach_dec * {1: 6.0, 3: 3.0}.get(int(getattr(dyn, "gemm_mode", 1)), 1.0) + (ach - ach_dec)),
+            "frac_of_bf16_roof": (ach_dec * {1: 6.0, 3: 3.0}[int(getattr(dyn, "gemm_mode", 1))] / PEAK_BF16_MFMA_TFLOPS)
+                                 if int(getattr(dyn, "gemm_mode", 1)) in (1, 3) else None,
             "mean_accept_prob": float(state["p"].mean()), "state_finite": bool(torch.isfinite(state["x"]).all()),
             "train": {"workload": "sampler update of mnist_vae.py:185-262, one differentiated proposal per step",
                       "ms_per_step": ms_train, "flops_per_chain": flops_train,

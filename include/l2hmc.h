@@ -334,7 +334,15 @@ typedef struct L2hmcSplitArgs {
                                   *       accuracy (measured against float64 in profiles/ and the config-5 parity tests);
                                   *       from 3072 chains at config 5's widths on operands PRE-SPLIT into bf16 planes
                                   *    2: the same six products with the split inside the k loop at every size -- bit-identical
-                                  *       results to mode 1 (the planes only move where the split happens); kept for tests and A/B */
+                                  *       results to mode 1 (the planes only move where the split happens); kept for tests and A/B
+                                  *    3: "f16x2 planes" (round 6; what l2hmc_amd.Dynamics asks for): x = X1 + X2 / 64 with X1 =
+                                  *       f16(x), X2 = f16(64 (x - X1)), stored as the three f16 planes X1 | X1 / 64 | X2, so that
+                                  *       x y = X1 Y1 + (X1 / 64) Y2 + X2 (Y1 / 64) is THREE f16 MFMAs on one accumulator: half of
+                                  *       mode 1's matrix-pipe work at the same fp32-level accuracy (dropped term <= 2^-24 |x y|)
+                                  *       for operand entries in [4e-3, 65504) -- smaller entries keep an absolute error of
+                                  *       2^-30, larger ones overflow to inf.  The sampler's activations, logits and BCE
+                                  *       gradients live there; the TRAINER's adjoint planes (entries scaled by 1 / chains) do
+                                  *       not: L2hmcTrainSplitArgs.gemm_mode 3 runs mode 1 (csrc/gemm_f32.hpp, gemm_xl.hpp)     */
   L2hmcNetCallback net_cb;       /* (ABI 5) non-NULL: the caller's nets (see L2hmcNetCallback); xnet = vnet = aux_encoder = NULL,
                                   *    H is ignored, hmc = 0.  With any target: energy_cb, a built-in energy, or (round 6) the
                                   *    decoder posterior -- the callback's nets then read the images on their own           */

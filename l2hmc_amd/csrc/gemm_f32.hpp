@@ -65,6 +65,9 @@ struct GemmArgs {
   const unsigned short* Ap; long long ap_plane; int ldap;
   const unsigned short* Bp; long long bp_plane; int ldbp;
   unsigned short* Cp; long long cp_plane; int ldcp;
+  // plane arithmetic: 0 = bf16x3 (h | m | l, six products), 1 = f16x2 (three f16 planes X1 | X1 / 64 | 64 (x - X1), three
+  // products: gemm_xl.hpp) -- what the planes Ap / Bp hold and what the epilogue writes to Cp
+  int pm;
 };
 
 #ifndef L2HMC_GEMM_GK
@@ -182,6 +185,31 @@ __device__ __forceinline__ Split4 split4(f4 x) {
   }
   return o;
 }
+// ---- f16x2 planes (GemmArgs.pm = 1) --------------------------------------------------------------------------------------
+// x = X1 + X2 / 64 with X1 = f16(x), X2 = f16(64 (x - X1)) (both round-to-nearest, |x - X1 - X2 / 64| <= 2^-24 |x| while X2 is a
+// normal f16: |x| >= 4e-3; below that its quantum is 2^-30 absolute; |x| < 65504).  Stored as TWO f16 planes X1 | X2 (4 bytes per
+// element against bf16x3's 6); the consumer forms X1 / 64 on its fragment (exact), so that  x y = X1 Y1 + (X1 / 64) Y2 + X2 (Y1 / 64)  (+ X2 Y2 / 4096 <= 2^-24 |x y|, dropped) is three MFMAs on one accumulator
+// with no rescaling: half the matrix-pipe work of the six bf16x3 products and two thirds of their plane traffic.  The f16 exponent range is what
+// bounds it: the SAMPLER's decoder products (activations, logits, BCE gradients: O(1e-3 ... 1e2)) take it; the trainer's adjoint
+// planes (entries scaled by 1 / chains) keep bf16x3.
+typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ Split4 split4_f16(f4 x) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  Split4 o;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const hf2 h = __builtin_convertvector(f2{a, b}, hf2);                                        // v_cvt_pk_f16_f32
+    const hf2 d = h * (_Float16)0.015625f;
+    const hf2 l = __builtin_convertvector(f2{(a - (float)h.x) * 64.f, (b - (float)h.y) * 64.f}, hf2);
+    o.h[i] = __builtin_bit_cast(unsigned, h); o.m[i] = __builtin_bit_cast(unsigned, d); o.l[i] = __builtin_bit_cast(unsigned, l);
+  }
+  return o;
+}
+__device__ __forceinline__ f4 mfma_f16(u4v a, u4v b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hf8, a), __builtin_bit_cast(hf8, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f4 mfma_bf16(u4v a, u4v b, f4 c) {
 #ifdef L2HMC_BF3_ABL_NOMFMA       // timing ablation only: the split results are consumed by one VALU op instead
   c.x += __uint_as_float(a.x ^ b.y);
@@ -275,10 +303,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f4 (&acc)
       if (g.C != nullptr) st4(g.C + m * g.ldc + n, out);
       if (has2 && g.C2 != nullptr) st4(g.C2 + m * g.ldc2 + n, out2);
       if (g.Cp != nullptr) {                     // the same four values as bf16 planes (the next product's A operand)
-        const Split4 sp = split4(out);
+        const Split4 sp = g.pm ? split4_f16(out) : split4(out);
         unsigned short* pp = g.Cp + m * g.ldcp + n;
         typedef unsigned u2v __attribute__((ext_vector_type(2)));
-        if (full) {
+        if (g.pm) {                              // f16x2: two planes, X1 | X2 (X1 / 64 is formed by the consumer)
+          if (full) {
+            *reinterpret_cast<u2v*>(pp) = u2v{sp.h[0], sp.h[1]};
+            *reinterpret_cast<u2v*>(pp + g.cp_plane) = u2v{sp.l[0], sp.l[1]};
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (n + t < g.N) {
+                pp[t] = (unsigned short)(sp.h[t >> 1] >> (16 * (t & 1)));
+                pp[g.cp_plane + t] = (unsigned short)(sp.l[t >> 1] >> (16 * (t & 1)));
+              }
+          }
+        } else if (full) {
           *reinterpret_cast<u2v*>(pp) = u2v{sp.h[0], sp.h[1]};
           *reinterpret_cast<u2v*>(pp + g.cp_plane) = u2v{sp.m[0], sp.m[1]};
           *reinterpret_cast<u2v*>(pp + 2 * g.cp_plane) = u2v{sp.l[0], sp.l[1]};

@@ -60,11 +60,13 @@ __device__ unsigned long long xl_ticks[4];
 #else
 #define XL_FENCE()
 #endif
-template <int EPI, int WMB, int WNB, int WAVES_M, int WAVES_N>
+// PM = 1: f16x2 planes (gemm_f32.hpp): three products per block pair instead of six
+template <int EPI, int WMB, int WNB, int WAVES_M, int WAVES_N, int PM = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const GemmArgs g) {
   constexpr int NT = 64 * WAVES_M * WAVES_N, RPS = NT / 4;            // threads; rows per staging pass
   constexpr int TM = 16 * WMB * WAVES_M, TN = 16 * WNB * WAVES_N, TR = TM + TN;
-  constexpr int BUFC = 3 * TR * 4;                                    // 16-byte chunks per buffer
+  constexpr int NPL = PM == 1 ? 2 : 3;                                // planes per operand (f16x2: X1 | X2, X1 / 64 formed in registers)
+  constexpr int BUFC = NPL * TR * 4;                                  // 16-byte chunks per buffer
   extern __shared__ __attribute__((aligned(16))) u4v xlp_smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
   const long long m0 = (long long)by * TM;
   const int n0 = bx * TN;
 
-  constexpr int PA = (TM + RPS - 1) / RPS, PB = (TN + RPS - 1) / RPS, NA = 3 * PA, NB = 3 * PB, NCH = NA + NB;
+  constexpr int PA = (TM + RPS - 1) / RPS, PB = (TN + RPS - 1) / RPS, NA = NPL * PA, NB = NPL * PB, NCH = NA + NB;
   u4v rch[NCH];
   const int srow = tid >> 2, sch = tid & 3;
   const int s_lds = srow * 4 + (sch ^ ((srow >> 2) & 3));             // this thread's chunk inside a pass of RPS rows
@@ -122,9 +124,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
   static_assert(WMB == 4 && WNB == 4, "the mid-barrier schedule is written for 4 x 4 blocks");
   auto main_loop = [&](auto fast_c) {
   Split3 sa[4], sw[4], sw0n;
-  auto rdA = [&](Split3& dst, const u4v* base, int j) { const u4v* pa = base + (wm + 16 * j) * 4; dst.h = pa[0]; dst.m = pa[TR * 4]; dst.l = pa[2 * TR * 4]; };
-  auto rdW = [&](Split3& dst, const u4v* base, int i) { const u4v* pw = base + (TM + wn + 16 * i) * 4; dst.h = pw[0]; dst.m = pw[TR * 4]; dst.l = pw[2 * TR * 4]; };
+  // (f16x2: plane 0 = X1, plane 1 = X2; the middle term X1 / 64 is four v_pk_mul_f16 on the fragment -- exact: a power of two)
+  auto d64 = [](u4v h) { return __builtin_bit_cast(u4v, __builtin_bit_cast(hf8, h) * (_Float16)0.015625f); };
+  auto rdA = [&](Split3& dst, const u4v* base, int j) {
+    const u4v* pa = base + (wm + 16 * j) * 4;
+    if constexpr (PM == 1) { dst.h = pa[0]; dst.l = pa[TR * 4]; dst.m = d64(dst.h); }
+    else { dst.h = pa[0]; dst.m = pa[TR * 4]; dst.l = pa[2 * TR * 4]; }
+  };
+  auto rdW = [&](Split3& dst, const u4v* base, int i) {
+    const u4v* pw = base + (TM + wn + 16 * i) * 4;
+    if constexpr (PM == 1) { dst.h = pw[0]; dst.l = pw[TR * 4]; dst.m = d64(dst.h); }
+    else { dst.h = pw[0]; dst.m = pw[TR * 4]; dst.l = pw[2 * TR * 4]; }
+  };
   auto mm = [&](const Split3& w_, const Split3& a0, const Split3& a1, f4& c0, f4& c1) {       // two accumulators, product-major
+    if constexpr (PM == 1) {
+      c0 = mfma_f16(w_.l, a0.m, c0); c1 = mfma_f16(w_.l, a1.m, c1);
+      c0 = mfma_f16(w_.m, a0.l, c0); c1 = mfma_f16(w_.m, a1.l, c1);
+      c0 = mfma_f16(w_.h, a0.h, c0); c1 = mfma_f16(w_.h, a1.h, c1);
+      return;
+    }
     c0 = mfma_bf16(w_.l, a0.h, c0); c1 = mfma_bf16(w_.l, a1.h, c1);
     c0 = mfma_bf16(w_.h, a0.l, c0); c1 = mfma_bf16(w_.h, a1.l, c1);
     c0 = mfma_bf16(w_.m, a0.m, c0); c1 = mfma_bf16(w_.m, a1.m, c1);
@@ -133,6 +151,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
     c0 = mfma_bf16(w_.h, a0.h, c0); c1 = mfma_bf16(w_.h, a1.h, c1);
   };
   auto mm4 = [&](const Split3& a_, int j) {                                                     // four accumulators (all W, one A)
+    if constexpr (PM == 1) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (p == 0) acc[i][j] = mfma_f16(sw[i].l, a_.m, acc[i][j]);
+          if (p == 1) acc[i][j] = mfma_f16(sw[i].m, a_.l, acc[i][j]);
+          if (p == 2) acc[i][j] = mfma_f16(sw[i].h, a_.h, acc[i][j]);
+        }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < 6; ++p)
 #pragma unroll
@@ -203,8 +232,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_xlp_kernel(const 
   gemm_epilogue<EPI, WMB, WNB, WAVES_N>(g, acc, m0, n0, wm, wn, w, c, q);
 }
 
-template <int WMB, int WNB, int WAVES_M, int WAVES_N>
-constexpr size_t gemm_xlp_lds_bytes() { return (size_t)2 * 3 * (16 * WMB * WAVES_M + 16 * WNB * WAVES_N) * 64; }
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, int PM = 0>
+constexpr size_t gemm_xlp_lds_bytes() { return (size_t)2 * (PM == 1 ? 2 : 3) * (16 * WMB * WAVES_M + 16 * WNB * WAVES_N) * 64; }
 
 constexpr int XLP_TM = 256, XLP_TN = 128;
 #ifndef XLP_MIN_TILES
@@ -215,9 +244,9 @@ inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 // The kernel's 144 KB of dynamic LDS have to be asked for once per instantiation: an entry point that is going to use the
 // planes form calls this FIRST and returns its error (the launches below cannot report one to their void callers)
 constexpr int XLP_WMB = 4, XLP_WNB = 4, XLP_WAVES_M = 4, XLP_WAVES_N = 2;
-template <int EPI>
+template <int EPI, int PM = 0>
 int gemm_planes_prepare() {
-  constexpr size_t lds = gemm_xlp_lds_bytes<XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>();
+  constexpr size_t lds = gemm_xlp_lds_bytes<XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N, PM>();
   static_assert(lds <= 160 * 1024, "two plane buffers must fit the CU's LDS");
   // The attribute is per DEVICE: remembered per device id (one bit each, atomically -- the only process-wide word the library
   // keeps, and it only ever says "already asked"); ids beyond 63 simply ask every time.  (Round 4 kept ONE flag: a second GPU of
@@ -227,7 +256,7 @@ int gemm_planes_prepare() {
   if (hipGetDevice(&dev) != hipSuccess) return fail(L2HMC_ERR_HIP, "gemm planes: %s", "hipGetDevice failed");
   const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
   if (bit && (asked.load(std::memory_order_acquire) & bit)) return L2HMC_OK;
-  auto kern = gemm_xlp_kernel<EPI, XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>;
+  auto kern = gemm_xlp_kernel<EPI, XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N, PM>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(L2HMC_ERR_HIP, "gemm planes: %s", "the device refuses the LDS size of the 256-row plane tiles");
   asked.fetch_or(bit, std::memory_order_release);
@@ -239,12 +268,13 @@ int launch_gemm_planes(const GemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return L2HMC_OK;
   if (g.ldap < ceil_to(g.K, 32) || g.ldbp < ceil_to(g.K, 32) || (g.ldap & 7) || (g.ldbp & 7))
     return fail(L2HMC_ERR_ARG, "gemm planes: row strides must cover ceil32(K) (zero-padded) in multiples of 8%s");
-  const int rc = gemm_planes_prepare<EPI>();
+  const int rc = g.pm ? gemm_planes_prepare<EPI, 1>() : gemm_planes_prepare<EPI, 0>();
   if (rc != L2HMC_OK) return rc;
   const dim3 grid((unsigned)((g.N + XLP_TN - 1) / XLP_TN), (unsigned)((g.M + XLP_TM - 1) / XLP_TM));
-  constexpr size_t lds = gemm_xlp_lds_bytes<XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>();
-  auto kern = gemm_xlp_kernel<EPI, XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N>;
-  hipLaunchKernelGGL(kern, grid, dim3(64 * XLP_WAVES_M * XLP_WAVES_N), lds, s, g);
+  constexpr size_t lds = gemm_xlp_lds_bytes<XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N, 0>();
+  constexpr size_t lds1 = gemm_xlp_lds_bytes<XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N, 1>();
+  if (g.pm) hipLaunchKernelGGL((gemm_xlp_kernel<EPI, XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N, 1>), grid, dim3(64 * XLP_WAVES_M * XLP_WAVES_N), lds1, s, g);
+  else hipLaunchKernelGGL((gemm_xlp_kernel<EPI, XLP_WMB, XLP_WNB, XLP_WAVES_M, XLP_WAVES_N, 0>), grid, dim3(64 * XLP_WAVES_M * XLP_WAVES_N), lds, s, g);
   return L2HMC_OK;
 }
 // can this product take the pre-split form?  (decoder-sized: from 3072 chains at the widths of config 5 -- a third of the CUs get a
@@ -260,7 +290,7 @@ inline int bce_tiles_planes(int n_pix) { return (n_pix + XLP_TN - 1) / XLP_TN; }
 
 // fp32 matrix (rows x K, row stride ld) -> its three bf16 planes of rows_pad x ldp elements each (rows_pad >= rows, ldp >= K, both
 // zero-filled beyond the matrix): weights, once per parameter update
-__global__ void to_planes_kernel(const float* W, int ld, long long rows, int K, unsigned short* P, long long rows_pad, int ldp) {
+__global__ void to_planes_kernel(const float* W, int ld, long long rows, int K, unsigned short* P, long long rows_pad, int ldp, int pm) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 4 consecutive k
   const int K4 = ldp / 4;
   if (i >= rows_pad * K4) return;
@@ -274,17 +304,22 @@ __global__ void to_planes_kernel(const float* W, int ld, long long rows, int K, 
     if (k + 2 < K) v.z = p[2];
     if (k + 3 < K) v.w = p[3];
   }
-  const Split4 sp = split4(v);
+  const Split4 sp = pm ? split4_f16(v) : split4(v);
   typedef unsigned u2v __attribute__((ext_vector_type(2)));
   unsigned short* o = P + r * ldp + k;
   const long long plane = rows_pad * (long long)ldp;
   *reinterpret_cast<u2v*>(o) = u2v{sp.h[0], sp.h[1]};
+  if (pm) {                                                      // f16x2: X1 | X2 (the third plane of the allocation stays unused)
+    *reinterpret_cast<u2v*>(o + plane) = u2v{sp.l[0], sp.l[1]};
+    return;
+  }
   *reinterpret_cast<u2v*>(o + plane) = u2v{sp.m[0], sp.m[1]};
   *reinterpret_cast<u2v*>(o + 2 * plane) = u2v{sp.l[0], sp.l[1]};
 }
-inline void to_planes(hipStream_t s, const float* W, int ld, long long rows, int K, unsigned short* P, long long rows_pad, int ldp) {
+inline void to_planes(hipStream_t s, const float* W, int ld, long long rows, int K, unsigned short* P, long long rows_pad, int ldp,
+                      int pm = 0) {
   const long long n = rows_pad * (ldp / 4);
-  hipLaunchKernelGGL(to_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ld, rows, K, P, rows_pad, ldp);
+  hipLaunchKernelGGL(to_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ld, rows, K, P, rows_pad, ldp, pm);
 }
 // zero the columns [N, ldp) of the three planes of an activation the epilogues write (they only touch columns < N)
 __global__ void planes_zero_pad_kernel(unsigned short* P, long long rows, int N, int ldp) {

@@ -286,11 +286,14 @@ struct Mlp3Ws {
 // L2hmcSplitArgs.gemm_mode / L2hmcTrainSplitArgs.gemm_mode of the call being served on this thread (set at the top of every
 // entry point, so no state survives a call): 1 = the decoder-sized products run as bf16x3 (gemm_f32.hpp)
 thread_local int t_gemm_bf3 = 0;
+// 1 = the pre-split planes of the call being served are f16x2 (GemmArgs.pm; gemm_mode 3: the sampler only)
+thread_local int t_plane_mode = 0;
 
 inline GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, long long M, int N, int K) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.bf3 = t_gemm_bf3;
+  g.pm = t_plane_mode;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.beta = 1.f;
   return g;
 }
@@ -467,6 +470,7 @@ int l2hmc_bf16_planes(const float* W, int32_t ld, int64_t rows, int32_t K, uint1
 int l2hmc_vae_energy(const L2hmcMlp3* decoder, const float* aux, const float* x, int64_t n_chains, int32_t d,
                      float* U_out, float* grad_out, float* workspace, float bce_scale, void* stream) {
   t_gemm_bf3 = 0;
+  t_plane_mode = 0;
   int rc = check_mlp(decoder, "l2hmc_vae_energy");
   if (rc) return rc;
   if (!aux || !x || !workspace || n_chains < 0 || d != decoder->n_in) return fail(L2HMC_ERR_ARG, "l2hmc_vae_energy: bad argument%s");
@@ -499,8 +503,9 @@ int l2hmc_p_accept_energies(const float* U0, const float* v0, const float* U1, c
 
 int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
-  if (a->gemm_mode < 0 || a->gemm_mode > 2) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA), 1 (bf16x3) or 2 (bf16x3, split in the loop)%s");
+  if (a->gemm_mode < 0 || a->gemm_mode > 3) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA), 1 (bf16x3), 2 (bf16x3, split in the loop) or 3 (f16x2 planes)%s");
   t_gemm_bf3 = a->gemm_mode != 0;
+  t_plane_mode = a->gemm_mode == 3;
   const bool user = a->energy_cb != nullptr;        // the caller's own energy, evaluated on the host between launches
   const bool builtin = a->energy != nullptr;        // a target of utils/distributions.py instead of the decoder posterior
   const bool unets = a->net_cb != nullptr;          // the caller's own S/T/Q nets (any callable, dynamics.py:69-79)
@@ -543,12 +548,16 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   static const L2hmcMlp3 no_dec = {};
   const L2hmcMlp3& dec = (builtin || user) ? no_dec : *a->decoder;
   Mlp3Ws dws = {w + p.dw1t, w + p.dw2t, w + p.dw3t, w + p.a1, w + p.s1, w + p.a2, w + p.s2};
-  const bool use_planes = p.planes && a->gemm_mode == 1 && !builtin && !user;
+  const bool use_planes = p.planes && (a->gemm_mode == 1 || a->gemm_mode == 3) && !builtin && !user;
   // (what l2hmc_last_kernel reports for this engine: the kernel of the decoder-sized products, or the net evaluation)
   note_kernel(builtin || user ? "net_eval_kernel" : use_planes ? "gemm_xlp_kernel" : "gemm_nt_kernel");
   if (use_planes) {     // the three epilogues vae_energy launches on planes
-    if ((rc = gemm_planes_prepare<EPI_BIAS_SOFTPLUS>()) != L2HMC_OK || (rc = gemm_planes_prepare<EPI_BCE>()) != L2HMC_OK ||
-        (rc = gemm_planes_prepare<EPI_MUL>()) != L2HMC_OK)
+    if (t_plane_mode) {
+      if ((rc = gemm_planes_prepare<EPI_BIAS_SOFTPLUS, 1>()) != L2HMC_OK || (rc = gemm_planes_prepare<EPI_BCE, 1>()) != L2HMC_OK ||
+          (rc = gemm_planes_prepare<EPI_MUL, 1>()) != L2HMC_OK)
+        return rc;
+    } else if ((rc = gemm_planes_prepare<EPI_BIAS_SOFTPLUS>()) != L2HMC_OK || (rc = gemm_planes_prepare<EPI_BCE>()) != L2HMC_OK ||
+               (rc = gemm_planes_prepare<EPI_MUL>()) != L2HMC_OK)
       return rc;
   }
   if (use_planes) {
@@ -573,10 +582,10 @@ int l2hmc_trajectory_split(const L2hmcSplitArgs* a, void* stream) {
   if (!builtin && !user && !have_w) {
     mlp3_transposes(s, dec, dws);
     if (use_planes) {       // the two decoder-sized layers, both orientations, as bf16 planes: once per parameter update
-      to_planes(s, dws.w2t, dec.n_h1, dec.n_h2, dec.n_h1, dws.pw2t, prows(dec.n_h2), pld(dec.n_h1));
-      to_planes(s, dws.w3t, dec.n_h2, dec.n_out, dec.n_h2, dws.pw3t, prows(dec.n_out), pld(dec.n_h2));
-      to_planes(s, dec.W2, dec.n_h2, dec.n_h1, dec.n_h2, dws.pw2, prows(dec.n_h1), pld(dec.n_h2));
-      to_planes(s, dec.W3, dec.n_out, dec.n_h2, dec.n_out, dws.pw3, prows(dec.n_h2), pld(dec.n_out));
+      to_planes(s, dws.w2t, dec.n_h1, dec.n_h2, dec.n_h1, dws.pw2t, prows(dec.n_h2), pld(dec.n_h1), t_plane_mode);
+      to_planes(s, dws.w3t, dec.n_h2, dec.n_out, dec.n_h2, dws.pw3t, prows(dec.n_out), pld(dec.n_h2), t_plane_mode);
+      to_planes(s, dec.W2, dec.n_h2, dec.n_h1, dec.n_h2, dws.pw2, prows(dec.n_h1), pld(dec.n_h2), t_plane_mode);
+      to_planes(s, dec.W3, dec.n_out, dec.n_h2, dec.n_out, dws.pw3, prows(dec.n_h2), pld(dec.n_out), t_plane_mode);
       // the epilogues write the columns of an activation only: its padding up to a whole k-tile is zeroed here
       planes_zero_pad(s, dws.pa1, N, dec.n_h1, pld(dec.n_h1));
       planes_zero_pad(s, dws.pa2, N, dec.n_h2, pld(dec.n_h2));

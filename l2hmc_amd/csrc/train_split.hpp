@@ -731,9 +731,10 @@ int64_t l2hmc_train_split_workspace_floats(int64_t n_chains, int32_t d, int32_t 
 }
 
 int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
-  if (a && (a->gemm_mode < 0 || a->gemm_mode > 2)) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA), 1 (bf16x3) or 2 (bf16x3, split in the loop)%s");
+  if (a && (a->gemm_mode < 0 || a->gemm_mode > 3)) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA), 1 (bf16x3), 2 (bf16x3, split in the loop) or 3 (the sampler's f16x2 planes: bf16x3 here)%s");
   if (a && (a->net_mode < 0 || a->net_mode > 1)) return fail(L2HMC_ERR_ARG, "net_mode must be 0 (fused) or 1 (three products)%s");
   t_gemm_bf3 = a ? a->gemm_mode != 0 : 0;
+  t_plane_mode = 0;          // (the adjoint planes hold entries scaled by 1 / chains: they need bf16's exponent range)
   if (!a) return fail(L2HMC_ERR_ARG, "args is NULL%s");
   const bool builtin = a->energy != nullptr;
   const bool user = a->energy_cb != nullptr;       // the caller's energy: U / grad U and Hessian-vector products by callback
@@ -793,7 +794,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
   Mlp3Ws dws = {w + f.dw1t, w + f.dw2t, w + f.dw3t, w + f.a1, w + f.s1, w + f.a2, w + f.s2};
   // the decoder-sized products of the forward pass and of the Hessian-vector products on pre-split planes (round 5), when the
   // sampler's own planes rule says so (gemm_mode 1, >= 84 tiles: 3072 chains at config 5's widths)
-  const bool use_planes = vae && f.planes && a->gemm_mode == 1;
+  const bool use_planes = vae && f.planes && (a->gemm_mode == 1 || a->gemm_mode == 3);
   if (use_planes) {
     if ((rc = gemm_planes_prepare<EPI_BIAS_SOFTPLUS>()) != L2HMC_OK || (rc = gemm_planes_prepare<EPI_BCE>()) != L2HMC_OK ||
         (rc = gemm_planes_prepare<EPI_MUL>()) != L2HMC_OK || (rc = gemm_planes_prepare<EPI_TAN>()) != L2HMC_OK)

@@ -61,8 +61,9 @@ class Dynamics(object):
         self.eps_override = None        # float: bypass exp(alpha) (exact step size for parity tests)
         self.anneal_beta = 0.0          # AIS bridge (utils/ais.py:46-47): U := (1-b) |x|^2/2 + b U; 0 = off
         self._user_nets = False         # nets outside the fused architecture: evaluated by the caller's torch code (net_cb)
-        self.gemm_mode = 1              # GEMM engine, decoder-sized products: 1 = bf16x3 (exact 3-way bf16 split of every
-        #                                 fp32 operand on the bf16 MFMA, fp32-level accuracy), 0 = f32-input MFMA
+        self.gemm_mode = 3              # GEMM engine, decoder-sized products: 3 = f16x2 planes (exact 2-way f16 split, three f16
+        #                                 MFMAs per product block; the trainer runs mode 1 for it), 1 = bf16x3 (exact 3-way bf16
+        #                                 split of every fp32 operand, six bf16 MFMAs), 0 = f32-input MFMA: include/l2hmc.h
         self.net_mode = 0               # GEMM-engine trainer: 0 = one launch per net evaluation / per its reverse; 1 = three products each (A/B)
 
         if not isinstance(energy_function, EnergyFunction):
@@ -504,7 +505,8 @@ class Dynamics(object):
             for m3 in (self._xw['aux_encoder'], self._fn.decoder if self._vae else None):
                 if m3 is not None:
                     ws_ += [m3[k] for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')]
-            wkey = (self._split_ws.data_ptr(), N, self.T) + tuple((t.data_ptr(), t._version) for t in ws_)
+            # (gemm_mode: the decoder weights sit in the workspace as the planes of THAT arithmetic)
+            wkey = (self._split_ws.data_ptr(), N, self.T, int(self.gemm_mode)) + tuple((t.data_ptr(), t._version) for t in ws_)
         reuse = 0
         if wkey is not None and wkey == self._split_key:
             reuse |= 1

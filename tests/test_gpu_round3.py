@@ -517,14 +517,15 @@ def test_training_the_vae_sampler_on_a_plain_closure_matches_the_reference_graph
     print("closure-trained VAE sampler: loss %.6e (ref %.6e)  worst tensor %s at %.2f of its gate" % (float(loss), float(g["loss"]), worst[1], worst[0]))
 
 
-@pytest.mark.parametrize("gemm_mode", [0, 1])
+@pytest.mark.parametrize("gemm_mode", [0, 1, 3])
 def test_config5_at_a_chain_count_that_takes_the_big_gemm_tiles(gemm_mode):
     """Config 5's widths (decoder 50 -> 1024 -> 1024 -> 784, H = 200 nets + image branch, Lf = 5) at 3072 chains -- the
     smallest batch whose decoder products take the big workgroup tiles, i.e. the kernels the 8192-chain numbers are quoted on
     (`test_config5_full_size_against_oracle`, 192 chains, only reaches the 64 x 64 form).  Both arithmetic modes of those
     products: 0 = f32-input MFMA on 128 x 128 / 128 x 112 tiles (gemm_nt_kernel), 1 = bf16x3 (exact three-way bf16 split of every
     fp32 operand, six products on the bf16 MFMA, fp32 accumulation) -- since round 4 on PRE-SPLIT planes and 256 x 128 tiles
-    (gemm_xlp_kernel; the in-loop split of round 3 stays in the training path, test below).  SAME tolerances for both, against
+    (gemm_xlp_kernel; the in-loop split of round 3 stays in the training path, test below), 3 = f16x2 planes (round 6: exact
+    two-way f16 split, THREE f16 MFMAs per block pair on the same plane layout; what Dynamics asks for).  SAME tolerances for all, against
     the float64 evaluation of the same map: positions 2e-4 relative, accept probability 1e-4 absolute (north_star)."""
     from l2hmc_amd import propose
     from tests.helpers import synthetic_vae_case
@@ -539,7 +540,7 @@ def test_config5_at_a_chain_count_that_takes_the_big_gemm_tiles(gemm_mode):
     Lx, _, px, outs = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(g["v"]),
                               u=to_dev(u), aux=aux)
     from l2hmc_amd import _ffi
-    assert _ffi.last_kernel() == ("gemm_xlp_kernel" if gemm_mode == 1 else "gemm_nt_kernel")
+    assert _ffi.last_kernel() == ("gemm_xlp_kernel" if gemm_mode in (1, 3) else "gemm_nt_kernel")
     od64 = oracle_dynamics(g, np.float64)
     with np.errstate(all="ignore"):
         tLx, _, tpx, _ = O.propose(g["x"].astype(np.float64), od64, g["v"].astype(np.float64), g["v"].astype(np.float64),

@@ -227,7 +227,7 @@ def test_config5_on_presplit_planes(N):
     from tests.helpers import aux_of, synthetic_vae_case
     g = synthetic_vae_case(N=N, seed=6)
     dyn = hip_dynamics(g)
-    assert dyn.gemm_mode == 1
+    assert dyn.gemm_mode == 3                                 # (f16x2 planes; the bf16x3 planes of round 4 are re-run below)
     rng = np.random.RandomState(3)
     direction = rng.randint(0, 2, size=N).astype(np.uint8)
     u = rng.rand(N).astype(np.float32)
@@ -248,6 +248,13 @@ def test_config5_on_presplit_planes(N):
     Lx0, _, px0, _ = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(g["v"]), u=to_dev(u), aux=aux)
     assert _ffi.last_kernel() == "gemm_nt_kernel"
     assert rel_err(to_np(Lx), to_np(Lx0)) < 2e-4 and abs_err(to_np(px), to_np(px0)) < 1e-4
+    # ... and so do the bf16x3 planes (gemm_mode 1), against the float64 map
+    dyn.gemm_mode = 1
+    Lx1, _, px1, _ = propose(to_dev(g["x"]), dyn, do_mh_step=True, direction=to_dev(direction), v=to_dev(g["v"]), u=to_dev(u), aux=aux)
+    assert _ffi.last_kernel() == "gemm_xlp_kernel"
+    e1x, e1p = rel_err(to_np(Lx1), tLx), abs_err(to_np(px1), tpx)
+    print("          bf16x3 planes: max rel err x %.2e  |p - p64| max %.2e   (f16x2 planes above: %.2e / %.2e)" % (e1x, e1p, ex, ep))
+    assert e1x < 2e-4 and e1p < 1e-4
 
 
 def test_device_bf16_planes_equal_the_numpy_restatement():
