@@ -112,6 +112,12 @@ __device__ __forceinline__ WF16 wsplit16(f4 w) {
   f.a2 = h8v{L01.x, L01.y, L23.x, L23.y, l01.x, l01.y, l23.x, l23.y};
   return f;
 }
+// The states a proposal starts from and arrives at are checked against this bound (|x|, |v|, |grad U|; one chain-wide flag beside
+// the energy sums): beyond it hd overflows, the hidden layer's relu can turn the NaN that follows into a plausible zero, and
+// the proposal is therefore POISONED instead -- Lx, Lv, log-det NaN, accept probability 0.  (The hidden activations have the
+// same bound; nets whose row sums of |W| exceed ~60 could reach it from states below it: variant 200 + v.)
+#define L2HMC_F16_STATE_MAX 4.0e6f
+__device__ __forceinline__ float amax4(f4 a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); }
 // acc += W^T a for the 16 logical k of one fragment
 __device__ __forceinline__ f4 mfma16x2(const WF16& W, h8v b, f4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.a1, b, acc, 0, 0, 0);
@@ -475,7 +481,12 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
 #pragma unroll
     for (int t = 0; t < DT; ++t) { x0[t] = x[t]; g0[t] = g[t]; }
     const f4 pv0 = pv[0];
-    float red[5];                  // U0, K0, U1, K1, logdet (per-lane partial sums)
+    float red[F16 ? 6 : 5];        // U0, K0, U1, K1, logdet (per-lane partial sums); f16x2: + the out-of-range flag
+    float amax_l = 0.f;
+    if constexpr (F16) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) amax_l = fmaxf(amax_l, fmaxf(amax4(x[t]), fmaxf(amax4(v[t]), amax4(g[t]))));
+    }
     red[0] = U_start;
     red[1] = 0.f;
 #pragma unroll
@@ -582,16 +593,29 @@ __global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(co
 
     // ---- per-proposal epilogue: proposal, log-det, accept probability, MH select -------------------
     const bool last = m == A.M - 1;
-    if (last) {
-      store_state<DT, NW>(A.x_out, A, chain, live, w, q, x);
-      store_state<DT, NW>(A.v_out, A, chain, live, w, q, v);
-    }
     red[3] = 0.f;
 #pragma unroll
     for (int t = 0; t < DT; ++t) red[3] += 0.5f * hsum(v[t] * v[t]);
     red[4] = ld;
     const float U_end = red[2];
-    chain_allreduce<NW, 5>(red, smem + A.o_red, w, lane);
+    if constexpr (F16) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) amax_l = fmaxf(amax_l, fmaxf(amax4(x[t]), fmaxf(amax4(v[t]), amax4(g[t]))));
+      red[5] = amax_l < L2HMC_F16_STATE_MAX ? 0.f : 1.f;
+    }
+    chain_allreduce<NW, F16 ? 6 : 5>(red, smem + A.o_red, w, lane);
+    if constexpr (F16) {
+      if (red[5] > 0.f) {            // outside the f16x2 range: a loud non-result (see L2HMC_F16_STATE_MAX)
+        const float qnan = __uint_as_float(0x7fc00000u);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) { x[t] = splat(qnan); v[t] = splat(qnan); }
+        red[4] = qnan;
+      }
+    }
+    if (last) {
+      store_state<DT, NW>(A.x_out, A, chain, live, w, q, x);
+      store_state<DT, NW>(A.v_out, A, chain, live, w, q, v);
+    }
     const bool writer = live && w == 0 && lane < 16;
     if (A.logjac_out != nullptr && writer) A.logjac_out[moff + chain] = red[4];
     if (need_p) {

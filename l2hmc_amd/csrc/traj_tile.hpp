@@ -418,6 +418,11 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
     red[1] = 0.f;
 #pragma unroll
     for (int t = 0; t < DT; ++t) red[1] += 0.5f * hsum(v[t] * v[t]);
+    float amax_l = 0.f;            // f16x2: the end points of the proposal against L2HMC_F16_STATE_MAX (traj_fast.hpp)
+#if L2HMC_BFH_TILE == 2
+#pragma unroll
+    for (int t = 0; t < DT; ++t) amax_l = fmaxf(amax_l, fmaxf(amax4(x[t]), fmaxf(amax4(v[t]), amax4(g[t]))));
+#endif
     f4 ldv = Z;
     const float ff = fwd ? 1.f : 0.f, nf = ff - 1.f;
     const int dofs = fwd ? 0 : DPp;
@@ -524,10 +529,6 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
       }, std::integral_constant<int, DT>());
     }
     const bool last = m == A.M - 1;
-    if (last) {
-      store_state<DT, 1>(A.x_out, A, chain, live, 0, q, x);
-      store_state<DT, 1>(A.v_out, A, chain, live, 0, q, v);
-    }
     red[2] = energy_part(x, g);
     red[3] = 0.f;
 #pragma unroll
@@ -538,6 +539,25 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
     for (int i = 0; i < 5; ++i) {
       red[i] += __shfl_xor(red[i], 16);
       red[i] += __shfl_xor(red[i], 32);
+    }
+#if L2HMC_BFH_TILE == 2
+    {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) amax_l = fmaxf(amax_l, fmaxf(amax4(x[t]), fmaxf(amax4(v[t]), amax4(g[t]))));
+      float oor = amax_l < L2HMC_F16_STATE_MAX ? 0.f : 1.f;
+      oor += __shfl_xor(oor, 16);
+      oor += __shfl_xor(oor, 32);
+      if (oor > 0.f) {               // outside the f16x2 range: a loud non-result
+        const float qnan = __uint_as_float(0x7fc00000u);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) { x[t] = splat(qnan); v[t] = splat(qnan); }
+        red[4] = qnan;
+      }
+    }
+#endif
+    if (last) {
+      store_state<DT, 1>(A.x_out, A, chain, live, 0, q, x);
+      store_state<DT, 1>(A.v_out, A, chain, live, 0, q, v);
     }
     const bool writer = live && lane < 16;
     if (A.logjac_out != nullptr && writer) A.logjac_out[moff + chain] = red[4];

@@ -352,3 +352,55 @@ def test_separate_image_branches_per_net_match_the_oracle():
     check_x_next(to_np(outs[0]), g["x"], rLx, rpx, u, P_TOL)
     # ... and it is NOT what the shared-branch fixture gives (the second branch matters)
     assert rel_err(to_np(Lx), g["prop.Lx"]) > 1e-3 or not np.array_equal(direction, g["prop.dir"])
+
+
+# ---- f16x2 contractions (csrc/traj_fast.hpp, traj_tile.hpp): what takes them, what keeps the f32-input MFMA, what overflow does ----
+def test_f16x2_dispatch_names_and_the_f32_switch():
+    """The elementwise targets run their four-wave and one-wave tile kernels with every contraction as two f16 MFMAs on an exact
+    split of both operands; `variant 200 + v` keeps the f32-input MFMA for the same geometry (the tile form then gives way to the
+    four-wave kernel), the funnel / mixtures / dense Gaussians never leave it.  Both arithmetics sit within the suite's
+    tolerances of the reference fixture AND within 5e-6 of each other on it (two fp32-accurate evaluations of one map)."""
+    from l2hmc_amd import _ffi, propose
+    g = load("icg50")
+    x, v = to_dev(g["x"]), to_dev(g["v"])
+    outs = {}
+    for var, name in ((4, "traj_fast_kernel<1, 1, 4, 3, 1>"), (204, "traj_fast_kernel<1, 1, 4, 3>"), (16, "traj_tile_kernel<1, 4, 3, 4, true>"),
+                      (1, "traj_kernel<1, 4, 1, 3>")):
+        dyn = hip_dynamics(g, var)
+        X, V, lj = dyn.forward(x, init_v=v, log_jac=True)
+        assert _ffi.last_kernel() == name, (var, _ffi.last_kernel())
+        outs[var] = (to_np(X), to_np(V), to_np(lj))
+        for got, key in zip(outs[var], ("fwd.x", "fwd.v", "fwd.logjac")):
+            assert rel_err(got, g[key]) < TRAJ_TOL, (var, key)
+    for var in (204, 16, 1):
+        for a, b in zip(outs[4], outs[var]):
+            assert rel_err(a, b) < 5e-6, var
+    dyn = hip_dynamics(g, 216)
+    with pytest.raises(RuntimeError):                 # the one-wave tile kernel has no f32-input form
+        dyn.forward(x, init_v=v)
+    f = load("funnel3")
+    hip_dynamics(f, 0).forward(to_dev(f["x"]), init_v=to_dev(f["v"]))
+    assert not _ffi.last_kernel().endswith(", 1>") or "traj_small" in _ffi.last_kernel()
+
+
+def test_f16x2_range_is_wide_and_its_overflow_is_loud():
+    """States of 1e5 -- beyond f16's 65504 -- are fine: the split works on a / 64 (range 4.2e6), and the result stays within 1e-5 of
+    the f32-input MFMA's.  States of 1e7 or 1e9 are outside it: the kernel checks the end points of every proposal against
+    L2HMC_F16_STATE_MAX and returns a NaN proposal with accept probability 0 (never a wrong finite number: the hidden layer's
+    relu would otherwise turn the overflow's NaN into a plausible zero), one wave per tile and four alike; the f32 switch
+    evaluates such states."""
+    g = dict(load("icg50"))
+    x0, v = g["x"].copy(), to_dev(g["v"])
+    for scale, finite in ((1e5, True), (1e7, False), (1e9, False)):
+        x = x0.copy()
+        x[:, 40:] += np.float32(scale)
+        d32 = hip_dynamics(g, 204)
+        X32, _, p32 = d32.forward(to_dev(x), init_v=v)
+        assert np.isfinite(to_np(X32)).all()
+        for var in (4, 16):
+            d16 = hip_dynamics(g, var)
+            X16, V16, p16 = d16.forward(to_dev(x), init_v=v)
+            if finite:
+                assert rel_err(to_np(X16) / scale, to_np(X32) / scale) < 1e-5 and abs_err(to_np(p16), to_np(p32)) < 1e-4
+            else:
+                assert np.isnan(to_np(X16)).all() and np.isnan(to_np(V16)).all() and np.all(to_np(p16) == 0), (scale, var)

@@ -69,7 +69,7 @@ mb, wc = mean("pmc_sq2", "SQ_VALU_MFMA_BUSY_CYCLES"), mean("pmc_sq", "SQ_WAVE_CY
 if f is not None and w is not None:
     json.dump({"mfma_pipe_busy": (mb / (4.0 * wc)) if (mb and wc) else None,
                "mfma_pipe_busy_source": "profiles/r06_pmc_summary.txt: SQ_VALU_MFMA_BUSY_CYCLES (cycles) / (4 x SQ_WAVE_CYCLES (quad-cycles)) of "
-                                        "traj_fast_kernel<1,1,4,3>, one wave per SIMD, per-dispatch means of two separate --pmc passes",
+                                        "traj_fast_kernel<1,1,4,3,1> (f16x2 contractions), one wave per SIMD, per-dispatch means of two separate --pmc passes",
                "source": "profiles/r06_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of tools/collect_r06.sh, "
                          "per-dispatch means of the trajectory kernel; written by the same script run as that summary)",
                "workload_chains": 4096, "proposals_per_launch": 25, "fetch_kb": round(f, 1), "write_kb": round(w, 1),
@@ -124,14 +124,14 @@ for r in csv.DictReader(open(fs[0])):
     k = r["Kernel_Name"].split("(")[0][:60]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 print("config 5 sampler (tools/bench_vae.py 8192), per-dispatch means.  GRBM_GUI_ACTIVE arrives summed over the 8 XCDs (gui / 8 = the kernel's cycles),")
-print("so  MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs);  f32 MFMA = 2048 flop, bf16 16x16x32 = 16384 flop per instruction")
+print("so  MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs);  f32 MFMA = 2048 flop, bf16 / f16 16x16x32 = 16384 flop per instruction (gemm_xlp_kernel<..., 1>: f16x2 planes, three products)")
 for k in sorted(acc, key=lambda k: -acc[k].get("GRBM_GUI_ACTIVE", 0)):
     c = {m: acc[k][m] / n[k][m] for m in acc[k]}
     if "GRBM_GUI_ACTIVE" not in c or c.get("SQ_INSTS_MFMA", 0) == 0: continue
     busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     bf16 = ("gemm_xlp" in k) or ("gemm_nt_kernel<" in k and k.rstrip().endswith(", 1>"))   # bf16 16x16x32 MFMAs (16 384 flop); the rest f32 16x16x4 (2048)
     print("%-62s calls %4d  MFMA insts %.3e (%s: %.2f GFLOP executed)  gui cycles / 8 %.3e  mfma-pipe busy %.2f" % (
-        k, n[k]["GRBM_GUI_ACTIVE"], c["SQ_INSTS_MFMA"], "bf16 16x16x32" if bf16 else "f32 16x16x4", c["SQ_INSTS_MFMA"] * (16384 if bf16 else 2048) / 1e9,
+        k, n[k]["GRBM_GUI_ACTIVE"], c["SQ_INSTS_MFMA"], "bf16/f16 16x16x32" if bf16 else "f32 16x16x4", c["SQ_INSTS_MFMA"] * (16384 if bf16 else 2048) / 1e9,
         c["GRBM_GUI_ACTIVE"] / 8, busy))
 PY
 cat $OUT/vae_pmc_summary.txt
