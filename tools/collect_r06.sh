@@ -105,7 +105,7 @@ cd $R
 timeout 200 python tools/bench_train.py --no-cpu 2>&1 | grep -v amdgpu > $OUT/train_timing.txt
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trk -o t -- python $R/tools/bench_train.py --no-cpu > /dev/null 2>&1; cp $OUT/trk/t_kernel_stats.csv $OUT/train_kernel_stats.csv 2>/dev/null; rm -rf $OUT/trk)
 timeout 200 python tools/bench_vae_train.py 2>&1 | grep -v amdgpu > $OUT/vae_train_timing.txt
-timeout 100 python tools/bench_vae.py 8192 1 2>&1 | grep -v amdgpu > $OUT/vae_modes.txt
+(for m in 1 3; do timeout 100 python tools/bench_vae.py 8192 $m 2>&1; done) | grep -v amdgpu > $OUT/vae_modes.txt
 timeout 600 python tools/bench_configs.py 2>&1 | grep -v amdgpu > $OUT/configs.txt
 cat $OUT/train_timing.txt $OUT/vae_train_timing.txt $OUT/vae_modes.txt $OUT/configs.txt
 fi
