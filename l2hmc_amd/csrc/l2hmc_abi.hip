@@ -102,6 +102,15 @@ __global__ void pack_lane_kernel(L2hmcNet net, int d, int H, float* out) {
   out[idx] = val;
 }
 
+// f16x2 fragments of one packed net (all its groups): thread = (group, lane)
+__global__ void pack_f16_kernel(const float* src, int groups, float* dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= groups * 64) return;
+  const WF16 f = wsplit16(reinterpret_cast<const f4*>(src)[idx]);
+  reinterpret_cast<h8v*>(dst)[idx] = f.a1;
+  reinterpret_cast<h8v*>(dst + (size_t)groups * 256)[idx] = f.a2;
+}
+
 __global__ void step_prep_kernel(float* trig, float c, float s) {
   if (threadIdx.x == 0) { trig[0] = c; trig[1] = s; }
 }
@@ -503,7 +512,8 @@ int64_t l2hmc_packed_nets_floats(int32_t d, int32_t H) {
   if (d < 1 || H < 1) return fail(L2HMC_ERR_ARG, "d and H must be >= 1%s");
   if (H > 15) return fail(L2HMC_ERR_UNSUPPORTED, "fused nets support H <= 15 (got %s%lld)", "", H);
   if (d > 512) return fail(L2HMC_ERR_UNSUPPORTED, "fused nets support d <= 512 (got %s%lld)", "", d);
-  return 2LL * net_floats(tiles_of(d)) + 2LL * lane_layout(d, H).total;     // MFMA fragments, then the lane layout
+  // MFMA fragments, then the lane layout, then (round 6) the fragments once more as f16x2 pairs
+  return 2LL * net_floats(tiles_of(d)) + 2LL * lane_layout(d, H).total + 2LL * net_f16_floats(tiles_of(d));
 }
 
 int l2hmc_pack_nets(const L2hmcNet* xnet, const L2hmcNet* vnet, int32_t d, int32_t H,
@@ -522,6 +532,9 @@ int l2hmc_pack_nets(const L2hmcNet* xnet, const L2hmcNet* vnet, int32_t d, int32
     const int LT = lane_layout(d, H).total;                     // traj_lane.hpp: wave-uniform rows for the scalar loads
     hipLaunchKernelGGL(pack_lane_kernel, dim3((LT + 255) / 256), dim3(256), 0, (hipStream_t)stream, *nets[i], d, H,
                        packed + 2 * (size_t)NF + (size_t)i * LT);
+    const int NG = net_groups(NT);
+    hipLaunchKernelGGL(pack_f16_kernel, dim3((NG * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, packed + (size_t)i * NF, NG,
+                       packed + 2 * (size_t)NF + 2 * (size_t)LT + (size_t)i * net_f16_floats(NT));
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(L2HMC_ERR_HIP, "pack launch: %s", hipGetErrorString(e));
@@ -584,7 +597,9 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a_in, void* stream) {
   }
   KArgs k;
   memset(&k, 0, sizeof(k));
-  k.packed = a->packed_nets; k.masks = a->masks; k.trig = a->trig; k.alpha = a->alpha;
+  k.packed = a->packed_nets;
+  k.packed16 = (a->packed_nets && a->H <= 15) ? a->packed_nets + 2 * (size_t)net_floats(tiles_of(a->d)) + 2 * (size_t)lane_layout(a->d, a->H).total : nullptr;
+  k.masks = a->masks; k.trig = a->trig; k.alpha = a->alpha;
   k.eps_host = a->eps_host; k.N = a->n_chains; k.d = a->d; k.H = a->H; k.T = a->T;
   k.step_begin = a->step_begin; k.n_steps = a->n_steps; k.NT = tiles_of(a->d);
   k.x = a->x; k.v = a->v; k.dir = a->direction; k.dir_all = a->direction_all; k.u = a->u;
@@ -634,9 +649,11 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a_in, void* stream) {
     return fail(L2HMC_ERR_UNSUPPORTED, "variant 8 (LDS-resident state) needs S/T/Q nets, a Gaussian or Rough-Well target, 64 <= d <= 512 and x_next when n_proposals > 1%s");
   if (wide_able && (a->variant == 8 || (a->variant == 0 && k.NT > (wide_dense ? WIDE_DENSE_MIN_NT : 8)))) {
     KArgs kw = k;
+    // f16x2 contractions for the elementwise targets without a tempered / annealed energy, unless the f32-input MFMA is asked for
+    if (force_f32 || wide_dense || k.beta != 1.f || k.temperature != 1.f) kw.packed16 = nullptr;
     const long long ldsw = plan_lds_wide(kw);
     if (ldsw <= 160 * 1024) {
-      note_kernel("traj_wide_kernel");
+      note_kernel(kw.packed16 != nullptr ? "traj_wide_kernel<f16x2>" : "traj_wide_kernel");
       return launch_wide(kw, KH, ldsw, s);
     }
     if (a->variant == 8) return fail(L2HMC_ERR_UNSUPPORTED, "variant 8: %s%lld bytes of LDS needed (T x d too large)", "", ldsw);

@@ -86,6 +86,9 @@ int launch_wide(const KArgs& k, int KH, long long lds, hipStream_t s);
 __host__ __device__ inline int net_groups(int NT) { return 5 * NT + 2; }
 __host__ __device__ inline int net_floats(int NT) { return net_groups(NT) * 256 + 32 * NT; }
 __host__ __device__ inline int gauss_floats(int NT) { return NT * NT * 256; }
+// the same groups as f16x2 fragments (traj_fast.hpp: [64 w_hi | w_hi] then [64 w_lo | w_lo], 16 bytes per lane each; all first
+// fragments of a net, then all second ones): what traj_wide_kernel streams from L2 for the elementwise targets
+__host__ __device__ inline int net_f16_floats(int NT) { return net_groups(NT) * 512; }
 
 inline int tiles_of(int d) { return (d + 15) / 16; }
 inline int khid_of(int H) { return (H + 1 + 3) / 4; }
@@ -95,6 +98,7 @@ inline int khid_of(int H) { return (H + 1 + 3) / 4; }
 // ------------------------------------------------------------------------------------------
 struct KArgs {
   const float* packed;
+  const float* packed16;     // the f16x2 fragments of both nets (net_f16_floats each) behind the lane layout, or NULL
   const float* masks;
   const float* trig;
   const float* alpha;

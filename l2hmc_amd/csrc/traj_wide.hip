@@ -14,7 +14,8 @@
 // every wave forms G (x' - mu) for its own tiles as NT x 4 MFMAs per tile, the packed precision fragments
 // (l2hmc_pack_gaussian) streamed from L2 four tiles ahead, the other waves' x' tiles read from the LDS state.  The
 // mixture of Gaussians (:104-134) does that per component, with the online softmax of traj_kernel.
-#include "l2hmc_kernels.hpp"
+#include <type_traits>
+#include "traj_fast.hpp"
 
 namespace l2hmc {
 
@@ -62,10 +63,17 @@ __device__ __forceinline__ f4 wide_grad(const KArgs& A, const float* smem, int t
   return g;
 }
 
-template <int EK, int KH, int NW>
+// PK = 1 (round 6, the elementwise targets): every contraction as f16x2 (traj_fast.hpp) -- the fragments stream from L2 already
+// split (KArgs.packed16, l2hmc_pack_nets), an activation is split by the wave that consumes it (the second hidden activation
+// once per net evaluation for all the wave's tiles), and the end points of a proposal are held against L2HMC_F16_STATE_MAX.
+template <int EK, int KH, int NW, int PK = 0>
 __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
   constexpr bool GMMK = EK == L2HMC_ENERGY_GMM;                 // (both: grad U couples all dimensions)
   constexpr bool DENSE = EK == L2HMC_ENERGY_GAUSS_DENSE || GMMK;
+  constexpr bool F16 = PK == 1;
+  static_assert(!(F16 && DENSE), "f16x2: elementwise targets only");
+  typedef std::conditional_t<F16, WF16, f4> Frag;                // a weight fragment
+  typedef std::conditional_t<F16, h8v, f4> HidB;                 // the second hidden activation as the heads' B operand
   extern __shared__ __attribute__((aligned(16))) float smem[];
   lds_poison(smem);
   constexpr int NTHR = 64 * NW;
@@ -79,6 +87,9 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
   const int t_lo = w * DTW, t_hi = (t_lo + DTW < NT) ? t_lo + DTW : NT;     // this wave's tiles
   const float* wx = A.packed;            // XNet fragments (global, L2-hot)
   const float* wv = A.packed + NF;       // VNet fragments
+  const int NG = net_groups(NT);
+  const float* wx16 = A.packed16;        // (F16) the same groups as f16x2 pairs
+  const float* wv16 = A.packed16 + (F16 ? net_f16_floats(NT) : 0);
 
   // ---- prologue: masks / time table / energy parameters into LDS -----------------------------------
   for (int i = tid; i < A.T * DP; i += NTHR) {
@@ -132,44 +143,69 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
   __syncthreads();
 
   const f4 Z = splat(0.f), O = splat(1.f);
-  const f4 w2x = lds4(wx + ((2 * NT + 1) * 64 + lane) * 4), w2v = lds4(wv + ((2 * NT + 1) * 64 + lane) * 4);
   int pb = 0;
   // Weight fragments stream from L2 (several hundred cycles away) and a runtime tile loop is not
   // software-pipelined by the compiler: every pass fetches the fragments of tile tg + 1 while it works on tg.
-  auto frag = [&](const float* wn, int grp) { return lds4(wn + (grp * 64 + lane) * 4); };
-  struct HeadW { f4 Ws, Wt, Wq, es, eq; };
-  auto head_frag = [&](const float* wn, int tg) {
-    const float* sc = wn + net_groups(NT) * 256;
+  // `net`: 0 = XNet, 1 = VNet
+  auto frag = [&](int net, int grp) -> Frag {
+    if constexpr (F16) {
+      const float* b = (net ? wv16 : wx16) + (grp * 64 + lane) * 4;
+      return WF16{*reinterpret_cast<const h8v*>(b), *reinterpret_cast<const h8v*>(b + NG * 256)};
+    } else {
+      return lds4((net ? wv : wx) + (grp * 64 + lane) * 4);
+    }
+  };
+  const Frag w2x = frag(0, 2 * NT + 1), w2v = frag(1, 2 * NT + 1);
+  struct HeadW { Frag Ws, Wt, Wq; f4 es, eq; };
+  auto head_frag = [&](int net, int tg) {
+    const float* sc = (net ? wv : wx) + net_groups(NT) * 256;
     HeadW hw;
-    hw.Ws = frag(wn, 2 * NT + 2 + 3 * tg + 0);
-    hw.Wt = frag(wn, 2 * NT + 2 + 3 * tg + 1);
-    hw.Wq = frag(wn, 2 * NT + 2 + 3 * tg + 2);
+    hw.Ws = frag(net, 2 * NT + 2 + 3 * tg + 0);
+    hw.Wt = frag(net, 2 * NT + 2 + 3 * tg + 1);
+    hw.Wq = frag(net, 2 * NT + 2 + 3 * tg + 2);
     hw.es = lds4(sc + 16 * tg + 4 * q);
     hw.eq = lds4(sc + 16 * NT + 16 * tg + 4 * q);
     return hw;
   };
   // layer-1 contribution of one tile: acc += W^T z
-  auto l1 = [&](f4 acc, f4 W, f4 z) {
+  auto l1 = [&](f4 acc, const Frag& W, f4 z) {
+    if constexpr (F16) {
+      return mfma16x2(W, split16<false>(z), acc);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = MFMA16(W[r], z[r], acc);
-    return acc;
+      for (int r = 0; r < 4; ++r) acc = MFMA16(W[r], z[r], acc);
+      return acc;
+    }
   };
-  // hidden activations after layer 2 from the exchanged layer-1 sum
-  auto layer2 = [&](f4 w2, f4 hpre, f4 tb) {
+  // hidden activations after layer 2 from the exchanged layer-1 sum (F16: already split for the heads)
+  auto layer2 = [&](const Frag& w2, f4 hpre, f4 tb) -> HidB {
     const f4 h = relu4(hpre + tb);
-    f4 acc = Z;
+    if constexpr (F16) {
+      return split16<false>(relu4(mfma16x2(w2, split16<false>(h), Z)));
+    } else {
+      f4 acc = Z;
 #pragma unroll
-    for (int r = 0; r < KH; ++r) acc = MFMA16(w2[r], h[r], acc);
-    return relu4(acc);
+      for (int r = 0; r < KH; ++r) acc = MFMA16(w2[r], h[r], acc);
+      return relu4(acc);
+    }
   };
   // heads of tile tg: ES = 2^aS, aS = kS e^{lam_s} tanh(zs), T, EQ = 2^{kQ e^{lam_q} tanh(zq)}
-  auto heads = [&](const HeadW& hw, f4 h, float kS, float kQ, f4& ES, f4& aS, f4& Tt, f4& EQ) {
+  auto heads = [&](const HeadW& hw, const HidB& h, float kS, float kQ, f4& ES, f4& aS, f4& Tt, f4& EQ) {
     f4 zs = Z, zt = Z, zq = Z;
+    if constexpr (F16) {
+      zs = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw.Ws.a1, h, zs, 0, 0, 0);
+      zq = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw.Wq.a1, h, zq, 0, 0, 0);
+      zt = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw.Wt.a1, h, zt, 0, 0, 0);
+      zs = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw.Ws.a2, h, zs, 0, 0, 0);
+      zq = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw.Wq.a2, h, zq, 0, 0, 0);
+      zt = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw.Wt.a2, h, zt, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int r = 0; r < KH; ++r) {
-      zs = MFMA16(hw.Ws[r], h[r], zs);
-      zq = MFMA16(hw.Wq[r], h[r], zq);
-      zt = MFMA16(hw.Wt[r], h[r], zt);
+      for (int r = 0; r < KH; ++r) {
+        zs = MFMA16(hw.Ws[r], h[r], zs);
+        zq = MFMA16(hw.Wq[r], h[r], zq);
+        zt = MFMA16(hw.Wt[r], h[r], zt);
+      }
     }
     aS = ctanh4(hw.es * kS, zs);
     ES = exp2_4(aS);
@@ -180,6 +216,11 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
 
   // y = G (x - mu) of tile tg from the complete position in SX: NT x 4 MFMAs, the packed fragments of row-tile tg
   // (l2hmc_pack_gaussian order) streamed from L2 four tiles ahead
+  auto l1f = [&](f4 acc, f4 W, f4 z) {             // (dense precisions: f32-input MFMA)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = MFMA16(W[r], z[r], acc);
+    return acc;
+  };
   auto matvec_tile = [&](const float* Gp, const float* mu, int tg) {
     const float* Grow = Gp + (size_t)tg * NT * 256;
     auto gfrag = [&](int ti) { return lds4(Grow + ((ti < NT ? ti : NT - 1) * 64 + lane) * 4); };
@@ -187,10 +228,10 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
     f4 G0 = gfrag(0), G1 = gfrag(1), G2 = gfrag(2), G3 = gfrag(3);
     for (int t0 = 0; t0 < NT; t0 += 4) {
       const f4 N0 = gfrag(t0 + 4), N1 = gfrag(t0 + 5), N2 = gfrag(t0 + 6), N3 = gfrag(t0 + 7);
-      acc = l1(acc, G0, tl(SX, t0, lane) - lds4(mu + 16 * t0 + 4 * q));
-      if (t0 + 1 < NT) acc = l1(acc, G1, tl(SX, t0 + 1, lane) - lds4(mu + 16 * (t0 + 1) + 4 * q));
-      if (t0 + 2 < NT) acc = l1(acc, G2, tl(SX, t0 + 2, lane) - lds4(mu + 16 * (t0 + 2) + 4 * q));
-      if (t0 + 3 < NT) acc = l1(acc, G3, tl(SX, t0 + 3, lane) - lds4(mu + 16 * (t0 + 3) + 4 * q));
+      acc = l1f(acc, G0, tl(SX, t0, lane) - lds4(mu + 16 * t0 + 4 * q));
+      if (t0 + 1 < NT) acc = l1f(acc, G1, tl(SX, t0 + 1, lane) - lds4(mu + 16 * (t0 + 1) + 4 * q));
+      if (t0 + 2 < NT) acc = l1f(acc, G2, tl(SX, t0 + 2, lane) - lds4(mu + 16 * (t0 + 2) + 4 * q));
+      if (t0 + 3 < NT) acc = l1f(acc, G3, tl(SX, t0 + 3, lane) - lds4(mu + 16 * (t0 + 3) + 4 * q));
       G0 = N0; G1 = N1; G2 = N2; G3 = N3;
     }
     return acc;
@@ -201,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
     __syncthreads();
     const float* mu = smem + A.o_mu;
     for (int tg = t_lo; tg < t_hi; ++tg) {
-      const f4 Wb = frag(wv, NT + tg);
+      const Frag Wb = frag(1, NT + tg);
       const f4 acc = matvec_tile(A.prec, mu, tg);
       const f4 x = tl(SX, tg, lane);
       float u = wantU ? 0.5f * hsum((x - lds4(mu + 16 * tg + 4 * q)) * acc) : 0.f;
@@ -254,7 +295,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
         }
         g = g * it;
         ts(SG, tg, lane, g);
-        a1 = l1(a1, frag(wv, NT + tg), g);
+        a1 = l1(a1, frag(1, NT + tg), g);
       }
     }
     if (wantU && w == 0 && lane < 16) U += A.beta * -(m + logf(ssum)) * it;      // once per chain
@@ -266,9 +307,9 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
   auto refresh = [&]() {                  // SG, U_start, pv from SX
     U_start = 0.f;
     f4 a0 = Z, a1 = Z;
-    f4 Wa = frag(wv, t_lo), Wb = frag(wv, NT + t_lo);
+    Frag Wa = frag(1, t_lo), Wb = frag(1, NT + t_lo);
     for (int tg = t_lo; tg < t_hi; ++tg) {
-      const f4 Wa_n = frag(wv, nxt(tg)), Wb_n = frag(wv, NT + nxt(tg));
+      const Frag Wa_n = frag(1, nxt(tg)), Wb_n = frag(1, NT + nxt(tg));
       const f4 x = tl(SX, tg, lane);
       a0 = l1(a0, Wa, x);
       if (!DENSE) {
@@ -303,7 +344,8 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       if (rng_d) fwd = fr;
       if (rng_u) u_m = ur;
     }
-    float red[5];                          // U0, K0, U1, K1, logdet (per-lane partial sums)
+    float red[F16 ? 6 : 5];                // U0, K0, U1, K1, logdet (per-lane partial sums); f16x2: + the out-of-range flag
+    float amax_l = 0.f;
     red[0] = U_start;
     red[1] = 0.f;
     for (int tg = t_lo; tg < t_hi; ++tg) {
@@ -318,6 +360,7 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       }
       ts(SV, tg, lane, v);
       red[1] += 0.5f * hsum(v * v);
+      if constexpr (F16) amax_l = fmaxf(amax_l, fmaxf(amax4(v), fmaxf(amax4(tl(SX, tg, lane)), amax4(tl(SG, tg, lane)))));
     }
     red[2] = U_start;                      // (n_steps == 0: the end point is the start point)
     f4 ldv = splat(0.f);
@@ -333,13 +376,13 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
         return sel4(fwd, mk, O - mk);
       };
       // ---- momentum half-update #1 (dynamics.py:118-125 / :162-170) + the XNet layer-1 sums of (v_h, k1 x)
-      f4 h = layer2(w2v, pv[0], tbv);
+      HidB h = layer2(w2v, pv[0], tbv);
       f4 pa = Z, pq = Z;
-      HeadW hw = head_frag(wv, t_lo);
-      f4 Wa = frag(wx, t_lo), Wb = frag(wx, NT + t_lo);
+      HeadW hw = head_frag(1, t_lo);
+      Frag Wa = frag(0, t_lo), Wb = frag(0, NT + t_lo);
       for (int tg = t_lo; tg < t_hi; ++tg) {
-        const HeadW hw_n = head_frag(wv, nxt(tg));
-        const f4 Wa_n = frag(wx, nxt(tg)), Wb_n = frag(wx, NT + nxt(tg));
+        const HeadW hw_n = head_frag(1, nxt(tg));
+        const Frag Wa_n = frag(0, nxt(tg)), Wb_n = frag(0, NT + nxt(tg));
         f4 ES, aS, Tt, EQ;
         heads(hw, h, kSv, kQ, ES, aS, Tt, EQ);
         const f4 vh = v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ldv);
@@ -353,11 +396,11 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       // ---- first masked position update (:127-137 / :172-182) + the layer-1 sum of k2 y
       h = layer2(w2x, px[0], tbx);
       pq = Z;
-      hw = head_frag(wx, t_lo);
-      Wb = frag(wx, NT + t_lo);
+      hw = head_frag(0, t_lo);
+      Wb = frag(0, NT + t_lo);
       for (int tg = t_lo; tg < t_hi; ++tg) {
-        const HeadW hw_n = head_frag(wx, nxt(tg));
-        const f4 Wb_n = frag(wx, NT + nxt(tg));
+        const HeadW hw_n = head_frag(0, nxt(tg));
+        const Frag Wb_n = frag(0, NT + nxt(tg));
         f4 ES, aS, Tt, EQ;
         heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
         const f4 k1 = k1_of(tg);
@@ -373,12 +416,12 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       const bool lastU = need_p && it == A.n_steps - 1;
       float Uend = 0.f;
       f4 a0 = Z, a1 = Z;
-      hw = head_frag(wx, t_lo);
-      Wa = frag(wv, t_lo);
-      Wb = frag(wv, NT + t_lo);
+      hw = head_frag(0, t_lo);
+      Wa = frag(1, t_lo);
+      Wb = frag(1, NT + t_lo);
       for (int tg = t_lo; tg < t_hi; ++tg) {
-        const HeadW hw_n = head_frag(wx, nxt(tg));
-        const f4 Wa_n = frag(wv, nxt(tg)), Wb_n = frag(wv, NT + nxt(tg));
+        const HeadW hw_n = head_frag(0, nxt(tg));
+        const Frag Wa_n = frag(1, nxt(tg)), Wb_n = frag(1, NT + nxt(tg));
         f4 ES, aS, Tt, EQ;
         heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
         const f4 xn = x_half(tl(SX, tg, lane), O - k1_of(tg), tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ldv);
@@ -398,9 +441,9 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       xchg<NW, 1>(pv, A, smem, w, lane, pb);
       // ---- momentum half-update #2 (:147-153 / :192-199)
       h = layer2(w2v, pv[0], tbv);
-      hw = head_frag(wv, t_lo);
+      hw = head_frag(1, t_lo);
       for (int tg = t_lo; tg < t_hi; ++tg) {
-        const HeadW hw_n = head_frag(wv, nxt(tg));
+        const HeadW hw_n = head_frag(1, nxt(tg));
         f4 ES, aS, Tt, EQ;
         heads(hw, h, kSv, kQ, ES, aS, Tt, EQ);
         ts(SV, tg, lane, v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ldv));
@@ -415,14 +458,24 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
     for (int tg = t_lo; tg < t_hi; ++tg) {
       const f4 v = tl(SV, tg, lane);
       red[3] += 0.5f * hsum(v * v);
-      if (last) {
-        gstore(A.x_out, tg, tl(SX, tg, lane));
-        gstore(A.v_out, tg, v);
-      }
+      if constexpr (F16) amax_l = fmaxf(amax_l, fmaxf(amax4(v), fmaxf(amax4(tl(SX, tg, lane)), amax4(tl(SG, tg, lane)))));
     }
     red[4] = ld;
     const float U_end = red[2];
-    chain_allreduce<NW, 5>(red, smem + A.o_red, w, lane);
+    if constexpr (F16) red[5] = amax_l < L2HMC_F16_STATE_MAX ? 0.f : 1.f;
+    chain_allreduce<NW, F16 ? 6 : 5>(red, smem + A.o_red, w, lane);
+    bool oor = false;                      // f16x2: a proposal outside the operand range is a loud non-result (traj_fast.hpp)
+    if constexpr (F16) {
+      oor = red[5] > 0.f;
+      if (oor) red[4] = __uint_as_float(0x7fc00000u);
+    }
+    if (last) {
+      for (int tg = t_lo; tg < t_hi; ++tg) {
+        const f4 qn = splat(__uint_as_float(0x7fc00000u));
+        gstore(A.x_out, tg, oor ? qn : tl(SX, tg, lane));
+        gstore(A.v_out, tg, oor ? qn : tl(SV, tg, lane));
+      }
+    }
     const bool writer = live && w == 0 && lane < 16;
     if (A.logjac_out != nullptr && writer) A.logjac_out[moff + chain] = red[4];
     bool resumed = false;                  // some chain of this tile went back to its start point
@@ -476,9 +529,9 @@ long long plan_lds_wide(KArgs& k) {
   return o * 4;
 }
 
-template <int EK, int KH, int NW>
+template <int EK, int KH, int NW, int PK = 0>
 static int launch_wide_t(const KArgs& k, long long lds, hipStream_t s) {
-  auto kern = traj_wide_kernel<EK, KH, NW>;
+  auto kern = traj_wide_kernel<EK, KH, NW, PK>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -497,6 +550,13 @@ int launch_wide(const KArgs& k, int KH, long long lds, hipStream_t s) {
            : (w8 ? launch_wide_t<EKv, 4, 8>(k, lds, s) : launch_wide_t<EKv, 4, 4>(k, lds, s)))
   if (dense) return L2HMC_WIDE(L2HMC_ENERGY_GAUSS_DENSE);
   if (k.ekind == L2HMC_ENERGY_GMM) return L2HMC_WIDE(L2HMC_ENERGY_GMM);
+  if (k.packed16 != nullptr) {            // the elementwise targets with f16x2 contractions (the dispatcher clears it for variant 200 + v)
+#define L2HMC_WIDE16(EKv)                                                                          \
+  (KH == 3 ? (w8 ? launch_wide_t<EKv, 3, 8, 1>(k, lds, s) : launch_wide_t<EKv, 3, 4, 1>(k, lds, s)) \
+           : (w8 ? launch_wide_t<EKv, 4, 8, 1>(k, lds, s) : launch_wide_t<EKv, 4, 4, 1>(k, lds, s)))
+    return diag ? L2HMC_WIDE16(L2HMC_ENERGY_GAUSS_DIAG) : L2HMC_WIDE16(L2HMC_ENERGY_ROUGHWELL);
+#undef L2HMC_WIDE16
+  }
   return diag ? L2HMC_WIDE(L2HMC_ENERGY_GAUSS_DIAG) : L2HMC_WIDE(L2HMC_ENERGY_ROUGHWELL);
 #undef L2HMC_WIDE
 }

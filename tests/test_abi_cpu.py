@@ -28,9 +28,10 @@ def test_abi_version_and_size_queries():
     assert int(re.search(r"#define L2HMC_ABI_VERSION (\d+)", hdr).group(1)) == _ffi.ABI_VERSION
     # MFMA fragments (5 NT + 2 groups of 256 + 32 NT scales per net) + the lane layout (traj_lane.hpp: rows of RS = 12)
     lane = (2 * 50 * 12 + 3 * 12 + 10 * 12 + 12 + 25 * (6 * 10 + 12) + 3) // 4 * 4      # DP = 50 rows, 10 units
-    assert L.l2hmc_packed_nets_floats(50, 10) == 2 * ((5 * 4 + 2) * 256 + 32 * 4) + 2 * lane
+    # ... + (round 6) the same groups once more as f16x2 fragment pairs (2 x 16 bytes per lane: 512 floats per group)
+    assert L.l2hmc_packed_nets_floats(50, 10) == 2 * ((5 * 4 + 2) * 256 + 32 * 4) + 2 * lane + 2 * (5 * 4 + 2) * 512
     lane2 = (2 * 2 * 12 + 3 * 12 + 10 * 12 + 12 + 1 * (6 * 10 + 12) + 3) // 4 * 4       # DP = 2
-    assert L.l2hmc_packed_nets_floats(2, 10) == 2 * (7 * 256 + 32) + 2 * lane2
+    assert L.l2hmc_packed_nets_floats(2, 10) == 2 * (7 * 256 + 32) + 2 * lane2 + 2 * 7 * 512
     assert L.l2hmc_packed_gaussian_floats(50) == 16 * 256
     assert L.l2hmc_packed_nets_floats(50, 16) == -2          # unsupported hidden width
     assert b"H <= 15" in L.l2hmc_last_error()

@@ -32,7 +32,7 @@ def variants(g):
     if d <= 16:
         return [0, 100] + ([32] if lane else [])
     if d > 128:          # 0: the LDS-resident-state kernel; 4 / 104: eight dim-tiles per wave on the register-resident kernels
-        return [0, 4, 104]
+        return [0, 4, 104, 200]      # (200: the LDS-resident-state kernel with the f32-input MFMA; 0 takes f16x2 on the elementwise targets)
     # 16: one wave per tile (many-chains form; elementwise targets with S/T/Q nets, 33 <= d <= 64)
     tile = 33 <= d <= 64 and not int(g["hmc"]) and int(g["H"]) <= 15 and (
         str(g["energy.kind"]) == "roughwell" or (str(g["energy.kind"]) == "gaussian" and
