@@ -123,10 +123,12 @@ typedef struct L2hmcTrajectoryArgs {
                              *   LDS-resident-state kernel; 100 + v = geometry v on the general kernel (which also
                              *   serves HMC mode, AIS mode and tempered energies); 200 + v = choice v with the
                              *   f32-input MFMA forced: the tile kernels of the elementwise targets (diagonal Gaussian,
-                             *   Rough Well) otherwise run their contractions as f16x2 -- two f16 MFMAs on an exact
-                             *   split of both operands, fp32-accurate for |state|, |grad U|, |activation| < 4.2e6 and
-                             *   |weight| < 1023 (csrc/traj_fast.hpp; L2HMC_F32_MFMA=1 in the environment = 200 + v
-                             *   for every call)                                                                    */
+                             *   Rough Well: four-wave, one-wave and LDS-resident-state forms) and the d <= 4 kernel of
+                             *   every target it serves otherwise run their contractions as f16x2 -- two f16 MFMAs on an
+                             *   exact split of both operands, fp32-accurate for |state|, |grad U|, |activation| < 4.2e6
+                             *   and |weight| < 1023; a proposal whose end points leave that range comes back as NaN
+                             *   with accept probability 0 (csrc/traj_fast.hpp; L2HMC_F32_MFMA=1 in the environment =
+                             *   200 + v for every call)                                                            */
   /* ---- persistent sampler loop (the notebook's per-MH-step sess.run loop, nb raw 288-298) -- */
   int32_t n_proposals;      /* M >= 1 proposals per launch (0 = 1).  With M > 1: v is (M,N,d),  */
                             /* direction (M,N), u (M,N) [required], p_out / logjac_out (M,N);   */

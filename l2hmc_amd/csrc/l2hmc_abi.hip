@@ -670,11 +670,13 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a_in, void* stream) {
   const bool small = fast && a->d <= 4 && geom_variant == 0 && k.ekind != L2HMC_ENERGY_FUNNEL &&
                      (k.ekind != L2HMC_ENERGY_GMM || k.ncomp <= 8);
   if (small) {
-    const long long ldss = plan_lds_fast(k, 1, 1);
+    // (f16x2 for the hidden layer and the head block unless the f32-input MFMA is asked for: every target this kernel serves --
+    //  Gaussians incl. dense, mixtures, Rough Well -- has a grad U that is linear or bounded in the state the range guard watches)
+    const long long ldss = plan_lds_fast(k, 1, 1, !force_f32);
     // (the per-step schedule records grow with T: past 160 KiB fall through to the fast / general kernel)
     if (ldss <= 160 * 1024) {
-      note_kernel("traj_small_kernel<%lld, %lld>", k.ekind, KH <= 3 ? 3 : 4);
-      return dispatch(OP_TRAJ_SMALL, k, 1, 1, KH, ldss, s);
+      note_kernel(force_f32 ? "traj_small_kernel<%lld, %lld>" : "traj_small_kernel<%lld, %lld, 1>", k.ekind, KH <= 3 ? 3 : 4);
+      return dispatch(force_f32 ? OP_TRAJ_SMALL : OP_TRAJ_SMALL16, k, 1, 1, KH, ldss, s);
     }
   }
   // many chains (>= 2 tiles per SIMD), 3-4 dimension slices, elementwise target: one wave per tile (traj_tile.hpp);
@@ -706,7 +708,8 @@ int l2hmc_trajectory(const L2hmcTrajectoryArgs* a_in, void* stream) {
     // f16x2 (traj_fast.hpp): every contraction of the step loop as two f16 MFMAs on an exact hi / lo split of both operands --
     // fp32-accurate while |states|, |activations|, |grad U| < 65504 (beyond: inf - inf = NaN, which the accept rule treats as a
     // rejection).  The elementwise targets take it unless the caller asks for the f32-input MFMA (variant 200 + v, or
-    // L2HMC_F32_MFMA=1 in the environment); the funnel (grad U ~ e^{-x_0}), the mixtures and dense Gaussians stay on f32.
+    // L2HMC_F32_MFMA=1 in the environment); the funnel (grad U ~ e^{-x_0}) stays on f32 everywhere, the mixtures and dense
+    // Gaussians on the tile kernels (their d <= 4 kernel takes f16x2 for its nets: above).
     const bool f16 = !force_f32 && (k.ekind == L2HMC_ENERGY_GAUSS_DIAG || k.ekind == L2HMC_ENERGY_ROUGHWELL);
     if (f16) {
       const long long lds16 = plan_lds_fast(k, NW, DT, true);

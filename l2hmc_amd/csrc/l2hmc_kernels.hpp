@@ -1235,7 +1235,7 @@ int launch(K kern, const KArgs& k, int NW, long long lds_bytes, hipStream_t s) {
   else if (DTv == 8 && NWv == 4) { CALL(8, 4) }          \
   else return fail(L2HMC_ERR_UNSUPPORTED, "no kernel for this geometry%s");
 
-enum { OP_TRAJ = 0, OP_ENERGY = 1, OP_PACCEPT = 2, OP_TRAJ_FAST = 3, OP_TRAJ_SMALL = 4 };
+enum { OP_TRAJ = 0, OP_ENERGY = 1, OP_PACCEPT = 2, OP_TRAJ_FAST = 3, OP_TRAJ_SMALL = 4, OP_TRAJ_SMALL16 = 5 };
 
 #define L2HMC_FAST_SWITCH(DTv, NWv, CALL)                \
   if (DTv == 1 && NWv == 1) { CALL(1, 1) }               \
@@ -1266,6 +1266,8 @@ int launch_tile_ek(const KArgs& k, int DT, int KH, int tpw, long long lds, hipSt
       L2HMC_FAST_SWITCH(DT, NW, L2HMC_CALL_FAST_##EKv)                                           \
     } else if (op == OP_TRAJ_SMALL) {                                                            \
       L2HMC_CALL_SMALL_##EKv                                                                     \
+    } else if (op == OP_TRAJ_SMALL16) {                                                          \
+      L2HMC_CALL_SMALL16_##EKv                                                                   \
     } else if (op == OP_ENERGY) {                                                                \
       L2HMC_GEOM_SWITCH(DT, NW, L2HMC_CALL_EN_##EKv)                                             \
     } else {                                                                                     \

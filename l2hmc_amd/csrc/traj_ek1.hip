@@ -12,6 +12,9 @@ namespace l2hmc {
 #define L2HMC_CALL_SMALL_1                                                        \
   if (KH <= 3) return launch(traj_small_kernel<1, 3>, k, 1, lds, s);              \
   else return launch(traj_small_kernel<1, 4>, k, 1, lds, s);
+#define L2HMC_CALL_SMALL16_1                                                      \
+  if (KH <= 3) return launch(traj_small_kernel<1, 3, 1>, k, 1, lds, s);           \
+  else return launch(traj_small_kernel<1, 4, 1>, k, 1, lds, s);
 #define L2HMC_CALL_EN_1(DTc, NWc) return launch(energy_kernel<1, DTc, NWc>, k, NWc, lds, s);
 #define L2HMC_CALL_PA_1(DTc, NWc) return launch(paccept_kernel<1, DTc, NWc>, k, NWc, lds, s);
 L2HMC_DEFINE_LAUNCH_EK(1)

@@ -15,6 +15,7 @@
 // Per leapfrog step and wave: 29 MFMAs (5 layer 1 + 12 layer 2 + 12 heads) instead of 68, 24 transcendentals
 // instead of 96.  Reference: utils/dynamics.py:115-309, utils/sampler.py:28-55 (same algorithm as traj_kernel).
 #pragma once
+#include <type_traits>
 #include "traj_fast.hpp"
 
 namespace l2hmc {
@@ -73,8 +74,12 @@ __device__ __forceinline__ float grad_small(const KArgs& A, const float* smem, c
   return livedim ? g : 0.f;
 }
 
-template <int EK, int KH>
+// PK = 1 (round 6): the hidden layer and the head block as f16x2 (traj_fast.hpp) -- 4 x 4 f16 MFMAs of 16 cycles per step that leave
+// the VALU free instead of 24 f32-input ones of 32 that block it; layer 1 is ONE k-step per input and keeps the f32-input MFMA (a
+// K = 32 instruction would carry four live slots).  The end points of a proposal are held against L2HMC_F16_STATE_MAX.
+template <int EK, int KH, int PK = 0>
 __global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
+  constexpr bool F16 = PK == 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   lds_poison(smem);
   const int lane = threadIdx.x;
@@ -86,16 +91,23 @@ __global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
   const float eps = A.alpha != nullptr ? expf(*A.alpha) : A.eps_host;
   const float heps = 0.5f * eps;
   constexpr int NTp = 1;
-  const int FWN = fast_fw_net_f32(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
+  const int FWN = F16 ? fast_fw_net(NTp, true) : fast_fw_net_f32(NTp), DPp = fast_dpp(NTp), FCN = fast_fc_net(NTp), R = fast_rec(NTp),
             RECD = fast_rec_dir(NTp, A.T);
 
   // ---- prologue: the same scaled tail fragments, constant tables and schedule records as traj_fast_kernel ----
-  for (int i = lane; i < 2 * (FWN / 4); i += 64) {
-    const int net = i >= FWN / 4, j = i - net * (FWN / 4), g = j >> 6;
+  constexpr int FW4 = fast_fw_net_f32(NTp) / 4;             // float4 fragments per net: W4, then (S, T, Q) of the one slice
+  for (int i = lane; i < 2 * FW4; i += 64) {
+    const int net = i >= FW4, j = i - net * FW4, g = j >> 6;
     float sc = 1.f;
     if (g > 0) sc = ((g - 1) % 3 == 1) ? (net == 0 ? eps : heps) : 2.f * LOG2E;
     const f4 src = reinterpret_cast<const f4*>(A.packed + (size_t)net * NF + 3 * 256)[j];
-    reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src * sc;
+    if constexpr (F16) {                                    // [first fragments of the net's four groups | second ones]
+      const WF16 f = wsplit16(src * sc);
+      reinterpret_cast<h8v*>(smem + A.o_fw + net * FWN)[j] = f.a1;
+      reinterpret_cast<h8v*>(smem + A.o_fw + net * FWN + 4 * FW4)[j] = f.a2;
+    } else {
+      reinterpret_cast<f4*>(smem + A.o_fw + net * FWN)[j] = src * sc;
+    }
   }
   for (int i = lane; i < 2 * 16; i += 64) {
     const int net = i / 16, dim = i % 16;
@@ -176,12 +188,20 @@ __global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
     else return MFMA16(vb, gg, MFMA16(va, xx, Z));
   };
   // tail of one net: hidden layers + the single (dimension, head) block; returns (z_S, z_T', z_Q) of this lane's dimension
-  struct TailS { f4 w2, hd; float cS, cQ, bQ; };
+  typedef std::conditional_t<F16, WF16, f4> FragS;
+  struct TailS { FragS w2, hd; float cS, cQ, bQ; };
+  auto load_frag_s = [&](const float* fw, int idx) -> FragS {          // fragment at float4 slot idx of the net
+    if constexpr (F16) return WF16{*reinterpret_cast<const h8v*>(fw + idx * 4), *reinterpret_cast<const h8v*>(fw + 4 * FW4 + idx * 4)};
+    else return lds4(fw + idx * 4);
+  };
   auto load_tail_s = [&](TailS& t, const float* fw, const float* fc, int dofs) {
-    t.w2 = lds4(fw + lane * 4);
+    t.w2 = load_frag_s(fw, lane);
     // head block row c = 4 q' + h: head h (S, T, Q) of dimension q'; fragment of head group h at lane (q', q)
     const int h = c & 3;
-    t.hd = h < 3 ? lds4(fw + ((1 + h) * 64 + (c >> 2) + 16 * q) * 4) : Z;
+    t.hd = load_frag_s(fw, (1 + (h < 3 ? h : 0)) * 64 + (c >> 2) + 16 * q);
+    if (h == 3) {                                                       // (rows 4 q' + 3 of the block: no head)
+      if constexpr (F16) { t.hd.a1 = h8v{}; t.hd.a2 = h8v{}; } else { t.hd = Z; }
+    }
     t.cS = fc[dofs + q];
     t.cQ = fc[2 * DPp + q];
     t.bQ = fc[3 * DPp + q];
@@ -190,14 +210,20 @@ __global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
     f4 h = Z;
 #pragma unroll
     for (int r = 0; r < KH; ++r) h[r] = relu_i(hs_[r]);
-    f4 acc = Z;
+    f4 acc = Z, z = Z;
+    if constexpr (F16) {
+      acc = mfma16x2(t.w2, split16<true>(h), Z);
 #pragma unroll
-    for (int r = 0; r < KH; ++r) acc = MFMA16(t.w2[r], h[r], acc);
+      for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
+      z = mfma16x2(t.hd, split16<true>(h), Z);
+    } else {
 #pragma unroll
-    for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
-    f4 z = Z;
+      for (int r = 0; r < KH; ++r) acc = MFMA16(t.w2[r], h[r], acc);
 #pragma unroll
-    for (int r = 0; r < KH; ++r) z = MFMA16(t.hd[r], h[r], z);
+      for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
+#pragma unroll
+      for (int r = 0; r < KH; ++r) z = MFMA16(t.hd[r], h[r], z);
+    }
     const float rS = __builtin_amdgcn_rcpf(-(__builtin_amdgcn_exp2f(z.x) * 0.5f + 0.5f));
     aS = rS * t.cS + t.cS;
     const float rQ = __builtin_amdgcn_rcpf(-(__builtin_amdgcn_exp2f(z.z) * 0.5f + 0.5f));
@@ -236,6 +262,7 @@ __global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
     }
     const float x0 = x, g0 = g;
     const f4 pv0 = pv;
+    float amax_l = F16 ? fmaxf(fabsf(x), fmaxf(fabsf(v), fabsf(g))) : 0.f;      // f16x2: the proposal's end points against the operand range
     float red[5];
     red[0] = U_start;
     red[1] = 0.5f * v * v;
@@ -287,10 +314,6 @@ __global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
       tbv = tbv_n;
     }
     const bool last = m == A.M - 1;
-    if (last && live && livedim) {
-      if (A.x_out != nullptr) A.x_out[chain * A.d + q] = x;
-      if (A.v_out != nullptr) A.v_out[chain * A.d + q] = v;
-    }
     red[3] = 0.5f * v * v;
     red[4] = ldv * 0.6931471805599453f;
     const float U_end = red[2];
@@ -298,6 +321,19 @@ __global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
     for (int i = 0; i < 5; ++i) {
       red[i] += __shfl_xor(red[i], 16);
       red[i] += __shfl_xor(red[i], 32);
+    }
+    if constexpr (F16) {
+      amax_l = fmaxf(amax_l, fmaxf(fabsf(x), fmaxf(fabsf(v), fabsf(g))));
+      float oor = amax_l < L2HMC_F16_STATE_MAX ? 0.f : 1.f;
+      oor += __shfl_xor(oor, 16);
+      oor += __shfl_xor(oor, 32);
+      if (oor > 0.f) {               // outside the f16x2 range: a loud non-result (traj_fast.hpp)
+        x = v = red[4] = __uint_as_float(0x7fc00000u);
+      }
+    }
+    if (last && live && livedim) {
+      if (A.x_out != nullptr) A.x_out[chain * A.d + q] = x;
+      if (A.v_out != nullptr) A.v_out[chain * A.d + q] = v;
     }
     const bool writer = live && lane < 16;
     if (A.logjac_out != nullptr && writer) A.logjac_out[moff + chain] = red[4];
