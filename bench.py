@@ -766,10 +766,11 @@ def main():
                          "kernel": main_kernel, "flops_per_chain_step": flops_cs,
                          # `achieved` = ALGORITHMIC fp32 flops / launch time against the f32 vector / f32-input-MFMA peak.  Since
                          # round 6 the kernels whose name ends in ", 1>" execute every contraction as two f16 MFMAs on an exact
-                         # two-term split of both operands (fp32-accurate: profiles/r06_f16x2_accuracy.txt) -- 4 x the
+                         # two-term split of both operands (22 significand bits per operand worst case; against float64 equal to the
+                         # f32-input MFMA: profiles/r06_f16x2_accuracy.txt) -- 4 x the
                          # f16 flops on a pipe 16 x as fast; results and `dtype` are fp32, `mfma_pipe_busy` is that pipe's share
                          "arithmetic": ("f16x2: two v_mfma_f32_16x16x32_f16 per 16-k block on exact hi/lo splits, fp32 accumulate, "
-                                        "fp32-accurate" if main_kernel.rstrip().endswith(", 1>") else "f32-input MFMA"),
+                                        "fp32-level accuracy (profiles/r06_f16x2_accuracy.txt)" if main_kernel.rstrip().endswith(", 1>") else "f32-input MFMA"),
                          "launch_us": launch_s * 1e6,
                          # bytes the persistent loop has to move per launch: x in, x_next out, p per proposal (the
                          # counters below replace this model when the committed PMC pass matches the workload)

@@ -125,7 +125,8 @@ typedef struct L2hmcTrajectoryArgs {
                              *   f32-input MFMA forced: the tile kernels of the elementwise targets (diagonal Gaussian,
                              *   Rough Well: four-wave, one-wave and LDS-resident-state forms) and the d <= 4 kernel of
                              *   every target it serves otherwise run their contractions as f16x2 -- two f16 MFMAs on an
-                             *   exact split of both operands, fp32-accurate for |state|, |grad U|, |activation| < 4.2e6
+                             *   two-term split of both operands (22 significand bits worst case: fp32-level, measured equal
+                             *   to the f32-input MFMA against float64) for |state|, |grad U| < 2.5e5 (activations < 4.2e6)
                              *   and |weight| < 1023; a proposal whose end points leave that range comes back as NaN
                              *   with accept probability 0 (csrc/traj_fast.hpp; L2HMC_F32_MFMA=1 in the environment =
                              *   200 + v for every call)                                                            */
@@ -340,7 +341,7 @@ typedef struct L2hmcSplitArgs {
                                   *    3: "f16x2 planes" (round 6; what l2hmc_amd.Dynamics asks for): x = X1 + X2 / 64 with X1 =
                                   *       f16(x), X2 = f16(64 (x - X1)), stored as the three f16 planes X1 | X1 / 64 | X2, so that
                                   *       x y = X1 Y1 + (X1 / 64) Y2 + X2 (Y1 / 64) is THREE f16 MFMAs on one accumulator: half of
-                                  *       mode 1's matrix-pipe work at the same fp32-level accuracy (dropped term <= 2^-24 |x y|)
+                                  *       mode 1's matrix-pipe work at fp32-level accuracy (22 significand bits per operand in the worst case)
                                   *       for operand entries in [4e-3, 65504) -- smaller entries keep an absolute error of
                                   *       2^-30, larger ones overflow to inf.  The sampler's activations, logits and BCE
                                   *       gradients live there; the TRAINER's adjoint planes (entries scaled by 1 / chains) do

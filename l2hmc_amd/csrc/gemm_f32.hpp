@@ -186,9 +186,9 @@ __device__ __forceinline__ Split4 split4(f4 x) {
   return o;
 }
 // ---- f16x2 planes (GemmArgs.pm = 1) --------------------------------------------------------------------------------------
-// x = X1 + X2 / 64 with X1 = f16(x), X2 = f16(64 (x - X1)) (both round-to-nearest, |x - X1 - X2 / 64| <= 2^-24 |x| while X2 is a
+// x = X1 + X2 / 64 with X1 = f16(x), X2 = f16(64 (x - X1)) (both round-to-nearest, |x - X1 - X2 / 64| <= 2^-22 |x| -- two 11-bit terms -- while X2 is a
 // normal f16: |x| >= 4e-3; below that its quantum is 2^-30 absolute; |x| < 65504).  Stored as TWO f16 planes X1 | X2 (4 bytes per
-// element against bf16x3's 6); the consumer forms X1 / 64 on its fragment (exact), so that  x y = X1 Y1 + (X1 / 64) Y2 + X2 (Y1 / 64)  (+ X2 Y2 / 4096 <= 2^-24 |x y|, dropped) is three MFMAs on one accumulator
+// element against bf16x3's 6); the consumer forms X1 / 64 on its fragment (exact), so that  x y = X1 Y1 + (X1 / 64) Y2 + X2 (Y1 / 64)  (+ X2 Y2 / 4096 <= 2^-22 |x y|, dropped) is three MFMAs on one accumulator
 // with no rescaling: half the matrix-pipe work of the six bf16x3 products and two thirds of their plane traffic.  The f16 exponent range is what
 // bounds it: the SAMPLER's decoder products (activations, logits, BCE gradients: O(1e-3 ... 1e2)) take it; the trainer's adjoint
 // planes (entries scaled by 1 / chains) keep bf16x3.

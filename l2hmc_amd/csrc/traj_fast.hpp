@@ -41,21 +41,24 @@ __device__ __forceinline__ f4 ex2_4(f4 a) {
             __builtin_amdgcn_exp2f(a.w)};
 }
 
-// ---- f16x2: every 16-wide contraction of the step loop as TWO f16 MFMAs at fp32 accuracy (round 6) --------------------------
+// ---- f16x2: every 16-wide contraction of the step loop as TWO f16 MFMAs at fp32-level accuracy (round 6) --------------------------
 // v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate and blocks the SIMD's VALU while it does (32 cycles per instruction,
 // profiles/r03_ubench_issue.txt); v_mfma_f32_16x16x32_f16 takes 16 cycles for K = 32 and leaves the plain VALU free.
 //   * w a = (64 w) (a / 64).  An activation a is split as  hd = f16(a / 64),  lo = f16(a - 64 hd)  (both round-to-nearest; the
-//     fma in front of the second rounding is exact):  |a - 64 hd - lo| <= 2^-24 |a| -- f32's own rounding -- while lo is a
-//     normal f16, |a| >= 0.25; below that lo's quantum is 2^-25 ABSOLUTE.  Eight VALU instructions per float4: 2 v_pk_mul_f32,
-//     2 v_cvt_pk_f16_f32, 4 v_fma_mixlo/hi_f16 (or ten: split16<true>).  hd overflows at |a| = 64 x 65504 = 4.2e6 (then inf - inf = NaN, loud: the
-//     accept rule takes a NaN as a rejection; variant 200 + v keeps the f32-input MFMA for such states).
-//   * A weight w is split as  w_hi = f16(w),  w_lo = f16(64 (w - w_hi)) / 64  -- exact to 2^-24 |w| down to |w| ~ 4e-3, whatever
+//     fma in front of the second rounding is exact):  |a - 64 hd - lo| <= 2^-22 |a| (two 11-bit terms: within a factor four of
+//     f32's own rounding of an operand) while lo is a normal f16, |a| >= 0.25; below that lo's error is
+//     2^-25 ABSOLUTE.  Eight VALU instructions per float4: 2 v_pk_mul_f32,
+//     2 v_cvt_pk_f16_f32, 4 v_fma_mixlo/hi_f16 (or ten: split16<true>).  hd overflows at |a| = 64 x 65504 = 4.2e6 (see L2HMC_F16_STATE_MAX
+//     below: proposals whose end points exceed 2.5e5 are poisoned; variant 200 + v keeps the f32-input MFMA for such states).
+//   * A weight w is split as  w_hi = f16(w),  w_lo = f16(64 (w - w_hi)) / 64  -- exact to 2^-22 |w| down to |w| ~ 4e-3, whatever
 //     the size of the activation it multiplies -- and staged as two fragments  [64 w_hi | w_hi]  and  [64 w_lo | w_lo]
 //     (|w| < 1023).
 //   * The k-slots of one MFMA carry [hd(k) | lo(k)] of the lane's own four k (slot 8q + j: hd of k = 4q + j for j < 4, lo of k =
 //     4q + j - 4 above): the first MFMA adds w_hi (64 hd + lo), the second one w_lo (64 hd + lo), ONE accumulate chain, no
 //     rescaling anywhere.  Products of two f16 are exact in the f32 accumulator.
-//   * Error of a K-term contraction: 2^-24 sum |w_k a_k| (as f32) + 2^-25 sum over {k: |a_k| < 1/4} of |w_k|.
+//   * Error of a K-term contraction: <= 2.5 x 2^-22 sum |w_k a_k| + 2^-25 sum over {k: |a_k| < 1/4} of |w_k| in the worst case
+//     (oracle/f16x2_oracle.py, tests/test_f16x2_oracle.py); in the median within a factor two of an fp32 dot product's own error,
+//     and end to end indistinguishable from the f32-input MFMA against float64 (profiles/r06_f16x2_accuracy.txt).
 //   * The two MFMAs of a chain MUST be the same instruction: a v_mfma_f32_16x16x16_f16 issued right behind the
 //     v_mfma_f32_16x16x32_f16 whose result it accumulates onto loses that result (roc-7.2.0 places no wait states between the
 //     two pass counts; tools/ubench_f16x2.hip).
@@ -113,10 +116,12 @@ __device__ __forceinline__ WF16 wsplit16(f4 w) {
   return f;
 }
 // The states a proposal starts from and arrives at are checked against this bound (|x|, |v|, |grad U|; one chain-wide flag beside
-// the energy sums): beyond it hd overflows, the hidden layer's relu can turn the NaN that follows into a plausible zero, and
-// the proposal is therefore POISONED instead -- Lx, Lv, log-det NaN, accept probability 0.  (The hidden activations have the
-// same bound; nets whose row sums of |W| exceed ~60 could reach it from states below it: variant 200 + v.)
-#define L2HMC_F16_STATE_MAX 4.0e6f
+// the energy sums): hd overflows at 4.2e6, the hidden layer's relu (an integer max on the bit pattern) can turn the NaN that
+// follows into a plausible zero, and the proposal is therefore POISONED instead -- Lx, Lv, log-det NaN, accept probability 0.
+// The bound sits a factor 16 under the operand's range because the HIDDEN activations share that range and are not watched:
+// |h1| <= (row sum of |W1|) max |input| + |bias|, so nets whose rows sum to less than 16 in absolute value (the reference's
+// initialisation: ~6 at d = 50) cannot overflow a hidden activation from a state inside the bound; others: variant 200 + v.
+#define L2HMC_F16_STATE_MAX 2.5e5f
 __device__ __forceinline__ float amax4(f4 a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); }
 // acc += W^T a for the 16 logical k of one fragment
 __device__ __forceinline__ f4 mfma16x2(const WF16& W, h8v b, f4 acc) {

@@ -384,7 +384,7 @@ def test_f16x2_dispatch_names_and_the_f32_switch():
 
 
 def test_f16x2_range_is_wide_and_its_overflow_is_loud():
-    """States of 1e5 -- beyond f16's 65504 -- are fine: the split works on a / 64 (range 4.2e6), and the result stays within 1e-5 of
+    """States of 1e5 -- beyond f16's 65504 -- are fine: the split works on a / 64 (operand range 4.2e6, the kernels' bound 2.5e5), and the result stays within 1e-5 of
     the f32-input MFMA's.  States of 1e7 or 1e9 are outside it: the kernel checks the end points of every proposal against
     L2HMC_F16_STATE_MAX and returns a NaN proposal with accept probability 0 (never a wrong finite number: the hidden layer's
     relu would otherwise turn the overflow's NaN into a plausible zero), one wave per tile and four alike; the f32 switch
