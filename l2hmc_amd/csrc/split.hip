@@ -281,6 +281,9 @@ struct Mlp3Ws {
   // pre-split bf16 planes (gemm_pl_kernel), NULL = the fp32 path: the weights of the two decoder-sized layers in both
   // orientations, and the activations that only ever feed the next product (a1, a2, the BCE gradient, d a2)
   unsigned short *pw2t, *pw3t, *pw2, *pw3, *pa1, *pa2, *plg, *pda2;
+  // the trainer's forward evaluations (vae_energy_keep): the same four weight matrices once more as f16x2 planes (two planes each),
+  // NULL = the forward pass uses the bf16x3 planes above like the reverse sweep
+  unsigned short *pw2t_h, *pw3t_h, *pw2_h, *pw3_h;
 };
 
 // L2hmcSplitArgs.gemm_mode / L2hmcTrainSplitArgs.gemm_mode of the call being served on this thread (set at the top of every

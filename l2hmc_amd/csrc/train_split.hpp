@@ -529,6 +529,7 @@ struct TrainSplitPlan {
   long long part_cap;
   long long HD1, HD2, M1, M2, RD;                   // decoder Hessian-vector product: tangents
   long long pHD1, pHD2, pRD, pM2;                   // ... and the ones that only feed the next decoder-sized product, as bf16 planes
+  long long pw2t_h, pw3t_h, pw2_h, pw3_h;           // gemm_mode 3: the decoder weights once more as f16x2 planes, for the FORWARD evaluations
   long long PS1, PS2, PRD, PB2, PB1;                // ... and, per trajectory point (T + 1 of them), the decoder's
                                                     // sigmoids, sigma' of the logits and the raw reverse products
   long long carry;                                  // Hessian-vector input carried to the same point's other use
@@ -575,9 +576,13 @@ inline TrainSplitPlan plan_train_split(long long N, int d, int H, int T, const L
     auto takep = [&](long long elems) { return take(p.fwd.planes ? (elems * 3 + 1) / 2 : 0); };
     p.pHD1 = takep(N * pld(dec->n_h1)); p.pHD2 = takep(N * pld(dec->n_h2));
     p.pRD = takep(N * pld(dec->n_out)); p.pM2 = takep(N * pld(dec->n_h2));
+    auto takeh = [&](long long elems) { return take(p.fwd.planes ? elems : 0); };          // two f16 planes = elems floats
+    p.pw2t_h = takeh(prows(dec->n_h2) * pld(dec->n_h1)); p.pw3t_h = takeh(prows(dec->n_out) * pld(dec->n_h2));
+    p.pw2_h = takeh(prows(dec->n_h1) * pld(dec->n_h2)); p.pw3_h = takeh(prows(dec->n_h2) * pld(dec->n_out));
     p.xq = 0;
   } else {
     p.pHD1 = p.pHD2 = p.pRD = p.pM2 = 0;
+    p.pw2t_h = p.pw3t_h = p.pw2_h = p.pw3_h = 0;
     p.HD1 = p.HD2 = p.M1 = p.M2 = p.RD = p.PS1 = p.PS2 = p.PRD = p.PB2 = p.PB1 = 0;
     p.xq = take(N * d);
   }
@@ -607,15 +612,22 @@ void vae_energy_keep(hipStream_t s, const L2hmcMlp3& dec, const float* aux, cons
     //      sides (gemm_xlp_kernel: bit-identical per product to the in-loop split, x1.37)
     const int l1 = pld(dec.n_h1), l2 = pld(dec.n_h2), lo = pld(dec.n_out);
     const long long n1 = N * l1, n2 = N * l2, no = N * lo;
+    // (gemm_mode 3: this evaluation is the SAMPLER's -- activations, logits, BCE gradients of O(1) -- and runs on f16x2 planes
+    //  like it, with the weights' f16 planes; the reverse sweep's tangents and adjoints keep bf16x3: split.hip t_plane_mode)
+    const int pm_keep = t_plane_mode;
+    const bool h16 = ws.pw2t_h != nullptr;
+    if (h16) t_plane_mode = 1;
+    const unsigned short *qw2t = h16 ? ws.pw2t_h : ws.pw2t, *qw3t = h16 ? ws.pw3t_h : ws.pw3t, *qw2 = h16 ? ws.pw2_h : ws.pw2,
+                         *qw3 = h16 ? ws.pw3_h : ws.pw3;
     GemmArgs g = gemm_args(z, ldz, ws.w1t, dec.n_in, nullptr, dec.n_h1, N, dec.n_h1, dec.n_in);
     g.bias = dec.b1; g.C2 = pt.s1; g.ldc2 = dec.n_h1; g.Cp = ws.pa1; g.cp_plane = n1; g.ldcp = l1;
     launch_gemm<EPI_BIAS_SOFTPLUS>(g, s, dec.n_in <= 64 ? SHAPE_MID : SHAPE_AUTO);                 // a1 (planes), s1
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_h1);
-    g.Ap = ws.pa1; g.ap_plane = n1; g.ldap = l1; g.Bp = ws.pw2t; g.bp_plane = prows(dec.n_h2) * l1; g.ldbp = l1;
+    g.Ap = ws.pa1; g.ap_plane = n1; g.ldap = l1; g.Bp = qw2t; g.bp_plane = prows(dec.n_h2) * l1; g.ldbp = l1;
     g.bias = dec.b2; g.C2 = pt.s2; g.ldc2 = dec.n_h2; g.Cp = ws.pa2; g.cp_plane = n2; g.ldcp = l2;
     launch_gemm_planes<EPI_BIAS_SOFTPLUS>(g, s);                                                     // a2 (planes), s2
     g = gemm_args(nullptr, 0, nullptr, 0, lg, dec.n_out, N, dec.n_out, dec.n_h2);                    // (lg in fp32 too: k_sigd reads it)
-    g.Ap = ws.pa2; g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw3t; g.bp_plane = prows(dec.n_out) * l2; g.ldbp = l2;
+    g.Ap = ws.pa2; g.ap_plane = n2; g.ldap = l2; g.Bp = qw3t; g.bp_plane = prows(dec.n_out) * l2; g.ldbp = l2;
     g.bias = dec.b3; g.E = aux; g.lde = dec.n_out; g.rowsum = rowsum; g.n_tiles = bce_tiles_planes(dec.n_out); g.beta = 1.f;
     g.Cp = ws.plg; g.cp_plane = no; g.ldcp = lo;
     launch_gemm_planes<EPI_BCE>(g, s);
@@ -624,13 +636,14 @@ void vae_energy_keep(hipStream_t s, const L2hmcMlp3& dec, const float* aux, cons
     const long long npix_ = N * dec.n_out;
     hipLaunchKernelGGL(k_sigd, dim3(nblk(npix_)), dim3(256), 0, s, lg, aux, pt.rd, npix_);
     g = gemm_args(nullptr, 0, nullptr, 0, nullptr, dec.n_h2, N, dec.n_h2, dec.n_out);
-    g.Ap = ws.plg; g.ap_plane = no; g.ldap = lo; g.Bp = ws.pw3; g.bp_plane = prows(dec.n_h2) * lo; g.ldbp = lo;
+    g.Ap = ws.plg; g.ap_plane = no; g.ldap = lo; g.Bp = qw3; g.bp_plane = prows(dec.n_h2) * lo; g.ldbp = lo;
     g.E = pt.s2; g.lde = dec.n_h2; g.C2 = pt.b2; g.ldc2 = dec.n_h2; g.Cp = ws.pda2; g.cp_plane = n2; g.ldcp = l2;
     launch_gemm_planes<EPI_MUL>(g, s);                                                               // c2 = s2 b2 (planes), b2
     g = gemm_args(nullptr, 0, nullptr, 0, ws.a1, dec.n_h1, N, dec.n_h1, dec.n_h2);
-    g.Ap = ws.pda2; g.ap_plane = n2; g.ldap = l2; g.Bp = ws.pw2; g.bp_plane = prows(dec.n_h1) * l2; g.ldbp = l2;
+    g.Ap = ws.pda2; g.ap_plane = n2; g.ldap = l2; g.Bp = qw2; g.bp_plane = prows(dec.n_h1) * l2; g.ldbp = l2;
     g.E = pt.s1; g.lde = dec.n_h1; g.C2 = pt.b1; g.ldc2 = dec.n_h1;
     launch_gemm_planes<EPI_MUL>(g, s);                                                               // c1 = s1 b1 (fp32), b1
+    t_plane_mode = pm_keep;
     g = gemm_args(ws.a1, dec.n_h1, dec.W1, dec.n_h1, grad, ldg, N, d, dec.n_h1);
     g.E = z; g.lde = ldz;
     launch_gemm<EPI_ADD>(g, s, d <= 64 ? SHAPE_SKINNY : SHAPE_MID);
@@ -802,6 +815,7 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     auto us = [&](long long off) { return reinterpret_cast<unsigned short*>(w + off); };
     dws.pw2t = us(f.pw2t); dws.pw3t = us(f.pw3t); dws.pw2 = us(f.pw2); dws.pw3 = us(f.pw3);
     dws.pa1 = us(f.pa1); dws.pa2 = us(f.pa2); dws.plg = us(f.plg); dws.pda2 = us(f.pda2);
+    if (a->gemm_mode == 3) { dws.pw2t_h = us(p.pw2t_h); dws.pw3t_h = us(p.pw3t_h); dws.pw2_h = us(p.pw2_h); dws.pw3_h = us(p.pw3_h); }
   }
   const int L = 2 * d;
   static const L2hmcNet no_net = {};              // lam_s == NULL: the update kernels and their adjoints take S | T | Q as they are
@@ -853,6 +867,12 @@ int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
     to_planes(s, dws.w3t, dec.n_h2, dec.n_out, dec.n_h2, dws.pw3t, prows(dec.n_out), pld(dec.n_h2));
     to_planes(s, dec.W2, dec.n_h2, dec.n_h1, dec.n_h2, dws.pw2, prows(dec.n_h1), pld(dec.n_h2));
     to_planes(s, dec.W3, dec.n_out, dec.n_h2, dec.n_out, dws.pw3, prows(dec.n_h2), pld(dec.n_out));
+    if (dws.pw2t_h != nullptr) {                     // ... and for the forward evaluations as f16x2 planes (gemm_mode 3)
+      to_planes(s, dws.w2t, dec.n_h1, dec.n_h2, dec.n_h1, dws.pw2t_h, prows(dec.n_h2), pld(dec.n_h1), 1);
+      to_planes(s, dws.w3t, dec.n_h2, dec.n_out, dec.n_h2, dws.pw3t_h, prows(dec.n_out), pld(dec.n_h2), 1);
+      to_planes(s, dec.W2, dec.n_h2, dec.n_h1, dec.n_h2, dws.pw2_h, prows(dec.n_h1), pld(dec.n_h2), 1);
+      to_planes(s, dec.W3, dec.n_out, dec.n_h2, dec.n_out, dws.pw3_h, prows(dec.n_h2), pld(dec.n_out), 1);
+    }
     planes_zero_pad(s, dws.pa1, N, dec.n_h1, pld(dec.n_h1));
     planes_zero_pad(s, dws.pa2, N, dec.n_h2, pld(dec.n_h2));
     planes_zero_pad(s, dws.plg, N, dec.n_out, pld(dec.n_out));

@@ -553,7 +553,7 @@ def test_config5_at_a_chain_count_that_takes_the_big_gemm_tiles(gemm_mode):
 
 
 def test_bf16x3_training_gradient_agrees_with_the_f32_mfma_one_at_big_tile_sizes():
-    """The sampler-training gradient (l2hmc_train_split_grad: forward with everything kept, reverse sweep, decoder
+    """(and, since round 6, gemm_mode 3: forward evaluations on f16x2 planes)  The sampler-training gradient (l2hmc_train_split_grad: forward with everything kept, reverse sweep, decoder
     Hessian-vector products) at 3072 chains of config 5's widths, decoder-sized products as bf16x3 vs as f32-input MFMA:
     loss, accept probabilities and the whole flat gradient [XNet | VNet | eps | image branch] agree to fp32 rounding level
     (the f32 form is pinned against the reference graph / the float64 autograd oracle at fixture sizes)."""
@@ -566,7 +566,7 @@ def test_bf16x3_training_gradient_agrees_with_the_f32_mfma_one_at_big_tile_sizes
     dr = {"v": rng.randn(N, 50).astype(np.float32), "dir": rng.randint(0, 2, N).astype(np.uint8), "u": rng.rand(N).astype(np.float32)}
     ls = np.full((N, 50), -0.5, np.float32)
     res = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 3):
         dyn = hip_dynamics(g)
         dyn.eps_override = None
         with torch.no_grad():
@@ -584,6 +584,12 @@ def test_bf16x3_training_gradient_agrees_with_the_f32_mfma_one_at_big_tile_sizes
     # (1 / v^2 weights of a few chains with v ~ 1e-4 amplify the 2e-5 difference in p that either arithmetic has against
     #  float64: the gate is the size of that conditioning, a wrong product would be off by O(scale))
     assert np.abs(a[2] - b[2]).max() < 1e-3 * scale
+    # gemm_mode 3 (round 6): the FORWARD evaluations on f16x2 planes, the reverse sweep's tangent / adjoint planes bf16x3 -- same gates
+    c = res[3]
+    print("mode 3: loss %.6e   |dp| %.2e   |dgrad| %.2e" % (c[0], np.abs(a[1] - c[1]).max(), np.abs(a[2] - c[2]).max()))
+    assert abs(a[0] - c[0]) < 1e-4 * max(1.0, abs(a[0]))
+    assert np.abs(a[1] - c[1]).max() < 5e-5
+    assert np.abs(a[2] - c[2]).max() < 1e-3 * scale
 
 
 @pytest.mark.parametrize("d", [2, 8, 32, 128, 512])
