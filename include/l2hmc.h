@@ -344,8 +344,9 @@ typedef struct L2hmcSplitArgs {
                                   *       mode 1's matrix-pipe work at fp32-level accuracy (22 significand bits per operand in the worst case)
                                   *       for operand entries in [4e-3, 65504) -- smaller entries keep an absolute error of
                                   *       2^-30, larger ones overflow to inf.  The sampler's activations, logits and BCE
-                                  *       gradients live there; the TRAINER's adjoint planes (entries scaled by 1 / chains) do
-                                  *       not: L2hmcTrainSplitArgs.gemm_mode 3 runs mode 1 (csrc/gemm_f32.hpp, gemm_xl.hpp)     */
+                                  *       gradients live there; the TRAINER's tangent / adjoint planes (entries scaled by 1 / chains)
+                                  *       do not: under L2hmcTrainSplitArgs.gemm_mode 3 its forward evaluations run on f16x2
+                                  *       planes, its reverse sweep as mode 1 (csrc/gemm_f32.hpp, gemm_xl.hpp, train_split.hpp)   */
   L2hmcNetCallback net_cb;       /* (ABI 5) non-NULL: the caller's nets (see L2hmcNetCallback); xnet = vnet = aux_encoder = NULL,
                                   *    H is ignored, hmc = 0.  With any target: energy_cb, a built-in energy, or (round 6) the
                                   *    decoder posterior -- the callback's nets then read the images on their own           */

@@ -744,7 +744,7 @@ int64_t l2hmc_train_split_workspace_floats(int64_t n_chains, int32_t d, int32_t 
 }
 
 int l2hmc_train_split_grad(const L2hmcTrainSplitArgs* a, void* stream) {
-  if (a && (a->gemm_mode < 0 || a->gemm_mode > 3)) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA), 1 (bf16x3), 2 (bf16x3, split in the loop) or 3 (the sampler's f16x2 planes: bf16x3 here)%s");
+  if (a && (a->gemm_mode < 0 || a->gemm_mode > 3)) return fail(L2HMC_ERR_ARG, "gemm_mode must be 0 (f32 MFMA), 1 (bf16x3), 2 (bf16x3, split in the loop) or 3 (f16x2 planes for the forward evaluations, bf16x3 for the reverse sweep)%s");
   if (a && (a->net_mode < 0 || a->net_mode > 1)) return fail(L2HMC_ERR_ARG, "net_mode must be 0 (fused) or 1 (three products)%s");
   t_gemm_bf3 = a ? a->gemm_mode != 0 : 0;
   t_plane_mode = 0;          // (the adjoint planes hold entries scaled by 1 / chains: they need bf16's exponent range)
