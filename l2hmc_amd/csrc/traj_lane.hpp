@@ -85,6 +85,130 @@ __device__ __forceinline__ f2 tanh2(f2 z) { return 1.f - 2.f * rcp2(1.f + ex2_2(
 //  through v_readlane again -- 272 cross-lane moves per step)
 #define LANE_EVAL_FENCE() LANE_NO_HOIST()
 
+// RES (round 6): where the weights of the step loop live.  At one wave per SIMD -- 65 536 chains of a d <= 2 target = 1024 waves --
+// nothing hides the scalar loads: the step loop of <GMM, 2, 5> holds 137 s_load_* and 49 s_waitcnt lgkmcnt(0) beside ~720 VALU
+// instructions, ~4000 cycles of issue and ~4500 of waiting per leapfrog step (8500 measured; profiles/r06_lane_resident.txt).
+// A wave-uniform value lives in SGPRs by the compiler's choice (100 of them: the whole budget); the kernel uses 84 of 256 VGPRs.
+//   RES = 0  weights by scalar loads inside the loop (rounds 2-5; any DP, HPR)
+//   RES = 1  XNet's layer-2 and head pairs (evaluated twice per step: a third of the weight traffic) passed through v_mov_b64
+//            once per launch -- ordinary VGPR pairs, which v_pk_fma_f32 takes as it takes the SGPR pairs (160 registers)
+//   RES = 2  EVERY weight of both nets in VGPRs, FOUR per register: lane l holds float 4 i + (l & 3) of the net's lane layout in
+//            register i, and the FMA reads it through a DPP quad broadcast -- v_fmac_f32_dpp acc, w4, x quad_perm:[k,k,k,k] --
+//            at the issue cost of a v_pk_fma_f32 (tools/ubench_dpp.hip: 5.13 cycles both).  Twice the FMA instructions (one
+//            hidden unit each instead of two), no scalar load and no s_waitcnt left in a net evaluation; 2 x 72 registers at
+//            d = 2, H = 10.  The FMAs run in the order of the packed form on the same operands: results are bit-identical.
+template <int HPR, int NP, int RES>
+struct LaneRes {};
+template <int HPR, int NP>
+struct LaneRes<HPR, NP, 1> {
+  f2 l2[2 * HPR][HPR];
+  f2 hd[NP][3][2 * HPR];
+};
+__device__ __forceinline__ f2 to_vgpr2(f2 sv) {
+  f2 v;
+  asm("v_mov_b64 %0, %1" : "=v"(v) : "s"(sv));
+  return v;
+}
+template <int DP, int HPR, int RES>
+__device__ __forceinline__ void lane_res_load(const float* __restrict__ W, LaneRes<HPR, DP / 2, RES>& R) {
+  if constexpr (RES == 1) {
+    using L = LaneL<DP, HPR>;
+#pragma unroll
+    for (int j = 0; j < 2 * HPR; ++j)
+#pragma unroll
+      for (int i = 0; i < HPR; ++i) R.l2[j][i] = to_vgpr2(ld2(W + L::l2 + j * L::RS + 2 * i));
+#pragma unroll
+    for (int p = 0; p < DP / 2; ++p)
+#pragma unroll
+      for (int hd = 0; hd < 3; ++hd)
+#pragma unroll
+        for (int j = 0; j < 2 * HPR; ++j) R.hd[p][hd][j] = to_vgpr2(ld2(W + L::hd + p * L::HB + hd * 4 * HPR + 2 * j));
+  }
+}
+
+// ---- RES = 2: four weights per VGPR, broadcast inside the FMA -----------------------------------------------------------------
+// (EXEC is full wherever these run: dead lanes shadow chain 0, the step loop has no divergent branch.  The packed registers are
+//  written once per launch, so the DPP read-after-VALU-write wait states never apply inside the loop.)
+#define L2HMC_DPP_Q(k) " quad_perm:[" #k "," #k "," #k "," #k "] row_mask:0xf bank_mask:0xf"
+__device__ __forceinline__ void fmac_q(float& acc, float w4, int q, float x) {      // acc += w4[quad lane q] * x  (q folds to a constant)
+  switch (q & 3) {
+    case 0: asm("v_fmac_f32_dpp %0, %1, %2" L2HMC_DPP_Q(0) : "+v"(acc) : "v"(w4), "v"(x)); break;
+    case 1: asm("v_fmac_f32_dpp %0, %1, %2" L2HMC_DPP_Q(1) : "+v"(acc) : "v"(w4), "v"(x)); break;
+    case 2: asm("v_fmac_f32_dpp %0, %1, %2" L2HMC_DPP_Q(2) : "+v"(acc) : "v"(w4), "v"(x)); break;
+    default: asm("v_fmac_f32_dpp %0, %1, %2" L2HMC_DPP_Q(3) : "+v"(acc) : "v"(w4), "v"(x)); break;
+  }
+}
+__device__ __forceinline__ float bcast_q(float w4, int q) {
+  float r;
+  switch (q & 3) {
+    case 0: asm("v_mov_b32_dpp %0, %1" L2HMC_DPP_Q(0) : "=v"(r) : "v"(w4)); break;
+    case 1: asm("v_mov_b32_dpp %0, %1" L2HMC_DPP_Q(1) : "=v"(r) : "v"(w4)); break;
+    case 2: asm("v_mov_b32_dpp %0, %1" L2HMC_DPP_Q(2) : "=v"(r) : "v"(w4)); break;
+    default: asm("v_mov_b32_dpp %0, %1" L2HMC_DPP_Q(3) : "=v"(r) : "v"(w4)); break;
+  }
+  return r;
+}
+template <int DP, int HPR>
+struct LaneDpp {
+  static constexpr int NF = (LaneL<DP, HPR>::hd + (DP / 2) * LaneL<DP, HPR>::HB + 3) / 4 * 4, NR = NF / 4;
+  float r[NR];
+  __device__ __forceinline__ void load(const float* __restrict__ W, int lane) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r[i] = W[4 * i + (lane & 3)];
+  }
+  __device__ __forceinline__ void fmac(float& acc, int o, float x) const { fmac_q(acc, r[o >> 2], o, x); }   // float o of the layout
+  __device__ __forceinline__ float get(int o) const { return bcast_q(r[o >> 2], o); }
+};
+// lane_hidden / lane_heads below on the packed registers: the same sums in the same order, one hidden unit per instruction
+template <int DP, int HPR, class FA, class FB>
+__device__ __forceinline__ void lane_hidden_dpp(const LaneDpp<DP, HPR>& W, FA&& a_of, FB&& b_of, float tc, float ts, f2 (&h2)[HPR]) {
+  using L = LaneL<DP, HPR>;
+  float acc[2 * HPR], o2[2 * HPR];
+  // (one pass over the hidden units per term: consecutive instructions write different accumulators -- a lone wave pays the
+  //  latency of every dependent pair; the order of the terms per accumulator is the packed form's)
+#pragma unroll
+  for (int j = 0; j < 2 * HPR; ++j) acc[j] = W.get(L::tb + 2 * L::RS + j);
+#pragma unroll
+  for (int j = 0; j < 2 * HPR; ++j) W.fmac(acc[j], L::tb + L::RS + j, ts);
+#pragma unroll
+  for (int j = 0; j < 2 * HPR; ++j) W.fmac(acc[j], L::tb + j, tc);
+#pragma unroll
+  for (int k = 0; k < DP; ++k) {
+    const float ak = a_of(k), bk = b_of(k);
+#pragma unroll
+    for (int j = 0; j < 2 * HPR; ++j) W.fmac(acc[j], L::l1b + k * L::RS + j, bk);
+#pragma unroll
+    for (int j = 0; j < 2 * HPR; ++j) W.fmac(acc[j], L::l1a + k * L::RS + j, ak);
+  }
+#pragma unroll
+  for (int j = 0; j < 2 * HPR; ++j) acc[j] = __int_as_float(max(__float_as_int(acc[j]), 0));
+#pragma unroll
+  for (int i = 0; i < 2 * HPR; ++i) o2[i] = W.get(L::b4 + i);
+#pragma unroll
+  for (int j = 0; j < 2 * HPR; ++j)
+#pragma unroll
+    for (int i = 0; i < 2 * HPR; ++i) W.fmac(o2[i], L::l2 + j * L::RS + i, acc[j]);
+#pragma unroll
+  for (int i = 0; i < HPR; ++i) h2[i] = relu2(f2{o2[2 * i], o2[2 * i + 1]});
+}
+template <int DP, int HPR>
+__device__ __forceinline__ void lane_heads_dpp(const LaneDpp<DP, HPR>& W, int p, const f2 (&h2)[HPR], f2& S, f2& T, f2& Q) {
+  using L = LaneL<DP, HPR>;
+  const int hb = L::hd + p * L::HB, cb = hb + 12 * HPR;
+  float z[6];                                    // (S, T, Q) x (dimension pair): six accumulators side by side
+#pragma unroll
+  for (int u = 0; u < 6; ++u) z[u] = W.get(cb + u);
+#pragma unroll
+  for (int j = 0; j < 2 * HPR; ++j) {
+    const float hj = (j & 1) ? h2[j >> 1].y : h2[j >> 1].x;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) W.fmac(z[u], hb + (u >> 1) * 4 * HPR + 2 * j + (u & 1), hj);
+  }
+  S = f2{W.get(cb + 6), W.get(cb + 7)} * tanh2(f2{z[0], z[1]});
+  T = f2{z[2], z[3]};
+  Q = f2{W.get(cb + 8), W.get(cb + 9)} * tanh2(f2{z[4], z[5]});
+}
+
 // grad U (and U) of one chain held by one lane; every parameter is wave-uniform.  prec / mu as the fused kernels get
 // them: diagonal precisions (d); MFMA-packed symmetric precisions (pack_gauss_kernel) for the dense kinds.
 // wave-uniform read-only tables: separate `const float* __restrict__` kernel parameters, so that the compiler may use
@@ -166,9 +290,9 @@ __device__ __forceinline__ float lane_grad(const KArgs& A, const float* __restri
 
 // hidden activations h2 (HPR pairs) of net W at inputs (a_k, b_k) and the lane's time encoding (tc, ts); every bound is a
 // compile-time constant (the layout is zero padded to DP rows and 2 HPR units)
-template <int DP, int HPR, class FA, class FB>
+template <int DP, int HPR, int RES = 0, class FA, class FB>
 __device__ __forceinline__ void lane_hidden(const float* __restrict__ W, FA&& a_of, FB&& b_of, float tc, float ts,
-                                            f2 (&h2)[HPR]) {
+                                            f2 (&h2)[HPR], const LaneRes<HPR, DP / 2, RES>* R = nullptr) {
   using L = LaneL<DP, HPR>;
   f2 acc[HPR];
   {
@@ -196,15 +320,19 @@ __device__ __forceinline__ void lane_hidden(const float* __restrict__ W, FA&& a_
     const f2 hj = splat2((j & 1) ? acc[j >> 1].y : acc[j >> 1].x);
     const float* r = W + L::l2 + j * L::RS;
 #pragma unroll
-    for (int i = 0; i < HPR; ++i) h2[i] = fma2(ld2(r + 2 * i), hj, h2[i]);
+    for (int i = 0; i < HPR; ++i) {
+      if constexpr (RES == 1) h2[i] = fma2(R->l2[j][i], hj, h2[i]);
+      else h2[i] = fma2(ld2(r + 2 * i), hj, h2[i]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < HPR; ++i) h2[i] = relu2(h2[i]);
 }
 
 // heads of dimension pair p: S = e^{lam_s} tanh(.), T, Q = e^{lam_q} tanh(.); one head at a time (2 HPR SGPR pairs live)
-template <int DP, int HPR>
-__device__ __forceinline__ void lane_heads(const float* __restrict__ W, int p, const f2 (&h2)[HPR], f2& S, f2& T, f2& Q) {
+template <int DP, int HPR, int RES = 0>
+__device__ __forceinline__ void lane_heads(const float* __restrict__ W, int p, const f2 (&h2)[HPR], f2& S, f2& T, f2& Q,
+                                           const LaneRes<HPR, DP / 2, RES>* R = nullptr) {
   using L = LaneL<DP, HPR>;
   const float* hb = W + L::hd + p * L::HB;
   const float* cb = hb + 12 * HPR;
@@ -216,7 +344,8 @@ __device__ __forceinline__ void lane_heads(const float* __restrict__ W, int p, c
 #pragma unroll
     for (int j = 0; j < 2 * HPR; ++j) {
       const f2 hj = splat2((j & 1) ? h2[j >> 1].y : h2[j >> 1].x);
-      acc = fma2(ld2(hb + hd * 4 * HPR + 2 * j), hj, acc);
+      if constexpr (RES == 1) acc = fma2(R->hd[p][hd][j], hj, acc);
+      else acc = fma2(ld2(hb + hd * 4 * HPR + 2 * j), hj, acc);
     }
     z[hd] = acc;
   }
@@ -226,8 +355,8 @@ __device__ __forceinline__ void lane_heads(const float* __restrict__ W, int p, c
   Q = ld2(cb + 8) * tanh2(z[2]);
 }
 
-template <int EK, int DP, int HPR>
-__global__ __launch_bounds__(64, DP <= 8 ? 4 : 2) void traj_lane_kernel(const KArgs A, const float* __restrict__ WX,
+template <int EK, int DP, int HPR, int RES = 0>
+__global__ __launch_bounds__(64, RES != 0 ? 2 : (DP <= 8 ? 4 : 2)) void traj_lane_kernel(const KArgs A, const float* __restrict__ WX,
                                                                         const float* __restrict__ WV,
                                                                         const float* __restrict__ MASKS,
                                                                         const float* __restrict__ TRIG,
@@ -253,6 +382,10 @@ __global__ __launch_bounds__(64, DP <= 8 ? 4 : 2) void traj_lane_kernel(const KA
 #pragma unroll
   for (int k = 0; k < DP; ++k) x[k] = (k < d) ? A.x[row * d + k] : 0.f;
   float U_cur = lane_grad<EK, DP>(A, MU, PREC, LOGC, x, g, need_p);
+  LaneRes<HPR, DP / 2, RES == 1 ? 1 : 0> RX;
+  lane_res_load<DP, HPR, RES == 1 ? 1 : 0>(WX, RX);
+  LaneDpp<DP, RES == 2 ? HPR : 1> PX, PV;             // (RES = 2; otherwise never touched: no registers)
+  if constexpr (RES == 2) { PX.load(WX, lane); PV.load(WV, lane); }
   if constexpr (DP > 16) {                 // x_next doubles as the current-state copy a rejected chain resumes from
     if (A.x_next != nullptr && live)
 #pragma unroll
@@ -323,7 +456,7 @@ __global__ __launch_bounds__(64, DP <= 8 ? 4 : 2) void traj_lane_kernel(const KA
         if constexpr (EK == L2HMC_ENERGY_GAUSS_DIAG) {
           const int kk = k < d ? k : d - 1;
           const float pk = k < d ? PREC[kk] : 0.f;
-          return (pk * (x[k] - MU[kk])) / A.temperature;
+          return pk * (x[k] - MU[kk]);       // (the dispatcher takes this kernel at temperature 1 only: l2hmc_abi.hip, lane_able)
         } else {
           return g[k];
         }
@@ -331,11 +464,13 @@ __global__ __launch_bounds__(64, DP <= 8 ? 4 : 2) void traj_lane_kernel(const KA
       // momentum half-update with V(z, grad U(z)) (dynamics.py:118-125,147-153 / :162-170,192-199)
       auto v_half = [&]() {
         LANE_EVAL_FENCE();
-        lane_hidden<DP, HPR>(WV, [&](int k) { return x[k]; }, g_of, tc, ts, h2);
+        if constexpr (RES == 2) lane_hidden_dpp<DP, HPR>(PV, [&](int k) { return x[k]; }, g_of, tc, ts, h2);
+        else lane_hidden<DP, HPR>(WV, [&](int k) { return x[k]; }, g_of, tc, ts, h2);
 #pragma unroll
         for (int p = 0; p < DP / 2; ++p) {
           f2 S, T, Q;
-          lane_heads<DP, HPR>(WV, p, h2, S, T, Q);
+          if constexpr (RES == 2) lane_heads_dpp<DP, HPR>(PV, p, h2, S, T, Q);
+          else lane_heads<DP, HPR>(WV, p, h2, S, T, Q);
           const f2 sv = S * (sgn * heps);
           const f2 ES = ex2_2(sv * LOG2E), EQ = ex2_2(Q * (eps * LOG2E));
           const f2 gg = f2{g_of(2 * p), g_of(2 * p + 1)}, vv = f2{v[2 * p], v[2 * p + 1]};
@@ -355,11 +490,13 @@ __global__ __launch_bounds__(64, DP <= 8 ? 4 : 2) void traj_lane_kernel(const KA
           kq[k] = first ? k1 : 1.f - k1;
         }
         LANE_EVAL_FENCE();
-        lane_hidden<DP, HPR>(WX, [&](int k) { return v[k]; }, [&](int k) { return kq[k] * x[k]; }, tc, ts, h2);
+        if constexpr (RES == 2) lane_hidden_dpp<DP, HPR>(PX, [&](int k) { return v[k]; }, [&](int k) { return kq[k] * x[k]; }, tc, ts, h2);
+        else lane_hidden<DP, HPR, RES == 1 ? 1 : 0>(WX, [&](int k) { return v[k]; }, [&](int k) { return kq[k] * x[k]; }, tc, ts, h2, &RX);
 #pragma unroll
         for (int p = 0; p < DP / 2; ++p) {
           f2 S, T, Q;
-          lane_heads<DP, HPR>(WX, p, h2, S, T, Q);
+          if constexpr (RES == 2) lane_heads_dpp<DP, HPR>(PX, p, h2, S, T, Q);
+          else lane_heads<DP, HPR, RES == 1 ? 1 : 0>(WX, p, h2, S, T, Q, &RX);
           const f2 up = 1.f - f2{kq[2 * p], kq[2 * p + 1]};
           const f2 sx = up * S * (sgn * eps);
           const f2 ES = ex2_2(sx * LOG2E), EQ = ex2_2(Q * (eps * LOG2E));

@@ -404,3 +404,44 @@ def test_f16x2_range_is_wide_and_its_overflow_is_loud():
                 assert rel_err(to_np(X16) / scale, to_np(X32) / scale) < 1e-5 and abs_err(to_np(p16), to_np(p32)) < 1e-4
             else:
                 assert np.isnan(to_np(X16)).all() and np.isnan(to_np(V16)).all() and np.all(to_np(p16) == 0), (scale, var)
+
+
+# ---- one chain per lane (csrc/traj_lane.hpp): where the weights live must not change a bit ---------------------------------------
+@pytest.mark.parametrize("case", ["scg2d", "mog2d", "ring4", "rough2_ne", "diag2"])
+def test_lane_kernel_weight_residency_forms_are_bit_identical(case, monkeypatch):
+    """traj_lane_kernel<., 2, 5, RES>: weights by scalar loads in the loop (RES 0), XNet's layer 2 and heads as VGPR pairs (1), every
+    weight of both nets in VGPRs four per register behind a DPP quad broadcast (2).  The three forms run the same FMAs on the same
+    operands in the same order: direction-mixed proposals with an MH step on a ragged chain count (two full waves and a part)
+    must agree BIT FOR BIT, and sit on the reference fixture like every other kernel."""
+    import torch
+    from l2hmc_amd import _ffi, propose
+    if case == "diag2":                                   # no d = 2 diagonal fixture: the strongly anisotropic Gaussian of scg2d's nets
+        g = dict(load("scg2d"))
+        g["energy.i_sigma"] = np.diag(np.array([100.0, 1.0], np.float32))      # (a diagonal precision -> the diagonal-Gaussian kernels)
+    else:
+        g = load(case)
+    n0 = g["x"].shape[0]
+    N = 2 * 64 + 37
+    rng = np.random.RandomState(11)
+    idx = rng.randint(0, n0, size=N)
+    x, v = to_dev(g["x"][idx] + 0.01 * rng.randn(N, 2).astype(np.float32)), to_dev(g["v"][idx])
+    direction, u = to_dev(rng.randint(0, 2, size=N).astype(np.uint8)), to_dev(rng.rand(N).astype(np.float32))
+    outs = []
+    for res in ("0", "1", "2"):
+        monkeypatch.setenv("L2HMC_LANE_RES", res)
+        dyn = hip_dynamics(g, 32)
+        Lx, Lv, px, o = propose(x, dyn, do_mh_step=True, direction=direction, v=v, u=u)
+        assert _ffi.last_kernel() == "traj_lane_kernel"
+        assert np.isfinite(to_np(Lx)).all() and 0.05 < float(px.mean()) <= 1.0
+        outs.append([t for t in (Lx, Lv, px, o[0]) if t is not None])
+    for other in outs[1:]:
+        assert len(other) == len(outs[0]) >= 3
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    if case != "diag2":                                   # and the fixture itself (all chains forward), on the default choice
+        monkeypatch.delenv("L2HMC_LANE_RES")
+        dyn = hip_dynamics(g, 32)
+        X, V, lj = dyn.forward(to_dev(g["x"]), init_v=to_dev(g["v"]), log_jac=True)
+        if not is_stiff(g):
+            for got, key in zip((X, V, lj), ("fwd.x", "fwd.v", "fwd.logjac")):
+                assert rel_err(to_np(got), g[key]) < TRAJ_TOL, key
