@@ -284,7 +284,17 @@ template <int EK, int DT, int NW, int KH, int PK = 0>
 #ifndef L2HMC_FAST_WAVES
 #define L2HMC_FAST_WAVES 2
 #endif
-__global__ __launch_bounds__(64 * NW, L2HMC_FAST_WAVES) void traj_fast_kernel(const KArgs A) {
+// Register budget (round 6, profiles/r06_fast_dt2_spills.txt): with two dimension tiles per wave the f16x2 form holds 120 VGPRs of
+// weight fragments (8 layer-1 + 7 tail WF16) beside the state -- under the two-waves-per-SIMD bound (256 VGPRs) the allocator spilled
+// 450-630 bytes per lane to SCRATCH inside the step loop (`.amdhsa_private_segment_fixed_size`).  One wave per SIMD for DT = 2: the
+// overflow goes to AGPRs (v_accvgpr_*), no scratch -- Rough Well d = 32 / 16 384 chains 62.1 -> 39.4 us per proposal, d = 96 ... 128
+// 207 -> 160 (it had been SLOWER than the f32-input form it replaced: 44.9 / 181).  DT = 1 keeps the two-wave bound (8192 chains =
+// two workgroups per CU; and with 512 registers the scheduler's choices cost 5-7 % there), and so does the f32-input form of
+// DT = 2 (44-184 bytes of scratch; one wave per SIMD measured 5-9 % slower: dense Gaussian d = 32 41.9 -> 45.6 us).
+#ifndef L2HMC_FAST_WAVES_DT2
+#define L2HMC_FAST_WAVES_DT2 1
+#endif
+__global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT2 : L2HMC_FAST_WAVES) void traj_fast_kernel(const KArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   lds_poison(smem);
   static_assert(DT <= 2, "the fast kernel keeps layer-1 and tail fragments in registers");

@@ -77,8 +77,11 @@ __device__ __forceinline__ float grad_small(const KArgs& A, const float* smem, c
 // PK = 1 (round 6): the hidden layer and the head block as f16x2 (traj_fast.hpp) -- 4 x 4 f16 MFMAs of 16 cycles per step that leave
 // the VALU free instead of 24 f32-input ones of 32 that block it; layer 1 is ONE k-step per input and keeps the f32-input MFMA (a
 // K = 32 instruction would carry four live slots).  The end points of a proposal are held against L2HMC_F16_STATE_MAX.
+#ifndef L2HMC_SMALL_WAVES
+#define L2HMC_SMALL_WAVES 4
+#endif
 template <int EK, int KH, int PK = 0>
-__global__ __launch_bounds__(64, 4) void traj_small_kernel(const KArgs A) {
+__global__ __launch_bounds__(64, L2HMC_SMALL_WAVES) void traj_small_kernel(const KArgs A) {
   constexpr bool F16 = PK == 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   lds_poison(smem);
