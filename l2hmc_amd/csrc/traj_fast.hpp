@@ -517,13 +517,14 @@ __global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT
     const int drec = fwd ? R : -R;
     f4 tbv = lds4(rec + 16);
 
-#ifdef L2HMC_FAST_RESIDENT_TAILS     // experiment (round 6): both nets' tail fragments + constants stay in registers for the whole proposal
+    // Resident tails (round 6, profiles/r06_resident_tails.txt): XNet's tail fragments and constants stay in registers for the whole
+    // proposal beside VNet's (44 VGPRs per net as f16x2) instead of being re-read from LDS twice per step -- 22 of a step's 37
+    // ds_read_b128: ICG-50 20.4 -> 19.4-19.6 us per proposal at 4096 chains, 31.3 -> 30.0 at 8192 (251 VGPRs, no scratch).  Not for
+    // the f32-input form of DT = 2, which spills under the two-wave bound already.  Same values, same arithmetic: same bits.
+    constexpr bool RT = DT == 1 || PK == 1;
     TailK<DT, F16> tkx;
-    load_tailk<DT>(tkx, fwx, fcx, dofs, NTp, w, lane);
-#define TKX tkx
-#else
-#define TKX tk
-#endif
+    if constexpr (RT) load_tailk<DT>(tkx, fwx, fcx, dofs, NTp, w, lane);
+    const TailK<DT, F16>& TKX = *(RT ? &tkx : &tk);
     load_tailk<DT>(tk, fwv, fcv, dofs, NTp, w, lane);
     for (int it = 0; it < A.n_steps; ++it) {
       f4 k1[DT], vh[DT], y[DT], xin[DT];
@@ -544,9 +545,7 @@ __global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT
       PT_MARK(2);  // VNet tail #1
 
       // ---- two masked position updates: XNet([v_h, kept * x, t])  (:127-145 / :172-190)
-#ifndef L2HMC_FAST_RESIDENT_TAILS
-      load_tailk<DT>(tk, fwx, fcx, dofs, NTp, w, lane);
-#endif
+      if constexpr (!RT) load_tailk<DT>(tk, fwx, fcx, dofs, NTp, w, lane);
 #pragma unroll
       for (int t = 0; t < DT; ++t) xin[t] = k1[t] * x[t];
       f4 pa, px[1];
@@ -586,9 +585,7 @@ __global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT
       PT_MARK(8);  // XNet tail #2
 
       // ---- momentum half-update #2 at the new position  (:147-153 / :192-199)
-#ifndef L2HMC_FAST_RESIDENT_TAILS
-      load_tailk<DT>(tk, fwv, fcv, dofs, NTp, w, lane);
-#endif
+      if constexpr (!RT) load_tailk<DT>(tk, fwv, fcv, dofs, NTp, w, lane);
       grad(x, g, red[2], need_p && it == A.n_steps - 1);
       pv[0] = vnet_l1(x, g);
       PT_MARK(9);  // grad U + VNet layer-1 partials

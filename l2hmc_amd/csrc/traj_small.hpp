@@ -77,8 +77,10 @@ __device__ __forceinline__ float grad_small(const KArgs& A, const float* smem, c
 // PK = 1 (round 6): the hidden layer and the head block as f16x2 (traj_fast.hpp) -- 4 x 4 f16 MFMAs of 16 cycles per step that leave
 // the VALU free instead of 24 f32-input ones of 32 that block it; layer 1 is ONE k-step per input and keeps the f32-input MFMA (a
 // K = 32 instruction would carry four live slots).  The end points of a proposal are held against L2HMC_F16_STATE_MAX.
+// Register budget: two waves per SIMD (256 VGPRs) since round 6 -- with both nets' tail fragments resident (below) the f16x2 form
+// needs ~150; the chain counts this kernel serves (up to 32 768 two-dimensional chains = two waves per SIMD) never held more.
 #ifndef L2HMC_SMALL_WAVES
-#define L2HMC_SMALL_WAVES 4
+#define L2HMC_SMALL_WAVES 2
 #endif
 template <int EK, int KH, int PK = 0>
 __global__ __launch_bounds__(64, L2HMC_SMALL_WAVES) void traj_small_kernel(const KArgs A) {
@@ -278,6 +280,16 @@ __global__ __launch_bounds__(64, L2HMC_SMALL_WAVES) void traj_small_kernel(const
     const int drec = fwd ? R : -R;
     f4 tbv = lds4(rec + 16 + 4 * q);
     load_tail_s(tk, fwv, fcv, dofs);
+    // both nets' tail fragments and constants stay in registers for the whole proposal (round 6; -DL2HMC_SMALL_RELOAD_TAILS: re-read
+    // from LDS twice per step as in rounds 2-5): MoG-2D / 8192 chains 36.1 -> 33.6 us per proposal, Rough Well d = 2 / 16 384 chains
+    // 11.8 -> 11.2, SCG-2D unchanged (profiles/r06_resident_tails.txt).  Same values, same arithmetic: same bits.
+#ifndef L2HMC_SMALL_RELOAD_TAILS
+    TailS tkx;
+    load_tail_s(tkx, fwx, fcx, dofs);
+#define SMALL_TKX tkx
+#else
+#define SMALL_TKX tk
+#endif
     for (int it = 0; it < A.n_steps; ++it) {
       const f4 tbx = lds4(rec + 4 * q);
       const float k1 = rec[32 + q], up1 = 1.f - k1;
@@ -291,22 +303,26 @@ __global__ __launch_bounds__(64, L2HMC_SMALL_WAVES) void traj_small_kernel(const
       float tr = T - EQ * g;
       const float vh = ES * (nf * tr + v) + ff * tr;
       // ---- two masked position updates  (:127-145 / :172-190)
+#ifdef L2HMC_SMALL_RELOAD_TAILS
       load_tail_s(tk, fwx, fcx, dofs);
+#endif
       const f4 pa = MFMA16(xa, vh, Z);
-      tail_s(tk, MFMA16(xb, k1 * x, pa) + tbx, aS, T, EQ);
+      tail_s(SMALL_TKX, MFMA16(xb, k1 * x, pa) + tbx, aS, T, EQ);
       float aSm = up1 * aS;
       ES = __builtin_amdgcn_exp2f(aSm);
       ldv += aSm;
       tr = up1 * (EQ * vh + T);
       const float y = ES * (nf * tr + x) + ff * tr;
-      tail_s(tk, MFMA16(xb, up1 * y, pa) + tbx, aS, T, EQ);
+      tail_s(SMALL_TKX, MFMA16(xb, up1 * y, pa) + tbx, aS, T, EQ);
       aSm = k1 * aS;
       ES = __builtin_amdgcn_exp2f(aSm);
       ldv += aSm;
       tr = k1 * (EQ * vh + T);
       x = ES * (nf * tr + y) + ff * tr;
       // ---- momentum half-update #2 at the new position  (:147-153 / :192-199)
+#ifdef L2HMC_SMALL_RELOAD_TAILS
       load_tail_s(tk, fwv, fcv, dofs);
+#endif
       g = grad_small<EK>(A, smem, E, lane, x, red[2], need_p && it == A.n_steps - 1);
       pv = vnet_l1(x, g);
       tail_s(tk, pv + tbv, aS, T, EQ);
