@@ -236,6 +236,46 @@ __global__ __launch_bounds__(64, L2HMC_SMALL_WAVES) void traj_small_kernel(const
     Tt = z.y;
   };
 
+  // two tails of ONE net on two inputs, stage by stage (the compiler keeps the source order of independent chains: written one
+  // after the other they run one after the other, each MFMA pair followed by its own s_nop 7)
+  auto tail_s2 = [&](const TailS& t, f4 hsa, f4 hsb, float& aSa, float& Ta, float& EQa, float& aSb, float& Tb, float& EQb) {
+    f4 ha = Z, hb = Z, za = Z, zb = Z;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) { ha[r] = relu_i(hsa[r]); hb[r] = relu_i(hsb[r]); }
+    if constexpr (F16) {
+      const h8v sa = split16<true>(ha), sb = split16<true>(hb);
+      f4 acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(t.w2.a1, sa, Z, 0, 0, 0);
+      f4 accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(t.w2.a1, sb, Z, 0, 0, 0);
+      acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(t.w2.a2, sa, acca, 0, 0, 0);
+      accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(t.w2.a2, sb, accb, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < KH; ++r) { ha[r] = relu_i(acca[r]); hb[r] = relu_i(accb[r]); }
+      const h8v ta = split16<true>(ha), tb = split16<true>(hb);
+      za = __builtin_amdgcn_mfma_f32_16x16x32_f16(t.hd.a1, ta, Z, 0, 0, 0);
+      zb = __builtin_amdgcn_mfma_f32_16x16x32_f16(t.hd.a1, tb, Z, 0, 0, 0);
+      za = __builtin_amdgcn_mfma_f32_16x16x32_f16(t.hd.a2, ta, za, 0, 0, 0);
+      zb = __builtin_amdgcn_mfma_f32_16x16x32_f16(t.hd.a2, tb, zb, 0, 0, 0);
+    } else {
+      f4 acca = Z, accb = Z;
+#pragma unroll
+      for (int r = 0; r < KH; ++r) { acca = MFMA16(t.w2[r], ha[r], acca); accb = MFMA16(t.w2[r], hb[r], accb); }
+#pragma unroll
+      for (int r = 0; r < KH; ++r) { ha[r] = relu_i(acca[r]); hb[r] = relu_i(accb[r]); }
+#pragma unroll
+      for (int r = 0; r < KH; ++r) { za = MFMA16(t.hd[r], ha[r], za); zb = MFMA16(t.hd[r], hb[r], zb); }
+    }
+    const float eSa = __builtin_amdgcn_exp2f(za.x), eSb = __builtin_amdgcn_exp2f(zb.x);
+    const float eQa = __builtin_amdgcn_exp2f(za.z), eQb = __builtin_amdgcn_exp2f(zb.z);
+    const float rSa = __builtin_amdgcn_rcpf(-(eSa * 0.5f + 0.5f)), rSb = __builtin_amdgcn_rcpf(-(eSb * 0.5f + 0.5f));
+    const float rQa = __builtin_amdgcn_rcpf(-(eQa * 0.5f + 0.5f)), rQb = __builtin_amdgcn_rcpf(-(eQb * 0.5f + 0.5f));
+    aSa = rSa * t.cS + t.cS;
+    aSb = rSb * t.cS + t.cS;
+    EQa = __builtin_amdgcn_exp2f(rQa * t.cQ + t.bQ);
+    EQb = __builtin_amdgcn_exp2f(rQb * t.cQ + t.bQ);
+    Ta = za.y;
+    Tb = zb.y;
+  };
+
   float U_start = 0.f;
   float g = grad_small<EK>(A, smem, E, lane, x, U_start, need_p);
   f4 pv = vnet_l1(x, g);
@@ -290,14 +330,27 @@ __global__ __launch_bounds__(64, L2HMC_SMALL_WAVES) void traj_small_kernel(const
 #else
 #define SMALL_TKX tk
 #endif
+    // VNet is evaluated at the same (x, grad U(x)) at the end of step t and at the start of step t + 1 -- only the time row differs --
+    // and its S, T, Q do not depend on the momentum: the two tails are INDEPENDENT given the shared layer-1 sum, so they are
+    // issued side by side (round 6; -DL2HMC_SMALL_SERIAL_TAILS: one after the other as in rounds 2-5).  A lone wave per SIMD -- every
+    // chain count this kernel serves -- is bound by the length of its dependent chain: four tails per step become three.  The last
+    // step's look-ahead tail is computed and dropped.  Same operations on the same operands: results are bit-identical.
+    float aS, T, EQ;
+#ifndef L2HMC_SMALL_SERIAL_TAILS
+    float aS_n, T_n, EQ_n;
+    tail_s(tk, pv + tbv, aS_n, T_n, EQ_n);
+#endif
     for (int it = 0; it < A.n_steps; ++it) {
       const f4 tbx = lds4(rec + 4 * q);
       const float k1 = rec[32 + q], up1 = 1.f - k1;
       rec += drec;
       const f4 tbv_n = lds4(rec + 16 + 4 * q);
-      float aS, T, EQ;
       // ---- momentum half-update #1  (dynamics.py:118-125 / :162-170)
+#ifdef L2HMC_SMALL_SERIAL_TAILS
       tail_s(tk, pv + tbv, aS, T, EQ);
+#else
+      aS = aS_n; T = T_n; EQ = EQ_n;
+#endif
       float ES = __builtin_amdgcn_exp2f(aS);
       ldv += aS;
       float tr = T - EQ * g;
@@ -325,7 +378,11 @@ __global__ __launch_bounds__(64, L2HMC_SMALL_WAVES) void traj_small_kernel(const
 #endif
       g = grad_small<EK>(A, smem, E, lane, x, red[2], need_p && it == A.n_steps - 1);
       pv = vnet_l1(x, g);
+#ifdef L2HMC_SMALL_SERIAL_TAILS
       tail_s(tk, pv + tbv, aS, T, EQ);
+#else
+      tail_s2(tk, pv + tbv, pv + tbv_n, aS, T, EQ, aS_n, T_n, EQ_n);   // + the next step's first half-update (its time row)
+#endif
       ES = __builtin_amdgcn_exp2f(aS);
       ldv += aS;
       tr = T - EQ * g;
