@@ -267,6 +267,53 @@ __device__ __forceinline__ void tail_fast(const TailK<DT, true>& tk, f4 hs_, F&&
   }
 }
 
+// TWO tails of one net on two inputs, stage by stage (round 6): VNet sees the same (x, grad U(x)) at the end of step t and at the start
+// of step t + 1 -- only the time row differs, and S, T, Q do not depend on the momentum -- so the two evaluations are independent
+// given the shared layer-1 sum.  The compiler keeps independent chains in source order (written one after the other, each MFMA pair
+// is followed by its own wait states): here every stage is written for both.  A lone wave per SIMD is bound by the length of its
+// dependent chain; four tails per step become three.  applyA consumes the first evaluation, keepB stores the second.
+template <int DT, int KH, class FA, class FB>
+__device__ __forceinline__ void tail_fast2(const TailK<DT, true>& tk, f4 hsa, f4 hsb, FA&& applyA, FB&& keepB) {
+  f4 ha = splat(0.f), hb = splat(0.f);
+#pragma unroll
+  for (int r = 0; r < KH; ++r) { ha[r] = relu_i(hsa[r]); hb[r] = relu_i(hsb[r]); }
+  {
+    const h8v sa = split16<true>(ha), sb = split16<true>(hb);
+    f4 acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.w2.a1, sa, splat(0.f), 0, 0, 0);
+    f4 accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.w2.a1, sb, splat(0.f), 0, 0, 0);
+    acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.w2.a2, sa, acca, 0, 0, 0);
+    accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.w2.a2, sb, accb, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) { ha[r] = relu_i(acca[r]); hb[r] = relu_i(accb[r]); }
+  }
+  const h8v ba = split16<true>(ha), bb = split16<true>(hb);
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    f4 zsa = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a1, ba, splat(0.f), 0, 0, 0);
+    f4 zqa = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hq[t].a1, ba, splat(0.f), 0, 0, 0);
+    f4 zta = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.ht[t].a1, ba, splat(0.f), 0, 0, 0);
+    f4 zsb = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a1, bb, splat(0.f), 0, 0, 0);
+    f4 zqb = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hq[t].a1, bb, splat(0.f), 0, 0, 0);
+    f4 ztb = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.ht[t].a1, bb, splat(0.f), 0, 0, 0);
+    zsa = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a2, ba, zsa, 0, 0, 0);
+    zqa = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hq[t].a2, ba, zqa, 0, 0, 0);
+    zta = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.ht[t].a2, ba, zta, 0, 0, 0);
+    zsb = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a2, bb, zsb, 0, 0, 0);
+    zqb = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hq[t].a2, bb, zqb, 0, 0, 0);
+    ztb = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.ht[t].a2, bb, ztb, 0, 0, 0);
+    const f4 rSa = rcp4(-(ex2_4(zsa) * 0.5f + 0.5f));
+    const f4 aSa = rSa * tk.cS[t] + tk.cS[t];
+    const f4 rQa = rcp4(-(ex2_4(zqa) * 0.5f + 0.5f));
+    const f4 EQa = ex2_4(rQa * tk.cQ[t] + tk.bQ[t]);
+    applyA(t, aSa, zta, EQa);
+    const f4 rSb = rcp4(-(ex2_4(zsb) * 0.5f + 0.5f));
+    const f4 aSb = rSb * tk.cS[t] + tk.cS[t];
+    const f4 rQb = rcp4(-(ex2_4(zqb) * 0.5f + 0.5f));
+    const f4 EQb = ex2_4(rQb * tk.cQ[t] + tk.bQ[t]);
+    keepB(t, aSb, ztb, EQb);
+  }
+}
+
 // layer-1 fragments of the f16x2 form (register-resident, split once per launch)
 template <int DT>
 struct L1W16 {
@@ -526,6 +573,17 @@ __global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT
     if constexpr (RT) load_tailk<DT>(tkx, fwx, fcx, dofs, NTp, w, lane);
     const TailK<DT, F16>& TKX = *(RT ? &tkx : &tk);
     load_tailk<DT>(tk, fwv, fcv, dofs, NTp, w, lane);
+    // VNet's evaluation for the next step's first half-update rides beside this step's second one (tail_fast2 above; f16x2 with
+    // resident tails; -DL2HMC_FAST_SERIAL_TAILS: four tails per step, one after the other)
+#ifndef L2HMC_FAST_SERIAL_TAILS
+    constexpr bool PAIR = F16 && RT && DT == 1;      // (DT = 2: measured neutral, profiles/r06_paired_tails.txt)
+#else
+    constexpr bool PAIR = false;
+#endif
+    f4 aS_n[DT], T_n[DT], EQ_n[DT];
+    if constexpr (PAIR) {
+      tail_fast<DT, KH>(tk, pv[0] + tbv, [&](int t, f4 aS, f4 T, f4 EQ) { aS_n[t] = aS; T_n[t] = T; EQ_n[t] = EQ; });
+    }
     for (int it = 0; it < A.n_steps; ++it) {
       f4 k1[DT], vh[DT], y[DT], xin[DT];
       const f4 tbx = lds4(rec);
@@ -536,12 +594,18 @@ __global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT
 
       PT_MARK(1);  // step head
       // ---- momentum half-update #1: VNet([x, grad U(x), t])  (dynamics.py:118-125 / :162-170)
-      tail_fast<DT, KH>(tk, pv[0] + tbv, [&](int t, f4 aS, f4 T, f4 EQ) {
+      auto vhalf1 = [&](int t, f4 aS, f4 T, f4 EQ) {
         const f4 ES = ex2_4(aS);
         ldv += aS;
         const f4 tr = T - EQ * g[t];
         vh[t] = ES * (nf * tr + v[t]) + ff * tr;
-      });
+      };
+      if constexpr (PAIR) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) vhalf1(t, aS_n[t], T_n[t], EQ_n[t]);
+      } else {
+        tail_fast<DT, KH>(tk, pv[0] + tbv, vhalf1);
+      }
       PT_MARK(2);  // VNet tail #1
 
       // ---- two masked position updates: XNet([v_h, kept * x, t])  (:127-145 / :172-190)
@@ -591,12 +655,17 @@ __global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT
       PT_MARK(9);  // grad U + VNet layer-1 partials
       xchg<NW, 1>(pv, A, smem, w, lane, pb);
       PT_MARK(10); // exchange
-      tail_fast<DT, KH>(tk, pv[0] + tbv, [&](int t, f4 aS, f4 T, f4 EQ) {
+      auto vhalf2 = [&](int t, f4 aS, f4 T, f4 EQ) {
         const f4 ES = ex2_4(aS);
         ldv += aS;
         const f4 tr = T - EQ * g[t];
         v[t] = ES * (nf * tr + vh[t]) + ff * tr;
-      });
+      };
+      if constexpr (PAIR) {
+        tail_fast2<DT, KH>(tk, pv[0] + tbv, pv[0] + tbv_n, vhalf2, [&](int t, f4 aS, f4 T, f4 EQ) { aS_n[t] = aS; T_n[t] = T; EQ_n[t] = EQ; });
+      } else {
+        tail_fast<DT, KH>(tk, pv[0] + tbv, vhalf2);
+      }
       PT_MARK(11); // VNet tail #2
       tbv = tbv_n;
     }
