@@ -539,9 +539,15 @@ __global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT
       if (A.u != nullptr && !rng_u && live) u_n = A.u[moff + A.N + chain];
     }
     // the start point: a rejected chain resumes from it (sampler.py:53-55)
-    f4 x0[DT], g0[DT];
+    // (the diagonal Gaussian's grad U is two packed instructions away from x: it is re-formed from the selected state at the end of
+    //  the proposal -- the same expression on the same x, the same bits -- instead of being held in registers through the trajectory)
+    constexpr bool KEEP_G0 = EK != L2HMC_ENERGY_GAUSS_DIAG;
+    f4 x0[DT], g0[KEEP_G0 ? DT : 1];
 #pragma unroll
-    for (int t = 0; t < DT; ++t) { x0[t] = x[t]; g0[t] = g[t]; }
+    for (int t = 0; t < DT; ++t) {
+      x0[t] = x[t];
+      if constexpr (KEEP_G0) g0[t] = g[t];
+    }
     const f4 pv0 = pv[0];
     float red[F16 ? 6 : 5];        // U0, K0, U1, K1, logdet (per-lane partial sums); f16x2: + the out-of-range flag
     float amax_l = 0.f;
@@ -708,7 +714,8 @@ __global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
           x[t] = sel4(acc, x[t], x0[t]);
-          g[t] = sel4(acc, g[t], g0[t]);
+          if constexpr (KEEP_G0) g[t] = sel4(acc, g[t], g0[t]);
+          else g[t] = er.prec[t] * (x[t] - er.mu[t]);
         }
         pv[0] = sel4(acc, pv[0], pv0);
         U_start = acc ? U_end : U_start;
