@@ -146,6 +146,17 @@ __host__ __device__ inline int fast_rec_dir(int NTp, int T) { return (T + 2) * f
 
 long long plan_lds_fast(KArgs& k, int NW, int DT, bool f16 = false);
 
+// which activation split the four-wave kernel's contractions take (split16 above): measured per place, profiles/r06_f16x2.txt section 3
+// and profiles/r06_paired_tails.txt section 4
+#ifndef L2HMC_FAST_SPLIT_LAT_TAIL
+#define L2HMC_FAST_SPLIT_LAT_TAIL true
+#endif
+#ifndef L2HMC_FAST_SPLIT_LAT_PAIR
+#define L2HMC_FAST_SPLIT_LAT_PAIR true
+#endif
+#ifndef L2HMC_FAST_SPLIT_LAT_L1
+#define L2HMC_FAST_SPLIT_LAT_L1 false        // (layer 1's splits in the 8-instruction form since the paired tails: 18.98 -> 18.70 us at 4096 chains, 8192 level)
+#endif
 template <int DT, bool F16 = false>
 struct TailK {
   f4 w2;
@@ -246,11 +257,11 @@ __device__ __forceinline__ void tail_fast(const TailK<DT, true>& tk, f4 hs_, F&&
 #pragma unroll
   for (int r = 0; r < KH; ++r) h[r] = relu_i(hs_[r]);
   {
-    const f4 acc = mfma16x2(tk.w2, split16<true>(h), splat(0.f));
+    const f4 acc = mfma16x2(tk.w2, split16<L2HMC_FAST_SPLIT_LAT_TAIL>(h), splat(0.f));
 #pragma unroll
     for (int r = 0; r < KH; ++r) h[r] = relu_i(acc[r]);
   }
-  const h8v b = split16<true>(h);
+  const h8v b = split16<L2HMC_FAST_SPLIT_LAT_TAIL>(h);
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
     f4 zs = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a1, b, splat(0.f), 0, 0, 0);
@@ -278,7 +289,7 @@ __device__ __forceinline__ void tail_fast2(const TailK<DT, true>& tk, f4 hsa, f4
 #pragma unroll
   for (int r = 0; r < KH; ++r) { ha[r] = relu_i(hsa[r]); hb[r] = relu_i(hsb[r]); }
   {
-    const h8v sa = split16<true>(ha), sb = split16<true>(hb);
+    const h8v sa = split16<L2HMC_FAST_SPLIT_LAT_PAIR>(ha), sb = split16<L2HMC_FAST_SPLIT_LAT_PAIR>(hb);
     f4 acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.w2.a1, sa, splat(0.f), 0, 0, 0);
     f4 accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.w2.a1, sb, splat(0.f), 0, 0, 0);
     acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.w2.a2, sa, acca, 0, 0, 0);
@@ -286,7 +297,7 @@ __device__ __forceinline__ void tail_fast2(const TailK<DT, true>& tk, f4 hsa, f4
 #pragma unroll
     for (int r = 0; r < KH; ++r) { ha[r] = relu_i(acca[r]); hb[r] = relu_i(accb[r]); }
   }
-  const h8v ba = split16<true>(ha), bb = split16<true>(hb);
+  const h8v ba = split16<L2HMC_FAST_SPLIT_LAT_PAIR>(ha), bb = split16<L2HMC_FAST_SPLIT_LAT_PAIR>(hb);
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
     f4 zsa = __builtin_amdgcn_mfma_f32_16x16x32_f16(tk.hs[t].a1, ba, splat(0.f), 0, 0, 0);
@@ -322,7 +333,7 @@ struct L1W16 {
 template <int DT>
 __device__ __forceinline__ f4 l1_part16(const f4 (&z)[DT], f4 acc, const WF16* W) {
 #pragma unroll
-  for (int t = 0; t < DT; ++t) acc = mfma16x2(W[t], split16<true>(z[t]), acc);
+  for (int t = 0; t < DT; ++t) acc = mfma16x2(W[t], split16<L2HMC_FAST_SPLIT_LAT_L1>(z[t]), acc);
   return acc;
 }
 
