@@ -593,7 +593,10 @@ __global__ __launch_bounds__(64 * NW, (DT >= 2 && PK == 1) ? L2HMC_FAST_WAVES_DT
     // VNet's evaluation for the next step's first half-update rides beside this step's second one (tail_fast2 above; f16x2 with
     // resident tails; -DL2HMC_FAST_SERIAL_TAILS: four tails per step, one after the other)
 #ifndef L2HMC_FAST_SERIAL_TAILS
-    constexpr bool PAIR = F16 && RT && DT == 1;      // (DT = 2: measured neutral, profiles/r06_paired_tails.txt)
+#ifndef L2HMC_FAST_PAIR_DT2
+#define L2HMC_FAST_PAIR_DT2 0
+#endif
+    constexpr bool PAIR = F16 && RT && (DT == 1 || L2HMC_FAST_PAIR_DT2);      // (DT = 2: measured neutral, profiles/r06_paired_tails.txt)
 #else
     constexpr bool PAIR = false;
 #endif
