@@ -147,12 +147,16 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
   // Weight fragments stream from L2 (several hundred cycles away) and a runtime tile loop is not
   // software-pipelined by the compiler: every pass fetches the fragments of tile tg + 1 while it works on tg.
   // `net`: 0 = XNet, 1 = VNet
+  // (round 6, last session: the wave-uniform part of a fragment's address -- net, group -- stays a scalar base and the lane its
+  //  16-byte index: `global_load_dwordx4 v, v_off, s[base]`; as (grp * 64 + lane) * 4 on a VGPR base every load paid a v_add_u32 and a
+  //  v_lshl_add_u64 -- 26 of a slice's ~210 VALU instructions)
   auto frag = [&](int net, int grp) -> Frag {
     if constexpr (F16) {
-      const float* b = (net ? wv16 : wx16) + (grp * 64 + lane) * 4;
-      return WF16{*reinterpret_cast<const h8v*>(b), *reinterpret_cast<const h8v*>(b + NG * 256)};
+      const h8v* b = reinterpret_cast<const h8v*>((net ? wv16 : wx16) + (size_t)grp * 256);
+      const h8v* b2 = reinterpret_cast<const h8v*>((net ? wv16 : wx16) + (size_t)grp * 256 + (size_t)NG * 256);
+      return WF16{b[lane], b2[lane]};
     } else {
-      return lds4((net ? wv : wx) + (grp * 64 + lane) * 4);
+      return reinterpret_cast<const f4*>((net ? wv : wx) + (size_t)grp * 256)[lane];
     }
   };
   const Frag w2x = frag(0, 2 * NT + 1), w2v = frag(1, 2 * NT + 1);
@@ -378,18 +382,25 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       // ---- momentum half-update #1 (dynamics.py:118-125 / :162-170) + the XNet layer-1 sums of (v_h, k1 x)
       HidB h = layer2(w2v, pv[0], tbv);
       f4 pa = Z, pq = Z;
-      HeadW hw = head_frag(1, t_lo);
-      Frag Wa = frag(0, t_lo), Wb = frag(0, NT + t_lo);
-      for (int tg = t_lo; tg < t_hi; ++tg) {
-        const HeadW hw_n = head_frag(1, nxt(tg));
-        const Frag Wa_n = frag(0, nxt(tg)), Wb_n = frag(0, NT + nxt(tg));
+      // Two register sets of prefetched fragments, used in turn (round 6, last session): as `hw = hw_n; Wa = Wa_n; Wb = Wb_n` at the end of a
+      // runtime loop's body the hand-over was 64 register moves per tile (24 v_mov_b64 + 16 v_mov_b32 of a slice's ~210 VALU
+      // instructions: the compiler cannot rename across a back edge); every tile loop below takes two tiles per trip instead.
+      HeadW hw = head_frag(1, t_lo), hw2;
+      Frag Wa = frag(0, t_lo), Wb = frag(0, NT + t_lo), Wa2, Wb2;
+      auto tileA = [&](int tg, const HeadW& hc, const Frag& Wac, const Frag& Wbc, HeadW& hn, Frag& Wan, Frag& Wbn) {
+        hn = head_frag(1, nxt(tg));
+        Wan = frag(0, nxt(tg));
+        Wbn = frag(0, NT + nxt(tg));
         f4 ES, aS, Tt, EQ;
-        heads(hw, h, kSv, kQ, ES, aS, Tt, EQ);
+        heads(hc, h, kSv, kQ, ES, aS, Tt, EQ);
         const f4 vh = v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ldv);
         ts(SV, tg, lane, vh);
-        pa = l1(pa, Wa, vh);
-        pq = l1(pq, Wb, k1_of(tg) * tl(SX, tg, lane));
-        hw = hw_n; Wa = Wa_n; Wb = Wb_n;
+        pa = l1(pa, Wac, vh);
+        pq = l1(pq, Wbc, k1_of(tg) * tl(SX, tg, lane));
+      };
+      for (int tg = t_lo; tg < t_hi; tg += 2) {
+        tileA(tg, hw, Wa, Wb, hw2, Wa2, Wb2);
+        if (tg + 1 < t_hi) tileA(tg + 1, hw2, Wa2, Wb2, hw, Wa, Wb);
       }
       f4 px[1] = {pa + pq};
       xchg<NW, 1>(px, A, smem, w, lane, pb);
@@ -398,16 +409,19 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       pq = Z;
       hw = head_frag(0, t_lo);
       Wb = frag(0, NT + t_lo);
-      for (int tg = t_lo; tg < t_hi; ++tg) {
-        const HeadW hw_n = head_frag(0, nxt(tg));
-        const Frag Wb_n = frag(0, NT + nxt(tg));
+      auto tileB = [&](int tg, const HeadW& hc, const Frag& Wbc, HeadW& hn, Frag& Wbn) {
+        hn = head_frag(0, nxt(tg));
+        Wbn = frag(0, NT + nxt(tg));
         f4 ES, aS, Tt, EQ;
-        heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
+        heads(hc, h, kSx, kQ, ES, aS, Tt, EQ);
         const f4 k1 = k1_of(tg);
         const f4 y = x_half(tl(SX, tg, lane), k1, tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ldv);
         ts(SX, tg, lane, y);
-        pq = l1(pq, Wb, (O - k1) * y);
-        hw = hw_n; Wb = Wb_n;
+        pq = l1(pq, Wbc, (O - k1) * y);
+      };
+      for (int tg = t_lo; tg < t_hi; tg += 2) {
+        tileB(tg, hw, Wb, hw2, Wb2);
+        if (tg + 1 < t_hi) tileB(tg + 1, hw2, Wb2, hw, Wb);
       }
       f4 py[1] = {pa + pq};
       xchg<NW, 1>(py, A, smem, w, lane, pb);
@@ -419,20 +433,24 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       hw = head_frag(0, t_lo);
       Wa = frag(1, t_lo);
       Wb = frag(1, NT + t_lo);
-      for (int tg = t_lo; tg < t_hi; ++tg) {
-        const HeadW hw_n = head_frag(0, nxt(tg));
-        const Frag Wa_n = frag(1, nxt(tg)), Wb_n = frag(1, NT + nxt(tg));
+      auto tileC = [&](int tg, const HeadW& hc, const Frag& Wac, const Frag& Wbc, HeadW& hn, Frag& Wan, Frag& Wbn) {
+        hn = head_frag(0, nxt(tg));
+        Wan = frag(1, nxt(tg));
+        Wbn = frag(1, NT + nxt(tg));
         f4 ES, aS, Tt, EQ;
-        heads(hw, h, kSx, kQ, ES, aS, Tt, EQ);
+        heads(hc, h, kSx, kQ, ES, aS, Tt, EQ);
         const f4 xn = x_half(tl(SX, tg, lane), O - k1_of(tg), tl(SV, tg, lane), ES, aS, Tt, EQ, eps, fwd, ldv);
         ts(SX, tg, lane, xn);
-        a0 = l1(a0, Wa, xn);
+        a0 = l1(a0, Wac, xn);
         if (!DENSE) {
           const f4 g = wide_grad<EK>(A, smem, tg, q, xn, Uend, lastU);
           ts(SG, tg, lane, g);
-          a1 = l1(a1, Wb, g);
+          a1 = l1(a1, Wbc, g);
         }
-        hw = hw_n; Wa = Wa_n; Wb = Wb_n;
+      };
+      for (int tg = t_lo; tg < t_hi; tg += 2) {
+        tileC(tg, hw, Wa, Wb, hw2, Wa2, Wb2);
+        if (tg + 1 < t_hi) tileC(tg + 1, hw2, Wa2, Wb2, hw, Wa, Wb);
       }
       if (GMMK) gmm_pass(Uend, lastU, a1);
       else if (DENSE) dense_pass(Uend, lastU, a1);
@@ -442,12 +460,15 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
       // ---- momentum half-update #2 (:147-153 / :192-199)
       h = layer2(w2v, pv[0], tbv);
       hw = head_frag(1, t_lo);
-      for (int tg = t_lo; tg < t_hi; ++tg) {
-        const HeadW hw_n = head_frag(1, nxt(tg));
+      auto tileD = [&](int tg, const HeadW& hc, HeadW& hn) {
+        hn = head_frag(1, nxt(tg));
         f4 ES, aS, Tt, EQ;
-        heads(hw, h, kSv, kQ, ES, aS, Tt, EQ);
+        heads(hc, h, kSv, kQ, ES, aS, Tt, EQ);
         ts(SV, tg, lane, v_half(tl(SV, tg, lane), tl(SG, tg, lane), ES, aS, Tt, EQ, heps, fwd, ldv));
-        hw = hw_n;
+      };
+      for (int tg = t_lo; tg < t_hi; tg += 2) {
+        tileD(tg, hw, hw2);
+        if (tg + 1 < t_hi) tileD(tg + 1, hw2, hw);
       }
     }
     const float ld = hsum(ldv) * 0.6931471805599453f;      // the log-det was accumulated in log2 units
