@@ -67,7 +67,14 @@ __device__ __forceinline__ f4 wide_grad(const KArgs& A, const float* smem, int t
 // split (KArgs.packed16, l2hmc_pack_nets), an activation is split by the wave that consumes it (the second hidden activation
 // once per net evaluation for all the wave's tiles), and the end points of a proposal are held against L2HMC_F16_STATE_MAX.
 template <int EK, int KH, int NW, int PK = 0>
-__global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
+// Register budget of the four-wave form (d <= 256: two workgroups per CU by its LDS plan, `wide_waves`).  With `__launch_bounds__(256)`
+// alone the compiler took 314-324 registers -- ONE workgroup per CU, half the waves the design counts on to hide the L2 latency of the
+// streamed fragments -- for all of rounds 3-6.  Two waves per SIMD (256 VGPRs, 192-240 bytes of scratch in the f16x2 form): Rough Well
+// d = 144 ... 256 / 16 384 chains 378 ... 499 -> 286 ... 378 us per proposal (profiles/r06_wide_handover.txt).
+#ifndef L2HMC_WIDE4_WAVES
+#define L2HMC_WIDE4_WAVES 2
+#endif
+__global__ __launch_bounds__(64 * NW, NW == 4 ? L2HMC_WIDE4_WAVES : 1) void traj_wide_kernel(const KArgs A) {
   constexpr bool GMMK = EK == L2HMC_ENERGY_GMM;                 // (both: grad U couples all dimensions)
   constexpr bool DENSE = EK == L2HMC_ENERGY_GAUSS_DENSE || GMMK;
   constexpr bool F16 = PK == 1;
@@ -532,7 +539,10 @@ __global__ __launch_bounds__(64 * NW) void traj_wide_kernel(const KArgs A) {
 
 // waves per workgroup of the wide kernel: 8 (two per SIMD hide the L2 latency of the streamed fragments) once
 // the state is so large that only one workgroup fits a CU, else 4 with two workgroups per CU
-int wide_waves(int NT) { return NT > 16 ? 8 : 4; }
+#ifndef L2HMC_WIDE_W8_FROM
+#define L2HMC_WIDE_W8_FROM 16
+#endif
+int wide_waves(int NT) { return NT > L2HMC_WIDE_W8_FROM ? 8 : 4; }
 
 // shared-memory plan of the wide kernel (bytes); fills the offsets it uses
 long long plan_lds_wide(KArgs& k) {
