@@ -195,6 +195,24 @@ __device__ __forceinline__ f4 ctanh4(f4 c, f4 z) {
 __device__ __forceinline__ float relu1(float a) { return fmaxf(a, 0.f); }
 __device__ __forceinline__ f4 relu4(f4 a) { return f4{relu1(a.x), relu1(a.y), relu1(a.z), relu1(a.w)}; }
 __device__ __forceinline__ float hsum(f4 a) { return (a.x + a.y) + (a.z + a.w); }
+// Sum over the four lanes (c, q = 0..3) = lanes c, c + 16, c + 32, c + 48 that hold one chain; every one of them gets the total.
+// gfx950's row swaps do it on the VALU -- v_permlane16_swap_b32 exchanges the odd 16-lane rows of one register with the even rows of
+// another, v_permlane32_swap_b32 the wave's halves -- where `v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)` compiles to two
+// dependent ds_bpermute_b32 (an LDS round trip each: ~100 cycles in front of a lone wave, four per leapfrog step in the mixtures'
+// grad U).  Same pairs added in the same order, (r0 + r1) + (r2 + r3) in every lane: the same bits as the shuffle form (round 6).
+typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float chain4_sum(float a) {
+#ifdef L2HMC_CHAIN_SUM_BPERMUTE
+  a += __shfl_xor(a, 16);
+  a += __shfl_xor(a, 32);
+  return a;
+#else
+  const u2v_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+  const float b = __uint_as_float(r.x) + __uint_as_float(r.y);
+  const u2v_ t = __builtin_amdgcn_permlane32_swap(__float_as_uint(b), __float_as_uint(b), false, false);
+  return __uint_as_float(t.x) + __uint_as_float(t.y);
+#endif
+}
 __device__ __forceinline__ f4 sel4(bool c, f4 a, f4 b) { return c ? a : b; }
 __device__ __forceinline__ f4 lds4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 
@@ -319,10 +337,7 @@ __device__ __forceinline__ void rng_state(const KArgs& A, long long gchain, unsi
 template <int NW, int NV>
 __device__ __forceinline__ void chain_allreduce(float (&v)[NV], float* red, int w, int lane) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    v[i] += __shfl_xor(v[i], 16);
-    v[i] += __shfl_xor(v[i], 32);
-  }
+  for (int i = 0; i < NV; ++i) v[i] = chain4_sum(v[i]);
   if (NW > 1) {
     if (lane < 16) {
 #pragma unroll

@@ -52,8 +52,7 @@ __device__ __forceinline__ float grad_small(const KArgs& A, const float* smem, c
         const float dx = x - E.mus[i];
         const f4 y = MFMA16(E.gf[i], dx, splat(0.f));
         float qq = dx * y.x;
-        qq += __shfl_xor(qq, 16);
-        qq += __shfl_xor(qq, 32);
+        qq = chain4_sum(qq);
         const float V = -(0.5f * qq) + smem[A.o_logc + i];
         const float mn = fmaxf(m, V);
         const float sc = (m == mn) ? 1.f : expf(m - mn), wi = (V == -INFINITY) ? 0.f : expf(V - mn);
@@ -395,14 +394,12 @@ __global__ __launch_bounds__(64, L2HMC_SMALL_WAVES) void traj_small_kernel(const
     const float U_end = red[2];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      red[i] += __shfl_xor(red[i], 16);
-      red[i] += __shfl_xor(red[i], 32);
+      red[i] = chain4_sum(red[i]);
     }
     if constexpr (F16) {
       amax_l = fmaxf(amax_l, fmaxf(fabsf(x), fmaxf(fabsf(v), fabsf(g))));
       float oor = amax_l < L2HMC_F16_STATE_MAX ? 0.f : 1.f;
-      oor += __shfl_xor(oor, 16);
-      oor += __shfl_xor(oor, 32);
+      oor = chain4_sum(oor);
       if (oor > 0.f) {               // outside the f16x2 range: a loud non-result (traj_fast.hpp)
         x = v = red[4] = __uint_as_float(0x7fc00000u);
       }
