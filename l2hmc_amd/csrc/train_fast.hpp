@@ -231,8 +231,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
     Fun F;
     F.v = __shfl(z[0], c);
     float part = hsum(z * z) - (q == 0 ? z[0] * z[0] : 0.f);
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
+    part = chain4_sum(part);
     F.qsum = part;
     const float clip = 4.f * A.eta;
     const bool hi = F.v > clip, lo = -clip > F.v;
@@ -264,8 +263,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
       const Fun F = fun_parts(z);
       const float u0 = __shfl(vec[0], c);
       float dot = hsum(z * vec) - (q == 0 ? z[0] * vec[0] : 0.f);
-      dot += __shfl_xor(dot, 16);
-      dot += __shfl_xor(dot, 32);
+      dot = chain4_sum(dot);
       const float fr = F.clipped ? 0.f : 1.f;
       o = vec * F.inv - z * (fr * u0 * F.inv);
       if (q == 0) o[0] = u0 * (1.f / (A.eta * A.eta) + fr * 0.5f * F.qsum * F.inv) - fr * dot * F.inv;
@@ -476,8 +474,7 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   red[5] = hsum(ldv);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    red[i] += __shfl_xor(red[i], 16);
-    red[i] += __shfl_xor(red[i], 32);
+    red[i] = chain4_sum(red[i]);
   }
   if (NW > 1) {
     float* R = smem + L.red;

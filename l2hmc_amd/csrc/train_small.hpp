@@ -265,8 +265,7 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
 
   // ---- energies (this lane's dimension) -----------------------------------------------------------------------------------
   auto qsum = [&](float a) {                        // sum over the chain's four dimension lanes
-    a += __shfl_xor(a, 16);
-    a += __shfl_xor(a, 32);
+    a = chain4_sum(a);
     return a;
   };
   // GMM: responsibilities r_k, y_k = G_k (z - mu_k) (this lane's dimension), g = sum_k r_k y_k and log sum_k e^{V_k} of the
@@ -461,8 +460,7 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
   red[5] = ldv * live1;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    red[i] += __shfl_xor(red[i], 16);
-    red[i] += __shfl_xor(red[i], 32);
+    red[i] = chain4_sum(red[i]);
   }
   const float val = (red[0] + red[1]) - (red[2] + red[3]) + red[5];
   const float p = accept_prob(val);
