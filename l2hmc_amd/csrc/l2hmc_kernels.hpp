@@ -336,8 +336,18 @@ __device__ __forceinline__ void rng_state(const KArgs& A, long long gchain, unsi
 // Sum over the lanes / waves that hold one chain; every lane of the chain gets the total.
 template <int NW, int NV>
 __device__ __forceinline__ void chain_allreduce(float (&v)[NV], float* red, int w, int lane) {
+  // (NV = 1 -- the mixtures' quadratic form, once per component and leapfrog step, with nothing to run beside it -- on the row swaps;
+  //  several values at once -- a proposal's epilogue -- through the LDS crossbar, whose requests pipeline: six swaps in a row measured
+  //  1.5 % of the bench kernel's cycles more than the twelve ds_bpermute they replaced, profiles/r06_chain_sum.txt)
+  if constexpr (NV == 1) {
+    v[0] = chain4_sum(v[0]);
+  } else {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = chain4_sum(v[i]);
+    for (int i = 0; i < NV; ++i) {
+      v[i] += __shfl_xor(v[i], 16);
+      v[i] += __shfl_xor(v[i], 32);
+    }
+  }
   if (NW > 1) {
     if (lane < 16) {
 #pragma unroll

@@ -474,7 +474,8 @@ __global__ __launch_bounds__(64 * NW, 1) void train_fast_kernel(const TArgs A) {
   red[5] = hsum(ldv);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    red[i] = chain4_sum(red[i]);
+    red[i] += __shfl_xor(red[i], 16);
+    red[i] += __shfl_xor(red[i], 32);
   }
   if (NW > 1) {
     float* R = smem + L.red;

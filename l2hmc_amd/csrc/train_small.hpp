@@ -460,7 +460,8 @@ __global__ __launch_bounds__(128, 1) void train_small_kernel(const TArgs A) {
   red[5] = ldv * live1;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    red[i] = chain4_sum(red[i]);
+    red[i] += __shfl_xor(red[i], 16);
+    red[i] += __shfl_xor(red[i], 32);
   }
   const float val = (red[0] + red[1]) - (red[2] + red[3]) + red[5];
   const float p = accept_prob(val);

@@ -394,12 +394,14 @@ __global__ __launch_bounds__(64, L2HMC_SMALL_WAVES) void traj_small_kernel(const
     const float U_end = red[2];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      red[i] = chain4_sum(red[i]);
+      red[i] += __shfl_xor(red[i], 16);
+      red[i] += __shfl_xor(red[i], 32);
     }
     if constexpr (F16) {
       amax_l = fmaxf(amax_l, fmaxf(fabsf(x), fmaxf(fabsf(v), fabsf(g))));
       float oor = amax_l < L2HMC_F16_STATE_MAX ? 0.f : 1.f;
-      oor = chain4_sum(oor);
+      oor += __shfl_xor(oor, 16);
+      oor += __shfl_xor(oor, 32);
       if (oor > 0.f) {               // outside the f16x2 range: a loud non-result (traj_fast.hpp)
         x = v = red[4] = __uint_as_float(0x7fc00000u);
       }

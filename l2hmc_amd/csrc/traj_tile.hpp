@@ -537,14 +537,16 @@ __global__ __launch_bounds__(64 * TPW, L2HMC_TILE_WPE) void traj_tile_kernel(con
     const float U_end = red[2];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      red[i] = chain4_sum(red[i]);
+      red[i] += __shfl_xor(red[i], 16);
+      red[i] += __shfl_xor(red[i], 32);
     }
 #if L2HMC_BFH_TILE == 2
     {
 #pragma unroll
       for (int t = 0; t < DT; ++t) amax_l = fmaxf(amax_l, fmaxf(amax4(x[t]), fmaxf(amax4(v[t]), amax4(g[t]))));
       float oor = amax_l < L2HMC_F16_STATE_MAX ? 0.f : 1.f;
-      oor = chain4_sum(oor);
+      oor += __shfl_xor(oor, 16);
+      oor += __shfl_xor(oor, 32);
       if (oor > 0.f) {               // outside the f16x2 range: a loud non-result
         const float qnan = __uint_as_float(0x7fc00000u);
 #pragma unroll
