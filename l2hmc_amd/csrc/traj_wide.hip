@@ -537,16 +537,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? L2HMC_WIDE4_WAVES : 1) void traj
     for (int tg = t_lo; tg < t_hi; ++tg) gstore(A.x_next, tg, tl(SX, tg, lane));
 }
 
-// waves per workgroup of the wide kernel: 8 (two per SIMD hide the L2 latency of the streamed fragments) once
-// the state is so large that only one workgroup fits a CU, else 4 with two workgroups per CU
-#ifndef L2HMC_WIDE_W8_FROM
-#define L2HMC_WIDE_W8_FROM 16
-#endif
-int wide_waves(int NT) { return NT > L2HMC_WIDE_W8_FROM ? 8 : 4; }
-
-// shared-memory plan of the wide kernel (bytes); fills the offsets it uses
-long long plan_lds_wide(KArgs& k) {
-  const int NT = k.NT, DP = 16 * NT, NW = wide_waves(NT);
+// shared-memory plan of the wide kernel for NW waves (floats); fills the offsets it uses
+static long long wide_lds_floats(KArgs& k, int NW) {
+  const int NT = k.NT, DP = 16 * NT;
   long long o = 0;
   k.o_mask = (int)o; o += (long long)k.T * DP;
   k.o_trig = (int)o; o += (2 * k.T + 3) / 4 * 4;
@@ -557,8 +550,21 @@ long long plan_lds_wide(KArgs& k) {
   k.o_prec = (int)o; if (k.ekind == L2HMC_ENERGY_GAUSS_DIAG) o += DP;
   k.o_logc = (int)o; if (k.ekind == L2HMC_ENERGY_GMM) o += (k.ncomp + 3) / 4 * 4;
   k.o_state = (int)o; o += 3LL * NT * 256;
-  return o * 4;
+  return o;
 }
+// waves per workgroup of the wide kernel: 4 with TWO workgroups per CU while two of them fit its LDS (round 6, last session: by the plan
+// itself -- until then "up to 16 tiles", which left d = 257 ... 288 on the eight-wave form: 552 against 445 us per proposal at d = 272 --
+// and with the four-wave form's registers bounded so that two workgroups really are resident, traj_wide_kernel above); else 8 waves (two
+// per SIMD hide the L2 latency of the streamed fragments) in the one workgroup that fits.
+#ifndef L2HMC_WIDE_LDS_PER_CU
+#define L2HMC_WIDE_LDS_PER_CU (160 * 1024)
+#endif
+static int wide_waves(const KArgs& k) {
+  KArgs t = k;
+  return 2 * 4 * wide_lds_floats(t, 4) <= L2HMC_WIDE_LDS_PER_CU ? 4 : 8;
+}
+
+long long plan_lds_wide(KArgs& k) { return 4 * wide_lds_floats(k, wide_waves(k)); }
 
 template <int EK, int KH, int NW, int PK = 0>
 static int launch_wide_t(const KArgs& k, long long lds, hipStream_t s) {
@@ -575,7 +581,7 @@ static int launch_wide_t(const KArgs& k, long long lds, hipStream_t s) {
 }
 
 int launch_wide(const KArgs& k, int KH, long long lds, hipStream_t s) {
-  const bool diag = k.ekind == L2HMC_ENERGY_GAUSS_DIAG, dense = k.ekind == L2HMC_ENERGY_GAUSS_DENSE, w8 = wide_waves(k.NT) == 8;
+  const bool diag = k.ekind == L2HMC_ENERGY_GAUSS_DIAG, dense = k.ekind == L2HMC_ENERGY_GAUSS_DENSE, w8 = wide_waves(k) == 8;
 #define L2HMC_WIDE(EKv)                                                                      \
   (KH == 3 ? (w8 ? launch_wide_t<EKv, 3, 8>(k, lds, s) : launch_wide_t<EKv, 3, 4>(k, lds, s)) \
            : (w8 ? launch_wide_t<EKv, 4, 8>(k, lds, s) : launch_wide_t<EKv, 4, 4>(k, lds, s)))
